@@ -1,0 +1,258 @@
+/* mazestep.h — C-ABI of the MI355X batched maze-environment stepper.
+ *
+ * This is the drop-in boundary for the hot path of kngwyu/mujoco-maze:
+ *
+ *   reference call (Python, one env)                       replaced by (batched, device)
+ *   -----------------------------------------------------  ------------------------------
+ *   MazeEnv.__init__       mujoco_maze/maze_env.py:28-233   mz_create   (compiled mz_model in)
+ *   MazeEnv.reset          mujoco_maze/maze_env.py:371-382  mz_reset
+ *     AntEnv.reset_model   mujoco_maze/ant.py:84-96
+ *     PointEnv.reset_model mujoco_maze/point.py:71-81
+ *   MazeEnv.step           mujoco_maze/maze_env.py:448-481  mz_step
+ *     AntEnv.step          mujoco_maze/ant.py:61-73           (ctrl write + mj_step x frame_skip,
+ *     PointEnv.step        mujoco_maze/point.py:44-61          forward reward, ctrl cost)
+ *     CollisionDetector.detect  maze_env_utils.py:186-206      (Point wall bounce)
+ *     MazeEnv._get_obs     mujoco_maze/maze_env.py:351-369     (obs assembly)
+ *     MazeTask.reward / termination  maze_task.py:77-81,110-111,403-407
+ *   MujocoEnv.set_state (gym) via set_xy  ant.py:105-108    mz_set_state / mz_get_state
+ *   mujoco-py exceptions / warnings                         integer status + mz_last_error,
+ *                                                           per-env status words (mz_get_status)
+ *
+ * All array arguments named *_dev are DEVICE pointers (HBM) owned by the caller
+ * (e.g. torch tensors' data_ptr()); the library never frees caller memory.  The
+ * handle owns the persistent per-env state.  Calls are asynchronous and ordered
+ * on the hipStream_t passed as `stream` (void* here so that this header needs
+ * no HIP include; NULL = the default stream).  One host thread per handle.
+ *
+ * No torch / C++ types appear in any signature.
+ */
+#ifndef MAZESTEP_H
+#define MAZESTEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_ABI_VERSION 1
+
+#define MZ_MAX_BODY 24
+#define MZ_MAX_JNT 24
+#define MZ_MAX_DOF 24
+#define MZ_MAX_Q 28
+#define MZ_MAX_GEOM 24
+#define MZ_MAX_ACT 8
+#define MZ_MAX_GRID 12
+#define MZ_MAX_SEG 96
+#define MZ_MAX_GOAL 8
+#define MZ_MAX_OBS 48
+
+/* robot kinds */
+#define MZ_ROBOT_POINT 0
+#define MZ_ROBOT_ANT 1
+#define MZ_ROBOT_SWIMMER 2
+
+/* joint types (MuJoCo numbering) */
+#define MZ_JNT_FREE 0
+#define MZ_JNT_BALL 1
+#define MZ_JNT_SLIDE 2
+#define MZ_JNT_HINGE 3
+
+/* geom types (MuJoCo numbering; pair order is by type) */
+#define MZ_GEOM_PLANE 0
+#define MZ_GEOM_SPHERE 2
+#define MZ_GEOM_CAPSULE 3
+#define MZ_GEOM_BOX 6
+
+/* maze cell codes in mz_model.grid (MazeCell, maze_env_utils.py:19-33) */
+#define MZ_CELL_EMPTY 0
+#define MZ_CELL_BLOCK 1
+#define MZ_CELL_CHASM 2
+#define MZ_CELL_ROBOT 255
+
+/* reward kinds (mujoco_maze_amd/maze_task.py) */
+#define MZ_REWARD_ZERO 0
+#define MZ_REWARD_FIRST_MATCH 1
+#define MZ_REWARD_NEG_DIST 2
+#define MZ_SLOT_AGENT 0
+#define MZ_SLOT_OBJECT 1
+
+/* per-env status bits (mz_get_status) */
+#define MZ_STATUS_OK 0
+#define MZ_STATUS_BAD_STATE 1      /* NaN / |x| > 1e10 in qpos/qvel/qacc (MuJoCo mj_check*) */
+#define MZ_STATUS_CONTACT_OVERFLOW 2 /* more simultaneous contacts than the kernel's buffer */
+#define MZ_STATUS_SOLVER_MAXITER 4 /* constraint solver hit its iteration cap */
+
+/* error codes */
+#define MZ_OK 0
+#define MZ_ERR_ARG (-1)
+#define MZ_ERR_HIP (-2)
+#define MZ_ERR_UNSUPPORTED (-3)
+
+/* The compiled model: what MazeEnv.__init__ + the MuJoCo model compiler produce
+ * in the reference (maze_env.py:97-218 writes MJCF; MuJoCo compiles it).  Built
+ * on the host by mujoco_maze_amd/model.py.  Plain doubles/ints; the library
+ * converts to fp32 device constants. */
+typedef struct mz_model {
+  int32_t abi_version;
+  int32_t robot; /* MZ_ROBOT_* */
+  int32_t nbody, njnt, nq, nv, ngeom, nu;
+  int32_t nq_robot, nv_robot; /* leading robot coordinates (ant 15/14, point 3/3) */
+  int32_t frame_skip;
+  int32_t integrator_rk4;
+  int32_t collision_predefined; /* swimmer: no dynamic contact pairs */
+  int32_t manual_collision;     /* Point: CollisionDetector bounce */
+  int32_t max_episode_steps;    /* gym TimeLimit (mujoco_maze/__init__.py:31) */
+  int32_t obs_dim;
+  int32_t reset_qvel_kind; /* 0 normal*0.1, 1 U[0,1)*0.1, 2 U(-.1,.1) */
+  int32_t pad0;
+  double timestep;
+  double gravity[3];
+  double density, viscosity;
+  double meaninertia;
+
+  /* bodies (0 = world) */
+  int32_t body_parent[MZ_MAX_BODY];
+  int32_t body_jntadr[MZ_MAX_BODY];
+  int32_t body_jntnum[MZ_MAX_BODY];
+  int32_t body_dofadr[MZ_MAX_BODY];
+  int32_t body_dofnum[MZ_MAX_BODY];
+  double body_pos[MZ_MAX_BODY][3];
+  double body_quat[MZ_MAX_BODY][4];
+  double body_ipos[MZ_MAX_BODY][3];
+  double body_inertia[MZ_MAX_BODY][6]; /* xx yy zz xy xz yz about COM, body frame */
+  double body_mass[MZ_MAX_BODY];
+  double body_invweight0[MZ_MAX_BODY][2];
+
+  /* joints */
+  int32_t jnt_type[MZ_MAX_JNT];
+  int32_t jnt_qposadr[MZ_MAX_JNT];
+  int32_t jnt_dofadr[MZ_MAX_JNT];
+  int32_t jnt_bodyid[MZ_MAX_JNT];
+  int32_t jnt_limited[MZ_MAX_JNT];
+  double jnt_pos[MZ_MAX_JNT][3];
+  double jnt_axis[MZ_MAX_JNT][3];
+  double jnt_range[MZ_MAX_JNT][2];
+  double jnt_margin[MZ_MAX_JNT];
+  double jnt_solref[MZ_MAX_JNT][2];
+  double jnt_solimp[MZ_MAX_JNT][5];
+
+  /* dofs */
+  int32_t dof_bodyid[MZ_MAX_DOF];
+  int32_t dof_jntid[MZ_MAX_DOF];
+  double dof_armature[MZ_MAX_DOF];
+  double dof_damping[MZ_MAX_DOF];
+  double dof_invweight0[MZ_MAX_DOF];
+  double qpos0[MZ_MAX_Q];
+
+  /* geoms (0 = floor plane; maze wall boxes are implicit in `grid`) */
+  int32_t geom_type[MZ_MAX_GEOM];
+  int32_t geom_bodyid[MZ_MAX_GEOM];
+  int32_t geom_contype[MZ_MAX_GEOM];
+  int32_t geom_conaffinity[MZ_MAX_GEOM];
+  int32_t geom_condim[MZ_MAX_GEOM];
+  double geom_pos[MZ_MAX_GEOM][3];
+  double geom_quat[MZ_MAX_GEOM][4];
+  double geom_size[MZ_MAX_GEOM][3];
+  double geom_friction[MZ_MAX_GEOM][3];
+  double geom_solref[MZ_MAX_GEOM][2];
+  double geom_solimp[MZ_MAX_GEOM][5];
+  double geom_margin[MZ_MAX_GEOM];
+  double geom_gap[MZ_MAX_GEOM];
+  double geom_rbound[MZ_MAX_GEOM];
+
+  /* actuators: motor on one dof */
+  int32_t act_dofid[MZ_MAX_ACT];
+  int32_t act_ctrllimited[MZ_MAX_ACT];
+  double act_gear[MZ_MAX_ACT];
+  double act_ctrlrange[MZ_MAX_ACT][2];
+
+  /* maze world (maze_env.py:116-152): cell (i,j) centre = (j*s - torso_x, i*s - torso_y) */
+  int32_t grid_rows, grid_cols;
+  uint8_t grid[MZ_MAX_GRID][MZ_MAX_GRID];
+  double maze_scale, torso_x, torso_y;
+  double wall_half_xy, wall_half_z, wall_center_z; /* box half sizes / centre height */
+  int32_t wall_contype, wall_conaffinity, wall_condim, pad1;
+  double wall_friction[3];
+  double wall_solref[2];
+  double wall_solimp[5];
+  double wall_margin, wall_gap;
+
+  /* Point manual collision (maze_env_utils.py:151-184; maze_env.py:36,457-464) */
+  int32_t nseg, pad2;
+  double seg[MZ_MAX_SEG][4]; /* x1 y1 x2 y2 */
+  double restitution;
+  double velocity_limit; /* point.py:33,56 */
+
+  /* task (maze_task.py) */
+  int32_t ngoal;
+  int32_t reward_kind, reward_slot, reward_binary, term_slot;
+  int32_t goal_dim[MZ_MAX_GOAL];
+  double goal_pos[MZ_MAX_GOAL][3];
+  double goal_threshold[MZ_MAX_GOAL];
+  double goal_reward_scale[MZ_MAX_GOAL];
+  double penalty, task_scale, inner_reward_scaling;
+  double forward_reward_weight, ctrl_cost_weight; /* ant.py:47-53 */
+} mz_model;
+
+typedef struct mz_handle mz_handle;
+
+int mz_abi_version(void);
+uint64_t mz_model_sizeof(void); /* host-side struct layout check for FFI users */
+
+/* Create a batch of `num_envs` environments on HIP device `device`.
+ * Returns NULL on failure with a message in err (if non-NULL). */
+mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, char* err, int32_t errlen);
+void mz_destroy(mz_handle* h);
+const char* mz_last_error(const mz_handle* h);
+
+int32_t mz_num_envs(const mz_handle* h);
+int32_t mz_obs_dim(const mz_handle* h);
+int32_t mz_nq(const mz_handle* h);
+int32_t mz_nv(const mz_handle* h);
+int32_t mz_nu(const mz_handle* h);
+
+/* Tunables: "auto_reset" (0/1), "solver_iterations", "solver_tolerance",
+ * "lanes_per_env" (ant kernel geometry). Returns MZ_OK or MZ_ERR_ARG. */
+int32_t mz_set_option(mz_handle* h, const char* key, double value);
+
+/* reset(): envs with mask_dev[i] != 0 (all when NULL) get t = 0 and a fresh state
+ * from the reference's reset distribution (counter-based RNG keyed by seed and
+ * env slot; streams differ from numpy's — distributional parity only).
+ * obs_dev [N, obs_dim] may be NULL. */
+int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* obs_dev, void* stream);
+
+/* State injection / read-back (row-major [N, nq], [N, nv], [N, nv], [N]).
+ * Any pointer may be NULL to skip that field. */
+int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev, const float* warmstart_dev,
+                     const int32_t* t_dev, void* stream);
+int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warmstart_dev, int32_t* t_dev,
+                     void* stream);
+
+/* One MazeEnv.step for every env.
+ *  actions_dev [N, nu] fp32 row-major
+ *  obs_dev     [N, obs_dim]
+ *  reward_dev  [N]            inner_reward_scaling * inner + task reward
+ *  done_dev    [N] u8         bit0 = task termination, bit1 = TimeLimit truncation
+ *  goal_idx_dev[N] i32        first matching goal index or -1   (nullable)
+ *  info_dev    [N, 4]         position x, y, reward_forward, reward_ctrl (nullable) */
+int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                int32_t* goal_idx_dev, float* info_dev, void* stream);
+
+/* Per-env status words accumulated since the last call (then cleared). [N] i32. */
+int32_t mz_get_status(mz_handle* h, int32_t* status_dev, void* stream);
+
+/* Diagnostics for parity tests: one forward-dynamics evaluation at the current
+ * state with ctrl = actions; writes qacc [N, nv] and ncon/nefc [N, 2]. */
+int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev, int32_t* counts_dev, void* stream);
+
+/* Name and average-duration bookkeeping for bench.py: time (ms) of the last
+ * mz_step's dominant kernel measured with hipEvents on `stream` when
+ * "time_kernels" option is 1; returns < 0 if not available. */
+double mz_last_kernel_ms(const mz_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAZESTEP_H */

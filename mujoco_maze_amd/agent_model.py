@@ -1,0 +1,61 @@
+"""Robot plugin surface (reference `mujoco_maze/agent_model.py:12-41`,
+`point.py:19-42`, `ant.py:38-54`, `swimmer.py:16-30`).
+
+In the reference these classes *are* the simulators (gym `MujocoEnv` subclasses
+driving MuJoCo).  Here the simulation lives in the HIP kernels; the classes keep
+the reference's class-level knobs (`FILE`, `MANUAL_COLLISION`, `ORI_IND`,
+`RADIUS`, `OBJBALL_TYPE`, `VELOCITY_LIMITS`) so that `MazeEnv(model_cls=...)`
+and user subclasses that tweak those knobs keep working, and name the built-in
+`RobotSpec` (`robots.py`) the kernels are specialised for.
+"""
+from typing import Optional
+
+
+class AgentModel:
+    FILE: str
+    ROBOT: str  # key into robots.ROBOTS
+    MANUAL_COLLISION: bool
+    ORI_IND: Optional[int] = None
+    RADIUS: Optional[float] = None
+    OBJBALL_TYPE: Optional[str] = None
+    FRAME_SKIP: int = 1
+
+
+class PointEnv(AgentModel):
+    FILE = "point.xml"
+    ROBOT = "point"
+    ORI_IND = 2
+    MANUAL_COLLISION = True
+    RADIUS = 0.4
+    OBJBALL_TYPE = "hinge"
+    VELOCITY_LIMITS = 10.0
+    FRAME_SKIP = 1
+
+
+class AntEnv(AgentModel):
+    FILE = "ant.xml"
+    ROBOT = "ant"
+    ORI_IND = 3
+    MANUAL_COLLISION = False
+    OBJBALL_TYPE = "freejoint"
+    FRAME_SKIP = 5
+
+
+class SwimmerEnv(AgentModel):
+    FILE = "swimmer.xml"
+    ROBOT = "swimmer"
+    MANUAL_COLLISION = False
+    FRAME_SKIP = 4
+
+
+class ReacherEnv(AgentModel):
+    """Registered for id parity only; the reference README (:129-130) marks it untested and it
+    is outside the hot-path scope."""
+
+    FILE = "reacher.xml"
+    ROBOT = "reacher"
+    MANUAL_COLLISION = False
+    FRAME_SKIP = 4
+
+
+ROBOT_CLASSES = {"point": PointEnv, "ant": AntEnv, "swimmer": SwimmerEnv}

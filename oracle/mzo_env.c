@@ -1,0 +1,306 @@
+/* mzo_env.c — CPU ORACLE (test infrastructure, not the product).
+ *
+ * Restates, in plain C / float64, the maze-level part of the reference hot
+ * path; each function cites the reference lines it follows.  Pinned against the
+ * golden vectors in tests/golden/ that were produced by running the reference's
+ * own pure-Python modules (tests/golden/make_golden.py).
+ *
+ *   mzo_detect     <- CollisionDetector.detect + Line.*   maze_env_utils.py:96-123,186-206
+ *   bounce logic   <- MazeEnv.step                         maze_env.py:451-464
+ *   point pre-step <- PointEnv.step                        point.py:44-61
+ *   ant reward     <- AntEnv.step / _forward_reward        ant.py:56-73
+ *   mzo_env_obs    <- MazeEnv._get_obs + robot _get_obs    maze_env.py:351-369, ant.py:75-82, point.py:63-69
+ *   mzo_task_eval  <- MazeGoal.neighbor, MazeTask.termination, reward variants
+ *                                                          maze_task.py:43-47,77-81,110-111,403-407,592-604,619-621
+ *   mzo_env_reset  <- reset_model                          ant.py:84-96, point.py:71-81
+ */
+#include <math.h>
+#include <string.h>
+
+#include "mzo.h"
+
+uint64_t mzo_model_sizeof(void) { return sizeof(mz_model); }
+uint64_t mzo_data_sizeof(void) { return sizeof(mzo_data); }
+
+/* ---------------------------------------------------------------- RNG (shared definition with the kernels) */
+static inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+uint32_t mzo_rng_u32(uint64_t seed, uint64_t env, uint32_t counter) {
+  uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (env + 1));
+  z = mix64(z + 0x9E3779B97F4A7C15ULL * ((uint64_t)counter + 1));
+  return (uint32_t)(z >> 32);
+}
+static inline double u01(uint64_t seed, uint64_t env, uint32_t c) { /* [0,1) on a 2^-24 lattice */
+  return (double)(mzo_rng_u32(seed, env, c) >> 8) * (1.0 / 16777216.0);
+}
+static inline double normal01(uint64_t seed, uint64_t env, uint32_t c) {
+  double u1 = ((double)(mzo_rng_u32(seed, env, c) >> 8) + 1.0) * (1.0 / 16777216.0);
+  double u2 = u01(seed, env, c + 1);
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+/* ---------------------------------------------------------------- wall segments */
+static inline double cross2(double ax, double ay, double bx, double by) { return ax * by + (-ay) * bx; }
+
+int mzo_detect(const mz_model* m, const double* o, const double* n, double* point, double* reflection) {
+  double mvx = n[0] - o[0], mvy = n[1] - o[1];
+  if (hypot(mvx, mvy) <= 1e-8) return 0; /* maze_env_utils.py:189 */
+  int found = 0, degenerate = 0;
+  double best = 0;
+  for (int k = 0; k < m->nseg; k++) {
+    const double* s = m->seg[k];
+    double wx = s[2] - s[0], wy = s[3] - s[1];
+    /* wall._intersect(move): move's end points on both sides of the wall line (<= 0: touching counts) */
+    double c1 = cross2(wx, wy, o[0] - s[0], o[1] - s[1]), c2 = cross2(wx, wy, n[0] - s[0], n[1] - s[1]);
+    if (!(c1 * c2 <= 0.0)) continue;
+    /* move._intersect(wall) */
+    double c3 = cross2(mvx, mvy, s[0] - o[0], s[1] - o[1]), c4 = cross2(mvx, mvy, s[2] - o[0], s[3] - o[1]);
+    if (!(c3 * c4 <= 0.0)) continue;
+    /* wall._cross_point(move): other = move -> other.p1 + b / a * (other.p2 - other.p1) */
+    double a = cross2(wx, wy, mvx, mvy), b = cross2(wx, wy, s[2] - o[0], s[3] - o[1]);
+    if (a == 0.0) { degenerate = 1; continue; } /* the reference raises ZeroDivisionError here */
+    double r = b / a, px = o[0] + r * mvx, py = o[1] + r * mvy;
+    double dist = hypot(px - o[0], py - o[1]);
+    if (!found || dist < best) {
+      found = 1; best = dist;
+      point[0] = px; point[1] = py;
+      /* wall.reflection(new): p + 2 * (projection(p) - p), projection along -v1 (maze_env_utils.py:101-108) */
+      double bx = -wx, by = -wy, n2 = hypot(bx, by);
+      n2 = n2 * n2;
+      double dx = n[0] - s[0], dy = n[1] - s[1];
+      double sc = (dx * bx - (-dy) * by) / n2;
+      double qx = s[0] + bx * sc, qy = s[1] + by * sc;
+      reflection[0] = n[0] + 2.0 * (qx - n[0]);
+      reflection[1] = n[1] + 2.0 * (qy - n[1]);
+    }
+  }
+  if (degenerate && !found) return -1;
+  return found;
+}
+
+/* Wall bounce of MazeEnv.step (maze_env.py:457-464): returns 0 no hit, 1 bounced, 2 gave up
+ * (position restored to old), -1 when the reference would have raised (collinear). */
+int mzo_bounce(const mz_model* m, const double* old_xy, const double* new_xy, double* final_xy) {
+  double pt[2], rf[2];
+  final_xy[0] = new_xy[0]; final_xy[1] = new_xy[1];
+  int hit = mzo_detect(m, old_xy, new_xy, pt, rf);
+  if (hit <= 0) return hit;
+  double pos[2] = {pt[0] + m->restitution * (rf[0] - pt[0]), pt[1] + m->restitution * (rf[1] - pt[1])}, p2[2], r2[2];
+  int again = mzo_detect(m, old_xy, pos, p2, r2);
+  if (again < 0) return -1;
+  if (again > 0) { final_xy[0] = old_xy[0]; final_xy[1] = old_xy[1]; return 2; }
+  final_xy[0] = pos[0]; final_xy[1] = pos[1];
+  return 1;
+}
+
+/* ---------------------------------------------------------------- task */
+static int goal_neighbor(const mz_model* m, int g, const double* slot) {
+  double s = 0;
+  for (int k = 0; k < m->goal_dim[g]; k++) { double e = slot[k] - m->goal_pos[g][k]; s += e * e; }
+  return sqrt(s) <= m->goal_threshold[g];
+}
+void mzo_task_eval(const mz_model* m, const double* obs, double* reward, int* done, int* goal_idx) {
+  const double* rslot = m->reward_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
+  const double* tslot = m->term_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
+  int term = 0, first = -1;
+  for (int g = 0; g < m->ngoal; g++)
+    if (goal_neighbor(m, g, tslot)) { term = 1; break; }
+  for (int g = 0; g < m->ngoal; g++)
+    if (goal_neighbor(m, g, rslot)) { first = g; break; }
+  double r = 0.0;
+  if (m->reward_kind == MZ_REWARD_FIRST_MATCH) {
+    if (m->reward_binary) r = term ? 1.0 : m->penalty; /* maze_task.py:110-111 */
+    else r = first >= 0 ? m->goal_reward_scale[first] : m->penalty; /* :403-407 */
+  } else if (m->reward_kind == MZ_REWARD_NEG_DIST) {
+    double s = 0;
+    for (int k = 0; k < m->goal_dim[0]; k++) { double e = rslot[k] - m->goal_pos[0][k]; s += e * e; }
+    r = -sqrt(s) / m->task_scale; /* :98-99, :619-621 */
+  }
+  *reward = r;
+  *done = term;
+  *goal_idx = first;
+}
+
+/* ---------------------------------------------------------------- obs */
+void mzo_env_obs(const mz_model* m, const mzo_env_state* s, double* obs) {
+  int k = 0;
+  for (int i = 0; i < m->nq_robot; i++) obs[k++] = s->qpos[i];
+  for (int i = 0; i < m->nv_robot; i++) obs[k++] = s->qvel[i];
+  obs[k++] = s->t * 0.001; /* maze_env.py:369 */
+}
+
+/* ---------------------------------------------------------------- reset */
+void mzo_env_reset(const mz_model* m, mzo_env_state* s, uint64_t seed, uint64_t env) {
+  memset(s, 0, sizeof(*s));
+  for (int i = 0; i < m->nq; i++) {
+    s->qpos[i] = m->qpos0[i];
+    if (i < m->nq_robot) s->qpos[i] += -0.1 + 0.2 * u01(seed, env, (uint32_t)i);
+  }
+  for (int i = 0; i < m->nv_robot; i++) {
+    uint32_t c = (uint32_t)(m->nq + 2 * i);
+    if (m->reset_qvel_kind == 0) s->qvel[i] = 0.1 * normal01(seed, env, c);
+    else if (m->reset_qvel_kind == 1) s->qvel[i] = 0.1 * u01(seed, env, c);
+    else s->qvel[i] = -0.1 + 0.2 * u01(seed, env, c);
+  }
+}
+
+/* ---------------------------------------------------------------- MazeEnv.step */
+void mzo_env_step(const mz_model* m, mzo_env_state* s, const double* action, double* obs, double* reward, uint8_t* done,
+                  int32_t* goal_idx, double* info4, double solver_tol) {
+  mzo_data d;
+  memset(&d, 0, sizeof(d));
+  d.solver_tol = solver_tol;
+  memcpy(d.qpos, s->qpos, sizeof(double) * m->nq);
+  memcpy(d.qvel, s->qvel, sizeof(double) * m->nv);
+  memcpy(d.qacc_warmstart, s->warmstart, sizeof(double) * m->nv);
+  s->t += 1; /* maze_env.py:449 */
+  double old_xy[2] = {d.qpos[0], d.qpos[1]};
+  double inner = 0.0, fwd = 0.0, ctrl_cost = 0.0;
+  if (m->robot == MZ_ROBOT_POINT) {
+    /* point.py:45-59 */
+    double th = d.qpos[2] + action[1];
+    if (th < -M_PI) th += M_PI * 2;
+    else if (M_PI < th) th -= M_PI * 2;
+    d.qpos[2] = th;
+    d.qpos[0] += cos(th) * action[0];
+    d.qpos[1] += sin(th) * action[0];
+    for (int i = 0; i < m->nv; i++) {
+      if (d.qvel[i] < -m->velocity_limit) d.qvel[i] = -m->velocity_limit;
+      if (d.qvel[i] > m->velocity_limit) d.qvel[i] = m->velocity_limit;
+    }
+    for (int k = 0; k < m->frame_skip; k++) mzo_mj_step(m, &d, NULL); /* ctrl is never written */
+  } else {
+    /* ant.py:61-73 / swimmer.py:37-48 */
+    for (int k = 0; k < m->frame_skip; k++) mzo_mj_step(m, &d, action);
+    double dt = m->timestep * m->frame_skip;
+    double vx = (d.qpos[0] - old_xy[0]) / dt, vy = (d.qpos[1] - old_xy[1]) / dt;
+    fwd = sqrt(vx * vx + vy * vy);
+    for (int a = 0; a < m->nu; a++) ctrl_cost += action[a] * action[a];
+    ctrl_cost *= m->ctrl_cost_weight;
+    inner = m->forward_reward_weight * fwd - ctrl_cost;
+  }
+  if (m->manual_collision) { /* maze_env.py:451-464 */
+    double new_xy[2] = {d.qpos[0], d.qpos[1]}, fin[2];
+    int r = mzo_bounce(m, old_xy, new_xy, fin);
+    if (r < 0) s->status |= 8;
+    d.qpos[0] = fin[0]; d.qpos[1] = fin[1];
+  }
+  memcpy(s->qpos, d.qpos, sizeof(double) * m->nq);
+  memcpy(s->qvel, d.qvel, sizeof(double) * m->nv);
+  memcpy(s->warmstart, d.qacc_warmstart, sizeof(double) * m->nv);
+  s->status |= d.status;
+  mzo_env_obs(m, s, obs);
+  double outer; int term, gi;
+  mzo_task_eval(m, obs, &outer, &term, &gi);
+  *reward = m->inner_reward_scaling * inner + outer; /* maze_env.py:477-481 */
+  *done = (uint8_t)((term ? 1 : 0) | (s->t >= m->max_episode_steps ? 2 : 0));
+  if (goal_idx) *goal_idx = gi;
+  if (info4) { info4[0] = d.qpos[0]; info4[1] = d.qpos[1]; info4[2] = fwd; info4[3] = -ctrl_cost; }
+}
+
+/* ---------------------------------------------------------------- batch drivers */
+void mzo_batch_step(const mz_model* m, int n, double* qpos, double* qvel, double* warm, int32_t* t, const double* actions,
+                    double* obs, double* reward, uint8_t* done, int32_t* goal_idx, double* info, int32_t* status,
+                    int nthreads, double solver_tol) {
+  (void)nthreads;
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+  for (int e = 0; e < n; e++) {
+    mzo_env_state s;
+    memset(&s, 0, sizeof(s));
+    memcpy(s.qpos, qpos + (size_t)e * m->nq, sizeof(double) * m->nq);
+    memcpy(s.qvel, qvel + (size_t)e * m->nv, sizeof(double) * m->nv);
+    memcpy(s.warmstart, warm + (size_t)e * m->nv, sizeof(double) * m->nv);
+    s.t = t[e];
+    double inf[4];
+    int32_t gi;
+    mzo_env_step(m, &s, actions + (size_t)e * m->nu, obs + (size_t)e * m->obs_dim, reward + e, done + e, &gi, inf, solver_tol);
+    memcpy(qpos + (size_t)e * m->nq, s.qpos, sizeof(double) * m->nq);
+    memcpy(qvel + (size_t)e * m->nv, s.qvel, sizeof(double) * m->nv);
+    memcpy(warm + (size_t)e * m->nv, s.warmstart, sizeof(double) * m->nv);
+    t[e] = s.t;
+    if (goal_idx) goal_idx[e] = gi;
+    if (info) memcpy(info + (size_t)e * 4, inf, sizeof(inf));
+    if (status) status[e] = s.status;
+  }
+}
+
+void mzo_batch_reset(const mz_model* m, int n, const uint8_t* mask, uint64_t seed, double* qpos, double* qvel, double* warm,
+                     int32_t* t, double* obs) {
+  for (int e = 0; e < n; e++) {
+    if (mask && !mask[e]) continue;
+    mzo_env_state s;
+    mzo_env_reset(m, &s, seed, (uint64_t)e);
+    memcpy(qpos + (size_t)e * m->nq, s.qpos, sizeof(double) * m->nq);
+    memcpy(qvel + (size_t)e * m->nv, s.qvel, sizeof(double) * m->nv);
+    memset(warm + (size_t)e * m->nv, 0, sizeof(double) * m->nv);
+    t[e] = 0;
+    if (obs) mzo_env_obs(m, &s, obs + (size_t)e * m->obs_dim);
+  }
+}
+
+void mzo_batch_forward(const mz_model* m, int n, const double* qpos, const double* qvel, const double* warm,
+                       const double* actions, double* qacc, int32_t* counts, double* Mout, double* bias) {
+  for (int e = 0; e < n; e++) {
+    mzo_data d;
+    memset(&d, 0, sizeof(d));
+    memcpy(d.qpos, qpos + (size_t)e * m->nq, sizeof(double) * m->nq);
+    memcpy(d.qvel, qvel + (size_t)e * m->nv, sizeof(double) * m->nv);
+    if (warm) memcpy(d.qacc_warmstart, warm + (size_t)e * m->nv, sizeof(double) * m->nv);
+    mzo_forward(m, &d, actions ? actions + (size_t)e * m->nu : NULL);
+    memcpy(qacc + (size_t)e * m->nv, d.qacc, sizeof(double) * m->nv);
+    if (counts) { counts[2 * e] = d.ncon; counts[2 * e + 1] = d.nefc; }
+    if (Mout)
+      for (int i = 0; i < m->nv; i++)
+        for (int j = 0; j < m->nv; j++) Mout[((size_t)e * m->nv + i) * m->nv + j] = d.M[i][j];
+    if (bias) memcpy(bias + (size_t)e * m->nv, d.qfrc_bias, sizeof(double) * m->nv);
+  }
+}
+
+/* diagnostics for the invariants tests: report = [ncon, nefc, solver_iter, kkt residual (inf-norm of
+ * M(qacc - qacc_smooth) - J^T f), sum of row forces, min row force, max |f * max(jar,0)| complementarity, status] */
+void mzo_forward_report(const mz_model* m, const double* qpos, const double* qvel, const double* warm, const double* ctrl,
+                        double* report, double* qacc_out) {
+  mzo_data d;
+  memset(&d, 0, sizeof(d));
+  memcpy(d.qpos, qpos, sizeof(double) * m->nq);
+  memcpy(d.qvel, qvel, sizeof(double) * m->nv);
+  if (warm) memcpy(d.qacc_warmstart, warm, sizeof(double) * m->nv);
+  mzo_forward(m, &d, ctrl);
+  double res = 0, fsum = 0, fmin = 0, comp = 0;
+  for (int i = 0; i < m->nv; i++) {
+    double s = 0;
+    for (int j = 0; j < m->nv; j++) s += d.M[i][j] * (d.qacc[j] - d.qacc_smooth[j]);
+    for (int r = 0; r < d.nefc; r++) s -= d.efc_J[r][i] * d.efc_force[r];
+    if (fabs(s) > res) res = fabs(s);
+  }
+  for (int r = 0; r < d.nefc; r++) {
+    double jar = -d.efc_aref[r];
+    for (int i = 0; i < m->nv; i++) jar += d.efc_J[r][i] * d.qacc[i];
+    fsum += d.efc_force[r];
+    if (r == 0 || d.efc_force[r] < fmin) fmin = d.efc_force[r];
+    double c = fabs(d.efc_force[r] * (jar > 0 ? jar : 0));
+    if (c > comp) comp = c;
+    /* soft-constraint law: f = -D * jar on active rows */
+    if (jar < 0) { double e = fabs(d.efc_force[r] + d.efc_D[r] * jar); if (e > comp) comp = e; }
+  }
+  report[0] = d.ncon; report[1] = d.nefc; report[2] = d.solver_iter; report[3] = res; report[4] = fsum; report[5] = fmin;
+  report[6] = comp; report[7] = d.status;
+  if (qacc_out) memcpy(qacc_out, d.qacc, sizeof(double) * m->nv);
+}
+
+/* raw mj_step x n on one state (no maze logic) + energy, for invariants tests */
+void mzo_raw_steps(const mz_model* m, double* qpos, double* qvel, const double* ctrl, int nsteps, double* energy_out) {
+  mzo_data d;
+  memset(&d, 0, sizeof(d));
+  memcpy(d.qpos, qpos, sizeof(double) * m->nq);
+  memcpy(d.qvel, qvel, sizeof(double) * m->nv);
+  for (int k = 0; k < nsteps; k++) {
+    if (energy_out) energy_out[k] = mzo_energy(m, &d);
+    mzo_mj_step(m, &d, ctrl);
+  }
+  memcpy(qpos, d.qpos, sizeof(double) * m->nq);
+  memcpy(qvel, d.qvel, sizeof(double) * m->nv);
+}

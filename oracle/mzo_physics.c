@@ -1,0 +1,953 @@
+/* mzo_physics.c — CPU ORACLE (test infrastructure, not the product).
+ *
+ * A from-scratch float64 restatement of the MuJoCo subset that the reference's
+ * hot path executes inside `mj_step` (called from mujoco_maze/ant.py:63 via
+ * gym's do_simulation, mujoco_maze/point.py:57-59, swimmer.py:39):
+ * kinematics, joint-space inertia (composite rigid body), bias forces
+ * (recursive Newton-Euler), passive damping, motor actuation with ctrl clamp,
+ * collision (plane-sphere, plane-capsule, sphere-box, capsule-box), joint-limit
+ * and pyramidal-cone contact constraints with MuJoCo's impedance / reference-
+ * acceleration model, the primal Newton solver, and RK4 integration with
+ * manifold quaternion update.
+ *
+ * PARITY UNPINNED for this file: MuJoCo itself (mujoco-py 2.0.2.13 / MuJoCo 2.0
+ * per the reference's poetry.lock:145-146; `mujoco` >= 2.2 per point.py:12) is a
+ * third-party dependency that is absent from /root/reference and from this
+ * image, and the reference's tests pin no numeric physics value
+ * (tests/test_envs.py asserts shapes and reward sign only).  The algorithm below
+ * restates MuJoCo's published computation model ("Computation" chapter:
+ * constraint model, impedance, reference acceleration, pyramidal cones, Newton
+ * solver, RK4); every place where a detail is an assumption is tagged
+ * [ASSUME-n] and listed in DESIGN.md.  It is validated by physical invariants
+ * (tests/test_oracle_physics.py) and cross-checked against an independent numpy
+ * mass matrix (mujoco_maze_amd/model.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mzo.h"
+
+#define NB MZ_MAX_BODY
+#define ND MZ_MAX_DOF
+#define MINVAL 1e-15
+
+/* ------------------------------------------------------------------ vec helpers */
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void cpy3(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+static inline void sub3(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static inline void add3(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+static inline void addscl3(double* r, const double* a, double s) { r[0] += a[0] * s; r[1] += a[1] * s; r[2] += a[2] * s; }
+static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
+static inline void mulmat3vec(double* r, const double* m, const double* v) { /* row-major 3x3 */
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void mulmat3Tvec(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+         z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void quat_mul(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static void quat_normalize(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void quat_to_mat(double* m, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+static void axis_angle_quat(double* q, const double* axis, double angle) {
+  double s = sin(0.5 * angle);
+  q[0] = cos(0.5 * angle); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+
+/* ------------------------------------------------------------------ kinematics */
+static void kinematics(const mz_model* m, mzo_data* d) {
+  memset(d->xpos[0], 0, sizeof(d->xpos[0]));
+  d->xquat[0][0] = 1; d->xquat[0][1] = d->xquat[0][2] = d->xquat[0][3] = 0;
+  quat_to_mat(d->xmat[0], d->xquat[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parent[b];
+    double pos[3], quat[4];
+    int j0 = m->body_jntadr[b], jn = m->body_jntnum[b];
+    if (jn == 1 && m->jnt_type[j0] == MZ_JNT_FREE) {
+      int qa = m->jnt_qposadr[j0];
+      cpy3(pos, d->qpos + qa);
+      memcpy(quat, d->qpos + qa + 3, sizeof(quat));
+      quat_normalize(quat);
+      cpy3(d->xanchor[j0], pos);
+      cpy3(d->xaxis[j0], m->jnt_axis[j0]);
+    } else {
+      double t[3];
+      mulmat3vec(t, d->xmat[p], m->body_pos[b]);
+      add3(pos, d->xpos[p], t);
+      quat_mul(quat, d->xquat[p], m->body_quat[b]);
+      for (int j = j0; j < j0 + jn; j++) {
+        double mat[9], axis[3], anchor[3];
+        quat_to_mat(mat, quat);
+        mulmat3vec(axis, mat, m->jnt_axis[j]);
+        mulmat3vec(anchor, mat, m->jnt_pos[j]);
+        add3(anchor, anchor, pos);
+        double q = d->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
+        if (m->jnt_type[j] == MZ_JNT_SLIDE) {
+          addscl3(pos, axis, q);
+        } else { /* hinge: rotate about the joint axis through the anchor */
+          double ql[4], qn[4], v[3];
+          axis_angle_quat(ql, m->jnt_axis[j], q);
+          quat_mul(qn, quat, ql);
+          memcpy(quat, qn, sizeof(quat));
+          quat_to_mat(mat, quat);
+          mulmat3vec(v, mat, m->jnt_pos[j]);
+          sub3(pos, anchor, v);
+        }
+        cpy3(d->xaxis[j], axis);
+        cpy3(d->xanchor[j], anchor);
+      }
+    }
+    quat_normalize(quat);
+    cpy3(d->xpos[b], pos);
+    memcpy(d->xquat[b], quat, sizeof(quat));
+    quat_to_mat(d->xmat[b], quat);
+    double t[3];
+    mulmat3vec(t, d->xmat[b], m->body_ipos[b]);
+    add3(d->xipos[b], d->xpos[b], t);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    double t[3], q[4];
+    mulmat3vec(t, d->xmat[b], m->geom_pos[g]);
+    add3(d->geom_xpos[g], d->xpos[b], t);
+    quat_mul(q, d->xquat[b], m->geom_quat[g]);
+    quat_to_mat(d->geom_xmat[g], q);
+  }
+}
+
+/* ------------------------------------------------------------------ spatial algebra
+ * 6-vectors are [angular(3); linear(3)], world orientation, taken at the fixed
+ * reference point c = origin of body 1 at this instant. */
+static void motion_cross(double* r, const double* v, const double* s) {
+  double a[3], b[3], c[3];
+  cross3(a, v, s);
+  cross3(b, v, s + 3);
+  cross3(c, v + 3, s);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+  r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+static void force_cross(double* r, const double* v, const double* f) { /* v x* f */
+  double a[3], b[3], c[3];
+  cross3(a, v, f);
+  cross3(b, v + 3, f + 3);
+  cross3(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+/* compact spatial inertia: [mass, h(3) = m*r, Ibar(6) = xx yy zz xy xz yz about c] */
+static void inertia_mul(double* r, const double* I, const double* v) {
+  const double* h = I + 1;
+  const double* J = I + 4;
+  double w[3] = {v[0], v[1], v[2]}, l[3] = {v[3], v[4], v[5]}, a[3], b[3];
+  cross3(a, h, l);
+  cross3(b, w, h);
+  r[0] = J[0] * w[0] + J[3] * w[1] + J[4] * w[2] + a[0];
+  r[1] = J[3] * w[0] + J[1] * w[1] + J[5] * w[2] + a[1];
+  r[2] = J[4] * w[0] + J[5] * w[1] + J[2] * w[2] + a[2];
+  r[3] = I[0] * l[0] + b[0]; r[4] = I[0] * l[1] + b[1]; r[5] = I[0] * l[2] + b[2];
+}
+static inline double dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+
+static int dof_parent(const mz_model* m, int i) { /* previous dof up the kinematic tree, -1 at the root */
+  int b = m->dof_bodyid[i];
+  if (i > m->body_dofadr[b]) return i - 1;
+  b = m->body_parent[b];
+  while (b > 0) {
+    if (m->body_dofnum[b] > 0) return m->body_dofadr[b] + m->body_dofnum[b] - 1;
+    b = m->body_parent[b];
+  }
+  return -1;
+}
+
+/* motion axes S, body spatial inertias, CRBA mass matrix */
+static void com_and_crb(const mz_model* m, mzo_data* d) {
+  const double* c = d->xpos[1];
+  cpy3(d->refpoint, c);
+  for (int j = 0; j < m->njnt; j++) {
+    int b = m->jnt_bodyid[j], d0 = m->jnt_dofadr[j];
+    double off[3];
+    if (m->jnt_type[j] == MZ_JNT_FREE) {
+      for (int k = 0; k < 3; k++) {
+        memset(d->S[d0 + k], 0, 6 * sizeof(double));
+        d->S[d0 + k][3 + k] = 1.0;
+        double ax[3] = {d->xmat[b][k], d->xmat[b][3 + k], d->xmat[b][6 + k]};
+        sub3(off, c, d->xpos[b]);
+        cpy3(d->S[d0 + 3 + k], ax);
+        cross3(d->S[d0 + 3 + k] + 3, ax, off);
+      }
+    } else if (m->jnt_type[j] == MZ_JNT_SLIDE) {
+      memset(d->S[d0], 0, 3 * sizeof(double));
+      cpy3(d->S[d0] + 3, d->xaxis[j]);
+    } else {
+      sub3(off, c, d->xanchor[j]);
+      cpy3(d->S[d0], d->xaxis[j]);
+      cross3(d->S[d0] + 3, d->xaxis[j], off);
+    }
+  }
+  for (int b = 1; b < m->nbody; b++) {
+    double r[3], Iw[9], tmp[9];
+    const double* I6 = m->body_inertia[b];
+    double Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+    const double* R = d->xmat[b];
+    for (int i = 0; i < 3; i++)
+      for (int k = 0; k < 3; k++) tmp[3 * i + k] = R[3 * i] * Ib[k] + R[3 * i + 1] * Ib[3 + k] + R[3 * i + 2] * Ib[6 + k];
+    for (int i = 0; i < 3; i++)
+      for (int k = 0; k < 3; k++) Iw[3 * i + k] = tmp[3 * i] * R[3 * k] + tmp[3 * i + 1] * R[3 * k + 1] + tmp[3 * i + 2] * R[3 * k + 2];
+    sub3(r, d->xipos[b], c);
+    double ms = m->body_mass[b], rr = dot3(r, r);
+    double* I = d->cinert[b];
+    I[0] = ms; I[1] = ms * r[0]; I[2] = ms * r[1]; I[3] = ms * r[2];
+    I[4] = Iw[0] + ms * (rr - r[0] * r[0]);
+    I[5] = Iw[4] + ms * (rr - r[1] * r[1]);
+    I[6] = Iw[8] + ms * (rr - r[2] * r[2]);
+    I[7] = Iw[1] - ms * r[0] * r[1];
+    I[8] = Iw[2] - ms * r[0] * r[2];
+    I[9] = Iw[5] - ms * r[1] * r[2];
+  }
+  /* composite inertias */
+  double crb[NB][10];
+  memcpy(crb, d->cinert, sizeof(crb));
+  for (int b = m->nbody - 1; b >= 1; b--) {
+    int p = m->body_parent[b];
+    if (p > 0)
+      for (int k = 0; k < 10; k++) crb[p][k] += crb[b][k];
+  }
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++)
+    for (int j = 0; j < nv; j++) d->M[i][j] = 0.0;
+  for (int i = 0; i < nv; i++) {
+    double F[6];
+    inertia_mul(F, crb[m->dof_bodyid[i]], d->S[i]);
+    d->M[i][i] = dot6(d->S[i], F) + m->dof_armature[i];
+    for (int j = dof_parent(m, i); j >= 0; j = dof_parent(m, j)) {
+      double v = dot6(d->S[j], F);
+      d->M[i][j] = v; d->M[j][i] = v;
+    }
+  }
+}
+
+/* dense Cholesky A = L L^T (lower), returns 0 on success */
+static int chol_factor(double A[][ND], int n) {
+  for (int j = 0; j < n; j++) {
+    double s = A[j][j];
+    for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
+    if (s < MINVAL) return -1;
+    A[j][j] = sqrt(s);
+    for (int i = j + 1; i < n; i++) {
+      double t = A[i][j];
+      for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
+      A[i][j] = t / A[j][j];
+    }
+  }
+  return 0;
+}
+static void chol_solve(double A[][ND], int n, double* x) {
+  for (int i = 0; i < n; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= A[i][k] * x[k];
+    x[i] = s / A[i][i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= A[k][i] * x[k];
+    x[i] = s / A[i][i];
+  }
+}
+
+/* velocities, bias forces via RNE with qacc = 0, passive, actuation (M7) */
+static void velocity_and_forces(const mz_model* m, mzo_data* d, const double* ctrl) {
+  double cvel[NB][6], cacc[NB][6], cfrc[NB][6];
+  memset(cvel[0], 0, sizeof(cvel[0]));
+  memset(cacc[0], 0, sizeof(cacc[0]));
+  cacc[0][3] = -m->gravity[0]; cacc[0][4] = -m->gravity[1]; cacc[0][5] = -m->gravity[2];
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parent[b];
+    double v[6], a[6];
+    memcpy(v, cvel[p], sizeof(v));
+    memcpy(a, cacc[p], sizeof(a));
+    int j0 = m->body_jntadr[b];
+    for (int j = j0; j < j0 + m->body_jntnum[b]; j++) {
+      int d0 = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == MZ_JNT_FREE) {
+        /* translational axes are world-fixed: Sdot = 0 */
+        for (int k = 0; k < 3; k++)
+          for (int e = 0; e < 6; e++) v[e] += d->S[d0 + k][e] * d->qvel[d0 + k];
+        double sd[3][6];
+        for (int k = 0; k < 3; k++) motion_cross(sd[k], v, d->S[d0 + 3 + k]);
+        for (int k = 0; k < 3; k++)
+          for (int e = 0; e < 6; e++) {
+            a[e] += sd[k][e] * d->qvel[d0 + 3 + k];
+            v[e] += d->S[d0 + 3 + k][e] * d->qvel[d0 + 3 + k];
+          }
+      } else {
+        double sd[6];
+        motion_cross(sd, v, d->S[d0]);
+        for (int e = 0; e < 6; e++) {
+          a[e] += sd[e] * d->qvel[d0];
+          v[e] += d->S[d0][e] * d->qvel[d0];
+        }
+      }
+    }
+    memcpy(cvel[b], v, sizeof(v));
+    memcpy(cacc[b], a, sizeof(a));
+    double Ia[6], Iv[6], vf[6];
+    inertia_mul(Ia, d->cinert[b], a);
+    inertia_mul(Iv, d->cinert[b], v);
+    force_cross(vf, v, Iv);
+    for (int e = 0; e < 6; e++) cfrc[b][e] = Ia[e] + vf[e];
+  }
+  memcpy(d->cvel, cvel, sizeof(cvel));
+  for (int b = m->nbody - 1; b >= 1; b--) {
+    int p = m->body_parent[b];
+    if (p > 0)
+      for (int e = 0; e < 6; e++) cfrc[p][e] += cfrc[b][e];
+  }
+  for (int i = 0; i < m->nv; i++) {
+    d->qfrc_bias[i] = dot6(d->S[i], cfrc[m->dof_bodyid[i]]);
+    d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
+    d->qfrc_actuator[i] = 0.0;
+  }
+  /* inertia-box fluid model (swimmer): [ASSUME-9] only when density/viscosity > 0 */
+  if (m->density > 0.0 || m->viscosity > 0.0) mzo_fluid_passive(m, d);
+  for (int a = 0; a < m->nu; a++) {
+    double u = ctrl ? ctrl[a] : 0.0;
+    if (m->act_ctrllimited[a]) {
+      if (u < m->act_ctrlrange[a][0]) u = m->act_ctrlrange[a][0];
+      if (u > m->act_ctrlrange[a][1]) u = m->act_ctrlrange[a][1];
+    }
+    d->qfrc_actuator[m->act_dofid[a]] += m->act_gear[a] * u;
+  }
+  for (int i = 0; i < m->nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+}
+
+/* MuJoCo's "inertia box" fluid force model for bodies moving in a medium
+ * (option density / viscosity; swimmer.xml:3).  [ASSUME-9] restated from the
+ * published description: each body is replaced by the box with the same mass and
+ * principal inertia; viscous drag  f = -3 beta pi d_eq v,  tau = -beta pi d_eq^3 w;
+ * quadratic drag per axis  f_i = -rho/2 * A_i |v_i| v_i  etc.  Expressed in the
+ * body's inertial frame and mapped back through the COM Jacobian. */
+void mzo_fluid_passive(const mz_model* m, mzo_data* d) {
+  const double* c = d->refpoint;
+  for (int b = 1; b < m->nbody; b++) {
+    double mass = m->body_mass[b];
+    if (mass < MINVAL) continue;
+    const double* I6 = m->body_inertia[b];
+    /* the robots here have principal body inertias aligned with the body frame
+       up to a rotation about z; use the diagonal (exact for the swimmer's capsules along x) */
+    double I[3] = {I6[0], I6[1], I6[2]};
+    double bx[3];
+    bx[0] = sqrt(fmax(MINVAL, (I[1] + I[2] - I[0])) / mass * 6.0);
+    bx[1] = sqrt(fmax(MINVAL, (I[0] + I[2] - I[1])) / mass * 6.0);
+    bx[2] = sqrt(fmax(MINVAL, (I[0] + I[1] - I[2])) / mass * 6.0);
+    /* velocity of the COM and angular velocity, local frame */
+    double w[3] = {d->cvel[b][0], d->cvel[b][1], d->cvel[b][2]}, r[3], wr[3], vc[3], lw[3], lv[3];
+    sub3(r, d->xipos[b], c);
+    cross3(wr, w, r);
+    vc[0] = d->cvel[b][3] + wr[0]; vc[1] = d->cvel[b][4] + wr[1]; vc[2] = d->cvel[b][5] + wr[2];
+    mulmat3Tvec(lw, d->xmat[b], w);
+    mulmat3Tvec(lv, d->xmat[b], vc);
+    double lf[3] = {0, 0, 0}, lt[3] = {0, 0, 0};
+    if (m->viscosity > 0.0) {
+      double diam = (bx[0] + bx[1] + bx[2]) / 3.0;
+      double s = -3.0 * m->viscosity * M_PI * diam;
+      double t = -m->viscosity * M_PI * diam * diam * diam;
+      for (int k = 0; k < 3; k++) { lf[k] += s * lv[k]; lt[k] += t * lw[k]; }
+    }
+    if (m->density > 0.0) {
+      lf[0] -= 0.5 * m->density * bx[1] * bx[2] * fabs(lv[0]) * lv[0];
+      lf[1] -= 0.5 * m->density * bx[0] * bx[2] * fabs(lv[1]) * lv[1];
+      lf[2] -= 0.5 * m->density * bx[0] * bx[1] * fabs(lv[2]) * lv[2];
+      lt[0] -= m->density * bx[0] * (pow(bx[1], 4) + pow(bx[2], 4)) * fabs(lw[0]) * lw[0] / 64.0;
+      lt[1] -= m->density * bx[1] * (pow(bx[0], 4) + pow(bx[2], 4)) * fabs(lw[1]) * lw[1] / 64.0;
+      lt[2] -= m->density * bx[2] * (pow(bx[0], 4) + pow(bx[1], 4)) * fabs(lw[2]) * lw[2] / 64.0;
+    }
+    double f[3], t[3], fsp[6], rf[3];
+    mulmat3vec(f, d->xmat[b], lf);
+    mulmat3vec(t, d->xmat[b], lt);
+    /* wrench at c: torque about c = t + r x f */
+    cross3(rf, r, f);
+    fsp[0] = t[0] + rf[0]; fsp[1] = t[1] + rf[1]; fsp[2] = t[2] + rf[2];
+    fsp[3] = f[0]; fsp[4] = f[1]; fsp[5] = f[2];
+    for (int i = 0; i < m->nv; i++) {
+      /* dof i moves body b iff body(i) is b or an ancestor */
+      int a = b, hit = 0;
+      while (a > 0) { if (a == m->dof_bodyid[i]) { hit = 1; break; } a = m->body_parent[a]; }
+      if (hit) d->qfrc_passive[i] += dot6(d->S[i], fsp);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ collision */
+static void make_frame(double* fr) { /* fr[0:3] normal given, fr[3:6] optional hint */
+  double n = norm3(fr);
+  fr[0] /= n; fr[1] /= n; fr[2] /= n;
+  if (norm3(fr + 3) < 0.5) {
+    fr[3] = 0; fr[4] = 0; fr[5] = 0;
+    if (fr[1] < 0.5 && fr[1] > -0.5) fr[4] = 1; else fr[5] = 1;
+  }
+  double t = dot3(fr, fr + 3);
+  addscl3(fr + 3, fr, -t);
+  n = norm3(fr + 3);
+  if (n < 1e-10) { /* hint parallel to the normal: fall back to the default rule */
+    fr[3] = 0; fr[4] = 0; fr[5] = 0;
+    if (fr[1] < 0.5 && fr[1] > -0.5) fr[4] = 1; else fr[5] = 1;
+    t = dot3(fr, fr + 3);
+    addscl3(fr + 3, fr, -t);
+    n = norm3(fr + 3);
+  }
+  fr[3] /= n; fr[4] /= n; fr[5] /= n;
+  cross3(fr + 6, fr, fr + 3);
+}
+
+typedef struct { /* mixed pair parameters */
+  double margin, gap, mu, solref[2], solimp[5];
+  int condim, b1, b2, g1, g2;
+} pairparam;
+
+static void add_contact(mzo_data* d, const pairparam* pp, double dist, const double* pos, const double* normal,
+                        const double* hint) {
+  if (d->ncon >= MZO_MAX_CON) { d->status |= MZ_STATUS_CONTACT_OVERFLOW; return; }
+  mzo_contact* c = &d->con[d->ncon++];
+  c->dist = dist;
+  cpy3(c->pos, pos);
+  cpy3(c->frame, normal);
+  if (hint) cpy3(c->frame + 3, hint); else c->frame[3] = c->frame[4] = c->frame[5] = 0;
+  make_frame(c->frame);
+  c->includemargin = pp->margin - pp->gap;
+  c->mu = pp->mu;
+  memcpy(c->solref, pp->solref, sizeof(c->solref));
+  memcpy(c->solimp, pp->solimp, sizeof(c->solimp));
+  c->dim = pp->condim;
+  c->body1 = pp->b1; c->body2 = pp->b2; c->geom1 = pp->g1; c->geom2 = pp->g2;
+}
+
+/* sphere (centre cs, radius r) against an axis-aligned-in-its-frame box.
+ * Normal points from the sphere (geom1) to the box (geom2). Returns 1 if within margin. */
+static int sphere_box(const double* cs, double r, const double* bpos, const double* bmat, const double* bsize,
+                      double margin, double* dist, double* pos, double* normal) {
+  double rel[3], c[3], q[3];
+  sub3(rel, cs, bpos);
+  mulmat3Tvec(c, bmat, rel);
+  int inside = 1;
+  for (int k = 0; k < 3; k++) {
+    q[k] = c[k];
+    if (q[k] > bsize[k]) { q[k] = bsize[k]; inside = 0; }
+    if (q[k] < -bsize[k]) { q[k] = -bsize[k]; inside = 0; }
+  }
+  double nl[3], dd;
+  if (!inside) {
+    double v[3];
+    sub3(v, q, c);
+    dd = norm3(v);
+    if (dd - r > margin) return 0;
+    nl[0] = v[0] / dd; nl[1] = v[1] / dd; nl[2] = v[2] / dd;
+    dd -= r;
+  } else { /* centre inside the box: push out through the nearest face */
+    int kbest = 0; double best = 1e30;
+    for (int k = 0; k < 3; k++) { double e = bsize[k] - fabs(c[k]); if (e < best) { best = e; kbest = k; } }
+    nl[0] = nl[1] = nl[2] = 0;
+    nl[kbest] = c[kbest] >= 0 ? -1.0 : 1.0;
+    dd = -best - r;
+  }
+  mulmat3vec(normal, bmat, nl);
+  *dist = dd;
+  pos[0] = cs[0] + normal[0] * (r + 0.5 * dd);
+  pos[1] = cs[1] + normal[1] * (r + 0.5 * dd);
+  pos[2] = cs[2] + normal[2] * (r + 0.5 * dd);
+  return dd <= margin;
+}
+
+/* squared-distance derivative helper for segment-vs-box: f'(t)/2 */
+static double seg_box_dfdt(const double* a, const double* dir, const double* s, double t) {
+  double g = 0;
+  for (int k = 0; k < 3; k++) {
+    double p = a[k] + t * dir[k];
+    if (p > s[k]) g += (p - s[k]) * dir[k];
+    else if (p < -s[k]) g += (p + s[k]) * dir[k];
+  }
+  return g;
+}
+/* parameter t in [0,1] of the segment point closest to the box (box frame). */
+static double seg_box_closest_t(const double* a, const double* b, const double* s) {
+  double dir[3], bp[8];
+  int n = 0;
+  sub3(dir, b, a);
+  bp[n++] = 0.0;
+  for (int k = 0; k < 3; k++) {
+    if (fabs(dir[k]) > 1e-300) {
+      double t1 = (s[k] - a[k]) / dir[k], t2 = (-s[k] - a[k]) / dir[k];
+      if (t1 > 0 && t1 < 1) bp[n++] = t1;
+      if (t2 > 0 && t2 < 1) bp[n++] = t2;
+    }
+  }
+  bp[n++] = 1.0;
+  for (int i = 1; i < n; i++) { /* insertion sort */
+    double v = bp[i]; int j = i - 1;
+    while (j >= 0 && bp[j] > v) { bp[j + 1] = bp[j]; j--; }
+    bp[j + 1] = v;
+  }
+  double g0 = seg_box_dfdt(a, dir, s, bp[0]);
+  if (g0 >= 0) return bp[0];
+  for (int i = 1; i < n; i++) {
+    double g1 = seg_box_dfdt(a, dir, s, bp[i]);
+    if (g1 >= 0) {
+      double t = bp[i - 1] - g0 * (bp[i] - bp[i - 1]) / (g1 - g0);
+      return t;
+    }
+    g0 = g1;
+  }
+  return 1.0;
+}
+
+/* capsule (geom1) vs box (geom2).  [ASSUME-6] MuJoCo's mjc_CapsuleBox feature
+ * search is not reproduced; contact A sits at the segment point closest to the
+ * box, contact B at the segment end farther from A when that end is itself
+ * within the margin. */
+static void capsule_box(mzo_data* d, const pairparam* pp, const double* cpos, const double* cmat, double r, double hl,
+                        const double* bpos, const double* bmat, const double* bsize) {
+  double axis[3] = {cmat[2], cmat[5], cmat[8]}, e1[3], e2[3], rel[3], a[3], b[3];
+  for (int k = 0; k < 3; k++) { e1[k] = cpos[k] + axis[k] * hl; e2[k] = cpos[k] - axis[k] * hl; }
+  sub3(rel, e1, bpos); mulmat3Tvec(a, bmat, rel);
+  sub3(rel, e2, bpos); mulmat3Tvec(b, bmat, rel);
+  double t = seg_box_closest_t(a, b, bsize);
+  double p[3], dist, pos[3], nrm[3];
+  for (int k = 0; k < 3; k++) p[k] = e1[k] + t * (e2[k] - e1[k]);
+  if (sphere_box(p, r, bpos, bmat, bsize, pp->margin, &dist, pos, nrm)) add_contact(d, pp, dist, pos, nrm, NULL);
+  const double* far = (t <= 0.5) ? e2 : e1;
+  double tf = (t <= 0.5) ? 1.0 : 0.0;
+  if (fabs(tf - t) * 2.0 * hl > 1e-6)
+    if (sphere_box(far, r, bpos, bmat, bsize, pp->margin, &dist, pos, nrm)) add_contact(d, pp, dist, pos, nrm, NULL);
+}
+
+static void mix_params(pairparam* pp, double m1, double m2, double g1, double g2, const double* f1, const double* f2,
+                       const double* sr1, const double* sr2, const double* si1, const double* si2, int cd1, int cd2) {
+  pp->margin = fmax(m1, m2);
+  pp->gap = fmax(g1, g2);
+  pp->mu = fmax(f1[0], f2[0]);
+  for (int k = 0; k < 2; k++) pp->solref[k] = 0.5 * (sr1[k] + sr2[k]); /* [ASSUME-4] equal solmix / priority */
+  for (int k = 0; k < 5; k++) pp->solimp[k] = 0.5 * (si1[k] + si2[k]);
+  pp->condim = cd1 > cd2 ? cd1 : cd2;
+}
+
+static void collide_plane(const mz_model* m, mzo_data* d, int gp, int g) {
+  pairparam pp;
+  mix_params(&pp, m->geom_margin[gp], m->geom_margin[g], m->geom_gap[gp], m->geom_gap[g], m->geom_friction[gp],
+             m->geom_friction[g], m->geom_solref[gp], m->geom_solref[g], m->geom_solimp[gp], m->geom_solimp[g],
+             m->geom_condim[gp], m->geom_condim[g]);
+  pp.b1 = m->geom_bodyid[gp]; pp.b2 = m->geom_bodyid[g]; pp.g1 = gp; pp.g2 = g;
+  const double* pm = d->geom_xmat[gp];
+  double n[3] = {pm[2], pm[5], pm[8]}, rel[3];
+  if (m->geom_type[g] == MZ_GEOM_SPHERE) {
+    double r = m->geom_size[g][0];
+    sub3(rel, d->geom_xpos[g], d->geom_xpos[gp]);
+    double dist = dot3(rel, n) - r;
+    if (dist > pp.margin) return;
+    double pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = d->geom_xpos[g][k] - n[k] * (r + 0.5 * dist);
+    add_contact(d, &pp, dist, pos, n, NULL);
+  } else if (m->geom_type[g] == MZ_GEOM_CAPSULE) {
+    double r = m->geom_size[g][0], hl = m->geom_size[g][1];
+    const double* cm = d->geom_xmat[g];
+    double axis[3] = {cm[2], cm[5], cm[8]};
+    for (int s = 0; s < 2; s++) { /* [ASSUME-5] end +axis first, then -axis; tangent hint = capsule axis */
+      double sg = s == 0 ? 1.0 : -1.0, e[3];
+      for (int k = 0; k < 3; k++) e[k] = d->geom_xpos[g][k] + sg * axis[k] * hl;
+      sub3(rel, e, d->geom_xpos[gp]);
+      double dist = dot3(rel, n) - r;
+      if (dist > pp.margin) continue;
+      double pos[3];
+      for (int k = 0; k < 3; k++) pos[k] = e[k] - n[k] * (r + 0.5 * dist);
+      add_contact(d, &pp, dist, pos, n, axis);
+    }
+  } else if (m->geom_type[g] == MZ_GEOM_BOX) {
+    /* plane-box: corners below the margin (up to 4 deepest in MuJoCo; all 8 candidates tested here) */
+    const double* bm = d->geom_xmat[g];
+    const double* sz = m->geom_size[g];
+    for (int cidx = 0; cidx < 8; cidx++) {
+      double loc[3] = {(cidx & 1 ? 1 : -1) * sz[0], (cidx & 2 ? 1 : -1) * sz[1], (cidx & 4 ? 1 : -1) * sz[2]}, w[3], e[3];
+      mulmat3vec(w, bm, loc);
+      add3(e, d->geom_xpos[g], w);
+      sub3(rel, e, d->geom_xpos[gp]);
+      double dist = dot3(rel, n);
+      if (dist > pp.margin) continue;
+      double pos[3];
+      for (int k = 0; k < 3; k++) pos[k] = e[k] - n[k] * (0.5 * dist);
+      add_contact(d, &pp, dist, pos, n, NULL);
+    }
+  }
+}
+
+static void collide_walls(const mz_model* m, mzo_data* d, int g) {
+  /* implicit maze boxes (world body): only cells overlapping the geom's bounding square can touch */
+  if (!((m->geom_contype[g] & m->wall_conaffinity) || (m->wall_contype & m->geom_conaffinity[g]))) return;
+  pairparam pp;
+  mix_params(&pp, m->geom_margin[g], m->wall_margin, m->geom_gap[g], m->wall_gap, m->geom_friction[g], m->wall_friction,
+             m->geom_solref[g], m->wall_solref, m->geom_solimp[g], m->wall_solimp, m->geom_condim[g], m->wall_condim);
+  pp.b1 = m->geom_bodyid[g]; pp.b2 = 0; pp.g1 = g; pp.g2 = -1;
+  double s = m->maze_scale, reach = m->geom_rbound[g] + pp.margin;
+  const double* gp = d->geom_xpos[g];
+  if (gp[2] - reach > m->wall_center_z + m->wall_half_z) return;
+  int j0 = (int)floor((gp[0] - reach + m->torso_x) / s + 0.5), j1 = (int)floor((gp[0] + reach + m->torso_x) / s + 0.5);
+  int i0 = (int)floor((gp[1] - reach + m->torso_y) / s + 0.5), i1 = (int)floor((gp[1] + reach + m->torso_y) / s + 0.5);
+  static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double bsize[3] = {m->wall_half_xy, m->wall_half_xy, m->wall_half_z};
+  for (int i = i0; i <= i1; i++)
+    for (int j = j0; j <= j1; j++) {
+      if (i < 0 || j < 0 || i >= m->grid_rows || j >= m->grid_cols) continue;
+      if (m->grid[i][j] != MZ_CELL_BLOCK) continue;
+      double bpos[3] = {j * s - m->torso_x, i * s - m->torso_y, m->wall_center_z};
+      if (m->geom_type[g] == MZ_GEOM_SPHERE) {
+        double dist, pos[3], nrm[3];
+        if (sphere_box(gp, m->geom_size[g][0], bpos, ident, bsize, pp.margin, &dist, pos, nrm))
+          add_contact(d, &pp, dist, pos, nrm, NULL);
+      } else if (m->geom_type[g] == MZ_GEOM_CAPSULE) {
+        capsule_box(d, &pp, gp, d->geom_xmat[g], m->geom_size[g][0], m->geom_size[g][1], bpos, ident, bsize);
+      } else {
+        d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* box-box: not restated yet (Point arrow, movable blocks) */
+      }
+    }
+}
+
+static void collision(const mz_model* m, mzo_data* d) {
+  d->ncon = 0;
+  if (m->collision_predefined) return; /* swimmer.xml:3 */
+  for (int g1 = 0; g1 < m->ngeom; g1++)
+    for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
+      int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+      if (b1 == b2) continue;
+      if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
+      /* parent-child filter does not apply when the parent is the world body */
+      if (b1 != 0 && b2 != 0 && (m->body_parent[b1] == b2 || m->body_parent[b2] == b1)) continue;
+      if (m->geom_type[g1] == MZ_GEOM_PLANE) collide_plane(m, d, g1, g2);
+      else d->status |= MZO_STATUS_UNSUPPORTED_PAIR;
+    }
+  for (int g = 1; g < m->ngeom; g++)
+    if (m->geom_bodyid[g] != 0) collide_walls(m, d, g);
+}
+
+/* ------------------------------------------------------------------ constraints */
+static void point_jacobian(const mz_model* m, const mzo_data* d, int body, const double* p, double jac[3][ND]) {
+  for (int i = 0; i < m->nv; i++) jac[0][i] = jac[1][i] = jac[2][i] = 0.0;
+  double off[3];
+  sub3(off, p, d->refpoint);
+  for (int b = body; b > 0; b = m->body_parent[b])
+    for (int i = m->body_dofadr[b]; i >= 0 && i < m->body_dofadr[b] + m->body_dofnum[b]; i++) {
+      double wx[3];
+      cross3(wx, d->S[i], off);
+      jac[0][i] = d->S[i][3] + wx[0]; jac[1][i] = d->S[i][4] + wx[1]; jac[2][i] = d->S[i][5] + wx[2];
+    }
+}
+
+static double impedance(const double* solimp, double x) { /* x = |pos - margin| */
+  double d0 = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  if (d0 == dmax || width <= MINVAL) return 0.5 * (d0 + dmax);
+  double xn = x / width;
+  if (xn >= 1.0) return dmax;
+  if (xn <= 0.0) return d0;
+  double y;
+  if (power <= 1.0 + 1e-12) y = xn;
+  else if (xn <= mid) y = pow(xn, power) / pow(mid, power - 1.0);
+  else y = 1.0 - pow(1.0 - xn, power) / pow(1.0 - mid, power - 1.0);
+  return d0 + y * (dmax - d0);
+}
+
+static void add_row(const mz_model* m, mzo_data* d, const double* J, double pos, double margin, double diag,
+                    const double* solref, const double* solimp) {
+  if (d->nefc >= MZO_MAX_EFC) { d->status |= MZ_STATUS_CONTACT_OVERFLOW; return; }
+  int r = d->nefc++;
+  memcpy(d->efc_J[r], J, sizeof(double) * m->nv);
+  d->efc_pos[r] = pos;
+  d->efc_margin[r] = margin;
+  double imp = impedance(solimp, fabs(pos - margin));
+  d->efc_R[r] = fmax(MINVAL, (1.0 - imp) * diag / imp);
+  /* reference acceleration coefficients: solref = (timeconst, dampratio), refsafe on [ASSUME-2] */
+  double tc = fmax(solref[0], 2.0 * m->timestep), dr = solref[1], dmax = solimp[1];
+  d->efc_K[r] = 1.0 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr);
+  d->efc_B[r] = 2.0 / fmax(MINVAL, dmax * tc);
+  d->efc_imp[r] = imp;
+}
+
+static void make_constraints(const mz_model* m, mzo_data* d) {
+  d->nefc = 0;
+  int nv = m->nv;
+  double J[ND];
+  /* joint limits */
+  for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j] || (m->jnt_type[j] != MZ_JNT_HINGE && m->jnt_type[j] != MZ_JNT_SLIDE)) continue;
+    double q = d->qpos[m->jnt_qposadr[j]];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side < 0 ? q - m->jnt_range[j][0] : m->jnt_range[j][1] - q;
+      if (dist < m->jnt_margin[j]) {
+        memset(J, 0, sizeof(J));
+        J[m->jnt_dofadr[j]] = -(double)side;
+        add_row(m, d, J, dist, m->jnt_margin[j], m->dof_invweight0[m->jnt_dofadr[j]], m->jnt_solref[j], m->jnt_solimp[j]);
+      }
+    }
+  }
+  /* contacts: pyramidal cone, condim 3 -> 4 rows (condim 1 -> 1 frictionless row) */
+  for (int c = 0; c < d->ncon; c++) {
+    mzo_contact* con = &d->con[c];
+    con->efc_address = -1;
+    if (!(con->dist < con->includemargin)) continue;
+    double j1[3][ND], j2[3][ND], jc[3][ND];
+    point_jacobian(m, d, con->body1, con->pos, j1);
+    point_jacobian(m, d, con->body2, con->pos, j2);
+    for (int k = 0; k < 3; k++)
+      for (int i = 0; i < nv; i++)
+        jc[k][i] = con->frame[3 * k] * (j2[0][i] - j1[0][i]) + con->frame[3 * k + 1] * (j2[1][i] - j1[1][i]) +
+                   con->frame[3 * k + 2] * (j2[2][i] - j1[2][i]);
+    double tran = m->body_invweight0[con->body1][0] + m->body_invweight0[con->body2][0];
+    con->efc_address = d->nefc;
+    if (con->dim == 1) {
+      add_row(m, d, jc[0], con->dist, con->includemargin, tran, con->solref, con->solimp);
+      continue;
+    }
+    int first = d->nefc;
+    double mu = con->mu;
+    for (int k = 1; k <= 2; k++)
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        for (int i = 0; i < nv; i++) J[i] = jc[0][i] + sgn * mu * jc[k][i];
+        add_row(m, d, J, con->dist, con->includemargin, tran + mu * mu * tran, con->solref, con->solimp);
+      }
+    /* [ASSUME-3] pyramid edges share R = 2 mu^2 R(first edge) */
+    double Rpy = 2.0 * mu * mu * d->efc_R[first];
+    for (int r = first; r < d->nefc; r++) d->efc_R[r] = Rpy;
+  }
+  for (int r = 0; r < d->nefc; r++) {
+    double vel = 0;
+    for (int i = 0; i < nv; i++) vel += d->efc_J[r][i] * d->qvel[i];
+    d->efc_D[r] = 1.0 / d->efc_R[r];
+    d->efc_aref[r] = -d->efc_B[r] * vel - d->efc_K[r] * d->efc_imp[r] * (d->efc_pos[r] - d->efc_margin[r]);
+  }
+}
+
+/* ------------------------------------------------------------------ Newton solver */
+typedef struct { double a; double jar, jv, D; } lsbp;
+static int cmp_bp(const void* x, const void* y) {
+  double a = ((const lsbp*)x)->a, b = ((const lsbp*)y)->a;
+  return (a > b) - (a < b);
+}
+
+static double eval_cost(const mz_model* m, const mzo_data* d, const double* qacc, double* jar_out) {
+  int nv = m->nv;
+  double cost = 0;
+  for (int i = 0; i < nv; i++) {
+    double s = 0;
+    for (int j = 0; j < nv; j++) s += d->M[i][j] * (qacc[j] - d->qacc_smooth[j]);
+    cost += 0.5 * s * (qacc[i] - d->qacc_smooth[i]);
+  }
+  for (int r = 0; r < d->nefc; r++) {
+    double jar = -d->efc_aref[r];
+    for (int i = 0; i < nv; i++) jar += d->efc_J[r][i] * qacc[i];
+    if (jar_out) jar_out[r] = jar;
+    if (jar < 0) cost += 0.5 * d->efc_D[r] * jar * jar;
+  }
+  return cost;
+}
+
+static void solve_constraints(const mz_model* m, mzo_data* d, double tol, int maxiter) {
+  int nv = m->nv, ne = d->nefc;
+  d->solver_iter = 0;
+  if (ne == 0) { memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv); return; }
+  double qacc[ND], jar[MZO_MAX_EFC], grad[ND], search[ND], Ms[ND], jv[MZO_MAX_EFC];
+  /* warm start: the better of qacc_warmstart and qacc_smooth */
+  double cw = eval_cost(m, d, d->qacc_warmstart, NULL), cs = eval_cost(m, d, d->qacc_smooth, NULL);
+  memcpy(qacc, cw < cs ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  double cost = eval_cost(m, d, qacc, jar);
+  double H[ND][ND];
+  for (int it = 0; it < maxiter; it++) {
+    /* gradient and Hessian on the current active set */
+    for (int i = 0; i < nv; i++) {
+      double s = 0;
+      for (int j = 0; j < nv; j++) s += d->M[i][j] * (qacc[j] - d->qacc_smooth[j]);
+      grad[i] = s;
+      for (int j = 0; j < nv; j++) H[i][j] = d->M[i][j];
+    }
+    for (int r = 0; r < ne; r++)
+      if (jar[r] < 0) {
+        double w = d->efc_D[r];
+        for (int i = 0; i < nv; i++) {
+          double ji = d->efc_J[r][i];
+          if (ji == 0.0) continue;
+          grad[i] += w * jar[r] * ji;
+          for (int j = 0; j < nv; j++) H[i][j] += w * ji * d->efc_J[r][j];
+        }
+      }
+    double gn = 0;
+    for (int i = 0; i < nv; i++) gn += grad[i] * grad[i];
+    if (scale * sqrt(gn) < tol) break;
+    if (chol_factor(H, nv)) { d->status |= MZ_STATUS_BAD_STATE; break; }
+    for (int i = 0; i < nv; i++) search[i] = -grad[i];
+    chol_solve(H, nv, search);
+    /* exact line search on the piecewise-quadratic phi(alpha) */
+    double p1 = 0, p2 = 0; /* phi'(a) = p1 + p2*a + sum_active D (jar + a jv) jv */
+    for (int i = 0; i < nv; i++) {
+      double s = 0, g0 = 0;
+      for (int j = 0; j < nv; j++) { s += d->M[i][j] * search[j]; g0 += d->M[i][j] * (qacc[j] - d->qacc_smooth[j]); }
+      Ms[i] = s;
+      p1 += search[i] * g0;
+      p2 += search[i] * s;
+    }
+    lsbp bp[MZO_MAX_EFC];
+    int nb = 0;
+    double q1 = p1, q2 = p2;
+    for (int r = 0; r < ne; r++) {
+      double v = 0;
+      for (int i = 0; i < nv; i++) v += d->efc_J[r][i] * search[i];
+      jv[r] = v;
+      int act0 = jar[r] < 0 || (jar[r] == 0.0 && v < 0); /* active for alpha -> 0+ */
+      if (act0) { q1 += d->efc_D[r] * jar[r] * v; q2 += d->efc_D[r] * v * v; }
+      if (v != 0.0) {
+        double a = -jar[r] / v;
+        if (a > 0) { bp[nb].a = a; bp[nb].jar = jar[r]; bp[nb].jv = v; bp[nb].D = d->efc_D[r]; nb++; }
+      }
+    }
+    qsort(bp, nb, sizeof(lsbp), cmp_bp);
+    double alpha = 0;
+    int found = 0;
+    for (int k = 0; k <= nb; k++) {
+      double hi = k < nb ? bp[k].a : INFINITY;
+      double root = q2 > 0 ? -q1 / q2 : INFINITY;
+      if (root <= hi) { alpha = root; found = 1; break; }
+      if (k < nb) { /* crossing breakpoint k toggles that row */
+        double sgn = (bp[k].jar < 0) ? -1.0 : 1.0; /* active -> inactive (-) or inactive -> active (+) */
+        q1 += sgn * bp[k].D * bp[k].jar * bp[k].jv;
+        q2 += sgn * bp[k].D * bp[k].jv * bp[k].jv;
+      }
+    }
+    if (!found || !(alpha > 0) || !isfinite(alpha)) break;
+    for (int i = 0; i < nv; i++) qacc[i] += alpha * search[i];
+    for (int r = 0; r < ne; r++) jar[r] += alpha * jv[r];
+    double newcost = eval_cost(m, d, qacc, jar); /* recompute jar exactly to avoid drift */
+    d->solver_iter = it + 1;
+    double improvement = scale * (cost - newcost);
+    cost = newcost;
+    if (!(improvement > 0)) break; /* round-off floor reached */
+    if (it == maxiter - 1) d->status |= MZ_STATUS_SOLVER_MAXITER;
+  }
+  memcpy(d->qacc, qacc, sizeof(double) * nv);
+  for (int r = 0; r < ne; r++) d->efc_force[r] = jar[r] < 0 ? -d->efc_D[r] * jar[r] : 0.0;
+}
+
+/* ------------------------------------------------------------------ forward dynamics */
+void mzo_forward(const mz_model* m, mzo_data* d, const double* ctrl) {
+  kinematics(m, d);
+  com_and_crb(m, d);
+  collision(m, d);
+  make_constraints(m, d);
+  velocity_and_forces(m, d, ctrl);
+  int nv = m->nv;
+  double L[ND][ND];
+  for (int i = 0; i < nv; i++) {
+    for (int j = 0; j < nv; j++) L[i][j] = d->M[i][j];
+    d->qacc_smooth[i] = d->qfrc_smooth[i];
+  }
+  if (chol_factor(L, nv)) d->status |= MZ_STATUS_BAD_STATE;
+  chol_solve(L, nv, d->qacc_smooth);
+  solve_constraints(m, d, d->solver_tol > 0 ? d->solver_tol : 1e-10, d->solver_maxiter > 0 ? d->solver_maxiter : 100);
+}
+
+static void integrate_pos(const mz_model* m, double* qpos, const double* vel, double h) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == MZ_JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += h * vel[da + k];
+      double w[3] = {vel[da + 3], vel[da + 4], vel[da + 5]};
+      double n = norm3(w);
+      if (n > MINVAL) {
+        double ax[3] = {w[0] / n, w[1] / n, w[2] / n}, qr[4], qn[4];
+        axis_angle_quat(qr, ax, h * n);
+        quat_mul(qn, qpos + qa + 3, qr);
+        memcpy(qpos + qa + 3, qn, sizeof(qn));
+      }
+      quat_normalize(qpos + qa + 3);
+    } else {
+      qpos[qa] += h * vel[da];
+    }
+  }
+}
+
+static int bad(const double* x, int n) {
+  for (int i = 0; i < n; i++)
+    if (!isfinite(x[i]) || fabs(x[i]) > 1e10) return 1;
+  return 0;
+}
+
+/* one mj_step with RK4 */
+void mzo_mj_step(const mz_model* m, mzo_data* d, const double* ctrl) {
+  int nq = m->nq, nv = m->nv;
+  double h = m->timestep;
+  static const double A[9] = {0.5, 0, 0, 0, 0.5, 0, 0, 0, 1.0}, B[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+  double X0q[MZ_MAX_Q], Xv[4][ND], F[4][ND], dv[ND], df[ND];
+  if (bad(d->qpos, nq) || bad(d->qvel, nv)) d->status |= MZ_STATUS_BAD_STATE;
+  mzo_forward(m, d, ctrl);
+  if (bad(d->qacc, nv)) d->status |= MZ_STATUS_BAD_STATE;
+  memcpy(X0q, d->qpos, sizeof(double) * nq);
+  memcpy(Xv[0], d->qvel, sizeof(double) * nv);
+  memcpy(F[0], d->qacc, sizeof(double) * nv);
+  for (int i = 1; i < 4; i++) {
+    for (int k = 0; k < nv; k++) {
+      dv[k] = df[k] = 0;
+      for (int j = 0; j < i; j++) { dv[k] += A[(i - 1) * 3 + j] * Xv[j][k]; df[k] += A[(i - 1) * 3 + j] * F[j][k]; }
+    }
+    memcpy(d->qpos, X0q, sizeof(double) * nq);
+    integrate_pos(m, d->qpos, dv, h);
+    for (int k = 0; k < nv; k++) { Xv[i][k] = Xv[0][k] + h * df[k]; d->qvel[k] = Xv[i][k]; }
+    mzo_forward(m, d, ctrl);
+    memcpy(F[i], d->qacc, sizeof(double) * nv);
+  }
+  for (int k = 0; k < nv; k++) {
+    dv[k] = df[k] = 0;
+    for (int j = 0; j < 4; j++) { dv[k] += B[j] * Xv[j][k]; df[k] += B[j] * F[j][k]; }
+  }
+  memcpy(d->qpos, X0q, sizeof(double) * nq);
+  for (int k = 0; k < nv; k++) d->qvel[k] = Xv[0][k] + h * df[k];
+  integrate_pos(m, d->qpos, dv, h);
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv); /* last stage's qacc, as mj_advance */
+  d->time += h;
+}
+
+void mzo_data_init(const mz_model* m, mzo_data* d) {
+  memset(d, 0, sizeof(*d));
+  memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
+}
+
+/* kinetic + potential energy (for invariants tests) */
+double mzo_energy(const mz_model* m, mzo_data* d) {
+  kinematics(m, d);
+  com_and_crb(m, d);
+  double e = 0;
+  for (int i = 0; i < m->nv; i++)
+    for (int j = 0; j < m->nv; j++) e += 0.5 * d->qvel[i] * d->M[i][j] * d->qvel[j];
+  for (int b = 1; b < m->nbody; b++) e -= m->body_mass[b] * dot3(m->gravity, d->xipos[b]);
+  return e;
+}

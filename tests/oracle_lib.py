@@ -1,0 +1,122 @@
+"""ctypes access to the CPU oracle (oracle/libmzo.so) — TEST INFRASTRUCTURE ONLY.
+
+Nothing under mujoco_maze_amd/ imports this module; the product path never
+touches the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mujoco_maze_amd.model import MzModel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libmzo.so")
+
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.mzo_model_sizeof.restype = C.c_uint64
+        lib.mzo_data_sizeof.restype = C.c_uint64
+        assert lib.mzo_model_sizeof() == C.sizeof(MzModel), "mz_model layout mismatch (header vs ctypes mirror)"
+        lib.mzo_energy.restype = C.c_double
+        lib.mzo_rng_u32.restype = C.c_uint32
+        lib.mzo_rng_u32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        lib.mzo_detect.restype = C.c_int
+        lib.mzo_detect.argtypes = [C.POINTER(MzModel), f64p, f64p, f64p, f64p]
+        lib.mzo_task_eval.argtypes = [C.POINTER(MzModel), f64p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.mzo_batch_step.argtypes = [C.POINTER(MzModel), C.c_int, f64p, f64p, f64p, i32p, f64p, f64p, f64p, u8p, i32p,
+                                       f64p, i32p, C.c_int, C.c_double]
+        lib.mzo_batch_reset.argtypes = [C.POINTER(MzModel), C.c_int, C.c_void_p, C.c_uint64, f64p, f64p, f64p, i32p, f64p]
+        lib.mzo_batch_forward.argtypes = [C.POINTER(MzModel), C.c_int, f64p, f64p, f64p, C.c_void_p, f64p, i32p, f64p, f64p]
+
+    def forward_report(self, cm, qpos, qvel, ctrl=None, warm=None):
+        m = cm.c
+        rep, qacc = np.zeros(8), np.zeros(m.nv)
+        vp = lambda a: None if a is None else np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
+        qp, qv = np.ascontiguousarray(qpos, np.float64), np.ascontiguousarray(qvel, np.float64)
+        c, w = (None if ctrl is None else np.ascontiguousarray(ctrl, np.float64)), (None if warm is None else np.ascontiguousarray(warm, np.float64))
+        self.lib.mzo_forward_report(C.byref(m), vp(qp), vp(qv), vp(w), vp(c), vp(rep), vp(qacc))
+        keys = ["ncon", "nefc", "iters", "kkt", "fsum", "fmin", "comp", "status"]
+        return dict(zip(keys, rep)), qacc
+
+    def raw_steps(self, cm, qpos, qvel, ctrl, nsteps, energy=True):
+        m = cm.c
+        qp, qv = np.array(qpos, np.float64), np.array(qvel, np.float64)
+        en = np.zeros(nsteps)
+        c = None if ctrl is None else np.ascontiguousarray(ctrl, np.float64)
+        self.lib.mzo_raw_steps(C.byref(m), qp.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p),
+                               None if c is None else c.ctypes.data_as(C.c_void_p), nsteps, en.ctypes.data_as(C.c_void_p))
+        return qp, qv, en
+
+    # -- maze level
+    def detect(self, cm, old, new):
+        pt, rf = np.zeros(2), np.zeros(2)
+        hit = self.lib.mzo_detect(C.byref(cm.c), np.ascontiguousarray(old, np.float64), np.ascontiguousarray(new, np.float64), pt, rf)
+        return hit, pt, rf
+
+    def bounce(self, cm, old, new):
+        fin = np.zeros(2)
+        self.lib.mzo_bounce.argtypes = [C.POINTER(MzModel), f64p, f64p, f64p]
+        r = self.lib.mzo_bounce(C.byref(cm.c), np.ascontiguousarray(old, np.float64), np.ascontiguousarray(new, np.float64), fin)
+        return r, fin
+
+    def task_eval(self, cm, obs):
+        r, d, g = C.c_double(), C.c_int(), C.c_int()
+        self.lib.mzo_task_eval(C.byref(cm.c), np.ascontiguousarray(obs, np.float64), C.byref(r), C.byref(d), C.byref(g))
+        return r.value, bool(d.value), g.value
+
+    # -- batch
+    def reset(self, cm, n, seed, mask=None):
+        m = cm.c
+        st = dict(qpos=np.zeros((n, m.nq)), qvel=np.zeros((n, m.nv)), warm=np.zeros((n, m.nv)), t=np.zeros(n, np.int32))
+        obs = np.zeros((n, m.obs_dim))
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data_as(C.c_void_p)
+        self.lib.mzo_batch_reset(C.byref(m), n, mk, seed, st["qpos"], st["qvel"], st["warm"], st["t"], obs)
+        return st, obs
+
+    def step(self, cm, st, actions, nthreads=1, tol=0.0):
+        m = cm.c
+        n = st["qpos"].shape[0]
+        actions = np.ascontiguousarray(actions, np.float64)
+        out = dict(obs=np.zeros((n, m.obs_dim)), reward=np.zeros(n), done=np.zeros(n, np.uint8), goal_idx=np.zeros(n, np.int32),
+                   info=np.zeros((n, 4)), status=np.zeros(n, np.int32))
+        self.lib.mzo_batch_step(C.byref(m), n, st["qpos"], st["qvel"], st["warm"], st["t"], actions, out["obs"], out["reward"],
+                                out["done"], out["goal_idx"], out["info"], out["status"], nthreads, tol)
+        return out
+
+    def forward(self, cm, qpos, qvel, actions=None, warm=None):
+        m = cm.c
+        qpos = np.ascontiguousarray(np.atleast_2d(qpos), np.float64)
+        qvel = np.ascontiguousarray(np.atleast_2d(qvel), np.float64)
+        n = qpos.shape[0]
+        warm = np.zeros((n, m.nv)) if warm is None else np.ascontiguousarray(np.atleast_2d(warm), np.float64)
+        act = None
+        if actions is not None:
+            actions = np.ascontiguousarray(np.atleast_2d(actions), np.float64)
+            act = actions.ctypes.data_as(C.c_void_p)
+        out = dict(qacc=np.zeros((n, m.nv)), counts=np.zeros((n, 2), np.int32), M=np.zeros((n, m.nv, m.nv)), bias=np.zeros((n, m.nv)))
+        self.lib.mzo_batch_forward(C.byref(m), n, qpos, qvel, warm, act, out["qacc"], out["counts"], out["M"], out["bias"])
+        return out
+
+
+_cached = None
+
+
+def load() -> Oracle:
+    global _cached
+    if _cached is None:
+        if not os.path.exists(LIB):
+            build()
+        _cached = Oracle(C.CDLL(LIB))
+    return _cached

@@ -1,0 +1,168 @@
+"""Host mirror + CPU oracle against golden vectors captured from the reference's
+own pure-Python modules (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import mujoco_maze_amd as mm
+from mujoco_maze_amd import maze_env_utils as U
+from mujoco_maze_amd import maze_task as T
+from mujoco_maze_amd import model
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+REG = json.load(open(os.path.join(G, "registry.json")))
+SEG = json.load(open(os.path.join(G, "segments.json")))
+WORLDS = json.load(open(os.path.join(G, "worlds.json")))
+KAT = json.load(open(os.path.join(G, "line_kat.json")))
+DET = np.load(os.path.join(G, "detect.npz"))
+REW = np.load(os.path.join(G, "reward.npz"))
+REW_META = json.load(open(os.path.join(G, "reward_meta.json")))
+
+_CODE = {v: k for k, v in T._CELL.items()}
+
+
+def _grid_text(structure):
+    return "/".join("".join(_CODE[c] for c in row) for row in structure)
+
+
+def test_registry_ids_match_reference():
+    assert set(mm.REGISTRY) == set(REG) and len(REG) == 145
+
+
+@pytest.mark.parametrize("env_id", sorted(REG))
+def test_registry_entry(env_id):
+    ref, spec = REG[env_id], mm.REGISTRY[env_id]
+    cls = spec.kwargs["maze_task"]
+    assert cls.__name__ == ref["task"]
+    assert spec.kwargs["model_cls"].__name__ == ref["robot"]
+    assert spec.kwargs["maze_size_scaling"] == ref["scale"]
+    assert spec.kwargs["inner_reward_scaling"] == ref["inner_reward_scaling"]
+    assert spec.max_episode_steps == ref["max_episode_steps"] and spec.reward_threshold == ref["reward_threshold"]
+    assert _grid_text(cls.create_maze()) == ref["grid"]
+    task = cls(ref["scale"])
+    assert len(task.goals) == len(ref["goals"])
+    for g, rg in zip(task.goals, ref["goals"]):
+        assert g.pos.tolist() == rg["pos"] and g.reward_scale == rg["reward_scale"]
+        assert g.threshold == rg["threshold"] and g.custom_size == rg["custom_size"]
+    assert cls.PENALTY == ref["penalty"]
+    assert cls.OBSERVE_BLOCKS == ref["observe_blocks"] and cls.OBSERVE_BALLS == ref["observe_balls"]
+    assert cls.OBJECT_BALL_SIZE == ref["object_ball_size"]
+    # which implementation reward()/termination() resolve to
+    own_term = "GoalRewardBilliard" in ref["termination_impl"] or "GoalRewardBlockCarry" in ref["termination_impl"]
+    desc = T.device_reward_descriptor(task)
+    assert desc is not None
+    assert (desc[3] == T.SLOT_OBJECT) == own_term
+
+
+def test_line_known_answers():
+    for c in KAT["distance"]:
+        assert U.Line(c["l1"], c["l2"]).distance(complex(*c["p"])) == c["ans"]
+        assert abs(c["ans"] - (2.0 ** 0.5 if c["p"] == [1.0, 3.0] else 2.4)) <= 1e-8  # reference tests/test_intersect.py:7-17
+    for c in KAT["intersect"]:
+        r = U.Line(c["l1p1"], c["l1p2"]).intersect(U.Line(c["l2p1"], c["l2p2"]))
+        if c["ans"] is None:
+            assert r is None
+        else:
+            assert [r.real, r.imag] == c["ans"]
+    for c in KAT["reflection"]:
+        r = U.Line(c["l1"], c["l2"]).reflection(complex(*c["p"]))
+        assert [r.real, r.imag] == c["ans"]
+
+
+def _point_model(env_id):
+    spec = mm.REGISTRY[env_id]
+    task = spec.kwargs["maze_task"](spec.kwargs["maze_size_scaling"])
+    return task, spec.kwargs["maze_size_scaling"]
+
+
+@pytest.mark.parametrize("env_id", sorted(SEG))
+def test_wall_segments(env_id):
+    task, scale = _point_model(env_id)
+    w = model.MazeWorld(task.create_maze(), scale)
+    det = U.CollisionDetector(task.create_maze(), scale, w.torso_x, w.torso_y, 0.4)
+    assert det.segments.tolist() == SEG[env_id]["robot"]
+    ball = U.CollisionDetector(task.create_maze(), scale, w.torso_x, w.torso_y, task.OBJECT_BALL_SIZE)
+    assert ball.segments.tolist() == SEG[env_id]["ball"]
+
+
+@pytest.mark.parametrize("env_id", ["PointUMaze-v0", "Point4Rooms-v0", "PointCorridor-v0", "PointTRoom-v0"])
+def test_detect_and_bounce(env_id, oracle):
+    tag = env_id.replace("-", "_")
+    old, new = DET[f"{tag}__old"], DET[f"{tag}__new"]
+    hit, point, refl = DET[f"{tag}__hit"], DET[f"{tag}__point"], DET[f"{tag}__refl"]
+    final, gave_up, valid = DET[f"{tag}__final"], DET[f"{tag}__gave_up"], DET[f"{tag}__valid"]
+    task, scale = _point_model(env_id)
+    cm = model.compile_model("point", task, scale)
+    w = cm.world
+    det = U.CollisionDetector(task.create_maze(), scale, w.torso_x, w.torso_y, 0.4)
+    assert hit.sum() > 200 and gave_up.sum() > 5  # the fixture exercises both branches
+    for k in range(len(old)):
+        if not valid[k]:
+            continue
+        # host mirror, bit-exact
+        col = det.detect(old[k], new[k]) if k % 7 == 0 else None
+        if k % 7 == 0:
+            assert (col is not None) == bool(hit[k])
+            if col is not None:
+                assert np.array_equal(col.point, point[k]) and np.array_equal(col.point + col.rest(), refl[k])
+        # oracle, bit-exact
+        h, pt, rf = oracle.detect(cm, old[k], new[k])
+        assert h == hit[k]
+        if h:
+            assert np.array_equal(pt, point[k]) and np.array_equal(pt + (rf - pt), refl[k])  # golden stores point + rest()
+        r, fin = oracle.bounce(cm, old[k], new[k])
+        assert np.array_equal(fin, final[k])
+        assert (r == 2) == bool(gave_up[k]) or (r == 2 and np.array_equal(final[k], old[k]))
+
+
+def test_reward_termination_all_tasks(oracle):
+    checked = 0
+    for tag, meta in REW_META.items():
+        cls = getattr(T, meta["task"])
+        scale = meta["scale"]
+        task = cls(scale)
+        obs, rew, term = REW[f"{tag}__obs"], REW[f"{tag}__reward"], REW[f"{tag}__term"]
+        mine_r = np.array([task.reward(o) for o in obs])
+        mine_t = np.array([task.termination(o) for o in obs], dtype=np.uint8)
+        assert np.array_equal(mine_r, rew), tag
+        assert np.array_equal(mine_t, term), tag
+        # oracle on the device descriptor (only mazes the device path supports are compilable)
+        try:
+            robot = "ant" if cls.MAZE_SIZE_SCALING.ant == scale else "point"
+            cm = model.compile_model(robot, task, scale)
+        except NotImplementedError:
+            continue
+        for o, r, t in zip(obs[::5], rew[::5], term[::5]):
+            orr, ot, _ = oracle.task_eval(cm, o)
+            assert orr == r and ot == bool(t), tag
+        checked += 1
+    assert checked >= 20
+
+
+@pytest.mark.parametrize("env_id,robot", [("PointUMaze-v0", "point"), ("AntUMaze-v0", "ant"), ("Ant4Rooms-v0", "ant"),
+                                          ("Point4Rooms-v0", "point")])
+def test_world_geometry(env_id, robot):
+    ref = WORLDS[env_id]
+    spec = mm.REGISTRY[env_id]
+    scale = spec.kwargs["maze_size_scaling"]
+    cm = model.compile_model(robot, spec.kwargs["maze_task"](scale), scale)
+    assert [list(b) for b in cm.world.wall_boxes()] == [b["pos"] + b["size"] for b in ref["boxes"]]
+    assert list(cm.world.xy_limits()) == ref["xy_limits"]
+    assert cm.c.obs_dim == ref["obs_dim"]
+    assert [cm.world.torso_x, cm.world.torso_y] == ref["init_torso"]
+    solimp = [float(v) for v in ref["default_geom_solimp"].split()] if ref["default_geom_solimp"] else None
+    if solimp:
+        assert list(cm.c.wall_solimp[:3]) == solimp
+    # goal site positions (maze_env.py:199-213) are the task goals
+    for g, s in zip(cm.task.goals, ref["sites"]):
+        assert g.pos.tolist() == s["pos"][: g.dim]
+
+
+@pytest.mark.parametrize("env_id", ["AntPush-v0", "AntFall-v0", "PointBilliard-v0"])
+def test_unsupported_mazes_fail_loudly(env_id):
+    spec = mm.REGISTRY[env_id]
+    scale = spec.kwargs["maze_size_scaling"]
+    with pytest.raises(NotImplementedError):
+        model.compile_model(spec.kwargs["model_cls"].ROBOT, spec.kwargs["maze_task"](scale), scale)
