@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched MazeEnv.step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one MazeEnv.step for every env of the batch (Ant: 5 MuJoCo frames x RK4
+= 20 forward-dynamics evaluations per env).  Workload: AntUMaze-v0, 4096 envs per GPU
+(BASELINE configs[2], the configuration the metric is quoted on), synthetic inputs:
+state from the reference's reset distribution, i.i.d. uniform actions in the action
+box, auto-reset on termination / 1000-step truncation.  For N > 1 each rank owns its
+own 4096 envs (weak scaling) and the only collective is the RCCL all-gather of the
+packed [N_local, 32] record (obs | reward | done) that north_star names.
+
+Prints ONE JSON line (rank 0) with the fields the driver expects plus
+  roofline     : algorithmic HBM bytes per launch / average kernel duration (HIP events on
+                 the launch stream, recorded inside the timed region)
+  cpu_baseline : the CPU oracle (a restatement — MuJoCo itself is not available) timed on
+                 this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+ENV_ID = "AntUMaze-v0"
+ALGO_BYTES_PER_ENV_STEP = 509  # 208 B read + 301 B written (fp32 state, action, obs, reward, done)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(model, seconds_target=12.0):
+    """Oracle (oracle/libmzo.so, kind 'port') on the host cores, OpenMP over envs."""
+    import numpy as np
+
+    from tests import oracle_lib
+
+    oracle = oracle_lib.load()
+    cores = os.cpu_count() or 1
+    n = ENVS_PER_GPU
+    st, _ = oracle.reset(model, n, 20260928)
+    rng = np.random.default_rng(0)
+    act = rng.uniform(-30, 30, (n, 8))
+    oracle.step(model, st, act, nthreads=cores)  # warm-up (page-in, first contacts)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        oracle.step(model, st, rng.uniform(-30, 30, (n, 8)), nthreads=cores)
+        steps += 1
+        if time.perf_counter() - t0 > seconds_target or steps >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{ENV_ID}, {n} envs x {steps} batch-steps ({dt:.1f} s), float64 CPU oracle (restatement, not mujoco-py), OpenMP over envs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per env (8/16/32/64); 0 = library default")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL obs all-gather for N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import mujoco_maze_amd as mm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    n = args.envs
+    env = mm.make(ENV_ID, num_envs=n, auto_reset=True, device=dev, force_vec=True)
+    if args.lanes:
+        env.set_option("lanes_per_env", args.lanes)
+    env.reset(seed=20260928 + rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pool = [(torch.rand((n, 8), device=dev, generator=g) * 60.0 - 30.0) for _ in range(32)]  # U(-30, 30)^8
+    packed = torch.empty((n, 32), dtype=torch.float32, device=dev)
+    gathered = torch.empty((n * world, 32), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def one_step(i):
+        obs, rew, done, _ = env.step(pool[i % len(pool)])
+        if world > 1 and not args.no_gather:
+            packed[:, :30] = obs
+            packed[:, 30] = rew
+            packed[:, 31] = done.float()
+            dist.all_gather_into_tensor(gathered, packed)
+
+    for i in range(args.warmup):
+        one_step(i)
+    env.set_option("time_kernels", args.steps)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    kernel_ms = env.kernel_ms()
+    status = env.status()
+    bad = int(((status & 3) != 0).sum().item())
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        total_env_steps = n * world * args.steps
+        value = total_env_steps / dt
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP * n
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+        out = {
+            "metric": "env-steps/sec (whole node), AntUMaze-v0, 4096 envs/GPU",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{ENV_ID}, {n} envs/GPU, frame_skip 5 x RK4, random actions U(-30,30)^8, auto-reset",
+                       "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
+                       "lanes_per_env": args.lanes or 16, "bad_envs": bad},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": "ant_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(env.model)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

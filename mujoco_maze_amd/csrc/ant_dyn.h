@@ -1,0 +1,904 @@
+// ant_dyn.h — Ant rigid-body forward dynamics + constraint solve + RK4, written
+// as *lane-group SPMD* code: one environment is advanced by a group of G
+// adjacent lanes of a wavefront; every cross-lane hand-off goes through the
+// env's LDS scratch block followed by cx.sync().
+//
+// What it replaces in the reference: the MuJoCo `mj_step` calls issued by
+// `AntEnv.step` (mujoco_maze/ant.py:61-73, `do_simulation(action, 5)`), plus the
+// surrounding `MazeEnv.step` bookkeeping (maze_env.py:448-481).  Pipeline per
+// forward evaluation (20 per env.step: 5 frames x RK4), SURVEY §8a M1-M9:
+//   K  kinematics of the 13 bodies in a torso-centred frame (fp32-safe far from the origin)
+//   I  spatial inertias, composite-rigid-body mass matrix in *arrow* form
+//      (6x6 root block + four 2x2 leg blocks + 6x2 couplings; legs never couple)
+//   V  velocities and bias forces (recursive Newton-Euler, gravity included)
+//   C  collision: floor plane vs sphere/capsule ends; maze wall boxes found through
+//      the cell grid (only the <= 2x2 cells under a geom's bounding square)
+//   J  contact Jacobians (3 x 8 sparse: root + own leg), joint-limit rows
+//   N  primal Newton solver on the pyramidal-cone soft-constraint cost; the Hessian
+//      keeps the arrow sparsity (a contact touches root + one leg), so each
+//      iteration factors four 2x2 blocks and one 6x6 Schur complement
+//   R  RK4 stage bookkeeping with manifold quaternion update
+//
+// Execution contexts (template parameter C):
+//   * device: csrc/mazestep.hip — G lanes per env, cx.sync() = __syncthreads() of a
+//     one-wavefront workgroup, cx.gsum() = DPP/shuffle butterfly inside the group;
+//   * host emulation (tests/emu, CPU tests of the kernel logic only — never a
+//     product path): nlanes = 1, so every MZ_FOR runs all its items in order.
+// Rule that makes both valid: inside one phase (between two cx.sync()) the
+// iterations of an MZ_FOR are independent, and nothing but LDS scratch carries
+// values from one phase to the next.
+#pragma once
+#include "ant_model.h"
+
+#if defined(__HIPCC__)
+#define MZ_HD __host__ __device__ __forceinline__
+#else
+#define MZ_HD inline
+#endif
+
+#define MZ_FOR(i, n) for (int i = cx.lane0(); i < (n); i += C::nlanes)
+
+struct HostCtx {
+  static constexpr int nlanes = 1;
+  MZ_HD int lane0() const { return 0; }
+  MZ_HD void sync() const {}
+  MZ_HD float gsum(float x) const { return x; }
+  MZ_HD bool any(bool p) const { return p; }
+};
+
+// ------------------------------------------------------------------ scratch (LDS) per env
+struct Arrow {       // symmetric matrix with the ant's sparsity
+  float rr[6][6];    // root block (full storage)
+  float rl[4][2][6]; // leg l, dof (0 hip, 1 ankle) x root
+  float ll[4][3];    // leg l: hh, ha, aa
+};
+struct ArrowFactor {
+  float inv[4][3];   // inverse of the 2x2 leg blocks
+  float T[4][2][6];  // inv * rl
+  float L[6][6];     // Cholesky factor of the Schur complement (lower)
+};
+
+struct AntScratch {
+  // step-persistent
+  float qpos[16], qvel[14], x0q[16], x0v[14], accv[14], accf[14], warm[14], fact[14];
+  float qacc[14], qas[14], qfs[14];
+  // kinematics (positions relative to the torso origin c)
+  float R0[9], cz;               // torso rotation (row-major), torso height
+  float p1[4][3], p2[4][3];      // aux / ankle body origins
+  float w[12][3], com[12][3];    // capsule axis and centre of body 1 + 3l + k
+  float zw[3];                   // hip axis (world) = R0 * ez
+  float Sh[4][3], Sa[4][6];      // hip: linear part (angular = zw); ankle: angular, linear
+  float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
+  float fleg[4][6], ftor[6], bias[14];
+  Arrow M, H;
+  ArrowFactor F;
+  float grad[14], search[14], Mx[14], Ms[14];
+  // contacts
+  int ncon, cnt[13], off[13];
+  int cleg[ANT_NC];              // leg of the contact's body (-1 torso), bit 8.. = class
+  float cJ[ANT_NC][3][8];        // [normal, mu*t1, mu*t2] x [root 6, hip, ankle]
+  float caref[ANT_NC][3], cD[ANT_NC], cu[ANT_NC][3], cjv[ANT_NC][3], cg[ANT_NC][3], cW[ANT_NC][5];
+  // joint limits (8 hinges)
+  float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
+  float red[4];
+  int status, iters;
+};
+
+// ------------------------------------------------------------------ small helpers
+MZ_HD float dot3f(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+MZ_HD void cross3f(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MZ_HD void inertia_mulf(float* r, const float* I, const float* v) {  // spatial inertia (compact) times motion vector
+  const float* h = I + 1;
+  const float* J = I + 4;
+  float a[3], b[3];
+  cross3f(a, h, v + 3);
+  cross3f(b, v, h);
+  r[0] = J[0] * v[0] + J[3] * v[1] + J[4] * v[2] + a[0];
+  r[1] = J[3] * v[0] + J[1] * v[1] + J[5] * v[2] + a[1];
+  r[2] = J[4] * v[0] + J[5] * v[1] + J[2] * v[2] + a[2];
+  r[3] = I[0] * v[3] + b[0]; r[4] = I[0] * v[4] + b[1]; r[5] = I[0] * v[5] + b[2];
+}
+MZ_HD void motion_crossf(float* r, const float* v, const float* s) {
+  float a[3], b[3], c[3];
+  cross3f(a, v, s); cross3f(b, v, s + 3); cross3f(c, v + 3, s);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+MZ_HD void force_crossf(float* r, const float* v, const float* f) {
+  float a[3], b[3], c[3];
+  cross3f(a, v, f); cross3f(b, v + 3, f + 3); cross3f(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+MZ_HD float dot6f(const float* a, const float* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+MZ_HD void quat_to_matf(float* m, const float* qin) {
+  float n = 1.0f / sqrtf(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+  float w = qin[0] * n, x = qin[1] * n, y = qin[2] * n, z = qin[3] * n;
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+MZ_HD void mat_vecf(float* r, const float* m, const float* v) {
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+        z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MZ_HD float impedancef(const float* si, float x) {
+  float d0 = si[0], dmax = si[1], width = si[2], mid = si[3], power = si[4];
+  if (d0 == dmax || width <= 1e-15f) return 0.5f * (d0 + dmax);
+  float xn = x / width;
+  if (xn >= 1.0f) return dmax;
+  if (xn <= 0.0f) return d0;
+  float y;
+  if (power <= 1.0f) y = xn;
+  else if (xn <= mid) y = powf(xn, power) / powf(mid, power - 1.0f);
+  else y = 1.0f - powf(1.0f - xn, power) / powf(1.0f - mid, power - 1.0f);
+  return d0 + y * (dmax - d0);
+}
+
+// body index b in 0..12: 0 torso, else leg l = (b-1)/3, level k = (b-1)%3 (0 welded leg, 1 aux, 2 ankle)
+MZ_HD int body_class(int b) { return b == 0 ? 0 : 1 + (b - 1) % 3; }
+
+// ------------------------------------------------------------------ K + I: kinematics, inertias, mass matrix
+template <class C>
+MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratch& s) {
+  MZ_FOR(l, 4) {
+    float R0[9];
+    quat_to_matf(R0, s.qpos + 3);
+    if (l == 0) {
+      for (int k = 0; k < 9; k++) s.R0[k] = R0[k];
+      s.zw[0] = R0[2]; s.zw[1] = R0[5]; s.zw[2] = R0[8];
+      s.cz = s.qpos[2];
+    }
+    const float isq2 = 0.70710678118654752f;
+    float sx = K.sx[l], sy = K.sy[l];
+    float u[3] = {sx * isq2, sy * isq2, 0.f}, off[3] = {sx * K.legoff, sy * K.legoff, 0.f};
+    float qh = s.qpos[7 + 2 * l], qa = s.qpos[8 + 2 * l];
+    float ch = cosf(qh), sh = sinf(qh), ca = cosf(qa), sa = sinf(qa);
+    float t[3], v[3];
+    // level 0: welded leg capsule, frame = torso frame
+    mat_vecf(s.w[3 * l], R0, u);
+    for (int k = 0; k < 3; k++) s.com[3 * l][k] = s.w[3 * l][k] * K.half_len[1];
+    // level 1: aux body at R0*off, rotated about the body z axis by the hip angle
+    mat_vecf(s.p1[l], R0, off);
+    t[0] = ch * u[0] - sh * u[1]; t[1] = sh * u[0] + ch * u[1]; t[2] = 0.f;  // Rz(qh) u
+    mat_vecf(s.w[3 * l + 1], R0, t);
+    for (int k = 0; k < 3; k++) s.com[3 * l + 1][k] = s.p1[l][k] + s.w[3 * l + 1][k] * K.half_len[2];
+    float zw[3] = {R0[2], R0[5], R0[8]};
+    cross3f(s.Sh[l], s.p1[l], zw);  // linear velocity at c of a unit hip rotation: zw x (c - p1)
+    // level 2: ankle body at p1 + R1*off, rotated about the local ankle axis
+    t[0] = ch * off[0] - sh * off[1]; t[1] = sh * off[0] + ch * off[1]; t[2] = 0.f;
+    mat_vecf(v, R0, t);
+    for (int k = 0; k < 3; k++) s.p2[l][k] = s.p1[l][k] + v[k];
+    const float* a = K.ank_axis[l];
+    float au = a[0] * u[0] + a[1] * u[1], axu[3];
+    cross3f(axu, a, u);
+    float ul[3];  // Rot(a, qa) u  (Rodrigues)
+    for (int k = 0; k < 3; k++) ul[k] = u[k] * ca + axu[k] * sa + a[k] * au * (1.f - ca);
+    t[0] = ch * ul[0] - sh * ul[1]; t[1] = sh * ul[0] + ch * ul[1]; t[2] = ul[2];
+    mat_vecf(s.w[3 * l + 2], R0, t);
+    for (int k = 0; k < 3; k++) s.com[3 * l + 2][k] = s.p2[l][k] + s.w[3 * l + 2][k] * K.half_len[3];
+    t[0] = ch * a[0] - sh * a[1]; t[1] = sh * a[0] + ch * a[1]; t[2] = a[2];
+    mat_vecf(s.Sa[l], R0, t);               // ankle axis (world)
+    cross3f(s.Sa[l] + 3, s.p2[l], s.Sa[l]); // aw x (c - p2)
+  }
+  cx.sync();
+  // spatial inertia of every body about c
+  MZ_FOR(b, ANT_NBODY) {
+    int c = body_class(b);
+    float m = K.mass[c], lat = K.ilat[c], dax = K.iax[c] - K.ilat[c];
+    float r[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+    if (b > 0) { for (int k = 0; k < 3; k++) { r[k] = s.com[b - 1][k]; w[k] = s.w[b - 1][k]; } }
+    float rr = dot3f(r, r);
+    float* I = s.cin[b];
+    I[0] = m; I[1] = m * r[0]; I[2] = m * r[1]; I[3] = m * r[2];
+    I[4] = lat + dax * w[0] * w[0] + m * (rr - r[0] * r[0]);
+    I[5] = lat + dax * w[1] * w[1] + m * (rr - r[1] * r[1]);
+    I[6] = lat + dax * w[2] * w[2] + m * (rr - r[2] * r[2]);
+    I[7] = dax * w[0] * w[1] - m * r[0] * r[1];
+    I[8] = dax * w[0] * w[2] - m * r[0] * r[2];
+    I[9] = dax * w[1] * w[2] - m * r[1] * r[2];
+  }
+  cx.sync();
+  // composite-rigid-body mass matrix, arrow storage
+  MZ_FOR(l, 4) {
+    float Ia[10], Ih[10], Sh[6], Fa[6], Fh[6];
+    for (int k = 0; k < 10; k++) { Ia[k] = s.cin[3 + 3 * l][k]; Ih[k] = Ia[k] + s.cin[2 + 3 * l][k]; }
+    for (int k = 0; k < 3; k++) { Sh[k] = s.zw[k]; Sh[3 + k] = s.Sh[l][k]; }
+    inertia_mulf(Fa, Ia, s.Sa[l]);
+    inertia_mulf(Fh, Ih, Sh);
+    s.M.ll[l][0] = dot6f(Sh, Fh) + K.armature;
+    s.M.ll[l][1] = dot6f(Sh, Fa);
+    s.M.ll[l][2] = dot6f(s.Sa[l], Fa) + K.armature;
+    for (int k = 0; k < 3; k++) {
+      s.M.rl[l][0][k] = Fh[3 + k];  // root linear dof k: S = [0; e_k]
+      s.M.rl[l][1][k] = Fa[3 + k];
+      float ax[3] = {s.R0[k], s.R0[3 + k], s.R0[6 + k]};  // root angular dof k: S = [R0[:,k]; 0]
+      s.M.rl[l][0][3 + k] = dot3f(ax, Fh);
+      s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
+    }
+  }
+  MZ_FOR(e, 21) {  // root 6x6 block from the whole-body composite inertia (lower triangle, mirrored)
+    int i = 0, j = e;
+    while (j > i) { j -= i + 1; i++; }  // e -> (i, j), j <= i
+    float m = 0, h[3] = {0, 0, 0}, J[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < ANT_NBODY; b++) {
+      m += s.cin[b][0];
+      for (int k = 0; k < 3; k++) h[k] += s.cin[b][1 + k];
+      for (int k = 0; k < 6; k++) J[k] += s.cin[b][4 + k];
+    }
+    float val;
+    if (i < 3) val = (i == j) ? m : 0.f;
+    else {
+      float ai[3] = {s.R0[i - 3], s.R0[3 + i - 3], s.R0[6 + i - 3]};
+      if (j < 3) {  // angular i with linear j: ai . (h x e_j)
+        float ej[3] = {j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f}, hx[3];
+        cross3f(hx, h, ej);
+        val = dot3f(ai, hx);
+      } else {
+        float aj[3] = {s.R0[j - 3], s.R0[3 + j - 3], s.R0[6 + j - 3]}, Jv[3];
+        Jv[0] = J[0] * aj[0] + J[3] * aj[1] + J[4] * aj[2];
+        Jv[1] = J[3] * aj[0] + J[1] * aj[1] + J[5] * aj[2];
+        Jv[2] = J[4] * aj[0] + J[5] * aj[1] + J[2] * aj[2];
+        val = dot3f(ai, Jv);
+      }
+    }
+    s.M.rr[i][j] = val; s.M.rr[j][i] = val;
+  }
+  cx.sync();
+}
+
+// ------------------------------------------------------------------ V: velocities, bias forces, smooth forces
+template <class C>
+MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratch& s) {
+  MZ_FOR(l, 5) {
+    float v0[6], a0[6], ww[3];
+    mat_vecf(ww, s.R0, s.qvel + 3);  // world angular velocity (root angular dofs are body-frame)
+    for (int k = 0; k < 3; k++) { v0[k] = ww[k]; v0[3 + k] = s.qvel[k]; a0[k] = 0.f; }
+    cross3f(a0 + 3, s.qvel, ww);  // sum_k Sdot_k * qvel_k of the root rotation = [0; pdot x w]
+    a0[5] -= K.gz;                // gravity as base acceleration
+    if (l == 4) {                 // torso
+      float Ia[6], Iv[6], vf[6];
+      inertia_mulf(Ia, s.cin[0], a0);
+      inertia_mulf(Iv, s.cin[0], v0);
+      force_crossf(vf, v0, Iv);
+      for (int k = 0; k < 6; k++) s.ftor[k] = Ia[k] + vf[k];
+    } else {
+      float Sh[6], sd[6], v1[6], a1[6], v2[6], a2[6], f[6], ft[6], Ia[6], Iv[6], vf[6];
+      float qdh = s.qvel[6 + 2 * l], qda = s.qvel[7 + 2 * l];
+      for (int k = 0; k < 3; k++) { Sh[k] = s.zw[k]; Sh[3 + k] = s.Sh[l][k]; }
+      // welded leg body moves with the torso
+      inertia_mulf(Ia, s.cin[1 + 3 * l], a0); inertia_mulf(Iv, s.cin[1 + 3 * l], v0); force_crossf(vf, v0, Iv);
+      for (int k = 0; k < 6; k++) ft[k] = Ia[k] + vf[k];
+      // aux body
+      motion_crossf(sd, v0, Sh);
+      for (int k = 0; k < 6; k++) { a1[k] = a0[k] + sd[k] * qdh; v1[k] = v0[k] + Sh[k] * qdh; }
+      inertia_mulf(Ia, s.cin[2 + 3 * l], a1); inertia_mulf(Iv, s.cin[2 + 3 * l], v1); force_crossf(vf, v1, Iv);
+      for (int k = 0; k < 6; k++) f[k] = Ia[k] + vf[k];
+      // ankle body
+      motion_crossf(sd, v1, s.Sa[l]);
+      for (int k = 0; k < 6; k++) { a2[k] = a1[k] + sd[k] * qda; v2[k] = v1[k] + s.Sa[l][k] * qda; }
+      inertia_mulf(Ia, s.cin[3 + 3 * l], a2); inertia_mulf(Iv, s.cin[3 + 3 * l], v2); force_crossf(vf, v2, Iv);
+      float fa[6];
+      for (int k = 0; k < 6; k++) { fa[k] = Ia[k] + vf[k]; f[k] += fa[k]; ft[k] += f[k]; }
+      s.bias[7 + 2 * l] = dot6f(s.Sa[l], fa);
+      s.bias[6 + 2 * l] = dot6f(Sh, f);
+      for (int k = 0; k < 6; k++) s.fleg[l][k] = ft[k];
+    }
+  }
+  cx.sync();
+  MZ_FOR(i, ANT_NV) {
+    float frc;
+    if (i < 6) {
+      float tot[3];
+      int o = i < 3 ? 3 : 0;  // linear dofs pick the force part, angular dofs the torque part
+      for (int k = 0; k < 3; k++) tot[k] = s.ftor[o + k] + s.fleg[0][o + k] + s.fleg[1][o + k] + s.fleg[2][o + k] + s.fleg[3][o + k];
+      float b;
+      if (i < 3) b = tot[i];
+      else { float ax[3] = {s.R0[i - 3], s.R0[3 + i - 3], s.R0[6 + i - 3]}; b = dot3f(ax, tot); }
+      s.bias[i] = b;
+      frc = -b;
+    } else {
+      frc = -K.damping * s.qvel[i] - s.bias[i] + s.fact[i];
+    }
+    s.qfs[i] = frc;
+  }
+  cx.sync();
+}
+
+// ------------------------------------------------------------------ arrow linear algebra
+template <class C>
+MZ_HD void arrow_factor(const C& cx, const Arrow& A, ArrowFactor& F) {
+  MZ_FOR(l, 4) {
+    float hh = A.ll[l][0], ha = A.ll[l][1], aa = A.ll[l][2];
+    float idet = 1.0f / (hh * aa - ha * ha);
+    float ihh = aa * idet, iha = -ha * idet, iaa = hh * idet;
+    F.inv[l][0] = ihh; F.inv[l][1] = iha; F.inv[l][2] = iaa;
+    for (int k = 0; k < 6; k++) {
+      F.T[l][0][k] = ihh * A.rl[l][0][k] + iha * A.rl[l][1][k];
+      F.T[l][1][k] = iha * A.rl[l][0][k] + iaa * A.rl[l][1][k];
+    }
+  }
+  cx.sync();
+  MZ_FOR(e, 21) {
+    int i = 0, j = e;
+    while (j > i) { j -= i + 1; i++; }
+    float v = A.rr[i][j];
+    for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
+    F.L[i][j] = v;
+  }
+  cx.sync();
+  MZ_FOR(one, 1) {  // 6x6 Cholesky, in place on the lower triangle
+    for (int j = 0; j < 6; j++) {
+      float d = F.L[j][j];
+      for (int k = 0; k < j; k++) d -= F.L[j][k] * F.L[j][k];
+      d = sqrtf(fmaxf(d, 1e-30f));
+      F.L[j][j] = d;
+      float id = 1.0f / d;
+      for (int i = j + 1; i < 6; i++) {
+        float t = F.L[i][j];
+        for (int k = 0; k < j; k++) t -= F.L[i][k] * F.L[j][k];
+        F.L[i][j] = t * id;
+      }
+    }
+  }
+  cx.sync();
+}
+// x = A^-1 g  (x and g may alias).  tmp: 6 floats of scratch for the root right-hand side.
+template <class C>
+MZ_HD void arrow_solve(const C& cx, const Arrow& A, const ArrowFactor& F, const float* g, float* x, float* tmp, float sign) {
+  (void)A;
+  MZ_FOR(k, 6) {
+    float r = g[k];
+    for (int l = 0; l < 4; l++) r -= F.T[l][0][k] * g[6 + 2 * l] + F.T[l][1][k] * g[7 + 2 * l];
+    tmp[k] = r;
+  }
+  cx.sync();
+  MZ_FOR(one, 1) {
+    float y[6];
+    for (int i = 0; i < 6; i++) { float t = tmp[i]; for (int k = 0; k < i; k++) t -= F.L[i][k] * y[k]; y[i] = t / F.L[i][i]; }
+    for (int i = 5; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < 6; k++) t -= F.L[k][i] * y[k]; y[i] = t / F.L[i][i]; }
+    for (int i = 0; i < 6; i++) tmp[i] = y[i];
+  }
+  cx.sync();
+  MZ_FOR(i, ANT_NV) {
+    float v;
+    if (i < 6) v = tmp[i];
+    else {
+      int l = (i - 6) >> 1, d = (i - 6) & 1;
+      float gh = g[6 + 2 * l], ga = g[7 + 2 * l];
+      v = d == 0 ? F.inv[l][0] * gh + F.inv[l][1] * ga : F.inv[l][1] * gh + F.inv[l][2] * ga;
+      for (int k = 0; k < 6; k++) v -= F.T[l][d][k] * tmp[k];
+    }
+    x[i] = sign * v;
+  }
+  cx.sync();
+}
+// y_i = (A x)_i for one dof (called inside an MZ_FOR over dofs)
+MZ_HD float arrow_row_mul(const Arrow& A, const float* x, int i) {
+  float v = 0.f;
+  if (i < 6) {
+    for (int k = 0; k < 6; k++) v += A.rr[i][k] * x[k];
+    for (int l = 0; l < 4; l++) v += A.rl[l][0][i] * x[6 + 2 * l] + A.rl[l][1][i] * x[7 + 2 * l];
+  } else {
+    int l = (i - 6) >> 1, d = (i - 6) & 1;
+    for (int k = 0; k < 6; k++) v += A.rl[l][d][k] * x[k];
+    v += d == 0 ? A.ll[l][0] * x[6 + 2 * l] + A.ll[l][1] * x[7 + 2 * l] : A.ll[l][1] * x[6 + 2 * l] + A.ll[l][2] * x[7 + 2 * l];
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------ C + J: collision and constraint rows
+struct ContactGeo { float dist, pos[3], n[3], hint[3]; int wall; };
+
+MZ_HD void make_tangents(const float* n, const float* hint, float* t1, float* t2) {
+  float y[3] = {hint[0], hint[1], hint[2]};
+  if (dot3f(y, y) < 0.25f) { y[0] = 0.f; y[1] = (n[1] < 0.5f && n[1] > -0.5f) ? 1.f : 0.f; y[2] = 1.f - y[1]; }
+  float d = dot3f(n, y);
+  for (int k = 0; k < 3; k++) y[k] -= n[k] * d;
+  float nn = sqrtf(dot3f(y, y));
+  if (nn < 1e-10f) {
+    y[0] = 0.f; y[1] = (n[1] < 0.5f && n[1] > -0.5f) ? 1.f : 0.f; y[2] = 1.f - y[1];
+    d = dot3f(n, y);
+    for (int k = 0; k < 3; k++) y[k] -= n[k] * d;
+    nn = sqrtf(dot3f(y, y));
+  }
+  for (int k = 0; k < 3; k++) t1[k] = y[k] / nn;
+  cross3f(t2, n, t1);
+}
+
+// sphere (centre c in box-centred coordinates, radius r) vs axis-aligned box of half sizes bs.
+// Normal points from the sphere to the box.  Returns true when dist <= margin.
+MZ_HD bool sphere_aabb(const float* c, float r, const float* bs, float margin, float* dist, float* pos, float* n) {
+  float q[3];
+  bool inside = true;
+  for (int k = 0; k < 3; k++) {
+    q[k] = fminf(fmaxf(c[k], -bs[k]), bs[k]);
+    if (q[k] != c[k]) inside = false;
+  }
+  float dd;
+  if (!inside) {
+    float v[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+    dd = sqrtf(dot3f(v, v));
+    if (dd - r > margin) return false;
+    float id = 1.0f / dd;
+    n[0] = v[0] * id; n[1] = v[1] * id; n[2] = v[2] * id;
+    dd -= r;
+  } else {
+    int kb = 0; float best = 1e30f;
+    for (int k = 0; k < 3; k++) { float e = bs[k] - fabsf(c[k]); if (e < best) { best = e; kb = k; } }
+    n[0] = n[1] = n[2] = 0.f;
+    n[kb] = c[kb] >= 0.f ? -1.f : 1.f;
+    dd = -best - r;
+  }
+  *dist = dd;
+  for (int k = 0; k < 3; k++) pos[k] = c[k] + n[k] * (r + 0.5f * dd);
+  return dd <= margin;
+}
+MZ_HD float seg_box_df(const float* a, const float* dir, const float* bs, float t) {
+  float g = 0.f;
+  for (int k = 0; k < 3; k++) {
+    float p = a[k] + t * dir[k];
+    if (p > bs[k]) g += (p - bs[k]) * dir[k];
+    else if (p < -bs[k]) g += (p + bs[k]) * dir[k];
+  }
+  return g;
+}
+MZ_HD float seg_box_t(const float* a, const float* b, const float* bs) {
+  float dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, bp[8];
+  int n = 0;
+  bp[n++] = 0.f;
+  for (int k = 0; k < 3; k++)
+    if (fabsf(dir[k]) > 1e-30f) {
+      float t1 = (bs[k] - a[k]) / dir[k], t2 = (-bs[k] - a[k]) / dir[k];
+      if (t1 > 0.f && t1 < 1.f) bp[n++] = t1;
+      if (t2 > 0.f && t2 < 1.f) bp[n++] = t2;
+    }
+  bp[n++] = 1.f;
+  for (int i = 1; i < n; i++) { float v = bp[i]; int j = i - 1; while (j >= 0 && bp[j] > v) { bp[j + 1] = bp[j]; j--; } bp[j + 1] = v; }
+  float g0 = seg_box_df(a, dir, bs, bp[0]);
+  if (g0 >= 0.f) return bp[0];
+  for (int i = 1; i < n; i++) {
+    float g1 = seg_box_df(a, dir, bs, bp[i]);
+    if (g1 >= 0.f) return bp[i - 1] - g0 * (bp[i] - bp[i - 1]) / (g1 - g0);
+    g0 = g1;
+  }
+  return 1.f;
+}
+
+// Enumerate the contacts of geom (= body) b.  `emit` is called once per contact, in a fixed
+// order (floor contacts first, then wall cells row-major), identical in the count and fill passes.
+template <class Emit>
+MZ_HD void geom_contacts(const AntDev& K, const AntScratch& s, int b, Emit&& emit) {
+  int c = body_class(b);
+  float r = K.radius[c], hl = K.half_len[c];
+  float ctr[3] = {0, 0, 0}, ax[3] = {0, 0, 0};
+  if (b > 0) for (int k = 0; k < 3; k++) { ctr[k] = s.com[b - 1][k]; ax[k] = s.w[b - 1][k]; }
+  ContactGeo cg;
+  // floor plane z = 0, normal +z; capsule ends in MuJoCo's geom-frame order [ASSUME-5]: the geom z axis of a
+  // fromto capsule points from `to` to `from`, i.e. along -w, so "+axis" is the end at the body origin
+  int nend = b == 0 ? 1 : 2;
+  for (int e = 0; e < nend; e++) {
+    float sg = e == 0 ? -1.f : 1.f, p[3];
+    for (int k = 0; k < 3; k++) p[k] = ctr[k] + sg * ax[k] * hl;
+    float dist = (s.cz + p[2]) - r;
+    if (dist < K.floor.margin) {
+      cg.dist = dist; cg.wall = 0;
+      cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
+      cg.pos[0] = p[0]; cg.pos[1] = p[1]; cg.pos[2] = p[2] - (r + 0.5f * dist);
+      for (int k = 0; k < 3; k++) cg.hint[k] = b == 0 ? 0.f : ax[k];
+      emit(cg);
+    }
+  }
+  // maze walls: cells under the bounding square of the geom
+  const MazeDev& z = K.maze;
+  float reach = r + hl + K.wall.margin;
+  float gx = s.qpos[0] + ctr[0], gy = s.qpos[1] + ctr[1], gz = s.cz + ctr[2];
+  if (gz - reach > z.center_z + z.half_z) return;
+  float inv = 1.0f / z.scale;
+  int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
+  int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
+  float bs[3] = {z.half_xy, z.half_xy, z.half_z};
+  for (int i = i0; i <= i1; i++)
+    for (int j = j0; j <= j1; j++) {
+      if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
+      if (!((z.rowmask[i] >> j) & 1u)) continue;
+      // box centre relative to the torso origin, computed so that the large world coordinates cancel first
+      float bx = (j * z.scale - z.tx) - s.qpos[0], by = (i * z.scale - z.ty) - s.qpos[1], bz = z.center_z - s.cz;
+      float cl[3] = {ctr[0] - bx, ctr[1] - by, ctr[2] - bz};  // geom centre in box coordinates
+      float dist, pos[3], n[3];
+      if (b == 0) {
+        if (sphere_aabb(cl, r, bs, K.wall.margin, &dist, pos, n) && dist < K.wall.margin) {
+          cg.dist = dist; cg.wall = 1;
+          for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.hint[k] = 0.f; }
+          cg.pos[0] = pos[0] + bx; cg.pos[1] = pos[1] + by; cg.pos[2] = pos[2] + bz;
+          emit(cg);
+        }
+      } else {  // capsule vs box [ASSUME-6]
+        float e1[3], e2[3];
+        for (int k = 0; k < 3; k++) { e1[k] = cl[k] - ax[k] * hl; e2[k] = cl[k] + ax[k] * hl; }  // e1 = +geom-z end
+        float t = seg_box_t(e1, e2, bs), p[3];
+        for (int k = 0; k < 3; k++) p[k] = e1[k] + t * (e2[k] - e1[k]);
+        if (sphere_aabb(p, r, bs, K.wall.margin, &dist, pos, n) && dist < K.wall.margin) {
+          cg.dist = dist; cg.wall = 1;
+          for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.hint[k] = 0.f; }
+          cg.pos[0] = pos[0] + bx; cg.pos[1] = pos[1] + by; cg.pos[2] = pos[2] + bz;
+          emit(cg);
+        }
+        float tf = t <= 0.5f ? 1.f : 0.f;
+        const float* far = t <= 0.5f ? e2 : e1;
+        if (fabsf(tf - t) * 2.f * hl > 1e-6f)
+          if (sphere_aabb(far, r, bs, K.wall.margin, &dist, pos, n) && dist < K.wall.margin) {
+            cg.dist = dist; cg.wall = 1;
+            for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.hint[k] = 0.f; }
+            cg.pos[0] = pos[0] + bx; cg.pos[1] = pos[1] + by; cg.pos[2] = pos[2] + bz;
+            emit(cg);
+          }
+      }
+    }
+}
+
+template <class C>
+MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratch& s) {
+  // pass 1: count contacts per geom
+  MZ_FOR(b, ANT_NBODY) {
+    int n = 0;
+    geom_contacts(K, s, b, [&](const ContactGeo&) { n++; });
+    s.cnt[b] = n;
+  }
+  cx.sync();
+  // pass 2: deterministic offsets (exclusive prefix over geoms), fill compact rows
+  MZ_FOR(b, ANT_NBODY) {
+    int off = 0;
+    for (int g = 0; g < b; g++) off += s.cnt[g];
+    if (b == ANT_NBODY - 1) {
+      int tot = off + s.cnt[b];
+      if (tot > ANT_NC) { tot = ANT_NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+      s.ncon = tot;
+    }
+    int cls = body_class(b), leg = b == 0 ? -1 : (b - 1) / 3, slot = off;
+    float tran = K.bw_tran[cls];
+    geom_contacts(K, s, b, [&](const ContactGeo& g) {
+      if (slot >= ANT_NC) { slot++; return; }
+      const PairDev& P = g.wall ? K.wall : K.floor;
+      float t1[3], t2[3];
+      make_tangents(g.n, g.hint, t1, t2);
+      float sgn = g.wall ? -1.f : 1.f;  // robot geom is geom2 against the floor, geom1 against a wall
+      float fr[3][3];
+      for (int k = 0; k < 3; k++) { fr[0][k] = sgn * g.n[k]; fr[1][k] = sgn * P.mu * t1[k]; fr[2][k] = sgn * P.mu * t2[k]; }
+      float(*J)[8] = s.cJ[slot];
+      for (int a = 0; a < 3; a++) {
+        for (int k = 0; k < 3; k++) J[a][k] = fr[a][k];  // root linear
+        for (int k = 0; k < 3; k++) {                    // root angular: (R0[:,k] x r) . f
+          float axk[3] = {s.R0[k], s.R0[3 + k], s.R0[6 + k]}, v[3];
+          cross3f(v, axk, g.pos);
+          J[a][3 + k] = dot3f(v, fr[a]);
+        }
+        float jh = 0.f, ja = 0.f;
+        if (cls >= 2) { float v[3]; cross3f(v, s.zw, g.pos); for (int k = 0; k < 3; k++) v[k] += s.Sh[leg][k]; jh = dot3f(v, fr[a]); }
+        if (cls == 3) { float v[3]; cross3f(v, s.Sa[leg], g.pos); for (int k = 0; k < 3; k++) v[k] += s.Sa[leg][3 + k]; ja = dot3f(v, fr[a]); }
+        J[a][6] = jh; J[a][7] = ja;
+      }
+      s.cleg[slot] = leg;
+      float imp = impedancef(P.solimp, fabsf(g.dist - P.margin));
+      float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
+      s.cD[slot] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
+      for (int a = 0; a < 3; a++) {
+        float vel = 0.f;
+        for (int k = 0; k < 6; k++) vel += J[a][k] * s.qvel[k];
+        if (leg >= 0) vel += J[a][6] * s.qvel[6 + 2 * leg] + J[a][7] * s.qvel[7 + 2 * leg];
+        s.caref[slot][a] = -P.B * vel - (a == 0 ? P.K * imp * (g.dist - P.margin) : 0.f);
+      }
+      slot++;
+    });
+  }
+  // joint limits: one slot per hinge (at most one side can be violated)
+  MZ_FOR(j, 8) {
+    int l = j >> 1;
+    float q = s.qpos[7 + j], lo = (j & 1) ? K.ank_lo[l] : K.hip_lo, hi = (j & 1) ? K.ank_hi[l] : K.hip_hi;
+    float sg = 0.f, pos = 0.f;
+    if (q - lo < 0.f) { sg = 1.f; pos = q - lo; }
+    else if (hi - q < 0.f) { sg = -1.f; pos = hi - q; }
+    float D = 0.f, aref = 0.f;
+    if (sg != 0.f) {
+      float imp = impedancef(K.lim_solimp, fabsf(pos));
+      float R = fmaxf(1e-15f, (1.f - imp) / imp * ((j & 1) ? K.dofw_ank : K.dofw_hip));
+      D = 1.0f / R;
+      aref = -K.lim_B * (sg * s.qvel[6 + j]) - K.lim_K * imp * pos;
+    }
+    s.lsign[j] = sg; s.lD[j] = D; s.laref[j] = aref;
+  }
+  cx.sync();
+}
+
+// ------------------------------------------------------------------ N: Newton solver
+// contact c: u = J qacc - aref (3), pyramid rows r = (u0+u1, u0-u1, u0+u2, u0-u2), active where r < 0
+MZ_HD float contact_eval(float D, const float* u, float* g, float* W) {
+  float r0 = u[0] + u[1], r1 = u[0] - u[1], r2 = u[0] + u[2], r3 = u[0] - u[2];
+  float a0 = r0 < 0.f ? 1.f : 0.f, a1 = r1 < 0.f ? 1.f : 0.f, a2 = r2 < 0.f ? 1.f : 0.f, a3 = r3 < 0.f ? 1.f : 0.f;
+  if (g) { g[0] = D * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3); g[1] = D * (a0 * r0 - a1 * r1); g[2] = D * (a2 * r2 - a3 * r3); }
+  if (W) { W[0] = D * (a0 + a1 + a2 + a3); W[1] = D * (a0 - a1); W[2] = D * (a2 - a3); W[3] = D * (a0 + a1); W[4] = D * (a2 + a3); }
+  return 0.5f * D * (a0 * r0 * r0 + a1 * r1 * r1 + a2 * r2 * r2 + a3 * r3 * r3);
+}
+MZ_HD float contact_Jdot(const AntScratch& s, int c, int a, const float* x) {
+  const float* J = s.cJ[c][a];
+  float v = 0.f;
+  for (int k = 0; k < 6; k++) v += J[k] * x[k];
+  int leg = s.cleg[c];
+  if (leg >= 0) v += J[6] * x[6 + 2 * leg] + J[7] * x[7 + 2 * leg];
+  return v;
+}
+// column of dof i in contact c's 3x8 Jacobian, -1 when the contact does not see that dof
+MZ_HD int contact_col(const AntScratch& s, int c, int i) {
+  if (i < 6) return i;
+  int leg = s.cleg[c];
+  return ((i - 6) >> 1) == leg ? 6 + ((i - 6) & 1) : -1;
+}
+
+// total cost at x (all lanes get the value); leaves M*(x - qas) in s.Mx
+template <class C>
+MZ_HD float ant_cost(const C& cx, const AntDev& K, AntScratch& s, const float* x) {
+  (void)K;
+  float part = 0.f;
+  MZ_FOR(i, ANT_NV) s.grad[i] = x[i] - s.qas[i];
+  cx.sync();
+  MZ_FOR(i, ANT_NV) { float v = arrow_row_mul(s.M, s.grad, i); s.Mx[i] = v; part += 0.5f * v * s.grad[i]; }
+  MZ_FOR(c, s.ncon) {
+    float u[3];
+    for (int a = 0; a < 3; a++) u[a] = contact_Jdot(s, c, a, x) - s.caref[c][a];
+    part += contact_eval(s.cD[c], u, nullptr, nullptr);
+  }
+  MZ_FOR(j, 8) {
+    if (s.lsign[j] != 0.f) { float jar = s.lsign[j] * x[6 + j] - s.laref[j]; if (jar < 0.f) part += 0.5f * s.lD[j] * jar * jar; }
+  }
+  float tot = cx.gsum(part);
+  cx.sync();
+  return tot;
+}
+
+template <class C>
+MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
+  bool has = false;
+  MZ_FOR(one, 1) { bool h = s.ncon > 0; for (int j = 0; j < 8; j++) h = h || s.lsign[j] != 0.f; s.red[0] = h ? 1.f : 0.f; }
+  cx.sync();
+  has = s.red[0] != 0.f;
+  cx.sync();
+  // warm start: the better of the previous step's acceleration and the unconstrained one
+  float cw = ant_cost(cx, K, s, s.warm), cs = ant_cost(cx, K, s, s.qas);
+  MZ_FOR(i, ANT_NV) s.qacc[i] = (has && cw < cs) ? s.warm[i] : s.qas[i];
+  cx.sync();
+  bool done = !has;
+  int it = 0;
+  while (cx.any(!done) && it < K.max_iter) {
+    // (a) M (qacc - qas) and the per-constraint gradient / curvature terms
+    MZ_FOR(i, ANT_NV) s.search[i] = s.qacc[i] - s.qas[i];
+    cx.sync();
+    MZ_FOR(i, ANT_NV) s.Mx[i] = arrow_row_mul(s.M, s.search, i);
+    MZ_FOR(c, s.ncon) {
+      float u[3];
+      for (int a = 0; a < 3; a++) u[a] = contact_Jdot(s, c, a, s.qacc) - s.caref[c][a];
+      for (int a = 0; a < 3; a++) s.cu[c][a] = u[a];
+      contact_eval(s.cD[c], u, s.cg[c], s.cW[c]);
+    }
+    MZ_FOR(j, 8) {
+      float jar = 0.f, act = 0.f;
+      if (s.lsign[j] != 0.f) { jar = s.lsign[j] * s.qacc[6 + j] - s.laref[j]; act = jar < 0.f ? s.lD[j] : 0.f; }
+      s.ljar[j] = jar; s.lact[j] = act;
+    }
+    cx.sync();
+    // (b) gradient and Hessian (arrow)
+    float gpart = 0.f, apart = 0.f;  // |grad|^2 and the squared magnitude of the terms that cancel in it
+    MZ_FOR(i, ANT_NV) {
+      float g = s.Mx[i], ga = fabsf(g);
+      for (int c = 0; c < s.ncon; c++) {
+        int col = contact_col(s, c, i);
+        if (col >= 0) {
+          float t = s.cJ[c][0][col] * s.cg[c][0] + s.cJ[c][1][col] * s.cg[c][1] + s.cJ[c][2][col] * s.cg[c][2];
+          g += t; ga += fabsf(t);
+        }
+      }
+      if (i >= 6 && s.lsign[i - 6] != 0.f) { float t = s.lsign[i - 6] * s.lact[i - 6] * s.ljar[i - 6]; g += t; ga += fabsf(t); }
+      s.grad[i] = g;
+      gpart += g * g;
+      apart += ga * ga;
+    }
+    MZ_FOR(e, 81) {  // 21 root-root + 48 root-leg + 12 leg-leg entries
+      int i, j, leg = -1;
+      float base;
+      if (e < 21) { i = 0; j = e; while (j > i) { j -= i + 1; i++; } base = s.M.rr[i][j]; }
+      else if (e < 69) { int q = e - 21; leg = q / 12; int d = (q % 12) / 6; j = q % 6; i = 6 + 2 * leg + d; base = s.M.rl[leg][d][j]; }
+      else { int q = e - 69; leg = q / 3; int t = q % 3; i = 6 + 2 * leg + (t == 2 ? 1 : 0); j = 6 + 2 * leg + (t >= 1 ? 1 : 0); base = s.M.ll[leg][t]; }
+      float acc = base;
+      for (int c = 0; c < s.ncon; c++) {
+        int ci = contact_col(s, c, i), cj = contact_col(s, c, j);
+        if (ci < 0 || cj < 0) continue;
+        const float* W = s.cW[c];
+        float n_i = s.cJ[c][0][ci], p_i = s.cJ[c][1][ci], q_i = s.cJ[c][2][ci];
+        float n_j = s.cJ[c][0][cj], p_j = s.cJ[c][1][cj], q_j = s.cJ[c][2][cj];
+        acc += W[0] * n_i * n_j + W[1] * (n_i * p_j + p_i * n_j) + W[2] * (n_i * q_j + q_i * n_j) + W[3] * p_i * p_j + W[4] * q_i * q_j;
+      }
+      if (e < 21) { s.H.rr[i][j] = acc; s.H.rr[j][i] = acc; }
+      else if (e < 69) { s.H.rl[leg][(i - 6) & 1][j] = acc; }
+      else { int t = (e - 69) % 3; if (t != 1) acc += s.lact[i - 6]; s.H.ll[leg][t] = acc; }
+    }
+    float gnorm = sqrtf(cx.gsum(gpart)), anorm = sqrtf(cx.gsum(apart));
+    cx.sync();
+    // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
+    if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
+    if (!cx.any(!done)) break;
+    // (c) Newton direction
+    arrow_factor(cx, s.H, s.F);
+    arrow_solve(cx, s.H, s.F, s.grad, s.search, s.Ms, -1.f);
+    // (d) exact line search on phi(alpha) = cost(qacc + alpha * search)
+    float p1 = 0.f, p2 = 0.f;
+    MZ_FOR(i, ANT_NV) { float ms = arrow_row_mul(s.M, s.search, i); s.Ms[i] = ms; p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
+    MZ_FOR(c, s.ncon) for (int a = 0; a < 3; a++) s.cjv[c][a] = contact_Jdot(s, c, a, s.search);
+    MZ_FOR(j, 8) s.ljv[j] = s.lsign[j] * s.search[6 + j];
+    p1 = cx.gsum(p1); p2 = cx.gsum(p2);
+    cx.sync();
+    float lo = 0.f, hi = -1.f, alpha = 0.f;  // hi < 0: no upper bracket yet
+    for (int ls = 0; ls < K.ls_iter; ls++) {
+      float d1 = 0.f, d2 = 0.f;
+      MZ_FOR(c, s.ncon) {
+        float D = s.cD[c];
+        float u0 = s.cu[c][0] + alpha * s.cjv[c][0], u1 = s.cu[c][1] + alpha * s.cjv[c][1], u2 = s.cu[c][2] + alpha * s.cjv[c][2];
+        float v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
+        float r, v;
+        r = u0 + u1; v = v0 + v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+        r = u0 - u1; v = v0 - v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+        r = u0 + u2; v = v0 + v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+        r = u0 - u2; v = v0 - v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+      }
+      MZ_FOR(j, 8) {
+        if (s.lsign[j] != 0.f) { float r = s.ljar[j] + alpha * s.ljv[j]; if (r < 0.f) { d1 += s.lD[j] * r * s.ljv[j]; d2 += s.lD[j] * s.ljv[j] * s.ljv[j]; } }
+      }
+      d1 = cx.gsum(d1) + p1 + alpha * p2;
+      d2 = cx.gsum(d2) + p2;
+      if (d1 < 0.f) lo = alpha; else hi = alpha;
+      float next = alpha - d1 / d2;                       // Newton step on the piecewise-linear derivative
+      if (hi >= 0.f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);  // safeguard
+      if (!(next > 0.f)) next = hi >= 0.f ? 0.5f * (lo + hi) : 0.f;
+      if (fabsf(next - alpha) <= 1e-7f * fabsf(next)) { alpha = next; break; }
+      alpha = next;
+    }
+    if (done) alpha = 0.f;
+    cx.sync();
+    MZ_FOR(i, ANT_NV) s.qacc[i] += alpha * s.search[i];
+    cx.sync();
+    it++;
+  }
+  MZ_FOR(one, 1) { s.iters = it; if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER; }
+  cx.sync();
+}
+
+// ------------------------------------------------------------------ one forward-dynamics evaluation: qacc from (qpos, qvel, fact)
+template <class C>
+MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratch& s) {
+  ant_kin_crb(cx, K, s);
+  ant_bias(cx, K, s);
+  arrow_factor(cx, s.M, s.F);
+  arrow_solve(cx, s.M, s.F, s.qfs, s.qas, s.Ms, 1.f);
+  ant_constraints(cx, K, s);
+  ant_solve(cx, K, s);
+}
+
+// qpos <- integrate(qpos, vel, h): free joint on the manifold, hinges linear (MuJoCo mj_integratePos)
+template <class C>
+MZ_HD void ant_integrate_pos(const C& cx, AntScratch& s, const float* base, const float* vel, float h) {
+  MZ_FOR(i, 12) {
+    if (i < 3) s.qpos[i] = base[i] + h * vel[i];
+    else if (i == 3) {
+      float w[3] = {vel[3], vel[4], vel[5]};
+      float n = sqrtf(dot3f(w, w));
+      float q[4] = {base[3], base[4], base[5], base[6]};
+      float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int k = 0; k < 4; k++) q[k] *= qn;
+      if (n > 1e-15f) {
+        float ang = 0.5f * h * n, sn = sinf(ang) / n, c0 = cosf(ang);
+        float r[4] = {c0, w[0] * sn, w[1] * sn, w[2] * sn}, o[4];
+        o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
+        o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
+        o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
+        o[3] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
+        float on = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+        for (int k = 0; k < 4; k++) q[k] = o[k] * on;
+      }
+      for (int k = 0; k < 4; k++) s.qpos[3 + k] = q[k];
+    } else {
+      int j = i - 4;  // hinges 0..7
+      s.qpos[7 + j] = base[7 + j] + h * vel[6 + j];
+    }
+  }
+}
+
+// one mj_step with RK4.  State in s.qpos / s.qvel / s.warm, actuator forces in s.fact.
+template <class C>
+MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratch& s) {
+  const float h = K.h;
+  MZ_FOR(i, 16) { if (i < ANT_NQ) s.x0q[i] = s.qpos[i]; }
+  MZ_FOR(i, ANT_NV) { s.x0v[i] = s.qvel[i]; s.accv[i] = 0.f; s.accf[i] = 0.f; }
+  cx.sync();
+  for (int st = 0; st < 4; st++) {
+    ant_forward(cx, K, s);
+    const float bw = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+    const float aw = st == 2 ? 1.0f : 0.5f;  // Butcher A: diag(1/2, 1/2, 1)
+    // accumulate B-weighted sums, form the next stage state from this stage's (qvel, qacc)
+    MZ_FOR(i, ANT_NV) {
+      s.accv[i] += bw * s.qvel[i];
+      s.accf[i] += bw * s.qacc[i];
+      s.Ms[i] = aw * s.qvel[i];   // dX velocity for the position update
+      s.Mx[i] = s.x0v[i] + h * aw * s.qacc[i];
+    }
+    cx.sync();
+    if (st < 3) {
+      ant_integrate_pos(cx, s, s.x0q, s.Ms, h);
+      MZ_FOR(i, ANT_NV) s.qvel[i] = s.Mx[i];
+      cx.sync();
+    }
+  }
+  ant_integrate_pos(cx, s, s.x0q, s.accv, h);
+  MZ_FOR(i, ANT_NV) { s.qvel[i] = s.x0v[i] + h * s.accf[i]; s.warm[i] = s.qacc[i]; }
+  cx.sync();
+}
+
+// ------------------------------------------------------------------ MazeTask reward / termination on the fp32 observation
+MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int* term, int* goal_idx) {
+  const float* rs = T.reward_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
+  const float* ts = T.term_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
+  int tm = 0, first = -1;
+  for (int g = 0; g < T.ngoal; g++) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < T.goal_dim[g]; k++) { float e = ts[k] - T.goal_pos[g][k]; a += e * e; float f = rs[k] - T.goal_pos[g][k]; b += f * f; }
+    if (!tm && sqrtf(a) <= T.thr[g]) tm = 1;
+    if (first < 0 && sqrtf(b) <= T.thr[g]) first = g;
+  }
+  float r = 0.f;
+  if (T.reward_kind == MZ_REWARD_FIRST_MATCH) r = T.reward_binary ? (tm ? 1.0f : T.penalty) : (first >= 0 ? T.rscale[first] : T.penalty);
+  else if (T.reward_kind == MZ_REWARD_NEG_DIST) {
+    float a = 0.f;
+    for (int k = 0; k < T.goal_dim[0]; k++) { float e = rs[k] - T.goal_pos[0][k]; a += e * e; }
+    r = -sqrtf(a) / T.task_scale;
+  }
+  *reward = r; *term = tm; *goal_idx = first;
+}
+
+// ------------------------------------------------------------------ MazeEnv.step for the Ant (maze_env.py:448-481, ant.py:61-73)
+// in: s.qpos/qvel/warm loaded, action[8], t (steps so far).  out: obs[30], reward, done, goal_idx, info[4]
+template <class C>
+MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratch& s, const float* action, int t_in, float* obs, float* reward,
+                        uint8_t* done, int* goal_idx, float* info, int* t_out) {
+  MZ_FOR(i, ANT_NV) s.fact[i] = 0.f;
+  MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
+  cx.sync();
+  MZ_FOR(u, ANT_NU) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(action[u], K.ctrl_lo), K.ctrl_hi);
+  cx.sync();
+  for (int f = 0; f < K.frame_skip; f++) ant_mj_step(cx, K, s);
+  int t = t_in + 1;
+  MZ_FOR(i, ANT_OBS) {
+    float v = i < ANT_NQ ? s.qpos[i] : (i < ANT_NQ + ANT_NV ? s.qvel[i - ANT_NQ] : (float)t * 0.001f);
+    obs[i] = v;
+  }
+  MZ_FOR(one, 1) {
+    float dt = K.h * (float)K.frame_skip;
+    float vx = (s.qpos[0] - s.red[1]) / dt, vy = (s.qpos[1] - s.red[2]) / dt;
+    float fwd = sqrtf(vx * vx + vy * vy), cc = 0.f;
+    for (int u = 0; u < ANT_NU; u++) cc += action[u] * action[u];
+    cc *= K.task.ctrl_w;
+    float o3[6] = {s.qpos[0], s.qpos[1], s.qpos[2], s.qpos[3], s.qpos[4], s.qpos[5]};
+    float outer; int tm, gi;
+    task_eval_dev(K.task, o3, &outer, &tm, &gi);
+    *reward = K.task.inner_scale * (K.task.fwd_w * fwd - cc) + outer;
+    *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
+    if (goal_idx) *goal_idx = gi;
+    if (info) { info[0] = s.qpos[0]; info[1] = s.qpos[1]; info[2] = fwd; info[3] = -cc; }
+    *t_out = t;
+    bool badv = false;
+    for (int i = 0; i < ANT_NQ; i++) badv = badv || !(fabsf(s.qpos[i]) < 1e10f);
+    for (int i = 0; i < ANT_NV; i++) badv = badv || !(fabsf(s.qvel[i]) < 1e10f);
+    if (badv) s.status |= MZ_STATUS_BAD_STATE;
+  }
+  cx.sync();
+}

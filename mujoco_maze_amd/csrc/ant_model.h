@@ -1,0 +1,164 @@
+// ant_model.h — fp32 device constants of the Ant maze stepper and their
+// derivation from the compiled `mz_model` (include/mazestep.h).
+//
+// The HIP kernel is specialised for the reference's Ant topology
+// (mujoco_maze/assets/ant.xml:21-66): free torso + four legs,
+// each leg = welded capsule -> hip hinge (body z) -> ankle hinge.  `ant_dev_from_model`
+// checks that the compiled model really has that shape and refuses anything
+// else (MZ_ERR_UNSUPPORTED) instead of silently computing the wrong robot.
+//
+// Plain C++ (no HIP): shared by csrc/mazestep.hip and the CPU emulation of the
+// kernel logic in tests/emu/.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/mazestep.h"
+
+#define ANT_NC 24     // contact slots per env
+#define ANT_NBODY 13  // moving bodies: torso + 4 x (leg, aux, ankle)
+#define ANT_NV 14
+#define ANT_NQ 15
+#define ANT_NU 8
+#define ANT_OBS 30
+
+struct PairDev {  // mixed contact parameters of one geom-pair class
+  float margin, mu, K, B, solimp[5];
+};
+
+struct TaskDev {
+  int ngoal, reward_kind, reward_slot, reward_binary, term_slot, max_steps;
+  int goal_dim[MZ_MAX_GOAL];
+  float goal_pos[MZ_MAX_GOAL][3], thr[MZ_MAX_GOAL], rscale[MZ_MAX_GOAL];
+  float penalty, task_scale, inner_scale, fwd_w, ctrl_w;
+};
+
+struct MazeDev {
+  int rows, cols;
+  uint32_t rowmask[MZ_MAX_GRID];  // bit j set <=> cell (i, j) is a BLOCK
+  float scale, tx, ty, half_xy, half_z, center_z;
+};
+
+struct AntDev {
+  float h, gz;
+  int frame_skip;
+  // body classes: 0 torso (sphere), 1 welded leg capsule, 2 aux capsule, 3 ankle capsule
+  float mass[4], ilat[4], iax[4], half_len[4], radius[4], bw_tran[4];
+  float legoff;  // |x| = |y| offset of aux / ankle body origins in the parent frame
+  float sx[4], sy[4];
+  float ank_axis[4][3];
+  float hip_lo, hip_hi, ank_lo[4], ank_hi[4];
+  float armature, damping, dofw_hip, dofw_ank;
+  float lim_K, lim_B, lim_solimp[5];
+  float ctrl_lo, ctrl_hi, gear;
+  int act_dof[ANT_NU];
+  PairDev floor, wall;
+  MazeDev maze;
+  TaskDev task;
+  float qpos0[ANT_NQ];
+  int reset_kind;
+  // solver
+  int max_iter, ls_iter;
+  float tol, rtol, inv_scale;  // inv_scale = 1 / (meaninertia * nv)
+};
+
+static inline int ant_fail(char* err, int n, const char* msg) {
+  if (err && n > 0) { strncpy(err, msg, (size_t)n - 1); err[n - 1] = 0; }
+  return MZ_ERR_UNSUPPORTED;
+}
+
+static inline void pair_from(PairDev* p, const mz_model* m, const double* f1, const double* sr1, const double* si1, double mg1,
+                             const double* f2, const double* sr2, const double* si2, double mg2) {
+  double sr[2], si[5];
+  for (int k = 0; k < 2; k++) sr[k] = 0.5 * (sr1[k] + sr2[k]);
+  for (int k = 0; k < 5; k++) si[k] = 0.5 * (si1[k] + si2[k]);
+  p->margin = (float)fmax(mg1, mg2);
+  p->mu = (float)fmax(f1[0], f2[0]);
+  double tc = fmax(sr[0], 2.0 * m->timestep), dr = sr[1], dmax = si[1];
+  p->K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr));
+  p->B = (float)(2.0 / (dmax * tc));
+  for (int k = 0; k < 5; k++) p->solimp[k] = (float)si[k];
+}
+
+static inline void task_dev_from_model(TaskDev* t, const mz_model* m) {
+  memset(t, 0, sizeof(*t));
+  t->ngoal = m->ngoal; t->reward_kind = m->reward_kind; t->reward_slot = m->reward_slot;
+  t->reward_binary = m->reward_binary; t->term_slot = m->term_slot; t->max_steps = m->max_episode_steps;
+  for (int g = 0; g < m->ngoal; g++) {
+    t->goal_dim[g] = m->goal_dim[g];
+    for (int k = 0; k < 3; k++) t->goal_pos[g][k] = (float)m->goal_pos[g][k];
+    t->thr[g] = (float)m->goal_threshold[g];
+    t->rscale[g] = (float)m->goal_reward_scale[g];
+  }
+  t->penalty = (float)m->penalty; t->task_scale = (float)m->task_scale; t->inner_scale = (float)m->inner_reward_scaling;
+  t->fwd_w = (float)m->forward_reward_weight; t->ctrl_w = (float)m->ctrl_cost_weight;
+}
+
+static inline void maze_dev_from_model(MazeDev* z, const mz_model* m) {
+  memset(z, 0, sizeof(*z));
+  z->rows = m->grid_rows; z->cols = m->grid_cols;
+  for (int i = 0; i < m->grid_rows; i++)
+    for (int j = 0; j < m->grid_cols; j++)
+      if (m->grid[i][j] == MZ_CELL_BLOCK) z->rowmask[i] |= (1u << j);
+  z->scale = (float)m->maze_scale; z->tx = (float)m->torso_x; z->ty = (float)m->torso_y;
+  z->half_xy = (float)m->wall_half_xy; z->half_z = (float)m->wall_half_z; z->center_z = (float)m->wall_center_z;
+}
+
+static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, int errlen) {
+  memset(a, 0, sizeof(*a));
+  if (m->robot != MZ_ROBOT_ANT || m->nbody != 14 || m->nv != ANT_NV || m->nq != ANT_NQ || m->nu != ANT_NU || m->ngeom != 14)
+    return ant_fail(err, errlen, "ant kernel: model is not the 14-body / 14-dof ant");
+  if (m->jnt_type[0] != MZ_JNT_FREE || m->geom_type[0] != MZ_GEOM_PLANE || m->geom_type[1] != MZ_GEOM_SPHERE)
+    return ant_fail(err, errlen, "ant kernel: expected free root joint, floor plane, torso sphere");
+  a->h = (float)m->timestep; a->gz = (float)m->gravity[2]; a->frame_skip = m->frame_skip;
+  // classes from leg 0 (bodies 2,3,4 / geoms 2,3,4), torso = body 1 / geom 1
+  const int cb[4] = {1, 2, 3, 4};
+  for (int c = 0; c < 4; c++) {
+    int b = cb[c], g = b;  // one geom per body, same order (model.py emits floor first)
+    a->mass[c] = (float)m->body_mass[b];
+    a->ilat[c] = (float)m->body_inertia[b][2];  // zz: capsules lie in the body xy plane
+    a->iax[c] = (float)(c == 0 ? m->body_inertia[b][2] : m->body_inertia[b][2] + 2.0 * (m->body_inertia[b][0] - m->body_inertia[b][2]));
+    a->radius[c] = (float)m->geom_size[g][0];
+    a->half_len[c] = (float)(c == 0 ? 0.0 : m->geom_size[g][1]);
+    a->bw_tran[c] = (float)m->body_invweight0[b][0];
+  }
+  a->legoff = (float)fabs(m->body_pos[3][0]);
+  for (int l = 0; l < 4; l++) {
+    int b_leg = 2 + 3 * l, b_aux = 3 + 3 * l, b_ank = 4 + 3 * l, j_hip = 1 + 2 * l, j_ank = 2 + 2 * l;
+    if (m->body_parent[b_leg] != 1 || m->body_parent[b_aux] != b_leg || m->body_parent[b_ank] != b_aux ||
+        m->body_jntnum[b_leg] != 0 || m->jnt_type[j_hip] != MZ_JNT_HINGE || m->jnt_type[j_ank] != MZ_JNT_HINGE ||
+        m->jnt_dofadr[j_hip] != 6 + 2 * l || m->geom_type[b_leg] != MZ_GEOM_CAPSULE || fabs(m->jnt_axis[j_hip][2] - 1.0) > 1e-12)
+      return ant_fail(err, errlen, "ant kernel: leg topology differs from ant.xml");
+    a->sx[l] = m->body_pos[b_aux][0] > 0 ? 1.f : -1.f;
+    a->sy[l] = m->body_pos[b_aux][1] > 0 ? 1.f : -1.f;
+    if (fabs(fabs(m->body_pos[b_aux][0]) - a->legoff) > 1e-6 || fabs(fabs(m->body_pos[b_ank][1]) - a->legoff) > 1e-6 ||
+        fabs(m->body_mass[b_leg] - m->body_mass[2]) > 1e-12 || fabs(m->body_mass[b_ank] - m->body_mass[4]) > 1e-12)
+      return ant_fail(err, errlen, "ant kernel: legs are not mirror images");
+    for (int k = 0; k < 3; k++) a->ank_axis[l][k] = (float)m->jnt_axis[j_ank][k];
+    a->ank_lo[l] = (float)m->jnt_range[j_ank][0]; a->ank_hi[l] = (float)m->jnt_range[j_ank][1];
+    if (!m->jnt_limited[j_hip] || !m->jnt_limited[j_ank]) return ant_fail(err, errlen, "ant kernel: hinges must be limited");
+  }
+  a->hip_lo = (float)m->jnt_range[1][0]; a->hip_hi = (float)m->jnt_range[1][1];
+  a->armature = (float)m->dof_armature[6]; a->damping = (float)m->dof_damping[6];
+  a->dofw_hip = (float)m->dof_invweight0[6]; a->dofw_ank = (float)m->dof_invweight0[7];
+  {
+    double tc = fmax(m->jnt_solref[1][0], 2.0 * m->timestep), dr = m->jnt_solref[1][1], dmax = m->jnt_solimp[1][1];
+    a->lim_K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr));
+    a->lim_B = (float)(2.0 / (dmax * tc));
+    for (int k = 0; k < 5; k++) a->lim_solimp[k] = (float)m->jnt_solimp[1][k];
+  }
+  a->ctrl_lo = (float)m->act_ctrlrange[0][0]; a->ctrl_hi = (float)m->act_ctrlrange[0][1]; a->gear = (float)m->act_gear[0];
+  for (int u = 0; u < ANT_NU; u++) a->act_dof[u] = m->act_dofid[u];
+  pair_from(&a->floor, m, m->geom_friction[0], m->geom_solref[0], m->geom_solimp[0], m->geom_margin[0], m->geom_friction[1],
+            m->geom_solref[1], m->geom_solimp[1], m->geom_margin[1]);
+  pair_from(&a->wall, m, m->geom_friction[1], m->geom_solref[1], m->geom_solimp[1], m->geom_margin[1], m->wall_friction,
+            m->wall_solref, m->wall_solimp, m->wall_margin);
+  maze_dev_from_model(&a->maze, m);
+  task_dev_from_model(&a->task, m);
+  for (int k = 0; k < ANT_NQ; k++) a->qpos0[k] = (float)m->qpos0[k];
+  a->reset_kind = m->reset_qvel_kind;
+  a->max_iter = 8; a->ls_iter = 12; a->tol = 1e-6f; a->rtol = 1e-6f;
+  a->inv_scale = (float)(1.0 / (m->meaninertia * m->nv));
+  return MZ_OK;
+}

@@ -1,0 +1,532 @@
+// mazestep.hip — HIP kernels (gfx950 / CDNA4) and the C-ABI of include/mazestep.h.
+//
+// Kernels
+//   ant_step_kernel<G>   one MazeEnv.step for the Ant: G lanes per environment, 64/G
+//                        environments per one-wavefront workgroup, the env's whole working
+//                        set (7.7 KB, AntScratch) resident in LDS across the 20 forward-
+//                        dynamics evaluations of the step; HBM is touched once per step
+//                        (192-B state record in, record + obs/reward/done out).
+//   point_step_kernel    one MazeEnv.step for the Point: one env per lane, SoA state.
+//   *_reset / state copy / debug kernels.
+//
+// Data layout in HBM
+//   Ant:   state[N][48] fp32 record  = qpos[15] | qvel[14] | qacc_warmstart[14] | t | episode | pad[3]
+//          (a lane group reads 48 consecutive words: coalesced for lane-group-per-env kernels;
+//          SoA would scatter a group's loads over 48 cache lines)
+//   Point: SoA  qpos[3][N] | qvel[3][N] fp32, t[N], episode[N] i32 (one env per lane: SoA is
+//          the coalesced layout)
+//   API arrays are row-major [N, k] as in include/mazestep.h.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "ant_dyn.h"
+#include "point_dyn.h"
+
+#define ANT_REC 48
+#define REC_T 43
+#define REC_EP 44
+
+// ------------------------------------------------------------------ device context of a lane group
+template <int G>
+struct DevCtx {
+  static constexpr int nlanes = G;
+  int l;
+  __device__ __forceinline__ int lane0() const { return l; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }  // one-wavefront workgroup: LDS fence, no cross-wave wait
+  __device__ __forceinline__ float gsum(float x) const {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, G);
+    return x;
+  }
+  __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+};
+
+// ------------------------------------------------------------------ RNG (same definition as the oracle's mzo_rng_u32)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t env, uint32_t counter) {
+  uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (env + 1));
+  z = mix64(z + 0x9E3779B97F4A7C15ULL * ((uint64_t)counter + 1));
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float rng_u01(uint64_t seed, uint64_t env, uint32_t c) { return (float)(rng_u32(seed, env, c) >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float rng_normal(uint64_t seed, uint64_t env, uint32_t c) {
+  float u1 = ((float)(rng_u32(seed, env, c) >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  float u2 = rng_u01(seed, env, c + 1);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+// reset distribution (ant.py:84-96, point.py:71-81): qpos0 + U(-.1,.1); qvel by kind
+__device__ __forceinline__ float reset_qpos(float q0, uint64_t seed, uint64_t env, int i) { return q0 + (-0.1f + 0.2f * rng_u01(seed, env, (uint32_t)i)); }
+__device__ __forceinline__ float reset_qvel(int kind, int nq, uint64_t seed, uint64_t env, int i) {
+  uint32_t c = (uint32_t)(nq + 2 * i);
+  if (kind == 0) return 0.1f * rng_normal(seed, env, c);
+  if (kind == 1) return 0.1f * rng_u01(seed, env, c);
+  return -0.1f + 0.2f * rng_u01(seed, env, c);
+}
+__host__ __device__ __forceinline__ uint64_t episode_seed(uint64_t seed, uint32_t episode) {
+  return episode == 0 ? seed : mix64(seed ^ (0xD6E8FEB86659FD93ULL * (uint64_t)episode));
+}
+
+// ------------------------------------------------------------------ Ant kernels
+template <int G>
+__device__ __forceinline__ void ant_load(const DevCtx<G>& cx, AntScratch& s, const float* rec) {
+  for (int i = cx.l; i < REC_T; i += G) {
+    float v = rec[i];
+    if (i < ANT_NQ) s.qpos[i] = v;
+    else if (i < ANT_NQ + ANT_NV) s.qvel[i - ANT_NQ] = v;
+    else s.warm[i - ANT_NQ - ANT_NV] = v;
+  }
+}
+template <int G>
+__device__ __forceinline__ void ant_store(const DevCtx<G>& cx, const AntScratch& s, float* rec) {
+  for (int i = cx.l; i < REC_T; i += G) {
+    float v = i < ANT_NQ ? s.qpos[i] : (i < ANT_NQ + ANT_NV ? s.qvel[i - ANT_NQ] : s.warm[i - ANT_NQ - ANT_NV]);
+    rec[i] = v;
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void ant_step_kernel(AntDev K, int n, float* __restrict__ state, const float* __restrict__ actions,
+                                                       float* __restrict__ obs, float* __restrict__ reward,
+                                                       uint8_t* __restrict__ done, int* __restrict__ goal_idx,
+                                                       float* __restrict__ info, int* __restrict__ status, int auto_reset,
+                                                       uint64_t seed) {
+  constexpr int EPB = 64 / G;
+  __shared__ AntScratch sc[EPB];
+  __shared__ float act_s[EPB][ANT_NU], obs_s[EPB][ANT_OBS + 2], out_s[EPB][8];
+  __shared__ int iout_s[EPB][4];
+  DevCtx<G> cx{(int)threadIdx.x % G};
+  const int slot = threadIdx.x / G;
+  int env = blockIdx.x * EPB + slot;
+  const bool live = env < n;
+  if (!live) env = n - 1;  // surplus groups shadow the last env (no stores) so that every lane reaches every barrier
+  AntScratch& s = sc[slot];
+  float* rec = state + (size_t)env * ANT_REC;
+  ant_load(cx, s, rec);
+  for (int i = cx.l; i < ANT_NU; i += G) act_s[slot][i] = actions[(size_t)env * ANT_NU + i];
+  int t_in = ((const int*)rec)[REC_T];
+  uint32_t episode = ((const uint32_t*)rec)[REC_EP];
+  cx.sync();
+  uint8_t* dn = (uint8_t*)&iout_s[slot][0];
+  ant_env_step(cx, K, s, act_s[slot], t_in, obs_s[slot], &out_s[slot][0], dn, &iout_s[slot][1], &out_s[slot][1], &iout_s[slot][2]);
+  cx.sync();
+  const uint8_t d = *dn;
+  const int t_new = iout_s[slot][2];
+  if (live) {
+    for (int i = cx.l; i < ANT_OBS; i += G) obs[(size_t)env * ANT_OBS + i] = obs_s[slot][i];
+    if (cx.l == 0) {
+      reward[env] = out_s[slot][0];
+      done[env] = d;
+      if (goal_idx) goal_idx[env] = iout_s[slot][1];
+      if (s.status) atomicOr(&status[env], s.status);
+    }
+    if (info) for (int i = cx.l; i < 4; i += G) info[(size_t)env * 4 + i] = out_s[slot][1 + i];
+  }
+  if (auto_reset && d) {  // masked reset inside the step
+    episode += 1;
+    uint64_t es = episode_seed(seed, episode);
+    for (int i = cx.l; i < ANT_NQ; i += G) s.qpos[i] = reset_qpos(K.qpos0[i], es, (uint64_t)env, i);
+    for (int i = cx.l; i < ANT_NV; i += G) { s.qvel[i] = reset_qvel(K.reset_kind, ANT_NQ, es, (uint64_t)env, i); s.warm[i] = 0.f; }
+  }
+  cx.sync();
+  if (live) {
+    ant_store(cx, s, rec);
+    if (cx.l == 0) { ((int*)rec)[REC_T] = (auto_reset && d) ? 0 : t_new; ((uint32_t*)rec)[REC_EP] = episode; }
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const float* __restrict__ state,
+                                                          const float* __restrict__ actions, float* __restrict__ qacc,
+                                                          int* __restrict__ counts) {
+  constexpr int EPB = 64 / G;
+  __shared__ AntScratch sc[EPB];
+  DevCtx<G> cx{(int)threadIdx.x % G};
+  const int slot = threadIdx.x / G;
+  int env = blockIdx.x * EPB + slot;
+  const bool live = env < n;
+  if (!live) env = n - 1;
+  AntScratch& s = sc[slot];
+  ant_load(cx, s, state + (size_t)env * ANT_REC);
+  for (int i = cx.l; i < ANT_NV; i += G) s.fact[i] = 0.f;
+  if (cx.l == 0) s.status = 0;
+  cx.sync();
+  if (actions)
+    for (int u = cx.l; u < ANT_NU; u += G) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(actions[(size_t)env * ANT_NU + u], K.ctrl_lo), K.ctrl_hi);
+  cx.sync();
+  ant_forward(cx, K, s);
+  if (live) {
+    for (int i = cx.l; i < ANT_NV; i += G) qacc[(size_t)env * ANT_NV + i] = s.qacc[i];
+    if (cx.l == 0 && counts) { counts[2 * env] = s.ncon; counts[2 * env + 1] = s.iters; }
+  }
+}
+
+__global__ void ant_reset_kernel(AntDev K, int n, float* state, const uint8_t* mask, uint64_t seed, float* obs) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  float* rec = state + (size_t)env * ANT_REC;
+  if (!mask || mask[env]) {
+    for (int i = 0; i < ANT_NQ; i++) rec[i] = reset_qpos(K.qpos0[i], seed, (uint64_t)env, i);
+    for (int i = 0; i < ANT_NV; i++) { rec[ANT_NQ + i] = reset_qvel(K.reset_kind, ANT_NQ, seed, (uint64_t)env, i); rec[ANT_NQ + ANT_NV + i] = 0.f; }
+    ((int*)rec)[REC_T] = 0;
+    ((uint32_t*)rec)[REC_EP] = 0;
+  }
+  if (obs) {
+    for (int i = 0; i < ANT_NQ + ANT_NV; i++) obs[(size_t)env * ANT_OBS + i] = rec[i];
+    obs[(size_t)env * ANT_OBS + ANT_OBS - 1] = (float)((int*)rec)[REC_T] * 0.001f;
+  }
+}
+
+// row-major API arrays <-> state records
+__global__ void ant_set_state_kernel(int n, float* state, const float* qpos, const float* qvel, const float* warm, const int* t) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int env = idx / ANT_REC, i = idx % ANT_REC;
+  if (env >= n) return;
+  float* rec = state + (size_t)env * ANT_REC;
+  if (i < ANT_NQ) { if (qpos) rec[i] = qpos[(size_t)env * ANT_NQ + i]; }
+  else if (i < ANT_NQ + ANT_NV) { if (qvel) rec[i] = qvel[(size_t)env * ANT_NV + i - ANT_NQ]; }
+  else if (i < REC_T) { if (warm) rec[i] = warm[(size_t)env * ANT_NV + i - ANT_NQ - ANT_NV]; }
+  else if (i == REC_T) { if (t) ((int*)rec)[REC_T] = t[env]; }
+}
+__global__ void ant_get_state_kernel(int n, const float* state, float* qpos, float* qvel, float* warm, int* t) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int env = idx / ANT_REC, i = idx % ANT_REC;
+  if (env >= n) return;
+  const float* rec = state + (size_t)env * ANT_REC;
+  if (i < ANT_NQ) { if (qpos) qpos[(size_t)env * ANT_NQ + i] = rec[i]; }
+  else if (i < ANT_NQ + ANT_NV) { if (qvel) qvel[(size_t)env * ANT_NV + i - ANT_NQ] = rec[i]; }
+  else if (i < REC_T) { if (warm) warm[(size_t)env * ANT_NV + i - ANT_NQ - ANT_NV] = rec[i]; }
+  else if (i == REC_T) { if (t) t[env] = ((const int*)rec)[REC_T]; }
+}
+
+// ------------------------------------------------------------------ Point kernels (SoA: q0 q1 q2 v0 v1 v2 | t | episode)
+struct PointState { float* qv; int* t; uint32_t* ep; };
+
+__global__ __launch_bounds__(256) void point_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
+                                                          const float* __restrict__ actions, float* __restrict__ obs,
+                                                          float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                          int* __restrict__ goal_idx, float* __restrict__ info,
+                                                          int* __restrict__ status, int auto_reset, uint64_t seed) {
+  __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
+  for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
+  __syncthreads();
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  double q[3], v[3], a[2];
+  for (int k = 0; k < 3; k++) { q[k] = (double)S.qv[(size_t)k * n + env]; v[k] = (double)S.qv[(size_t)(3 + k) * n + env]; }
+  a[0] = (double)actions[(size_t)env * 2]; a[1] = (double)actions[(size_t)env * 2 + 1];
+  int t_new;
+  int st = point_env_step(P, q, v, a, S.t[env], nullptr, nullptr, nullptr, nullptr, nullptr, &t_new);
+  float o[7];
+  for (int k = 0; k < 3; k++) { o[k] = (float)q[k]; o[3 + k] = (float)v[k]; }
+  o[6] = (float)t_new * 0.001f;
+  float outer; int tm, gi;
+  task_eval_dev(P.task, o, &outer, &tm, &gi);  // flags from the fp32 observation that is returned
+  uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
+  for (int k = 0; k < 7; k++) obs[(size_t)env * 7 + k] = o[k];
+  reward[env] = outer;  // Point inner reward is 0.0 (point.py:61)
+  done[env] = d;
+  if (goal_idx) goal_idx[env] = gi;
+  if (info) { info[(size_t)env * 4] = o[0]; info[(size_t)env * 4 + 1] = o[1]; info[(size_t)env * 4 + 2] = 0.f; info[(size_t)env * 4 + 3] = 0.f; }
+  if (st) atomicOr(&status[env], st);
+  uint32_t ep = S.ep[env];
+  if (auto_reset && d) {
+    ep += 1;
+    uint64_t es = episode_seed(seed, ep);
+    for (int k = 0; k < 3; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, (uint64_t)env, k); o[3 + k] = reset_qvel(P.reset_kind, 3, es, (uint64_t)env, k); }
+    t_new = 0;
+  }
+  for (int k = 0; k < 6; k++) S.qv[(size_t)k * n + env] = o[k];
+  S.t[env] = t_new;
+  S.ep[env] = ep;
+}
+
+__global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, float* obs) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  if (!mask || mask[env]) {
+    for (int k = 0; k < 3; k++) {
+      S.qv[(size_t)k * n + env] = reset_qpos((float)Pp->qpos0[k], seed, (uint64_t)env, k);
+      S.qv[(size_t)(3 + k) * n + env] = reset_qvel(Pp->reset_kind, 3, seed, (uint64_t)env, k);
+    }
+    S.t[env] = 0;
+    S.ep[env] = 0;
+  }
+  if (obs) {
+    for (int k = 0; k < 6; k++) obs[(size_t)env * 7 + k] = S.qv[(size_t)k * n + env];
+    obs[(size_t)env * 7 + 6] = (float)S.t[env] * 0.001f;
+  }
+}
+__global__ void point_set_state_kernel(int n, PointState S, const float* qpos, const float* qvel, const int* t) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  for (int k = 0; k < 3; k++) {
+    if (qpos) S.qv[(size_t)k * n + env] = qpos[(size_t)env * 3 + k];
+    if (qvel) S.qv[(size_t)(3 + k) * n + env] = qvel[(size_t)env * 3 + k];
+  }
+  if (t) S.t[env] = t[env];
+}
+__global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* qvel, float* warm, int* t) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  for (int k = 0; k < 3; k++) {
+    if (qpos) qpos[(size_t)env * 3 + k] = S.qv[(size_t)k * n + env];
+    if (qvel) qvel[(size_t)env * 3 + k] = S.qv[(size_t)(3 + k) * n + env];
+    if (warm) warm[(size_t)env * 3 + k] = 0.f;
+  }
+  if (t) t[env] = S.t[env];
+}
+
+__global__ void fetch_clear_status_kernel(int n, int* status, int* out) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  out[env] = status[env];
+  status[env] = 0;
+}
+
+// ------------------------------------------------------------------ handle
+struct mz_handle {
+  mz_model model;
+  int n, device, robot;
+  AntDev ant;
+  PointDev* point_dev;  // device copy
+  PointDev point;
+  float* state;         // ant: [n][48]; point: [6][n]
+  int* pt_t;
+  uint32_t* pt_ep;
+  int* status;
+  int auto_reset, lanes;
+  uint64_t seed;
+  char err[256];
+  // kernel timing ring (option "time_kernels")
+  int ntime, itime;
+  hipEvent_t* ev;  // 2 * ntime
+  long nsteps;
+};
+
+static int set_err(mz_handle* h, int code, const char* what, hipError_t e) {
+  if (h) snprintf(h->err, sizeof(h->err), "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+  return code;
+}
+#define HIPCHK(h, call)                                                      \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) return set_err((h), MZ_ERR_HIP, #call, _e);        \
+  } while (0)
+
+template <int G>
+static void launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
+  constexpr int EPB = 64 / G;
+  hipLaunchKernelGGL(ant_step_kernel<G>, dim3((h->n + EPB - 1) / EPB), dim3(64), 0, st, h->ant, h->n, h->state, a, o, r, d, gi, inf,
+                     h->status, h->auto_reset, h->seed);
+}
+template <int G>
+static void launch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
+  constexpr int EPB = 64 / G;
+  hipLaunchKernelGGL(ant_forward_kernel<G>, dim3((h->n + EPB - 1) / EPB), dim3(64), 0, st, h->ant, h->n, h->state, a, qacc, counts);
+}
+
+extern "C" {
+
+int mz_abi_version(void) { return MZ_ABI_VERSION; }
+uint64_t mz_model_sizeof(void) { return sizeof(mz_model); }
+
+mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, char* err, int32_t errlen) {
+  auto fail = [&](const char* msg) -> mz_handle* {
+    if (err && errlen > 0) { strncpy(err, msg, (size_t)errlen - 1); err[errlen - 1] = 0; }
+    return nullptr;
+  };
+  if (!model || num_envs <= 0) return fail("mz_create: bad arguments");
+  if (model->abi_version != MZ_ABI_VERSION) return fail("mz_create: mz_model.abi_version mismatch");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("mz_create: no HIP device (the stepper has no CPU path)");
+  if (device < 0 || device >= ndev) return fail("mz_create: device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return fail("mz_create: hipSetDevice failed");
+  mz_handle* h = new (std::nothrow) mz_handle();
+  if (!h) return fail("mz_create: out of memory");
+  memset(h, 0, sizeof(*h));
+  h->model = *model; h->n = num_envs; h->device = device; h->robot = model->robot; h->lanes = 16; h->seed = 0x5EEDULL;
+  char msg[200] = {0};
+  int rc = MZ_OK;
+  if (model->robot == MZ_ROBOT_ANT) rc = ant_dev_from_model(&h->ant, model, msg, sizeof(msg));
+  else if (model->robot == MZ_ROBOT_POINT) rc = point_dev_from_model(&h->point, model, msg, sizeof(msg));
+  else { rc = MZ_ERR_UNSUPPORTED; snprintf(msg, sizeof(msg), "mz_create: robot kind %d has no device kernel yet", model->robot); }
+  if (rc != MZ_OK) { delete h; return fail(msg); }
+  hipError_t e = hipSuccess;
+  if (h->robot == MZ_ROBOT_ANT) {
+    e = hipMalloc(&h->state, (size_t)num_envs * ANT_REC * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * ANT_REC * sizeof(float));
+  } else {
+    e = hipMalloc(&h->state, (size_t)num_envs * 6 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->point_dev, sizeof(PointDev));
+    if (e == hipSuccess) e = hipMemcpy(h->point_dev, &h->point, sizeof(PointDev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * 6 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->pt_t, 0, (size_t)num_envs * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->pt_ep, 0, (size_t)num_envs * sizeof(uint32_t));
+  }
+  if (e == hipSuccess) e = hipMalloc(&h->status, (size_t)num_envs * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(h->status, 0, (size_t)num_envs * sizeof(int));
+  if (e != hipSuccess) {
+    snprintf(msg, sizeof(msg), "mz_create: device allocation failed: %s", hipGetErrorString(e));
+    mz_destroy(h);
+    return fail(msg);
+  }
+  return h;
+}
+
+void mz_destroy(mz_handle* h) {
+  if (!h) return;
+  if (h->state) (void)hipFree(h->state);
+  if (h->pt_t) (void)hipFree(h->pt_t);
+  if (h->pt_ep) (void)hipFree(h->pt_ep);
+  if (h->point_dev) (void)hipFree(h->point_dev);
+  if (h->status) (void)hipFree(h->status);
+  if (h->ev) { for (int i = 0; i < 2 * h->ntime; i++) (void)hipEventDestroy(h->ev[i]); free(h->ev); }
+  delete h;
+}
+
+const char* mz_last_error(const mz_handle* h) { return h ? h->err : "null handle"; }
+int32_t mz_num_envs(const mz_handle* h) { return h->n; }
+int32_t mz_obs_dim(const mz_handle* h) { return h->model.obs_dim; }
+int32_t mz_nq(const mz_handle* h) { return h->model.nq; }
+int32_t mz_nv(const mz_handle* h) { return h->model.nv; }
+int32_t mz_nu(const mz_handle* h) { return h->model.nu; }
+
+int32_t mz_set_option(mz_handle* h, const char* key, double value) {
+  if (!h || !key) return MZ_ERR_ARG;
+  if (!strcmp(key, "auto_reset")) { h->auto_reset = value != 0; return MZ_OK; }
+  if (!strcmp(key, "seed")) { h->seed = (uint64_t)value; return MZ_OK; }
+  if (!strcmp(key, "solver_iterations")) { h->ant.max_iter = (int)value; return MZ_OK; }
+  if (!strcmp(key, "solver_tolerance")) { h->ant.tol = (float)value; return MZ_OK; }
+  if (!strcmp(key, "solver_rtol")) { h->ant.rtol = (float)value; return MZ_OK; }
+  if (!strcmp(key, "ls_iterations")) { h->ant.ls_iter = (int)value; return MZ_OK; }
+  if (!strcmp(key, "lanes_per_env")) {
+    int g = (int)value;
+    if (g != 8 && g != 16 && g != 32 && g != 64) return set_err(h, MZ_ERR_ARG, "lanes_per_env must be 8, 16, 32 or 64", hipSuccess);
+    h->lanes = g;
+    return MZ_OK;
+  }
+  if (!strcmp(key, "time_kernels")) {
+    if (h->ev) { for (int i = 0; i < 2 * h->ntime; i++) (void)hipEventDestroy(h->ev[i]); free(h->ev); h->ev = nullptr; }
+    h->ntime = (int)value; h->itime = 0;
+    if (h->ntime > 0) {
+      h->ev = (hipEvent_t*)calloc((size_t)2 * h->ntime, sizeof(hipEvent_t));
+      for (int i = 0; i < 2 * h->ntime; i++) HIPCHK(h, hipEventCreate(&h->ev[i]));
+    }
+    return MZ_OK;
+  }
+  return set_err(h, MZ_ERR_ARG, "unknown option", hipSuccess);
+}
+
+int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* obs_dev, void* stream) {
+  if (!h) return MZ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  h->seed = seed;
+  int nb = (h->n + 255) / 256;
+  if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->n, h->state, mask_dev, seed, obs_dev);
+  else {
+    PointState S{h->state, h->pt_t, h->pt_ep};
+    hipLaunchKernelGGL(point_reset_kernel, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, obs_dev);
+  }
+  HIPCHK(h, hipGetLastError());
+  return MZ_OK;
+}
+
+int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev, const float* warmstart_dev, const int32_t* t_dev,
+                     void* stream) {
+  if (!h) return MZ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (h->robot == MZ_ROBOT_ANT) {
+    int tot = h->n * ANT_REC;
+    hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+  } else {
+    PointState S{h->state, h->pt_t, h->pt_ep};
+    hipLaunchKernelGGL(point_set_state_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
+  }
+  HIPCHK(h, hipGetLastError());
+  return MZ_OK;
+}
+
+int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warmstart_dev, int32_t* t_dev, void* stream) {
+  if (!h) return MZ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (h->robot == MZ_ROBOT_ANT) {
+    int tot = h->n * ANT_REC;
+    hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+  } else {
+    PointState S{h->state, h->pt_t, h->pt_ep};
+    hipLaunchKernelGGL(point_get_state_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+  }
+  HIPCHK(h, hipGetLastError());
+  return MZ_OK;
+}
+
+int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, int32_t* goal_idx_dev,
+                float* info_dev, void* stream) {
+  if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev) return h ? set_err(h, MZ_ERR_ARG, "mz_step: null array", hipSuccess) : MZ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int slot = -1;
+  if (h->ntime > 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
+  if (h->robot == MZ_ROBOT_ANT) {
+    switch (h->lanes) {
+      case 8: launch_ant_step<8>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 32: launch_ant_step<32>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 64: launch_ant_step<64>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      default: launch_ant_step<16>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+    }
+  } else {
+    PointState S{h->state, h->pt_t, h->pt_ep};
+    hipLaunchKernelGGL(point_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->point_dev, h->n, S, actions_dev, obs_dev,
+                       reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (slot >= 0) { HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st)); h->itime++; }
+  h->nsteps++;
+  return MZ_OK;
+}
+
+int32_t mz_get_status(mz_handle* h, int32_t* status_dev, void* stream) {
+  if (!h || !status_dev) return MZ_ERR_ARG;
+  hipLaunchKernelGGL(fetch_clear_status_kernel, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->n, h->status, status_dev);
+  HIPCHK(h, hipGetLastError());
+  return MZ_OK;
+}
+
+int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev, int32_t* counts_dev, void* stream) {
+  if (!h || !qacc_dev) return MZ_ERR_ARG;
+  if (h->robot != MZ_ROBOT_ANT) return set_err(h, MZ_ERR_UNSUPPORTED, "mz_debug_forward: ant only", hipSuccess);
+  hipStream_t st = (hipStream_t)stream;
+  switch (h->lanes) {
+    case 8: launch_ant_forward<8>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    case 32: launch_ant_forward<32>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    case 64: launch_ant_forward<64>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    default: launch_ant_forward<16>(h, st, actions_dev, qacc_dev, counts_dev); break;
+  }
+  HIPCHK(h, hipGetLastError());
+  return MZ_OK;
+}
+
+// Average duration (ms) of the step kernel over the recorded ring (after synchronising on the last event).
+double mz_last_kernel_ms(const mz_handle* h) {
+  if (!h || h->ntime <= 0 || h->itime <= 0) return -1.0;
+  int cnt = h->itime < h->ntime ? h->itime : h->ntime;
+  double tot = 0.0;
+  for (int i = 0; i < cnt; i++) {
+    if (hipEventSynchronize(h->ev[2 * i + 1]) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) != hipSuccess) return -1.0;
+    tot += ms;
+  }
+  return tot / cnt;
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+"""Batched maze environment on the MI355X and the reference-shaped single env.
+
+`VecMazeEnv` is the drop-in for the reference's hot path (`MazeEnv.step/reset`,
+mujoco_maze/maze_env.py:371-382,448-481) over `num_envs` environments in
+lock-step: Python -> ctypes -> C-ABI (include/mazestep.h) -> HIP kernels.  Tensors
+stay on the GPU (torch is only the owner of device memory and streams).
+
+`MazeEnv` keeps the reference constructor signature (maze_env.py:28-44) and the
+`reset() -> (obs, info)` / `step(a) -> (obs, reward, done, info)` shapes for one
+environment (numpy in / numpy out, float64 like the reference), implemented as a
+`VecMazeEnv` of size 1.
+"""
+import ctypes as C
+from typing import Optional, Tuple, Type
+
+import numpy as np
+
+from mujoco_maze_amd import _capi
+from mujoco_maze_amd.agent_model import AgentModel
+from mujoco_maze_amd.maze_task import MazeTask
+from mujoco_maze_amd.model import CompiledModel, compile_model
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency)."""
+
+    def __init__(self, low, high):
+        self.low = np.asarray(low, dtype=np.float32)
+        self.high = np.asarray(high, dtype=np.float32)
+        self.shape = self.low.shape
+        self.dtype = np.float32
+
+    def sample(self, rng: Optional[np.random.Generator] = None):
+        rng = rng or np.random.default_rng()
+        return rng.uniform(self.low, self.high).astype(np.float32)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class VecMazeEnv:
+    def __init__(self, model_cls: Type[AgentModel], maze_task: Type[MazeTask] = MazeTask, num_envs: int = 1,
+                 maze_height: float = 0.5, maze_size_scaling: float = 4.0, inner_reward_scaling: float = 1.0,
+                 restitution_coef: float = 0.8, task_kwargs: Optional[dict] = None, device=None,
+                 max_episode_steps: int = 1000, auto_reset: bool = False, seed: int = 0, include_position: bool = True,
+                 **kwargs) -> None:
+        import torch  # device memory + streams only
+
+        self._torch = torch
+        self.num_envs = int(num_envs)
+        self._task = maze_task(maze_size_scaling, **(task_kwargs or {}))
+        robot = getattr(model_cls, "ROBOT", None)
+        if robot not in ("ant", "point"):
+            raise NotImplementedError(f"robot {model_cls.__name__} has no device kernel yet (SURVEY §8f)")
+        self.model: CompiledModel = compile_model(
+            robot, self._task, maze_size_scaling, inner_reward_scaling=inner_reward_scaling,
+            restitution_coef=restitution_coef, maze_height=maze_height, max_episode_steps=max_episode_steps,
+            forward_reward_weight=kwargs.pop("forward_reward_weight", 1.0), ctrl_cost_weight=kwargs.pop("ctrl_cost_weight", 1e-4),
+            manual_collision=model_cls.MANUAL_COLLISION, radius=model_cls.RADIUS)
+        self.wrapped_cls = model_cls
+        if not torch.cuda.is_available():
+            raise _capi.MazeStepError("no GPU visible: mujoco_maze_amd steps environments on an MI355X only (no CPU fallback)")
+        self._lib = _capi.load()
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        err = C.create_string_buffer(256)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._h = self._lib.mz_create(C.byref(self.model.c), self.num_envs, idx, err, 256)
+        if not self._h:
+            raise _capi.MazeStepError(f"mz_create failed: {err.value.decode()}")
+        m = self.model.c
+        self.nq, self.nv, self.nu, self.obs_dim = m.nq, m.nv, m.nu, m.obs_dim
+        n, dev = self.num_envs, self.device
+        self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=dev)
+        self._reward = torch.empty(n, dtype=torch.float32, device=dev)
+        self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._goal = torch.empty(n, dtype=torch.int32, device=dev)
+        self._info = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        self._seed = int(seed)
+        self.set_option("auto_reset", 1.0 if auto_reset else 0.0)
+        lo = np.array([m.act_ctrlrange[a][0] for a in range(m.nu)], dtype=np.float32)
+        hi = np.array([m.act_ctrlrange[a][1] for a in range(m.nu)], dtype=np.float32)
+        self.action_space = Box(lo, hi)
+        high = np.full(self.obs_dim, np.inf, dtype=np.float32)
+        low = -high
+        low[0], high[0], low[1], high[1] = self.model.world.xy_limits()
+        self.observation_space = Box(low, high)
+        self._host_rewards = not self.model.device_rewards
+
+    # -- plumbing ----------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_option(self, key: str, value: float) -> None:
+        _capi.check(self._lib, self._h, self._lib.mz_set_option(self._h, key.encode(), float(value)), f"mz_set_option({key})")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._torch.cuda.synchronize(self.device)
+            self._lib.mz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- API ---------------------------------------------------------------
+    def reset(self, mask=None, seed: Optional[int] = None):
+        """Reset all (or the masked) envs; returns the observation tensor [N, obs_dim] on the GPU."""
+        if seed is not None:
+            self._seed = int(seed)
+        mk = None
+        if mask is not None:
+            mk = self._torch.as_tensor(mask, device=self.device).to(self._torch.uint8).contiguous()
+        rc = self._lib.mz_reset(self._h, _ptr(mk), C.c_uint64(self._seed), _ptr(self._obs), self._stream())
+        _capi.check(self._lib, self._h, rc, "mz_reset")
+        self._seed += 1
+        return self._obs
+
+    def step(self, actions):
+        """actions: float32 tensor [N, nu] on the same GPU.  Returns (obs, reward, done, info) tensors;
+        `done` is uint8 with bit0 = task termination, bit1 = TimeLimit truncation."""
+        torch = self._torch
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32), device=self.device)
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(a.shape) != (self.num_envs, self.nu):
+            raise ValueError(f"actions must have shape {(self.num_envs, self.nu)}, got {tuple(a.shape)}")
+        rc = self._lib.mz_step(self._h, _ptr(a), _ptr(self._obs), _ptr(self._reward), _ptr(self._done), _ptr(self._goal),
+                               _ptr(self._info), self._stream())
+        _capi.check(self._lib, self._h, rc, "mz_step")
+        if self._host_rewards:
+            self._apply_host_task()
+        info = {"position": self._info[:, :2], "reward_forward": self._info[:, 2], "reward_ctrl": self._info[:, 3],
+                "goal_index": self._goal}
+        return self._obs, self._reward, self._done, info
+
+    def _apply_host_task(self):
+        """User-defined Python reward()/termination(): evaluated on the host from the obs batch
+        (the kernel still supplied the inner reward; the task part is recomputed here)."""
+        obs = self._obs.double().cpu().numpy()
+        inner = (self._info[:, 2] + self._info[:, 3]).double().cpu().numpy() * self.model.c.inner_reward_scaling
+        if self.model.c.robot == 0:
+            inner[:] = 0.0
+        rew = np.array([self._task.reward(o) for o in obs]) + inner
+        term = np.array([bool(self._task.termination(o)) for o in obs])
+        trunc = (self._done.cpu().numpy() & 2)
+        self._reward.copy_(self._torch.as_tensor(rew, dtype=self._torch.float32))
+        self._done.copy_(self._torch.as_tensor((term.astype(np.uint8) | trunc).astype(np.uint8)))
+
+    def get_state(self):
+        torch, n = self._torch, self.num_envs
+        qpos = torch.empty((n, self.nq), dtype=torch.float32, device=self.device)
+        qvel = torch.empty((n, self.nv), dtype=torch.float32, device=self.device)
+        warm = torch.empty((n, self.nv), dtype=torch.float32, device=self.device)
+        t = torch.empty(n, dtype=torch.int32, device=self.device)
+        _capi.check(self._lib, self._h, self._lib.mz_get_state(self._h, _ptr(qpos), _ptr(qvel), _ptr(warm), _ptr(t), self._stream()), "mz_get_state")
+        return qpos, qvel, warm, t
+
+    def set_state(self, qpos=None, qvel=None, warmstart=None, t=None):
+        torch = self._torch
+
+        def prep(x, dt, shape):
+            if x is None:
+                return None
+            x = torch.as_tensor(x, device=self.device).to(dt).contiguous()
+            if tuple(x.shape) != shape:
+                raise ValueError(f"expected shape {shape}, got {tuple(x.shape)}")
+            return x
+
+        n = self.num_envs
+        qpos = prep(qpos, torch.float32, (n, self.nq)); qvel = prep(qvel, torch.float32, (n, self.nv))
+        warmstart = prep(warmstart, torch.float32, (n, self.nv)); t = prep(t, torch.int32, (n,))
+        rc = self._lib.mz_set_state(self._h, _ptr(qpos), _ptr(qvel), _ptr(warmstart), _ptr(t), self._stream())
+        _capi.check(self._lib, self._h, rc, "mz_set_state")
+        torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
+
+    def status(self):
+        out = self._torch.empty(self.num_envs, dtype=self._torch.int32, device=self.device)
+        _capi.check(self._lib, self._h, self._lib.mz_get_status(self._h, _ptr(out), self._stream()), "mz_get_status")
+        return out
+
+    def debug_forward(self, actions=None):
+        torch, n = self._torch, self.num_envs
+        qacc = torch.empty((n, self.nv), dtype=torch.float32, device=self.device)
+        counts = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+        a = None if actions is None else torch.as_tensor(actions, device=self.device).to(torch.float32).contiguous()
+        _capi.check(self._lib, self._h, self._lib.mz_debug_forward(self._h, _ptr(a), _ptr(qacc), _ptr(counts), self._stream()), "mz_debug_forward")
+        return qacc, counts
+
+    def kernel_ms(self) -> float:
+        return float(self._lib.mz_last_kernel_ms(self._h))
+
+    @property
+    def has_extended_obs(self) -> bool:
+        return bool(self._task.TOP_DOWN_VIEW or self._task.OBSERVE_BLOCKS or self._task.OBSERVE_BALLS)
+
+
+class MazeEnv:
+    """Single environment with the reference's constructor and step/reset shapes."""
+
+    def __init__(self, model_cls: Type[AgentModel], maze_task: Type[MazeTask] = MazeTask, include_position: bool = True,
+                 maze_height: float = 0.5, maze_size_scaling: float = 4.0, inner_reward_scaling: float = 1.0,
+                 restitution_coef: float = 0.8, task_kwargs: Optional[dict] = None, websock_port: Optional[int] = None,
+                 camera_move_x=None, camera_move_y=None, camera_zoom=None, image_shape: Tuple[int, int] = (600, 480),
+                 **kwargs) -> None:
+        self.vec = VecMazeEnv(model_cls, maze_task, num_envs=1, maze_height=maze_height, maze_size_scaling=maze_size_scaling,
+                              inner_reward_scaling=inner_reward_scaling, restitution_coef=restitution_coef,
+                              task_kwargs=task_kwargs, **kwargs)
+        self._task = self.vec._task
+        self.t = 0
+        self.action_space = self.vec.action_space
+        self.observation_space = self.vec.observation_space
+        self._max_steps = self.vec.model.c.max_episode_steps
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def has_extended_obs(self) -> bool:
+        return self.vec.has_extended_obs
+
+    @property
+    def _observe_balls(self) -> bool:
+        return self._task.OBSERVE_BALLS
+
+    def reset(self, **kwargs):
+        self.t = 0
+        obs = self.vec.reset(seed=kwargs.get("seed"))
+        return obs[0].double().cpu().numpy(), {}
+
+    def step(self, action):
+        self.t += 1
+        a = np.asarray(action, dtype=np.float32).reshape(1, -1)
+        obs, reward, done, info = self.vec.step(a)
+        d = int(done[0].item())
+        out_info = {"position": info["position"][0].double().cpu().numpy(),
+                    "reward_forward": float(info["reward_forward"][0]), "reward_ctrl": float(info["reward_ctrl"][0])}
+        if d & 2:
+            out_info["TimeLimit.truncated"] = not (d & 1)
+        return obs[0].double().cpu().numpy(), float(reward[0].item()), bool(d), out_info
+
+    def close(self) -> None:
+        self.vec.close()

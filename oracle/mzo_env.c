@@ -304,3 +304,18 @@ void mzo_raw_steps(const mz_model* m, double* qpos, double* qvel, const double* 
   memcpy(qpos, d.qpos, sizeof(double) * m->nq);
   memcpy(qvel, d.qvel, sizeof(double) * m->nv);
 }
+
+/* diagnostics: list the contacts of one state: out[c] = (geom1, geom2, dist, pos[3], normal[3]) */
+int mzo_list_contacts(const mz_model* m, const double* qpos, const double* qvel, double* out, int maxc) {
+  mzo_data d;
+  memset(&d, 0, sizeof(d));
+  memcpy(d.qpos, qpos, sizeof(double) * m->nq);
+  memcpy(d.qvel, qvel, sizeof(double) * m->nv);
+  mzo_forward(m, &d, NULL);
+  for (int c = 0; c < d.ncon && c < maxc; c++) {
+    double* o = out + 9 * c;
+    o[0] = d.con[c].geom1; o[1] = d.con[c].geom2; o[2] = d.con[c].dist;
+    for (int k = 0; k < 3; k++) { o[3 + k] = d.con[c].pos[k]; o[6 + k] = d.con[c].frame[k]; }
+  }
+  return d.ncon;
+}

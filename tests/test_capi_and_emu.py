@@ -1,0 +1,112 @@
+"""CPU-side checks of the product's boundary and of the kernel logic.
+
+* the C-ABI library loads and exports every symbol include/mazestep.h declares (no
+  compute calls without a GPU);
+* the product refuses to run without a GPU (no CPU fallback);
+* the kernel's lane-group source (csrc/ant_dyn.h), compiled for the host by the
+  one-lane emulation in tests/emu, agrees with the float64 oracle after one full
+  MazeEnv.step — this is how kernel logic and fp32 numerics are iterated on a box
+  without a GPU; the GPU tests repeat it on the real device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mujoco_maze_amd as mm
+from mujoco_maze_amd import _capi, model
+from mujoco_maze_amd import maze_task as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    lib = _capi.load()
+    header = open(os.path.join(ROOT, "include", "mazestep.h")).read()
+    declared = set(re.findall(r"\b(mz_[a-z_0-9]+)\s*\(", header))
+    declared -= {"mz_handle", "mz_model"}
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mz_abi_version() == model.MZ_ABI_VERSION
+    assert lib.mz_model_sizeof() == model.C.sizeof(model.MzModel)
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_capi.MazeStepError):
+        mm.make("AntUMaze-v0", num_envs=4)
+    # and the package never imports the oracle or the emulation
+    for root, _, files in os.walk(os.path.join(ROOT, "mujoco_maze_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("no oracle", "") or f == "model.py", f
+                assert "emu_lib" not in src and "libmzo" not in src and "libantemu" not in src, f
+
+
+def _f32(st):
+    out = {k: v.copy() for k, v in st.items()}
+    for k in ("qpos", "qvel", "warm"):
+        out[k] = out[k].astype(np.float32).astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("env_id,scale", [("UMaze", 8.0), ("4Rooms", 4.0)])
+def test_kernel_logic_emulation_matches_oracle(oracle, env_id, scale):
+    from tests import emu_lib
+
+    task = T.TaskRegistry.tasks(env_id)[0](scale)
+    cm = model.compile_model("ant", task, scale)
+    n = 128
+    st, _ = oracle.reset(cm, n, 5)
+    rng = np.random.default_rng(0)
+    worst_q = worst_v = 0.0
+    for k in range(61):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32).astype(np.float64)
+        if k in (0, 1, 10, 60):
+            s64 = _f32(st)
+            s32 = emu_lib.f32_state(s64)
+            ro = oracle.step(cm, s64, act, nthreads=8)
+            re_ = emu_lib.env_step(cm, s32, act)
+            assert np.all(np.abs(s32["qpos"] - s64["qpos"]) <= 1e-5 + 1e-5 * np.abs(s64["qpos"]))
+            assert np.all(np.abs(s32["qvel"] - s64["qvel"]) <= 1e-5 + 1e-5 * np.abs(s64["qvel"]))
+            assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 1e-5 + 1e-5 * np.abs(ro["obs"]))
+            assert np.abs(re_["reward"] - ro["reward"]).max() < 1e-6
+            assert np.array_equal(re_["done"], ro["done"]) and np.array_equal(re_["goal_idx"], ro["goal_idx"])
+            assert np.all((re_["status"] & 3) == 0)
+            worst_q = max(worst_q, np.abs(s32["qpos"] - s64["qpos"]).max())
+            worst_v = max(worst_v, np.abs(s32["qvel"] - s64["qvel"]).max())
+        oracle.step(cm, st, act, nthreads=8)
+    assert worst_q < 2e-6 and worst_v < 1e-5
+
+
+def test_kernel_logic_wall_contacts(oracle):
+    """Sphere-box / capsule-box contacts against maze walls: identical contact sets and accelerations."""
+    from tests import emu_lib
+
+    cm = model.compile_model("ant", T.DistRewardUMaze(8.0), 8.0)
+    n = 64
+    st, _ = oracle.reset(cm, n, 9)
+    rng = np.random.default_rng(1)
+    for _ in range(30):
+        oracle.step(cm, st, rng.uniform(-30, 30, (n, 8)), nthreads=8)
+    st["qpos"][:, 0] = 19.0 + rng.uniform(0.0, 0.9, n)  # east wall face of the start row is at x = 20
+    st["qpos"][:, 1] = rng.uniform(-3.5, 3.5, n)        # some near the corner walls at y = +-4
+    st["qvel"][:, 0] = 2.0
+    st = _f32(st)
+    act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+    f = emu_lib.forward(cm, st["qpos"], st["qvel"], act, st["warm"])
+    g = oracle.forward(cm, st["qpos"], st["qvel"], act.astype(np.float64), st["warm"])
+    assert np.array_equal(f["counts"][:, 0], g["counts"][:, 0])
+    floor_only = oracle.forward(cm, st["qpos"] - np.array([10.0] + [0] * 14), st["qvel"], act.astype(np.float64), st["warm"])
+    assert (g["counts"][:, 0] > floor_only["counts"][:, 0]).sum() > n // 2  # wall contacts really present
+    err = np.abs(f["qacc"] - g["qacc"])
+    assert np.all(err <= 1e-3 + 5e-6 * np.abs(g["qacc"])), err.max()
+    s32 = emu_lib.f32_state(st)
+    ro = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    re_ = emu_lib.env_step(cm, s32, act)
+    assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 2e-5 + 1e-5 * np.abs(ro["obs"]))

@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (north_star: "within 1e-5 fp32 per DoF, bit-exact for termination flags and
+goal indices"): |dev - oracle| <= 1e-5 + 1e-5 * |oracle| on qpos / qvel / obs after ONE
+MazeEnv.step (= 20 forward-dynamics evaluations for the Ant) from an identical fp32
+state; flags exact.  Trajectories are chaotic, so parity is asserted per step from
+injected states (SURVEY §8d "Parity inputs")."""
+import os
+
+import numpy as np
+import pytest
+
+import mujoco_maze_amd as mm
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 1e-5, 1e-5
+
+
+def _close(a, b, atol=ATOL, rtol=RTOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) <= atol + rtol * np.abs(b)
+
+
+def _f32(st):
+    out = {k: v.copy() for k, v in st.items()}
+    for k in ("qpos", "qvel", "warm"):
+        out[k] = out[k].astype(np.float32).astype(np.float64)
+    return out
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_native_library_is_the_in_tree_one(torch):
+    from mujoco_maze_amd import _capi
+
+    lib = _capi.load()
+    assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
+    assert lib.mz_abi_version() == 1
+
+
+def _rollout_states(oracle, cm, n, seed, checkpoints, robot="ant"):
+    rng = np.random.default_rng(seed)
+    st, _ = oracle.reset(cm, n, seed)
+    snaps = {}
+    for k in range(max(checkpoints) + 1):
+        if k in checkpoints:
+            snaps[k] = _f32(st)
+        act = rng.uniform(-30, 30, (n, 8)) if robot == "ant" else np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.25, 0.25, n)], 1)
+        oracle.step(cm, st, act, nthreads=8)
+    return snaps
+
+
+@pytest.mark.parametrize("env_id", ["AntUMaze-v0", "Ant4Rooms-v0"])
+def test_ant_single_step_parity(torch, oracle, env_id):
+    n = 256
+    env = mm.make(env_id, num_envs=n)
+    cm = env.model
+    snaps = _rollout_states(oracle, cm, n, 11, {0, 1, 10, 100})
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for k, st in sorted(snaps.items()):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+        qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
+        ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)  # advances st in place
+        assert np.all(_close(qpos, st["qpos"])), (k, np.abs(qpos - st["qpos"]).max())
+        assert np.all(_close(qvel, st["qvel"])), (k, np.abs(qvel - st["qvel"]).max())
+        assert np.all(_close(obs.cpu().numpy(), ref["obs"]))
+        assert np.all(_close(rew.cpu().numpy(), ref["reward"], atol=1e-6))
+        assert np.array_equal(done.cpu().numpy(), ref["done"])
+        assert np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
+        assert np.all(_close(info["position"].cpu().numpy(), ref["info"][:, :2]))
+        assert np.all(_close(info["reward_forward"].cpu().numpy(), ref["info"][:, 2], atol=1e-4))
+        assert np.array_equal(t, st["t"])
+        worst = max(worst, np.abs(qvel - st["qvel"]).max())
+        bad = env.status().cpu().numpy()
+        assert np.all((bad & 3) == 0)  # no NaN, no contact overflow
+    print(f"{env_id}: worst |qvel - oracle| over checkpoints = {worst:.2e}")
+    env.close()
+
+
+def test_ant_forward_dynamics_and_contact_counts(torch, oracle):
+    n = 256
+    env = mm.make("AntUMaze-v0", num_envs=n)
+    cm = env.model
+    st = _rollout_states(oracle, cm, n, 3, {30})[30]
+    act = np.random.default_rng(1).uniform(-30, 30, (n, 8)).astype(np.float32)
+    env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+    qacc, counts = env.debug_forward(act)
+    ref = oracle.forward(cm, st["qpos"], st["qvel"], act.astype(np.float64), st["warm"])
+    assert np.array_equal(counts.cpu().numpy()[:, 0], ref["counts"][:, 0])  # identical contact sets
+    assert ref["counts"][:, 0].sum() > n  # the fixture really has contacts
+    err = np.abs(qacc.cpu().numpy() - ref["qacc"])
+    assert np.all(err <= 5e-4 + 2e-6 * np.abs(ref["qacc"])), err.max()  # h * 5e-4 = 1e-5 on qvel
+    env.close()
+
+
+def test_ant_lane_group_widths_agree(torch, oracle):
+    n = 128
+    cmref = None
+    outs = {}
+    for g in (8, 16, 32, 64):
+        env = mm.make("AntUMaze-v0", num_envs=n)
+        env.set_option("lanes_per_env", g)
+        cm = env.model
+        if cmref is None:
+            cmref = _rollout_states(oracle, cm, n, 21, {20})[20]
+            act = np.random.default_rng(2).uniform(-30, 30, (n, 8)).astype(np.float32)
+        env.set_state(cmref["qpos"], cmref["qvel"], cmref["warm"], cmref["t"])
+        obs, *_ = env.step(torch.as_tensor(act, device=env.device))
+        outs[g] = obs.cpu().numpy().copy()
+        env.close()
+    for g in (8, 32, 64):
+        assert np.all(_close(outs[g], outs[16])), g
+
+
+def _place_ant(st, xy, yaw=0.0):
+    st["qpos"][:, 0], st["qpos"][:, 1] = xy[0], xy[1]
+    st["qpos"][:, 3] = np.cos(yaw / 2) * np.ones(len(st["qpos"]))
+    st["qpos"][:, 4:6] = 0
+    st["qpos"][:, 6] = np.sin(yaw / 2)
+    return st
+
+
+def test_ant_wall_contacts_and_goal(torch, oracle):
+    """Capsule-box / sphere-box wall contacts (rare under random actions) and the goal flag."""
+    n = 64
+    env = mm.make("AntUMaze-v0", num_envs=n)
+    cm = env.model
+    st = _rollout_states(oracle, cm, n, 8, {40})[40]
+    rng = np.random.default_rng(4)
+    # push half of the ants against the wall east of the start cell (x = 4 is the wall face of the corridor end)
+    st["qpos"][: n // 2, 0] = 19.0 + rng.uniform(0.0, 0.9, n // 2)   # east wall of the top-right cell: face at x = 20
+    st["qpos"][: n // 2, 1] = rng.uniform(-1, 1, n // 2)
+    st["qvel"][: n // 2, 0] = 2.0
+    st["qpos"][n // 2:, 0] = rng.uniform(-0.5, 0.5, n - n // 2)       # goal region (0, 16)
+    st["qpos"][n // 2:, 1] = 16.0 + rng.uniform(-0.7, 0.7, n - n // 2)
+    st = _f32(st)
+    act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+    env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+    _, counts = env.debug_forward(act)
+    fref = oracle.forward(cm, st["qpos"], st["qvel"], act.astype(np.float64), st["warm"])
+    assert np.array_equal(counts.cpu().numpy()[:, 0], fref["counts"][:, 0])
+    obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+    ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=2e-5))
+    assert np.array_equal(done.cpu().numpy(), ref["done"]) and ref["done"][n // 2:].sum() > 5
+    assert np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
+    assert np.all(_close(rew.cpu().numpy(), ref["reward"], atol=1e-6))
+    env.close()
+
+
+def test_point_step_parity_and_bounce(torch, oracle):
+    n = 4096
+    env = mm.make("PointUMaze-v0", num_envs=n)
+    cm = env.model
+    rng = np.random.default_rng(9)
+    xmin, xmax, ymin, ymax = cm.world.xy_limits()
+    st = dict(qpos=np.stack([rng.uniform(xmin, xmax, n), rng.uniform(ymin, ymax, n), rng.uniform(-3.2, 3.2, n)], 1),
+              qvel=np.stack([rng.uniform(0, 0.1, n), rng.uniform(0, 0.1, n), rng.uniform(-12, 12, n)], 1),
+              warm=np.zeros((n, 3)), t=rng.integers(0, 1000, n).astype(np.int32))
+    st["t"][:8] = 999
+    st = _f32(st)
+    act = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.25, 0.25, n)], 1).astype(np.float32)
+    act[: n // 4, 0] *= 4.0  # the reference does not clip actions (point.py:44-55): long teleports -> bounces / give-ups
+    env.set_state(st["qpos"], st["qvel"], None, st["t"])
+    obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+    status = env.status().cpu().numpy()
+    ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    # compare where neither side is in the (not yet modelled) MuJoCo wall-contact regime
+    free = ((status & 16) == 0) & ((ref["status"] & ~8) == 0)
+    assert free.sum() > n // 4
+    o = obs.cpu().numpy()
+    assert np.all(_close(o[free], ref["obs"][free], atol=1e-6))
+    assert np.array_equal(done.cpu().numpy()[free], ref["done"][free])
+    assert np.array_equal(info["goal_index"].cpu().numpy()[free], ref["goal_idx"][free])
+    assert np.array_equal(rew.cpu().numpy()[free], ref["reward"][free].astype(np.float32))
+    assert np.all(done.cpu().numpy()[:8] & 2)
+    env.close()
+
+
+def test_reset_distribution_and_oracle_rng(torch, oracle):
+    n = 2048
+    for env_id, nq, nv in (("AntUMaze-v0", 15, 14), ("PointUMaze-v0", 3, 3)):
+        env = mm.make(env_id, num_envs=n)
+        obs = env.reset(seed=1234).cpu().numpy()
+        ref_st, ref_obs = oracle.reset(env.model, n, 1234)
+        assert np.abs(obs - ref_obs).max() < 2e-6
+        q0 = np.array(env.model.c.qpos0[:nq])
+        assert np.all(np.abs(obs[:, :nq] - q0) <= 0.1 + 1e-6)  # ant.py:85-89 / point.py:72-74
+        assert np.all(obs[:, -1] == 0.0)
+        v = obs[:, nq:nq + nv]
+        if nq == 3:
+            assert v.min() >= 0.0 and v.max() < 0.1 + 1e-6  # point.py:75: U[0,1) * 0.1
+        else:
+            assert abs(v.std() - 0.1) < 0.01 and abs(v.mean()) < 0.01  # ant.py:90: randn * 0.1
+        # masked reset leaves the others untouched
+        a = np.zeros((n, env.nu), np.float32)
+        env.step(a)
+        before = env.get_state()[0].cpu().numpy()
+        mask = np.zeros(n, np.uint8); mask[::2] = 1
+        env.reset(mask=mask, seed=99)
+        after = env.get_state()[0].cpu().numpy()
+        assert np.array_equal(after[1::2], before[1::2]) and not np.array_equal(after[::2], before[::2])
+        env.close()
+
+
+def test_full_size_properties(torch):
+    """BASELINE size (4096 envs): size-independent properties over a 60-step rollout with auto-reset."""
+    n = 4096
+    env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True)
+    env.reset(seed=5)
+    g = torch.Generator(device=env.device).manual_seed(0)
+    goal = torch.tensor([0.0, 16.0], device=env.device)
+    for k in range(60):
+        act = (torch.rand((n, 8), device=env.device, generator=g) * 60 - 30)
+        obs, rew, done, info = env.step(act)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        # termination flag is exactly the predicate on the returned observation (maze_task.py:43-44,77-81)
+        pred = ((obs[:, :2] - goal).norm(dim=1) <= 0.6).to(torch.uint8)
+        assert torch.equal(done & 1, pred)
+        assert torch.all(obs[:, -1] == (k + 1) * 0.001) or (done != 0).any()
+        qn = obs[:, 3:7].norm(dim=1)
+        assert torch.all((qn - 1).abs() < 1e-5)  # integrated quaternions stay unit
+    st = env.status().cpu().numpy()
+    assert np.all((st & 1) == 0), "NaN / diverged envs"
+    assert (st & 2).mean() < 0.01, "contact buffer overflow"
+    # TimeLimit: envs at t = 999 truncate on the next step and auto-reset to t = 0
+    qpos, qvel, warm, t = env.get_state()
+    t[:] = 999
+    env.set_state(t=t)
+    obs, rew, done, info = env.step(torch.zeros((n, 8), device=env.device))
+    assert torch.all(done & 2)
+    assert torch.all(env.get_state()[3] == 0)
+    env.close()
+
+
+def test_single_env_facade_shapes(torch):
+    """What the reference's tests/test_envs.py pins: obs shapes and reward sign."""
+    rng = np.random.default_rng(0)
+    for maze_id in ("UMaze", "4Rooms", "SimpleRoom", "Corridor"):
+        for i in range(2):
+            env = mm.make(f"Ant{maze_id}-v{i}")
+            s0, info = env.reset()
+            s, r, d, inf = env.step(env.action_space.sample(rng))
+            assert s0.shape == (30,) and s.shape == (30,) and s.dtype == np.float64
+            assert set(inf) >= {"position", "reward_forward", "reward_ctrl"}
+            env.close()
+            env = mm.make(f"Point{maze_id}-v{i}")
+            s0, _ = env.reset()
+            s, r, d, _ = env.step(env.action_space.sample(rng))
+            assert s0.shape == (7,) and s.shape == (7,)
+            # reference test expects r != 0 for -v0 and r == PENALTY for -v1; both resolve to the goal
+            # reward, so away from the goal both give PENALTY
+            assert r == pytest.approx(env._task.PENALTY) and r < 0.0
+            env.close()
+    env = mm.make("PointTRoom-v0", task_kwargs={"goal": (-2.0, -3.0)})  # tests/test_envs.py:81-86
+    assert env.reset()[0].shape == (7,)
+    env.close()
+    env = mm.make("Point4Rooms-v2")
+    assert len(env._task.goals) > 1
+    env.close()
