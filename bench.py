@@ -33,6 +33,18 @@ ALGO_BYTES_PER_ENV_STEP = 509  # 208 B read + 301 B written (fp32 s
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(model, seconds_target=12.0):
     """Oracle (oracle/libmzo.so, kind 'port') on the host cores, OpenMP over envs."""
     import numpy as np
@@ -40,7 +52,7 @@ def cpu_baseline(model, seconds_target=12.0):
     from tests import oracle_lib
 
     oracle = oracle_lib.load()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = ENVS_PER_GPU
     st, _ = oracle.reset(model, n, 20260928)
     rng = np.random.default_rng(0)
@@ -141,7 +153,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{ENV_ID}, {n} envs/GPU, frame_skip 5 x RK4, random actions U(-30,30)^8, auto-reset",
                        "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
-                       "lanes_per_env": args.lanes or 16, "bad_envs": bad},
+                       "lanes_per_env": args.lanes or 32, "bad_envs": bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "kernel": "ant_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,

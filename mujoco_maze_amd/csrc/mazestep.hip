@@ -352,7 +352,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   mz_handle* h = new (std::nothrow) mz_handle();
   if (!h) return fail("mz_create: out of memory");
   memset(h, 0, sizeof(*h));
-  h->model = *model; h->n = num_envs; h->device = device; h->robot = model->robot; h->lanes = 16; h->seed = 0x5EEDULL;
+  h->model = *model; h->n = num_envs; h->device = device; h->robot = model->robot; h->lanes = 32; h->seed = 0x5EEDULL;
   char msg[200] = {0};
   int rc = MZ_OK;
   if (model->robot == MZ_ROBOT_ANT) rc = ant_dev_from_model(&h->ant, model, msg, sizeof(msg));
@@ -479,9 +479,9 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   if (h->robot == MZ_ROBOT_ANT) {
     switch (h->lanes) {
       case 8: launch_ant_step<8>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      case 32: launch_ant_step<32>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 16: launch_ant_step<16>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
       case 64: launch_ant_step<64>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      default: launch_ant_step<16>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      default: launch_ant_step<32>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
     }
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
@@ -507,9 +507,9 @@ int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev
   hipStream_t st = (hipStream_t)stream;
   switch (h->lanes) {
     case 8: launch_ant_forward<8>(h, st, actions_dev, qacc_dev, counts_dev); break;
-    case 32: launch_ant_forward<32>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    case 16: launch_ant_forward<16>(h, st, actions_dev, qacc_dev, counts_dev); break;
     case 64: launch_ant_forward<64>(h, st, actions_dev, qacc_dev, counts_dev); break;
-    default: launch_ant_forward<16>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    default: launch_ant_forward<32>(h, st, actions_dev, qacc_dev, counts_dev); break;
   }
   HIPCHK(h, hipGetLastError());
   return MZ_OK;

@@ -227,7 +227,9 @@ def test_full_size_properties(torch):
         # termination flag is exactly the predicate on the returned observation (maze_task.py:43-44,77-81)
         pred = ((obs[:, :2] - goal).norm(dim=1) <= 0.6).to(torch.uint8)
         assert torch.equal(done & 1, pred)
-        assert torch.all(obs[:, -1] == (k + 1) * 0.001) or (done != 0).any()
+        fresh = done == 0  # envs that have not auto-reset yet carry the global step count
+        if k < 5:
+            assert torch.allclose(obs[:, -1][fresh], torch.tensor((k + 1) * 0.001, device=env.device))
         qn = obs[:, 3:7].norm(dim=1)
         assert torch.all((qn - 1).abs() < 1e-5)  # integrated quaternions stay unit
     st = env.status().cpu().numpy()

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs under gpurun_out/prof_<tag> into profiles/<tag>_summary.md (+ trimmed CSV)."""
+import csv, glob, os, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+lines = [f"# rocprofv3 summary — {tag}", "", "command: `python bench.py --steps 100 --warmup 30 --no-cpu-baseline` (AntUMaze-v0, 4096 envs, 1 x MI355X)", ""]
+for f in glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True):
+    lines += ["## kernel stats (`rocprofv3 --kernel-trace --stats`)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(f)):
+        name = r["Name"].split("(")[0][:60]
+        lines.append(f"| {name} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+    lines.append("")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{src}/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for extra in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size"):
+            if extra in r: agg[k]["_" + extra] = [float(r[extra])]
+lines += ["## PMC counters (separate `--pmc` passes), per-launch averages", ""]
+for k, d in agg.items():
+    if "ant_step" not in k and "point_step" not in k: continue
+    lines += [f"### {k[:70]}", "", "| counter | avg per launch | launches |", "|---|---|---|"]
+    for c, v in sorted(d.items()):
+        lines.append(f"| {c} | {sum(v)/len(v):.4g} | {len(v)} |")
+    lines.append("")
+open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines))
+print("\n".join(lines))
