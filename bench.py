@@ -103,19 +103,20 @@ def main():
     env = mm.make(ENV_ID, num_envs=n, auto_reset=True, device=dev, force_vec=True)
     if args.lanes:
         env.set_option("lanes_per_env", args.lanes)
-    env.reset(seed=20260928 + rank)
+    from mujoco_maze_amd import sharding
+
+    lo, _ = sharding.shard_range(rank, world, n)
+    env.set_option("env_index_offset", float(lo))  # reset noise keyed by the global env slot
+    env.reset(seed=20260928)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = [(torch.rand((n, 8), device=dev, generator=g) * 60.0 - 30.0) for _ in range(32)]  # U(-30, 30)^8
-    packed = torch.empty((n, 32), dtype=torch.float32, device=dev)
-    gathered = torch.empty((n * world, 32), dtype=torch.float32, device=dev) if world > 1 else None
+    gatherer = sharding.RecordGatherer(n, env.obs_dim, dev) if (world > 1 and not args.no_gather) else None
 
     def one_step(i):
         obs, rew, done, _ = env.step(pool[i % len(pool)])
-        if world > 1 and not args.no_gather:
-            packed[:, :30] = obs
-            packed[:, 30] = rew
-            packed[:, 31] = done.float()
-            dist.all_gather_into_tensor(gathered, packed)
+        if gatherer is not None:
+            gatherer.wait()                     # previous step's gather must be done before its buffer is reused
+            gatherer.start(obs, rew, done)      # async RCCL all-gather, overlaps the next step's kernel
 
     for i in range(args.warmup):
         one_step(i)
@@ -127,6 +128,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    if gatherer is not None:
+        gatherer.wait()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()

@@ -213,8 +213,10 @@ int32_t mz_nq(const mz_handle* h);
 int32_t mz_nv(const mz_handle* h);
 int32_t mz_nu(const mz_handle* h);
 
-/* Tunables: "auto_reset" (0/1), "solver_iterations", "solver_tolerance",
- * "lanes_per_env" (ant kernel geometry). Returns MZ_OK or MZ_ERR_ARG. */
+/* Tunables: "auto_reset" (0/1), "seed", "env_index_offset" (global slot of local env 0 in a
+ * sharded run: keys the reset RNG), "solver_iterations", "solver_tolerance", "solver_rtol",
+ * "ls_iterations", "lanes_per_env" (8/16/32/64: ant kernel geometry), "time_kernels" (ring of
+ * HIP event pairs around the step kernel). Returns MZ_OK or MZ_ERR_ARG. */
 int32_t mz_set_option(mz_handle* h, const char* key, double value);
 
 /* reset(): envs with mask_dev[i] != 0 (all when NULL) get t = 0 and a fresh state

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void ant_step_kernel(AntDev K, int n, float* __
                                                        float* __restrict__ obs, float* __restrict__ reward,
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
-                                                       uint64_t seed) {
+                                                       uint64_t seed, uint64_t env0) {
   constexpr int EPB = 64 / G;
   __shared__ AntScratch sc[EPB];
   __shared__ float act_s[EPB][ANT_NU], obs_s[EPB][ANT_OBS + 2], out_s[EPB][8];
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(64) void ant_step_kernel(AntDev K, int n, float* __
   if (auto_reset && d) {  // masked reset inside the step
     episode += 1;
     uint64_t es = episode_seed(seed, episode);
-    for (int i = cx.l; i < ANT_NQ; i += G) s.qpos[i] = reset_qpos(K.qpos0[i], es, (uint64_t)env, i);
-    for (int i = cx.l; i < ANT_NV; i += G) { s.qvel[i] = reset_qvel(K.reset_kind, ANT_NQ, es, (uint64_t)env, i); s.warm[i] = 0.f; }
+    for (int i = cx.l; i < ANT_NQ; i += G) s.qpos[i] = reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env, i);
+    for (int i = cx.l; i < ANT_NV; i += G) { s.qvel[i] = reset_qvel(K.reset_kind, ANT_NQ, es, env0 + (uint64_t)env, i); s.warm[i] = 0.f; }
   }
   cx.sync();
   if (live) {
@@ -168,13 +168,13 @@ __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const 
   }
 }
 
-__global__ void ant_reset_kernel(AntDev K, int n, float* state, const uint8_t* mask, uint64_t seed, float* obs) {
+__global__ void ant_reset_kernel(AntDev K, int n, float* state, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   float* rec = state + (size_t)env * ANT_REC;
   if (!mask || mask[env]) {
-    for (int i = 0; i < ANT_NQ; i++) rec[i] = reset_qpos(K.qpos0[i], seed, (uint64_t)env, i);
-    for (int i = 0; i < ANT_NV; i++) { rec[ANT_NQ + i] = reset_qvel(K.reset_kind, ANT_NQ, seed, (uint64_t)env, i); rec[ANT_NQ + ANT_NV + i] = 0.f; }
+    for (int i = 0; i < ANT_NQ; i++) rec[i] = reset_qpos(K.qpos0[i], seed, env0 + (uint64_t)env, i);
+    for (int i = 0; i < ANT_NV; i++) { rec[ANT_NQ + i] = reset_qvel(K.reset_kind, ANT_NQ, seed, env0 + (uint64_t)env, i); rec[ANT_NQ + ANT_NV + i] = 0.f; }
     ((int*)rec)[REC_T] = 0;
     ((uint32_t*)rec)[REC_EP] = 0;
   }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void point_step_kernel(const PointDev* __restr
                                                           const float* __restrict__ actions, float* __restrict__ obs,
                                                           float* __restrict__ reward, uint8_t* __restrict__ done,
                                                           int* __restrict__ goal_idx, float* __restrict__ info,
-                                                          int* __restrict__ status, int auto_reset, uint64_t seed) {
+                                                          int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0) {
   __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
   for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
   __syncthreads();
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void point_step_kernel(const PointDev* __restr
   if (auto_reset && d) {
     ep += 1;
     uint64_t es = episode_seed(seed, ep);
-    for (int k = 0; k < 3; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, (uint64_t)env, k); o[3 + k] = reset_qvel(P.reset_kind, 3, es, (uint64_t)env, k); }
+    for (int k = 0; k < 3; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k); o[3 + k] = reset_qvel(P.reset_kind, 3, es, env0 + (uint64_t)env, k); }
     t_new = 0;
   }
   for (int k = 0; k < 6; k++) S.qv[(size_t)k * n + env] = o[k];
@@ -248,13 +248,13 @@ __global__ __launch_bounds__(256) void point_step_kernel(const PointDev* __restr
   S.ep[env] = ep;
 }
 
-__global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, float* obs) {
+__global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   if (!mask || mask[env]) {
     for (int k = 0; k < 3; k++) {
-      S.qv[(size_t)k * n + env] = reset_qpos((float)Pp->qpos0[k], seed, (uint64_t)env, k);
-      S.qv[(size_t)(3 + k) * n + env] = reset_qvel(Pp->reset_kind, 3, seed, (uint64_t)env, k);
+      S.qv[(size_t)k * n + env] = reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k);
+      S.qv[(size_t)(3 + k) * n + env] = reset_qvel(Pp->reset_kind, 3, seed, env0 + (uint64_t)env, k);
     }
     S.t[env] = 0;
     S.ep[env] = 0;
@@ -303,7 +303,7 @@ struct mz_handle {
   uint32_t* pt_ep;
   int* status;
   int auto_reset, lanes;
-  uint64_t seed;
+  uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
   char err[256];
   // kernel timing ring (option "time_kernels")
   int ntime, itime;
@@ -325,7 +325,7 @@ template <int G>
 static void launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   constexpr int EPB = 64 / G;
   hipLaunchKernelGGL(ant_step_kernel<G>, dim3((h->n + EPB - 1) / EPB), dim3(64), 0, st, h->ant, h->n, h->state, a, o, r, d, gi, inf,
-                     h->status, h->auto_reset, h->seed);
+                     h->status, h->auto_reset, h->seed, h->env0);
 }
 template <int G>
 static void launch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
@@ -405,6 +405,7 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!h || !key) return MZ_ERR_ARG;
   if (!strcmp(key, "auto_reset")) { h->auto_reset = value != 0; return MZ_OK; }
   if (!strcmp(key, "seed")) { h->seed = (uint64_t)value; return MZ_OK; }
+  if (!strcmp(key, "env_index_offset")) { h->env0 = (uint64_t)value; return MZ_OK; }
   if (!strcmp(key, "solver_iterations")) { h->ant.max_iter = (int)value; return MZ_OK; }
   if (!strcmp(key, "solver_tolerance")) { h->ant.tol = (float)value; return MZ_OK; }
   if (!strcmp(key, "solver_rtol")) { h->ant.rtol = (float)value; return MZ_OK; }
@@ -432,10 +433,10 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
   hipStream_t st = (hipStream_t)stream;
   h->seed = seed;
   int nb = (h->n + 255) / 256;
-  if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->n, h->state, mask_dev, seed, obs_dev);
+  if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->n, h->state, mask_dev, seed, h->env0, obs_dev);
   else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    hipLaunchKernelGGL(point_reset_kernel, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, obs_dev);
+    hipLaunchKernelGGL(point_reset_kernel, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
   }
   HIPCHK(h, hipGetLastError());
   return MZ_OK;
@@ -486,7 +487,7 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->point_dev, h->n, S, actions_dev, obs_dev,
-                       reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed);
+                       reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
   }
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) { HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st)); h->itime++; }

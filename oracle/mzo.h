@@ -70,8 +70,8 @@ void mzo_env_reset(const mz_model* m, mzo_env_state* s, uint64_t seed, uint64_t 
 void mzo_batch_step(const mz_model* m, int n, double* qpos, double* qvel, double* warm, int32_t* t, const double* actions,
                     double* obs, double* reward, uint8_t* done, int32_t* goal_idx, double* info, int32_t* status,
                     int nthreads, double solver_tol);
-void mzo_batch_reset(const mz_model* m, int n, const uint8_t* mask, uint64_t seed, double* qpos, double* qvel, double* warm,
-                     int32_t* t, double* obs);
+void mzo_batch_reset(const mz_model* m, int n, const uint8_t* mask, uint64_t seed, uint64_t env0, double* qpos, double* qvel,
+                     double* warm, int32_t* t, double* obs);
 /* diagnostics: one forward evaluation per env */
 void mzo_batch_forward(const mz_model* m, int n, const double* qpos, const double* qvel, const double* warm,
                        const double* actions, double* qacc, int32_t* counts, double* Mout, double* bias);

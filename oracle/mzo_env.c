@@ -227,12 +227,12 @@ void mzo_batch_step(const mz_model* m, int n, double* qpos, double* qvel, double
   }
 }
 
-void mzo_batch_reset(const mz_model* m, int n, const uint8_t* mask, uint64_t seed, double* qpos, double* qvel, double* warm,
-                     int32_t* t, double* obs) {
+void mzo_batch_reset(const mz_model* m, int n, const uint8_t* mask, uint64_t seed, uint64_t env0, double* qpos, double* qvel,
+                     double* warm, int32_t* t, double* obs) {
   for (int e = 0; e < n; e++) {
     if (mask && !mask[e]) continue;
     mzo_env_state s;
-    mzo_env_reset(m, &s, seed, (uint64_t)e);
+    mzo_env_reset(m, &s, seed, env0 + (uint64_t)e);
     memcpy(qpos + (size_t)e * m->nq, s.qpos, sizeof(double) * m->nq);
     memcpy(qvel + (size_t)e * m->nv, s.qvel, sizeof(double) * m->nv);
     memset(warm + (size_t)e * m->nv, 0, sizeof(double) * m->nv);

@@ -37,7 +37,7 @@ class Oracle:
         lib.mzo_task_eval.argtypes = [C.POINTER(MzModel), f64p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.mzo_batch_step.argtypes = [C.POINTER(MzModel), C.c_int, f64p, f64p, f64p, i32p, f64p, f64p, f64p, u8p, i32p,
                                        f64p, i32p, C.c_int, C.c_double]
-        lib.mzo_batch_reset.argtypes = [C.POINTER(MzModel), C.c_int, C.c_void_p, C.c_uint64, f64p, f64p, f64p, i32p, f64p]
+        lib.mzo_batch_reset.argtypes = [C.POINTER(MzModel), C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, f64p, f64p, f64p, i32p, f64p]
         lib.mzo_batch_forward.argtypes = [C.POINTER(MzModel), C.c_int, f64p, f64p, f64p, C.c_void_p, f64p, i32p, f64p, f64p]
 
     def forward_report(self, cm, qpos, qvel, ctrl=None, warm=None):
@@ -77,12 +77,12 @@ class Oracle:
         return r.value, bool(d.value), g.value
 
     # -- batch
-    def reset(self, cm, n, seed, mask=None):
+    def reset(self, cm, n, seed, mask=None, env0=0):
         m = cm.c
         st = dict(qpos=np.zeros((n, m.nq)), qvel=np.zeros((n, m.nv)), warm=np.zeros((n, m.nv)), t=np.zeros(n, np.int32))
         obs = np.zeros((n, m.obs_dim))
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data_as(C.c_void_p)
-        self.lib.mzo_batch_reset(C.byref(m), n, mk, seed, st["qpos"], st["qvel"], st["warm"], st["t"], obs)
+        self.lib.mzo_batch_reset(C.byref(m), n, mk, seed, env0, st["qpos"], st["qvel"], st["warm"], st["t"], obs)
         return st, obs
 
     def step(self, cm, st, actions, nthreads=1, tol=0.0):
