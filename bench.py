@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (8/16/32/64); 0 = library default")
+    ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup (1/2/4); 0 = library default")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL obs all-gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -103,6 +104,8 @@ def main():
     env = mm.make(ENV_ID, num_envs=n, auto_reset=True, device=dev, force_vec=True)
     if args.lanes:
         env.set_option("lanes_per_env", args.lanes)
+    if args.wpb:
+        env.set_option("waves_per_block", args.wpb)
     from mujoco_maze_amd import sharding
 
     lo, _ = sharding.shard_range(rank, world, n)
@@ -156,7 +159,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{ENV_ID}, {n} envs/GPU, frame_skip 5 x RK4, random actions U(-30,30)^8, auto-reset",
                        "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
-                       "lanes_per_env": args.lanes or 32, "bad_envs": bad},
+                       "lanes_per_env": args.lanes or 32, "waves_per_block": args.wpb or 1, "bad_envs": bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "kernel": "ant_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,

@@ -249,6 +249,11 @@ int32_t mz_get_status(mz_handle* h, int32_t* status_dev, void* stream);
  * state with ctrl = actions; writes qacc [N, nv] and ncon/nefc [N, 2]. */
 int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev, int32_t* counts_dev, void* stream);
 
+/* Kernel-internal phase timers (option "profile_phases" = 1 selects the instrumented kernel build):
+ * 16 shader-cycle accumulators (phase ids documented in csrc/ant_dyn.h), summed over the first env group
+ * of every workgroup since the last read; out16_host is HOST memory. */
+int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host);
+
 /* Name and average-duration bookkeeping for bench.py: time (ms) of the last
  * mz_step's dominant kernel measured with hipEvents on `stream` when
  * "time_kernels" option is 1; returns < 0 if not available. */

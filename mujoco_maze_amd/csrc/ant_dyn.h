@@ -44,6 +44,7 @@ struct HostCtx {
   MZ_HD void sync() const {}
   MZ_HD float gsum(float x) const { return x; }
   MZ_HD bool any(bool p) const { return p; }
+  template <class S> MZ_HD void tick(S&, int) const {}
 };
 
 // ------------------------------------------------------------------ scratch (LDS) per env
@@ -55,7 +56,8 @@ struct Arrow {       // symmetric matrix with the ant's sparsity
 struct ArrowFactor {
   float inv[4][3];   // inverse of the 2x2 leg blocks
   float T[4][2][6];  // inv * rl
-  float L[6][6];     // Cholesky factor of the Schur complement (lower)
+  float L[6][6];     // Schur complement (lower triangle)
+  float rhs[6];      // reduced right-hand side / root solution
 };
 
 struct AntScratch {
@@ -74,14 +76,18 @@ struct AntScratch {
   ArrowFactor F;
   float grad[14], search[14], Mx[14], Ms[14];
   // contacts
-  int ncon, cnt[13], off[13];
+  int ncon, cnt[13], cbeg[5];    // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); torso contacts [0, cbeg[0])
   int cleg[ANT_NC];              // leg of the contact's body (-1 torso), bit 8.. = class
   float cJ[ANT_NC][3][8];        // [normal, mu*t1, mu*t2] x [root 6, hip, ankle]
-  float caref[ANT_NC][3], cD[ANT_NC], cu[ANT_NC][3], cjv[ANT_NC][3], cg[ANT_NC][3], cW[ANT_NC][5];
+  float cY[ANT_NC][3][8];        // W * J of the current Newton iterate
+  float caref[ANT_NC][3], cD[ANT_NC], cu[ANT_NC][3], cjv[ANT_NC][3], cg[ANT_NC][3];
   // joint limits (8 hinges)
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   float red[4];
   int status, iters;
+  // optional phase timers (device builds with PROF): cycles per phase id, last timestamp
+  unsigned long long prof_t0;
+  unsigned int prof[16];
 };
 
 // ------------------------------------------------------------------ small helpers
@@ -310,73 +316,6 @@ MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratch& s) {
 }
 
 // ------------------------------------------------------------------ arrow linear algebra
-template <class C>
-MZ_HD void arrow_factor(const C& cx, const Arrow& A, ArrowFactor& F) {
-  MZ_FOR(l, 4) {
-    float hh = A.ll[l][0], ha = A.ll[l][1], aa = A.ll[l][2];
-    float idet = 1.0f / (hh * aa - ha * ha);
-    float ihh = aa * idet, iha = -ha * idet, iaa = hh * idet;
-    F.inv[l][0] = ihh; F.inv[l][1] = iha; F.inv[l][2] = iaa;
-    for (int k = 0; k < 6; k++) {
-      F.T[l][0][k] = ihh * A.rl[l][0][k] + iha * A.rl[l][1][k];
-      F.T[l][1][k] = iha * A.rl[l][0][k] + iaa * A.rl[l][1][k];
-    }
-  }
-  cx.sync();
-  MZ_FOR(e, 21) {
-    int i = 0, j = e;
-    while (j > i) { j -= i + 1; i++; }
-    float v = A.rr[i][j];
-    for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
-    F.L[i][j] = v;
-  }
-  cx.sync();
-  MZ_FOR(one, 1) {  // 6x6 Cholesky, in place on the lower triangle
-    for (int j = 0; j < 6; j++) {
-      float d = F.L[j][j];
-      for (int k = 0; k < j; k++) d -= F.L[j][k] * F.L[j][k];
-      d = sqrtf(fmaxf(d, 1e-30f));
-      F.L[j][j] = d;
-      float id = 1.0f / d;
-      for (int i = j + 1; i < 6; i++) {
-        float t = F.L[i][j];
-        for (int k = 0; k < j; k++) t -= F.L[i][k] * F.L[j][k];
-        F.L[i][j] = t * id;
-      }
-    }
-  }
-  cx.sync();
-}
-// x = A^-1 g  (x and g may alias).  tmp: 6 floats of scratch for the root right-hand side.
-template <class C>
-MZ_HD void arrow_solve(const C& cx, const Arrow& A, const ArrowFactor& F, const float* g, float* x, float* tmp, float sign) {
-  (void)A;
-  MZ_FOR(k, 6) {
-    float r = g[k];
-    for (int l = 0; l < 4; l++) r -= F.T[l][0][k] * g[6 + 2 * l] + F.T[l][1][k] * g[7 + 2 * l];
-    tmp[k] = r;
-  }
-  cx.sync();
-  MZ_FOR(one, 1) {
-    float y[6];
-    for (int i = 0; i < 6; i++) { float t = tmp[i]; for (int k = 0; k < i; k++) t -= F.L[i][k] * y[k]; y[i] = t / F.L[i][i]; }
-    for (int i = 5; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < 6; k++) t -= F.L[k][i] * y[k]; y[i] = t / F.L[i][i]; }
-    for (int i = 0; i < 6; i++) tmp[i] = y[i];
-  }
-  cx.sync();
-  MZ_FOR(i, ANT_NV) {
-    float v;
-    if (i < 6) v = tmp[i];
-    else {
-      int l = (i - 6) >> 1, d = (i - 6) & 1;
-      float gh = g[6 + 2 * l], ga = g[7 + 2 * l];
-      v = d == 0 ? F.inv[l][0] * gh + F.inv[l][1] * ga : F.inv[l][1] * gh + F.inv[l][2] * ga;
-      for (int k = 0; k < 6; k++) v -= F.T[l][d][k] * tmp[k];
-    }
-    x[i] = sign * v;
-  }
-  cx.sync();
-}
 // y_i = (A x)_i for one dof (called inside an MZ_FOR over dofs)
 MZ_HD float arrow_row_mul(const Arrow& A, const float* x, int i) {
   float v = 0.f;
@@ -448,25 +387,25 @@ MZ_HD float seg_box_df(const float* a, const float* dir, const float* bs, float 
   return g;
 }
 MZ_HD float seg_box_t(const float* a, const float* b, const float* bs) {
-  float dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, bp[8];
-  int n = 0;
-  bp[n++] = 0.f;
+  // f(t) = dist^2(segment point, box) is convex with a monotone piecewise-linear derivative g(t) whose kinks
+  // are the slab crossings.  The minimiser lies between the largest candidate with g < 0 and the smallest
+  // with g >= 0 — found without sorting (no dynamically indexed array => no scratch memory on the GPU).
+  float dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  float tlo = 0.f, glo = seg_box_df(a, dir, bs, 0.f);
+  if (glo >= 0.f) return 0.f;
+  float thi = 1.f, ghi = seg_box_df(a, dir, bs, 1.f);
+  if (ghi < 0.f) return 1.f;
   for (int k = 0; k < 3; k++)
     if (fabsf(dir[k]) > 1e-30f) {
-      float t1 = (bs[k] - a[k]) / dir[k], t2 = (-bs[k] - a[k]) / dir[k];
-      if (t1 > 0.f && t1 < 1.f) bp[n++] = t1;
-      if (t2 > 0.f && t2 < 1.f) bp[n++] = t2;
+      for (int sgn = 0; sgn < 2; sgn++) {
+        float t = ((sgn ? -bs[k] : bs[k]) - a[k]) / dir[k];
+        if (t > tlo && t < thi) {
+          float g = seg_box_df(a, dir, bs, t);
+          if (g < 0.f) { tlo = t; glo = g; } else { thi = t; ghi = g; }
+        }
+      }
     }
-  bp[n++] = 1.f;
-  for (int i = 1; i < n; i++) { float v = bp[i]; int j = i - 1; while (j >= 0 && bp[j] > v) { bp[j + 1] = bp[j]; j--; } bp[j + 1] = v; }
-  float g0 = seg_box_df(a, dir, bs, bp[0]);
-  if (g0 >= 0.f) return bp[0];
-  for (int i = 1; i < n; i++) {
-    float g1 = seg_box_df(a, dir, bs, bp[i]);
-    if (g1 >= 0.f) return bp[i - 1] - g0 * (bp[i] - bp[i - 1]) / (g1 - g0);
-    g0 = g1;
-  }
-  return 1.f;
+  return tlo - glo * (thi - tlo) / (ghi - glo);
 }
 
 // Enumerate the contacts of geom (= body) b.  `emit` is called once per contact, in a fixed
@@ -558,7 +497,9 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratch& s) {
       int tot = off + s.cnt[b];
       if (tot > ANT_NC) { tot = ANT_NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
       s.ncon = tot;
+      s.cbeg[4] = tot;
     }
+    if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < ANT_NC ? off : ANT_NC;
     int cls = body_class(b), leg = b == 0 ? -1 : (b - 1) / 3, slot = off;
     float tran = K.bw_tran[cls];
     geom_contacts(K, s, b, [&](const ContactGeo& g) {
@@ -631,57 +572,122 @@ MZ_HD float contact_Jdot(const AntScratch& s, int c, int a, const float* x) {
   if (leg >= 0) v += J[6] * x[6 + 2 * leg] + J[7] * x[7 + 2 * leg];
   return v;
 }
-// column of dof i in contact c's 3x8 Jacobian, -1 when the contact does not see that dof
-MZ_HD int contact_col(const AntScratch& s, int c, int i) {
-  if (i < 6) return i;
-  int leg = s.cleg[c];
-  return ((i - 6) >> 1) == leg ? 6 + ((i - 6) & 1) : -1;
-}
 
-// total cost at x (all lanes get the value); leaves M*(x - qas) in s.Mx
+// Fused factor + solve of an arrow system A x = sign * g:
+//   phase 1 (4 leg lanes)  2x2 inverses and T = inv * rl
+//   phase 2 (27 lanes)     21 Schur-complement entries + 6 reduced right-hand sides
+//   phase 3 (1 lane)       6x6 Cholesky and both substitutions, entirely in registers
+//   phase 4 (14 lanes)     back-substitution of the leg dofs
 template <class C>
-MZ_HD float ant_cost(const C& cx, const AntDev& K, AntScratch& s, const float* x) {
-  (void)K;
-  float part = 0.f;
-  MZ_FOR(i, ANT_NV) s.grad[i] = x[i] - s.qas[i];
-  cx.sync();
-  MZ_FOR(i, ANT_NV) { float v = arrow_row_mul(s.M, s.grad, i); s.Mx[i] = v; part += 0.5f * v * s.grad[i]; }
-  MZ_FOR(c, s.ncon) {
-    float u[3];
-    for (int a = 0; a < 3; a++) u[a] = contact_Jdot(s, c, a, x) - s.caref[c][a];
-    part += contact_eval(s.cD[c], u, nullptr, nullptr);
+MZ_HD void arrow_factor_solve(const C& cx, const Arrow& A, ArrowFactor& F, const float* g, float* x, float sign) {
+  MZ_FOR(l, 4) {
+    float hh = A.ll[l][0], ha = A.ll[l][1], aa = A.ll[l][2];
+    float idet = 1.0f / (hh * aa - ha * ha);
+    float ihh = aa * idet, iha = -ha * idet, iaa = hh * idet;
+    F.inv[l][0] = ihh; F.inv[l][1] = iha; F.inv[l][2] = iaa;
+    for (int k = 0; k < 6; k++) {
+      F.T[l][0][k] = ihh * A.rl[l][0][k] + iha * A.rl[l][1][k];
+      F.T[l][1][k] = iha * A.rl[l][0][k] + iaa * A.rl[l][1][k];
+    }
   }
-  MZ_FOR(j, 8) {
-    if (s.lsign[j] != 0.f) { float jar = s.lsign[j] * x[6 + j] - s.laref[j]; if (jar < 0.f) part += 0.5f * s.lD[j] * jar * jar; }
-  }
-  float tot = cx.gsum(part);
   cx.sync();
-  return tot;
+  MZ_FOR(e, 27) {
+    if (e < 21) {
+      int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : 5;
+      int j = e - (i * (i + 1)) / 2;
+      float v = A.rr[i][j];
+      for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
+      F.L[i][j] = v;
+    } else {
+      int k = e - 21;
+      float r = g[k];
+      for (int l = 0; l < 4; l++) r -= F.T[l][0][k] * g[6 + 2 * l] + F.T[l][1][k] * g[7 + 2 * l];
+      F.rhs[k] = r;
+    }
+  }
+  cx.sync();
+  MZ_FOR(one, 1) {
+    float L[6][6], y[6];
+    for (int i = 0; i < 6; i++) for (int j = 0; j <= i; j++) L[i][j] = F.L[i][j];
+    for (int i = 0; i < 6; i++) y[i] = F.rhs[i];
+    float id[6];
+    for (int j = 0; j < 6; j++) {
+      float d = L[j][j];
+      for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+      float r = 1.0f / sqrtf(fmaxf(d, 1e-30f));
+      id[j] = r;
+      for (int i = j + 1; i < 6; i++) {
+        float t = L[i][j];
+        for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+        L[i][j] = t * r;
+      }
+    }
+    for (int i = 0; i < 6; i++) { float t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * id[i]; }
+    for (int i = 5; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < 6; k++) t -= L[k][i] * y[k]; y[i] = t * id[i]; }
+    for (int i = 0; i < 6; i++) F.rhs[i] = y[i];
+  }
+  cx.sync();
+  MZ_FOR(i, ANT_NV) {
+    float v;
+    if (i < 6) v = F.rhs[i];
+    else {
+      int l = (i - 6) >> 1, d = (i - 6) & 1;
+      float gh = g[6 + 2 * l], ga = g[7 + 2 * l];
+      v = d == 0 ? F.inv[l][0] * gh + F.inv[l][1] * ga : F.inv[l][1] * gh + F.inv[l][2] * ga;
+      for (int k = 0; k < 6; k++) v -= F.T[l][d][k] * F.rhs[k];
+    }
+    x[i] = sign * v;
+  }
+  cx.sync();
 }
 
 template <class C>
 MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
   bool has = false;
   MZ_FOR(one, 1) { bool h = s.ncon > 0; for (int j = 0; j < 8; j++) h = h || s.lsign[j] != 0.f; s.red[0] = h ? 1.f : 0.f; }
+  // warm start: the better of the warm-start acceleration and the unconstrained one (one fused cost pass;
+  // the smooth part of the cost vanishes at qacc_smooth)
+  MZ_FOR(i, ANT_NV) s.grad[i] = s.warm[i] - s.qas[i];
   cx.sync();
   has = s.red[0] != 0.f;
+  float cw = 0.f, cs = 0.f;
+  MZ_FOR(i, ANT_NV) cw += 0.5f * arrow_row_mul(s.M, s.grad, i) * s.grad[i];
+  MZ_FOR(c, s.ncon) {
+    float uw[3], us[3];
+    for (int a = 0; a < 3; a++) { uw[a] = contact_Jdot(s, c, a, s.warm) - s.caref[c][a]; us[a] = contact_Jdot(s, c, a, s.qas) - s.caref[c][a]; }
+    cw += contact_eval(s.cD[c], uw, nullptr, nullptr);
+    cs += contact_eval(s.cD[c], us, nullptr, nullptr);
+  }
+  MZ_FOR(j, 8) {
+    if (s.lsign[j] != 0.f) {
+      float jw = s.lsign[j] * s.warm[6 + j] - s.laref[j], js = s.lsign[j] * s.qas[6 + j] - s.laref[j];
+      if (jw < 0.f) cw += 0.5f * s.lD[j] * jw * jw;
+      if (js < 0.f) cs += 0.5f * s.lD[j] * js * js;
+    }
+  }
+  cw = cx.gsum(cw); cs = cx.gsum(cs);
   cx.sync();
-  // warm start: the better of the previous step's acceleration and the unconstrained one
-  float cw = ant_cost(cx, K, s, s.warm), cs = ant_cost(cx, K, s, s.qas);
   MZ_FOR(i, ANT_NV) s.qacc[i] = (has && cw < cs) ? s.warm[i] : s.qas[i];
   cx.sync();
+  cx.tick(s, 4);
   bool done = !has;
   int it = 0;
   while (cx.any(!done) && it < K.max_iter) {
-    // (a) M (qacc - qas) and the per-constraint gradient / curvature terms
+    // (a) M (qacc - qas); per-contact residual u, gradient block g3, curvature W and Y = W J
     MZ_FOR(i, ANT_NV) s.search[i] = s.qacc[i] - s.qas[i];
     cx.sync();
     MZ_FOR(i, ANT_NV) s.Mx[i] = arrow_row_mul(s.M, s.search, i);
     MZ_FOR(c, s.ncon) {
-      float u[3];
+      float u[3], W[5];
       for (int a = 0; a < 3; a++) u[a] = contact_Jdot(s, c, a, s.qacc) - s.caref[c][a];
       for (int a = 0; a < 3; a++) s.cu[c][a] = u[a];
-      contact_eval(s.cD[c], u, s.cg[c], s.cW[c]);
+      contact_eval(s.cD[c], u, s.cg[c], W);
+      for (int k = 0; k < 8; k++) {
+        float n_ = s.cJ[c][0][k], p_ = s.cJ[c][1][k], q_ = s.cJ[c][2][k];
+        s.cY[c][0][k] = W[0] * n_ + W[1] * p_ + W[2] * q_;
+        s.cY[c][1][k] = W[1] * n_ + W[3] * p_;
+        s.cY[c][2][k] = W[2] * n_ + W[4] * q_;
+      }
     }
     MZ_FOR(j, 8) {
       float jar = 0.f, act = 0.f;
@@ -689,63 +695,66 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
       s.ljar[j] = jar; s.lact[j] = act;
     }
     cx.sync();
-    // (b) gradient and Hessian (arrow)
+    // (b) gradient (14 dofs) and Hessian (96 arrow entries); contacts of leg l are the slots [cbeg[l], cbeg[l+1])
     float gpart = 0.f, apart = 0.f;  // |grad|^2 and the squared magnitude of the terms that cancel in it
     MZ_FOR(i, ANT_NV) {
       float g = s.Mx[i], ga = fabsf(g);
-      for (int c = 0; c < s.ncon; c++) {
-        int col = contact_col(s, c, i);
-        if (col >= 0) {
-          float t = s.cJ[c][0][col] * s.cg[c][0] + s.cJ[c][1][col] * s.cg[c][1] + s.cJ[c][2][col] * s.cg[c][2];
-          g += t; ga += fabsf(t);
-        }
+      int c0 = 0, c1 = s.ncon, col = i;
+      if (i >= 6) { int l = (i - 6) >> 1; c0 = s.cbeg[l]; c1 = s.cbeg[l + 1]; col = 6 + ((i - 6) & 1); }
+      for (int c = c0; c < c1; c++) {
+        float t = s.cJ[c][0][col] * s.cg[c][0] + s.cJ[c][1][col] * s.cg[c][1] + s.cJ[c][2][col] * s.cg[c][2];
+        g += t; ga += fabsf(t);
       }
       if (i >= 6 && s.lsign[i - 6] != 0.f) { float t = s.lsign[i - 6] * s.lact[i - 6] * s.ljar[i - 6]; g += t; ga += fabsf(t); }
       s.grad[i] = g;
       gpart += g * g;
       apart += ga * ga;
     }
-    MZ_FOR(e, 81) {  // 21 root-root + 48 root-leg + 12 leg-leg entries
-      int i, j, leg = -1;
-      float base;
-      if (e < 21) { i = 0; j = e; while (j > i) { j -= i + 1; i++; } base = s.M.rr[i][j]; }
-      else if (e < 69) { int q = e - 21; leg = q / 12; int d = (q % 12) / 6; j = q % 6; i = 6 + 2 * leg + d; base = s.M.rl[leg][d][j]; }
-      else { int q = e - 69; leg = q / 3; int t = q % 3; i = 6 + 2 * leg + (t == 2 ? 1 : 0); j = 6 + 2 * leg + (t >= 1 ? 1 : 0); base = s.M.ll[leg][t]; }
-      float acc = base;
-      for (int c = 0; c < s.ncon; c++) {
-        int ci = contact_col(s, c, i), cj = contact_col(s, c, j);
-        if (ci < 0 || cj < 0) continue;
-        const float* W = s.cW[c];
-        float n_i = s.cJ[c][0][ci], p_i = s.cJ[c][1][ci], q_i = s.cJ[c][2][ci];
-        float n_j = s.cJ[c][0][cj], p_j = s.cJ[c][1][cj], q_j = s.cJ[c][2][cj];
-        acc += W[0] * n_i * n_j + W[1] * (n_i * p_j + p_i * n_j) + W[2] * (n_i * q_j + q_i * n_j) + W[3] * p_i * p_j + W[4] * q_i * q_j;
+    MZ_FOR(e, 96) {  // 36 root-root (full square) + 48 root-leg + 12 leg-leg
+      int ci, cj, c0 = 0, c1 = s.ncon;
+      float* dst;
+      float acc;
+      if (e < 36) { ci = e / 6; cj = e - 6 * ci; dst = &s.H.rr[ci][cj]; acc = s.M.rr[ci][cj]; }
+      else if (e < 84) {
+        int q = e - 36, l = q / 12, r = q - 12 * l, d = r / 6;
+        cj = r - 6 * d; ci = 6 + d;
+        c0 = s.cbeg[l]; c1 = s.cbeg[l + 1];
+        dst = &s.H.rl[l][d][cj]; acc = s.M.rl[l][d][cj];
+      } else {
+        int q = e - 84, l = q / 3, t = q - 3 * l;
+        ci = 6 + (t == 2 ? 1 : 0); cj = 6 + (t >= 1 ? 1 : 0);
+        c0 = s.cbeg[l]; c1 = s.cbeg[l + 1];
+        dst = &s.H.ll[l][t]; acc = s.M.ll[l][t];
+        if (t != 1) acc += s.lact[2 * l + (t == 2 ? 1 : 0)];
       }
-      if (e < 21) { s.H.rr[i][j] = acc; s.H.rr[j][i] = acc; }
-      else if (e < 69) { s.H.rl[leg][(i - 6) & 1][j] = acc; }
-      else { int t = (e - 69) % 3; if (t != 1) acc += s.lact[i - 6]; s.H.ll[leg][t] = acc; }
+      for (int c = c0; c < c1; c++)
+        acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
+      *dst = acc;
     }
     float gnorm = sqrtf(cx.gsum(gpart)), anorm = sqrtf(cx.gsum(apart));
     cx.sync();
     // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
     if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
+    cx.tick(s, 5);
     if (!cx.any(!done)) break;
     // (c) Newton direction
-    arrow_factor(cx, s.H, s.F);
-    arrow_solve(cx, s.H, s.F, s.grad, s.search, s.Ms, -1.f);
+    arrow_factor_solve(cx, s.H, s.F, s.grad, s.search, -1.f);
+    cx.tick(s, 6);
     // (d) exact line search on phi(alpha) = cost(qacc + alpha * search)
     float p1 = 0.f, p2 = 0.f;
-    MZ_FOR(i, ANT_NV) { float ms = arrow_row_mul(s.M, s.search, i); s.Ms[i] = ms; p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
+    MZ_FOR(i, ANT_NV) { float ms = arrow_row_mul(s.M, s.search, i); p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
     MZ_FOR(c, s.ncon) for (int a = 0; a < 3; a++) s.cjv[c][a] = contact_Jdot(s, c, a, s.search);
     MZ_FOR(j, 8) s.ljv[j] = s.lsign[j] * s.search[6 + j];
     p1 = cx.gsum(p1); p2 = cx.gsum(p2);
     cx.sync();
-    float lo = 0.f, hi = -1.f, alpha = 0.f;  // hi < 0: no upper bracket yet
+    float lo = 0.f, hi = -1.f, alpha = 0.f, prev_d2 = -1.f;  // hi < 0: no upper bracket yet
+    bool exact = false;
     for (int ls = 0; ls < K.ls_iter; ls++) {
       float d1 = 0.f, d2 = 0.f;
       MZ_FOR(c, s.ncon) {
         float D = s.cD[c];
-        float u0 = s.cu[c][0] + alpha * s.cjv[c][0], u1 = s.cu[c][1] + alpha * s.cjv[c][1], u2 = s.cu[c][2] + alpha * s.cjv[c][2];
         float v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
+        float u0 = s.cu[c][0] + alpha * v0, u1 = s.cu[c][1] + alpha * v1, u2 = s.cu[c][2] + alpha * v2;
         float r, v;
         r = u0 + u1; v = v0 + v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
         r = u0 - u1; v = v0 - v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
@@ -757,8 +766,12 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
       }
       d1 = cx.gsum(d1) + p1 + alpha * p2;
       d2 = cx.gsum(d2) + p2;
+      // phi' is piecewise linear: if the slope did not change since the previous iterate, the active set is
+      // the same and alpha (the root of that linear piece) is exact
+      if (d2 == prev_d2) { exact = ls == 1; break; }
+      prev_d2 = d2;
       if (d1 < 0.f) lo = alpha; else hi = alpha;
-      float next = alpha - d1 / d2;                       // Newton step on the piecewise-linear derivative
+      float next = alpha - d1 / d2;                                           // Newton step on phi'
       if (hi >= 0.f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);  // safeguard
       if (!(next > 0.f)) next = hi >= 0.f ? 0.5f * (lo + hi) : 0.f;
       if (fabsf(next - alpha) <= 1e-7f * fabsf(next)) { alpha = next; break; }
@@ -768,20 +781,29 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
     cx.sync();
     MZ_FOR(i, ANT_NV) s.qacc[i] += alpha * s.search[i];
     cx.sync();
+    // The full Newton step stayed inside one active set: the cost is exactly quadratic there, so the new
+    // point is its minimiser — no verification pass needed.
+    if (exact && K.trust_exact) done = true;
+    cx.tick(s, 7);
     it++;
   }
-  MZ_FOR(one, 1) { s.iters = it; if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER; }
+  MZ_FOR(one, 1) { s.iters = it; if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER; s.prof[15] += (unsigned)it; }
   cx.sync();
+  cx.tick(s, 8);
 }
 
 // ------------------------------------------------------------------ one forward-dynamics evaluation: qacc from (qpos, qvel, fact)
 template <class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratch& s) {
+  cx.tick(s, 9);
   ant_kin_crb(cx, K, s);
+  cx.tick(s, 0);
   ant_bias(cx, K, s);
-  arrow_factor(cx, s.M, s.F);
-  arrow_solve(cx, s.M, s.F, s.qfs, s.qas, s.Ms, 1.f);
+  cx.tick(s, 1);
+  arrow_factor_solve(cx, s.M, s.F, s.qfs, s.qas, 1.f);
+  cx.tick(s, 2);
   ant_constraints(cx, K, s);
+  cx.tick(s, 3);
   ant_solve(cx, K, s);
 }
 
@@ -831,6 +853,10 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratch& s) {
       s.accf[i] += bw * s.qacc[i];
       s.Ms[i] = aw * s.qvel[i];   // dX velocity for the position update
       s.Mx[i] = s.x0v[i] + h * aw * s.qacc[i];
+      // initial guess of the next stage's constraint solve = this stage's solution (MuJoCo re-uses the
+      // previous step's; the optimum is unique, only the iteration count changes); after the 4th stage this
+      // is exactly MuJoCo's qacc_warmstart
+      s.warm[i] = s.qacc[i];
     }
     cx.sync();
     if (st < 3) {
@@ -840,7 +866,7 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratch& s) {
     }
   }
   ant_integrate_pos(cx, s, s.x0q, s.accv, h);
-  MZ_FOR(i, ANT_NV) { s.qvel[i] = s.x0v[i] + h * s.accf[i]; s.warm[i] = s.qacc[i]; }
+  MZ_FOR(i, ANT_NV) s.qvel[i] = s.x0v[i] + h * s.accf[i];
   cx.sync();
 }
 

@@ -16,7 +16,7 @@
 
 #include "../../include/mazestep.h"
 
-#define ANT_NC 24     // contact slots per env
+#define ANT_NC 16     // contact slots per env (random-action rollouts peak at 4; overflow is flagged per env)
 #define ANT_NBODY 13  // moving bodies: torso + 4 x (leg, aux, ankle)
 #define ANT_NV 14
 #define ANT_NQ 15
@@ -59,7 +59,7 @@ struct AntDev {
   float qpos0[ANT_NQ];
   int reset_kind;
   // solver
-  int max_iter, ls_iter;
+  int max_iter, ls_iter, trust_exact;
   float tol, rtol, inv_scale;  // inv_scale = 1 / (meaninertia * nv)
 };
 
@@ -158,7 +158,7 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
   task_dev_from_model(&a->task, m);
   for (int k = 0; k < ANT_NQ; k++) a->qpos0[k] = (float)m->qpos0[k];
   a->reset_kind = m->reset_qvel_kind;
-  a->max_iter = 8; a->ls_iter = 12; a->tol = 1e-6f; a->rtol = 1e-6f;
+  a->max_iter = 8; a->ls_iter = 12; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
   a->inv_scale = (float)(1.0 / (m->meaninertia * m->nv));
   return MZ_OK;
 }

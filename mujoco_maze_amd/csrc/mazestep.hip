@@ -31,12 +31,29 @@
 #define REC_EP 44
 
 // ------------------------------------------------------------------ device context of a lane group
-template <int G>
+template <int G, bool PROF = false>
 struct DevCtx {
   static constexpr int nlanes = G;
   int l;
+  // phase timer (PROF builds only): lane 0 of the group accumulates shader cycles since the previous tick
+  __device__ __forceinline__ void tick(AntScratch& s, int id) const {
+    if constexpr (PROF) {
+      if (l == 0) {
+        unsigned long long now = __builtin_amdgcn_s_memtime();
+        s.prof[id] += (unsigned)(now - s.prof_t0);
+        s.prof_t0 = now;
+      }
+    }
+  }
   __device__ __forceinline__ int lane0() const { return l; }
-  __device__ __forceinline__ void sync() const { __syncthreads(); }  // one-wavefront workgroup: LDS fence, no cross-wave wait
+  // A lane group never spans wavefronts and LDS operations of one wavefront execute in order, so a
+  // hand-off between lanes of a group needs no s_barrier: a wavefront-scope fence (no instruction, it only
+  // pins the compiler's ordering of the LDS stores before and loads after) is a complete phase boundary.
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   __device__ __forceinline__ float gsum(float x) const {
 #pragma unroll
     for (int m = G / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, G);
@@ -75,8 +92,8 @@ __host__ __device__ __forceinline__ uint64_t episode_seed(uint64_t seed, uint32_
 }
 
 // ------------------------------------------------------------------ Ant kernels
-template <int G>
-__device__ __forceinline__ void ant_load(const DevCtx<G>& cx, AntScratch& s, const float* rec) {
+template <int G, bool P>
+__device__ __forceinline__ void ant_load(const DevCtx<G, P>& cx, AntScratch& s, const float* rec) {
   for (int i = cx.l; i < REC_T; i += G) {
     float v = rec[i];
     if (i < ANT_NQ) s.qpos[i] = v;
@@ -84,50 +101,65 @@ __device__ __forceinline__ void ant_load(const DevCtx<G>& cx, AntScratch& s, con
     else s.warm[i - ANT_NQ - ANT_NV] = v;
   }
 }
-template <int G>
-__device__ __forceinline__ void ant_store(const DevCtx<G>& cx, const AntScratch& s, float* rec) {
+template <int G, bool P>
+__device__ __forceinline__ void ant_store(const DevCtx<G, P>& cx, const AntScratch& s, float* rec) {
   for (int i = cx.l; i < REC_T; i += G) {
     float v = i < ANT_NQ ? s.qpos[i] : (i < ANT_NQ + ANT_NV ? s.qvel[i - ANT_NQ] : s.warm[i - ANT_NQ - ANT_NV]);
     rec[i] = v;
   }
 }
 
+struct AntIO {  // per-env staging of the step's inputs / outputs next to the scratch block
+  float act[ANT_NU], obs[ANT_OBS + 2], out[8];
+  int iout[4];
+};
+struct AntEnvLDS { AntScratch s; AntIO io; };
+
+// Register budget per lane-group width: the batch is fixed (4096 envs/GPU), so the wave count is 64*N/G and
+// the kernel must fit  N*G/64 / 1024 SIMDs  waves per SIMD to be resident in one round.
 template <int G>
-__global__ __launch_bounds__(64) void ant_step_kernel(AntDev K, int n, float* __restrict__ state, const float* __restrict__ actions,
+constexpr int ant_waves_per_simd() { return G >= 64 ? 4 : (G == 32 ? 2 : 1); }
+
+template <int G, bool PROF>
+__global__ __launch_bounds__(256, ant_waves_per_simd<G>()) void ant_step_kernel(AntDev K, int n, float* __restrict__ state, const float* __restrict__ actions,
                                                        float* __restrict__ obs, float* __restrict__ reward,
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
-                                                       uint64_t seed, uint64_t env0) {
-  constexpr int EPB = 64 / G;
-  __shared__ AntScratch sc[EPB];
-  __shared__ float act_s[EPB][ANT_NU], obs_s[EPB][ANT_OBS + 2], out_s[EPB][8];
-  __shared__ int iout_s[EPB][4];
-  DevCtx<G> cx{(int)threadIdx.x % G};
+                                                       uint64_t seed, uint64_t env0, unsigned long long* __restrict__ prof) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  AntEnvLDS* lds = reinterpret_cast<AntEnvLDS*>(lds_raw);
+  const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
+  DevCtx<G, PROF> cx{(int)threadIdx.x % G};
   const int slot = threadIdx.x / G;
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
-  if (!live) env = n - 1;  // surplus groups shadow the last env (no stores) so that every lane reaches every barrier
-  AntScratch& s = sc[slot];
+  if (!live) env = n - 1;  // surplus groups shadow the last env (no stores)
+  AntScratch& s = lds[slot].s;
+  float* act_s = lds[slot].io.act;
+  float* obs_s = lds[slot].io.obs;
+  float* out_s = lds[slot].io.out;
+  int* iout_s = lds[slot].io.iout;
   float* rec = state + (size_t)env * ANT_REC;
   ant_load(cx, s, rec);
-  for (int i = cx.l; i < ANT_NU; i += G) act_s[slot][i] = actions[(size_t)env * ANT_NU + i];
+  for (int i = cx.l; i < ANT_NU; i += G) act_s[i] = actions[(size_t)env * ANT_NU + i];
   int t_in = ((const int*)rec)[REC_T];
   uint32_t episode = ((const uint32_t*)rec)[REC_EP];
+  if constexpr (PROF) { if (cx.l == 0) { for (int k = 0; k < 16; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
   cx.sync();
-  uint8_t* dn = (uint8_t*)&iout_s[slot][0];
-  ant_env_step(cx, K, s, act_s[slot], t_in, obs_s[slot], &out_s[slot][0], dn, &iout_s[slot][1], &out_s[slot][1], &iout_s[slot][2]);
+  uint8_t* dn = (uint8_t*)&iout_s[0];
+  ant_env_step(cx, K, s, act_s, t_in, obs_s, &out_s[0], dn, &iout_s[1], &out_s[1], &iout_s[2]);
   cx.sync();
   const uint8_t d = *dn;
-  const int t_new = iout_s[slot][2];
+  const int t_new = iout_s[2];
   if (live) {
-    for (int i = cx.l; i < ANT_OBS; i += G) obs[(size_t)env * ANT_OBS + i] = obs_s[slot][i];
+    for (int i = cx.l; i < ANT_OBS; i += G) obs[(size_t)env * ANT_OBS + i] = obs_s[i];
     if (cx.l == 0) {
-      reward[env] = out_s[slot][0];
+      reward[env] = out_s[0];
       done[env] = d;
-      if (goal_idx) goal_idx[env] = iout_s[slot][1];
+      if (goal_idx) goal_idx[env] = iout_s[1];
       if (s.status) atomicOr(&status[env], s.status);
     }
-    if (info) for (int i = cx.l; i < 4; i += G) info[(size_t)env * 4 + i] = out_s[slot][1 + i];
+    if (info) for (int i = cx.l; i < 4; i += G) info[(size_t)env * 4 + i] = out_s[1 + i];
   }
   if (auto_reset && d) {  // masked reset inside the step
     episode += 1;
@@ -139,6 +171,10 @@ __global__ __launch_bounds__(64) void ant_step_kernel(AntDev K, int n, float* __
   if (live) {
     ant_store(cx, s, rec);
     if (cx.l == 0) { ((int*)rec)[REC_T] = (auto_reset && d) ? 0 : t_new; ((uint32_t*)rec)[REC_EP] = episode; }
+  }
+  if constexpr (PROF) {
+    cx.tick(s, 10);
+    if (live && threadIdx.x == 0 && prof) for (int k = 0; k < 16; k++) atomicAdd(&prof[k], (unsigned long long)s.prof[k]);
   }
 }
 
@@ -302,7 +338,8 @@ struct mz_handle {
   int* pt_t;
   uint32_t* pt_ep;
   int* status;
-  int auto_reset, lanes;
+  unsigned long long* prof;  // 16 phase-cycle accumulators (option "profile_phases")
+  int auto_reset, lanes, waves_per_block;
   uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
   char err[256];
   // kernel timing ring (option "time_kernels")
@@ -322,10 +359,23 @@ static int set_err(mz_handle* h, int code, const char* what, hipError_t e) {
   } while (0)
 
 template <int G>
-static void launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
-  constexpr int EPB = 64 / G;
-  hipLaunchKernelGGL(ant_step_kernel<G>, dim3((h->n + EPB - 1) / EPB), dim3(64), 0, st, h->ant, h->n, h->state, a, o, r, d, gi, inf,
-                     h->status, h->auto_reset, h->seed, h->env0);
+static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
+  const int wpb = h->waves_per_block, epb = wpb * 64 / G;
+  const size_t lds = (size_t)epb * sizeof(AntEnvLDS);
+  const dim3 grid((h->n + epb - 1) / epb), block(64 * wpb);
+  hipError_t e;
+  if (h->prof) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ant_step_kernel<G, true>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
+                       h->auto_reset, h->seed, h->env0, h->prof);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ant_step_kernel<G, false>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
+                       h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr);
+  }
+  return hipSuccess;
 }
 template <int G>
 static void launch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
@@ -352,7 +402,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   mz_handle* h = new (std::nothrow) mz_handle();
   if (!h) return fail("mz_create: out of memory");
   memset(h, 0, sizeof(*h));
-  h->model = *model; h->n = num_envs; h->device = device; h->robot = model->robot; h->lanes = 32; h->seed = 0x5EEDULL;
+  h->model = *model; h->n = num_envs; h->device = device; h->robot = model->robot; h->lanes = 32; h->waves_per_block = 1; h->seed = 0x5EEDULL;
   char msg[200] = {0};
   int rc = MZ_OK;
   if (model->robot == MZ_ROBOT_ANT) rc = ant_dev_from_model(&h->ant, model, msg, sizeof(msg));
@@ -390,6 +440,7 @@ void mz_destroy(mz_handle* h) {
   if (h->pt_ep) (void)hipFree(h->pt_ep);
   if (h->point_dev) (void)hipFree(h->point_dev);
   if (h->status) (void)hipFree(h->status);
+  if (h->prof) (void)hipFree(h->prof);
   if (h->ev) { for (int i = 0; i < 2 * h->ntime; i++) (void)hipEventDestroy(h->ev[i]); free(h->ev); }
   delete h;
 }
@@ -414,6 +465,17 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
     int g = (int)value;
     if (g != 8 && g != 16 && g != 32 && g != 64) return set_err(h, MZ_ERR_ARG, "lanes_per_env must be 8, 16, 32 or 64", hipSuccess);
     h->lanes = g;
+    return MZ_OK;
+  }
+  if (!strcmp(key, "profile_phases")) {
+    if (value != 0 && !h->prof) { HIPCHK(h, hipMalloc(&h->prof, 16 * sizeof(unsigned long long))); HIPCHK(h, hipMemset(h->prof, 0, 16 * sizeof(unsigned long long))); }
+    if (value == 0 && h->prof) { (void)hipFree(h->prof); h->prof = nullptr; }
+    return MZ_OK;
+  }
+  if (!strcmp(key, "waves_per_block")) {
+    int w = (int)value;
+    if (w != 1 && w != 2 && w != 4) return set_err(h, MZ_ERR_ARG, "waves_per_block must be 1, 2 or 4", hipSuccess);
+    h->waves_per_block = w;
     return MZ_OK;
   }
   if (!strcmp(key, "time_kernels")) {
@@ -478,12 +540,14 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   int slot = -1;
   if (h->ntime > 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
   if (h->robot == MZ_ROBOT_ANT) {
+    hipError_t le;
     switch (h->lanes) {
-      case 8: launch_ant_step<8>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      case 16: launch_ant_step<16>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      case 64: launch_ant_step<64>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      default: launch_ant_step<32>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 8: le = launch_ant_step<8>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 16: le = launch_ant_step<16>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 64: le = launch_ant_step<64>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      default: le = launch_ant_step<32>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
     }
+    HIPCHK(h, le);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->point_dev, h->n, S, actions_dev, obs_dev,
@@ -513,6 +577,15 @@ int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev
     default: launch_ant_forward<32>(h, st, actions_dev, qacc_dev, counts_dev); break;
   }
   HIPCHK(h, hipGetLastError());
+  return MZ_OK;
+}
+
+// Phase timers of the PROF kernel build: copies the 16 accumulators to host memory and clears them.
+int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host) {
+  if (!h || !out16_host || !h->prof) return MZ_ERR_ARG;
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(out16_host, h->prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemset(h->prof, 0, 16 * sizeof(unsigned long long)));
   return MZ_OK;
 }
 

@@ -192,6 +192,12 @@ class VecMazeEnv:
         _capi.check(self._lib, self._h, self._lib.mz_debug_forward(self._h, _ptr(a), _ptr(qacc), _ptr(counts), self._stream()), "mz_debug_forward")
         return qacc, counts
 
+    def phase_cycles(self):
+        """Phase timers of the instrumented kernel (set_option('profile_phases', 1) first)."""
+        out = (C.c_uint64 * 16)()
+        _capi.check(self._lib, self._h, self._lib.mz_read_phase_cycles(self._h, out), "mz_read_phase_cycles")
+        return list(out)
+
     def kernel_ms(self) -> float:
         return float(self._lib.mz_last_kernel_ms(self._h))
 

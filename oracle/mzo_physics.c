@@ -495,36 +495,25 @@ static double seg_box_dfdt(const double* a, const double* dir, const double* s, 
   }
   return g;
 }
-/* parameter t in [0,1] of the segment point closest to the box (box frame). */
+/* parameter t in [0,1] of the segment point closest to the box (box frame): root of the monotone
+ * piecewise-linear derivative, bracketed by the slab-crossing candidates (smallest t on a flat stretch) */
 static double seg_box_closest_t(const double* a, const double* b, const double* s) {
-  double dir[3], bp[8];
-  int n = 0;
+  double dir[3];
   sub3(dir, b, a);
-  bp[n++] = 0.0;
-  for (int k = 0; k < 3; k++) {
-    if (fabs(dir[k]) > 1e-300) {
-      double t1 = (s[k] - a[k]) / dir[k], t2 = (-s[k] - a[k]) / dir[k];
-      if (t1 > 0 && t1 < 1) bp[n++] = t1;
-      if (t2 > 0 && t2 < 1) bp[n++] = t2;
-    }
-  }
-  bp[n++] = 1.0;
-  for (int i = 1; i < n; i++) { /* insertion sort */
-    double v = bp[i]; int j = i - 1;
-    while (j >= 0 && bp[j] > v) { bp[j + 1] = bp[j]; j--; }
-    bp[j + 1] = v;
-  }
-  double g0 = seg_box_dfdt(a, dir, s, bp[0]);
-  if (g0 >= 0) return bp[0];
-  for (int i = 1; i < n; i++) {
-    double g1 = seg_box_dfdt(a, dir, s, bp[i]);
-    if (g1 >= 0) {
-      double t = bp[i - 1] - g0 * (bp[i] - bp[i - 1]) / (g1 - g0);
-      return t;
-    }
-    g0 = g1;
-  }
-  return 1.0;
+  double tlo = 0.0, glo = seg_box_dfdt(a, dir, s, 0.0);
+  if (glo >= 0) return 0.0;
+  double thi = 1.0, ghi = seg_box_dfdt(a, dir, s, 1.0);
+  if (ghi < 0) return 1.0;
+  for (int k = 0; k < 3; k++)
+    if (fabs(dir[k]) > 1e-300)
+      for (int sgn = 0; sgn < 2; sgn++) {
+        double t = ((sgn ? -s[k] : s[k]) - a[k]) / dir[k];
+        if (t > tlo && t < thi) {
+          double g = seg_box_dfdt(a, dir, s, t);
+          if (g < 0) { tlo = t; glo = g; } else { thi = t; ghi = g; }
+        }
+      }
+  return tlo - glo * (thi - tlo) / (ghi - glo);
 }
 
 /* capsule (geom1) vs box (geom2).  [ASSUME-6] MuJoCo's mjc_CapsuleBox feature

@@ -138,7 +138,7 @@ def test_ant_wall_contacts_and_goal(torch, oracle):
     st = _rollout_states(oracle, cm, n, 8, {40})[40]
     rng = np.random.default_rng(4)
     # push half of the ants against the wall east of the start cell (x = 4 is the wall face of the corridor end)
-    st["qpos"][: n // 2, 0] = 19.0 + rng.uniform(0.0, 0.9, n // 2)   # east wall of the top-right cell: face at x = 20
+    st["qpos"][: n // 2, 0] = 18.9 + rng.uniform(0.0, 0.5, n // 2)   # east wall face at x = 20: leg tips touch / dig in <= 0.3
     st["qpos"][: n // 2, 1] = rng.uniform(-1, 1, n // 2)
     st["qvel"][: n // 2, 0] = 2.0
     st["qpos"][n // 2:, 0] = rng.uniform(-0.5, 0.5, n - n // 2)       # goal region (0, 16)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""GPU box helper: per-phase shader-cycle breakdown of ant_step_kernel (instrumented build)."""
+import sys, json
+import torch
+import mujoco_maze_amd as mm
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+n = 4096
+env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True, force_vec=True)
+env.set_option("lanes_per_env", lanes)
+env.reset(seed=1)
+g = torch.Generator(device=env.device).manual_seed(0)
+acts = [(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30) for _ in range(16)]
+for i in range(100): env.step(acts[i % 16])
+env.set_option("profile_phases", 1)
+env.step(acts[0]); env.phase_cycles()
+steps = 50
+for i in range(steps): env.step(acts[i % 16])
+cyc = env.phase_cycles()
+names = ["kin+crb", "bias", "factorM+qas", "constraints", "solve:init(cost x2)", "solve:grad+H", "solve:factor+dir", "solve:linesearch", "solve:tail",
+         "rk4/integrate", "io+epilogue"]
+wgs = n // (64 // lanes)
+tot = sum(cyc[:11])
+print(f"lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")
+for k, nm in enumerate(names):
+    print(f"  {nm:24s} {cyc[k]/steps/wgs:10.0f} cycles/step  {100*cyc[k]/tot:5.1f} %")
