@@ -44,6 +44,7 @@ struct HostCtx {
   MZ_HD void sync() const {}
   MZ_HD float gsum(float x) const { return x; }
   MZ_HD bool any(bool p) const { return p; }
+  MZ_HD bool gany(bool p) const { return p; }
   template <class S> MZ_HD void tick(S&, int) const {}
 };
 
@@ -642,33 +643,42 @@ MZ_HD void arrow_factor_solve(const C& cx, const Arrow& A, ArrowFactor& F, const
 }
 
 template <class C>
-MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
+MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) {
   bool has = false;
   MZ_FOR(one, 1) { bool h = s.ncon > 0; for (int j = 0; j < 8; j++) h = h || s.lsign[j] != 0.f; s.red[0] = h ? 1.f : 0.f; }
-  // warm start: the better of the warm-start acceleration and the unconstrained one (one fused cost pass;
-  // the smooth part of the cost vanishes at qacc_smooth)
-  MZ_FOR(i, ANT_NV) s.grad[i] = s.warm[i] - s.qas[i];
+  cx.sync();
+  // Initial guess.  `compare` (first evaluation of a step): MuJoCo's rule — the better of the warm-start
+  // acceleration and the unconstrained one, by cost (one fused pass; the smooth part vanishes at qacc_smooth).
+  // Later evaluations start from the previous evaluation's solution shifted by the change of the
+  // unconstrained acceleration (s.warm was prepared by the caller); the optimum is unique, so the start only
+  // changes the iteration count.
+  if (compare) {
+    MZ_FOR(i, ANT_NV) s.grad[i] = s.warm[i] - s.qas[i];
+    cx.sync();
+    float cw = 0.f, cs = 0.f;
+    MZ_FOR(i, ANT_NV) cw += 0.5f * arrow_row_mul(s.M, s.grad, i) * s.grad[i];
+    MZ_FOR(c, s.ncon) {
+      float uw[3], us[3];
+      for (int a = 0; a < 3; a++) { uw[a] = contact_Jdot(s, c, a, s.warm) - s.caref[c][a]; us[a] = contact_Jdot(s, c, a, s.qas) - s.caref[c][a]; }
+      cw += contact_eval(s.cD[c], uw, nullptr, nullptr);
+      cs += contact_eval(s.cD[c], us, nullptr, nullptr);
+    }
+    MZ_FOR(j, 8) {
+      if (s.lsign[j] != 0.f) {
+        float jw = s.lsign[j] * s.warm[6 + j] - s.laref[j], js = s.lsign[j] * s.qas[6 + j] - s.laref[j];
+        if (jw < 0.f) cw += 0.5f * s.lD[j] * jw * jw;
+        if (js < 0.f) cs += 0.5f * s.lD[j] * js * js;
+      }
+    }
+    cw = cx.gsum(cw); cs = cx.gsum(cs);
+    cx.sync();
+    MZ_FOR(i, ANT_NV) s.qacc[i] = (cw < cs) ? s.warm[i] : s.qas[i];
+  } else {
+    MZ_FOR(i, ANT_NV) s.qacc[i] = s.warm[i];
+  }
   cx.sync();
   has = s.red[0] != 0.f;
-  float cw = 0.f, cs = 0.f;
-  MZ_FOR(i, ANT_NV) cw += 0.5f * arrow_row_mul(s.M, s.grad, i) * s.grad[i];
-  MZ_FOR(c, s.ncon) {
-    float uw[3], us[3];
-    for (int a = 0; a < 3; a++) { uw[a] = contact_Jdot(s, c, a, s.warm) - s.caref[c][a]; us[a] = contact_Jdot(s, c, a, s.qas) - s.caref[c][a]; }
-    cw += contact_eval(s.cD[c], uw, nullptr, nullptr);
-    cs += contact_eval(s.cD[c], us, nullptr, nullptr);
-  }
-  MZ_FOR(j, 8) {
-    if (s.lsign[j] != 0.f) {
-      float jw = s.lsign[j] * s.warm[6 + j] - s.laref[j], js = s.lsign[j] * s.qas[6 + j] - s.laref[j];
-      if (jw < 0.f) cw += 0.5f * s.lD[j] * jw * jw;
-      if (js < 0.f) cs += 0.5f * s.lD[j] * js * js;
-    }
-  }
-  cw = cx.gsum(cw); cs = cx.gsum(cs);
-  cx.sync();
-  MZ_FOR(i, ANT_NV) s.qacc[i] = (has && cw < cs) ? s.warm[i] : s.qas[i];
-  cx.sync();
+  if (!has) { MZ_FOR(i, ANT_NV) s.qacc[i] = s.qas[i]; cx.sync(); }
   cx.tick(s, 4);
   bool done = !has;
   int it = 0;
@@ -710,7 +720,11 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
       gpart += g * g;
       apart += ga * ga;
     }
-    MZ_FOR(e, 96) {  // 36 root-root (full square) + 48 root-leg + 12 leg-leg
+    float gnorm = sqrtf(cx.gsum(gpart)), anorm = sqrtf(cx.gsum(apart));
+    // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
+    if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
+    if (!cx.any(!done)) { cx.sync(); cx.tick(s, 5); break; }
+    MZ_FOR(e, 96) {  // Hessian: 36 root-root (full square) + 48 root-leg + 12 leg-leg arrow entries
       int ci, cj, c0 = 0, c1 = s.ncon;
       float* dst;
       float acc;
@@ -731,52 +745,65 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
         acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
       *dst = acc;
     }
-    float gnorm = sqrtf(cx.gsum(gpart)), anorm = sqrtf(cx.gsum(apart));
     cx.sync();
-    // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
-    if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
     cx.tick(s, 5);
-    if (!cx.any(!done)) break;
     // (c) Newton direction
     arrow_factor_solve(cx, s.H, s.F, s.grad, s.search, -1.f);
     cx.tick(s, 6);
-    // (d) exact line search on phi(alpha) = cost(qacc + alpha * search)
-    float p1 = 0.f, p2 = 0.f;
-    MZ_FOR(i, ANT_NV) { float ms = arrow_row_mul(s.M, s.search, i); p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
+    // (d) exact line search on phi(alpha) = cost(qacc + alpha * search).  The Newton direction makes
+    // alpha = 1 the exact minimiser whenever the active set at qacc + search equals the one H was built on:
+    // test that first with one ballot; only otherwise find the root of the piecewise-linear phi'.
     MZ_FOR(c, s.ncon) for (int a = 0; a < 3; a++) s.cjv[c][a] = contact_Jdot(s, c, a, s.search);
     MZ_FOR(j, 8) s.ljv[j] = s.lsign[j] * s.search[6 + j];
-    p1 = cx.gsum(p1); p2 = cx.gsum(p2);
     cx.sync();
-    float lo = 0.f, hi = -1.f, alpha = 0.f, prev_d2 = -1.f;  // hi < 0: no upper bracket yet
-    bool exact = false;
-    for (int ls = 0; ls < K.ls_iter; ls++) {
-      float d1 = 0.f, d2 = 0.f;
-      MZ_FOR(c, s.ncon) {
-        float D = s.cD[c];
-        float v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
-        float u0 = s.cu[c][0] + alpha * v0, u1 = s.cu[c][1] + alpha * v1, u2 = s.cu[c][2] + alpha * v2;
-        float r, v;
-        r = u0 + u1; v = v0 + v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
-        r = u0 - u1; v = v0 - v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
-        r = u0 + u2; v = v0 + v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
-        r = u0 - u2; v = v0 - v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
-      }
-      MZ_FOR(j, 8) {
-        if (s.lsign[j] != 0.f) { float r = s.ljar[j] + alpha * s.ljv[j]; if (r < 0.f) { d1 += s.lD[j] * r * s.ljv[j]; d2 += s.lD[j] * s.ljv[j] * s.ljv[j]; } }
-      }
-      d1 = cx.gsum(d1) + p1 + alpha * p2;
-      d2 = cx.gsum(d2) + p2;
-      // phi' is piecewise linear: if the slope did not change since the previous iterate, the active set is
-      // the same and alpha (the root of that linear piece) is exact
-      if (d2 == prev_d2) { exact = ls == 1; break; }
-      prev_d2 = d2;
-      if (d1 < 0.f) lo = alpha; else hi = alpha;
-      float next = alpha - d1 / d2;                                           // Newton step on phi'
-      if (hi >= 0.f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);  // safeguard
-      if (!(next > 0.f)) next = hi >= 0.f ? 0.5f * (lo + hi) : 0.f;
-      if (fabsf(next - alpha) <= 1e-7f * fabsf(next)) { alpha = next; break; }
-      alpha = next;
+    bool changed = false;
+    MZ_FOR(c, s.ncon) {
+      float u0 = s.cu[c][0], u1 = s.cu[c][1], u2 = s.cu[c][2];
+      float w0 = u0 + s.cjv[c][0], w1 = u1 + s.cjv[c][1], w2 = u2 + s.cjv[c][2];
+      changed = changed || ((u0 + u1 < 0.f) != (w0 + w1 < 0.f)) || ((u0 - u1 < 0.f) != (w0 - w1 < 0.f)) ||
+                ((u0 + u2 < 0.f) != (w0 + w2 < 0.f)) || ((u0 - u2 < 0.f) != (w0 - w2 < 0.f));
     }
+    MZ_FOR(j, 8) {
+      if (s.lsign[j] != 0.f) changed = changed || ((s.ljar[j] < 0.f) != (s.ljar[j] + s.ljv[j] < 0.f));
+    }
+    changed = cx.gany(changed);
+    float alpha = 1.f;
+    bool exact = !changed;
+    if (changed) {
+      float p1 = 0.f, p2 = 0.f;
+      MZ_FOR(i, ANT_NV) { float ms = arrow_row_mul(s.M, s.search, i); p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
+      p1 = cx.gsum(p1); p2 = cx.gsum(p2);
+      float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
+      for (int ls = 0; ls < K.ls_iter; ls++) {
+        float d1 = 0.f, d2 = 0.f;
+        MZ_FOR(c, s.ncon) {
+          float D = s.cD[c];
+          float v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
+          float u0 = s.cu[c][0] + alpha * v0, u1 = s.cu[c][1] + alpha * v1, u2 = s.cu[c][2] + alpha * v2;
+          float r, v;
+          r = u0 + u1; v = v0 + v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+          r = u0 - u1; v = v0 - v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+          r = u0 + u2; v = v0 + v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+          r = u0 - u2; v = v0 - v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+        }
+        MZ_FOR(j, 8) {
+          if (s.lsign[j] != 0.f) { float r = s.ljar[j] + alpha * s.ljv[j]; if (r < 0.f) { d1 += s.lD[j] * r * s.ljv[j]; d2 += s.lD[j] * s.ljv[j] * s.ljv[j]; } }
+        }
+        d1 = cx.gsum(d1) + p1 + alpha * p2;
+        d2 = cx.gsum(d2) + p2;
+        if (d2 == prev_d2) break;  // same slope as at the previous iterate: same linear piece, alpha is its root
+        prev_d2 = d2;
+        if (d1 < 0.f) lo = alpha; else hi = alpha;
+        float next = alpha - d1 / d2;                                           // Newton step on phi'
+        if (hi >= 0.f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);  // safeguard
+        if (!(next > 0.f)) next = hi >= 0.f ? 0.5f * (lo + hi) : 0.f;
+        if (fabsf(next - alpha) <= 1e-7f * fabsf(next)) { alpha = next; break; }
+        alpha = next;
+      }
+    }
+#ifdef MZ_TRACE
+    printf("  it %d gnorm %.3e anorm %.3e changed %d alpha %.6f ncon %d\n", it, gnorm, anorm, (int)changed, alpha, s.ncon);
+#endif
     if (done) alpha = 0.f;
     cx.sync();
     MZ_FOR(i, ANT_NV) s.qacc[i] += alpha * s.search[i];
@@ -793,18 +820,22 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s) {
 }
 
 // ------------------------------------------------------------------ one forward-dynamics evaluation: qacc from (qpos, qvel, fact)
+// `first`: first evaluation of an env.step (warm = MuJoCo's qacc_warmstart, compared by cost against
+// qacc_smooth); otherwise s.warm holds the previous evaluation's solution and s.qas its qacc_smooth.
 template <class C>
-MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratch& s) {
+MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratch& s, bool first) {
   cx.tick(s, 9);
   ant_kin_crb(cx, K, s);
   cx.tick(s, 0);
   ant_bias(cx, K, s);
   cx.tick(s, 1);
+  if (!first) { MZ_FOR(i, ANT_NV) s.warm[i] -= s.qas[i]; cx.sync(); }
   arrow_factor_solve(cx, s.M, s.F, s.qfs, s.qas, 1.f);
+  if (!first) { MZ_FOR(i, ANT_NV) s.warm[i] += s.qas[i]; cx.sync(); }
   cx.tick(s, 2);
   ant_constraints(cx, K, s);
   cx.tick(s, 3);
-  ant_solve(cx, K, s);
+  ant_solve(cx, K, s, first);
 }
 
 // qpos <- integrate(qpos, vel, h): free joint on the manifold, hinges linear (MuJoCo mj_integratePos)
@@ -838,13 +869,13 @@ MZ_HD void ant_integrate_pos(const C& cx, AntScratch& s, const float* base, cons
 
 // one mj_step with RK4.  State in s.qpos / s.qvel / s.warm, actuator forces in s.fact.
 template <class C>
-MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratch& s) {
+MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratch& s, bool first_frame) {
   const float h = K.h;
   MZ_FOR(i, 16) { if (i < ANT_NQ) s.x0q[i] = s.qpos[i]; }
   MZ_FOR(i, ANT_NV) { s.x0v[i] = s.qvel[i]; s.accv[i] = 0.f; s.accf[i] = 0.f; }
   cx.sync();
   for (int st = 0; st < 4; st++) {
-    ant_forward(cx, K, s);
+    ant_forward(cx, K, s, first_frame && st == 0);
     const float bw = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float aw = st == 2 ? 1.0f : 0.5f;  // Butcher A: diag(1/2, 1/2, 1)
     // accumulate B-weighted sums, form the next stage state from this stage's (qvel, qacc)
@@ -901,7 +932,7 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratch& s, const float
   cx.sync();
   MZ_FOR(u, ANT_NU) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(action[u], K.ctrl_lo), K.ctrl_hi);
   cx.sync();
-  for (int f = 0; f < K.frame_skip; f++) ant_mj_step(cx, K, s);
+  for (int f = 0; f < K.frame_skip; f++) ant_mj_step(cx, K, s, f == 0);
   int t = t_in + 1;
   MZ_FOR(i, ANT_OBS) {
     float v = i < ANT_NQ ? s.qpos[i] : (i < ANT_NQ + ANT_NV ? s.qvel[i - ANT_NQ] : (float)t * 0.001f);

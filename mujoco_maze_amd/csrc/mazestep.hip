@@ -60,6 +60,13 @@ struct DevCtx {
     return x;
   }
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+  // any() restricted to this lane group: one ballot, no shuffles
+  __device__ __forceinline__ bool gany(bool p) const {
+    unsigned long long b = __ballot(p);
+    unsigned lane = __lane_id();
+    unsigned long long gm = (G >= 64) ? ~0ULL : (((1ULL << (G & 63)) - 1ULL) << (lane - (unsigned)l));
+    return (b & gm) != 0ULL;
+  }
 };
 
 // ------------------------------------------------------------------ RNG (same definition as the oracle's mzo_rng_u32)
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const 
   if (actions)
     for (int u = cx.l; u < ANT_NU; u += G) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(actions[(size_t)env * ANT_NU + u], K.ctrl_lo), K.ctrl_hi);
   cx.sync();
-  ant_forward(cx, K, s);
+  ant_forward(cx, K, s, true);
   if (live) {
     for (int i = cx.l; i < ANT_NV; i += G) qacc[(size_t)env * ANT_NV + i] = s.qacc[i];
     if (cx.l == 0 && counts) { counts[2 * env] = s.ncon; counts[2 * env + 1] = s.iters; }

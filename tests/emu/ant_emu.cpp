@@ -61,7 +61,7 @@ int emu_ant_forward(const mz_model* m, int n, const float* qpos, const float* qv
     if (actions)
       for (int u = 0; u < ANT_NU; u++) s->fact[K.act_dof[u]] = K.gear * fminf(fmaxf(actions[e * ANT_NU + u], K.ctrl_lo), K.ctrl_hi);
     s->status = 0;
-    ant_forward(cx, K, *s);
+    ant_forward(cx, K, *s, true);
     for (int k = 0; k < ANT_NV; k++) qacc[e * ANT_NV + k] = s->qacc[k];
     if (counts) { counts[2 * e] = s->ncon; counts[2 * e + 1] = s->iters; }
     if (bias) for (int k = 0; k < ANT_NV; k++) bias[e * ANT_NV + k] = s->bias[k];
