@@ -72,13 +72,13 @@ struct AntScratch {
   float zw[3];                   // hip axis (world) = R0 * ez
   float Sh[4][3], Sa[4][6];      // hip: linear part (angular = zw); ankle: angular, linear
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
-  float fleg[4][6], ftor[6], bias[14];
+  float fleg[4][6], ftor[6], bias[14], Iall[10];
   Arrow M, H;
   ArrowFactor F;
   float grad[14], search[14], Mx[14], Ms[14];
   // contacts
   int ncon, cnt[13], cbeg[5];    // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); torso contacts [0, cbeg[0])
-  int cleg[ANT_NC];              // leg of the contact's body (-1 torso), bit 8.. = class
+  int cleg[ANT_NC], ccls[ANT_NC]; // leg (-1 torso) and body class of the contact's robot body
   float cJ[ANT_NC][3][8];        // [normal, mu*t1, mu*t2] x [root 6, hip, ankle]
   float cY[ANT_NC][3][8];        // W * J of the current Newton iterate
   float caref[ANT_NC][3], cD[ANT_NC], cu[ANT_NC][3], cjv[ANT_NC][3], cg[ANT_NC][3];
@@ -141,6 +141,7 @@ MZ_HD float impedancef(const float* si, float x) {
   if (xn <= 0.0f) return d0;
   float y;
   if (power <= 1.0f) y = xn;
+  else if (power == 2.0f) y = xn <= mid ? xn * xn / mid : 1.0f - (1.0f - xn) * (1.0f - xn) / (1.0f - mid);  // MuJoCo default
   else if (xn <= mid) y = powf(xn, power) / powf(mid, power - 1.0f);
   else y = 1.0f - powf(1.0f - xn, power) / powf(1.0f - mid, power - 1.0f);
   return d0 + y * (dmax - d0);
@@ -228,15 +229,17 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratch& s) {
       s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
     }
   }
+  MZ_FOR(k, 10) {  // whole-body composite inertia about c
+    float v = 0.f;
+    for (int b = 0; b < ANT_NBODY; b++) v += s.cin[b][k];
+    s.Iall[k] = v;
+  }
+  cx.sync();
   MZ_FOR(e, 21) {  // root 6x6 block from the whole-body composite inertia (lower triangle, mirrored)
-    int i = 0, j = e;
-    while (j > i) { j -= i + 1; i++; }  // e -> (i, j), j <= i
-    float m = 0, h[3] = {0, 0, 0}, J[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < ANT_NBODY; b++) {
-      m += s.cin[b][0];
-      for (int k = 0; k < 3; k++) h[k] += s.cin[b][1 + k];
-      for (int k = 0; k < 6; k++) J[k] += s.cin[b][4 + k];
-    }
+    int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : 5;
+    int j = e - (i * (i + 1)) / 2;
+    float m = s.Iall[0], h[3] = {s.Iall[1], s.Iall[2], s.Iall[3]}, J[6];
+    for (int k = 0; k < 6; k++) J[k] = s.Iall[4 + k];
     float val;
     if (i < 3) val = (i == j) ? m : 0.f;
     else {
@@ -409,6 +412,16 @@ MZ_HD float seg_box_t(const float* a, const float* b, const float* bs) {
   return tlo - glo * (thi - tlo) / (ghi - glo);
 }
 
+// Row bitmask of the cell grid for a per-lane row index.  The grid lives in the kernel-argument block
+// (scalar registers); a select chain keeps it there — indexing the array with a vector index would make the
+// compiler spill it to scratch memory (one ~500-cycle load per probe).
+MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
+  uint32_t m = 0u;
+#pragma unroll
+  for (int r = 0; r < MZ_MAX_GRID; r++) m = (r == i) ? z.rowmask[r] : m;
+  return m;
+}
+
 // Enumerate the contacts of geom (= body) b.  `emit` is called once per contact, in a fixed
 // order (floor contacts first, then wall cells row-major), identical in the count and fill passes.
 template <class Emit>
@@ -445,7 +458,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratch& s, int b, Emit&& emi
   for (int i = i0; i <= i1; i++)
     for (int j = j0; j <= j1; j++) {
       if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
-      if (!((z.rowmask[i] >> j) & 1u)) continue;
+      if (!((maze_row(z, i) >> j) & 1u)) continue;
       // box centre relative to the torso origin, computed so that the large world coordinates cancel first
       float bx = (j * z.scale - z.tx) - s.qpos[0], by = (i * z.scale - z.ty) - s.qpos[1], bz = z.center_z - s.cz;
       float cl[3] = {ctr[0] - bx, ctr[1] - by, ctr[2] - bz};  // geom centre in box coordinates
@@ -490,7 +503,9 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratch& s) {
     s.cnt[b] = n;
   }
   cx.sync();
-  // pass 2: deterministic offsets (exclusive prefix over geoms), fill compact rows
+  cx.tick(s, 11);
+  // pass 2a: deterministic offsets (exclusive prefix over geoms); contact geometry into the compact slots
+  // (staged in cY, which the solver only uses later)
   MZ_FOR(b, ANT_NBODY) {
     int off = 0;
     for (int g = 0; g < b; g++) off += s.cnt[g];
@@ -502,41 +517,52 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratch& s) {
     }
     if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < ANT_NC ? off : ANT_NC;
     int cls = body_class(b), leg = b == 0 ? -1 : (b - 1) / 3, slot = off;
-    float tran = K.bw_tran[cls];
     geom_contacts(K, s, b, [&](const ContactGeo& g) {
       if (slot >= ANT_NC) { slot++; return; }
-      const PairDev& P = g.wall ? K.wall : K.floor;
-      float t1[3], t2[3];
-      make_tangents(g.n, g.hint, t1, t2);
-      float sgn = g.wall ? -1.f : 1.f;  // robot geom is geom2 against the floor, geom1 against a wall
-      float fr[3][3];
-      for (int k = 0; k < 3; k++) { fr[0][k] = sgn * g.n[k]; fr[1][k] = sgn * P.mu * t1[k]; fr[2][k] = sgn * P.mu * t2[k]; }
-      float(*J)[8] = s.cJ[slot];
-      for (int a = 0; a < 3; a++) {
-        for (int k = 0; k < 3; k++) J[a][k] = fr[a][k];  // root linear
-        for (int k = 0; k < 3; k++) {                    // root angular: (R0[:,k] x r) . f
-          float axk[3] = {s.R0[k], s.R0[3 + k], s.R0[6 + k]}, v[3];
-          cross3f(v, axk, g.pos);
-          J[a][3 + k] = dot3f(v, fr[a]);
-        }
-        float jh = 0.f, ja = 0.f;
-        if (cls >= 2) { float v[3]; cross3f(v, s.zw, g.pos); for (int k = 0; k < 3; k++) v[k] += s.Sh[leg][k]; jh = dot3f(v, fr[a]); }
-        if (cls == 3) { float v[3]; cross3f(v, s.Sa[leg], g.pos); for (int k = 0; k < 3; k++) v[k] += s.Sa[leg][3 + k]; ja = dot3f(v, fr[a]); }
-        J[a][6] = jh; J[a][7] = ja;
-      }
+      float* q = &s.cY[slot][0][0];
+      for (int k = 0; k < 3; k++) { q[k] = g.pos[k]; q[3 + k] = g.n[k]; q[8 + k] = g.hint[k]; }
+      q[6] = g.dist; q[7] = g.wall ? 1.f : 0.f;
       s.cleg[slot] = leg;
-      float imp = impedancef(P.solimp, fabsf(g.dist - P.margin));
-      float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
-      s.cD[slot] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
-      for (int a = 0; a < 3; a++) {
-        float vel = 0.f;
-        for (int k = 0; k < 6; k++) vel += J[a][k] * s.qvel[k];
-        if (leg >= 0) vel += J[a][6] * s.qvel[6 + 2 * leg] + J[a][7] * s.qvel[7 + 2 * leg];
-        s.caref[slot][a] = -P.B * vel - (a == 0 ? P.K * imp * (g.dist - P.margin) : 0.f);
-      }
+      s.ccls[slot] = cls;
       slot++;
     });
   }
+  cx.sync();
+  cx.tick(s, 12);
+  // pass 2b: one lane per (contact, frame row): Jacobian row [f | R0^T (r x f) | hip | ankle], row velocity,
+  // reference acceleration; the normal row also sets the pyramid's D
+  MZ_FOR(item, 3 * s.ncon) {
+    int c = item / 3, a = item - 3 * c;
+    const float* q = &s.cY[c][0][0];
+    float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
+    bool wall = q[7] != 0.f;
+    const PairDev& P = wall ? K.wall : K.floor;
+    int leg = s.cleg[c], cls = s.ccls[c];
+    float t1[3], t2[3], f[3];
+    make_tangents(n, hint, t1, t2);
+    float sc = (wall ? -1.f : 1.f) * (a == 0 ? 1.f : P.mu);  // robot geom is geom2 against the floor, geom1 against a wall
+    for (int k = 0; k < 3; k++) f[k] = sc * (a == 0 ? n[k] : (a == 1 ? t1[k] : t2[k]));
+    float m[3];
+    cross3f(m, r, f);  // (axis x r) . f = axis . (r x f)
+    float J[8];
+    for (int k = 0; k < 3; k++) { J[k] = f[k]; J[3 + k] = s.R0[k] * m[0] + s.R0[3 + k] * m[1] + s.R0[6 + k] * m[2]; }
+    J[6] = cls >= 2 ? dot3f(s.zw, m) + dot3f(s.Sh[leg], f) : 0.f;
+    J[7] = cls == 3 ? dot3f(s.Sa[leg], m) + dot3f(s.Sa[leg] + 3, f) : 0.f;
+    float vel = 0.f;
+    for (int k = 0; k < 6; k++) vel += J[k] * s.qvel[k];
+    if (leg >= 0) vel += J[6] * s.qvel[6 + 2 * leg] + J[7] * s.qvel[7 + 2 * leg];
+    float aref = -P.B * vel;
+    if (a == 0) {
+      float imp = impedancef(P.solimp, fabsf(dist - P.margin));
+      float tran = K.bw_tran[cls];
+      float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
+      s.cD[c] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
+      aref -= P.K * imp * (dist - P.margin);
+    }
+    for (int k = 0; k < 8; k++) s.cJ[c][a][k] = J[k];
+    s.caref[c][a] = aref;
+  }
+  cx.tick(s, 13);
   // joint limits: one slot per hinge (at most one side can be violated)
   MZ_FOR(j, 8) {
     int l = j >> 1;

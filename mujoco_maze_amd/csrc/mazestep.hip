@@ -54,9 +54,25 @@ struct DevCtx {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  // All-reduce (sum) inside the lane group.  Rows of 16 lanes reduce with four DPP moves (quad_perm xor 1,
+  // xor 2, row_half_mirror, row_mirror: VALU-rate, no LDS crossbar); only the cross-row steps use ds_bpermute.
+  static __device__ __forceinline__ float dpp_add(float x, const int ctrl_sel) {
+    int xi = __float_as_int(x), yi;
+    switch (ctrl_sel) {
+      case 0: yi = __builtin_amdgcn_mov_dpp(xi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+      case 1: yi = __builtin_amdgcn_mov_dpp(xi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+      case 2: yi = __builtin_amdgcn_mov_dpp(xi, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+      default: yi = __builtin_amdgcn_mov_dpp(xi, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return x + __int_as_float(yi);
+  }
   __device__ __forceinline__ float gsum(float x) const {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, G);
+    if constexpr (G >= 2) x = dpp_add(x, 0);
+    if constexpr (G >= 4) x = dpp_add(x, 1);
+    if constexpr (G >= 8) x = dpp_add(x, 2);
+    if constexpr (G >= 16) x = dpp_add(x, 3);
+    if constexpr (G >= 32) x += __shfl_xor(x, 16, 64);
+    if constexpr (G >= 64) x += __shfl_xor(x, 32, 64);
     return x;
   }
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }

@@ -20,6 +20,7 @@ names = ["kin+crb", "bias", "factorM+qas", "constraints", "solve:init(cost x2)",
          "rk4/integrate", "io+epilogue"]
 wgs = n // (64 // lanes)
 tot = sum(cyc[:11])
+print("  constraints split: pass1 %.0f  pass2a %.0f  pass2b %.0f  limits(rest, in constraints line) cycles/step" % (cyc[11]/steps/wgs, cyc[12]/steps/wgs, cyc[13]/steps/wgs))
 print(f"lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")
 for k, nm in enumerate(names):
     print(f"  {nm:24s} {cyc[k]/steps/wgs:10.0f} cycles/step  {100*cyc[k]/tot:5.1f} %")
