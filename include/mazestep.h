@@ -194,6 +194,12 @@ typedef struct mz_model {
   double goal_reward_scale[MZ_MAX_GOAL];
   double penalty, task_scale, inner_reward_scaling;
   double forward_reward_weight, ctrl_cost_weight; /* ant.py:47-53 */
+
+  /* movable XY blocks (maze_env.py:563-660: body + slide-x + slide-y + box geom appended after the
+   * robot); observed as body xpos at obs[3:3+3*nblock] when observe_blocks (maze_env.py:364-368) */
+  int32_t nblock, observe_blocks;
+  int32_t block_bodyid[4];
+  int32_t block_geomid[4];
 } mz_model;
 
 typedef struct mz_handle mz_handle;

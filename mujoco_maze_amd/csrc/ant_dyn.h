@@ -8,25 +8,30 @@
 // surrounding `MazeEnv.step` bookkeeping (maze_env.py:448-481).  Pipeline per
 // forward evaluation (20 per env.step: 5 frames x RK4), SURVEY §8a M1-M9:
 //   K  kinematics of the 13 bodies in a torso-centred frame (fp32-safe far from the origin)
-//   I  spatial inertias, composite-rigid-body mass matrix in *arrow* form
-//      (6x6 root block + four 2x2 leg blocks + 6x2 couplings; legs never couple)
+//   I  spatial inertias, composite-rigid-body mass matrix in *arrow* form: a dense hub block
+//      (6 root dofs + 2 slide dofs per movable block), four 2x2 leg blocks and hub x leg couplings
+//      (legs never couple with each other)
 //   V  velocities and bias forces (recursive Newton-Euler, gravity included)
-//   C  collision: floor plane vs sphere/capsule ends; maze wall boxes found through
-//      the cell grid (only the <= 2x2 cells under a geom's bounding square)
-//   J  contact Jacobians (3 x 8 sparse: root + own leg), joint-limit rows
-//   N  primal Newton solver on the pyramidal-cone soft-constraint cost; the Hessian
-//      keeps the arrow sparsity (a contact touches root + one leg), so each
-//      iteration factors four 2x2 blocks and one 6x6 Schur complement
+//   C  collision: floor plane vs sphere/capsule ends; maze wall boxes found through the cell grid
+//      (only the <= 2x2 cells under a geom's bounding square); movable XY blocks (axis-aligned boxes:
+//      block-floor corners, block-wall, robot-block)
+//   J  contact Jacobians (3 x (hub + 2) sparse: hub + own leg), joint-limit rows
+//   N  primal Newton solver on the pyramidal-cone soft-constraint cost; the Hessian keeps the arrow
+//      sparsity (a contact touches hub + one leg), so each iteration factors four 2x2 blocks and one
+//      hub-sized Schur complement
 //   R  RK4 stage bookkeeping with manifold quaternion update
 //
+// Template parameter NB = number of movable XY blocks of the maze (0 for AntUMaze / Ant4Rooms,
+// 1 for AntPush / AntBlockMaze / AntBlockCarry; mujoco_maze/maze_env.py:563-660).
+//
 // Execution contexts (template parameter C):
-//   * device: csrc/mazestep.hip — G lanes per env, cx.sync() = __syncthreads() of a
-//     one-wavefront workgroup, cx.gsum() = DPP/shuffle butterfly inside the group;
+//   * device: csrc/mazestep.hip — G lanes per env, cx.sync() = wavefront-scope fence,
+//     cx.gsum() = DPP/shuffle butterfly inside the group;
 //   * host emulation (tests/emu, CPU tests of the kernel logic only — never a
 //     product path): nlanes = 1, so every MZ_FOR runs all its items in order.
 // Rule that makes both valid: inside one phase (between two cx.sync()) the
 // iterations of an MZ_FOR are independent, and nothing but LDS scratch carries
-// values from one phase to the next.
+// values from one phase to the next (group-uniform scalars may live in registers).
 #pragma once
 #include "ant_model.h"
 
@@ -48,23 +53,43 @@ struct HostCtx {
   template <class S> MZ_HD void tick(S&, int) const {}
 };
 
-// ------------------------------------------------------------------ scratch (LDS) per env
-struct Arrow {       // symmetric matrix with the ant's sparsity
-  float rr[6][6];    // root block (full storage)
-  float rl[4][2][6]; // leg l, dof (0 hip, 1 ankle) x root
-  float ll[4][3];    // leg l: hh, ha, aa
+// ------------------------------------------------------------------ sizes
+template <int NB>
+struct AntDims {
+  static constexpr int NH = 6 + 2 * NB;    // hub dofs: root 6 + 2 per block
+  static constexpr int NV = 14 + 2 * NB;   // MuJoCo dof order: root 0-5, legs 6-13, blocks 14..
+  static constexpr int NQ = 15 + 2 * NB;
+  static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
+  static constexpr int NC = NB ? 28 : 16;  // contact slots (a block alone holds ~10: 4 floor corners + walls)
+  static constexpr int NGEOM = 13 + NB;    // contact enumerators: blocks first, then the 13 robot geoms
+  static constexpr int NHESS = NH * NH + 8 * NH + 12;
+  static constexpr int NTRI = NH * (NH + 1) / 2;
+  static constexpr int REC_T = NQ + 2 * NV;              // state record: qpos | qvel | warm | t | episode
+  static constexpr int REC = (REC_T + 2 + 15) / 16 * 16;
 };
+MZ_HD int hub2dof(int h) { return h < 6 ? h : h + 8; }
+
+// ------------------------------------------------------------------ scratch (LDS) per env
+template <int NH>
+struct Arrow {        // symmetric matrix with the ant's sparsity
+  float rr[NH][NH];   // hub block (full storage)
+  float rl[4][2][NH]; // leg l, dof (0 hip, 1 ankle) x hub
+  float ll[4][3];     // leg l: hh, ha, aa
+};
+template <int NH>
 struct ArrowFactor {
-  float inv[4][3];   // inverse of the 2x2 leg blocks
-  float T[4][2][6];  // inv * rl
-  float L[6][6];     // Schur complement (lower triangle)
-  float rhs[6];      // reduced right-hand side / root solution
+  float inv[4][3];    // inverse of the 2x2 leg blocks
+  float T[4][2][NH];  // inv * rl
+  float L[NH][NH];    // Schur complement (lower triangle)
+  float rhs[NH];      // reduced right-hand side / hub solution
 };
 
-struct AntScratch {
+template <int NB>
+struct AntScratchT {
+  using D = AntDims<NB>;
   // step-persistent
-  float qpos[16], qvel[14], x0q[16], x0v[14], accv[14], accf[14], warm[14], fact[14];
-  float qacc[14], qas[14], qfs[14];
+  float qpos[D::NQ + 1], qvel[D::NV], x0q[D::NQ + 1], x0v[D::NV], accv[D::NV], accf[D::NV], warm[D::NV], fact[D::NV];
+  float qacc[D::NV], qas[D::NV], qfs[D::NV];
   // kinematics (positions relative to the torso origin c)
   float R0[9], cz;               // torso rotation (row-major), torso height
   float p1[4][3], p2[4][3];      // aux / ankle body origins
@@ -72,16 +97,16 @@ struct AntScratch {
   float zw[3];                   // hip axis (world) = R0 * ez
   float Sh[4][3], Sa[4][6];      // hip: linear part (angular = zw); ankle: angular, linear
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
-  float fleg[4][6], ftor[6], bias[14], Iall[10];
-  Arrow M, H;
-  ArrowFactor F;
-  float grad[14], search[14], Mx[14], Ms[14];
+  float fleg[4][6], ftor[6], bias[D::NV], Iall[10];
+  Arrow<D::NH> M, H;
+  ArrowFactor<D::NH> F;
+  float grad[D::NV], search[D::NV], Mx[D::NV];
   // contacts
-  int ncon, cnt[13], cbeg[5];    // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); torso contacts [0, cbeg[0])
-  int cleg[ANT_NC], ccls[ANT_NC]; // leg (-1 torso) and body class of the contact's robot body
-  float cJ[ANT_NC][3][8];        // [normal, mu*t1, mu*t2] x [root 6, hip, ankle]
-  float cY[ANT_NC][3][8];        // W * J of the current Newton iterate
-  float caref[ANT_NC][3], cD[ANT_NC], cu[ANT_NC][3], cjv[ANT_NC][3], cg[ANT_NC][3];
+  int ncon, cnt[D::NGEOM], cbeg[5];  // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); hub-only contacts [0, cbeg[0])
+  int cleg[D::NC], ccls[D::NC];      // leg (-1 none) and robot body class (-1 none) of the contact
+  float cJ[D::NC][3][D::NCOL];       // [normal, mu*t1, mu*t2] x [hub, hip, ankle]
+  float cY[D::NC][3][D::NCOL];       // W * J of the current Newton iterate (also stages contact geometry)
+  float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3], cg[D::NC][3];
   // joint limits (8 hinges)
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   float red[4];
@@ -90,6 +115,7 @@ struct AntScratch {
   unsigned long long prof_t0;
   unsigned int prof[16];
 };
+using AntScratch = AntScratchT<0>;
 
 // ------------------------------------------------------------------ small helpers
 MZ_HD float dot3f(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -147,12 +173,14 @@ MZ_HD float impedancef(const float* si, float x) {
   return d0 + y * (dmax - d0);
 }
 
+
 // body index b in 0..12: 0 torso, else leg l = (b-1)/3, level k = (b-1)%3 (0 welded leg, 1 aux, 2 ankle)
 MZ_HD int body_class(int b) { return b == 0 ? 0 : 1 + (b - 1) % 3; }
 
 // ------------------------------------------------------------------ K + I: kinematics, inertias, mass matrix
-template <class C>
-MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratch& s) {
+template <int NB, class C>
+MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
+  constexpr int NH = AntDims<NB>::NH;
   MZ_FOR(l, 4) {
     float R0[9];
     quat_to_matf(R0, s.qpos + 3);
@@ -228,6 +256,7 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratch& s) {
       s.M.rl[l][0][3 + k] = dot3f(ax, Fh);
       s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
     }
+    for (int k = 6; k < NH; k++) { s.M.rl[l][0][k] = 0.f; s.M.rl[l][1][k] = 0.f; }  // blocks are separate trees
   }
   MZ_FOR(k, 10) {  // whole-body composite inertia about c
     float v = 0.f;
@@ -235,7 +264,14 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratch& s) {
     s.Iall[k] = v;
   }
   cx.sync();
-  MZ_FOR(e, 21) {  // root 6x6 block from the whole-body composite inertia (lower triangle, mirrored)
+  MZ_FOR(e, 21 + (NH - 6) * NH) {
+    if (e >= 21) {  // block rows of the hub: diag(mass), no coupling
+      int q = e - 21, i = 6 + q / NH, j = q - (i - 6) * NH;
+      float val = (i == j) ? K.block_mass : 0.f;
+      s.M.rr[i][j] = val; s.M.rr[j][i] = val;
+      continue;
+    }
+    // root 6x6 block from the whole-body composite inertia (lower triangle, mirrored)
     int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : 5;
     int j = e - (i * (i + 1)) / 2;
     float m = s.Iall[0], h[3] = {s.Iall[1], s.Iall[2], s.Iall[3]}, J[6];
@@ -262,8 +298,9 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratch& s) {
 }
 
 // ------------------------------------------------------------------ V: velocities, bias forces, smooth forces
-template <class C>
-MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratch& s) {
+template <int NB, class C>
+MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
+  constexpr int NV = AntDims<NB>::NV;
   MZ_FOR(l, 5) {
     float v0[6], a0[6], ww[3];
     mat_vecf(ww, s.R0, s.qvel + 3);  // world angular velocity (root angular dofs are body-frame)
@@ -300,7 +337,7 @@ MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratch& s) {
     }
   }
   cx.sync();
-  MZ_FOR(i, ANT_NV) {
+  MZ_FOR(i, NV) {
     float frc;
     if (i < 6) {
       float tot[3];
@@ -311,8 +348,11 @@ MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratch& s) {
       else { float ax[3] = {s.R0[i - 3], s.R0[3 + i - 3], s.R0[6 + i - 3]}; b = dot3f(ax, tot); }
       s.bias[i] = b;
       frc = -b;
-    } else {
+    } else if (i < 14) {
       frc = -K.damping * s.qvel[i] - s.bias[i] + s.fact[i];
+    } else {  // block slides: horizontal, undamped, unactuated (maze_env.py:600-633)
+      s.bias[i] = 0.f;
+      frc = 0.f;
     }
     s.qfs[i] = frc;
   }
@@ -320,22 +360,95 @@ MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratch& s) {
 }
 
 // ------------------------------------------------------------------ arrow linear algebra
-// y_i = (A x)_i for one dof (called inside an MZ_FOR over dofs)
-MZ_HD float arrow_row_mul(const Arrow& A, const float* x, int i) {
+// y_i = (A x)_i for one dof in MuJoCo order (called inside an MZ_FOR over dofs)
+template <int NH>
+MZ_HD float arrow_row_mul(const Arrow<NH>& A, const float* x, int i) {
   float v = 0.f;
-  if (i < 6) {
-    for (int k = 0; k < 6; k++) v += A.rr[i][k] * x[k];
-    for (int l = 0; l < 4; l++) v += A.rl[l][0][i] * x[6 + 2 * l] + A.rl[l][1][i] * x[7 + 2 * l];
+  if (i < 6 || i >= 14) {
+    int h = i < 6 ? i : i - 8;
+    for (int k = 0; k < NH; k++) v += A.rr[h][k] * x[hub2dof(k)];
+    for (int l = 0; l < 4; l++) v += A.rl[l][0][h] * x[6 + 2 * l] + A.rl[l][1][h] * x[7 + 2 * l];
   } else {
     int l = (i - 6) >> 1, d = (i - 6) & 1;
-    for (int k = 0; k < 6; k++) v += A.rl[l][d][k] * x[k];
+    for (int k = 0; k < NH; k++) v += A.rl[l][d][k] * x[hub2dof(k)];
     v += d == 0 ? A.ll[l][0] * x[6 + 2 * l] + A.ll[l][1] * x[7 + 2 * l] : A.ll[l][1] * x[6 + 2 * l] + A.ll[l][2] * x[7 + 2 * l];
   }
   return v;
 }
 
+// Fused factor + solve of an arrow system A x = sign * g (vectors in MuJoCo dof order):
+//   phase 1 (4 leg lanes)  2x2 inverses and T = inv * rl
+//   phase 2                NH(NH+1)/2 Schur-complement entries + NH reduced right-hand sides
+//   phase 3 (1 lane)       NH x NH Cholesky and both substitutions, entirely in registers
+//   phase 4 (NV lanes)     back-substitution of the leg dofs
+template <int NH, int NV, class C>
+MZ_HD void arrow_factor_solve(const C& cx, const Arrow<NH>& A, ArrowFactor<NH>& F, const float* g, float* x, float sign) {
+  constexpr int NTRI = NH * (NH + 1) / 2;
+  MZ_FOR(l, 4) {
+    float hh = A.ll[l][0], ha = A.ll[l][1], aa = A.ll[l][2];
+    float idet = 1.0f / (hh * aa - ha * ha);
+    float ihh = aa * idet, iha = -ha * idet, iaa = hh * idet;
+    F.inv[l][0] = ihh; F.inv[l][1] = iha; F.inv[l][2] = iaa;
+    for (int k = 0; k < NH; k++) {
+      F.T[l][0][k] = ihh * A.rl[l][0][k] + iha * A.rl[l][1][k];
+      F.T[l][1][k] = iha * A.rl[l][0][k] + iaa * A.rl[l][1][k];
+    }
+  }
+  cx.sync();
+  MZ_FOR(e, NTRI + NH) {
+    if (e < NTRI) {
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= e) i++;
+      int j = e - (i * (i + 1)) / 2;
+      float v = A.rr[i][j];
+      for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
+      F.L[i][j] = v;
+    } else {
+      int k = e - NTRI;
+      float r = g[hub2dof(k)];
+      for (int l = 0; l < 4; l++) r -= F.T[l][0][k] * g[6 + 2 * l] + F.T[l][1][k] * g[7 + 2 * l];
+      F.rhs[k] = r;
+    }
+  }
+  cx.sync();
+  MZ_FOR(one, 1) {
+    float L[NH][NH], y[NH], id[NH];
+    for (int i = 0; i < NH; i++) for (int j = 0; j <= i; j++) L[i][j] = F.L[i][j];
+    for (int i = 0; i < NH; i++) y[i] = F.rhs[i];
+    for (int j = 0; j < NH; j++) {
+      float d = L[j][j];
+      for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+      float r = 1.0f / sqrtf(fmaxf(d, 1e-30f));
+      id[j] = r;
+      for (int i = j + 1; i < NH; i++) {
+        float t = L[i][j];
+        for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+        L[i][j] = t * r;
+      }
+    }
+    for (int i = 0; i < NH; i++) { float t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * id[i]; }
+    for (int i = NH - 1; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < NH; k++) t -= L[k][i] * y[k]; y[i] = t * id[i]; }
+    for (int i = 0; i < NH; i++) F.rhs[i] = y[i];
+  }
+  cx.sync();
+  MZ_FOR(i, NV) {
+    float v;
+    if (i < 6) v = F.rhs[i];
+    else if (i >= 14) v = F.rhs[i - 8];
+    else {
+      int l = (i - 6) >> 1, d = (i - 6) & 1;
+      float gh = g[6 + 2 * l], ga = g[7 + 2 * l];
+      v = d == 0 ? F.inv[l][0] * gh + F.inv[l][1] * ga : F.inv[l][1] * gh + F.inv[l][2] * ga;
+      for (int k = 0; k < NH; k++) v -= F.T[l][d][k] * F.rhs[k];
+    }
+    x[i] = sign * v;
+  }
+  cx.sync();
+}
+
 // ------------------------------------------------------------------ C + J: collision and constraint rows
-struct ContactGeo { float dist, pos[3], n[3], hint[3]; int wall; };
+// kind: 0 robot geom vs floor, 1 robot geom vs wall, 2 robot geom vs movable block, 3 block vs floor, 4 block vs wall
+struct ContactGeo { float dist, pos[3], n[3], hint[3]; int kind, blk; };
 
 MZ_HD void make_tangents(const float* n, const float* hint, float* t1, float* t2) {
   float y[3] = {hint[0], hint[1], hint[2]};
@@ -412,9 +525,10 @@ MZ_HD float seg_box_t(const float* a, const float* b, const float* bs) {
   return tlo - glo * (thi - tlo) / (ghi - glo);
 }
 
+
 // Row bitmask of the cell grid for a per-lane row index.  The grid lives in the kernel-argument block
 // (scalar registers); a select chain keeps it there — indexing the array with a vector index would make the
-// compiler spill it to scratch memory (one ~500-cycle load per probe).
+// compiler spill it to scratch memory.
 MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
   uint32_t m = 0u;
 #pragma unroll
@@ -422,106 +536,195 @@ MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
   return m;
 }
 
-// Enumerate the contacts of geom (= body) b.  `emit` is called once per contact, in a fixed
-// order (floor contacts first, then wall cells row-major), identical in the count and fill passes.
+// sphere / capsule (centre ctr, axis ax, half length hl, radius r; torso-relative) against an axis-aligned box
+// (centre bc torso-relative, half sizes bs): up to two contacts [ASSUME-6], normal from the robot geom to the box
 template <class Emit>
-MZ_HD void geom_contacts(const AntDev& K, const AntScratch& s, int b, Emit&& emit) {
+MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl, float r, const float* bc, const float* bs,
+                        float margin, int kind, int blk, Emit&& emit) {
+  float cl[3] = {ctr[0] - bc[0], ctr[1] - bc[1], ctr[2] - bc[2]};  // geom centre in box coordinates
+  float dist, pos[3], n[3];
+  ContactGeo cg;
+  cg.kind = kind; cg.blk = blk;
+  cg.hint[0] = cg.hint[1] = cg.hint[2] = 0.f;
+  if (sphere) {
+    if (sphere_aabb(cl, r, bs, margin, &dist, pos, n) && dist < margin) {
+      cg.dist = dist;
+      for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.pos[k] = pos[k] + bc[k]; }
+      emit(cg);
+    }
+    return;
+  }
+  float e1[3], e2[3];
+  for (int k = 0; k < 3; k++) { e1[k] = cl[k] - ax[k] * hl; e2[k] = cl[k] + ax[k] * hl; }  // e1 = +geom-z end
+  float t = seg_box_t(e1, e2, bs), p[3];
+  for (int k = 0; k < 3; k++) p[k] = e1[k] + t * (e2[k] - e1[k]);
+  if (sphere_aabb(p, r, bs, margin, &dist, pos, n) && dist < margin) {
+    cg.dist = dist;
+    for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.pos[k] = pos[k] + bc[k]; }
+    emit(cg);
+  }
+  float tf = t <= 0.5f ? 1.f : 0.f;
+  float far[3];
+  for (int k = 0; k < 3; k++) far[k] = t <= 0.5f ? e2[k] : e1[k];
+  if (fabsf(tf - t) * 2.f * hl > 1e-6f)
+    if (sphere_aabb(far, r, bs, margin, &dist, pos, n) && dist < margin) {
+      cg.dist = dist;
+      for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.pos[k] = pos[k] + bc[k]; }
+      emit(cg);
+    }
+}
+
+// torso-relative centre of movable block k
+template <int NB>
+MZ_HD void block_center(const AntDev& K, const AntScratchT<NB>& s, int k, float* bc) {
+  float p0[3] = {0.f, 0.f, 0.f}, qx = 0.f, qy = 0.f;
+#pragma unroll
+  for (int j = 0; j < (NB ? NB : 1); j++)
+    if (j == k && j < NB) { p0[0] = K.block_pos0[j][0]; p0[1] = K.block_pos0[j][1]; p0[2] = K.block_pos0[j][2]; qx = s.qpos[15 + 2 * j]; qy = s.qpos[16 + 2 * j]; }
+  bc[0] = (p0[0] - s.qpos[0]) + qx; bc[1] = (p0[1] - s.qpos[1]) + qy; bc[2] = p0[2] - s.cz;
+}
+
+// Enumerate the contacts of enumerator e: e < NB -> movable block e (floor corners, walls);
+// else robot geom (= body) b = e - NB (floor, walls, blocks).  `emit` is called once per contact, in a fixed
+// order, identical in the count and fill passes.
+template <int NB, class Emit>
+MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&& emit) {
+  const MazeDev& z = K.maze;
+  float inv = 1.0f / z.scale;
+  float bs[3] = {z.half_xy, z.half_xy, z.half_z};
+  ContactGeo cg;
+  if (e < NB) {  // ---- movable block
+    float bc[3];
+    block_center<NB>(K, s, e, bc);
+    const float* hb = K.block_half;
+    float bottom = (bc[2] + s.cz) - hb[2];  // absolute height of the bottom face
+    if (bottom < K.floor.margin)
+      for (int ci = 0; ci < 4; ci++) {  // plane-box: the four bottom corners
+        cg.kind = 3; cg.blk = e; cg.dist = bottom;
+        cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
+        cg.hint[0] = cg.hint[1] = cg.hint[2] = 0.f;
+        cg.pos[0] = bc[0] + ((ci & 1) ? hb[0] : -hb[0]); cg.pos[1] = bc[1] + ((ci & 2) ? hb[1] : -hb[1]);
+        cg.pos[2] = 0.5f * bottom - s.cz;
+        emit(cg);
+      }
+    float reach = sqrtf(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]) + K.wall.margin;
+    float gx = s.qpos[0] + bc[0], gy = s.qpos[1] + bc[1];
+    int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
+    int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
+    for (int i = i0; i <= i1; i++)
+      for (int j = j0; j <= j1; j++) {
+        if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
+        if (!((maze_row(z, i) >> j) & 1u)) continue;
+        // aligned box-box [ASSUME-12]: geom1 = wall, geom2 = block
+        float c1[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
+        float gap[3];
+        int ax = 0;
+        for (int k = 0; k < 3; k++) gap[k] = fabsf(bc[k] - c1[k]) - (bs[k] + hb[k]);
+        if (gap[1] > gap[ax]) ax = 1;
+        if (gap[2] > gap[ax]) ax = 2;
+        float gmax = ax == 0 ? gap[0] : (ax == 1 ? gap[1] : gap[2]);
+        if (!(gmax < K.wall.margin)) continue;
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+          lo[k] = fmaxf(c1[k] - bs[k], bc[k] - hb[k]);
+          hi[k] = fminf(c1[k] + bs[k], bc[k] + hb[k]);
+          if (hi[k] < lo[k]) { float mid = 0.5f * (lo[k] + hi[k]); lo[k] = mid; hi[k] = mid; }
+        }
+        int u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
+        if (ax == 1) { u = 2; v = 0; }
+        float c1a = ax == 0 ? c1[0] : (ax == 1 ? c1[1] : c1[2]), bca = ax == 0 ? bc[0] : (ax == 1 ? bc[1] : bc[2]);
+        float bsa = ax == 0 ? bs[0] : (ax == 1 ? bs[1] : bs[2]);
+        float sg = bca >= c1a ? 1.f : -1.f;
+        float lou = u == 0 ? lo[0] : (u == 1 ? lo[1] : lo[2]), hiu = u == 0 ? hi[0] : (u == 1 ? hi[1] : hi[2]);
+        float lov = v == 0 ? lo[0] : (v == 1 ? lo[1] : lo[2]), hiv = v == 0 ? hi[0] : (v == 1 ? hi[1] : hi[2]);
+        int nu = (hiu - lou > 1e-6f) ? 2 : 1, nv = (hiv - lov > 1e-6f) ? 2 : 1;
+        for (int iu = 0; iu < nu; iu++)
+          for (int iv = 0; iv < nv; iv++) {
+            cg.kind = 4; cg.blk = e; cg.dist = gmax;
+            float pa = c1a + sg * (bsa + 0.5f * gmax), pu = iu ? hiu : lou, pv = iv ? hiv : lov;
+            for (int k = 0; k < 3; k++) { cg.n[k] = k == ax ? sg : 0.f; cg.hint[k] = 0.f; cg.pos[k] = k == ax ? pa : (k == u ? pu : pv); }
+            emit(cg);
+          }
+      }
+    return;
+  }
+  // ---- robot geom
+  int b = e - NB;
   int c = body_class(b);
   float r = K.radius[c], hl = K.half_len[c];
   float ctr[3] = {0, 0, 0}, ax[3] = {0, 0, 0};
   if (b > 0) for (int k = 0; k < 3; k++) { ctr[k] = s.com[b - 1][k]; ax[k] = s.w[b - 1][k]; }
-  ContactGeo cg;
   // floor plane z = 0, normal +z; capsule ends in MuJoCo's geom-frame order [ASSUME-5]: the geom z axis of a
   // fromto capsule points from `to` to `from`, i.e. along -w, so "+axis" is the end at the body origin
   int nend = b == 0 ? 1 : 2;
-  for (int e = 0; e < nend; e++) {
-    float sg = e == 0 ? -1.f : 1.f, p[3];
+  for (int k2 = 0; k2 < nend; k2++) {
+    float sg = k2 == 0 ? -1.f : 1.f, p[3];
     for (int k = 0; k < 3; k++) p[k] = ctr[k] + sg * ax[k] * hl;
     float dist = (s.cz + p[2]) - r;
     if (dist < K.floor.margin) {
-      cg.dist = dist; cg.wall = 0;
+      cg.dist = dist; cg.kind = 0; cg.blk = 0;
       cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
       cg.pos[0] = p[0]; cg.pos[1] = p[1]; cg.pos[2] = p[2] - (r + 0.5f * dist);
       for (int k = 0; k < 3; k++) cg.hint[k] = b == 0 ? 0.f : ax[k];
       emit(cg);
     }
   }
+  // movable blocks
+  for (int k = 0; k < NB; k++) {
+    float bc[3];
+    block_center<NB>(K, s, k, bc);
+    float d2 = 0.f;
+    for (int q = 0; q < 3; q++) { float dd = fmaxf(fabsf(ctr[q] - bc[q]) - K.block_half[q], 0.f); d2 += dd * dd; }
+    float reachb = r + hl + K.wall.margin;
+    if (d2 < reachb * reachb) round_vs_box(b == 0, ctr, ax, hl, r, bc, K.block_half, K.wall.margin, 2, k, emit);
+  }
   // maze walls: cells under the bounding square of the geom
-  const MazeDev& z = K.maze;
   float reach = r + hl + K.wall.margin;
   float gx = s.qpos[0] + ctr[0], gy = s.qpos[1] + ctr[1], gz = s.cz + ctr[2];
   if (gz - reach > z.center_z + z.half_z) return;
-  float inv = 1.0f / z.scale;
   int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
   int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
-  float bs[3] = {z.half_xy, z.half_xy, z.half_z};
   for (int i = i0; i <= i1; i++)
     for (int j = j0; j <= j1; j++) {
       if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
       if (!((maze_row(z, i) >> j) & 1u)) continue;
       // box centre relative to the torso origin, computed so that the large world coordinates cancel first
-      float bx = (j * z.scale - z.tx) - s.qpos[0], by = (i * z.scale - z.ty) - s.qpos[1], bz = z.center_z - s.cz;
-      float cl[3] = {ctr[0] - bx, ctr[1] - by, ctr[2] - bz};  // geom centre in box coordinates
-      float dist, pos[3], n[3];
-      if (b == 0) {
-        if (sphere_aabb(cl, r, bs, K.wall.margin, &dist, pos, n) && dist < K.wall.margin) {
-          cg.dist = dist; cg.wall = 1;
-          for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.hint[k] = 0.f; }
-          cg.pos[0] = pos[0] + bx; cg.pos[1] = pos[1] + by; cg.pos[2] = pos[2] + bz;
-          emit(cg);
-        }
-      } else {  // capsule vs box [ASSUME-6]
-        float e1[3], e2[3];
-        for (int k = 0; k < 3; k++) { e1[k] = cl[k] - ax[k] * hl; e2[k] = cl[k] + ax[k] * hl; }  // e1 = +geom-z end
-        float t = seg_box_t(e1, e2, bs), p[3];
-        for (int k = 0; k < 3; k++) p[k] = e1[k] + t * (e2[k] - e1[k]);
-        if (sphere_aabb(p, r, bs, K.wall.margin, &dist, pos, n) && dist < K.wall.margin) {
-          cg.dist = dist; cg.wall = 1;
-          for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.hint[k] = 0.f; }
-          cg.pos[0] = pos[0] + bx; cg.pos[1] = pos[1] + by; cg.pos[2] = pos[2] + bz;
-          emit(cg);
-        }
-        float tf = t <= 0.5f ? 1.f : 0.f;
-        const float* far = t <= 0.5f ? e2 : e1;
-        if (fabsf(tf - t) * 2.f * hl > 1e-6f)
-          if (sphere_aabb(far, r, bs, K.wall.margin, &dist, pos, n) && dist < K.wall.margin) {
-            cg.dist = dist; cg.wall = 1;
-            for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.hint[k] = 0.f; }
-            cg.pos[0] = pos[0] + bx; cg.pos[1] = pos[1] + by; cg.pos[2] = pos[2] + bz;
-            emit(cg);
-          }
-      }
+      float bc[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
+      round_vs_box(b == 0, ctr, ax, hl, r, bc, bs, K.wall.margin, 1, 0, emit);
     }
 }
 
-template <class C>
-MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratch& s) {
-  // pass 1: count contacts per geom
-  MZ_FOR(b, ANT_NBODY) {
+template <int NB, class C>
+MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
+  using D = AntDims<NB>;
+  constexpr int NH = D::NH, NC = D::NC, NG = D::NGEOM;
+  // pass 1: count contacts per enumerator
+  MZ_FOR(e, NG) {
     int n = 0;
-    geom_contacts(K, s, b, [&](const ContactGeo&) { n++; });
-    s.cnt[b] = n;
+    geom_contacts<NB>(K, s, e, [&](const ContactGeo&) { n++; });
+    s.cnt[e] = n;
   }
   cx.sync();
   cx.tick(s, 11);
-  // pass 2a: deterministic offsets (exclusive prefix over geoms); contact geometry into the compact slots
-  // (staged in cY, which the solver only uses later)
-  MZ_FOR(b, ANT_NBODY) {
+  // pass 2a: deterministic offsets (exclusive prefix over enumerators); contact geometry into the compact
+  // slots (staged in cY, which the solver only uses later)
+  MZ_FOR(e, NG) {
     int off = 0;
-    for (int g = 0; g < b; g++) off += s.cnt[g];
-    if (b == ANT_NBODY - 1) {
-      int tot = off + s.cnt[b];
-      if (tot > ANT_NC) { tot = ANT_NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+    for (int g = 0; g < e; g++) off += s.cnt[g];
+    if (e == NG - 1) {
+      int tot = off + s.cnt[e];
+      if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
       s.ncon = tot;
       s.cbeg[4] = tot;
     }
-    if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < ANT_NC ? off : ANT_NC;
-    int cls = body_class(b), leg = b == 0 ? -1 : (b - 1) / 3, slot = off;
-    geom_contacts(K, s, b, [&](const ContactGeo& g) {
-      if (slot >= ANT_NC) { slot++; return; }
+    int b = e - NB;
+    if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
+    int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, slot = off;
+    geom_contacts<NB>(K, s, e, [&](const ContactGeo& g) {
+      if (slot >= NC) { slot++; return; }
       float* q = &s.cY[slot][0][0];
       for (int k = 0; k < 3; k++) { q[k] = g.pos[k]; q[3 + k] = g.n[k]; q[8 + k] = g.hint[k]; }
-      q[6] = g.dist; q[7] = g.wall ? 1.f : 0.f;
+      q[6] = g.dist; q[7] = (float)(g.kind + 8 * g.blk);
       s.cleg[slot] = leg;
       s.ccls[slot] = cls;
       slot++;
@@ -529,37 +732,42 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratch& s) {
   }
   cx.sync();
   cx.tick(s, 12);
-  // pass 2b: one lane per (contact, frame row): Jacobian row [f | R0^T (r x f) | hip | ankle], row velocity,
-  // reference acceleration; the normal row also sets the pyramid's D
+  // pass 2b: one lane per (contact, frame row): Jacobian row, row velocity, reference acceleration; the normal
+  // row also sets the pyramid's D.  Sign convention J = J(geom2 body) - J(geom1 body): the robot geom is geom2
+  // against the floor and geom1 against walls and blocks; a block is geom2 against floor, walls and robot geoms.
   MZ_FOR(item, 3 * s.ncon) {
     int c = item / 3, a = item - 3 * c;
     const float* q = &s.cY[c][0][0];
     float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
-    bool wall = q[7] != 0.f;
-    const PairDev& P = wall ? K.wall : K.floor;
+    int code = (int)q[7], kind = code & 7, blk = code >> 3;
+    const PairDev& P = (kind == 0 || kind == 3) ? K.floor : K.wall;
     int leg = s.cleg[c], cls = s.ccls[c];
     float t1[3], t2[3], f[3];
     make_tangents(n, hint, t1, t2);
-    float sc = (wall ? -1.f : 1.f) * (a == 0 ? 1.f : P.mu);  // robot geom is geom2 against the floor, geom1 against a wall
+    float sr = kind == 0 ? 1.f : (kind <= 2 ? -1.f : 0.f), sb = kind >= 2 ? 1.f : 0.f;
+    float sc = a == 0 ? 1.f : P.mu;
     for (int k = 0; k < 3; k++) f[k] = sc * (a == 0 ? n[k] : (a == 1 ? t1[k] : t2[k]));
     float m[3];
     cross3f(m, r, f);  // (axis x r) . f = axis . (r x f)
-    float J[8];
-    for (int k = 0; k < 3; k++) { J[k] = f[k]; J[3 + k] = s.R0[k] * m[0] + s.R0[3 + k] * m[1] + s.R0[6 + k] * m[2]; }
-    J[6] = cls >= 2 ? dot3f(s.zw, m) + dot3f(s.Sh[leg], f) : 0.f;
-    J[7] = cls == 3 ? dot3f(s.Sa[leg], m) + dot3f(s.Sa[leg] + 3, f) : 0.f;
+    float J[D::NCOL];
+    for (int k = 0; k < 3; k++) { J[k] = sr * f[k]; J[3 + k] = sr * (s.R0[k] * m[0] + s.R0[3 + k] * m[1] + s.R0[6 + k] * m[2]); }
+    for (int k = 6; k < NH; k++) J[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; k++) if (k == blk && kind >= 2) { J[6 + 2 * k] = sb * f[0]; J[7 + 2 * k] = sb * f[1]; }
+    J[NH] = cls >= 2 ? sr * (dot3f(s.zw, m) + dot3f(s.Sh[leg < 0 ? 0 : leg], f)) : 0.f;
+    J[NH + 1] = cls == 3 ? sr * (dot3f(s.Sa[leg < 0 ? 0 : leg], m) + dot3f(s.Sa[leg < 0 ? 0 : leg] + 3, f)) : 0.f;
     float vel = 0.f;
-    for (int k = 0; k < 6; k++) vel += J[k] * s.qvel[k];
-    if (leg >= 0) vel += J[6] * s.qvel[6 + 2 * leg] + J[7] * s.qvel[7 + 2 * leg];
+    for (int k = 0; k < NH; k++) vel += J[k] * s.qvel[hub2dof(k)];
+    if (leg >= 0) vel += J[NH] * s.qvel[6 + 2 * leg] + J[NH + 1] * s.qvel[7 + 2 * leg];
     float aref = -P.B * vel;
     if (a == 0) {
       float imp = impedancef(P.solimp, fabsf(dist - P.margin));
-      float tran = K.bw_tran[cls];
+      float tran = (cls >= 0 ? K.bw_tran[cls] : 0.f) + (kind >= 2 ? K.block_bw_tran : 0.f);
       float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
       s.cD[c] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
       aref -= P.K * imp * (dist - P.margin);
     }
-    for (int k = 0; k < 8; k++) s.cJ[c][a][k] = J[k];
+    for (int k = 0; k < D::NCOL; k++) s.cJ[c][a][k] = J[k];
     s.caref[c][a] = aref;
   }
   cx.tick(s, 13);
@@ -570,14 +778,14 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratch& s) {
     float sg = 0.f, pos = 0.f;
     if (q - lo < 0.f) { sg = 1.f; pos = q - lo; }
     else if (hi - q < 0.f) { sg = -1.f; pos = hi - q; }
-    float D = 0.f, aref = 0.f;
+    float Dl = 0.f, aref = 0.f;
     if (sg != 0.f) {
       float imp = impedancef(K.lim_solimp, fabsf(pos));
       float R = fmaxf(1e-15f, (1.f - imp) / imp * ((j & 1) ? K.dofw_ank : K.dofw_hip));
-      D = 1.0f / R;
+      Dl = 1.0f / R;
       aref = -K.lim_B * (sg * s.qvel[6 + j]) - K.lim_K * imp * pos;
     }
-    s.lsign[j] = sg; s.lD[j] = D; s.laref[j] = aref;
+    s.lsign[j] = sg; s.lD[j] = Dl; s.laref[j] = aref;
   }
   cx.sync();
 }
@@ -591,85 +799,21 @@ MZ_HD float contact_eval(float D, const float* u, float* g, float* W) {
   if (W) { W[0] = D * (a0 + a1 + a2 + a3); W[1] = D * (a0 - a1); W[2] = D * (a2 - a3); W[3] = D * (a0 + a1); W[4] = D * (a2 + a3); }
   return 0.5f * D * (a0 * r0 * r0 + a1 * r1 * r1 + a2 * r2 * r2 + a3 * r3 * r3);
 }
-MZ_HD float contact_Jdot(const AntScratch& s, int c, int a, const float* x) {
+template <int NB>
+MZ_HD float contact_Jdot(const AntScratchT<NB>& s, int c, int a, const float* x) {
+  constexpr int NH = AntDims<NB>::NH;
   const float* J = s.cJ[c][a];
   float v = 0.f;
-  for (int k = 0; k < 6; k++) v += J[k] * x[k];
+  for (int k = 0; k < NH; k++) v += J[k] * x[hub2dof(k)];
   int leg = s.cleg[c];
-  if (leg >= 0) v += J[6] * x[6 + 2 * leg] + J[7] * x[7 + 2 * leg];
+  if (leg >= 0) v += J[NH] * x[6 + 2 * leg] + J[NH + 1] * x[7 + 2 * leg];
   return v;
 }
 
-// Fused factor + solve of an arrow system A x = sign * g:
-//   phase 1 (4 leg lanes)  2x2 inverses and T = inv * rl
-//   phase 2 (27 lanes)     21 Schur-complement entries + 6 reduced right-hand sides
-//   phase 3 (1 lane)       6x6 Cholesky and both substitutions, entirely in registers
-//   phase 4 (14 lanes)     back-substitution of the leg dofs
-template <class C>
-MZ_HD void arrow_factor_solve(const C& cx, const Arrow& A, ArrowFactor& F, const float* g, float* x, float sign) {
-  MZ_FOR(l, 4) {
-    float hh = A.ll[l][0], ha = A.ll[l][1], aa = A.ll[l][2];
-    float idet = 1.0f / (hh * aa - ha * ha);
-    float ihh = aa * idet, iha = -ha * idet, iaa = hh * idet;
-    F.inv[l][0] = ihh; F.inv[l][1] = iha; F.inv[l][2] = iaa;
-    for (int k = 0; k < 6; k++) {
-      F.T[l][0][k] = ihh * A.rl[l][0][k] + iha * A.rl[l][1][k];
-      F.T[l][1][k] = iha * A.rl[l][0][k] + iaa * A.rl[l][1][k];
-    }
-  }
-  cx.sync();
-  MZ_FOR(e, 27) {
-    if (e < 21) {
-      int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : 5;
-      int j = e - (i * (i + 1)) / 2;
-      float v = A.rr[i][j];
-      for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
-      F.L[i][j] = v;
-    } else {
-      int k = e - 21;
-      float r = g[k];
-      for (int l = 0; l < 4; l++) r -= F.T[l][0][k] * g[6 + 2 * l] + F.T[l][1][k] * g[7 + 2 * l];
-      F.rhs[k] = r;
-    }
-  }
-  cx.sync();
-  MZ_FOR(one, 1) {
-    float L[6][6], y[6];
-    for (int i = 0; i < 6; i++) for (int j = 0; j <= i; j++) L[i][j] = F.L[i][j];
-    for (int i = 0; i < 6; i++) y[i] = F.rhs[i];
-    float id[6];
-    for (int j = 0; j < 6; j++) {
-      float d = L[j][j];
-      for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-      float r = 1.0f / sqrtf(fmaxf(d, 1e-30f));
-      id[j] = r;
-      for (int i = j + 1; i < 6; i++) {
-        float t = L[i][j];
-        for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-        L[i][j] = t * r;
-      }
-    }
-    for (int i = 0; i < 6; i++) { float t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * id[i]; }
-    for (int i = 5; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < 6; k++) t -= L[k][i] * y[k]; y[i] = t * id[i]; }
-    for (int i = 0; i < 6; i++) F.rhs[i] = y[i];
-  }
-  cx.sync();
-  MZ_FOR(i, ANT_NV) {
-    float v;
-    if (i < 6) v = F.rhs[i];
-    else {
-      int l = (i - 6) >> 1, d = (i - 6) & 1;
-      float gh = g[6 + 2 * l], ga = g[7 + 2 * l];
-      v = d == 0 ? F.inv[l][0] * gh + F.inv[l][1] * ga : F.inv[l][1] * gh + F.inv[l][2] * ga;
-      for (int k = 0; k < 6; k++) v -= F.T[l][d][k] * F.rhs[k];
-    }
-    x[i] = sign * v;
-  }
-  cx.sync();
-}
-
-template <class C>
-MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) {
+template <int NB, class C>
+MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool compare) {
+  using D = AntDims<NB>;
+  constexpr int NH = D::NH, NV = D::NV, NCOL = D::NCOL;
   bool has = false;
   MZ_FOR(one, 1) { bool h = s.ncon > 0; for (int j = 0; j < 8; j++) h = h || s.lsign[j] != 0.f; s.red[0] = h ? 1.f : 0.f; }
   cx.sync();
@@ -679,13 +823,13 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
   // unconstrained acceleration (s.warm was prepared by the caller); the optimum is unique, so the start only
   // changes the iteration count.
   if (compare) {
-    MZ_FOR(i, ANT_NV) s.grad[i] = s.warm[i] - s.qas[i];
+    MZ_FOR(i, NV) s.grad[i] = s.warm[i] - s.qas[i];
     cx.sync();
     float cw = 0.f, cs = 0.f;
-    MZ_FOR(i, ANT_NV) cw += 0.5f * arrow_row_mul(s.M, s.grad, i) * s.grad[i];
+    MZ_FOR(i, NV) cw += 0.5f * arrow_row_mul<NH>(s.M, s.grad, i) * s.grad[i];
     MZ_FOR(c, s.ncon) {
       float uw[3], us[3];
-      for (int a = 0; a < 3; a++) { uw[a] = contact_Jdot(s, c, a, s.warm) - s.caref[c][a]; us[a] = contact_Jdot(s, c, a, s.qas) - s.caref[c][a]; }
+      for (int a = 0; a < 3; a++) { uw[a] = contact_Jdot<NB>(s, c, a, s.warm) - s.caref[c][a]; us[a] = contact_Jdot<NB>(s, c, a, s.qas) - s.caref[c][a]; }
       cw += contact_eval(s.cD[c], uw, nullptr, nullptr);
       cs += contact_eval(s.cD[c], us, nullptr, nullptr);
     }
@@ -698,27 +842,27 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
     }
     cw = cx.gsum(cw); cs = cx.gsum(cs);
     cx.sync();
-    MZ_FOR(i, ANT_NV) s.qacc[i] = (cw < cs) ? s.warm[i] : s.qas[i];
+    MZ_FOR(i, NV) s.qacc[i] = (cw < cs) ? s.warm[i] : s.qas[i];
   } else {
-    MZ_FOR(i, ANT_NV) s.qacc[i] = s.warm[i];
+    MZ_FOR(i, NV) s.qacc[i] = s.warm[i];
   }
   cx.sync();
   has = s.red[0] != 0.f;
-  if (!has) { MZ_FOR(i, ANT_NV) s.qacc[i] = s.qas[i]; cx.sync(); }
+  if (!has) { MZ_FOR(i, NV) s.qacc[i] = s.qas[i]; cx.sync(); }
   cx.tick(s, 4);
   bool done = !has;
   int it = 0;
   while (cx.any(!done) && it < K.max_iter) {
     // (a) M (qacc - qas); per-contact residual u, gradient block g3, curvature W and Y = W J
-    MZ_FOR(i, ANT_NV) s.search[i] = s.qacc[i] - s.qas[i];
+    MZ_FOR(i, NV) s.search[i] = s.qacc[i] - s.qas[i];
     cx.sync();
-    MZ_FOR(i, ANT_NV) s.Mx[i] = arrow_row_mul(s.M, s.search, i);
+    MZ_FOR(i, NV) s.Mx[i] = arrow_row_mul<NH>(s.M, s.search, i);
     MZ_FOR(c, s.ncon) {
       float u[3], W[5];
-      for (int a = 0; a < 3; a++) u[a] = contact_Jdot(s, c, a, s.qacc) - s.caref[c][a];
+      for (int a = 0; a < 3; a++) u[a] = contact_Jdot<NB>(s, c, a, s.qacc) - s.caref[c][a];
       for (int a = 0; a < 3; a++) s.cu[c][a] = u[a];
       contact_eval(s.cD[c], u, s.cg[c], W);
-      for (int k = 0; k < 8; k++) {
+      for (int k = 0; k < NCOL; k++) {
         float n_ = s.cJ[c][0][k], p_ = s.cJ[c][1][k], q_ = s.cJ[c][2][k];
         s.cY[c][0][k] = W[0] * n_ + W[1] * p_ + W[2] * q_;
         s.cY[c][1][k] = W[1] * n_ + W[3] * p_;
@@ -731,17 +875,17 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
       s.ljar[j] = jar; s.lact[j] = act;
     }
     cx.sync();
-    // (b) gradient (14 dofs) and Hessian (96 arrow entries); contacts of leg l are the slots [cbeg[l], cbeg[l+1])
+    // (b) gradient; contacts of leg l are the slots [cbeg[l], cbeg[l+1])
     float gpart = 0.f, apart = 0.f;  // |grad|^2 and the squared magnitude of the terms that cancel in it
-    MZ_FOR(i, ANT_NV) {
+    MZ_FOR(i, NV) {
       float g = s.Mx[i], ga = fabsf(g);
-      int c0 = 0, c1 = s.ncon, col = i;
-      if (i >= 6) { int l = (i - 6) >> 1; c0 = s.cbeg[l]; c1 = s.cbeg[l + 1]; col = 6 + ((i - 6) & 1); }
+      int c0 = 0, c1 = s.ncon, col = i < 6 ? i : i - 8;
+      if (i >= 6 && i < 14) { int l = (i - 6) >> 1; c0 = s.cbeg[l]; c1 = s.cbeg[l + 1]; col = NH + ((i - 6) & 1); }
       for (int c = c0; c < c1; c++) {
         float t = s.cJ[c][0][col] * s.cg[c][0] + s.cJ[c][1][col] * s.cg[c][1] + s.cJ[c][2][col] * s.cg[c][2];
         g += t; ga += fabsf(t);
       }
-      if (i >= 6 && s.lsign[i - 6] != 0.f) { float t = s.lsign[i - 6] * s.lact[i - 6] * s.ljar[i - 6]; g += t; ga += fabsf(t); }
+      if (i >= 6 && i < 14 && s.lsign[i - 6] != 0.f) { float t = s.lsign[i - 6] * s.lact[i - 6] * s.ljar[i - 6]; g += t; ga += fabsf(t); }
       s.grad[i] = g;
       gpart += g * g;
       apart += ga * ga;
@@ -750,19 +894,19 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
     // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
     if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
     if (!cx.any(!done)) { cx.sync(); cx.tick(s, 5); break; }
-    MZ_FOR(e, 96) {  // Hessian: 36 root-root (full square) + 48 root-leg + 12 leg-leg arrow entries
+    MZ_FOR(e, D::NHESS) {  // Hessian: NH x NH hub (full square) + 8 NH hub-leg + 12 leg-leg arrow entries
       int ci, cj, c0 = 0, c1 = s.ncon;
       float* dst;
       float acc;
-      if (e < 36) { ci = e / 6; cj = e - 6 * ci; dst = &s.H.rr[ci][cj]; acc = s.M.rr[ci][cj]; }
-      else if (e < 84) {
-        int q = e - 36, l = q / 12, r = q - 12 * l, d = r / 6;
-        cj = r - 6 * d; ci = 6 + d;
+      if (e < NH * NH) { ci = e / NH; cj = e - NH * ci; dst = &s.H.rr[ci][cj]; acc = s.M.rr[ci][cj]; }
+      else if (e < NH * NH + 8 * NH) {
+        int q = e - NH * NH, l = q / (2 * NH), r = q - 2 * NH * l, d = r / NH;
+        cj = r - NH * d; ci = NH + d;
         c0 = s.cbeg[l]; c1 = s.cbeg[l + 1];
         dst = &s.H.rl[l][d][cj]; acc = s.M.rl[l][d][cj];
       } else {
-        int q = e - 84, l = q / 3, t = q - 3 * l;
-        ci = 6 + (t == 2 ? 1 : 0); cj = 6 + (t >= 1 ? 1 : 0);
+        int q = e - NH * NH - 8 * NH, l = q / 3, t = q - 3 * l;
+        ci = NH + (t == 2 ? 1 : 0); cj = NH + (t >= 1 ? 1 : 0);
         c0 = s.cbeg[l]; c1 = s.cbeg[l + 1];
         dst = &s.H.ll[l][t]; acc = s.M.ll[l][t];
         if (t != 1) acc += s.lact[2 * l + (t == 2 ? 1 : 0)];
@@ -774,12 +918,12 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
     cx.sync();
     cx.tick(s, 5);
     // (c) Newton direction
-    arrow_factor_solve(cx, s.H, s.F, s.grad, s.search, -1.f);
+    arrow_factor_solve<NH, NV>(cx, s.H, s.F, s.grad, s.search, -1.f);
     cx.tick(s, 6);
     // (d) exact line search on phi(alpha) = cost(qacc + alpha * search).  The Newton direction makes
     // alpha = 1 the exact minimiser whenever the active set at qacc + search equals the one H was built on:
     // test that first with one ballot; only otherwise find the root of the piecewise-linear phi'.
-    MZ_FOR(c, s.ncon) for (int a = 0; a < 3; a++) s.cjv[c][a] = contact_Jdot(s, c, a, s.search);
+    MZ_FOR(c, s.ncon) for (int a = 0; a < 3; a++) s.cjv[c][a] = contact_Jdot<NB>(s, c, a, s.search);
     MZ_FOR(j, 8) s.ljv[j] = s.lsign[j] * s.search[6 + j];
     cx.sync();
     bool changed = false;
@@ -797,20 +941,20 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
     bool exact = !changed;
     if (changed) {
       float p1 = 0.f, p2 = 0.f;
-      MZ_FOR(i, ANT_NV) { float ms = arrow_row_mul(s.M, s.search, i); p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
+      MZ_FOR(i, NV) { float ms = arrow_row_mul<NH>(s.M, s.search, i); p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
       p1 = cx.gsum(p1); p2 = cx.gsum(p2);
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
       for (int ls = 0; ls < K.ls_iter; ls++) {
         float d1 = 0.f, d2 = 0.f;
         MZ_FOR(c, s.ncon) {
-          float D = s.cD[c];
+          float Dc = s.cD[c];
           float v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
           float u0 = s.cu[c][0] + alpha * v0, u1 = s.cu[c][1] + alpha * v1, u2 = s.cu[c][2] + alpha * v2;
           float r, v;
-          r = u0 + u1; v = v0 + v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
-          r = u0 - u1; v = v0 - v1; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
-          r = u0 + u2; v = v0 + v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
-          r = u0 - u2; v = v0 - v2; if (r < 0.f) { d1 += D * r * v; d2 += D * v * v; }
+          r = u0 + u1; v = v0 + v1; if (r < 0.f) { d1 += Dc * r * v; d2 += Dc * v * v; }
+          r = u0 - u1; v = v0 - v1; if (r < 0.f) { d1 += Dc * r * v; d2 += Dc * v * v; }
+          r = u0 + u2; v = v0 + v2; if (r < 0.f) { d1 += Dc * r * v; d2 += Dc * v * v; }
+          r = u0 - u2; v = v0 - v2; if (r < 0.f) { d1 += Dc * r * v; d2 += Dc * v * v; }
         }
         MZ_FOR(j, 8) {
           if (s.lsign[j] != 0.f) { float r = s.ljar[j] + alpha * s.ljv[j]; if (r < 0.f) { d1 += s.lD[j] * r * s.ljv[j]; d2 += s.lD[j] * s.ljv[j] * s.ljv[j]; } }
@@ -827,12 +971,9 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
         alpha = next;
       }
     }
-#ifdef MZ_TRACE
-    printf("  it %d gnorm %.3e anorm %.3e changed %d alpha %.6f ncon %d\n", it, gnorm, anorm, (int)changed, alpha, s.ncon);
-#endif
     if (done) alpha = 0.f;
     cx.sync();
-    MZ_FOR(i, ANT_NV) s.qacc[i] += alpha * s.search[i];
+    MZ_FOR(i, NV) s.qacc[i] += alpha * s.search[i];
     cx.sync();
     // The full Newton step stayed inside one active set: the cost is exactly quadratic there, so the new
     // point is its minimiser — no verification pass needed.
@@ -848,26 +989,27 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratch& s, bool compare) 
 // ------------------------------------------------------------------ one forward-dynamics evaluation: qacc from (qpos, qvel, fact)
 // `first`: first evaluation of an env.step (warm = MuJoCo's qacc_warmstart, compared by cost against
 // qacc_smooth); otherwise s.warm holds the previous evaluation's solution and s.qas its qacc_smooth.
-template <class C>
-MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratch& s, bool first) {
+template <int NB, class C>
+MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
+  using D = AntDims<NB>;
   cx.tick(s, 9);
-  ant_kin_crb(cx, K, s);
+  ant_kin_crb<NB>(cx, K, s);
   cx.tick(s, 0);
-  ant_bias(cx, K, s);
+  ant_bias<NB>(cx, K, s);
   cx.tick(s, 1);
-  if (!first) { MZ_FOR(i, ANT_NV) s.warm[i] -= s.qas[i]; cx.sync(); }
-  arrow_factor_solve(cx, s.M, s.F, s.qfs, s.qas, 1.f);
-  if (!first) { MZ_FOR(i, ANT_NV) s.warm[i] += s.qas[i]; cx.sync(); }
+  if (!first) { MZ_FOR(i, D::NV) s.warm[i] -= s.qas[i]; cx.sync(); }
+  arrow_factor_solve<D::NH, D::NV>(cx, s.M, s.F, s.qfs, s.qas, 1.f);
+  if (!first) { MZ_FOR(i, D::NV) s.warm[i] += s.qas[i]; cx.sync(); }
   cx.tick(s, 2);
-  ant_constraints(cx, K, s);
+  ant_constraints<NB>(cx, K, s);
   cx.tick(s, 3);
-  ant_solve(cx, K, s, first);
+  ant_solve<NB>(cx, K, s, first);
 }
 
-// qpos <- integrate(qpos, vel, h): free joint on the manifold, hinges linear (MuJoCo mj_integratePos)
-template <class C>
-MZ_HD void ant_integrate_pos(const C& cx, AntScratch& s, const float* base, const float* vel, float h) {
-  MZ_FOR(i, 12) {
+// qpos <- integrate(qpos, vel, h): free joint on the manifold, hinges and block slides linear (mj_integratePos)
+template <int NB, class C>
+MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base, const float* vel, float h) {
+  MZ_FOR(i, 12 + 2 * NB) {
     if (i < 3) s.qpos[i] = base[i] + h * vel[i];
     else if (i == 3) {
       float w[3] = {vel[3], vel[4], vel[5]};
@@ -887,28 +1029,29 @@ MZ_HD void ant_integrate_pos(const C& cx, AntScratch& s, const float* base, cons
       }
       for (int k = 0; k < 4; k++) s.qpos[3 + k] = q[k];
     } else {
-      int j = i - 4;  // hinges 0..7
+      int j = i - 4;  // hinges 0..7, then block slides
       s.qpos[7 + j] = base[7 + j] + h * vel[6 + j];
     }
   }
 }
 
 // one mj_step with RK4.  State in s.qpos / s.qvel / s.warm, actuator forces in s.fact.
-template <class C>
-MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratch& s, bool first_frame) {
+template <int NB, class C>
+MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame) {
+  using D = AntDims<NB>;
   const float h = K.h;
-  MZ_FOR(i, 16) { if (i < ANT_NQ) s.x0q[i] = s.qpos[i]; }
-  MZ_FOR(i, ANT_NV) { s.x0v[i] = s.qvel[i]; s.accv[i] = 0.f; s.accf[i] = 0.f; }
+  MZ_FOR(i, D::NQ) s.x0q[i] = s.qpos[i];
+  MZ_FOR(i, D::NV) { s.x0v[i] = s.qvel[i]; s.accv[i] = 0.f; s.accf[i] = 0.f; }
   cx.sync();
   for (int st = 0; st < 4; st++) {
-    ant_forward(cx, K, s, first_frame && st == 0);
+    ant_forward<NB>(cx, K, s, first_frame && st == 0);
     const float bw = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float aw = st == 2 ? 1.0f : 0.5f;  // Butcher A: diag(1/2, 1/2, 1)
     // accumulate B-weighted sums, form the next stage state from this stage's (qvel, qacc)
-    MZ_FOR(i, ANT_NV) {
+    MZ_FOR(i, D::NV) {
       s.accv[i] += bw * s.qvel[i];
       s.accf[i] += bw * s.qacc[i];
-      s.Ms[i] = aw * s.qvel[i];   // dX velocity for the position update
+      s.grad[i] = aw * s.qvel[i];   // dX velocity for the position update
       s.Mx[i] = s.x0v[i] + h * aw * s.qacc[i];
       // initial guess of the next stage's constraint solve = this stage's solution (MuJoCo re-uses the
       // previous step's; the optimum is unique, only the iteration count changes); after the 4th stage this
@@ -917,70 +1060,93 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratch& s, bool first_f
     }
     cx.sync();
     if (st < 3) {
-      ant_integrate_pos(cx, s, s.x0q, s.Ms, h);
-      MZ_FOR(i, ANT_NV) s.qvel[i] = s.Mx[i];
+      ant_integrate_pos<NB>(cx, s, s.x0q, s.grad, h);
+      MZ_FOR(i, D::NV) s.qvel[i] = s.Mx[i];
       cx.sync();
     }
   }
-  ant_integrate_pos(cx, s, s.x0q, s.accv, h);
-  MZ_FOR(i, ANT_NV) s.qvel[i] = s.x0v[i] + h * s.accf[i];
+  ant_integrate_pos<NB>(cx, s, s.x0q, s.accv, h);
+  MZ_FOR(i, D::NV) s.qvel[i] = s.x0v[i] + h * s.accf[i];
   cx.sync();
 }
 
 // ------------------------------------------------------------------ MazeTask reward / termination on the fp32 observation
 MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int* term, int* goal_idx) {
-  const float* rs = T.reward_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
-  const float* ts = T.term_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
+  float slot_a[3] = {obs[0], obs[1], obs[2]}, slot_o[3] = {obs[3], obs[4], obs[5]};
   int tm = 0, first = -1;
   for (int g = 0; g < T.ngoal; g++) {
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < T.goal_dim[g]; k++) { float e = ts[k] - T.goal_pos[g][k]; a += e * e; float f = rs[k] - T.goal_pos[g][k]; b += f * f; }
+    for (int k = 0; k < 3; k++)
+      if (k < T.goal_dim[g]) {
+        float e = (T.term_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; a += e * e;
+        float f = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; b += f * f;
+      }
     if (!tm && sqrtf(a) <= T.thr[g]) tm = 1;
     if (first < 0 && sqrtf(b) <= T.thr[g]) first = g;
   }
   float r = 0.f;
   if (T.reward_kind == MZ_REWARD_FIRST_MATCH) r = T.reward_binary ? (tm ? 1.0f : T.penalty) : (first >= 0 ? T.rscale[first] : T.penalty);
-  else if (T.reward_kind == MZ_REWARD_NEG_DIST) {
+  else if (T.reward_kind == MZ_REWARD_NEG_DIST && T.ngoal > 0) {
     float a = 0.f;
-    for (int k = 0; k < T.goal_dim[0]; k++) { float e = rs[k] - T.goal_pos[0][k]; a += e * e; }
+    for (int k = 0; k < 3; k++)
+      if (k < T.goal_dim[0]) { float e = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[0][k]; a += e * e; }
     r = -sqrtf(a) / T.task_scale;
   }
   *reward = r; *term = tm; *goal_idx = first;
 }
 
+// observation element i (maze_env.py:351-369): qpos[:3] | block xpos (3 each, if observed) | qpos[3:15] | qvel[:14] | t/1000
+template <int NB>
+MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t) {
+  int nb3 = K.observe_blocks ? 3 * NB : 0;
+  if (i < 3) return s.qpos[i];
+  if (i < 3 + nb3) {
+    int k = (i - 3) / 3, c = (i - 3) - 3 * k;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < (NB ? NB : 1); j++)
+      if (j == k && j < NB) v = c == 2 ? K.block_pos0[j][2] : K.block_pos0[j][c] + s.qpos[15 + 2 * j + c];
+    return v;
+  }
+  int q = i - nb3;
+  if (q < ANT_NQ) return s.qpos[q];
+  if (q < ANT_NQ + ANT_NV) return s.qvel[q - ANT_NQ];
+  return (float)t * 0.001f;
+}
+
 // ------------------------------------------------------------------ MazeEnv.step for the Ant (maze_env.py:448-481, ant.py:61-73)
-// in: s.qpos/qvel/warm loaded, action[8], t (steps so far).  out: obs[30], reward, done, goal_idx, info[4]
-template <class C>
-MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratch& s, const float* action, int t_in, float* obs, float* reward,
+// in: s.qpos/qvel/warm loaded, action[8], t (steps so far).  out: obs[obs_dim], reward, done, goal_idx, info[4]
+template <int NB, class C>
+MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const float* action, int t_in, float* obs, float* reward,
                         uint8_t* done, int* goal_idx, float* info, int* t_out) {
-  MZ_FOR(i, ANT_NV) s.fact[i] = 0.f;
+  using D = AntDims<NB>;
+  MZ_FOR(i, D::NV) s.fact[i] = 0.f;
   MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
   cx.sync();
   MZ_FOR(u, ANT_NU) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(action[u], K.ctrl_lo), K.ctrl_hi);
   cx.sync();
-  for (int f = 0; f < K.frame_skip; f++) ant_mj_step(cx, K, s, f == 0);
+  for (int f = 0; f < K.frame_skip; f++) ant_mj_step<NB>(cx, K, s, f == 0);
   int t = t_in + 1;
-  MZ_FOR(i, ANT_OBS) {
-    float v = i < ANT_NQ ? s.qpos[i] : (i < ANT_NQ + ANT_NV ? s.qvel[i - ANT_NQ] : (float)t * 0.001f);
-    obs[i] = v;
-  }
+  int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
+  MZ_FOR(i, obs_dim) obs[i] = ant_obs_elem<NB>(K, s, i, t);
   MZ_FOR(one, 1) {
     float dt = K.h * (float)K.frame_skip;
     float vx = (s.qpos[0] - s.red[1]) / dt, vy = (s.qpos[1] - s.red[2]) / dt;
     float fwd = sqrtf(vx * vx + vy * vy), cc = 0.f;
     for (int u = 0; u < ANT_NU; u++) cc += action[u] * action[u];
     cc *= K.task.ctrl_w;
-    float o3[6] = {s.qpos[0], s.qpos[1], s.qpos[2], s.qpos[3], s.qpos[4], s.qpos[5]};
+    float o6[6];
+    for (int k = 0; k < 6; k++) o6[k] = ant_obs_elem<NB>(K, s, k, t);
     float outer; int tm, gi;
-    task_eval_dev(K.task, o3, &outer, &tm, &gi);
+    task_eval_dev(K.task, o6, &outer, &tm, &gi);
     *reward = K.task.inner_scale * (K.task.fwd_w * fwd - cc) + outer;
     *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
     if (goal_idx) *goal_idx = gi;
     if (info) { info[0] = s.qpos[0]; info[1] = s.qpos[1]; info[2] = fwd; info[3] = -cc; }
     *t_out = t;
     bool badv = false;
-    for (int i = 0; i < ANT_NQ; i++) badv = badv || !(fabsf(s.qpos[i]) < 1e10f);
-    for (int i = 0; i < ANT_NV; i++) badv = badv || !(fabsf(s.qvel[i]) < 1e10f);
+    for (int i = 0; i < D::NQ; i++) badv = badv || !(fabsf(s.qpos[i]) < 1e10f);
+    for (int i = 0; i < D::NV; i++) badv = badv || !(fabsf(s.qvel[i]) < 1e10f);
     if (badv) s.status |= MZ_STATUS_BAD_STATE;
   }
   cx.sync();

@@ -16,7 +16,6 @@
 
 #include "../../include/mazestep.h"
 
-#define ANT_NC 16     // contact slots per env (random-action rollouts peak at 4; overflow is flagged per env)
 #define ANT_NBODY 13  // moving bodies: torso + 4 x (leg, aux, ankle)
 #define ANT_NV 14
 #define ANT_NQ 15
@@ -58,6 +57,9 @@ struct AntDev {
   TaskDev task;
   float qpos0[ANT_NQ];
   int reset_kind;
+  // movable XY blocks (all the same size: one maze cell); see maze_env.py:563-660
+  int nblock, observe_blocks;
+  float block_mass, block_bw_tran, block_half[3], block_pos0[4][3];
   // solver
   int max_iter, ls_iter, trust_exact;
   float tol, rtol, inv_scale;  // inv_scale = 1 / (meaninertia * nv)
@@ -107,8 +109,22 @@ static inline void maze_dev_from_model(MazeDev* z, const mz_model* m) {
 
 static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, int errlen) {
   memset(a, 0, sizeof(*a));
-  if (m->robot != MZ_ROBOT_ANT || m->nbody != 14 || m->nv != ANT_NV || m->nq != ANT_NQ || m->nu != ANT_NU || m->ngeom != 14)
-    return ant_fail(err, errlen, "ant kernel: model is not the 14-body / 14-dof ant");
+  const int nb = m->nblock;
+  if (nb < 0 || nb > 4) return ant_fail(err, errlen, "ant kernel: at most 4 movable blocks");
+  if (m->robot != MZ_ROBOT_ANT || m->nbody != 14 + nb || m->nv != ANT_NV + 2 * nb || m->nq != ANT_NQ + 2 * nb || m->nu != ANT_NU ||
+      m->ngeom != 14 + nb)
+    return ant_fail(err, errlen, "ant kernel: model is not the 14-body / 14-dof ant (+ XY blocks)");
+  a->nblock = nb; a->observe_blocks = m->observe_blocks;
+  for (int k = 0; k < nb; k++) {
+    int b = m->block_bodyid[k], g = m->block_geomid[k], j0 = m->body_jntadr[b];
+    if (b != 14 + k || m->body_jntnum[b] != 2 || m->jnt_type[j0] != MZ_JNT_SLIDE || m->jnt_type[j0 + 1] != MZ_JNT_SLIDE ||
+        m->jnt_dofadr[j0] != ANT_NV + 2 * k || fabs(m->jnt_axis[j0][0] - 1.0) > 1e-12 || fabs(m->jnt_axis[j0 + 1][1] - 1.0) > 1e-12 ||
+        m->geom_type[g] != MZ_GEOM_BOX || m->jnt_limited[j0] || m->jnt_limited[j0 + 1])
+      return ant_fail(err, errlen, "ant kernel: movable block is not a slide-x / slide-y box body");
+    for (int q = 0; q < 3; q++) { a->block_pos0[k][q] = (float)m->body_pos[b][q]; a->block_half[q] = (float)m->geom_size[g][q]; }
+    a->block_mass = (float)m->body_mass[b];
+    a->block_bw_tran = (float)m->body_invweight0[b][0];
+  }
   if (m->jnt_type[0] != MZ_JNT_FREE || m->geom_type[0] != MZ_GEOM_PLANE || m->geom_type[1] != MZ_GEOM_SPHERE)
     return ant_fail(err, errlen, "ant kernel: expected free root joint, floor plane, torso sphere");
   a->h = (float)m->timestep; a->gz = (float)m->gravity[2]; a->frame_skip = m->frame_skip;
@@ -158,7 +174,7 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
   task_dev_from_model(&a->task, m);
   for (int k = 0; k < ANT_NQ; k++) a->qpos0[k] = (float)m->qpos0[k];
   a->reset_kind = m->reset_qvel_kind;
-  a->max_iter = 8; a->ls_iter = 12; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
+  a->max_iter = nb ? 24 : 10; a->ls_iter = 12; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
   a->inv_scale = (float)(1.0 / (m->meaninertia * m->nv));
   return MZ_OK;
 }

@@ -10,7 +10,8 @@
 //   *_reset / state copy / debug kernels.
 //
 // Data layout in HBM
-//   Ant:   state[N][48] fp32 record  = qpos[15] | qvel[14] | qacc_warmstart[14] | t | episode | pad[3]
+//   Ant:   state[N][REC] fp32 record = qpos[nq] | qvel[nv] | qacc_warmstart[nv] | t | episode | pad
+//          (REC = 48 words for the plain ant, 64 with one movable block: AntDims<NB>::REC)
 //          (a lane group reads 48 consecutive words: coalesced for lane-group-per-env kernels;
 //          SoA would scatter a group's loads over 48 cache lines)
 //   Point: SoA  qpos[3][N] | qvel[3][N] fp32, t[N], episode[N] i32 (one env per lane: SoA is
@@ -26,9 +27,6 @@
 #include "ant_dyn.h"
 #include "point_dyn.h"
 
-#define ANT_REC 48
-#define REC_T 43
-#define REC_EP 44
 
 // ------------------------------------------------------------------ device context of a lane group
 template <int G, bool PROF = false>
@@ -36,7 +34,8 @@ struct DevCtx {
   static constexpr int nlanes = G;
   int l;
   // phase timer (PROF builds only): lane 0 of the group accumulates shader cycles since the previous tick
-  __device__ __forceinline__ void tick(AntScratch& s, int id) const {
+  template <class S>
+  __device__ __forceinline__ void tick(S& s, int id) const {
     if constexpr (PROF) {
       if (l == 0) {
         unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -115,67 +114,72 @@ __host__ __device__ __forceinline__ uint64_t episode_seed(uint64_t seed, uint32_
 }
 
 // ------------------------------------------------------------------ Ant kernels
-template <int G, bool P>
-__device__ __forceinline__ void ant_load(const DevCtx<G, P>& cx, AntScratch& s, const float* rec) {
-  for (int i = cx.l; i < REC_T; i += G) {
+template <int NB, int G, bool P>
+__device__ __forceinline__ void ant_load(const DevCtx<G, P>& cx, AntScratchT<NB>& s, const float* rec) {
+  using D = AntDims<NB>;
+  for (int i = cx.l; i < D::REC_T; i += G) {
     float v = rec[i];
-    if (i < ANT_NQ) s.qpos[i] = v;
-    else if (i < ANT_NQ + ANT_NV) s.qvel[i - ANT_NQ] = v;
-    else s.warm[i - ANT_NQ - ANT_NV] = v;
+    if (i < D::NQ) s.qpos[i] = v;
+    else if (i < D::NQ + D::NV) s.qvel[i - D::NQ] = v;
+    else s.warm[i - D::NQ - D::NV] = v;
   }
 }
-template <int G, bool P>
-__device__ __forceinline__ void ant_store(const DevCtx<G, P>& cx, const AntScratch& s, float* rec) {
-  for (int i = cx.l; i < REC_T; i += G) {
-    float v = i < ANT_NQ ? s.qpos[i] : (i < ANT_NQ + ANT_NV ? s.qvel[i - ANT_NQ] : s.warm[i - ANT_NQ - ANT_NV]);
+template <int NB, int G, bool P>
+__device__ __forceinline__ void ant_store(const DevCtx<G, P>& cx, const AntScratchT<NB>& s, float* rec) {
+  using D = AntDims<NB>;
+  for (int i = cx.l; i < D::REC_T; i += G) {
+    float v = i < D::NQ ? s.qpos[i] : (i < D::NQ + D::NV ? s.qvel[i - D::NQ] : s.warm[i - D::NQ - D::NV]);
     rec[i] = v;
   }
 }
 
 struct AntIO {  // per-env staging of the step's inputs / outputs next to the scratch block
-  float act[ANT_NU], obs[ANT_OBS + 2], out[8];
+  float act[ANT_NU], obs[MZ_MAX_OBS], out[8];
   int iout[4];
 };
-struct AntEnvLDS { AntScratch s; AntIO io; };
+template <int NB>
+struct AntEnvLDS { AntScratchT<NB> s; AntIO io; };
 
 // Register budget per lane-group width: the batch is fixed (4096 envs/GPU), so the wave count is 64*N/G and
 // the kernel must fit  N*G/64 / 1024 SIMDs  waves per SIMD to be resident in one round.
 template <int G>
 constexpr int ant_waves_per_simd() { return G >= 64 ? 4 : (G == 32 ? 2 : 1); }
 
-template <int G, bool PROF>
-__global__ __launch_bounds__(256, ant_waves_per_simd<G>()) void ant_step_kernel(AntDev K, int n, float* __restrict__ state, const float* __restrict__ actions,
+template <int NB, int G, bool PROF>
+__global__ __launch_bounds__(256, (NB ? 1 : ant_waves_per_simd<G>())) void ant_step_kernel(AntDev K, int n, float* __restrict__ state, const float* __restrict__ actions,
                                                        float* __restrict__ obs, float* __restrict__ reward,
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
                                                        uint64_t seed, uint64_t env0, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  AntEnvLDS* lds = reinterpret_cast<AntEnvLDS*>(lds_raw);
+  using D = AntDims<NB>;
+  AntEnvLDS<NB>* lds = reinterpret_cast<AntEnvLDS<NB>*>(lds_raw);
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
   const int slot = threadIdx.x / G;
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
   if (!live) env = n - 1;  // surplus groups shadow the last env (no stores)
-  AntScratch& s = lds[slot].s;
+  AntScratchT<NB>& s = lds[slot].s;
   float* act_s = lds[slot].io.act;
   float* obs_s = lds[slot].io.obs;
   float* out_s = lds[slot].io.out;
   int* iout_s = lds[slot].io.iout;
-  float* rec = state + (size_t)env * ANT_REC;
-  ant_load(cx, s, rec);
+  float* rec = state + (size_t)env * D::REC;
+  ant_load<NB>(cx, s, rec);
   for (int i = cx.l; i < ANT_NU; i += G) act_s[i] = actions[(size_t)env * ANT_NU + i];
-  int t_in = ((const int*)rec)[REC_T];
-  uint32_t episode = ((const uint32_t*)rec)[REC_EP];
+  int t_in = ((const int*)rec)[D::REC_T];
+  uint32_t episode = ((const uint32_t*)rec)[D::REC_T + 1];
+  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
   if constexpr (PROF) { if (cx.l == 0) { for (int k = 0; k < 16; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
   cx.sync();
   uint8_t* dn = (uint8_t*)&iout_s[0];
-  ant_env_step(cx, K, s, act_s, t_in, obs_s, &out_s[0], dn, &iout_s[1], &out_s[1], &iout_s[2]);
+  ant_env_step<NB>(cx, K, s, act_s, t_in, obs_s, &out_s[0], dn, &iout_s[1], &out_s[1], &iout_s[2]);
   cx.sync();
   const uint8_t d = *dn;
   const int t_new = iout_s[2];
   if (live) {
-    for (int i = cx.l; i < ANT_OBS; i += G) obs[(size_t)env * ANT_OBS + i] = obs_s[i];
+    for (int i = cx.l; i < obs_dim; i += G) obs[(size_t)env * obs_dim + i] = obs_s[i];
     if (cx.l == 0) {
       reward[env] = out_s[0];
       done[env] = d;
@@ -187,13 +191,14 @@ __global__ __launch_bounds__(256, ant_waves_per_simd<G>()) void ant_step_kernel(
   if (auto_reset && d) {  // masked reset inside the step
     episode += 1;
     uint64_t es = episode_seed(seed, episode);
-    for (int i = cx.l; i < ANT_NQ; i += G) s.qpos[i] = reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env, i);
-    for (int i = cx.l; i < ANT_NV; i += G) { s.qvel[i] = reset_qvel(K.reset_kind, ANT_NQ, es, env0 + (uint64_t)env, i); s.warm[i] = 0.f; }
+    // robot coordinates get the reset noise; movable blocks return to their cells (ant.py:84-96)
+    for (int i = cx.l; i < D::NQ; i += G) s.qpos[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env, i) : 0.f;
+    for (int i = cx.l; i < D::NV; i += G) { s.qvel[i] = i < ANT_NV ? reset_qvel(K.reset_kind, D::NQ, es, env0 + (uint64_t)env, i) : 0.f; s.warm[i] = 0.f; }
   }
   cx.sync();
   if (live) {
-    ant_store(cx, s, rec);
-    if (cx.l == 0) { ((int*)rec)[REC_T] = (auto_reset && d) ? 0 : t_new; ((uint32_t*)rec)[REC_EP] = episode; }
+    ant_store<NB>(cx, s, rec);
+    if (cx.l == 0) { ((int*)rec)[D::REC_T] = (auto_reset && d) ? 0 : t_new; ((uint32_t*)rec)[D::REC_T + 1] = episode; }
   }
   if constexpr (PROF) {
     cx.tick(s, 10);
@@ -201,68 +206,80 @@ __global__ __launch_bounds__(256, ant_waves_per_simd<G>()) void ant_step_kernel(
   }
 }
 
-template <int G>
+template <int NB, int G>
 __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const float* __restrict__ state,
                                                           const float* __restrict__ actions, float* __restrict__ qacc,
                                                           int* __restrict__ counts) {
+  using D = AntDims<NB>;
   constexpr int EPB = 64 / G;
-  __shared__ AntScratch sc[EPB];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  AntScratchT<NB>* sc = reinterpret_cast<AntScratchT<NB>*>(lds_raw);
   DevCtx<G> cx{(int)threadIdx.x % G};
   const int slot = threadIdx.x / G;
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
   if (!live) env = n - 1;
-  AntScratch& s = sc[slot];
-  ant_load(cx, s, state + (size_t)env * ANT_REC);
-  for (int i = cx.l; i < ANT_NV; i += G) s.fact[i] = 0.f;
+  AntScratchT<NB>& s = sc[slot];
+  ant_load<NB>(cx, s, state + (size_t)env * D::REC);
+  for (int i = cx.l; i < D::NV; i += G) s.fact[i] = 0.f;
   if (cx.l == 0) s.status = 0;
   cx.sync();
   if (actions)
     for (int u = cx.l; u < ANT_NU; u += G) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(actions[(size_t)env * ANT_NU + u], K.ctrl_lo), K.ctrl_hi);
   cx.sync();
-  ant_forward(cx, K, s, true);
+  ant_forward<NB>(cx, K, s, true);
   if (live) {
-    for (int i = cx.l; i < ANT_NV; i += G) qacc[(size_t)env * ANT_NV + i] = s.qacc[i];
+    for (int i = cx.l; i < D::NV; i += G) qacc[(size_t)env * D::NV + i] = s.qacc[i];
     if (cx.l == 0 && counts) { counts[2 * env] = s.ncon; counts[2 * env + 1] = s.iters; }
   }
 }
 
-__global__ void ant_reset_kernel(AntDev K, int n, float* state, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+struct AntLayout { int nq, nv, rec, rec_t, obs_dim, nblock3; };  // record layout of the instantiated NB
+
+__global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
-  float* rec = state + (size_t)env * ANT_REC;
+  float* rec = state + (size_t)env * L.rec;
   if (!mask || mask[env]) {
-    for (int i = 0; i < ANT_NQ; i++) rec[i] = reset_qpos(K.qpos0[i], seed, env0 + (uint64_t)env, i);
-    for (int i = 0; i < ANT_NV; i++) { rec[ANT_NQ + i] = reset_qvel(K.reset_kind, ANT_NQ, seed, env0 + (uint64_t)env, i); rec[ANT_NQ + ANT_NV + i] = 0.f; }
-    ((int*)rec)[REC_T] = 0;
-    ((uint32_t*)rec)[REC_EP] = 0;
+    for (int i = 0; i < L.nq; i++) rec[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], seed, env0 + (uint64_t)env, i) : 0.f;
+    for (int i = 0; i < L.nv; i++) {
+      rec[L.nq + i] = i < ANT_NV ? reset_qvel(K.reset_kind, L.nq, seed, env0 + (uint64_t)env, i) : 0.f;
+      rec[L.nq + L.nv + i] = 0.f;
+    }
+    ((int*)rec)[L.rec_t] = 0;
+    ((uint32_t*)rec)[L.rec_t + 1] = 0;
   }
   if (obs) {
-    for (int i = 0; i < ANT_NQ + ANT_NV; i++) obs[(size_t)env * ANT_OBS + i] = rec[i];
-    obs[(size_t)env * ANT_OBS + ANT_OBS - 1] = (float)((int*)rec)[REC_T] * 0.001f;
+    float* o = obs + (size_t)env * L.obs_dim;
+    int k = 0;
+    for (int i = 0; i < 3; i++) o[k++] = rec[i];
+    for (int b = 0; b < L.nblock3 / 3; b++) { o[k++] = K.block_pos0[b][0] + rec[15 + 2 * b]; o[k++] = K.block_pos0[b][1] + rec[16 + 2 * b]; o[k++] = K.block_pos0[b][2]; }
+    for (int i = 3; i < ANT_NQ; i++) o[k++] = rec[i];
+    for (int i = 0; i < ANT_NV; i++) o[k++] = rec[L.nq + i];
+    o[k] = (float)((int*)rec)[L.rec_t] * 0.001f;
   }
 }
 
 // row-major API arrays <-> state records
-__global__ void ant_set_state_kernel(int n, float* state, const float* qpos, const float* qvel, const float* warm, const int* t) {
+__global__ void ant_set_state_kernel(AntLayout L, int n, float* state, const float* qpos, const float* qvel, const float* warm, const int* t) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int env = idx / ANT_REC, i = idx % ANT_REC;
+  int env = idx / L.rec, i = idx % L.rec;
   if (env >= n) return;
-  float* rec = state + (size_t)env * ANT_REC;
-  if (i < ANT_NQ) { if (qpos) rec[i] = qpos[(size_t)env * ANT_NQ + i]; }
-  else if (i < ANT_NQ + ANT_NV) { if (qvel) rec[i] = qvel[(size_t)env * ANT_NV + i - ANT_NQ]; }
-  else if (i < REC_T) { if (warm) rec[i] = warm[(size_t)env * ANT_NV + i - ANT_NQ - ANT_NV]; }
-  else if (i == REC_T) { if (t) ((int*)rec)[REC_T] = t[env]; }
+  float* rec = state + (size_t)env * L.rec;
+  if (i < L.nq) { if (qpos) rec[i] = qpos[(size_t)env * L.nq + i]; }
+  else if (i < L.nq + L.nv) { if (qvel) rec[i] = qvel[(size_t)env * L.nv + i - L.nq]; }
+  else if (i < L.rec_t) { if (warm) rec[i] = warm[(size_t)env * L.nv + i - L.nq - L.nv]; }
+  else if (i == L.rec_t) { if (t) ((int*)rec)[L.rec_t] = t[env]; }
 }
-__global__ void ant_get_state_kernel(int n, const float* state, float* qpos, float* qvel, float* warm, int* t) {
+__global__ void ant_get_state_kernel(AntLayout L, int n, const float* state, float* qpos, float* qvel, float* warm, int* t) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int env = idx / ANT_REC, i = idx % ANT_REC;
+  int env = idx / L.rec, i = idx % L.rec;
   if (env >= n) return;
-  const float* rec = state + (size_t)env * ANT_REC;
-  if (i < ANT_NQ) { if (qpos) qpos[(size_t)env * ANT_NQ + i] = rec[i]; }
-  else if (i < ANT_NQ + ANT_NV) { if (qvel) qvel[(size_t)env * ANT_NV + i - ANT_NQ] = rec[i]; }
-  else if (i < REC_T) { if (warm) warm[(size_t)env * ANT_NV + i - ANT_NQ - ANT_NV] = rec[i]; }
-  else if (i == REC_T) { if (t) t[env] = ((const int*)rec)[REC_T]; }
+  const float* rec = state + (size_t)env * L.rec;
+  if (i < L.nq) { if (qpos) qpos[(size_t)env * L.nq + i] = rec[i]; }
+  else if (i < L.nq + L.nv) { if (qvel) qvel[(size_t)env * L.nv + i - L.nq] = rec[i]; }
+  else if (i < L.rec_t) { if (warm) warm[(size_t)env * L.nv + i - L.nq - L.nv] = rec[i]; }
+  else if (i == L.rec_t) { if (t) t[env] = ((const int*)rec)[L.rec_t]; }
 }
 
 // ------------------------------------------------------------------ Point kernels (SoA: q0 q1 q2 v0 v1 v2 | t | episode)
@@ -355,6 +372,7 @@ struct mz_handle {
   mz_model model;
   int n, device, robot;
   AntDev ant;
+  AntLayout lay;
   PointDev* point_dev;  // device copy
   PointDev point;
   float* state;         // ant: [n][48]; point: [6][n]
@@ -381,29 +399,50 @@ static int set_err(mz_handle* h, int code, const char* what, hipError_t e) {
     if (_e != hipSuccess) return set_err((h), MZ_ERR_HIP, #call, _e);        \
   } while (0)
 
-template <int G>
+template <int NB, int G>
 static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
-  const int wpb = h->waves_per_block, epb = wpb * 64 / G;
-  const size_t lds = (size_t)epb * sizeof(AntEnvLDS);
+  int wpb = h->waves_per_block;
+  int epb = wpb * 64 / G;
+  size_t lds = (size_t)epb * sizeof(AntEnvLDS<NB>);
+  while (lds > 160 * 1024 && wpb > 1) { wpb /= 2; epb = wpb * 64 / G; lds = (size_t)epb * sizeof(AntEnvLDS<NB>); }
   const dim3 grid((h->n + epb - 1) / epb), block(64 * wpb);
   hipError_t e;
   if (h->prof) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ant_step_kernel<G, true>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
+    hipLaunchKernelGGL((ant_step_kernel<NB, G, true>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
                        h->auto_reset, h->seed, h->env0, h->prof);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ant_step_kernel<G, false>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
+    hipLaunchKernelGGL((ant_step_kernel<NB, G, false>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
                        h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr);
   }
   return hipSuccess;
 }
-template <int G>
-static void launch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
+template <int NB, int G>
+static hipError_t launch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
   constexpr int EPB = 64 / G;
-  hipLaunchKernelGGL(ant_forward_kernel<G>, dim3((h->n + EPB - 1) / EPB), dim3(64), 0, st, h->ant, h->n, h->state, a, qacc, counts);
+  const size_t lds = (size_t)EPB * sizeof(AntScratchT<NB>);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_forward_kernel<NB, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ant_forward_kernel<NB, G>), dim3((h->n + EPB - 1) / EPB), dim3(64), lds, st, h->ant, h->n, h->state, a, qacc, counts);
+  return hipSuccess;
+}
+// lane widths: the plain ant is instantiated for 8/16/32/64 lanes per env, mazes with movable blocks for 16/32
+template <int NB>
+static hipError_t dispatch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
+  if constexpr (NB == 0) {
+    if (h->lanes == 8) return launch_ant_step<NB, 8>(h, st, a, o, r, d, gi, inf);
+    if (h->lanes == 64) return launch_ant_step<NB, 64>(h, st, a, o, r, d, gi, inf);
+  }
+  if (h->lanes == 16) return launch_ant_step<NB, 16>(h, st, a, o, r, d, gi, inf);
+  return launch_ant_step<NB, 32>(h, st, a, o, r, d, gi, inf);
+}
+template <int NB>
+static hipError_t dispatch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
+  if (h->lanes == 16) return launch_ant_forward<NB, 16>(h, st, a, qacc, counts);
+  return launch_ant_forward<NB, 32>(h, st, a, qacc, counts);
 }
 
 extern "C" {
@@ -434,8 +473,15 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   if (rc != MZ_OK) { delete h; return fail(msg); }
   hipError_t e = hipSuccess;
   if (h->robot == MZ_ROBOT_ANT) {
-    e = hipMalloc(&h->state, (size_t)num_envs * ANT_REC * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * ANT_REC * sizeof(float));
+    const int nb = h->ant.nblock;
+    if (nb > 2) { delete h; return fail("mz_create: more than 2 movable blocks are not instantiated yet"); }
+    h->lay.nq = ANT_NQ + 2 * nb; h->lay.nv = ANT_NV + 2 * nb; h->lay.rec_t = h->lay.nq + 2 * h->lay.nv;
+    h->lay.rec = (h->lay.rec_t + 2 + 15) / 16 * 16;
+    h->lay.nblock3 = model->observe_blocks ? 3 * nb : 0;
+    h->lay.obs_dim = ANT_OBS + h->lay.nblock3;
+    if (h->lay.obs_dim != model->obs_dim || h->lay.obs_dim > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }
+    e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
     e = hipMalloc(&h->state, (size_t)num_envs * 6 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
@@ -518,7 +564,7 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
   hipStream_t st = (hipStream_t)stream;
   h->seed = seed;
   int nb = (h->n + 255) / 256;
-  if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->n, h->state, mask_dev, seed, h->env0, obs_dev);
+  if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->lay, h->n, h->state, mask_dev, seed, h->env0, obs_dev);
   else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_reset_kernel, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
@@ -532,8 +578,8 @@ int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev,
   if (!h) return MZ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (h->robot == MZ_ROBOT_ANT) {
-    int tot = h->n * ANT_REC;
-    hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+    int tot = h->n * h->lay.rec;
+    hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_set_state_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
@@ -546,8 +592,8 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
   if (!h) return MZ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (h->robot == MZ_ROBOT_ANT) {
-    int tot = h->n * ANT_REC;
-    hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+    int tot = h->n * h->lay.rec;
+    hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_get_state_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
@@ -564,11 +610,10 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   if (h->ntime > 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
   if (h->robot == MZ_ROBOT_ANT) {
     hipError_t le;
-    switch (h->lanes) {
-      case 8: le = launch_ant_step<8>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      case 16: le = launch_ant_step<16>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      case 64: le = launch_ant_step<64>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      default: le = launch_ant_step<32>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+    switch (h->ant.nblock) {
+      case 0: le = dispatch_ant_step<0>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 1: le = dispatch_ant_step<1>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      default: le = dispatch_ant_step<2>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
     }
     HIPCHK(h, le);
   } else {
@@ -593,12 +638,13 @@ int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev
   if (!h || !qacc_dev) return MZ_ERR_ARG;
   if (h->robot != MZ_ROBOT_ANT) return set_err(h, MZ_ERR_UNSUPPORTED, "mz_debug_forward: ant only", hipSuccess);
   hipStream_t st = (hipStream_t)stream;
-  switch (h->lanes) {
-    case 8: launch_ant_forward<8>(h, st, actions_dev, qacc_dev, counts_dev); break;
-    case 16: launch_ant_forward<16>(h, st, actions_dev, qacc_dev, counts_dev); break;
-    case 64: launch_ant_forward<64>(h, st, actions_dev, qacc_dev, counts_dev); break;
-    default: launch_ant_forward<32>(h, st, actions_dev, qacc_dev, counts_dev); break;
+  hipError_t le;
+  switch (h->ant.nblock) {
+    case 0: le = dispatch_ant_forward<0>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    case 1: le = dispatch_ant_forward<1>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    default: le = dispatch_ant_forward<2>(h, st, actions_dev, qacc_dev, counts_dev); break;
   }
+  HIPCHK(h, le);
   HIPCHK(h, hipGetLastError());
   return MZ_OK;
 }

@@ -72,6 +72,7 @@ class MzModel(C.Structure):
         ("goal_reward_scale", f64 * MAX_GOAL),
         ("penalty", f64), ("task_scale", f64), ("inner_reward_scaling", f64),
         ("forward_reward_weight", f64), ("ctrl_cost_weight", f64),
+        ("nblock", i32), ("observe_blocks", i32), ("block_bodyid", i32 * 4), ("block_geomid", i32 * 4),
     ]
 
 
@@ -191,6 +192,10 @@ class MazeWorld:
         self.half_z = maze_height / 2.0 * scale
         self.height_offset = maze_height * scale if self.elevated else 0.0
 
+    def movable_cells(self):
+        """[(i, j, cell)] of movable-block cells in row-major order (maze_env.py:153-166)."""
+        return [(i, j, self.structure[i][j]) for i in range(self.rows) for j in range(self.cols) if self.structure[i][j].can_move()]
+
     def cell_center(self, i, j):
         return j * self.scale - self.torso_x, i * self.scale - self.torso_y
 
@@ -243,10 +248,13 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     spec = R.robot_spec(robot)
     structure = task.create_maze()
     world = MazeWorld(structure, scale, maze_height)
-    if world.elevated or world.has_blocks or world.has_balls:
-        raise NotImplementedError(
-            "mazes with chasms / movable blocks / object balls are not on the device path yet "
-            "(SURVEY §8f rank 3; AntPush = BASELINE config 5 is scheduled after box-box contacts)")
+    if world.elevated or world.has_balls:
+        raise NotImplementedError("mazes with chasms / object balls are not on the device path yet (SURVEY §8f rank 3)")
+    blocks = world.movable_cells()
+    if any(cell is not MazeCell.XY_BLOCK for _, _, cell in blocks):
+        raise NotImplementedError("only XY_BLOCK movable blocks are supported (no z-moving / half / spin blocks yet)")
+    if len(blocks) > 4:
+        raise NotImplementedError("more than 4 movable blocks")
     if world.rows > MAX_GRID or world.cols > MAX_GRID:
         raise ValueError("maze grid larger than MZ_MAX_GRID")
 
@@ -262,6 +270,29 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     m.max_episode_steps = max_episode_steps
     m.reset_qvel_kind = RESET_KIND[spec.reset_qvel]
     m.nq_robot, m.nv_robot = spec.nq_robot, spec.nv_robot
+
+    # movable blocks change the default geom class (maze_env.py:108-112) and add bodies (maze_env.py:563-660)
+    import copy
+    import dataclasses
+
+    spec = copy.deepcopy(spec)
+    if blocks:
+        stiff = (0.995, 0.995, 0.01, 0.5, 2.0)
+        for gs in [spec.floor, spec.wall_geom_defaults] + [g for b in spec.bodies for g in b.geoms]:
+            if not gs.explicit_solimp:
+                gs.solimp = stiff
+    block_body_index = []
+    for (bi_, bj_, _cell) in blocks:
+        bx, by = world.cell_center(bi_, bj_)
+        half = world.scale * 0.5
+        geom = dataclasses.replace(spec.wall_geom_defaults, name=f"block_{bi_}_{bj_}", type=R.BOX, size=(half, half, world.half_z),
+                                   pos=(0.0, 0.0, 0.0), fromto=None, mass=0.0002, contype=1, conaffinity=1)
+        body = R.BodySpec(f"movable_{bi_}_{bj_}", -1, (bx, by, world.half_z + world.height_offset),
+                          joints=[R.JointSpec(f"movable_x_{bi_}_{bj_}", R.SLIDE, axis=(1.0, 0.0, 0.0), margin=0.01),
+                                  R.JointSpec(f"movable_y_{bi_}_{bj_}", R.SLIDE, axis=(0.0, 1.0, 0.0), margin=0.01)],
+                          geoms=[geom])
+        block_body_index.append(1 + len(spec.bodies))
+        spec.bodies.append(body)
 
     # ---- bodies / joints / dofs / geoms
     nbody = 1 + len(spec.bodies)
@@ -420,7 +451,7 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     m.grid_rows, m.grid_cols = world.rows, world.cols
     for i in range(world.rows):
         for j in range(world.cols):
-            m.grid[i][j] = CELL_CODE[structure[i][j]]
+            m.grid[i][j] = CELL_CODE.get(structure[i][j], 0)  # movable cells are bodies, not grid walls
     m.maze_scale, m.torso_x, m.torso_y = world.scale, world.torso_x, world.torso_y
     m.wall_half_xy, m.wall_half_z = world.scale * 0.5, world.half_z
     m.wall_center_z = world.half_z + world.height_offset
@@ -468,7 +499,12 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     m.task_scale = task.scale
     m.inner_reward_scaling = task.INNER_REWARD_SCALING if inner_reward_scaling is None else inner_reward_scaling
     m.forward_reward_weight, m.ctrl_cost_weight = forward_reward_weight, ctrl_cost_weight
-    m.obs_dim = spec.nq_robot + spec.nv_robot + 1
+    m.nblock = len(blocks)
+    m.observe_blocks = int(bool(task.OBSERVE_BLOCKS))
+    for k, bidx in enumerate(block_body_index):
+        m.block_bodyid[k] = bidx
+        m.block_geomid[k] = next(gi for gi, (bb, _g) in enumerate(geoms) if bb == bidx)
+    m.obs_dim = spec.nq_robot + spec.nv_robot + 1 + (3 * len(blocks) if task.OBSERVE_BLOCKS else 0)
     cm = CompiledModel(m, spec, world, task, device_rewards)
     cm.extra = extra
     return cm

@@ -33,6 +33,7 @@ class GeomSpec:
     solimp: Tuple[float, float, float, float, float] = (0.9, 0.95, 0.001, 0.5, 2.0)
     margin: float = 0.0
     gap: float = 0.0
+    explicit_solimp: bool = False  # set on the geom itself (not inherited from <default>)
 
 
 @dataclass
@@ -132,8 +133,8 @@ def _point() -> RobotSpec:
                      joints=[JointSpec("ballx", SLIDE, axis=(1.0, 0.0, 0.0)),
                              JointSpec("bally", SLIDE, axis=(0.0, 1.0, 0.0)),
                              JointSpec("rot", HINGE, axis=(0.0, 0.0, 1.0))],
-                     geoms=[g("pointbody", type=SPHERE, size=(0.5,), pos=(0.0, 0.0, 0.5), solimp=stiff),
-                            g("pointarrow", type=BOX, size=(0.5, 0.1, 0.1), pos=(0.6, 0.0, 0.5), solimp=stiff)])
+                     geoms=[g("pointbody", type=SPHERE, size=(0.5,), pos=(0.0, 0.0, 0.5), solimp=stiff, explicit_solimp=True),
+                            g("pointarrow", type=BOX, size=(0.5, 0.1, 0.1), pos=(0.6, 0.0, 0.5), solimp=stiff, explicit_solimp=True)])
     acts = [ActuatorSpec("ballx", 1.0, (-1.0, 1.0)), ActuatorSpec("rot", 1.0, (-0.25, 0.25))]
     floor = g("floor", type=PLANE, size=(40.0, 40.0, 40.0), conaffinity=1)
     return RobotSpec("point", [torso], acts, floor, g("wall", type=BOX, size=(1, 1, 1), conaffinity=1),

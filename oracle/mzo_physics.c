@@ -536,6 +536,41 @@ static void capsule_box(mzo_data* d, const pairparam* pp, const double* cpos, co
     if (sphere_box(far, r, bpos, bmat, bsize, pp->margin, &dist, pos, nrm)) add_contact(d, pp, dist, pos, nrm, NULL);
 }
 
+/* Two axis-aligned boxes (movable XY blocks never rotate; maze walls are grid-aligned).  [ASSUME-12] MuJoCo's
+ * mjc_BoxBox is not reproduced: the contact normal is the axis of largest gap (first axis on ties), the contact
+ * points are the distinct corners of the overlap rectangle of the two facing faces, placed midway between them.
+ * Normal points from box 1 to box 2. */
+static void box_box_aligned(mzo_data* d, const pairparam* pp, const double* c1, const double* h1, const double* c2,
+                            const double* h2) {
+  double gap[3];
+  int ax = 0;
+  for (int k = 0; k < 3; k++) { gap[k] = fabs(c2[k] - c1[k]) - (h1[k] + h2[k]); if (gap[k] > gap[ax]) ax = k; }
+  if (gap[ax] > pp->margin) return;
+  double dist = gap[ax], sg = c2[ax] >= c1[ax] ? 1.0 : -1.0;
+  int u = (ax + 1) % 3, v = (ax + 2) % 3;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) {
+    lo[k] = fmax(c1[k] - h1[k], c2[k] - h2[k]);
+    hi[k] = fmin(c1[k] + h1[k], c2[k] + h2[k]);
+    if (hi[k] < lo[k]) lo[k] = hi[k] = 0.5 * (lo[k] + hi[k]);
+  }
+  double nrm[3] = {0, 0, 0};
+  nrm[ax] = sg;
+  int nu = (hi[u] - lo[u] > 1e-12) ? 2 : 1, nvv = (hi[v] - lo[v] > 1e-12) ? 2 : 1;
+  for (int iu = 0; iu < nu; iu++)
+    for (int iv = 0; iv < nvv; iv++) {
+      double pos[3];
+      pos[ax] = c1[ax] + sg * (h1[ax] + 0.5 * dist);
+      pos[u] = iu ? hi[u] : lo[u];
+      pos[v] = iv ? hi[v] : lo[v];
+      add_contact(d, pp, dist, pos, nrm, NULL);
+    }
+}
+
+static int is_axis_aligned(const double* mat) {
+  return fabs(mat[0] - 1.0) < 1e-12 && fabs(mat[4] - 1.0) < 1e-12 && fabs(mat[8] - 1.0) < 1e-12;
+}
+
 static void mix_params(pairparam* pp, double m1, double m2, double g1, double g2, const double* f1, const double* f2,
                        const double* sr1, const double* sr2, const double* si1, const double* si2, int cd1, int cd2) {
   pp->margin = fmax(m1, m2);
@@ -619,10 +654,39 @@ static void collide_walls(const mz_model* m, mzo_data* d, int g) {
           add_contact(d, &pp, dist, pos, nrm, NULL);
       } else if (m->geom_type[g] == MZ_GEOM_CAPSULE) {
         capsule_box(d, &pp, gp, d->geom_xmat[g], m->geom_size[g][0], m->geom_size[g][1], bpos, ident, bsize);
+      } else if (m->geom_type[g] == MZ_GEOM_BOX && is_axis_aligned(d->geom_xmat[g])) {
+        /* wall geoms precede the movable bodies' geoms in MuJoCo's geom order: geom1 = wall, geom2 = block */
+        pairparam q = pp;
+        q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
+        box_box_aligned(d, &q, bpos, bsize, gp, m->geom_size[g]);
       } else {
-        d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* box-box: not restated yet (Point arrow, movable blocks) */
+        d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* rotated box vs box (Point arrow): not restated */
       }
     }
+}
+
+/* explicit non-plane pairs: robot sphere / capsule against a movable block's box, block against block */
+static void collide_pair(const mz_model* m, mzo_data* d, int ga, int gb) {
+  int g1 = ga, g2 = gb;
+  if (m->geom_type[g1] > m->geom_type[g2]) { g1 = gb; g2 = ga; } /* MuJoCo orders a pair by geom type */
+  pairparam pp;
+  mix_params(&pp, m->geom_margin[g1], m->geom_margin[g2], m->geom_gap[g1], m->geom_gap[g2], m->geom_friction[g1],
+             m->geom_friction[g2], m->geom_solref[g1], m->geom_solref[g2], m->geom_solimp[g1], m->geom_solimp[g2],
+             m->geom_condim[g1], m->geom_condim[g2]);
+  pp.b1 = m->geom_bodyid[g1]; pp.b2 = m->geom_bodyid[g2]; pp.g1 = g1; pp.g2 = g2;
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  if (t2 == MZ_GEOM_BOX && t1 == MZ_GEOM_SPHERE) {
+    double dist, pos[3], nrm[3];
+    if (sphere_box(d->geom_xpos[g1], m->geom_size[g1][0], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], pp.margin, &dist, pos, nrm))
+      add_contact(d, &pp, dist, pos, nrm, NULL);
+  } else if (t2 == MZ_GEOM_BOX && t1 == MZ_GEOM_CAPSULE) {
+    capsule_box(d, &pp, d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1][0], m->geom_size[g1][1], d->geom_xpos[g2],
+                d->geom_xmat[g2], m->geom_size[g2]);
+  } else if (t1 == MZ_GEOM_BOX && t2 == MZ_GEOM_BOX && is_axis_aligned(d->geom_xmat[g1]) && is_axis_aligned(d->geom_xmat[g2])) {
+    box_box_aligned(d, &pp, d->geom_xpos[g1], m->geom_size[g1], d->geom_xpos[g2], m->geom_size[g2]);
+  } else {
+    d->status |= MZO_STATUS_UNSUPPORTED_PAIR;
+  }
 }
 
 static void collision(const mz_model* m, mzo_data* d) {
@@ -636,7 +700,7 @@ static void collision(const mz_model* m, mzo_data* d) {
       /* parent-child filter does not apply when the parent is the world body */
       if (b1 != 0 && b2 != 0 && (m->body_parent[b1] == b2 || m->body_parent[b2] == b1)) continue;
       if (m->geom_type[g1] == MZ_GEOM_PLANE) collide_plane(m, d, g1, g2);
-      else d->status |= MZO_STATUS_UNSUPPORTED_PAIR;
+      else collide_pair(m, d, g1, g2);
     }
   for (int g = 1; g < m->ngeom; g++)
     if (m->geom_bodyid[g] != 0) collide_walls(m, d, g);

@@ -34,7 +34,7 @@ def env_step(cm, st, actions, max_iter=0, tol=0.0, rtol=-1.0):
     lib = load()
     n = st["qpos"].shape[0]
     a = np.ascontiguousarray(actions, np.float32)
-    out = dict(obs=np.zeros((n, 30), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+    out = dict(obs=np.zeros((n, cm.c.obs_dim), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
                goal_idx=np.zeros(n, np.int32), info=np.zeros((n, 4), np.float32), status=np.zeros(n, np.int32),
                iters=np.zeros(n, np.int32))
     rc = lib.emu_ant_env_step(C.byref(cm.c), n, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["warm"]), _vp(st["t"]), _vp(a),
@@ -51,8 +51,9 @@ def forward(cm, qpos, qvel, actions=None, warm=None, max_iter=0, tol=0.0, rtol=-
     n = qpos.shape[0]
     warm = None if warm is None else np.ascontiguousarray(np.atleast_2d(warm), np.float32)
     actions = None if actions is None else np.ascontiguousarray(np.atleast_2d(actions), np.float32)
-    out = dict(qacc=np.zeros((n, 14), np.float32), counts=np.zeros((n, 2), np.int32), M=np.zeros((n, 14, 14), np.float32),
-               bias=np.zeros((n, 14), np.float32), qas=np.zeros((n, 14), np.float32))
+    nv = cm.c.nv
+    out = dict(qacc=np.zeros((n, nv), np.float32), counts=np.zeros((n, 2), np.int32), M=np.zeros((n, nv, nv), np.float32),
+               bias=np.zeros((n, nv), np.float32), qas=np.zeros((n, nv), np.float32))
     rc = lib.emu_ant_forward(C.byref(cm.c), n, _vp(qpos), _vp(qvel), _vp(warm), _vp(actions), _vp(out["qacc"]), _vp(out["counts"]),
                              _vp(out["M"]), _vp(out["bias"]), _vp(out["qas"]), C.c_int(max_iter), C.c_float(tol), C.c_float(rtol))
     assert rc == 0, rc

@@ -110,3 +110,35 @@ def test_kernel_logic_wall_contacts(oracle):
     ro = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     re_ = emu_lib.env_step(cm, s32, act)
     assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 2e-5 + 1e-5 * np.abs(ro["obs"]))
+
+
+def test_kernel_logic_movable_block(oracle):
+    """AntPush (BASELINE config 5): one movable XY block — block-floor / block-wall / robot-block contacts, 8-dof
+    hub in the arrow solver, block xyz in the observation.  Contact *counts* may differ at the activation
+    boundary (the resting block sits exactly at dist = margin, where the row force is zero), so parity is
+    asserted on the results."""
+    from tests import emu_lib
+
+    cm = model.compile_model("ant", T.DistRewardPush(8.0), 8.0)
+    n = 96
+    st, _ = oracle.reset(cm, n, 5)
+    rng = np.random.default_rng(0)
+    st["qpos"][:32, 1] = 3.0 + rng.uniform(0.2, 0.6, 32)  # a third of the ants walk into the block (its face is at y = 4)
+    st["qvel"][:32, 1] = 1.5
+    moved = 0.0
+    for k in range(41):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        if k in (2, 10, 40):
+            s64 = _f32(st)
+            s32 = emu_lib.f32_state(s64)
+            ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            re_ = emu_lib.env_step(cm, s32, act)
+            assert re_["obs"].shape == (n, 33)
+            assert np.all(np.abs(s32["qvel"] - s64["qvel"]) <= 2e-5 + 1e-5 * np.abs(s64["qvel"])), np.abs(s32["qvel"] - s64["qvel"]).max()
+            assert np.all(np.abs(s32["qpos"] - s64["qpos"]) <= 1e-5 + 1e-5 * np.abs(s64["qpos"]))
+            assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 2e-5 + 1e-5 * np.abs(ro["obs"]))
+            assert np.abs(re_["reward"] - ro["reward"]).max() < 1e-6
+            assert np.array_equal(re_["done"], ro["done"]) and np.all((re_["status"] & 7) == 0)
+            moved = max(moved, np.abs(s64["qpos"][:, 15:]).max())
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    assert moved > 0.1  # the block really gets pushed

@@ -158,6 +158,46 @@ def test_ant_wall_contacts_and_goal(torch, oracle):
     env.close()
 
 
+def test_ant_push_movable_block(torch, oracle):
+    """BASELINE config 5: AntPush-v0, 2048 envs — movable-block contacts, obs (33,) with block xyz at [3:6]."""
+    n = 2048
+    env = mm.make("AntPush-v0", num_envs=n)
+    cm = env.model
+    assert env.obs_dim == 33 and env.nq == 17 and env.nv == 16
+    st, _ = oracle.reset(cm, n, 5)
+    rng = np.random.default_rng(0)
+    st["qpos"][: n // 3, 1] = 3.0 + rng.uniform(0.2, 0.6, n // 3)
+    st["qvel"][: n // 3, 1] = 1.5
+    for k in range(12):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        if k in (2, 11):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], s64["warm"], s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            # Movable-block mazes switch every default geom to solimp .995 (maze_env.py:108-112): contact rows are
+            # ~50x stiffer than in AntUMaze and the block weighs 0.2 g, so fp32 round-off reaches a few 1e-5 on the
+            # torso's angular rates in ~1 % of the envs, and an env whose contact crosses the activation distance
+            # within round-off sees MuJoCo's (discontinuous) damping term switch on a stage earlier or later.
+            # Bar: >= 98.5 % of the envs inside 1e-5 (+1e-5 rel), the rest inside 1e-4 except such flips (< 0.3 %).
+            err = np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))
+            per_env = err.max(1)
+            assert (per_env <= 1e-5).mean() >= 0.985, (per_env <= 1e-5).mean()
+            assert (per_env <= 1e-4).mean() >= 0.997, (per_env <= 1e-4).mean()
+            assert np.median(per_env) < 2e-6
+            ok = per_env <= 1e-4
+            assert np.all(_close(qpos[ok], s64["qpos"][ok], atol=2e-5))
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=1e-4))
+            assert np.all(_close(rew.cpu().numpy()[ok], ref["reward"][ok], atol=1e-5))
+            assert np.array_equal(done.cpu().numpy(), ref["done"])
+            assert np.array_equal(obs.cpu().numpy()[:, 5], np.full(n, 2.0, np.float32))  # block z in the obs slot
+            assert np.all((env.status().cpu().numpy() & 7) == 0)
+            assert np.abs(s64["qpos"][:, 15:]).max() > 0.05  # blocks are being pushed
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    env.close()
+
+
 def test_point_step_parity_and_bounce(torch, oracle):
     n = 4096
     env = mm.make("PointUMaze-v0", num_envs=n)

@@ -160,7 +160,33 @@ def test_world_geometry(env_id, robot):
         assert g.pos.tolist() == s["pos"][: g.dim]
 
 
-@pytest.mark.parametrize("env_id", ["AntPush-v0", "AntFall-v0", "PointBilliard-v0"])
+def test_movable_block_world(oracle):
+    """AntPush / AntBlockMaze: block body, joints, mass, default-geom solimp switch and obs layout
+    (maze_env.py:108-112, 563-660, 351-369) against the MJCF the reference generates."""
+    for env_id in ("AntPush-v0", "AntBlockMaze-v0"):
+        ref = WORLDS[env_id]
+        spec = mm.REGISTRY[env_id]
+        scale = spec.kwargs["maze_size_scaling"]
+        cm = model.compile_model("ant", spec.kwargs["maze_task"](scale), scale)
+        m = cm.c
+        assert m.nblock == len(ref["movable"]) == 1 and m.obs_dim == ref["obs_dim"] == 33 and m.nq == 17 and m.nv == 16
+        b, g = m.block_bodyid[0], m.block_geomid[0]
+        mv = ref["movable"][0]
+        assert list(m.body_pos[b]) == mv["pos"] and list(m.geom_size[g]) == mv["geom"]["size"]
+        assert m.body_mass[b] == mv["geom"]["mass"] == 0.0002
+        j0 = m.body_jntadr[b]
+        assert [list(m.jnt_axis[j0]), list(m.jnt_axis[j0 + 1])] == [j["axis"] for j in mv["joints"]]
+        assert not m.jnt_limited[j0] and m.jnt_margin[j0] == float(mv["joints"][0]["margin"])
+        solimp = [float(v) for v in ref["default_geom_solimp"].split()]
+        assert list(m.wall_solimp[:3]) == solimp == list(m.geom_solimp[g][:3]) == list(m.geom_solimp[1][:3]) == list(m.geom_solimp[0][:3])
+        assert [list(bx) for bx in cm.world.wall_boxes()] == [bb["pos"] + bb["size"] for bb in ref["boxes"]]
+        # obs layout: qpos[:3] | block xpos | qpos[3:15] | qvel[:14] | t
+        st, obs = oracle.reset(cm, 2, 3)
+        assert np.array_equal(obs[:, 3:6], np.tile(mv["pos"], (2, 1))) and np.array_equal(obs[:, :3], st["qpos"][:, :3])
+        assert np.array_equal(obs[:, 6:18], st["qpos"][:, 3:15]) and np.array_equal(obs[:, 18:32], st["qvel"][:, :14])
+
+
+@pytest.mark.parametrize("env_id", ["AntFall-v0", "PointBilliard-v0"])
 def test_unsupported_mazes_fail_loudly(env_id):
     spec = mm.REGISTRY[env_id]
     scale = spec.kwargs["maze_size_scaling"]
