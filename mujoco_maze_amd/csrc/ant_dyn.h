@@ -92,6 +92,7 @@ struct AntScratchT {
   float qacc[D::NV], qas[D::NV], qfs[D::NV];
   // kinematics (positions relative to the torso origin c)
   float R0[9], cz;               // torso rotation (row-major), torso height
+  int nearwall;                  // 0: no maze wall within the ant's reach of the torso (wall tests skipped)
   float p1[4][3], p2[4][3];      // aux / ankle body origins
   float w[12][3], com[12][3];    // capsule axis and centre of body 1 + 3l + k
   float zw[3];                   // hip axis (world) = R0 * ez
@@ -174,6 +175,16 @@ MZ_HD float impedancef(const float* si, float x) {
 }
 
 
+// Row bitmask of the cell grid for a per-lane row index.  The grid lives in the kernel-argument block
+// (scalar registers); a select chain keeps it there — indexing the array with a vector index would make the
+// compiler spill it to scratch memory.
+MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
+  uint32_t m = 0u;
+#pragma unroll
+  for (int r = 0; r < MZ_MAX_GRID; r++) m = (r == i) ? z.rowmask[r] : m;
+  return m;
+}
+
 // body index b in 0..12: 0 torso, else leg l = (b-1)/3, level k = (b-1)%3 (0 welded leg, 1 aux, 2 ankle)
 MZ_HD int body_class(int b) { return b == 0 ? 0 : 1 + (b - 1) % 3; }
 
@@ -181,7 +192,33 @@ MZ_HD int body_class(int b) { return b == 0 ? 0 : 1 + (b - 1) % 3; }
 template <int NB, class C>
 MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
   constexpr int NH = AntDims<NB>::NH;
-  MZ_FOR(l, 4) {
+  MZ_FOR(l, 5) {
+    if (l == 4) {
+      // Wall broad phase for the whole robot (runs beside the four leg lanes): every robot geom lies within
+      // ANT_REACH of the torso origin (torso sphere 0.25; leg chain 0.2*sqrt2*2 + 0.4*sqrt2 + capsule radius 0.08
+      // + margin 0.01 < 1.25), so when no BLOCK cell comes that close in xy no geom can touch a wall.
+      const MazeDev& z = K.maze;
+      const float reach = 1.25f;
+      float x = s.qpos[0] + z.tx, y = s.qpos[1] + z.ty, inv = 1.0f / z.scale;
+      int jc = (int)floorf(x * inv + 0.5f), ic = (int)floorf(y * inv + 0.5f);
+      float fx = x - jc * z.scale, fy = y - ic * z.scale;  // offset from the centre of the torso's own cell
+      // only the neighbour cells on the side(s) the torso is close to can matter
+      int sj = fx > 0.f ? 1 : -1, si = fy > 0.f ? 1 : -1;
+      float gx = z.half_xy - fabsf(fx), gy = z.half_xy - fabsf(fy);  // distance to the nearer x / y cell border
+      bool inside = ic >= 0 && ic < z.rows && jc >= 0 && jc < z.cols;
+      uint32_t row0 = inside ? maze_row(z, ic) : 0u;
+      int near = (row0 >> (jc & 31)) & 1u;  // torso inside a wall cell (deep penetration): keep testing
+      int j2 = jc + sj, i2 = ic + si;
+      if (gx < reach && ic >= 0 && ic < z.rows && j2 >= 0 && j2 < z.cols && ((maze_row(z, ic) >> j2) & 1u)) near = 1;
+      if (gy < reach && i2 >= 0 && i2 < z.rows) {
+        uint32_t row1 = maze_row(z, i2);
+        if (jc >= 0 && jc < z.cols && ((row1 >> jc) & 1u)) near = 1;
+        if (j2 >= 0 && j2 < z.cols && ((row1 >> j2) & 1u) && gx * gx + gy * gy < reach * reach) near = 1;
+      }
+      if (!inside) near = 1;
+      s.nearwall = near;
+      continue;
+    }
     float R0[9];
     quat_to_matf(R0, s.qpos + 3);
     if (l == 0) {
@@ -397,8 +434,7 @@ MZ_HD void arrow_factor_solve(const C& cx, const Arrow<NH>& A, ArrowFactor<NH>& 
   cx.sync();
   MZ_FOR(e, NTRI + NH) {
     if (e < NTRI) {
-      int i = 0;
-      while ((i + 1) * (i + 2) / 2 <= e) i++;
+      int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : e < 21 ? 5 : e < 28 ? 6 : e < 36 ? 7 : e < 45 ? 8 : 9;
       int j = e - (i * (i + 1)) / 2;
       float v = A.rr[i][j];
       for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
@@ -525,16 +561,6 @@ MZ_HD float seg_box_t(const float* a, const float* b, const float* bs) {
   return tlo - glo * (thi - tlo) / (ghi - glo);
 }
 
-
-// Row bitmask of the cell grid for a per-lane row index.  The grid lives in the kernel-argument block
-// (scalar registers); a select chain keeps it there — indexing the array with a vector index would make the
-// compiler spill it to scratch memory.
-MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
-  uint32_t m = 0u;
-#pragma unroll
-  for (int r = 0; r < MZ_MAX_GRID; r++) m = (r == i) ? z.rowmask[r] : m;
-  return m;
-}
 
 // sphere / capsule (centre ctr, axis ax, half length hl, radius r; torso-relative) against an axis-aligned box
 // (centre bc torso-relative, half sizes bs): up to two contacts [ASSUME-6], normal from the robot geom to the box
@@ -678,7 +704,8 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     float reachb = r + hl + K.wall.margin;
     if (d2 < reachb * reachb) round_vs_box(b == 0, ctr, ax, hl, r, bc, K.block_half, K.wall.margin, 2, k, emit);
   }
-  // maze walls: cells under the bounding square of the geom
+  // maze walls: cells under the bounding square of the geom (skipped when the torso-level broad phase is clear)
+  if (!s.nearwall) return;
   float reach = r + hl + K.wall.margin;
   float gx = s.qpos[0] + ctr[0], gy = s.qpos[1] + ctr[1], gz = s.cz + ctr[2];
   if (gz - reach > z.center_z + z.half_z) return;

@@ -146,13 +146,14 @@ template <int G>
 constexpr int ant_waves_per_simd() { return G >= 64 ? 4 : (G == 32 ? 2 : 1); }
 
 template <int NB, int G, bool PROF>
-__global__ __launch_bounds__(256, (NB ? 1 : ant_waves_per_simd<G>())) void ant_step_kernel(AntDev K, int n, float* __restrict__ state, const float* __restrict__ actions,
+__global__ __launch_bounds__(256, (NB ? 1 : ant_waves_per_simd<G>())) void ant_step_kernel(const AntDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
                                                        float* __restrict__ obs, float* __restrict__ reward,
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
                                                        uint64_t seed, uint64_t env0, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   using D = AntDims<NB>;
+  const AntDev& K = *Kp;  // model constants: scalar loads from a device-resident block (L2 / scalar-cache hits)
   AntEnvLDS<NB>* lds = reinterpret_cast<AntEnvLDS<NB>*>(lds_raw);
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
@@ -372,6 +373,8 @@ struct mz_handle {
   mz_model model;
   int n, device, robot;
   AntDev ant;
+  AntDev* ant_dev;  // device copy read by the step kernel (refreshed when an option changes it)
+  int ant_dirty;
   AntLayout lay;
   PointDev* point_dev;  // device copy
   PointDev point;
@@ -410,12 +413,12 @@ static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, 
   if (h->prof) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ant_step_kernel<NB, G, true>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
+    hipLaunchKernelGGL((ant_step_kernel<NB, G, true>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
                        h->auto_reset, h->seed, h->env0, h->prof);
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ant_step_kernel<NB, G, false>), grid, block, lds, st, h->ant, h->n, h->state, a, o, r, d, gi, inf, h->status,
+    hipLaunchKernelGGL((ant_step_kernel<NB, G, false>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
                        h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr);
   }
   return hipSuccess;
@@ -480,7 +483,9 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     h->lay.nblock3 = model->observe_blocks ? 3 * nb : 0;
     h->lay.obs_dim = ANT_OBS + h->lay.nblock3;
     if (h->lay.obs_dim != model->obs_dim || h->lay.obs_dim > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }
-    e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
+    e = hipMalloc(&h->ant_dev, sizeof(AntDev));
+    h->ant_dirty = 1;
+    if (e == hipSuccess) e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
     e = hipMalloc(&h->state, (size_t)num_envs * 6 * sizeof(float));
@@ -508,6 +513,7 @@ void mz_destroy(mz_handle* h) {
   if (h->pt_t) (void)hipFree(h->pt_t);
   if (h->pt_ep) (void)hipFree(h->pt_ep);
   if (h->point_dev) (void)hipFree(h->point_dev);
+  if (h->ant_dev) (void)hipFree(h->ant_dev);
   if (h->status) (void)hipFree(h->status);
   if (h->prof) (void)hipFree(h->prof);
   if (h->ev) { for (int i = 0; i < 2 * h->ntime; i++) (void)hipEventDestroy(h->ev[i]); free(h->ev); }
@@ -526,10 +532,10 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "auto_reset")) { h->auto_reset = value != 0; return MZ_OK; }
   if (!strcmp(key, "seed")) { h->seed = (uint64_t)value; return MZ_OK; }
   if (!strcmp(key, "env_index_offset")) { h->env0 = (uint64_t)value; return MZ_OK; }
-  if (!strcmp(key, "solver_iterations")) { h->ant.max_iter = (int)value; return MZ_OK; }
-  if (!strcmp(key, "solver_tolerance")) { h->ant.tol = (float)value; return MZ_OK; }
-  if (!strcmp(key, "solver_rtol")) { h->ant.rtol = (float)value; return MZ_OK; }
-  if (!strcmp(key, "ls_iterations")) { h->ant.ls_iter = (int)value; return MZ_OK; }
+  if (!strcmp(key, "solver_iterations")) { h->ant_dirty = 1; h->ant.max_iter = (int)value; return MZ_OK; }
+  if (!strcmp(key, "solver_tolerance")) { h->ant_dirty = 1; h->ant.tol = (float)value; return MZ_OK; }
+  if (!strcmp(key, "solver_rtol")) { h->ant_dirty = 1; h->ant.rtol = (float)value; return MZ_OK; }
+  if (!strcmp(key, "ls_iterations")) { h->ant_dirty = 1; h->ant.ls_iter = (int)value; return MZ_OK; }
   if (!strcmp(key, "lanes_per_env")) {
     int g = (int)value;
     if (g != 8 && g != 16 && g != 32 && g != 64) return set_err(h, MZ_ERR_ARG, "lanes_per_env must be 8, 16, 32 or 64", hipSuccess);
@@ -609,6 +615,7 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   int slot = -1;
   if (h->ntime > 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
   if (h->robot == MZ_ROBOT_ANT) {
+    if (h->ant_dirty) { HIPCHK(h, hipMemcpyAsync(h->ant_dev, &h->ant, sizeof(AntDev), hipMemcpyHostToDevice, st)); h->ant_dirty = 0; }
     hipError_t le;
     switch (h->ant.nblock) {
       case 0: le = dispatch_ant_step<0>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
