@@ -85,7 +85,7 @@ struct ArrowFactor {
 };
 
 template <int NB>
-struct AntScratchT {
+struct alignas(16) AntScratchT {
   using D = AntDims<NB>;
   // step-persistent
   float qpos[D::NQ + 1], qvel[D::NV], x0q[D::NQ + 1], x0v[D::NV], accv[D::NV], accf[D::NV], warm[D::NV], fact[D::NV];
@@ -99,14 +99,14 @@ struct AntScratchT {
   float Sh[4][3], Sa[4][6];      // hip: linear part (angular = zw); ankle: angular, linear
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
   float fleg[4][6], ftor[6], bias[D::NV], Iall[10];
-  Arrow<D::NH> M, H;
+  alignas(16) Arrow<D::NH> M, H;
   ArrowFactor<D::NH> F;
   float grad[D::NV], search[D::NV], Mx[D::NV];
   // contacts
   int ncon, cnt[D::NGEOM], cbeg[5];  // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); hub-only contacts [0, cbeg[0])
   int cleg[D::NC], ccls[D::NC];      // leg (-1 none) and robot body class (-1 none) of the contact
-  float cJ[D::NC][3][D::NCOL];       // [normal, mu*t1, mu*t2] x [hub, hip, ankle]
-  float cY[D::NC][3][D::NCOL];       // W * J of the current Newton iterate (also stages contact geometry)
+  alignas(16) float cJ[D::NC][3][D::NCOL];  // [normal, mu*t1, mu*t2] x [hub, hip, ankle]
+  alignas(16) float cY[D::NC][3][D::NCOL];  // W * J of the current Newton iterate (also stages contact geometry)
   float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3], cg[D::NC][3];
   // joint limits (8 hinges)
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
@@ -880,10 +880,8 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
   bool done = !has;
   int it = 0;
   while (cx.any(!done) && it < K.max_iter) {
-    // (a) M (qacc - qas); per-contact residual u, gradient block g3, curvature W and Y = W J
-    MZ_FOR(i, NV) s.search[i] = s.qacc[i] - s.qas[i];
-    cx.sync();
-    MZ_FOR(i, NV) s.Mx[i] = arrow_row_mul<NH>(s.M, s.search, i);
+    // (a) M (qacc - qas) = M qacc - qfrc_smooth; per-contact residual u, gradient block g3, curvature W, Y = W J
+    MZ_FOR(i, NV) s.Mx[i] = arrow_row_mul<NH>(s.M, s.qacc, i) - s.qfs[i];
     MZ_FOR(c, s.ncon) {
       float u[3], W[5];
       for (int a = 0; a < 3; a++) u[a] = contact_Jdot<NB>(s, c, a, s.qacc) - s.caref[c][a];

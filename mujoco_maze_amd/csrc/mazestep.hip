@@ -138,7 +138,7 @@ struct AntIO {  // per-env staging of the step's inputs / outputs next to the sc
   int iout[4];
 };
 template <int NB>
-struct AntEnvLDS { AntScratchT<NB> s; AntIO io; };
+struct alignas(16) AntEnvLDS { AntScratchT<NB> s; AntIO io; };
 
 // Register budget per lane-group width: the batch is fixed (4096 envs/GPU), so the wave count is 64*N/G and
 // the kernel must fit  N*G/64 / 1024 SIMDs  waves per SIMD to be resident in one round.

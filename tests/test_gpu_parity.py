@@ -285,6 +285,42 @@ def test_full_size_properties(torch):
     env.close()
 
 
+def test_rollout_tracks_oracle_and_long_run_is_clean(torch, oracle):
+    """(1) 10-step rollouts with identical actions stay close to the float64 oracle for the bulk of the envs
+    (contact dynamics amplify round-off, so this is a statistical statement); (2) 1500 auto-reset steps at the
+    BASELINE size produce no NaN / overflow status and episode bookkeeping stays consistent."""
+    n = 512
+    env = mm.make("AntUMaze-v0", num_envs=n)
+    cm = env.model
+    st, _ = oracle.reset(cm, n, 31)
+    st = _f32(st)
+    env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+    rng = np.random.default_rng(6)
+    for k in range(10):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        obs, *_ = env.step(torch.as_tensor(act, device=env.device))
+        ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    err = np.abs(obs.cpu().numpy() - ref["obs"]).max(1)
+    assert np.median(err) < 1e-4 and np.quantile(err, 0.9) < 1e-2, (np.median(err), np.quantile(err, 0.9))
+    env.close()
+    n = 4096
+    env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True)
+    env.reset(seed=77)
+    g = torch.Generator(device=env.device).manual_seed(3)
+    acts = [(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30) for _ in range(8)]
+    ndone = 0
+    for k in range(1500):
+        obs, rew, done, info = env.step(acts[k % 8])
+        if k % 100 == 99:
+            ndone += int((done != 0).sum().item())
+            assert torch.isfinite(obs).all()
+    stt = env.status().cpu().numpy()
+    assert np.all((stt & 3) == 0), (int((stt & 1).sum()), int((stt & 2).sum()))
+    t = env.get_state()[3].cpu().numpy()
+    assert t.min() >= 0 and t.max() <= 1000 and (t == 500).sum() > n // 2  # 1500 steps = one truncation + 500
+    env.close()
+
+
 def test_single_env_facade_shapes(torch):
     """What the reference's tests/test_envs.py pins: obs shapes and reward sign."""
     rng = np.random.default_rng(0)
