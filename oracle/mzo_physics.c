@@ -567,6 +567,66 @@ static void box_box_aligned(mzo_data* d, const pairparam* pp, const double* c1, 
     }
 }
 
+/* Box rotated about the vertical axis (the Point's arrow, point.xml:22) against a grid-aligned wall box.
+ * [ASSUME-13] MuJoCo's mjc_BoxBox is not reproduced.  Both boxes overlap in z, so this is a 2-D
+ * rectangle-rectangle test: separating-axis search over the four face normals (wall x, wall y, arrow x, arrow y;
+ * first axis on ties), distance = largest separation, contact points = the deepest vertex / vertices of the
+ * incident rectangle (within 1e-9 of the minimum), placed midway between the surfaces at the arrow's height.
+ * geom1 = wall (world geoms precede the robot's), geom2 = arrow: normal from the wall to the arrow. */
+static void box_zrot_vs_aabb(mzo_data* d, const pairparam* pp, const double* wc, const double* wh, const double* bc,
+                             const double* bmat, const double* bh) {
+  if (fabs(bc[2] - wc[2]) > bh[2] + wh[2] + pp->margin) return;
+  double ex[2] = {bmat[0], bmat[3]}, ey[2] = {bmat[1], bmat[4]};
+  double dx = bc[0] - wc[0], dy = bc[1] - wc[1];
+  double axes[4][2] = {{1, 0}, {0, 1}, {ex[0], ex[1]}, {ey[0], ey[1]}};
+  int best = -1;
+  double bestsep = -1e30, bestsign = 1;
+  for (int a = 0; a < 4; a++) {
+    double nx = axes[a][0], ny = axes[a][1];
+    double proj = dx * nx + dy * ny;
+    double ra = wh[0] * fabs(nx) + wh[1] * fabs(ny);
+    double rb = bh[0] * fabs(ex[0] * nx + ex[1] * ny) + bh[1] * fabs(ey[0] * nx + ey[1] * ny);
+    double sep = fabs(proj) - (ra + rb);
+    if (sep > bestsep) { bestsep = sep; best = a; bestsign = proj >= 0 ? 1.0 : -1.0; }
+  }
+  if (bestsep > pp->margin) return;
+  double n[3] = {axes[best][0] * bestsign, axes[best][1] * bestsign, 0.0}; /* wall -> arrow */
+  double vx[4], vy[4], depth[4], dmin = 1e30;
+  if (best < 2) { /* reference face on the wall: incident vertices are the arrow's corners */
+    for (int k = 0; k < 4; k++) {
+      double sx = (k & 1) ? 1.0 : -1.0, sy = (k & 2) ? 1.0 : -1.0;
+      vx[k] = bc[0] + sx * bh[0] * ex[0] + sy * bh[1] * ey[0];
+      vy[k] = bc[1] + sx * bh[0] * ex[1] + sy * bh[1] * ey[1];
+      depth[k] = (vx[k] - wc[0]) * n[0] + (vy[k] - wc[1]) * n[1] - (wh[0] * fabs(n[0]) + wh[1] * fabs(n[1]));
+      if (depth[k] < dmin) dmin = depth[k];
+    }
+    for (int k = 0; k < 4; k++)
+      if (depth[k] <= dmin + 1e-9) {
+        double pos[3] = {vx[k] - n[0] * 0.5 * depth[k], vy[k] - n[1] * 0.5 * depth[k], bc[2]};
+        add_contact(d, pp, depth[k], pos, n, NULL);
+      }
+  } else { /* reference face on the arrow: incident vertices are the wall's corners */
+    double href = best == 2 ? bh[0] : bh[1];
+    for (int k = 0; k < 4; k++) {
+      vx[k] = wc[0] + ((k & 1) ? wh[0] : -wh[0]);
+      vy[k] = wc[1] + ((k & 2) ? wh[1] : -wh[1]);
+      depth[k] = (bc[0] - vx[k]) * n[0] + (bc[1] - vy[k]) * n[1] - href;
+      if (depth[k] < dmin) dmin = depth[k];
+    }
+    for (int k = 0; k < 4; k++)
+      if (depth[k] <= dmin + 1e-9) {
+        double pos[3] = {vx[k] + n[0] * 0.5 * depth[k], vy[k] + n[1] * 0.5 * depth[k], bc[2]};
+        add_contact(d, pp, depth[k], pos, n, NULL);
+      }
+  }
+}
+
+static int is_block_geom(const mz_model* m, int g) {
+  for (int k = 0; k < m->nblock; k++)
+    if (m->block_geomid[k] == g) return 1;
+  return 0;
+}
+
 static int is_axis_aligned(const double* mat) {
   return fabs(mat[0] - 1.0) < 1e-12 && fabs(mat[4] - 1.0) < 1e-12 && fabs(mat[8] - 1.0) < 1e-12;
 }
@@ -654,13 +714,17 @@ static void collide_walls(const mz_model* m, mzo_data* d, int g) {
           add_contact(d, &pp, dist, pos, nrm, NULL);
       } else if (m->geom_type[g] == MZ_GEOM_CAPSULE) {
         capsule_box(d, &pp, gp, d->geom_xmat[g], m->geom_size[g][0], m->geom_size[g][1], bpos, ident, bsize);
-      } else if (m->geom_type[g] == MZ_GEOM_BOX && is_axis_aligned(d->geom_xmat[g])) {
+      } else if (m->geom_type[g] == MZ_GEOM_BOX && is_block_geom(m, g) && is_axis_aligned(d->geom_xmat[g])) {
         /* wall geoms precede the movable bodies' geoms in MuJoCo's geom order: geom1 = wall, geom2 = block */
         pairparam q = pp;
         q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
         box_box_aligned(d, &q, bpos, bsize, gp, m->geom_size[g]);
+      } else if (m->geom_type[g] == MZ_GEOM_BOX && fabs(d->geom_xmat[g][8] - 1.0) < 1e-12) {
+        pairparam q = pp; /* box rotated about z only (the Point's arrow) */
+        q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
+        box_zrot_vs_aabb(d, &q, bpos, bsize, gp, d->geom_xmat[g], m->geom_size[g]);
       } else {
-        d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* rotated box vs box (Point arrow): not restated */
+        d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* generally rotated box vs box: not restated */
       }
     }
 }

@@ -106,3 +106,34 @@ int emu_ant_forward(const mz_model* m, int n, const float* qpos, const float* qv
   }
 }
 }
+
+// ---------------------------------------------------------------- Point: the per-lane step function of point_step_kernel
+#include "../../mujoco_maze_amd/csrc/point_dyn.h"
+
+extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
+                                  float* reward, uint8_t* done, int32_t* goal_idx, int32_t* status) {
+  PointDev* P = (PointDev*)calloc(1, sizeof(PointDev));
+  char err[128];
+  int rc = point_dev_from_model(P, m, err, sizeof(err));
+  if (rc != MZ_OK) { free(P); return rc; }
+  for (int e = 0; e < n; e++) {
+    double q[3], v[3], a[2] = {(double)actions[2 * e], (double)actions[2 * e + 1]};
+    for (int k = 0; k < 3; k++) { q[k] = (double)qpos[3 * e + k]; v[k] = (double)qvel[3 * e + k]; }
+    int t_new;
+    int st = point_env_step(*P, q, v, a, t[e], nullptr, nullptr, nullptr, nullptr, nullptr, &t_new);
+    float o[7];
+    for (int k = 0; k < 3; k++) { o[k] = (float)q[k]; o[3 + k] = (float)v[k]; }
+    o[6] = (float)t_new * 0.001f;
+    float outer; int tm, gi;
+    task_eval_dev(P->task, o, &outer, &tm, &gi);
+    for (int k = 0; k < 7; k++) obs[7 * e + k] = o[k];
+    for (int k = 0; k < 3; k++) { qpos[3 * e + k] = o[k]; qvel[3 * e + k] = o[3 + k]; }
+    reward[e] = outer;
+    done[e] = (uint8_t)((tm ? 1 : 0) | (t_new >= P->task.max_steps ? 2 : 0));
+    if (goal_idx) goal_idx[e] = gi;
+    if (status) status[e] = st;
+    t[e] = t_new;
+  }
+  free(P);
+  return MZ_OK;
+}

@@ -63,3 +63,16 @@ def forward(cm, qpos, qvel, actions=None, warm=None, max_iter=0, tol=0.0, rtol=-
 def f32_state(st):
     return dict(qpos=st["qpos"].astype(np.float32), qvel=st["qvel"].astype(np.float32), warm=st["warm"].astype(np.float32),
                 t=st["t"].copy())
+
+
+def point_env_step(cm, st, actions):
+    """st: dict of float32 qpos [n,3], qvel [n,3], int32 t [n] (updated in place)."""
+    lib = load()
+    n = st["qpos"].shape[0]
+    a = np.ascontiguousarray(actions, np.float32)
+    out = dict(obs=np.zeros((n, 7), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+               goal_idx=np.zeros(n, np.int32), status=np.zeros(n, np.int32))
+    rc = lib.emu_point_env_step(C.byref(cm.c), n, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["t"]), _vp(a), _vp(out["obs"]),
+                                _vp(out["reward"]), _vp(out["done"]), _vp(out["goal_idx"]), _vp(out["status"]))
+    assert rc == 0, rc
+    return out

@@ -142,3 +142,33 @@ def test_kernel_logic_movable_block(oracle):
             moved = max(moved, np.abs(s64["qpos"][:, 15:]).max())
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     assert moved > 0.1  # the block really gets pushed
+
+
+def test_point_step_logic_with_mujoco_wall_contacts(oracle):
+    """Point (BASELINE config 2): teleport + RK4 + MuJoCo sphere-box / arrow box-box wall contacts + manual bounce,
+    over the whole maze (about half of the random states have active MuJoCo contacts)."""
+    from tests import emu_lib
+
+    cm = model.compile_model("point", T.DistRewardUMaze(4.0), 4.0)
+    n = 4096
+    rng = np.random.default_rng(9)
+    xmin, xmax, ymin, ymax = cm.world.xy_limits()
+    st = dict(qpos=np.stack([rng.uniform(xmin, xmax, n), rng.uniform(ymin, ymax, n), rng.uniform(-3.2, 3.2, n)], 1),
+              qvel=np.stack([rng.uniform(0, 0.1, n), rng.uniform(0, 0.1, n), rng.uniform(-12, 12, n)], 1),
+              warm=np.zeros((n, 3)), t=rng.integers(0, 990, n).astype(np.int32))
+    st = _f32(st)
+    act = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.25, 0.25, n)], 1).astype(np.float32)
+    act[: n // 4, 0] *= 4.0  # unclipped actions (point.py:44-55): long teleports -> bounces / give-ups
+    s32 = dict(qpos=st["qpos"].astype(np.float32), qvel=st["qvel"].astype(np.float32), t=st["t"].copy())
+    g = oracle.forward(cm, st["qpos"], st["qvel"])
+    assert (g["counts"][:, 1] > 0).sum() > n // 4  # MuJoCo contact rows really active in the fixture
+    start = st["qpos"].copy()
+    ro = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    re_ = emu_lib.point_env_step(cm, s32, act)
+    ok = (ro["status"] & ~8) == 0  # 8 = collinear move (the reference raises ZeroDivisionError there)
+    assert ok.mean() > 0.999 and np.all((ro["status"] & 256) == 0)
+    assert np.all(np.abs(re_["obs"][ok] - ro["obs"][ok]) <= 1e-6 + 2e-7 * np.abs(ro["obs"][ok]))
+    assert np.array_equal(re_["done"][ok], ro["done"][ok]) and np.array_equal(re_["goal_idx"][ok], ro["goal_idx"][ok])
+    assert np.array_equal(re_["reward"][ok], ro["reward"][ok].astype(np.float32))
+    gave_up = np.all(ro["obs"][:, :2] == start[:, :2].astype(np.float32).astype(np.float64), axis=1)
+    assert gave_up.sum() > 20  # the give-up branch of the manual bounce is exercised
