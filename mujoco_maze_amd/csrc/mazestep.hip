@@ -26,6 +26,7 @@
 
 #include "ant_dyn.h"
 #include "point_dyn.h"
+#include "swimmer_dyn.h"
 
 
 // ------------------------------------------------------------------ device context of a lane group
@@ -341,24 +342,84 @@ __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, cons
     obs[(size_t)env * 7 + 6] = (float)S.t[env] * 0.001f;
   }
 }
+template <int KQ>
 __global__ void point_set_state_kernel(int n, PointState S, const float* qpos, const float* qvel, const int* t) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
-  for (int k = 0; k < 3; k++) {
-    if (qpos) S.qv[(size_t)k * n + env] = qpos[(size_t)env * 3 + k];
-    if (qvel) S.qv[(size_t)(3 + k) * n + env] = qvel[(size_t)env * 3 + k];
+  for (int k = 0; k < KQ; k++) {
+    if (qpos) S.qv[(size_t)k * n + env] = qpos[(size_t)env * KQ + k];
+    if (qvel) S.qv[(size_t)(KQ + k) * n + env] = qvel[(size_t)env * KQ + k];
   }
   if (t) S.t[env] = t[env];
 }
+template <int KQ>
 __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* qvel, float* warm, int* t) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
-  for (int k = 0; k < 3; k++) {
-    if (qpos) qpos[(size_t)env * 3 + k] = S.qv[(size_t)k * n + env];
-    if (qvel) qvel[(size_t)env * 3 + k] = S.qv[(size_t)(3 + k) * n + env];
-    if (warm) warm[(size_t)env * 3 + k] = 0.f;
+  for (int k = 0; k < KQ; k++) {
+    if (qpos) qpos[(size_t)env * KQ + k] = S.qv[(size_t)k * n + env];
+    if (qvel) qvel[(size_t)env * KQ + k] = S.qv[(size_t)(KQ + k) * n + env];
+    if (warm) warm[(size_t)env * KQ + k] = 0.f;
   }
   if (t) t[env] = S.t[env];
+}
+
+// ------------------------------------------------------------------ Swimmer kernels (SoA: q0..q4 v0..v4 | t | episode)
+__global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __restrict__ Pp, int n, PointState S,
+                                                            const float* __restrict__ actions, float* __restrict__ obs,
+                                                            float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                            int* __restrict__ goal_idx, float* __restrict__ info,
+                                                            int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  const SwimmerDev& P = *Pp;
+  double q[5], v[5], a[2], inner, inf4[4];
+  for (int k = 0; k < 5; k++) { q[k] = (double)S.qv[(size_t)k * n + env]; v[k] = (double)S.qv[(size_t)(5 + k) * n + env]; }
+  a[0] = (double)actions[(size_t)env * 2]; a[1] = (double)actions[(size_t)env * 2 + 1];
+  int t_new;
+  int st = swimmer_env_step(P, q, v, a, S.t[env], &inner, inf4, &t_new);
+  float o[11];
+  for (int k = 0; k < 5; k++) { o[k] = (float)q[k]; o[5 + k] = (float)v[k]; }
+  o[10] = (float)t_new * 0.001f;
+  float outer; int tm, gi;
+  task_eval_dev(P.task, o, &outer, &tm, &gi);
+  uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
+  for (int k = 0; k < 11; k++) obs[(size_t)env * 11 + k] = o[k];
+  reward[env] = (float)(P.task.inner_scale * inner) + outer;
+  done[env] = d;
+  if (goal_idx) goal_idx[env] = gi;
+  if (info) for (int k = 0; k < 4; k++) info[(size_t)env * 4 + k] = (float)inf4[k];
+  bool badv = false;
+  for (int k = 0; k < 10; k++) badv = badv || !(fabsf(o[k]) < 1e10f);
+  if (badv) st |= MZ_STATUS_BAD_STATE;
+  if (st) atomicOr(&status[env], st);
+  uint32_t ep = S.ep[env];
+  if (auto_reset && d) {
+    ep += 1;
+    uint64_t es = episode_seed(seed, ep);
+    for (int k = 0; k < 5; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k); o[5 + k] = reset_qvel(P.reset_kind, 5, es, env0 + (uint64_t)env, k); }
+    t_new = 0;
+  }
+  for (int k = 0; k < 10; k++) S.qv[(size_t)k * n + env] = o[k];
+  S.t[env] = t_new;
+  S.ep[env] = ep;
+}
+
+__global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  if (!mask || mask[env]) {
+    for (int k = 0; k < 5; k++) {
+      S.qv[(size_t)k * n + env] = reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k);
+      S.qv[(size_t)(5 + k) * n + env] = reset_qvel(Pp->reset_kind, 5, seed, env0 + (uint64_t)env, k);
+    }
+    S.t[env] = 0;
+    S.ep[env] = 0;
+  }
+  if (obs) {
+    for (int k = 0; k < 10; k++) obs[(size_t)env * 11 + k] = S.qv[(size_t)k * n + env];
+    obs[(size_t)env * 11 + 10] = (float)S.t[env] * 0.001f;
+  }
 }
 
 __global__ void fetch_clear_status_kernel(int n, int* status, int* out) {
@@ -378,6 +439,8 @@ struct mz_handle {
   AntLayout lay;
   PointDev* point_dev;  // device copy
   PointDev point;
+  SwimmerDev* swimmer_dev;
+  SwimmerDev swimmer;
   float* state;         // ant: [n][48]; point: [6][n]
   int* pt_t;
   uint32_t* pt_ep;
@@ -472,6 +535,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   int rc = MZ_OK;
   if (model->robot == MZ_ROBOT_ANT) rc = ant_dev_from_model(&h->ant, model, msg, sizeof(msg));
   else if (model->robot == MZ_ROBOT_POINT) rc = point_dev_from_model(&h->point, model, msg, sizeof(msg));
+  else if (model->robot == MZ_ROBOT_SWIMMER) rc = swimmer_dev_from_model(&h->swimmer, model, msg, sizeof(msg));
   else { rc = MZ_ERR_UNSUPPORTED; snprintf(msg, sizeof(msg), "mz_create: robot kind %d has no device kernel yet", model->robot); }
   if (rc != MZ_OK) { delete h; return fail(msg); }
   hipError_t e = hipSuccess;
@@ -488,12 +552,18 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     if (e == hipSuccess) e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
-    e = hipMalloc(&h->state, (size_t)num_envs * 6 * sizeof(float));
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? 5 : 3;
+    e = hipMalloc(&h->state, (size_t)num_envs * 2 * kq * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&h->point_dev, sizeof(PointDev));
-    if (e == hipSuccess) e = hipMemcpy(h->point_dev, &h->point, sizeof(PointDev), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * 6 * sizeof(float));
+    if (h->robot == MZ_ROBOT_SWIMMER) {
+      if (e == hipSuccess) e = hipMalloc(&h->swimmer_dev, sizeof(SwimmerDev));
+      if (e == hipSuccess) e = hipMemcpy(h->swimmer_dev, &h->swimmer, sizeof(SwimmerDev), hipMemcpyHostToDevice);
+    } else {
+      if (e == hipSuccess) e = hipMalloc(&h->point_dev, sizeof(PointDev));
+      if (e == hipSuccess) e = hipMemcpy(h->point_dev, &h->point, sizeof(PointDev), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * 2 * kq * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->pt_t, 0, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->pt_ep, 0, (size_t)num_envs * sizeof(uint32_t));
   }
@@ -513,6 +583,7 @@ void mz_destroy(mz_handle* h) {
   if (h->pt_t) (void)hipFree(h->pt_t);
   if (h->pt_ep) (void)hipFree(h->pt_ep);
   if (h->point_dev) (void)hipFree(h->point_dev);
+  if (h->swimmer_dev) (void)hipFree(h->swimmer_dev);
   if (h->ant_dev) (void)hipFree(h->ant_dev);
   if (h->status) (void)hipFree(h->status);
   if (h->prof) (void)hipFree(h->prof);
@@ -571,7 +642,10 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
   h->seed = seed;
   int nb = (h->n + 255) / 256;
   if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->lay, h->n, h->state, mask_dev, seed, h->env0, obs_dev);
-  else {
+  else if (h->robot == MZ_ROBOT_SWIMMER) {
+    PointState S{h->state, h->pt_t, h->pt_ep};
+    hipLaunchKernelGGL(swimmer_reset_kernel, dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+  } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_reset_kernel, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
   }
@@ -588,7 +662,10 @@ int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev,
     hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    hipLaunchKernelGGL(point_set_state_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
+    if (h->robot == MZ_ROBOT_SWIMMER)
+      hipLaunchKernelGGL(point_set_state_kernel<5>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
+    else
+      hipLaunchKernelGGL(point_set_state_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
   }
   HIPCHK(h, hipGetLastError());
   return MZ_OK;
@@ -602,7 +679,10 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
     hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    hipLaunchKernelGGL(point_get_state_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+    if (h->robot == MZ_ROBOT_SWIMMER)
+      hipLaunchKernelGGL(point_get_state_kernel<5>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+    else
+      hipLaunchKernelGGL(point_get_state_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   }
   HIPCHK(h, hipGetLastError());
   return MZ_OK;
@@ -623,6 +703,10 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
       default: le = dispatch_ant_step<2>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
     }
     HIPCHK(h, le);
+  } else if (h->robot == MZ_ROBOT_SWIMMER) {
+    PointState S{h->state, h->pt_t, h->pt_ep};
+    hipLaunchKernelGGL(swimmer_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev,
+                       reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->point_dev, h->n, S, actions_dev, obs_dev,

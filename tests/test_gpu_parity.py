@@ -228,9 +228,39 @@ def test_point_step_parity_and_bounce(torch, oracle):
     env.close()
 
 
+def test_swimmer_step_parity(torch, oracle):
+    n = 4096
+    env = mm.make("SwimmerUMaze-v0", num_envs=n)
+    cm = env.model
+    assert env.obs_dim == 11
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(0)
+    st["qpos"][:, 3:5] = rng.uniform(-1.9, 1.9, (n, 2))
+    st["qvel"] = rng.normal(size=(n, 5)) * 2
+    for k in range(6):
+        act = rng.uniform(-1.5, 1.5, (n, 2)).astype(np.float32)
+        if k in (0, 5):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], None, s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=1e-6, rtol=2e-7))
+            assert np.all(_close(rew.cpu().numpy(), ref["reward"], atol=1e-7))
+            assert np.array_equal(done.cpu().numpy(), ref["done"])
+            assert np.all(_close(info["reward_forward"].cpu().numpy(), ref["info"][:, 2], atol=1e-6))
+            assert np.all(env.status().cpu().numpy() == 0)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    env.close()
+    single = mm.make("SwimmerSquareRoom-v1")
+    s0, _ = single.reset()
+    s, r, d, inf = single.step(single.action_space.sample(np.random.default_rng(1)))
+    assert s0.shape == (11,) and s.shape == (11,)  # reference tests/test_envs.py:77-78
+    single.close()
+
+
 def test_reset_distribution_and_oracle_rng(torch, oracle):
     n = 2048
-    for env_id, nq, nv in (("AntUMaze-v0", 15, 14), ("PointUMaze-v0", 3, 3)):
+    for env_id, nq, nv in (("AntUMaze-v0", 15, 14), ("PointUMaze-v0", 3, 3), ("SwimmerUMaze-v0", 5, 5)):
         env = mm.make(env_id, num_envs=n)
         obs = env.reset(seed=1234).cpu().numpy()
         ref_st, ref_obs = oracle.reset(env.model, n, 1234)
@@ -241,6 +271,8 @@ def test_reset_distribution_and_oracle_rng(torch, oracle):
         v = obs[:, nq:nq + nv]
         if nq == 3:
             assert v.min() >= 0.0 and v.max() < 0.1 + 1e-6  # point.py:75: U[0,1) * 0.1
+        elif nq == 5:
+            assert v.min() >= -0.1 - 1e-6 and v.max() <= 0.1 + 1e-6 and abs(v.mean()) < 0.01  # swimmer.py:61-65
         else:
             assert abs(v.std() - 0.1) < 0.01 and abs(v.mean()) < 0.01  # ant.py:90: randn * 0.1
         # masked reset leaves the others untouched
