@@ -541,7 +541,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   hipError_t e = hipSuccess;
   if (h->robot == MZ_ROBOT_ANT) {
     const int nb = h->ant.nblock;
-    if (nb > 2) { delete h; return fail("mz_create: more than 2 movable blocks are not instantiated yet"); }
+    if (nb > 1) { delete h; return fail("mz_create: mazes with more than one movable block need block-block contacts (not on the device path yet)"); }
     h->lay.nq = ANT_NQ + 2 * nb; h->lay.nv = ANT_NV + 2 * nb; h->lay.rec_t = h->lay.nq + 2 * h->lay.nv;
     h->lay.rec = (h->lay.rec_t + 2 + 15) / 16 * 16;
     h->lay.nblock3 = model->observe_blocks ? 3 * nb : 0;

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """GPU box helper: throughput of other configs (not the headline bench): AntPush-v0 2048, Ant4Rooms-v0 4096, PointUMaze-v0 4096."""
 import time, torch
 import mujoco_maze_amd as mm

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 np.set_printoptions(linewidth=220, precision=6, suppress=True)
 import mujoco_maze_amd as mm

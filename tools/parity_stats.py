@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """GPU box helper: worst / quantile single-step errors vs the oracle (AntUMaze-v0, rollout checkpoints)."""
 import numpy as np, torch
 import mujoco_maze_amd as mm

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """GPU box helper: per-phase shader-cycle breakdown of ant_step_kernel (instrumented build)."""
 import sys, json
 import torch

@@ -3,7 +3,7 @@
 import csv, glob, os, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
-os.makedirs("profiles", exist_ok=True)
+os.makedirs(f"profiles/{tag}", exist_ok=True)
 lines = [f"# rocprofv3 summary — {tag}", "", "command: `python bench.py --steps 100 --warmup 30 --no-cpu-baseline` (AntUMaze-v0, 4096 envs, 1 x MI355X)", ""]
 for f in glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True):
     lines += ["## kernel stats (`rocprofv3 --kernel-trace --stats`)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
@@ -25,5 +25,5 @@ for k, d in agg.items():
     for c, v in sorted(d.items()):
         lines.append(f"| {c} | {sum(v)/len(v):.4g} | {len(v)} |")
     lines.append("")
-open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines))
+open(f"profiles/{tag}/summary.md", "w").write("\n".join(lines))
 print("\n".join(lines))

@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box helper: rocprofv3 kernel stats + PMC passes of the default bench command -> gpurun_out/prof_$1
+# GPU box helper: rocprofv3 kernel stats + PMC passes of the bench command -> gpurun_out/prof_$1
+# (counters are collected in their own passes, never together with --kernel-trace/--stats tracing domains)
 tag=${1:-r01}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
