@@ -42,6 +42,10 @@
 #endif
 
 #define MZ_FOR(i, n) for (int i = cx.lane0(); i < (n); i += C::nlanes)
+// items 0..n-1 on the lanes base, base+1, ... (mod group size): lets unrelated work share one phase
+#define MZ_FOR_AT(i, n, base) for (int i = mz_first_item(cx.lane0(), (base), C::nlanes); i < (n); i += C::nlanes)
+
+MZ_HD int mz_first_item(int lane, int base, int nl) { int r = (lane - base) % nl; return r < 0 ? r + nl : r; }
 
 struct HostCtx {
   static constexpr int nlanes = 1;
@@ -188,11 +192,12 @@ MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
 // body index b in 0..12: 0 torso, else leg l = (b-1)/3, level k = (b-1)%3 (0 welded leg, 1 aux, 2 ankle)
 MZ_HD int body_class(int b) { return b == 0 ? 0 : 1 + (b - 1) % 3; }
 
-// ------------------------------------------------------------------ K + I: kinematics, inertias, mass matrix
-template <int NB, class C>
-MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
-  constexpr int NH = AntDims<NB>::NH;
-  MZ_FOR(l, 5) {
+// ------------------------------------------------------------------ K + I + V: per-item bodies of the kinematics, inertia,
+// mass-matrix and bias-force phases (scheduled onto lanes by ant_forward)
+template <int NB>
+MZ_HD void kin_item(const AntDev& K, AntScratchT<NB>& s, int l) {
+  constexpr int NH = AntDims<NB>::NH; (void)NH;
+
     if (l == 4) {
       // Wall broad phase for the whole robot (runs beside the four leg lanes): every robot geom lies within
       // ANT_REACH of the torso origin (torso sphere 0.25; leg chain 0.2*sqrt2*2 + 0.4*sqrt2 + capsule radius 0.08
@@ -217,7 +222,7 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
       }
       if (!inside) near = 1;
       s.nearwall = near;
-      continue;
+      return;
     }
     float R0[9];
     quat_to_matf(R0, s.qpos + 3);
@@ -257,10 +262,11 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
     t[0] = ch * a[0] - sh * a[1]; t[1] = sh * a[0] + ch * a[1]; t[2] = a[2];
     mat_vecf(s.Sa[l], R0, t);               // ankle axis (world)
     cross3f(s.Sa[l] + 3, s.p2[l], s.Sa[l]); // aw x (c - p2)
-  }
-  cx.sync();
-  // spatial inertia of every body about c
-  MZ_FOR(b, ANT_NBODY) {
+}
+
+template <int NB>
+MZ_HD void inertia_item(const AntDev& K, AntScratchT<NB>& s, int b) {
+
     int c = body_class(b);
     float m = K.mass[c], lat = K.ilat[c], dax = K.iax[c] - K.ilat[c];
     float r[3] = {0, 0, 0}, w[3] = {0, 0, 0};
@@ -274,10 +280,12 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
     I[7] = dax * w[0] * w[1] - m * r[0] * r[1];
     I[8] = dax * w[0] * w[2] - m * r[0] * r[2];
     I[9] = dax * w[1] * w[2] - m * r[1] * r[2];
-  }
-  cx.sync();
-  // composite-rigid-body mass matrix, arrow storage
-  MZ_FOR(l, 4) {
+}
+
+template <int NB>
+MZ_HD void crb_leg_item(const AntDev& K, AntScratchT<NB>& s, int l) {
+  constexpr int NH = AntDims<NB>::NH;
+
     float Ia[10], Ih[10], Sh[6], Fa[6], Fh[6];
     for (int k = 0; k < 10; k++) { Ia[k] = s.cin[3 + 3 * l][k]; Ih[k] = Ia[k] + s.cin[2 + 3 * l][k]; }
     for (int k = 0; k < 3; k++) { Sh[k] = s.zw[k]; Sh[3 + k] = s.Sh[l][k]; }
@@ -294,19 +302,25 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
       s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
     }
     for (int k = 6; k < NH; k++) { s.M.rl[l][0][k] = 0.f; s.M.rl[l][1][k] = 0.f; }  // blocks are separate trees
-  }
-  MZ_FOR(k, 10) {  // whole-body composite inertia about c
+}
+
+template <int NB>
+MZ_HD void iall_item(const AntDev& K, AntScratchT<NB>& s, int k) {
+  // whole-body composite inertia about c
     float v = 0.f;
     for (int b = 0; b < ANT_NBODY; b++) v += s.cin[b][k];
     s.Iall[k] = v;
-  }
-  cx.sync();
-  MZ_FOR(e, 21 + (NH - 6) * NH) {
+}
+
+template <int NB>
+MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+  constexpr int NH = AntDims<NB>::NH;
+
     if (e >= 21) {  // block rows of the hub: diag(mass), no coupling
       int q = e - 21, i = 6 + q / NH, j = q - (i - 6) * NH;
       float val = (i == j) ? K.block_mass : 0.f;
       s.M.rr[i][j] = val; s.M.rr[j][i] = val;
-      continue;
+      return;
     }
     // root 6x6 block from the whole-body composite inertia (lower triangle, mirrored)
     int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : 5;
@@ -330,15 +344,11 @@ MZ_HD void ant_kin_crb(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
       }
     }
     s.M.rr[i][j] = val; s.M.rr[j][i] = val;
-  }
-  cx.sync();
 }
 
-// ------------------------------------------------------------------ V: velocities, bias forces, smooth forces
-template <int NB, class C>
-MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
-  constexpr int NV = AntDims<NB>::NV;
-  MZ_FOR(l, 5) {
+template <int NB>
+MZ_HD void bias_leg_item(const AntDev& K, AntScratchT<NB>& s, int l) {
+
     float v0[6], a0[6], ww[3];
     mat_vecf(ww, s.R0, s.qvel + 3);  // world angular velocity (root angular dofs are body-frame)
     for (int k = 0; k < 3; k++) { v0[k] = ww[k]; v0[3 + k] = s.qvel[k]; a0[k] = 0.f; }
@@ -372,9 +382,11 @@ MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
       s.bias[6 + 2 * l] = dot6f(Sh, f);
       for (int k = 0; k < 6; k++) s.fleg[l][k] = ft[k];
     }
-  }
-  cx.sync();
-  MZ_FOR(i, NV) {
+}
+
+template <int NB>
+MZ_HD void bias_dof_item(const AntDev& K, AntScratchT<NB>& s, int i) {
+
     float frc;
     if (i < 6) {
       float tot[3];
@@ -392,9 +404,10 @@ MZ_HD void ant_bias(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
       frc = 0.f;
     }
     s.qfs[i] = frc;
-  }
-  cx.sync();
 }
+
+
+
 
 // ------------------------------------------------------------------ arrow linear algebra
 // y_i = (A x)_i for one dof in MuJoCo order (called inside an MZ_FOR over dofs)
@@ -413,6 +426,69 @@ MZ_HD float arrow_row_mul(const Arrow<NH>& A, const float* x, int i) {
   return v;
 }
 
+// ---- the four phases of the fused arrow factor + solve, as per-item functions (so that they can share a phase
+// ---- with unrelated work on other lanes)
+template <int NH>
+MZ_HD void factor_leg_item(const Arrow<NH>& A, ArrowFactor<NH>& F, int l) {
+  float hh = A.ll[l][0], ha = A.ll[l][1], aa = A.ll[l][2];
+  float idet = 1.0f / (hh * aa - ha * ha);
+  float ihh = aa * idet, iha = -ha * idet, iaa = hh * idet;
+  F.inv[l][0] = ihh; F.inv[l][1] = iha; F.inv[l][2] = iaa;
+  for (int k = 0; k < NH; k++) {
+    F.T[l][0][k] = ihh * A.rl[l][0][k] + iha * A.rl[l][1][k];
+    F.T[l][1][k] = iha * A.rl[l][0][k] + iaa * A.rl[l][1][k];
+  }
+}
+template <int NH>
+MZ_HD void factor_schur_item(const Arrow<NH>& A, ArrowFactor<NH>& F, const float* g, int e) {
+  constexpr int NTRI = NH * (NH + 1) / 2;
+  if (e < NTRI) {
+    int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : e < 21 ? 5 : e < 28 ? 6 : e < 36 ? 7 : e < 45 ? 8 : 9;
+    int j = e - (i * (i + 1)) / 2;
+    float v = A.rr[i][j];
+    for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
+    F.L[i][j] = v;
+  } else {
+    int k = e - NTRI;
+    float r = g[hub2dof(k)];
+    for (int l = 0; l < 4; l++) r -= F.T[l][0][k] * g[6 + 2 * l] + F.T[l][1][k] * g[7 + 2 * l];
+    F.rhs[k] = r;
+  }
+}
+template <int NH>
+MZ_HD void factor_serial_item(ArrowFactor<NH>& F) {
+  float L[NH][NH], y[NH], id[NH];
+  for (int i = 0; i < NH; i++) for (int j = 0; j <= i; j++) L[i][j] = F.L[i][j];
+  for (int i = 0; i < NH; i++) y[i] = F.rhs[i];
+  for (int j = 0; j < NH; j++) {
+    float d = L[j][j];
+    for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+    float r = 1.0f / sqrtf(fmaxf(d, 1e-30f));
+    id[j] = r;
+    for (int i = j + 1; i < NH; i++) {
+      float t = L[i][j];
+      for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+      L[i][j] = t * r;
+    }
+  }
+  for (int i = 0; i < NH; i++) { float t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * id[i]; }
+  for (int i = NH - 1; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < NH; k++) t -= L[k][i] * y[k]; y[i] = t * id[i]; }
+  for (int i = 0; i < NH; i++) F.rhs[i] = y[i];
+}
+template <int NH>
+MZ_HD float factor_back_item(const ArrowFactor<NH>& F, const float* g, float sign, int i) {
+  float v;
+  if (i < 6) v = F.rhs[i];
+  else if (i >= 14) v = F.rhs[i - 8];
+  else {
+    int l = (i - 6) >> 1, d = (i - 6) & 1;
+    float gh = g[6 + 2 * l], ga = g[7 + 2 * l];
+    v = d == 0 ? F.inv[l][0] * gh + F.inv[l][1] * ga : F.inv[l][1] * gh + F.inv[l][2] * ga;
+    for (int k = 0; k < NH; k++) v -= F.T[l][d][k] * F.rhs[k];
+  }
+  return sign * v;
+}
+
 // Fused factor + solve of an arrow system A x = sign * g (vectors in MuJoCo dof order):
 //   phase 1 (4 leg lanes)  2x2 inverses and T = inv * rl
 //   phase 2                NH(NH+1)/2 Schur-complement entries + NH reduced right-hand sides
@@ -420,67 +496,16 @@ MZ_HD float arrow_row_mul(const Arrow<NH>& A, const float* x, int i) {
 //   phase 4 (NV lanes)     back-substitution of the leg dofs
 template <int NH, int NV, class C>
 MZ_HD void arrow_factor_solve(const C& cx, const Arrow<NH>& A, ArrowFactor<NH>& F, const float* g, float* x, float sign) {
-  constexpr int NTRI = NH * (NH + 1) / 2;
-  MZ_FOR(l, 4) {
-    float hh = A.ll[l][0], ha = A.ll[l][1], aa = A.ll[l][2];
-    float idet = 1.0f / (hh * aa - ha * ha);
-    float ihh = aa * idet, iha = -ha * idet, iaa = hh * idet;
-    F.inv[l][0] = ihh; F.inv[l][1] = iha; F.inv[l][2] = iaa;
-    for (int k = 0; k < NH; k++) {
-      F.T[l][0][k] = ihh * A.rl[l][0][k] + iha * A.rl[l][1][k];
-      F.T[l][1][k] = iha * A.rl[l][0][k] + iaa * A.rl[l][1][k];
-    }
-  }
+  MZ_FOR(l, 4) factor_leg_item<NH>(A, F, l);
   cx.sync();
-  MZ_FOR(e, NTRI + NH) {
-    if (e < NTRI) {
-      int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : e < 21 ? 5 : e < 28 ? 6 : e < 36 ? 7 : e < 45 ? 8 : 9;
-      int j = e - (i * (i + 1)) / 2;
-      float v = A.rr[i][j];
-      for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
-      F.L[i][j] = v;
-    } else {
-      int k = e - NTRI;
-      float r = g[hub2dof(k)];
-      for (int l = 0; l < 4; l++) r -= F.T[l][0][k] * g[6 + 2 * l] + F.T[l][1][k] * g[7 + 2 * l];
-      F.rhs[k] = r;
-    }
-  }
+  MZ_FOR(e, NH * (NH + 1) / 2 + NH) factor_schur_item<NH>(A, F, g, e);
   cx.sync();
-  MZ_FOR(one, 1) {
-    float L[NH][NH], y[NH], id[NH];
-    for (int i = 0; i < NH; i++) for (int j = 0; j <= i; j++) L[i][j] = F.L[i][j];
-    for (int i = 0; i < NH; i++) y[i] = F.rhs[i];
-    for (int j = 0; j < NH; j++) {
-      float d = L[j][j];
-      for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-      float r = 1.0f / sqrtf(fmaxf(d, 1e-30f));
-      id[j] = r;
-      for (int i = j + 1; i < NH; i++) {
-        float t = L[i][j];
-        for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-        L[i][j] = t * r;
-      }
-    }
-    for (int i = 0; i < NH; i++) { float t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * id[i]; }
-    for (int i = NH - 1; i >= 0; i--) { float t = y[i]; for (int k = i + 1; k < NH; k++) t -= L[k][i] * y[k]; y[i] = t * id[i]; }
-    for (int i = 0; i < NH; i++) F.rhs[i] = y[i];
-  }
+  MZ_FOR(one, 1) factor_serial_item<NH>(F);
   cx.sync();
-  MZ_FOR(i, NV) {
-    float v;
-    if (i < 6) v = F.rhs[i];
-    else if (i >= 14) v = F.rhs[i - 8];
-    else {
-      int l = (i - 6) >> 1, d = (i - 6) & 1;
-      float gh = g[6 + 2 * l], ga = g[7 + 2 * l];
-      v = d == 0 ? F.inv[l][0] * gh + F.inv[l][1] * ga : F.inv[l][1] * gh + F.inv[l][2] * ga;
-      for (int k = 0; k < NH; k++) v -= F.T[l][d][k] * F.rhs[k];
-    }
-    x[i] = sign * v;
-  }
+  MZ_FOR(i, NV) x[i] = factor_back_item<NH>(F, g, sign, i);
   cx.sync();
 }
+
 
 // ------------------------------------------------------------------ C + J: collision and constraint rows
 // kind: 0 robot geom vs floor, 1 robot geom vs wall, 2 robot geom vs movable block, 3 block vs floor, 4 block vs wall
@@ -721,21 +746,20 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     }
 }
 
-template <int NB, class C>
-MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
-  using D = AntDims<NB>;
-  constexpr int NH = D::NH, NC = D::NC, NG = D::NGEOM;
-  // pass 1: count contacts per enumerator
-  MZ_FOR(e, NG) {
+// per-item bodies of the collision / constraint-row phases
+template <int NB>
+MZ_HD void con_count_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+
     int n = 0;
     geom_contacts<NB>(K, s, e, [&](const ContactGeo&) { n++; });
     s.cnt[e] = n;
-  }
-  cx.sync();
-  cx.tick(s, 11);
-  // pass 2a: deterministic offsets (exclusive prefix over enumerators); contact geometry into the compact
-  // slots (staged in cY, which the solver only uses later)
-  MZ_FOR(e, NG) {
+}
+
+template <int NB>
+MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+  using D = AntDims<NB>;
+  constexpr int NC = D::NC, NG = D::NGEOM;
+
     int off = 0;
     for (int g = 0; g < e; g++) off += s.cnt[g];
     if (e == NG - 1) {
@@ -756,13 +780,13 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
       s.ccls[slot] = cls;
       slot++;
     });
-  }
-  cx.sync();
-  cx.tick(s, 12);
-  // pass 2b: one lane per (contact, frame row): Jacobian row, row velocity, reference acceleration; the normal
-  // row also sets the pyramid's D.  Sign convention J = J(geom2 body) - J(geom1 body): the robot geom is geom2
-  // against the floor and geom1 against walls and blocks; a block is geom2 against floor, walls and robot geoms.
-  MZ_FOR(item, 3 * s.ncon) {
+}
+
+template <int NB>
+MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
+  using D = AntDims<NB>;
+  constexpr int NH = D::NH;
+
     int c = item / 3, a = item - 3 * c;
     const float* q = &s.cY[c][0][0];
     float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
@@ -796,10 +820,11 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
     }
     for (int k = 0; k < D::NCOL; k++) s.cJ[c][a][k] = J[k];
     s.caref[c][a] = aref;
-  }
-  cx.tick(s, 13);
-  // joint limits: one slot per hinge (at most one side can be violated)
-  MZ_FOR(j, 8) {
+}
+
+template <int NB>
+MZ_HD void limit_item(const AntDev& K, AntScratchT<NB>& s, int j) {
+
     int l = j >> 1;
     float q = s.qpos[7 + j], lo = (j & 1) ? K.ank_lo[l] : K.hip_lo, hi = (j & 1) ? K.ank_hi[l] : K.hip_hi;
     float sg = 0.f, pos = 0.f;
@@ -813,9 +838,8 @@ MZ_HD void ant_constraints(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
       aref = -K.lim_B * (sg * s.qvel[6 + j]) - K.lim_K * imp * pos;
     }
     s.lsign[j] = sg; s.lD[j] = Dl; s.laref[j] = aref;
-  }
-  cx.sync();
 }
+
 
 // ------------------------------------------------------------------ N: Newton solver
 // contact c: u = J qacc - aref (3), pyramid rows r = (u0+u1, u0-u1, u0+u2, u0-u2), active where r < 0
@@ -1014,22 +1038,57 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
 // ------------------------------------------------------------------ one forward-dynamics evaluation: qacc from (qpos, qvel, fact)
 // `first`: first evaluation of an env.step (warm = MuJoCo's qacc_warmstart, compared by cost against
 // qacc_smooth); otherwise s.warm holds the previous evaluation's solution and s.qas its qacc_smooth.
+//
+// Schedule: independent pieces of work share a phase on different lanes (MZ_FOR_AT(item, count, first lane)),
+// so one evaluation needs 8 phase boundaries before the solver instead of 13:
+//   P0  leg kinematics (4) | wall broad phase (1)
+//   P1  body inertias (13) | contact count per geom (13 + NB)
+//   P2  leg mass-matrix blocks (4) | composite inertia (10) | leg bias forces (5) | contact geometry fill (13 + NB)
+//   P3  hub mass-matrix entries (21 + ..) | bias / smooth force per dof (NV)
+//   P4  2x2 leg inverses of M (4) | contact Jacobian rows (3 ncon) | joint-limit rows (8)
+//   P5  Schur entries + reduced rhs    P6  hub Cholesky (1 lane)    P7  back-substitution -> qacc_smooth
 template <int NB, class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   using D = AntDims<NB>;
+  constexpr int NH = D::NH, NV = D::NV, NG = D::NGEOM, NROOT = 21 + (NH - 6) * NH;
   cx.tick(s, 9);
-  ant_kin_crb<NB>(cx, K, s);
+  MZ_FOR(l, 5) kin_item<NB>(K, s, l);
+  cx.sync();
   cx.tick(s, 0);
-  ant_bias<NB>(cx, K, s);
+  MZ_FOR_AT(b, ANT_NBODY, 0) inertia_item<NB>(K, s, b);
+  MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e);
+  cx.sync();
   cx.tick(s, 1);
-  if (!first) { MZ_FOR(i, D::NV) s.warm[i] -= s.qas[i]; cx.sync(); }
-  arrow_factor_solve<D::NH, D::NV>(cx, s.M, s.F, s.qfs, s.qas, 1.f);
-  if (!first) { MZ_FOR(i, D::NV) s.warm[i] += s.qas[i]; cx.sync(); }
+  MZ_FOR_AT(l, 4, 0) crb_leg_item<NB>(K, s, l);
+  MZ_FOR_AT(k, 10, 4) iall_item<NB>(K, s, k);
+  MZ_FOR_AT(l, 5, 14) bias_leg_item<NB>(K, s, l);
+  MZ_FOR_AT(e, NG, 19) con_fill_item<NB>(K, s, e);
+  cx.sync();
   cx.tick(s, 2);
-  ant_constraints<NB>(cx, K, s);
+  MZ_FOR_AT(e, NROOT, 0) crb_root_item<NB>(K, s, e);
+  MZ_FOR_AT(i, NV, NROOT) bias_dof_item<NB>(K, s, i);
+  if (!first) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7
+  cx.sync();
   cx.tick(s, 3);
+  MZ_FOR_AT(l, 4, 0) factor_leg_item<NH>(s.M, s.F, l);
+  MZ_FOR_AT(item, 3 * s.ncon, 4) con_row_item<NB>(K, s, item);
+  MZ_FOR_AT(j, 8, 4 + 3 * s.ncon) limit_item<NB>(K, s, j);
+  cx.sync();
+  cx.tick(s, 11);
+  MZ_FOR(e, NH * (NH + 1) / 2 + NH) factor_schur_item<NH>(s.M, s.F, s.qfs, e);
+  cx.sync();
+  MZ_FOR(one, 1) factor_serial_item<NH>(s.F);
+  cx.sync();
+  MZ_FOR(i, NV) {
+    float v = factor_back_item<NH>(s.F, s.qfs, 1.f, i);
+    s.qas[i] = v;
+    if (!first) s.warm[i] += v;
+  }
+  cx.sync();
+  cx.tick(s, 12);
   ant_solve<NB>(cx, K, s, first);
 }
+
 
 // qpos <- integrate(qpos, vel, h): free joint on the manifold, hinges and block slides linear (mj_integratePos)
 template <int NB, class C>

@@ -18,11 +18,10 @@ env.step(acts[0]); env.phase_cycles()
 steps = 50
 for i in range(steps): env.step(acts[i % 16])
 cyc = env.phase_cycles()
-names = ["kin+crb", "bias", "factorM+qas", "constraints", "solve:init(cost x2)", "solve:grad+H", "solve:factor+dir", "solve:linesearch", "solve:tail",
-         "rk4/integrate", "io+epilogue"]
+names = ["P0 kinematics+broadphase", "P1 inertia|contact count", "P2 crb|bias legs|contact fill", "P3 hub M|bias dofs", "solve:init", "solve:grad+H", "solve:factor+dir", "solve:linesearch", "solve:tail",
+         "rk4/integrate", "io+epilogue", "P4 M leg inv|contact rows|limits", "P5-7 factor M -> qacc_smooth"]
 wgs = n // (64 // lanes)
-tot = sum(cyc[:11])
-print("  constraints split: pass1 %.0f  pass2a %.0f  pass2b %.0f  limits(rest, in constraints line) cycles/step" % (cyc[11]/steps/wgs, cyc[12]/steps/wgs, cyc[13]/steps/wgs))
+tot = sum(cyc[:13])
 print(f"lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")
 for k, nm in enumerate(names):
-    print(f"  {nm:24s} {cyc[k]/steps/wgs:10.0f} cycles/step  {100*cyc[k]/tot:5.1f} %")
+    print(f"  {nm:36s} {cyc[k]/steps/wgs:10.0f} cycles/step  {100*cyc[k]/tot:5.1f} %")
