@@ -64,7 +64,8 @@ struct AntDims {
   static constexpr int NV = 14 + 2 * NB;   // MuJoCo dof order: root 0-5, legs 6-13, blocks 14..
   static constexpr int NQ = 15 + 2 * NB;
   static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
-  static constexpr int NC = NB ? 28 : 16;  // contact slots (a block alone holds ~10: 4 floor corners + walls)
+  // contact slots: a block resting in a corridor holds 4 floor corners + 4 per adjacent wall/block face
+  static constexpr int NC = NB == 0 ? 16 : (NB == 1 ? 28 : (NB == 2 ? 40 : 72));
   static constexpr int NGEOM = 13 + NB;    // contact enumerators: blocks first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;
@@ -207,18 +208,20 @@ MZ_HD void kin_item(const AntDev& K, AntScratchT<NB>& s, int l) {
       float x = s.qpos[0] + z.tx, y = s.qpos[1] + z.ty, inv = 1.0f / z.scale;
       int jc = (int)floorf(x * inv + 0.5f), ic = (int)floorf(y * inv + 0.5f);
       float fx = x - jc * z.scale, fy = y - ic * z.scale;  // offset from the centre of the torso's own cell
-      // only the neighbour cells on the side(s) the torso is close to can matter
-      int sj = fx > 0.f ? 1 : -1, si = fy > 0.f ? 1 : -1;
-      float gx = z.half_xy - fabsf(fx), gy = z.half_xy - fabsf(fy);  // distance to the nearer x / y cell border
       bool inside = ic >= 0 && ic < z.rows && jc >= 0 && jc < z.cols;
-      uint32_t row0 = inside ? maze_row(z, ic) : 0u;
-      int near = (row0 >> (jc & 31)) & 1u;  // torso inside a wall cell (deep penetration): keep testing
-      int j2 = jc + sj, i2 = ic + si;
-      if (gx < reach && ic >= 0 && ic < z.rows && j2 >= 0 && j2 < z.cols && ((maze_row(z, ic) >> j2) & 1u)) near = 1;
-      if (gy < reach && i2 >= 0 && i2 < z.rows) {
-        uint32_t row1 = maze_row(z, i2);
-        if (jc >= 0 && jc < z.cols && ((row1 >> jc) & 1u)) near = 1;
-        if (j2 >= 0 && j2 < z.cols && ((row1 >> j2) & 1u) && gx * gx + gy * gy < reach * reach) near = 1;
+      int near = inside ? (int)((maze_row(z, ic) >> jc) & 1u) : 1;  // torso inside a wall cell / off the grid: keep testing
+      if (z.scale < reach) near = 1;  // cells smaller than the reach: more than one ring of neighbours could matter
+      for (int di = -1; di <= 1; di++) {
+        int i2 = ic + di;
+        if (i2 < 0 || i2 >= z.rows) continue;
+        uint32_t row = maze_row(z, i2);
+        float dy = di == 0 ? 0.f : z.half_xy - di * fy;  // distance to the border shared with that row
+        for (int dj = -1; dj <= 1; dj++) {
+          int j2 = jc + dj;
+          if (j2 < 0 || j2 >= z.cols || !((row >> j2) & 1u)) continue;
+          float dx = dj == 0 ? 0.f : z.half_xy - dj * fx;
+          if (dx * dx + dy * dy < reach * reach) near = 1;
+        }
       }
       if (!inside) near = 1;
       s.nearwall = near;
@@ -443,7 +446,8 @@ template <int NH>
 MZ_HD void factor_schur_item(const Arrow<NH>& A, ArrowFactor<NH>& F, const float* g, int e) {
   constexpr int NTRI = NH * (NH + 1) / 2;
   if (e < NTRI) {
-    int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : e < 21 ? 5 : e < 28 ? 6 : e < 36 ? 7 : e < 45 ? 8 : 9;
+    int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : e < 21 ? 5 : e < 28 ? 6 : e < 36 ? 7 : e < 45 ? 8 : e < 55 ? 9 : e < 66 ? 10 : 11;
+    static_assert(NH <= 12, "triangular index decode covers 12 hub dofs");
     int j = e - (i * (i + 1)) / 2;
     float v = A.rr[i][j];
     for (int l = 0; l < 4; l++) v -= A.rl[l][0][i] * F.T[l][0][j] + A.rl[l][1][i] * F.T[l][1][j];
@@ -508,8 +512,9 @@ MZ_HD void arrow_factor_solve(const C& cx, const Arrow<NH>& A, ArrowFactor<NH>& 
 
 
 // ------------------------------------------------------------------ C + J: collision and constraint rows
-// kind: 0 robot geom vs floor, 1 robot geom vs wall, 2 robot geom vs movable block, 3 block vs floor, 4 block vs wall
-struct ContactGeo { float dist, pos[3], n[3], hint[3]; int kind, blk; };
+// kind: 0 robot geom vs floor, 1 robot geom vs wall, 2 robot geom vs movable block, 3 block vs floor, 4 block vs wall,
+// 5 block `other` (geom1) vs block `blk` (geom2)
+struct ContactGeo { float dist, pos[3], n[3], hint[3]; int kind, blk, other; };
 
 MZ_HD void make_tangents(const float* n, const float* hint, float* t1, float* t2) {
   float y[3] = {hint[0], hint[1], hint[2]};
@@ -595,7 +600,7 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
   float cl[3] = {ctr[0] - bc[0], ctr[1] - bc[1], ctr[2] - bc[2]};  // geom centre in box coordinates
   float dist, pos[3], n[3];
   ContactGeo cg;
-  cg.kind = kind; cg.blk = blk;
+  cg.kind = kind; cg.blk = blk; cg.other = 0;
   cg.hint[0] = cg.hint[1] = cg.hint[2] = 0.f;
   if (sphere) {
     if (sphere_aabb(cl, r, bs, margin, &dist, pos, n) && dist < margin) {
@@ -651,7 +656,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     float bottom = (bc[2] + s.cz) - hb[2];  // absolute height of the bottom face
     if (bottom < K.floor.margin)
       for (int ci = 0; ci < 4; ci++) {  // plane-box: the four bottom corners
-        cg.kind = 3; cg.blk = e; cg.dist = bottom;
+        cg.kind = 3; cg.blk = e; cg.other = 0; cg.dist = bottom;
         cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
         cg.hint[0] = cg.hint[1] = cg.hint[2] = 0.f;
         cg.pos[0] = bc[0] + ((ci & 1) ? hb[0] : -hb[0]); cg.pos[1] = bc[1] + ((ci & 2) ? hb[1] : -hb[1]);
@@ -679,7 +684,6 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         for (int k = 0; k < 3; k++) {
           lo[k] = fmaxf(c1[k] - bs[k], bc[k] - hb[k]);
           hi[k] = fminf(c1[k] + bs[k], bc[k] + hb[k]);
-          if (hi[k] < lo[k]) { float mid = 0.5f * (lo[k] + hi[k]); lo[k] = mid; hi[k] = mid; }
         }
         int u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
         if (ax == 1) { u = 2; v = 0; }
@@ -688,15 +692,46 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         float sg = bca >= c1a ? 1.f : -1.f;
         float lou = u == 0 ? lo[0] : (u == 1 ? lo[1] : lo[2]), hiu = u == 0 ? hi[0] : (u == 1 ? hi[1] : hi[2]);
         float lov = v == 0 ? lo[0] : (v == 1 ? lo[1] : lo[2]), hiv = v == 0 ? hi[0] : (v == 1 ? hi[1] : hi[2]);
-        int nu = (hiu - lou > 1e-6f) ? 2 : 1, nv = (hiv - lov > 1e-6f) ? 2 : 1;
-        for (int iu = 0; iu < nu; iu++)
-          for (int iv = 0; iv < nv; iv++) {
-            cg.kind = 4; cg.blk = e; cg.dist = gmax;
+        if (!(hiu - lou > 1e-6f) || !(hiv - lov > 1e-6f)) continue;  // edge / corner touch: no face contact
+        for (int iu = 0; iu < 2; iu++)
+          for (int iv = 0; iv < 2; iv++) {
+            cg.kind = 4; cg.blk = e; cg.other = 0; cg.dist = gmax;
             float pa = c1a + sg * (bsa + 0.5f * gmax), pu = iu ? hiu : lou, pv = iv ? hiv : lov;
             for (int k = 0; k < 3; k++) { cg.n[k] = k == ax ? sg : 0.f; cg.hint[k] = 0.f; cg.pos[k] = k == ax ? pa : (k == u ? pu : pv); }
             emit(cg);
           }
       }
+    // lower-numbered movable blocks: aligned box-box [ASSUME-12], geom1 = block k, geom2 = block e
+    for (int k = 0; k < e; k++) {
+      float c1[3];
+      block_center<NB>(K, s, k, c1);
+      float gap[3];
+      int ax = 0;
+      for (int q = 0; q < 3; q++) gap[q] = fabsf(bc[q] - c1[q]) - 2.f * hb[q];
+      if (gap[1] > gap[ax]) ax = 1;
+      if (gap[2] > gap[ax]) ax = 2;
+      float gmax = ax == 0 ? gap[0] : (ax == 1 ? gap[1] : gap[2]);
+      if (!(gmax < K.wall.margin)) continue;
+      float lo[3], hi[3];
+      for (int q = 0; q < 3; q++) {
+        lo[q] = fmaxf(c1[q] - hb[q], bc[q] - hb[q]);
+        hi[q] = fminf(c1[q] + hb[q], bc[q] + hb[q]);
+      }
+      int u = ax == 0 ? 1 : (ax == 1 ? 2 : 0), v = ax == 0 ? 2 : (ax == 1 ? 0 : 1);
+      float c1a = ax == 0 ? c1[0] : (ax == 1 ? c1[1] : c1[2]), bca = ax == 0 ? bc[0] : (ax == 1 ? bc[1] : bc[2]);
+      float hba = ax == 0 ? hb[0] : (ax == 1 ? hb[1] : hb[2]);
+      float sg = bca >= c1a ? 1.f : -1.f;
+      float lou = u == 0 ? lo[0] : (u == 1 ? lo[1] : lo[2]), hiu = u == 0 ? hi[0] : (u == 1 ? hi[1] : hi[2]);
+      float lov = v == 0 ? lo[0] : (v == 1 ? lo[1] : lo[2]), hiv = v == 0 ? hi[0] : (v == 1 ? hi[1] : hi[2]);
+      if (!(hiu - lou > 1e-6f) || !(hiv - lov > 1e-6f)) continue;
+      for (int iu = 0; iu < 2; iu++)
+        for (int iv = 0; iv < 2; iv++) {
+          cg.kind = 5; cg.blk = e; cg.other = k; cg.dist = gmax;
+          float pa = c1a + sg * (hba + 0.5f * gmax), pu = iu ? hiu : lou, pv = iv ? hiv : lov;
+          for (int q = 0; q < 3; q++) { cg.n[q] = q == ax ? sg : 0.f; cg.hint[q] = 0.f; cg.pos[q] = q == ax ? pa : (q == u ? pu : pv); }
+          emit(cg);
+        }
+    }
     return;
   }
   // ---- robot geom
@@ -713,7 +748,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     for (int k = 0; k < 3; k++) p[k] = ctr[k] + sg * ax[k] * hl;
     float dist = (s.cz + p[2]) - r;
     if (dist < K.floor.margin) {
-      cg.dist = dist; cg.kind = 0; cg.blk = 0;
+      cg.dist = dist; cg.kind = 0; cg.blk = 0; cg.other = 0;
       cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
       cg.pos[0] = p[0]; cg.pos[1] = p[1]; cg.pos[2] = p[2] - (r + 0.5f * dist);
       for (int k = 0; k < 3; k++) cg.hint[k] = b == 0 ? 0.f : ax[k];
@@ -775,7 +810,7 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       if (slot >= NC) { slot++; return; }
       float* q = &s.cY[slot][0][0];
       for (int k = 0; k < 3; k++) { q[k] = g.pos[k]; q[3 + k] = g.n[k]; q[8 + k] = g.hint[k]; }
-      q[6] = g.dist; q[7] = (float)(g.kind + 8 * g.blk);
+      q[6] = g.dist; q[7] = (float)(g.kind + 8 * g.blk + 64 * g.other);
       s.cleg[slot] = leg;
       s.ccls[slot] = cls;
       slot++;
@@ -790,7 +825,7 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     int c = item / 3, a = item - 3 * c;
     const float* q = &s.cY[c][0][0];
     float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
-    int code = (int)q[7], kind = code & 7, blk = code >> 3;
+    int code = (int)q[7], kind = code & 7, blk = (code >> 3) & 7, other = code >> 6;
     const PairDev& P = (kind == 0 || kind == 3) ? K.floor : K.wall;
     int leg = s.cleg[c], cls = s.ccls[c];
     float t1[3], t2[3], f[3];
@@ -804,7 +839,10 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     for (int k = 0; k < 3; k++) { J[k] = sr * f[k]; J[3 + k] = sr * (s.R0[k] * m[0] + s.R0[3 + k] * m[1] + s.R0[6 + k] * m[2]); }
     for (int k = 6; k < NH; k++) J[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < NB; k++) if (k == blk && kind >= 2) { J[6 + 2 * k] = sb * f[0]; J[7 + 2 * k] = sb * f[1]; }
+    for (int k = 0; k < NB; k++) {
+      if (k == blk && kind >= 2) { J[6 + 2 * k] = sb * f[0]; J[7 + 2 * k] = sb * f[1]; }
+      if (kind == 5 && k == other) { J[6 + 2 * k] = -f[0]; J[7 + 2 * k] = -f[1]; }  // geom1 of a block-block pair
+    }
     J[NH] = cls >= 2 ? sr * (dot3f(s.zw, m) + dot3f(s.Sh[leg < 0 ? 0 : leg], f)) : 0.f;
     J[NH + 1] = cls == 3 ? sr * (dot3f(s.Sa[leg < 0 ? 0 : leg], m) + dot3f(s.Sa[leg < 0 ? 0 : leg] + 3, f)) : 0.f;
     float vel = 0.f;
@@ -813,7 +851,7 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     float aref = -P.B * vel;
     if (a == 0) {
       float imp = impedancef(P.solimp, fabsf(dist - P.margin));
-      float tran = (cls >= 0 ? K.bw_tran[cls] : 0.f) + (kind >= 2 ? K.block_bw_tran : 0.f);
+      float tran = (cls >= 0 ? K.bw_tran[cls] : 0.f) + (kind >= 2 ? K.block_bw_tran : 0.f) + (kind == 5 ? K.block_bw_tran : 0.f);
       float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
       s.cD[c] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
       aref -= P.K * imp * (dist - P.margin);

@@ -541,7 +541,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   hipError_t e = hipSuccess;
   if (h->robot == MZ_ROBOT_ANT) {
     const int nb = h->ant.nblock;
-    if (nb > 1) { delete h; return fail("mz_create: mazes with more than one movable block need block-block contacts (not on the device path yet)"); }
+    if (nb > 3) { delete h; return fail("mz_create: more than 3 movable blocks are not instantiated"); }
     h->lay.nq = ANT_NQ + 2 * nb; h->lay.nv = ANT_NV + 2 * nb; h->lay.rec_t = h->lay.nq + 2 * h->lay.nv;
     h->lay.rec = (h->lay.rec_t + 2 + 15) / 16 * 16;
     h->lay.nblock3 = model->observe_blocks ? 3 * nb : 0;
@@ -700,7 +700,8 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
     switch (h->ant.nblock) {
       case 0: le = dispatch_ant_step<0>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
       case 1: le = dispatch_ant_step<1>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
-      default: le = dispatch_ant_step<2>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      case 2: le = dispatch_ant_step<2>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
+      default: le = dispatch_ant_step<3>(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev); break;
     }
     HIPCHK(h, le);
   } else if (h->robot == MZ_ROBOT_SWIMMER) {
@@ -733,7 +734,8 @@ int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev
   switch (h->ant.nblock) {
     case 0: le = dispatch_ant_forward<0>(h, st, actions_dev, qacc_dev, counts_dev); break;
     case 1: le = dispatch_ant_forward<1>(h, st, actions_dev, qacc_dev, counts_dev); break;
-    default: le = dispatch_ant_forward<2>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    case 2: le = dispatch_ant_forward<2>(h, st, actions_dev, qacc_dev, counts_dev); break;
+    default: le = dispatch_ant_forward<3>(h, st, actions_dev, qacc_dev, counts_dev); break;
   }
   HIPCHK(h, le);
   HIPCHK(h, hipGetLastError());

@@ -253,8 +253,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     blocks = world.movable_cells()
     if any(cell is not MazeCell.XY_BLOCK for _, _, cell in blocks):
         raise NotImplementedError("only XY_BLOCK movable blocks are supported (no z-moving / half / spin blocks yet)")
-    if len(blocks) > 4:
-        raise NotImplementedError("more than 4 movable blocks")
+    if len(blocks) > 3:
+        raise NotImplementedError("more than 3 movable blocks")
     if world.rows > MAX_GRID or world.cols > MAX_GRID:
         raise ValueError("maze grid larger than MZ_MAX_GRID")
 

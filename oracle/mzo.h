@@ -7,7 +7,7 @@
 extern "C" {
 #endif
 
-#define MZO_MAX_CON 64
+#define MZO_MAX_CON 96
 #define MZO_MAX_EFC (8 + 2 * MZ_MAX_JNT + 4 * MZO_MAX_CON)
 #define MZO_STATUS_UNSUPPORTED_PAIR 256
 

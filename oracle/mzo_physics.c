@@ -552,11 +552,13 @@ static void box_box_aligned(mzo_data* d, const pairparam* pp, const double* c1, 
   for (int k = 0; k < 3; k++) {
     lo[k] = fmax(c1[k] - h1[k], c2[k] - h2[k]);
     hi[k] = fmin(c1[k] + h1[k], c2[k] + h2[k]);
-    if (hi[k] < lo[k]) lo[k] = hi[k] = 0.5 * (lo[k] + hi[k]);
   }
+  /* faces must overlap by a positive area: boxes that only share an edge or a corner (a block at its spawn
+   * position against the diagonal wall cells) make no contact, so that the grid-aligned rest state is not a tie */
+  if (!(hi[u] - lo[u] > 1e-6) || !(hi[v] - lo[v] > 1e-6)) return;
   double nrm[3] = {0, 0, 0};
   nrm[ax] = sg;
-  int nu = (hi[u] - lo[u] > 1e-12) ? 2 : 1, nvv = (hi[v] - lo[v] > 1e-12) ? 2 : 1;
+  const int nu = 2, nvv = 2;
   for (int iu = 0; iu < nu; iu++)
     for (int iv = 0; iv < nvv; iv++) {
       double pos[3];

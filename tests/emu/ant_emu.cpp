@@ -87,6 +87,7 @@ int emu_ant_env_step(const mz_model* m, int n, float* qpos, float* qvel, float* 
     case 0: return env_step_t<0>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
     case 1: return env_step_t<1>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
     case 2: return env_step_t<2>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
+    case 3: return env_step_t<3>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
     default: return MZ_ERR_UNSUPPORTED;
   }
 }
@@ -102,6 +103,7 @@ int emu_ant_forward(const mz_model* m, int n, const float* qpos, const float* qv
     case 0: return forward_t<0>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);
     case 1: return forward_t<1>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);
     case 2: return forward_t<2>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);
+    case 3: return forward_t<3>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);
     default: return MZ_ERR_UNSUPPORTED;
   }
 }

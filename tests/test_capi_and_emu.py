@@ -144,6 +144,59 @@ def test_kernel_logic_movable_block(oracle):
     assert moved > 0.1  # the block really gets pushed
 
 
+@pytest.mark.parametrize("name,nblock,obs_dim", [("MultiPush", 2, 36), ("MultiPushSmall", 3, 39), ("PushMaze", 3, 39)])
+def test_kernel_logic_multi_block_mazes(oracle, name, nblock, obs_dim):
+    """Mazes with two / three movable XY blocks (maze_task.py:259-330; scale 2 = the reference's default for
+    them is 4, halved here so that the ant starts within reach of walls and blocks): block-block contacts, hub of
+    10 / 12 dofs, up to 72 contact slots.  Blocks are kicked so that they hit walls and each other."""
+    from tests import emu_lib
+
+    cm = model.compile_model("ant", T.TaskRegistry.tasks(name)[0](2.0), 2.0)
+    m = cm.c
+    assert m.nblock == nblock and m.obs_dim == obs_dim
+    n = 48
+    st, _ = oracle.reset(cm, n, 5)
+    rng = np.random.default_rng(0)
+    st["qvel"][:, 14:] = rng.uniform(-3, 3, (n, 2 * nblock))
+    worst = []
+    for k in range(21):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        if k in (0, 5, 20):
+            s64 = _f32(st)
+            s32 = emu_lib.f32_state(s64)
+            ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            re_ = emu_lib.env_step(cm, s32, act)
+            assert np.all((re_["status"] & 7) == 0) and np.all((ro["status"] & 7) == 0)
+            per_env = (np.abs(s32["qvel"] - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
+            worst.append(per_env)
+            ok = per_env <= 1e-4
+            assert np.all(np.abs(re_["obs"][ok] - ro["obs"][ok]) <= 1e-4 + 1e-5 * np.abs(ro["obs"][ok]))
+            assert np.array_equal(re_["done"], ro["done"])
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    worst = np.concatenate(worst)
+    assert np.median(worst) < 3e-6 and (worst <= 2e-5).mean() >= 0.97, (np.median(worst), (worst <= 2e-5).mean(), worst.max())
+
+
+def test_wall_broad_phase_small_cells(oracle):
+    """Cells narrower than twice the ant's reach (scale 2): walls on BOTH sides of the torso's cell are within
+    reach at spawn, so the torso-level broad phase must look at all eight neighbours."""
+    from tests import emu_lib
+
+    cm = model.compile_model("ant", T.TaskRegistry.tasks("UMaze")[0](2.0), 2.0)
+    n = 64
+    st, _ = oracle.reset(cm, n, 9)
+    rng = np.random.default_rng(1)
+    st["qpos"][:, 7:15:2] += rng.uniform(-0.5, 0.5, (n, 4))  # swing the hips so that the feet sweep the walls
+    st["qpos"][:, 2] = 0.6
+    s64 = _f32(st)
+    act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+    fo = oracle.forward(cm, s64["qpos"], s64["qvel"], act.astype(np.float64), s64["warm"])
+    fe = emu_lib.forward(cm, s64["qpos"], s64["qvel"], act, s64["warm"])
+    assert fo["counts"][:, 0].max() >= 2  # some feet do touch walls in this pose
+    assert np.array_equal(fo["counts"][:, 0], fe["counts"][:, 0])
+    assert np.all(np.abs(fo["qacc"] - fe["qacc"]) <= 2e-3 + 1e-5 * np.abs(fo["qacc"]))
+
+
 def test_point_step_logic_with_mujoco_wall_contacts(oracle):
     """Point (BASELINE config 2): teleport + RK4 + MuJoCo sphere-box / arrow box-box wall contacts + manual bounce,
     over the whole maze (about half of the random states have active MuJoCo contacts)."""

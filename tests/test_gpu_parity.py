@@ -225,6 +225,38 @@ def test_ant_push_movable_block(torch, oracle):
     env.close()
 
 
+@pytest.mark.parametrize("env_id,nblock", [("AntMultiPush-v0", 2), ("AntPushMaze-v0", 3)])
+def test_ant_multi_block_mazes(torch, oracle, env_id, nblock):
+    """Two / three movable blocks at maze scale 2 (ant within reach of walls and blocks at spawn): block-block
+    contacts, 10 / 12-dof hub, up to 72 contact slots."""
+    n = 512
+    env = mm.make(env_id, num_envs=n, maze_size_scaling=2.0)
+    cm = env.model
+    assert cm.c.nblock == nblock and env.obs_dim == 30 + 3 * nblock
+    st, _ = oracle.reset(cm, n, 5)
+    rng = np.random.default_rng(0)
+    st["qvel"][:, 14:] = rng.uniform(-3, 3, (n, 2 * nblock))
+    worst = []
+    for k in range(21):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        if k in (0, 5, 20):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], s64["warm"], s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
+            worst.append(per_env)
+            ok = per_env <= 1e-4
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=1e-4))
+            assert np.array_equal(done.cpu().numpy(), ref["done"])
+            assert np.all((env.status().cpu().numpy() & 7) == 0)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    worst = np.concatenate(worst)
+    assert np.median(worst) < 3e-6 and (worst <= 2e-5).mean() >= 0.97, (np.median(worst), (worst <= 2e-5).mean(), worst.max())
+    env.close()
+
+
 def test_point_step_parity_and_bounce(torch, oracle):
     n = 4096
     env = mm.make("PointUMaze-v0", num_envs=n)
