@@ -45,6 +45,26 @@ def usable_cores():
     return n
 
 
+def pmc_traffic(n_envs):
+    """HBM bytes per launch from the newest committed PMC summary (collected by tools/profile.sh in separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the default bench command, 4096 envs), or None.
+    rocprofv3 reports both in KB; the guide's x2 correction applies to wide (16 B/lane) streaming reads only, these
+    are 4-B-per-lane loads, so the raw sum is reported."""
+    import glob
+    if n_envs != ENVS_PER_GPU:
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_ant_step_kernel.csv")))
+    if not files:
+        return None
+    vals = {}
+    for line in open(files[-1]).read().splitlines()[1:]:
+        k, v, _ = line.split(",")
+        vals[k] = float(v)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(model, seconds_target=12.0):
     """Oracle (oracle/libmzo.so, kind 'port') on the host cores, OpenMP over envs."""
     import numpy as np
@@ -161,8 +181,9 @@ def main():
                        "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
                        "lanes_per_env": args.lanes or 32, "waves_per_block": args.wpb or 1, "bad_envs": bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(n),
                          "kernel": "ant_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic_source": "profiles/*/pmc_ant_step_kernel.csv: FETCH_SIZE + WRITE_SIZE (KB) of the committed rocprofv3 --pmc passes of this command, bytes per launch; not collected live",
                          "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -5,7 +5,8 @@ tag=${1:-r01}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 30 --no-cpu-baseline"
+# the default bench command (100 warm-up + 200 timed steps), minus the CPU leg
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $CMD > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $CMD > $out/bench_write.log 2>&1
