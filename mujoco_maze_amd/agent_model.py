@@ -49,8 +49,9 @@ class SwimmerEnv(AgentModel):
 
 
 class ReacherEnv(AgentModel):
-    """Registered for id parity only; the reference README (:129-130) marks it untested and it
-    is outside the hot-path scope."""
+    """reacher.py:15-80 / assets/reacher.xml: the swimmer's first two links with one motor (the asset even
+    declares `<mujoco model="swimmer">`), same medium, same step / reward code.  Runs on the swimmer kernels
+    instantiated for two links (`csrc/swimmer_dyn.h`)."""
 
     FILE = "reacher.xml"
     ROBOT = "reacher"
@@ -58,4 +59,4 @@ class ReacherEnv(AgentModel):
     FRAME_SKIP = 4
 
 
-ROBOT_CLASSES = {"point": PointEnv, "ant": AntEnv, "swimmer": SwimmerEnv}
+ROBOT_CLASSES = {"point": PointEnv, "ant": AntEnv, "swimmer": SwimmerEnv, "reacher": ReacherEnv}

@@ -364,7 +364,8 @@ __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* 
   if (t) t[env] = S.t[env];
 }
 
-// ------------------------------------------------------------------ Swimmer kernels (SoA: q0..q4 v0..v4 | t | episode)
+// ------------------------------------------------------------------ Swimmer / Reacher kernels (NL links; SoA: q0..q[NV-1] v0..v[NV-1] | t | episode)
+template <int NL>
 __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __restrict__ Pp, int n, PointState S,
                                                             const float* __restrict__ actions, float* __restrict__ obs,
                                                             float* __restrict__ reward, uint8_t* __restrict__ done,
@@ -372,53 +373,56 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
                                                             int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
+  constexpr int NV = NL + 2, NH = NL - 1, NO = 2 * NV + 1;
   const SwimmerDev& P = *Pp;
-  double q[5], v[5], a[2], inner, inf4[4];
-  for (int k = 0; k < 5; k++) { q[k] = (double)S.qv[(size_t)k * n + env]; v[k] = (double)S.qv[(size_t)(5 + k) * n + env]; }
-  a[0] = (double)actions[(size_t)env * 2]; a[1] = (double)actions[(size_t)env * 2 + 1];
+  double q[NV], v[NV], a[NH], inner, inf4[4];
+  for (int k = 0; k < NV; k++) { q[k] = (double)S.qv[(size_t)k * n + env]; v[k] = (double)S.qv[(size_t)(NV + k) * n + env]; }
+  for (int k = 0; k < NH; k++) a[k] = (double)actions[(size_t)env * NH + k];
   int t_new;
-  int st = swimmer_env_step(P, q, v, a, S.t[env], &inner, inf4, &t_new);
-  float o[11];
-  for (int k = 0; k < 5; k++) { o[k] = (float)q[k]; o[5 + k] = (float)v[k]; }
-  o[10] = (float)t_new * 0.001f;
+  int st = swimmer_env_step<NL>(P, q, v, a, S.t[env], &inner, inf4, &t_new);
+  float o[NO];
+  for (int k = 0; k < NV; k++) { o[k] = (float)q[k]; o[NV + k] = (float)v[k]; }
+  o[2 * NV] = (float)t_new * 0.001f;
   float outer; int tm, gi;
   task_eval_dev(P.task, o, &outer, &tm, &gi);
   uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
-  for (int k = 0; k < 11; k++) obs[(size_t)env * 11 + k] = o[k];
+  for (int k = 0; k < NO; k++) obs[(size_t)env * NO + k] = o[k];
   reward[env] = (float)(P.task.inner_scale * inner) + outer;
   done[env] = d;
   if (goal_idx) goal_idx[env] = gi;
   if (info) for (int k = 0; k < 4; k++) info[(size_t)env * 4 + k] = (float)inf4[k];
   bool badv = false;
-  for (int k = 0; k < 10; k++) badv = badv || !(fabsf(o[k]) < 1e10f);
+  for (int k = 0; k < 2 * NV; k++) badv = badv || !(fabsf(o[k]) < 1e10f);
   if (badv) st |= MZ_STATUS_BAD_STATE;
   if (st) atomicOr(&status[env], st);
   uint32_t ep = S.ep[env];
   if (auto_reset && d) {
     ep += 1;
     uint64_t es = episode_seed(seed, ep);
-    for (int k = 0; k < 5; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k); o[5 + k] = reset_qvel(P.reset_kind, 5, es, env0 + (uint64_t)env, k); }
+    for (int k = 0; k < NV; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k); o[NV + k] = reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k); }
     t_new = 0;
   }
-  for (int k = 0; k < 10; k++) S.qv[(size_t)k * n + env] = o[k];
+  for (int k = 0; k < 2 * NV; k++) S.qv[(size_t)k * n + env] = o[k];
   S.t[env] = t_new;
   S.ep[env] = ep;
 }
 
+template <int NL>
 __global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+  constexpr int NV = NL + 2, NO = 2 * NV + 1;
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   if (!mask || mask[env]) {
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < NV; k++) {
       S.qv[(size_t)k * n + env] = reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k);
-      S.qv[(size_t)(5 + k) * n + env] = reset_qvel(Pp->reset_kind, 5, seed, env0 + (uint64_t)env, k);
+      S.qv[(size_t)(NV + k) * n + env] = reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k);
     }
     S.t[env] = 0;
     S.ep[env] = 0;
   }
   if (obs) {
-    for (int k = 0; k < 10; k++) obs[(size_t)env * 11 + k] = S.qv[(size_t)k * n + env];
-    obs[(size_t)env * 11 + 10] = (float)S.t[env] * 0.001f;
+    for (int k = 0; k < 2 * NV; k++) obs[(size_t)env * NO + k] = S.qv[(size_t)k * n + env];
+    obs[(size_t)env * NO + 2 * NV] = (float)S.t[env] * 0.001f;
   }
 }
 
@@ -552,7 +556,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     if (e == hipSuccess) e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? 5 : 3;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3;
     e = hipMalloc(&h->state, (size_t)num_envs * 2 * kq * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
@@ -644,7 +648,8 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
   if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->lay, h->n, h->state, mask_dev, seed, h->env0, obs_dev);
   else if (h->robot == MZ_ROBOT_SWIMMER) {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    hipLaunchKernelGGL(swimmer_reset_kernel, dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+    if (h->swimmer.nlink == 3) hipLaunchKernelGGL(swimmer_reset_kernel<3>, dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+    else hipLaunchKernelGGL(swimmer_reset_kernel<2>, dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_reset_kernel, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
@@ -662,8 +667,10 @@ int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev,
     hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    if (h->robot == MZ_ROBOT_SWIMMER)
+    if (h->robot == MZ_ROBOT_SWIMMER && h->swimmer.nlink == 3)
       hipLaunchKernelGGL(point_set_state_kernel<5>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
+    else if (h->robot == MZ_ROBOT_SWIMMER)
+      hipLaunchKernelGGL(point_set_state_kernel<4>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
     else
       hipLaunchKernelGGL(point_set_state_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
   }
@@ -679,8 +686,10 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
     hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    if (h->robot == MZ_ROBOT_SWIMMER)
+    if (h->robot == MZ_ROBOT_SWIMMER && h->swimmer.nlink == 3)
       hipLaunchKernelGGL(point_get_state_kernel<5>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+    else if (h->robot == MZ_ROBOT_SWIMMER)
+      hipLaunchKernelGGL(point_get_state_kernel<4>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
     else
       hipLaunchKernelGGL(point_get_state_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   }
@@ -706,8 +715,12 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
     HIPCHK(h, le);
   } else if (h->robot == MZ_ROBOT_SWIMMER) {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    hipLaunchKernelGGL(swimmer_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev,
-                       reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
+    if (h->swimmer.nlink == 3)
+      hipLaunchKernelGGL(swimmer_step_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev,
+                         reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
+    else
+      hipLaunchKernelGGL(swimmer_step_kernel<2>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev,
+                         reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     hipLaunchKernelGGL(point_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->point_dev, h->n, S, actions_dev, obs_dev,

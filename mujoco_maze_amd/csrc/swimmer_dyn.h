@@ -1,4 +1,8 @@
-// swimmer_dyn.h — the Swimmer robot's MazeEnv.step, one environment per lane (fp64).
+// swimmer_dyn.h — the Swimmer robot's (and the Reacher's) MazeEnv.step, one environment per lane (fp64).
+//
+// The Reacher (mujoco_maze/reacher.py:15-80, assets/reacher.xml — whose <mujoco model="swimmer">) is the same
+// planar chain with TWO links and one motor, same medium, same step/reward code: the functions below are
+// templated on the link count NL (3 = Swimmer, 2 = Reacher); dofs = NL + 2, inner hinges = motors = NL - 1.
 //
 // Replaces SwimmerEnv.step (mujoco_maze/swimmer.py:37-53: `do_simulation(action, 4)` = 4 x mj_step with
 // RK4, h = 0.01; forward reward = |xy velocity|, ctrl cost 1e-4 |a|^2) and the MazeEnv.step bookkeeping
@@ -28,20 +32,24 @@ struct SwimmerDev {
   double off[3];                      // origin of link b in its parent's frame, along the parent's local x
   double lim_lo[2], lim_hi[2], lim_K, lim_B, lim_solimp[5], dofw[2];
   double qpos0[5];
+  int nlink;                          // 3 Swimmer, 2 Reacher
   TaskDev task;
 };
 
 static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char* err, int errlen) {
   memset(p, 0, sizeof(*p));
-  if (m->robot != MZ_ROBOT_SWIMMER || m->nv != 5 || m->nq != 5 || m->nbody != 4 || m->nu != 2 || !m->collision_predefined ||
-      m->jnt_type[0] != MZ_JNT_SLIDE || m->jnt_type[1] != MZ_JNT_SLIDE || m->jnt_type[2] != MZ_JNT_HINGE ||
-      m->jnt_type[3] != MZ_JNT_HINGE || m->jnt_type[4] != MZ_JNT_HINGE || m->act_dofid[0] != 3 || m->act_dofid[1] != 4)
-    return ant_fail(err, errlen, "swimmer kernel: model is not the 3-link planar swimmer");
+  const int nl = m->nbody - 1;
+  bool ok = m->robot == MZ_ROBOT_SWIMMER && (nl == 2 || nl == 3) && m->nv == nl + 2 && m->nq == nl + 2 && m->nu == nl - 1 &&
+            m->collision_predefined && m->jnt_type[0] == MZ_JNT_SLIDE && m->jnt_type[1] == MZ_JNT_SLIDE;
+  for (int j = 2; ok && j < nl + 2; j++) ok = m->jnt_type[j] == MZ_JNT_HINGE;
+  for (int a = 0; ok && a < nl - 1; a++) ok = m->act_dofid[a] == 3 + a;
+  if (!ok) return ant_fail(err, errlen, "swimmer kernel: model is not the 2- or 3-link planar swimmer / reacher");
+  p->nlink = nl;
   p->h = m->timestep; p->frame_skip = m->frame_skip; p->reset_kind = m->reset_qvel_kind;
   p->gear = m->act_gear[0]; p->ctrl_lo = m->act_ctrlrange[0][0]; p->ctrl_hi = m->act_ctrlrange[0][1];
   p->armature = m->dof_armature[0]; p->density = m->density; p->viscosity = m->viscosity;
   p->inv_scale = 1.0 / (m->meaninertia * m->nv);
-  for (int b = 0; b < 3; b++) {
+  for (int b = 0; b < nl; b++) {
     const double* I = m->body_inertia[b + 1];
     if (fabs(m->body_ipos[b + 1][1]) > 1e-12 || fabs(I[3]) + fabs(I[4]) + fabs(I[5]) > 1e-12)
       return ant_fail(err, errlen, "swimmer kernel: links must lie on their local x axis");
@@ -51,7 +59,7 @@ static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char*
     p->box[b][1] = sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / p->mass[b] * 6.0);
     p->box[b][2] = sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / p->mass[b] * 6.0);
   }
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < nl - 1; k++) {
     int j = 3 + k;
     if (!m->jnt_limited[j]) return ant_fail(err, errlen, "swimmer kernel: inner hinges must be limited");
     p->lim_lo[k] = m->jnt_range[j][0]; p->lim_hi[k] = m->jnt_range[j][1]; p->dofw[k] = m->dof_invweight0[j];
@@ -59,7 +67,8 @@ static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char*
   double tc = fmax(m->jnt_solref[3][0], 2.0 * m->timestep), dr = m->jnt_solref[3][1], dmax = m->jnt_solimp[3][1];
   p->lim_K = 1.0 / (dmax * dmax * tc * tc * dr * dr);
   p->lim_B = 2.0 / (dmax * tc);
-  for (int k = 0; k < 5; k++) { p->lim_solimp[k] = m->jnt_solimp[3][k]; p->qpos0[k] = m->qpos0[k]; }
+  for (int k = 0; k < 5; k++) p->lim_solimp[k] = m->jnt_solimp[3][k];
+  for (int k = 0; k < nl + 2; k++) p->qpos0[k] = m->qpos0[k];
   task_dev_from_model(&p->task, m);
   return MZ_OK;
 }
@@ -83,35 +92,39 @@ MZS_HD double sw_impedance(const double* si, double x) {
   return d0 + y * (dmax - d0);
 }
 
-// dense symmetric positive definite solve A x = b (n = 5), Cholesky in registers
-MZS_HD void sw_solve5(const double A[5][5], const double* b, double* x) {
-  double L[5][5];
-  for (int j = 0; j < 5; j++) {
+// dense symmetric positive definite solve A x = b (n = NV <= 5), Cholesky in registers
+template <int NV>
+MZS_HD void sw_solve(const double A[NV][NV], const double* b, double* x) {
+  double L[NV][NV];
+  for (int j = 0; j < NV; j++) {
     double d = A[j][j];
     for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
     d = sqrt(fmax(d, 1e-300));
     L[j][j] = d;
-    for (int i = j + 1; i < 5; i++) {
+    for (int i = j + 1; i < NV; i++) {
       double t = A[i][j];
       for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
       L[i][j] = t / d;
     }
   }
-  double y[5];
-  for (int i = 0; i < 5; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
-  for (int i = 4; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * x[k]; x[i] = t / L[i][i]; }
+  double y[NV];
+  for (int i = 0; i < NV; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
+  for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k]; x[i] = t / L[i][i]; }
 }
 
-// forward dynamics: qacc from (q, v, motor torques tau[2]); returns status bits
+// forward dynamics: qacc from (q, v, motor torques tau[NL - 1]); returns status bits
+template <int NL>
 MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v, const double* tau, double* qacc) {
+  constexpr int NV = NL + 2, NH = NL - 1;
   // link orientation angles and rates
-  double phi[3] = {q[2], q[2] + q[3], q[2] + q[3] + q[4]}, om[3] = {v[2], v[2] + v[3], v[2] + v[3] + v[4]};
-  double c[3], s[3];
-  for (int b = 0; b < 3; b++) { c[b] = cos(phi[b]); s[b] = sin(phi[b]); }
+  double phi[NL], om[NL], c[NL], s[NL];
+  phi[0] = q[2]; om[0] = v[2];
+  for (int b = 1; b < NL; b++) { phi[b] = phi[b - 1] + q[2 + b]; om[b] = om[b - 1] + v[2 + b]; }
+  for (int b = 0; b < NL; b++) { c[b] = cos(phi[b]); s[b] = sin(phi[b]); }
   // position Jacobians of the link centres: p_b = p0 + sum_{k<b} off[k+1] e(phi_k) + com[b] e(phi_b)
-  double Jx[3][5], Jy[3][5], ax[3], ay[3], vx[3], vy[3];
-  for (int b = 0; b < 3; b++) {
-    for (int k = 0; k < 5; k++) { Jx[b][k] = 0.0; Jy[b][k] = 0.0; }
+  double Jx[NL][NV], Jy[NL][NV], ax[NL], ay[NL], vx[NL], vy[NL];
+  for (int b = 0; b < NL; b++) {
+    for (int k = 0; k < NV; k++) { Jx[b][k] = 0.0; Jy[b][k] = 0.0; }
     Jx[b][0] = 1.0; Jy[b][1] = 1.0;
     ax[b] = 0.0; ay[b] = 0.0;
     for (int k = 0; k <= b; k++) {
@@ -122,14 +135,14 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
       ax[b] += -om[k] * om[k] * ex; ay[b] += -om[k] * om[k] * ey;  // centripetal acceleration at qacc = 0
     }
     vx[b] = 0.0; vy[b] = 0.0;
-    for (int k = 0; k < 5; k++) { vx[b] += Jx[b][k] * v[k]; vy[b] += Jy[b][k] * v[k]; }
+    for (int k = 0; k < NV; k++) { vx[b] += Jx[b][k] * v[k]; vy[b] += Jy[b][k] * v[k]; }
   }
-  double M[5][5], frc[5];
-  for (int i = 0; i < 5; i++) {
+  double M[NV][NV], frc[NV];
+  for (int i = 0; i < NV; i++) {
     frc[i] = 0.0;
-    for (int j = 0; j < 5; j++) M[i][j] = i == j ? P.armature : 0.0;
+    for (int j = 0; j < NV; j++) M[i][j] = i == j ? P.armature : 0.0;
   }
-  for (int b = 0; b < 3; b++) {
+  for (int b = 0; b < NL; b++) {
     double m = P.mass[b];
     // fluid forces in the link frame at its centre (MuJoCo inertia-box model)
     double lvx = c[b] * vx[b] + s[b] * vy[b], lvy = -s[b] * vx[b] + c[b] * vy[b], w = om[b];
@@ -146,23 +159,24 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
       tz -= P.density * bx[2] * (bx[0] * bx[0] * bx[0] * bx[0] + bx[1] * bx[1] * bx[1] * bx[1]) * fabs(w) * w / 64.0;
     }
     double Fx = c[b] * fx - s[b] * fy, Fy = s[b] * fx + c[b] * fy;
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < NV; i++) {
       double jw_i = (i >= 2 && i <= 2 + b) ? 1.0 : 0.0;
       frc[i] += Jx[b][i] * (Fx - m * ax[b]) + Jy[b][i] * (Fy - m * ay[b]) + jw_i * tz;
-      for (int j = 0; j < 5; j++) {
+      for (int j = 0; j < NV; j++) {
         double jw_j = (j >= 2 && j <= 2 + b) ? 1.0 : 0.0;
         M[i][j] += m * (Jx[b][i] * Jx[b][j] + Jy[b][i] * Jy[b][j]) + P.izz[b] * jw_i * jw_j;
       }
     }
   }
-  frc[3] += tau[0]; frc[4] += tau[1];
-  double qas[5];
-  sw_solve5(M, frc, qas);
-  for (int i = 0; i < 5; i++) qacc[i] = qas[i];
+  for (int k = 0; k < NH; k++) frc[3 + k] += tau[k];
+  double qas[NV];
+  sw_solve<NV>(M, frc, qas);
+  for (int i = 0; i < NV; i++) qacc[i] = qas[i];
   // joint limits on the inner hinges
-  double sg[2] = {0, 0}, D[2] = {0, 0}, aref[2] = {0, 0};
+  double sg[NH], D[NH], aref[NH];
+  for (int k = 0; k < NH; k++) { sg[k] = 0.0; D[k] = 0.0; aref[k] = 0.0; }
   bool any = false;
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < NH; k++) {
     double qq = q[3 + k], pos = 0.0;
     if (qq - P.lim_lo[k] < 0.0) { sg[k] = 1.0; pos = qq - P.lim_lo[k]; }
     else if (P.lim_hi[k] - qq < 0.0) { sg[k] = -1.0; pos = P.lim_hi[k] - qq; }
@@ -176,34 +190,34 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
   if (!any) return 0;
   int status = 0;
   for (int it = 0; it < 50; it++) {
-    double grad[5], H[5][5], jar[2], act[2];
-    for (int i = 0; i < 5; i++) {
+    double grad[NV], H[NV][NV], jar[NH], act[NH];
+    for (int i = 0; i < NV; i++) {
       grad[i] = 0.0;
-      for (int j = 0; j < 5; j++) { grad[i] += M[i][j] * (qacc[j] - qas[j]); H[i][j] = M[i][j]; }
+      for (int j = 0; j < NV; j++) { grad[i] += M[i][j] * (qacc[j] - qas[j]); H[i][j] = M[i][j]; }
     }
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < NH; k++) {
       jar[k] = sg[k] != 0.0 ? sg[k] * qacc[3 + k] - aref[k] : 0.0;
       act[k] = (sg[k] != 0.0 && jar[k] < 0.0) ? D[k] : 0.0;
       grad[3 + k] += sg[k] * act[k] * jar[k];
       H[3 + k][3 + k] += act[k];
     }
     double gn = 0.0;
-    for (int i = 0; i < 5; i++) gn += grad[i] * grad[i];
+    for (int i = 0; i < NV; i++) gn += grad[i] * grad[i];
     if (P.inv_scale * sqrt(gn) < 1e-10) break;
     if (it == 49) status |= MZ_STATUS_SOLVER_MAXITER;
-    double sr[5], ng[5];
-    for (int i = 0; i < 5; i++) ng[i] = -grad[i];
-    sw_solve5(H, ng, sr);
+    double sr[NV], ng[NV];
+    for (int i = 0; i < NV; i++) ng[i] = -grad[i];
+    sw_solve<NV>(H, ng, sr);
     double p1 = 0.0, p2 = 0.0;
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < NV; i++) {
       double ms = 0.0, mx = 0.0;
-      for (int j = 0; j < 5; j++) { ms += M[i][j] * sr[j]; mx += M[i][j] * (qacc[j] - qas[j]); }
+      for (int j = 0; j < NV; j++) { ms += M[i][j] * sr[j]; mx += M[i][j] * (qacc[j] - qas[j]); }
       p1 += sr[i] * mx; p2 += sr[i] * ms;
     }
     double lo = 0.0, hi = -1.0, alpha = 1.0, prev_d2 = -1.0;
     for (int ls = 0; ls < 30; ls++) {
       double d1 = p1 + alpha * p2, d2 = p2;
-      for (int k = 0; k < 2; k++)
+      for (int k = 0; k < NH; k++)
         if (sg[k] != 0.0) {
           double jv = sg[k] * sr[3 + k], r = jar[k] + alpha * jv;
           if (r < 0.0) { d1 += D[k] * r * jv; d2 += D[k] * jv * jv; }
@@ -217,36 +231,40 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
       if (fabs(next - alpha) <= 1e-15 * fabs(next)) { alpha = next; break; }
       alpha = next;
     }
-    for (int i = 0; i < 5; i++) qacc[i] += alpha * sr[i];
+    for (int i = 0; i < NV; i++) qacc[i] += alpha * sr[i];
   }
   return status;
 }
 
 // One MazeEnv.step: q, v in/out (fp64 working copy); info4 = x, y, reward_forward, reward_ctrl
+template <int NL>
 MZS_HD int swimmer_env_step(const SwimmerDev& P, double* q, double* v, const double* action, int t_in, double* inner_reward,
                             double* info4, int* t_out) {
   int status = 0;
   double x0 = q[0], y0 = q[1];
-  double tau[2];
-  for (int k = 0; k < 2; k++) tau[k] = P.gear * fmin(fmax(action[k], P.ctrl_lo), P.ctrl_hi);
+  constexpr int NV = NL + 2, NH = NL - 1;
+  double tau[NH];
+  for (int k = 0; k < NH; k++) tau[k] = P.gear * fmin(fmax(action[k], P.ctrl_lo), P.ctrl_hi);
   for (int f = 0; f < P.frame_skip; f++) {
     const double h = P.h;
-    double q0[5], v0[5], accv[5], accf[5], qs[5], vs[5], a[5];
-    for (int k = 0; k < 5; k++) { q0[k] = q[k]; v0[k] = v[k]; accv[k] = 0.0; accf[k] = 0.0; qs[k] = q[k]; vs[k] = v[k]; }
+    double q0[NV], v0[NV], accv[NV], accf[NV], qs[NV], vs[NV], a[NV];
+    for (int k = 0; k < NV; k++) { q0[k] = q[k]; v0[k] = v[k]; accv[k] = 0.0; accf[k] = 0.0; qs[k] = q[k]; vs[k] = v[k]; }
     for (int st = 0; st < 4; st++) {
-      status |= swimmer_forward(P, qs, vs, tau, a);
+      status |= swimmer_forward<NL>(P, qs, vs, tau, a);
       double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
-      for (int k = 0; k < 5; k++) {
+      for (int k = 0; k < NV; k++) {
         accv[k] += bw * vs[k]; accf[k] += bw * a[k];
         double nq = q0[k] + h * (aw * vs[k]), nv = v0[k] + h * (aw * a[k]);
         qs[k] = nq; vs[k] = nv;
       }
     }
-    for (int k = 0; k < 5; k++) { q[k] = q0[k] + h * accv[k]; v[k] = v0[k] + h * accf[k]; }
+    for (int k = 0; k < NV; k++) { q[k] = q0[k] + h * accv[k]; v[k] = v0[k] + h * accf[k]; }
   }
   double dt = P.h * P.frame_skip;
   double vx = (q[0] - x0) / dt, vy = (q[1] - y0) / dt;
-  double fwd = sqrt(vx * vx + vy * vy), cc = P.task.ctrl_w * (action[0] * action[0] + action[1] * action[1]);
+  double fwd = sqrt(vx * vx + vy * vy), cc = 0.0;
+  for (int k = 0; k < NH; k++) cc += action[k] * action[k];
+  cc *= P.task.ctrl_w;
   *inner_reward = P.task.fwd_w * fwd - cc;
   info4[0] = q[0]; info4[1] = q[1]; info4[2] = fwd; info4[3] = -cc;
   *t_out = t_in + 1;

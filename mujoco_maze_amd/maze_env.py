@@ -51,7 +51,7 @@ class VecMazeEnv:
         self.num_envs = int(num_envs)
         self._task = maze_task(maze_size_scaling, **(task_kwargs or {}))
         robot = getattr(model_cls, "ROBOT", None)
-        if robot not in ("ant", "point", "swimmer"):
+        if robot not in ("ant", "point", "swimmer", "reacher"):
             raise NotImplementedError(f"robot {model_cls.__name__} has no device kernel yet (SURVEY §8f)")
         self.model: CompiledModel = compile_model(
             robot, self._task, maze_size_scaling, inner_reward_scaling=inner_reward_scaling,

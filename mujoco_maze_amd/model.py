@@ -76,7 +76,7 @@ class MzModel(C.Structure):
     ]
 
 
-ROBOT_ID = {"point": 0, "ant": 1, "swimmer": 2}
+ROBOT_ID = {"point": 0, "ant": 1, "swimmer": 2, "reacher": 2}  # the Reacher is the 2-link member of the swimmer family
 RESET_KIND = {"normal": 0, "uniform01": 1, "uniform_sym": 2}
 CELL_CODE = {MazeCell.EMPTY: 0, MazeCell.BLOCK: 1, MazeCell.CHASM: 2, MazeCell.ROBOT: 255}
 

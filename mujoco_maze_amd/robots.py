@@ -168,7 +168,15 @@ def _swimmer() -> RobotSpec:
                      collision_predefined=True, reset_qvel="uniform_sym")
 
 
-ROBOTS = {"ant": _ant, "point": _point, "swimmer": _swimmer}
+def _reacher() -> RobotSpec:
+    """assets/reacher.xml:1-36 (`<mujoco model="swimmer">`): the swimmer's first two links, one motor on `rot2`."""
+    sw = _swimmer()
+    return RobotSpec("reacher", sw.bodies[:2], sw.actuators[:1], sw.floor, sw.wall_geom_defaults,
+                     timestep=0.01, frame_skip=4, nq_robot=4, nv_robot=4, density=4000.0, viscosity=0.1,
+                     collision_predefined=True, reset_qvel="uniform_sym")
+
+
+ROBOTS = {"ant": _ant, "point": _point, "swimmer": _swimmer, "reacher": _reacher}
 
 
 def robot_spec(name: str) -> RobotSpec:

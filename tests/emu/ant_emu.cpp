@@ -143,24 +143,23 @@ extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* 
 // ---------------------------------------------------------------- Swimmer: the per-lane step function of swimmer_step_kernel
 #include "../../mujoco_maze_amd/csrc/swimmer_dyn.h"
 
-extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
-                                    float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
-  SwimmerDev P;
-  char err[128];
-  int rc = swimmer_dev_from_model(&P, m, err, sizeof(err));
-  if (rc != MZ_OK) return rc;
+template <int NL>
+static int swimmer_env_step_t(const SwimmerDev& P, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
+                              float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
+  constexpr int NV = NL + 2, NH = NL - 1, NO = 2 * NV + 1;
   for (int e = 0; e < n; e++) {
-    double q[5], v[5], a[2] = {(double)actions[2 * e], (double)actions[2 * e + 1]}, inner, inf4[4];
-    for (int k = 0; k < 5; k++) { q[k] = (double)qpos[5 * e + k]; v[k] = (double)qvel[5 * e + k]; }
+    double q[NV], v[NV], a[NH], inner, inf4[4];
+    for (int k = 0; k < NH; k++) a[k] = (double)actions[NH * e + k];
+    for (int k = 0; k < NV; k++) { q[k] = (double)qpos[NV * e + k]; v[k] = (double)qvel[NV * e + k]; }
     int t_new;
-    int st = swimmer_env_step(P, q, v, a, t[e], &inner, inf4, &t_new);
-    float o[11];
-    for (int k = 0; k < 5; k++) { o[k] = (float)q[k]; o[5 + k] = (float)v[k]; }
-    o[10] = (float)t_new * 0.001f;
+    int st = swimmer_env_step<NL>(P, q, v, a, t[e], &inner, inf4, &t_new);
+    float o[NO];
+    for (int k = 0; k < NV; k++) { o[k] = (float)q[k]; o[NV + k] = (float)v[k]; }
+    o[2 * NV] = (float)t_new * 0.001f;
     float outer; int tm, gi;
     task_eval_dev(P.task, o, &outer, &tm, &gi);
-    for (int k = 0; k < 11; k++) obs[11 * e + k] = o[k];
-    for (int k = 0; k < 5; k++) { qpos[5 * e + k] = o[k]; qvel[5 * e + k] = o[5 + k]; }
+    for (int k = 0; k < NO; k++) obs[NO * e + k] = o[k];
+    for (int k = 0; k < NV; k++) { qpos[NV * e + k] = o[k]; qvel[NV * e + k] = o[NV + k]; }
     reward[e] = (float)(P.task.inner_scale * inner) + outer;
     done[e] = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
     if (goal_idx) goal_idx[e] = gi;
@@ -169,4 +168,14 @@ extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float
     t[e] = t_new;
   }
   return MZ_OK;
+}
+
+extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
+                                    float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
+  SwimmerDev P;
+  char err[128];
+  int rc = swimmer_dev_from_model(&P, m, err, sizeof(err));
+  if (rc != MZ_OK) return rc;
+  if (P.nlink == 3) return swimmer_env_step_t<3>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
+  return swimmer_env_step_t<2>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
 }

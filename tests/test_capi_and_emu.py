@@ -227,31 +227,34 @@ def test_point_step_logic_with_mujoco_wall_contacts(oracle):
     assert gave_up.sum() > 20  # the give-up branch of the manual bounce is exercised
 
 
-def test_swimmer_step_logic(oracle):
-    """Swimmer (north_star): the kernel's planar closed-form dynamics (3-link chain, inertia-box
-    fluid forces, motor gear 150 with ctrl clamp, +-100 deg limits, RK4 x 4 frames) against the oracle's general
-    rigid-body path — two independent formulations of the same model."""
+@pytest.mark.parametrize("robot,nq", [("swimmer", 5), ("reacher", 4)])
+def test_swimmer_step_logic(oracle, robot, nq):
+    """Swimmer (north_star) and Reacher (its 2-link variant, reacher.py / reacher.xml): the kernel's
+    planar closed-form dynamics (link chain, inertia-box fluid forces, motor gear 150 with ctrl clamp, +-100 deg
+    limits, RK4 x 4 frames) against the oracle's general rigid-body path — two independent formulations of the
+    same model."""
     from tests import emu_lib
 
-    cm = model.compile_model("swimmer", T.DistRewardUMaze(4.0), 4.0)
-    assert cm.c.obs_dim == 11 and cm.c.nq == 5 and cm.c.nu == 2 and cm.c.frame_skip == 4  # tests/test_envs.py:77-78
+    cm = model.compile_model(robot, T.DistRewardUMaze(4.0), 4.0)
+    nu = nq - 3
+    assert cm.c.obs_dim == 2 * nq + 1 and cm.c.nq == nq and cm.c.nu == nu and cm.c.frame_skip == 4  # tests/test_envs.py:77-78
     n = 512
     st, obs0 = oracle.reset(cm, n, 3)
-    assert np.all(np.abs(obs0[:, :10]) <= 0.1 + 1e-12)  # swimmer.py:55-66: U(-.1,.1) on qpos and qvel
+    assert np.all(np.abs(obs0[:, :2 * nq]) <= 0.1 + 1e-12)  # swimmer.py:55-66 / reacher.py:58-72: U(-.1,.1) on qpos and qvel
     rng = np.random.default_rng(0)
-    st["qpos"][:, 3:5] = rng.uniform(-1.9, 1.9, (n, 2))  # beyond the +-100 deg limits for some envs
-    st["qvel"] = rng.normal(size=(n, 5)) * 2
+    st["qpos"][:, 3:] = rng.uniform(-1.9, 1.9, (n, nu))  # beyond the +-100 deg limits for some envs
+    st["qvel"] = rng.normal(size=(n, nq)) * 2
     hit_limit = 0
     for k in range(21):
-        act = rng.uniform(-1.5, 1.5, (n, 2)).astype(np.float32)  # outside the ctrl range too
+        act = rng.uniform(-1.5, 1.5, (n, nu)).astype(np.float32)  # outside the ctrl range too
         if k in (0, 5, 20):
             s64 = _f32(st)
             s32 = dict(qpos=s64["qpos"].astype(np.float32), qvel=s64["qvel"].astype(np.float32), t=s64["t"].copy())
-            hit_limit += int((np.abs(s64["qpos"][:, 3:5]) > np.radians(100)).any(1).sum())
+            hit_limit += int((np.abs(s64["qpos"][:, 3:]) > np.radians(100)).any(1).sum())
             ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             re_ = emu_lib.swimmer_env_step(cm, s32, act)
             assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 1e-6 + 2e-7 * np.abs(ro["obs"]))
             assert np.abs(re_["reward"] - ro["reward"]).max() < 1e-7 and np.abs(re_["info"] - ro["info"]).max() < 1e-6
             assert np.array_equal(re_["done"], ro["done"]) and np.all(re_["status"] == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
-    assert hit_limit > 100
+    assert hit_limit > 50 * nu

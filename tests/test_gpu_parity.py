@@ -287,17 +287,20 @@ def test_point_step_parity_and_bounce(torch, oracle):
     env.close()
 
 
-def test_swimmer_step_parity(torch, oracle):
+@pytest.mark.parametrize("robot,nq", [("Swimmer", 5), ("Reacher", 4)])
+def test_swimmer_step_parity(torch, oracle, robot, nq):
+    """Swimmer and its 2-link variant, the Reacher (reacher.py / reacher.xml), on the planar-chain kernels."""
     n = 4096
-    env = mm.make("SwimmerUMaze-v0", num_envs=n)
+    env = mm.make(f"{robot}UMaze-v0", num_envs=n)
     cm = env.model
-    assert env.obs_dim == 11
+    nu = nq - 3
+    assert env.obs_dim == 2 * nq + 1 and env.nu == nu
     st, _ = oracle.reset(cm, n, 3)
     rng = np.random.default_rng(0)
-    st["qpos"][:, 3:5] = rng.uniform(-1.9, 1.9, (n, 2))
-    st["qvel"] = rng.normal(size=(n, 5)) * 2
+    st["qpos"][:, 3:] = rng.uniform(-1.9, 1.9, (n, nu))
+    st["qvel"] = rng.normal(size=(n, nq)) * 2
     for k in range(6):
-        act = rng.uniform(-1.5, 1.5, (n, 2)).astype(np.float32)
+        act = rng.uniform(-1.5, 1.5, (n, nu)).astype(np.float32)
         if k in (0, 5):
             s64 = _f32(st)
             env.set_state(s64["qpos"], s64["qvel"], None, s64["t"])
@@ -310,10 +313,10 @@ def test_swimmer_step_parity(torch, oracle):
             assert np.all(env.status().cpu().numpy() == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     env.close()
-    single = mm.make("SwimmerSquareRoom-v1")
+    single = mm.make(f"{robot}SquareRoom-v1")
     s0, _ = single.reset()
     s, r, d, inf = single.step(single.action_space.sample(np.random.default_rng(1)))
-    assert s0.shape == (11,) and s.shape == (11,)  # reference tests/test_envs.py:77-78
+    assert s0.shape == (2 * nq + 1,) and s.shape == (2 * nq + 1,)  # reference tests/test_envs.py:77-78 (swimmer: 11)
     single.close()
 
 
