@@ -4,22 +4,23 @@ import csv, glob, os, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs(f"profiles/{tag}", exist_ok=True)
-lines = [f"# rocprofv3 summary — {tag}", "", "command: `python bench.py --no-cpu-baseline` (= the default bench run: 100 warm-up + 200 timed steps) (AntUMaze-v0, 4096 envs, 1 x MI355X)", ""]
+lines = [f"# rocprofv3 summary — {tag}", "", "command: `python bench.py --no-cpu-baseline` (= the default bench run: 100 warm-up + 1000 timed steps) (AntUMaze-v0, 4096 envs, 1 x MI355X)", ""]
 for f in glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True):
     lines += ["## kernel stats (`rocprofv3 --kernel-trace --stats`)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(f)):
         name = r["Name"].split("(")[0][:60]
         lines.append(f"| {name} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     lines.append("")
-# the bench line times the LAST 200 launches (after 100 warm-up steps): same window from the kernel trace
+# the bench line times the launches after the 100 warm-up steps: same window from the kernel trace
+WARM = 100
 for f in glob.glob(f"{src}/stats/**/*kernel_trace.csv", recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if "ant_step_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-    if len(dur) >= 200:
-        timed = dur[-200:]
-        lines += [f"`ant_step_kernel` over the timed window (last 200 of {len(dur)} launches): avg **{sum(timed)/len(timed):.1f} us** "
-                  f"(min {min(timed):.1f}, max {max(timed):.1f}); warm-up launches avg {sum(dur[:-200])/max(1,len(dur)-200):.1f} us "
+    if len(dur) > WARM:
+        timed = dur[WARM:]
+        lines += [f"`ant_step_kernel` over the timed window (launches {WARM + 1}..{len(dur)}): avg **{sum(timed)/len(timed):.1f} us** "
+                  f"(min {min(timed):.1f}, max {max(timed):.1f}); warm-up launches avg {sum(dur[:WARM])/WARM:.1f} us "
                   "(early in the rollout the ants are still airborne / settling: fewer contacts).", ""]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{src}/pmc_*/**/*counter_collection.csv", recursive=True):
