@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup (1/2/4); 0 = library default")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL obs all-gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="extra library option key=value (tuning experiments)")
     args = ap.parse_args()
 
     import torch
@@ -140,6 +141,9 @@ def main():
         env.set_option("lanes_per_env", args.lanes)
     if args.wpb:
         env.set_option("waves_per_block", args.wpb)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        env.set_option(k, float(v))
     from mujoco_maze_amd import sharding
 
     lo, _ = sharding.shard_range(rank, world, n)
