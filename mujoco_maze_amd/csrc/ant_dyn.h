@@ -52,6 +52,7 @@ struct HostCtx {
   MZ_HD int lane0() const { return 0; }
   MZ_HD void sync() const {}
   MZ_HD float gsum(float x) const { return x; }
+  MZ_HD double gsum(double x) const { return x; }
   MZ_HD bool any(bool p) const { return p; }
   MZ_HD bool gany(bool p) const { return p; }
   template <class S> MZ_HD void tick(S&, int) const {}

@@ -6,7 +6,7 @@
 //                        set (7.7 KB, AntScratch) resident in LDS across the 20 forward-
 //                        dynamics evaluations of the step; HBM is touched once per step
 //                        (192-B state record in, record + obs/reward/done out).
-//   point_step_kernel    one MazeEnv.step for the Point: one env per lane, SoA state.
+//   planar_step_kernel   one MazeEnv.step for the Point (+ movable blocks): lane group per env, SoA state.
 //   *_reset / state copy / debug kernels.
 //
 // Data layout in HBM
@@ -26,6 +26,7 @@
 
 #include "ant_dyn.h"
 #include "point_dyn.h"
+#include "planar_dyn.h"
 #include "swimmer_dyn.h"
 
 
@@ -73,6 +74,11 @@ struct DevCtx {
     if constexpr (G >= 16) x = dpp_add(x, 3);
     if constexpr (G >= 32) x += __shfl_xor(x, 16, 64);
     if constexpr (G >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+  }
+  __device__ __forceinline__ double gsum(double x) const {  // fp64 paths (Point): plain butterfly
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) x += __shfl_xor(x, o, 64);
     return x;
   }
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
@@ -293,61 +299,94 @@ __global__ void ant_get_state_kernel(AntLayout L, int n, const float* state, flo
 // ------------------------------------------------------------------ Point kernels (SoA: q0 q1 q2 v0 v1 v2 | t | episode)
 struct PointState { float* qv; int* t; uint32_t* ep; };
 
-__global__ __launch_bounds__(256) void point_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
+// One MazeEnv.step of the Point (+ NB movable blocks): G lanes per env, PlanarScratch in LDS, SoA state in HBM
+// (q_0..q_{NV-1} | v_0..v_{NV-1}, each [n]).
+template <int NB, int G>
+__global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
                                                           const float* __restrict__ actions, float* __restrict__ obs,
                                                           float* __restrict__ reward, uint8_t* __restrict__ done,
                                                           int* __restrict__ goal_idx, float* __restrict__ info,
                                                           int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0) {
+  using D = PlanarDims<NB>;
+  constexpr int NV = D::NV, NOBS = D::NOBS, EPW = 64 / G;
   __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
+  __shared__ PlanarScratch<NB> scr[EPW];
+  __shared__ float obuf[EPW][MZ_MAX_OBS];
   for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
   __syncthreads();
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= n) return;
-  double q[3], v[3], a[2];
-  for (int k = 0; k < 3; k++) { q[k] = (double)S.qv[(size_t)k * n + env]; v[k] = (double)S.qv[(size_t)(3 + k) * n + env]; }
-  a[0] = (double)actions[(size_t)env * 2]; a[1] = (double)actions[(size_t)env * 2 + 1];
-  int t_new;
-  int st = point_env_step(P, q, v, a, S.t[env], nullptr, nullptr, nullptr, nullptr, nullptr, &t_new);
-  float o[7];
-  for (int k = 0; k < 3; k++) { o[k] = (float)q[k]; o[3 + k] = (float)v[k]; }
-  o[6] = (float)t_new * 0.001f;
+  DevCtx<G> cx{(int)threadIdx.x % G};
+  const int grp = threadIdx.x / G;
+  int env = blockIdx.x * EPW + grp;
+  const bool live = env < n;
+  if (!live) env = n - 1;  // idle groups shadow the last env (no stores) so that every lane reaches the wave-level votes
+  PlanarScratch<NB>& s = scr[grp];
+  for (int k = cx.l; k < NV; k += G) { s.q[k] = (double)S.qv[(size_t)k * n + env]; s.v[k] = (double)S.qv[(size_t)(NV + k) * n + env]; }
+  double a[2] = {(double)actions[(size_t)env * 2], (double)actions[(size_t)env * 2 + 1]};
+  const int t_new = S.t[env] + 1;
+  cx.sync();
+  planar_env_step<NB>(cx, P, s, a);
+  float* o = obuf[grp];
+  for (int i = cx.l; i < NOBS; i += G) o[i] = planar_obs_elem<NB>(P, s, i, t_new);
+  cx.sync();
   float outer; int tm, gi;
   task_eval_dev(P.task, o, &outer, &tm, &gi);  // flags from the fp32 observation that is returned
-  uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
-  for (int k = 0; k < 7; k++) obs[(size_t)env * 7 + k] = o[k];
-  reward[env] = outer;  // Point inner reward is 0.0 (point.py:61)
-  done[env] = d;
-  if (goal_idx) goal_idx[env] = gi;
-  if (info) { info[(size_t)env * 4] = o[0]; info[(size_t)env * 4 + 1] = o[1]; info[(size_t)env * 4 + 2] = 0.f; info[(size_t)env * 4 + 3] = 0.f; }
-  if (st) atomicOr(&status[env], st);
-  uint32_t ep = S.ep[env];
-  if (auto_reset && d) {
-    ep += 1;
-    uint64_t es = episode_seed(seed, ep);
-    for (int k = 0; k < 3; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k); o[3 + k] = reset_qvel(P.reset_kind, 3, es, env0 + (uint64_t)env, k); }
-    t_new = 0;
+  const uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
+  if (live) {
+    for (int i = cx.l; i < NOBS; i += G) obs[(size_t)env * NOBS + i] = o[i];
+    if (cx.l == 0) {
+      reward[env] = outer;  // Point inner reward is 0.0 (point.py:61)
+      done[env] = d;
+      if (goal_idx) goal_idx[env] = gi;
+      if (info) { info[(size_t)env * 4] = o[0]; info[(size_t)env * 4 + 1] = o[1]; info[(size_t)env * 4 + 2] = 0.f; info[(size_t)env * 4 + 3] = 0.f; }
+      int st = s.status;
+      bool badv = false;
+      for (int k = 0; k < NV; k++) badv = badv || !(fabs(s.q[k]) < 1e10) || !(fabs(s.v[k]) < 1e10);
+      if (badv) st |= MZ_STATUS_BAD_STATE;
+      if (st) atomicOr(&status[env], st);
+    }
+    uint32_t ep = S.ep[env];
+    const bool rst = auto_reset && d;
+    if (rst) ep += 1;
+    const uint64_t es = episode_seed(seed, ep);
+    for (int k = cx.l; k < NV; k += G) {
+      float qk = (float)s.q[k], vk = (float)s.v[k];
+      if (rst) {  // point.py:71-81: noise on the robot, blocks back to their spawn state
+        qk = k < 3 ? reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k) : 0.f;
+        vk = k < 3 ? reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k) : 0.f;
+      }
+      S.qv[(size_t)k * n + env] = qk;
+      S.qv[(size_t)(NV + k) * n + env] = vk;
+    }
+    if (cx.l == 0) { S.t[env] = rst ? 0 : t_new; S.ep[env] = ep; }
   }
-  for (int k = 0; k < 6; k++) S.qv[(size_t)k * n + env] = o[k];
-  S.t[env] = t_new;
-  S.ep[env] = ep;
 }
 
+template <int NB>
 __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+  constexpr int NV = 3 + 2 * NB, NOBS = 7 + 3 * NB;
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   if (!mask || mask[env]) {
-    for (int k = 0; k < 3; k++) {
-      S.qv[(size_t)k * n + env] = reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k);
-      S.qv[(size_t)(3 + k) * n + env] = reset_qvel(Pp->reset_kind, 3, seed, env0 + (uint64_t)env, k);
+    for (int k = 0; k < NV; k++) {
+      S.qv[(size_t)k * n + env] = k < 3 ? reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k) : 0.f;
+      S.qv[(size_t)(NV + k) * n + env] = k < 3 ? reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k) : 0.f;
     }
     S.t[env] = 0;
     S.ep[env] = 0;
   }
   if (obs) {
-    for (int k = 0; k < 6; k++) obs[(size_t)env * 7 + k] = S.qv[(size_t)k * n + env];
-    obs[(size_t)env * 7 + 6] = (float)S.t[env] * 0.001f;
+    const int nb3 = Pp->observe_blocks ? 3 * NB : 0;
+    float* o = obs + (size_t)env * NOBS;
+    for (int k = 0; k < 3; k++) { o[k] = S.qv[(size_t)k * n + env]; o[3 + nb3 + k] = S.qv[(size_t)(NV + k) * n + env]; }
+    for (int b = 0; b < NB && nb3; b++) {
+      o[3 + 3 * b] = (float)Pp->block_pos0[b][0] + S.qv[(size_t)(3 + 2 * b) * n + env];
+      o[4 + 3 * b] = (float)Pp->block_pos0[b][1] + S.qv[(size_t)(4 + 2 * b) * n + env];
+      o[5 + 3 * b] = (float)Pp->block_pos0[b][2];
+    }
+    o[6 + nb3] = (float)S.t[env] * 0.001f;
   }
 }
+
 template <int KQ>
 __global__ void point_set_state_kernel(int n, PointState S, const float* qpos, const float* qvel, const int* t) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -562,7 +601,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     if (e == hipSuccess) e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3 + 2 * h->point.nblock;
     e = hipMalloc(&h->state, (size_t)num_envs * 2 * kq * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
@@ -658,7 +697,12 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
     else hipLaunchKernelGGL(swimmer_reset_kernel<2>, dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    hipLaunchKernelGGL(point_reset_kernel, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+    switch (h->point.nblock) {
+      case 0: hipLaunchKernelGGL(point_reset_kernel<0>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+      case 1: hipLaunchKernelGGL(point_reset_kernel<1>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+      case 2: hipLaunchKernelGGL(point_reset_kernel<2>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+      default: hipLaunchKernelGGL(point_reset_kernel<3>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+    }
   }
   HIPCHK(h, hipGetLastError());
   return MZ_OK;
@@ -673,12 +717,15 @@ int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev,
     hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    if (h->robot == MZ_ROBOT_SWIMMER && h->swimmer.nlink == 3)
-      hipLaunchKernelGGL(point_set_state_kernel<5>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
-    else if (h->robot == MZ_ROBOT_SWIMMER)
-      hipLaunchKernelGGL(point_set_state_kernel<4>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
-    else
-      hipLaunchKernelGGL(point_set_state_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, t_dev);
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3 + 2 * h->point.nblock;
+    const dim3 grid((h->n + 255) / 256), blk(256);
+    switch (kq) {
+      case 3: hipLaunchKernelGGL(point_set_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+      case 4: hipLaunchKernelGGL(point_set_state_kernel<4>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+      case 5: hipLaunchKernelGGL(point_set_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+      case 7: hipLaunchKernelGGL(point_set_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+      default: hipLaunchKernelGGL(point_set_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+    }
   }
   HIPCHK(h, hipGetLastError());
   return MZ_OK;
@@ -692,12 +739,15 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
     hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    if (h->robot == MZ_ROBOT_SWIMMER && h->swimmer.nlink == 3)
-      hipLaunchKernelGGL(point_get_state_kernel<5>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
-    else if (h->robot == MZ_ROBOT_SWIMMER)
-      hipLaunchKernelGGL(point_get_state_kernel<4>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
-    else
-      hipLaunchKernelGGL(point_get_state_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev);
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3 + 2 * h->point.nblock;
+    const dim3 grid((h->n + 255) / 256), blk(256);
+    switch (kq) {
+      case 3: hipLaunchKernelGGL(point_get_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+      case 4: hipLaunchKernelGGL(point_get_state_kernel<4>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+      case 5: hipLaunchKernelGGL(point_get_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+      case 7: hipLaunchKernelGGL(point_get_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+      default: hipLaunchKernelGGL(point_get_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+    }
   }
   HIPCHK(h, hipGetLastError());
   return MZ_OK;
@@ -729,8 +779,17 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
                          reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    hipLaunchKernelGGL(point_step_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->point_dev, h->n, S, actions_dev, obs_dev,
-                       reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
+    // lanes per env: 16 for the bare robot (18 collision enumerators), 32 / 64 with blocks (bigger contact sets in LDS)
+#define MZ_PLANAR_LAUNCH(NB, G)                                                                                                     \
+  hipLaunchKernelGGL((planar_step_kernel<NB, G>), dim3((h->n + 64 / G - 1) / (64 / G)), dim3(64), 0, st, h->point_dev, h->n, S, actions_dev, \
+                     obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0)
+    switch (h->point.nblock) {
+      case 0: MZ_PLANAR_LAUNCH(0, 16); break;
+      case 1: MZ_PLANAR_LAUNCH(1, 32); break;
+      case 2: MZ_PLANAR_LAUNCH(2, 64); break;
+      default: MZ_PLANAR_LAUNCH(3, 64); break;
+    }
+#undef MZ_PLANAR_LAUNCH
   }
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) { HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st)); h->itime++; }

@@ -1,0 +1,491 @@
+// planar_dyn.h — the Point robot's MazeEnv.step with NB movable XY blocks, as lane-group SPMD code (fp64).
+//
+// Same programming model as ant_dyn.h: G lanes advance one environment, its working set (PlanarScratch<NB>) lives
+// in LDS for the whole step, a phase is an MZ_FOR over independent items, cx.sync() is the hand-off.  The
+// single-lane host context (tests/emu) runs the same source on the CPU.
+//
+// Replaces, per env: PointEnv.step (mujoco_maze/point.py:44-61), the MuJoCo step behind it on the planar
+// system  q = (x, y, theta | bx_0, by_0 | ...)  — robot: slide-slide-hinge body with COM offset (point.xml:21-25);
+// blocks: slide-x + slide-y boxes (maze_env.py:563-660) — and the manual wall bounce of MazeEnv.step
+// (maze_env.py:451-464).  Dynamics per forward evaluation (4 per env.step: RK4, frame_skip 1):
+//   * unconstrained acceleration in closed form (robot: centripetal term of the COM offset; blocks: none);
+//   * collision by enumerators spread over the lanes (two passes: count, fill — no atomics):
+//       sphere / arrow vs the 3 x 3 wall cells around the robot, sphere / arrow vs each block,
+//       each block vs the 3 x 3 wall cells around it, block vs block;
+//     every geom margin of the Point model is 0, so a contact exists only under penetration (dist < 0);
+//     the floor touches sphere and blocks at dist = 0 exactly (z is not a degree of freedom): never a contact;
+//   * contacts as 3 x NV Jacobians [n; mu t1; mu t2] (pyramid edges u0 +- u1, u0 +- u2), dense NV x NV Newton
+//     with exact line search, Cholesky by one lane — same cost model and stopping rule as the one-lane code
+//     this replaces.
+#pragma once
+#include "ant_dyn.h"    // MZ_FOR, HostCtx, maze_row
+#include "point_dyn.h"  // PointDev, point_detect, pt_impedance
+
+template <int NB>
+struct PlanarDims {
+  static constexpr int NV = 3 + 2 * NB;
+  static constexpr int NC = NB == 0 ? 12 : (NB == 1 ? 40 : (NB == 2 ? 64 : 96));  // contact slots
+  // enumerators: 9 sphere-wall, 9 arrow-wall | per block: sphere-block, arrow-block, 9 block-wall | block pairs
+  static constexpr int NE = 18 + 11 * NB + NB * (NB - 1) / 2;
+  static constexpr int NOBS = 7 + 3 * NB;
+};
+
+template <int NB>
+struct alignas(16) PlanarScratch {
+  using D = PlanarDims<NB>;
+  double q[D::NV], v[D::NV];  // state of the current RK4 stage
+  double x0[D::NV], v0[D::NV], accv[D::NV], accf[D::NV];
+  double qas[D::NV], qacc[D::NV], grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
+  double M3[3][3];            // robot block of the mass matrix (blocks: block_mass on the diagonal)
+  double H[D::NV][D::NV];
+  double cJ[D::NC][3][D::NV], caref[D::NC][3], cD[D::NC], cu[D::NC][3], cg[D::NC][3], cW[D::NC][5], cjv[D::NC][3];
+  double co, si;              // cos / sin of the heading of the current stage
+  int ncon, cnt[D::NE], cbeg[D::NE], status, robot_near;
+};
+
+// ---- small helpers
+MZP_HD double pl_mass(const PointDev& P, const double M3[3][3], int i, int j) {
+  if (i < 3 && j < 3) return M3[i][j];
+  return i == j ? P.block_mass : 0.0;
+}
+template <int NB>
+MZP_HD void pl_block_center(const PointDev& P, const PlanarScratch<NB>& s, int b, double* c) {
+  c[0] = P.block_pos0[b][0] + s.q[3 + 2 * b]; c[1] = P.block_pos0[b][1] + s.q[4 + 2 * b]; c[2] = P.block_pos0[b][2];
+}
+
+// One contact candidate: dist, position, normal (geom1 -> geom2), bodies (-1 world, 0 robot, 1 + k block k)
+struct PlContact { double dist, pos[3], n[3]; int b1, b2, cls; };
+
+// sphere (centre c relative to the box centre) vs axis-aligned box; normal from the sphere to the box
+MZP_HD bool pl_sphere_box(const double* c, double r, const double* hb, double margin, double* dist, double* nrm) {
+  double cl[3], dd;
+  bool inside = true;
+  for (int k = 0; k < 3; k++) { cl[k] = fmin(fmax(c[k], -hb[k]), hb[k]); if (cl[k] != c[k]) inside = false; }
+  if (!inside) {
+    double w[3] = {cl[0] - c[0], cl[1] - c[1], cl[2] - c[2]};
+    dd = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (dd - r > margin) return false;
+    for (int k = 0; k < 3; k++) nrm[k] = w[k] / dd;
+    dd -= r;
+  } else {
+    int kb = 0; double best = 1e30;
+    for (int k = 0; k < 3; k++) { double e = hb[k] - fabs(c[k]); if (e < best) { best = e; kb = k; } }
+    nrm[0] = nrm[1] = nrm[2] = 0.0;
+    double sg = (kb == 0 ? c[0] : (kb == 1 ? c[1] : c[2])) >= 0.0 ? -1.0 : 1.0;
+    if (kb == 0) nrm[0] = sg; else if (kb == 1) nrm[1] = sg; else nrm[2] = sg;
+    dd = -best - r;
+  }
+  *dist = dd;
+  return true;
+}
+
+// z-rotated box (the arrow: centre bc, axes ex / ey, half sizes ahx / ahy, height az) vs an axis-aligned box (centre
+// wc, half sizes wh) [ASSUME-13]; `flip`: report the normal from the arrow to the box (movable block = geom2)
+template <class Emit>
+MZP_HD void pl_arrow_box(const PointDev& P, const double* bc, double co, double si, const double* wc, const double* wh, double margin,
+                         bool flip, int b1, int b2, int cls, Emit&& emit) {
+  if (fabs(P.arr_z - wc[2]) > P.arr_hz + wh[2] + margin) return;
+  double ex[2] = {co, si}, ey[2] = {-si, co}, dx = bc[0] - wc[0], dy = bc[1] - wc[1];
+  int best = -1; double bestsep = -1e30, bestsign = 1.0;
+  for (int a = 0; a < 4; a++) {
+    double nx = a == 0 ? 1.0 : (a == 1 ? 0.0 : (a == 2 ? ex[0] : ey[0])), ny = a == 0 ? 0.0 : (a == 1 ? 1.0 : (a == 2 ? ex[1] : ey[1]));
+    double proj = dx * nx + dy * ny;
+    double ra = wh[0] * fabs(nx) + wh[1] * fabs(ny);
+    double rb = P.arr_hx * fabs(ex[0] * nx + ex[1] * ny) + P.arr_hy * fabs(ey[0] * nx + ey[1] * ny);
+    double sep = fabs(proj) - (ra + rb);
+    if (sep > bestsep) { bestsep = sep; best = a; bestsign = proj >= 0.0 ? 1.0 : -1.0; }
+  }
+  if (bestsep > margin) return;
+  double nx = best == 0 ? 1.0 : (best == 1 ? 0.0 : (best == 2 ? ex[0] : ey[0])), ny = best == 0 ? 0.0 : (best == 1 ? 1.0 : (best == 2 ? ex[1] : ey[1]));
+  double n[3] = {nx * bestsign, ny * bestsign, 0.0};  // box -> arrow
+  double vx[4], vy[4], dep[4], dmin = 1e30;
+  for (int k = 0; k < 4; k++) {
+    double sx = (k & 1) ? 1.0 : -1.0, sy = (k & 2) ? 1.0 : -1.0;
+    if (best < 2) {
+      vx[k] = bc[0] + sx * P.arr_hx * ex[0] + sy * P.arr_hy * ey[0];
+      vy[k] = bc[1] + sx * P.arr_hx * ex[1] + sy * P.arr_hy * ey[1];
+      dep[k] = (vx[k] - wc[0]) * n[0] + (vy[k] - wc[1]) * n[1] - (wh[0] * fabs(n[0]) + wh[1] * fabs(n[1]));
+    } else {
+      vx[k] = wc[0] + sx * wh[0];
+      vy[k] = wc[1] + sy * wh[1];
+      dep[k] = (bc[0] - vx[k]) * n[0] + (bc[1] - vy[k]) * n[1] - (best == 2 ? P.arr_hx : P.arr_hy);
+    }
+    if (dep[k] < dmin) dmin = dep[k];
+  }
+  for (int k = 0; k < 4; k++)
+    if (dep[k] <= dmin + 1e-9) {
+      double sg = best < 2 ? -0.5 : 0.5;
+      PlContact c;
+      c.dist = dep[k];
+      c.pos[0] = vx[k] + sg * n[0] * dep[k]; c.pos[1] = vy[k] + sg * n[1] * dep[k]; c.pos[2] = P.arr_z;
+      c.n[0] = flip ? -n[0] : n[0]; c.n[1] = flip ? -n[1] : n[1]; c.n[2] = 0.0;
+      c.b1 = b1; c.b2 = b2; c.cls = cls;
+      emit(c);
+    }
+}
+
+// axis-aligned box (geom1: centre c1, half h1) vs axis-aligned box (geom2: centre c2, half h2) [ASSUME-12]
+template <class Emit>
+MZP_HD void pl_box_box(const double* c1, const double* h1, const double* c2, const double* h2, double margin, int b1, int b2, int cls,
+                       Emit&& emit) {
+  double gap[3];
+  int ax = 0;
+  for (int k = 0; k < 3; k++) gap[k] = fabs(c2[k] - c1[k]) - (h1[k] + h2[k]);
+  if (gap[1] > gap[ax]) ax = 1;
+  if (gap[2] > gap[ax]) ax = 2;
+  double gmax = ax == 0 ? gap[0] : (ax == 1 ? gap[1] : gap[2]);
+  if (gmax > margin) return;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) { lo[k] = fmax(c1[k] - h1[k], c2[k] - h2[k]); hi[k] = fmin(c1[k] + h1[k], c2[k] + h2[k]); }
+  int u = (ax + 1) % 3, w = (ax + 2) % 3;
+  if (!(hi[u] - lo[u] > 1e-6) || !(hi[w] - lo[w] > 1e-6)) return;  // edge / corner touch: no face contact
+  double sg = c2[ax] >= c1[ax] ? 1.0 : -1.0;
+  for (int iu = 0; iu < 2; iu++)
+    for (int iw = 0; iw < 2; iw++) {
+      PlContact c;
+      c.dist = gmax;
+      for (int k = 0; k < 3; k++) c.n[k] = 0.0;
+      c.n[ax] = sg;
+      c.pos[ax] = c1[ax] + sg * (h1[ax] + 0.5 * gmax);
+      c.pos[u] = iu ? hi[u] : lo[u];
+      c.pos[w] = iw ? hi[w] : lo[w];
+      c.b1 = b1; c.b2 = b2; c.cls = cls;
+      emit(c);
+    }
+}
+
+// wall cell (di, dj) of the 3 x 3 neighbourhood of the cell under (x, y): centre in wc; false when not a BLOCK cell
+MZP_HD bool pl_wall_cell(const MazeDev& z, double x, double y, int k9, double* wc) {
+  int jc = (int)floor((x + z.tx) / z.scale + 0.5), ic = (int)floor((y + z.ty) / z.scale + 0.5);
+  int i = ic + k9 / 3 - 1, j = jc + k9 % 3 - 1;
+  if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) return false;
+  if (!((maze_row(z, i) >> j) & 1u)) return false;
+  wc[0] = j * (double)z.scale - z.tx; wc[1] = i * (double)z.scale - z.ty; wc[2] = z.center_z;
+  return true;
+}
+
+// Contacts of enumerator e, in a fixed order (identical in the count and the fill pass)
+template <int NB, class Emit>
+MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB>& s, int e, Emit&& emit) {
+  const MazeDev& z = P.maze;
+  double wh[3] = {z.half_xy, z.half_xy, z.half_z};
+  double arrow[2] = {s.q[0] + P.arr_off * s.co, s.q[1] + P.arr_off * s.si};
+  if (e < 18) {  // ---- robot vs wall cells
+    if (!s.robot_near) return;
+    double wc[3];
+    if (!pl_wall_cell(z, s.q[0], s.q[1], e % 9, wc)) return;
+    const PtPair& pr = P.pair[0];
+    if (e < 9) {  // sphere (geom1) vs wall (geom2)
+      double c[3] = {s.q[0] - wc[0], s.q[1] - wc[1], P.sph_z - wc[2]}, dd, nrm[3];
+      if (!pl_sphere_box(c, P.sph_r, wh, pr.margin, &dd, nrm)) return;
+      PlContact ct;
+      ct.dist = dd;
+      ct.pos[0] = s.q[0] + nrm[0] * (P.sph_r + 0.5 * dd); ct.pos[1] = s.q[1] + nrm[1] * (P.sph_r + 0.5 * dd); ct.pos[2] = P.sph_z + nrm[2] * (P.sph_r + 0.5 * dd);
+      for (int k = 0; k < 3; k++) ct.n[k] = nrm[k];
+      ct.b1 = 0; ct.b2 = -1; ct.cls = 0;
+      emit(ct);
+    } else {      // wall (geom1) vs arrow (geom2)
+      pl_arrow_box(P, arrow, s.co, s.si, wc, wh, pr.margin, false, -1, 0, 0, emit);
+    }
+    return;
+  }
+  if constexpr (NB > 0) {
+    int r = e - 18;
+    if (r < 11 * NB) {
+      int b = r / 11, k = r - 11 * b;
+      double bc[3];
+      pl_block_center<NB>(P, s, b, bc);
+      if (k == 0) {         // sphere (geom1) vs block (geom2)
+        const PtPair& pr = P.pair[1];
+        double c[3] = {s.q[0] - bc[0], s.q[1] - bc[1], P.sph_z - bc[2]}, dd, nrm[3];
+        if (!pl_sphere_box(c, P.sph_r, P.block_half, pr.margin, &dd, nrm)) return;
+        PlContact ct;
+        ct.dist = dd;
+        ct.pos[0] = s.q[0] + nrm[0] * (P.sph_r + 0.5 * dd); ct.pos[1] = s.q[1] + nrm[1] * (P.sph_r + 0.5 * dd); ct.pos[2] = P.sph_z + nrm[2] * (P.sph_r + 0.5 * dd);
+        for (int q = 0; q < 3; q++) ct.n[q] = nrm[q];
+        ct.b1 = 0; ct.b2 = 1 + b; ct.cls = 1;
+        emit(ct);
+      } else if (k == 1) {  // arrow (geom1) vs block (geom2)
+        pl_arrow_box(P, arrow, s.co, s.si, bc, P.block_half, P.pair[1].margin, true, 0, 1 + b, 1, emit);
+      } else {              // wall (geom1) vs block (geom2)
+        double wc[3];
+        if (!pl_wall_cell(z, bc[0], bc[1], k - 2, wc)) return;
+        pl_box_box(wc, wh, bc, P.block_half, P.pair[2].margin, -1, 1 + b, 2, emit);
+      }
+      return;
+    }
+    if constexpr (NB > 1) {  // block pairs (a < b): geom1 = block a, geom2 = block b
+      int p = r - 11 * NB, a = 0, b = 1;
+      if (p == 1) { a = 0; b = 2; } else if (p == 2) { a = 1; b = 2; }
+      if (b < NB) {
+        double ca[3], cb[3];
+        pl_block_center<NB>(P, s, a, ca);
+        pl_block_center<NB>(P, s, b, cb);
+        pl_box_box(ca, P.block_half, cb, P.block_half, P.pair[3].margin, 1 + a, 1 + b, 3, emit);
+      }
+    }
+  }
+}
+
+// Jacobian row of body `body` for a unit force direction f at the world point p
+template <int NB>
+MZP_HD void pl_add_body_row(const PlanarScratch<NB>& s, int body, const double* f, const double* p, double sgn, double* J) {
+  if (body == 0) {
+    double rx = p[0] - s.q[0], ry = p[1] - s.q[1];
+    J[0] += sgn * f[0]; J[1] += sgn * f[1]; J[2] += sgn * (-f[0] * ry + f[1] * rx);
+  } else if (body > 0) {
+    for (int b = 0; b < NB; b++)
+      if (b == body - 1) { J[3 + 2 * b] += sgn * f[0]; J[4 + 2 * b] += sgn * f[1]; }
+  }
+}
+
+template <int NB>
+MZP_HD void planar_fill_contact(const PointDev& P, PlanarScratch<NB>& s, int slot, const PlContact& c) {
+  constexpr int NV = PlanarDims<NB>::NV;
+  const PtPair& pr = P.pair[c.cls];
+  const double* n = c.n;
+  double y[3] = {0.0, (n[1] < 0.5 && n[1] > -0.5) ? 1.0 : 0.0, 0.0};
+  y[2] = 1.0 - y[1];
+  double dt = n[0] * y[0] + n[1] * y[1] + n[2] * y[2];
+  for (int k = 0; k < 3; k++) y[k] -= n[k] * dt;
+  double nn = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+  double t1[3] = {y[0] / nn, y[1] / nn, y[2] / nn};
+  double t2[3] = {n[1] * t1[2] - n[2] * t1[1], n[2] * t1[0] - n[0] * t1[2], n[0] * t1[1] - n[1] * t1[0]};
+  double imp = pt_impedance(pr.solimp, fabs(c.dist - pr.margin));
+  double R = fmax(1e-15, (1.0 - imp) / imp * (1.0 + pr.mu * pr.mu) * pr.wsum);
+  s.cD[slot] = 1.0 / (2.0 * pr.mu * pr.mu * R);
+  for (int a = 0; a < 3; a++) {
+    const double* f = a == 0 ? n : (a == 1 ? t1 : t2);
+    double sc = a == 0 ? 1.0 : pr.mu;
+    double J[NV];
+    for (int i = 0; i < NV; i++) J[i] = 0.0;
+    pl_add_body_row<NB>(s, c.b2, f, c.pos, sc, J);
+    pl_add_body_row<NB>(s, c.b1, f, c.pos, -sc, J);
+    double vel = 0.0;
+    for (int i = 0; i < NV; i++) { s.cJ[slot][a][i] = J[i]; vel += J[i] * s.v[i]; }
+    s.caref[slot][a] = -pr.B * vel - (a == 0 ? pr.K * imp * (c.dist - pr.margin) : 0.0);
+  }
+}
+
+// pyramidal contact: gradient block and curvature of the four edge rows (same as pt_contact_eval)
+MZP_HD void pl_contact_eval(double D, const double* u, double* g, double* W) {
+  double r0 = u[0] + u[1], r1 = u[0] - u[1], r2 = u[0] + u[2], r3 = u[0] - u[2];
+  double a0 = r0 < 0 ? 1.0 : 0.0, a1 = r1 < 0 ? 1.0 : 0.0, a2 = r2 < 0 ? 1.0 : 0.0, a3 = r3 < 0 ? 1.0 : 0.0;
+  g[0] = D * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3); g[1] = D * (a0 * r0 - a1 * r1); g[2] = D * (a2 * r2 - a3 * r3);
+  W[0] = D * (a0 + a1 + a2 + a3); W[1] = D * (a0 - a1); W[2] = D * (a2 - a3); W[3] = D * (a0 + a1); W[4] = D * (a2 + a3);
+}
+
+// ------------------------------------------------------------------ one forward-dynamics evaluation: s.q, s.v -> s.qacc
+template <int NB, class C>
+MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s) {
+  using D = PlanarDims<NB>;
+  constexpr int NV = D::NV, NC = D::NC, NE = D::NE;
+  MZ_FOR(one, 1) {
+    double co = cos(s.q[2]), si = sin(s.q[2]), w2 = s.v[2] * s.v[2], mc = P.mass * P.com_x;
+    s.co = co; s.si = si;
+    s.qas[0] = P.com_x * w2 * co; s.qas[1] = P.com_x * w2 * si; s.qas[2] = 0.0;
+    for (int i = 3; i < NV; i++) s.qas[i] = 0.0;
+    s.M3[0][0] = P.mass; s.M3[0][1] = 0.0; s.M3[0][2] = -mc * si;
+    s.M3[1][0] = 0.0; s.M3[1][1] = P.mass; s.M3[1][2] = mc * co;
+    s.M3[2][0] = -mc * si; s.M3[2][1] = mc * co; s.M3[2][2] = P.izz;
+    s.robot_near = point_near_wall(P, s.q[0], s.q[1]) ? 1 : 0;
+  }
+  cx.sync();
+  MZ_FOR(i, NV) s.qacc[i] = s.qas[i];
+  bool maybe = NB > 0 || s.robot_near != 0;  // group-uniform
+  if (!cx.any(maybe)) { cx.sync(); return; }
+  // ---- collision: count, prefix, fill
+  MZ_FOR(e, NE) {
+    int n = 0;
+    if (maybe) planar_contacts<NB>(P, s, e, [&](const PlContact& c) { if (c.dist < P.pair[c.cls].margin) n++; });
+    s.cnt[e] = n;
+  }
+  cx.sync();
+  MZ_FOR(one, 1) {
+    int tot = 0;
+    for (int e = 0; e < NE; e++) { s.cbeg[e] = tot; tot += s.cnt[e]; }
+    if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+    s.ncon = tot;
+  }
+  cx.sync();
+  const int ncon = s.ncon;
+  if (!cx.any(ncon > 0)) return;
+  MZ_FOR(e, NE) {
+    if (s.cnt[e] > 0) {
+      int slot = s.cbeg[e];
+      planar_contacts<NB>(P, s, e, [&](const PlContact& c) {
+        if (c.dist < P.pair[c.cls].margin) { if (slot < NC) planar_fill_contact<NB>(P, s, slot, c); slot++; }
+      });
+    }
+  }
+  cx.sync();
+  // ---- Newton on the primal problem (dense), exact line search
+  bool done = ncon == 0;
+  int it = 0;
+  while (cx.any(!done) && it < 50) {
+    MZ_FOR(i, NV) {
+      double t = 0.0;
+      for (int j = 0; j < NV; j++) t += pl_mass(P, s.M3, i, j) * (s.qacc[j] - s.qas[j]);
+      s.Mx[i] = t;
+    }
+    MZ_FOR(c, ncon) {
+      double u[3];
+      for (int a = 0; a < 3; a++) {
+        double t = -s.caref[c][a];
+        for (int i = 0; i < NV; i++) t += s.cJ[c][a][i] * s.qacc[i];
+        u[a] = t; s.cu[c][a] = t;
+      }
+      pl_contact_eval(s.cD[c], u, s.cg[c], s.cW[c]);
+    }
+    cx.sync();
+    double gpart = 0.0;
+    MZ_FOR(i, NV) {
+      double g = s.Mx[i];
+      for (int c = 0; c < ncon; c++) g += s.cJ[c][0][i] * s.cg[c][0] + s.cJ[c][1][i] * s.cg[c][1] + s.cJ[c][2][i] * s.cg[c][2];
+      s.grad[i] = g;
+      gpart += g * g;
+    }
+    double gn = sqrt(cx.gsum(gpart));
+    if (!done && P.inv_scale * gn < 1e-10) done = true;
+    if (!cx.any(!done)) break;
+    if (it == 49 && !done) { MZ_FOR(one, 1) s.status |= MZ_STATUS_SOLVER_MAXITER; }
+    MZ_FOR(e, NV * NV) {
+      int i = e / NV, j = e - NV * i;
+      double acc = pl_mass(P, s.M3, i, j);
+      for (int c = 0; c < ncon; c++) {
+        double ni = s.cJ[c][0][i], pi = s.cJ[c][1][i], qi = s.cJ[c][2][i], nj = s.cJ[c][0][j], pj = s.cJ[c][1][j], qj = s.cJ[c][2][j];
+        const double* W = s.cW[c];
+        acc += W[0] * ni * nj + W[1] * (ni * pj + pi * nj) + W[2] * (ni * qj + qi * nj) + W[3] * pi * pj + W[4] * qi * qj;
+      }
+      s.H[i][j] = acc;
+    }
+    cx.sync();
+    MZ_FOR(one, 1) {  // Cholesky H = L L^T and H search = -grad, one lane
+      double L[NV][NV], y[NV];
+      for (int j = 0; j < NV; j++) {
+        double d = s.H[j][j];
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+        d = sqrt(fmax(d, 1e-300));
+        L[j][j] = d;
+        for (int i = j + 1; i < NV; i++) {
+          double t = s.H[i][j];
+          for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+          L[i][j] = t / d;
+        }
+      }
+      for (int i = 0; i < NV; i++) { double t = -s.grad[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
+      for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * y[k]; y[i] = t / L[i][i]; }
+      for (int i = 0; i < NV; i++) s.search[i] = y[i];
+    }
+    cx.sync();
+    double p1p = 0.0, p2p = 0.0;
+    MZ_FOR(i, NV) {
+      double t = 0.0;
+      for (int j = 0; j < NV; j++) t += pl_mass(P, s.M3, i, j) * s.search[j];
+      p1p += s.search[i] * s.Mx[i]; p2p += s.search[i] * t;
+    }
+    MZ_FOR(c, ncon) {
+      for (int a = 0; a < 3; a++) {
+        double t = 0.0;
+        for (int i = 0; i < NV; i++) t += s.cJ[c][a][i] * s.search[i];
+        s.cjv[c][a] = t;
+      }
+    }
+    double p1 = cx.gsum(p1p), p2 = cx.gsum(p2p);
+    cx.sync();
+    double lo = 0.0, hi = -1.0, alpha = 1.0, prev_d2 = -1.0;
+    for (int ls = 0; ls < 30; ls++) {
+      double d1 = 0.0, d2 = 0.0;
+      MZ_FOR(c, ncon) {
+        double Dc = s.cD[c], v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
+        double u0 = s.cu[c][0] + alpha * v0, u1 = s.cu[c][1] + alpha * v1, u2 = s.cu[c][2] + alpha * v2, r, w;
+        r = u0 + u1; w = v0 + v1; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+        r = u0 - u1; w = v0 - v1; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+        r = u0 + u2; w = v0 + v2; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+        r = u0 - u2; w = v0 - v2; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+      }
+      d1 = cx.gsum(d1) + p1 + alpha * p2;
+      d2 = cx.gsum(d2) + p2;
+      if (d2 == prev_d2) break;
+      prev_d2 = d2;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double next = alpha - d1 / d2;
+      if (hi >= 0 && !(next > lo && next < hi)) next = 0.5 * (lo + hi);
+      if (!(next > 0)) next = hi >= 0 ? 0.5 * (lo + hi) : 0.0;
+      if (fabs(next - alpha) <= 1e-15 * fabs(next)) { alpha = next; break; }
+      alpha = next;
+    }
+    if (done) alpha = 0.0;
+    cx.sync();
+    MZ_FOR(i, NV) s.qacc[i] += alpha * s.search[i];
+    cx.sync();
+    it++;
+  }
+  cx.sync();
+}
+
+// ------------------------------------------------------------------ One MazeEnv.step.  s.q / s.v hold the state in and out.
+template <int NB, class C>
+MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB>& s, const double* action) {
+  constexpr int NV = PlanarDims<NB>::NV;
+  const double PI = 3.141592653589793;
+  double old_x = s.q[0], old_y = s.q[1];  // every lane reads the same values
+  cx.sync();
+  MZ_FOR(one, 1) {  // point.py:45-56
+    double th = s.q[2] + action[1];
+    if (th < -PI) th += PI * 2;
+    else if (PI < th) th -= PI * 2;
+    s.q[2] = th;
+    s.q[0] += cos(th) * action[0];
+    s.q[1] += sin(th) * action[0];
+    s.status = 0;
+  }
+  MZ_FOR(i, NV) s.v[i] = fmin(fmax(s.v[i], -P.vel_limit), P.vel_limit);  // the clip covers the whole qvel (point.py:54-55)
+  cx.sync();
+  for (int f = 0; f < P.frame_skip; f++) {  // mj_step, RK4 (point.xml:3)
+    const double h = P.h;
+    MZ_FOR(i, NV) { s.x0[i] = s.q[i]; s.v0[i] = s.v[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; }
+    cx.sync();
+    for (int st = 0; st < 4; st++) {
+      planar_forward<NB>(cx, P, s);
+      double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
+      MZ_FOR(i, NV) {
+        s.accv[i] += bw * s.v[i]; s.accf[i] += bw * s.qacc[i];
+        double nq = s.x0[i] + h * (aw * s.v[i]), nv = s.v0[i] + h * (aw * s.qacc[i]);
+        s.q[i] = nq; s.v[i] = nv;
+      }
+      cx.sync();
+    }
+    MZ_FOR(i, NV) { s.q[i] = s.x0[i] + h * s.accv[i]; s.v[i] = s.v0[i] + h * s.accf[i]; }
+    cx.sync();
+  }
+  // maze_env.py:454-464: manual wall bounce on the robot's xy
+  if (P.nseg > 0) {
+    MZ_FOR(one, 1) {
+      double old_xy[2] = {old_x, old_y}, new_xy[2] = {s.q[0], s.q[1]}, pt[2], rf[2];
+      int hit = point_detect(P, old_xy, new_xy, pt, rf);
+      if (hit < 0) s.status |= MZ_STATUS_COLLINEAR;
+      if (hit > 0) {
+        double pos[2] = {pt[0] + P.restitution * (rf[0] - pt[0]), pt[1] + P.restitution * (rf[1] - pt[1])}, p2[2], r2[2];
+        int again = point_detect(P, old_xy, pos, p2, r2);
+        if (again < 0) s.status |= MZ_STATUS_COLLINEAR;
+        if (again > 0) { s.q[0] = old_xy[0]; s.q[1] = old_xy[1]; }
+        else if (again == 0) { s.q[0] = pos[0]; s.q[1] = pos[1]; }
+      }
+    }
+    cx.sync();
+  }
+}
+
+// observation element i of the returned row: qpos[:3] | block xyz ... | qvel[:3] | t * 0.001  (maze_env.py:351-369)
+template <int NB>
+MZP_HD float planar_obs_elem(const PointDev& P, const PlanarScratch<NB>& s, int i, int t) {
+  int nb3 = P.observe_blocks ? 3 * NB : 0;
+  if (i < 3) return (float)s.q[i];
+  if (i < 3 + nb3) {
+    int b = (i - 3) / 3, c = (i - 3) % 3;
+    return (float)(c == 2 ? P.block_pos0[b][2] : P.block_pos0[b][c] + s.q[3 + 2 * b + c]);
+  }
+  if (i < 6 + nb3) return (float)s.v[i - 3 - nb3];
+  return (float)t * 0.001f;
+}

@@ -574,9 +574,11 @@ static void box_box_aligned(mzo_data* d, const pairparam* pp, const double* c1, 
  * rectangle-rectangle test: separating-axis search over the four face normals (wall x, wall y, arrow x, arrow y;
  * first axis on ties), distance = largest separation, contact points = the deepest vertex / vertices of the
  * incident rectangle (within 1e-9 of the minimum), placed midway between the surfaces at the arrow's height.
- * geom1 = wall (world geoms precede the robot's), geom2 = arrow: normal from the wall to the arrow. */
+ * geom1 = wall (world geoms precede the robot's), geom2 = arrow: normal from the wall to the arrow.
+ * The same rule serves the arrow against a movable block (an axis-aligned box that comes AFTER the arrow in the
+ * geom order): `flip` = 1 reports the normal from the rotated box to the aligned one. */
 static void box_zrot_vs_aabb(mzo_data* d, const pairparam* pp, const double* wc, const double* wh, const double* bc,
-                             const double* bmat, const double* bh) {
+                             const double* bmat, const double* bh, int flip) {
   if (fabs(bc[2] - wc[2]) > bh[2] + wh[2] + pp->margin) return;
   double ex[2] = {bmat[0], bmat[3]}, ey[2] = {bmat[1], bmat[4]};
   double dx = bc[0] - wc[0], dy = bc[1] - wc[1];
@@ -605,7 +607,8 @@ static void box_zrot_vs_aabb(mzo_data* d, const pairparam* pp, const double* wc,
     for (int k = 0; k < 4; k++)
       if (depth[k] <= dmin + 1e-9) {
         double pos[3] = {vx[k] - n[0] * 0.5 * depth[k], vy[k] - n[1] * 0.5 * depth[k], bc[2]};
-        add_contact(d, pp, depth[k], pos, n, NULL);
+        double nn[3] = {flip ? -n[0] : n[0], flip ? -n[1] : n[1], 0.0};
+        add_contact(d, pp, depth[k], pos, nn, NULL);
       }
   } else { /* reference face on the arrow: incident vertices are the wall's corners */
     double href = best == 2 ? bh[0] : bh[1];
@@ -618,7 +621,8 @@ static void box_zrot_vs_aabb(mzo_data* d, const pairparam* pp, const double* wc,
     for (int k = 0; k < 4; k++)
       if (depth[k] <= dmin + 1e-9) {
         double pos[3] = {vx[k] + n[0] * 0.5 * depth[k], vy[k] + n[1] * 0.5 * depth[k], bc[2]};
-        add_contact(d, pp, depth[k], pos, n, NULL);
+        double nn[3] = {flip ? -n[0] : n[0], flip ? -n[1] : n[1], 0.0};
+        add_contact(d, pp, depth[k], pos, nn, NULL);
       }
   }
 }
@@ -724,7 +728,7 @@ static void collide_walls(const mz_model* m, mzo_data* d, int g) {
       } else if (m->geom_type[g] == MZ_GEOM_BOX && fabs(d->geom_xmat[g][8] - 1.0) < 1e-12) {
         pairparam q = pp; /* box rotated about z only (the Point's arrow) */
         q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
-        box_zrot_vs_aabb(d, &q, bpos, bsize, gp, d->geom_xmat[g], m->geom_size[g]);
+        box_zrot_vs_aabb(d, &q, bpos, bsize, gp, d->geom_xmat[g], m->geom_size[g], 0);
       } else {
         d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* generally rotated box vs box: not restated */
       }
@@ -750,6 +754,9 @@ static void collide_pair(const mz_model* m, mzo_data* d, int ga, int gb) {
                 d->geom_xmat[g2], m->geom_size[g2]);
   } else if (t1 == MZ_GEOM_BOX && t2 == MZ_GEOM_BOX && is_axis_aligned(d->geom_xmat[g1]) && is_axis_aligned(d->geom_xmat[g2])) {
     box_box_aligned(d, &pp, d->geom_xpos[g1], m->geom_size[g1], d->geom_xpos[g2], m->geom_size[g2]);
+  } else if (t1 == MZ_GEOM_BOX && t2 == MZ_GEOM_BOX && is_axis_aligned(d->geom_xmat[g2]) && fabs(d->geom_xmat[g1][8] - 1.0) < 1e-12) {
+    /* the Point's arrow (rotated about z, geom1) against a movable block (aligned, geom2) [ASSUME-13] */
+    box_zrot_vs_aabb(d, &pp, d->geom_xpos[g2], m->geom_size[g2], d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], 1);
   } else {
     d->status |= MZO_STATUS_UNSUPPORTED_PAIR;
   }

@@ -110,8 +110,36 @@ int emu_ant_forward(const mz_model* m, int n, const float* qpos, const float* qv
 }
 }
 
-// ---------------------------------------------------------------- Point: the per-lane step function of point_step_kernel
-#include "../../mujoco_maze_amd/csrc/point_dyn.h"
+// ---------------------------------------------------------------- Point (+ movable blocks): the lane-group step of planar_step_kernel
+#include "../../mujoco_maze_amd/csrc/planar_dyn.h"
+
+template <int NB>
+static int planar_env_step_t(const PointDev& P, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
+                             float* reward, uint8_t* done, int32_t* goal_idx, int32_t* status) {
+  using D = PlanarDims<NB>;
+  constexpr int NV = D::NV, NOBS = D::NOBS;
+  HostCtx cx;
+  PlanarScratch<NB>* s = (PlanarScratch<NB>*)calloc(1, sizeof(PlanarScratch<NB>));
+  for (int e = 0; e < n; e++) {
+    double a[2] = {(double)actions[2 * e], (double)actions[2 * e + 1]};
+    for (int k = 0; k < NV; k++) { s->q[k] = (double)qpos[NV * e + k]; s->v[k] = (double)qvel[NV * e + k]; }
+    const int t_new = t[e] + 1;
+    planar_env_step<NB>(cx, P, *s, a);
+    float o[NOBS];
+    for (int i = 0; i < NOBS; i++) o[i] = planar_obs_elem<NB>(P, *s, i, t_new);
+    float outer; int tm, gi;
+    task_eval_dev(P.task, o, &outer, &tm, &gi);
+    for (int k = 0; k < NOBS; k++) obs[NOBS * e + k] = o[k];
+    for (int k = 0; k < NV; k++) { qpos[NV * e + k] = (float)s->q[k]; qvel[NV * e + k] = (float)s->v[k]; }
+    reward[e] = outer;
+    done[e] = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
+    if (goal_idx) goal_idx[e] = gi;
+    if (status) status[e] = s->status;
+    t[e] = t_new;
+  }
+  free(s);
+  return MZ_OK;
+}
 
 extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
                                   float* reward, uint8_t* done, int32_t* goal_idx, int32_t* status) {
@@ -119,26 +147,14 @@ extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* 
   char err[128];
   int rc = point_dev_from_model(P, m, err, sizeof(err));
   if (rc != MZ_OK) { free(P); return rc; }
-  for (int e = 0; e < n; e++) {
-    double q[3], v[3], a[2] = {(double)actions[2 * e], (double)actions[2 * e + 1]};
-    for (int k = 0; k < 3; k++) { q[k] = (double)qpos[3 * e + k]; v[k] = (double)qvel[3 * e + k]; }
-    int t_new;
-    int st = point_env_step(*P, q, v, a, t[e], nullptr, nullptr, nullptr, nullptr, nullptr, &t_new);
-    float o[7];
-    for (int k = 0; k < 3; k++) { o[k] = (float)q[k]; o[3 + k] = (float)v[k]; }
-    o[6] = (float)t_new * 0.001f;
-    float outer; int tm, gi;
-    task_eval_dev(P->task, o, &outer, &tm, &gi);
-    for (int k = 0; k < 7; k++) obs[7 * e + k] = o[k];
-    for (int k = 0; k < 3; k++) { qpos[3 * e + k] = o[k]; qvel[3 * e + k] = o[3 + k]; }
-    reward[e] = outer;
-    done[e] = (uint8_t)((tm ? 1 : 0) | (t_new >= P->task.max_steps ? 2 : 0));
-    if (goal_idx) goal_idx[e] = gi;
-    if (status) status[e] = st;
-    t[e] = t_new;
+  switch (P->nblock) {
+    case 0: rc = planar_env_step_t<0>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
+    case 1: rc = planar_env_step_t<1>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
+    case 2: rc = planar_env_step_t<2>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
+    default: rc = planar_env_step_t<3>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
   }
   free(P);
-  return MZ_OK;
+  return rc;
 }
 
 // ---------------------------------------------------------------- Swimmer: the per-lane step function of swimmer_step_kernel

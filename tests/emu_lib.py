@@ -66,11 +66,11 @@ def f32_state(st):
 
 
 def point_env_step(cm, st, actions):
-    """st: dict of float32 qpos [n,3], qvel [n,3], int32 t [n] (updated in place)."""
+    """st: dict of float32 qpos [n,nv], qvel [n,nv], int32 t [n] (updated in place); nv = 3 + 2 * movable blocks."""
     lib = load()
     n = st["qpos"].shape[0]
     a = np.ascontiguousarray(actions, np.float32)
-    out = dict(obs=np.zeros((n, 7), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+    out = dict(obs=np.zeros((n, cm.c.obs_dim), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
                goal_idx=np.zeros(n, np.int32), status=np.zeros(n, np.int32))
     rc = lib.emu_point_env_step(C.byref(cm.c), n, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["t"]), _vp(a), _vp(out["obs"]),
                                 _vp(out["reward"]), _vp(out["done"]), _vp(out["goal_idx"]), _vp(out["status"]))

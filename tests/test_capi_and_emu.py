@@ -227,6 +227,41 @@ def test_point_step_logic_with_mujoco_wall_contacts(oracle):
     assert gave_up.sum() > 20  # the give-up branch of the manual bounce is exercised
 
 
+@pytest.mark.parametrize("name,nblock", [("Push", 1), ("MultiPush", 2), ("PushMaze", 3), ("BlockMaze", 1)])
+def test_point_with_movable_blocks(oracle, name, nblock):
+    """Point + movable XY blocks (PointPush & co., maze_task.py:179-330): the lane-group planar code (csrc/planar_dyn.h:
+    sphere / arrow vs block, block vs wall, block vs block contacts; dense (3 + 2 NB)-dof Newton) against the oracle's
+    general rigid-body path.  The robot teleports by its action every step, so it regularly lands inside a block."""
+    from tests import emu_lib
+
+    task_cls = T.TaskRegistry.tasks(name)[0]
+    scale = task_cls.MAZE_SIZE_SCALING.point
+    cm = model.compile_model("point", task_cls(scale), scale)
+    m = cm.c
+    assert m.nblock == nblock and m.nv == 3 + 2 * nblock and m.obs_dim == 7 + 3 * nblock
+    n = 192
+    st, _ = oracle.reset(cm, n, 1)
+    assert np.all(st["qpos"][:, 3:] == 0.0) and np.all(st["qvel"][:, 3:] == 0.0)  # point.py:78-80: blocks reset to their spawn state
+    rng = np.random.default_rng(0)
+    moved, errs = 0.0, []
+    for k in range(101):
+        act = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.25, 0.25, n)], 1).astype(np.float32)
+        if k % 20 == 0:
+            s64 = _f32(st)
+            s32 = dict(qpos=s64["qpos"].astype(np.float32), qvel=s64["qvel"].astype(np.float32), t=s64["t"].copy())
+            ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            re_ = emu_lib.point_env_step(cm, s32, act)
+            errs.append(np.abs(re_["obs"] - ro["obs"]).max(1))
+            assert np.array_equal(re_["done"], ro["done"]) and np.array_equal(re_["goal_idx"], ro["goal_idx"])
+            assert np.all((re_["status"] & ~8) == 0) and np.all((ro["status"] & ~8) == 0)
+            moved = max(moved, np.abs(s64["qpos"][:, 3:]).max())
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    errs = np.concatenate(errs)
+    # stiff contacts on a 0.2 g block: an env whose contact switches within round-off lands on the other branch
+    assert np.median(errs) < 3e-7 and (errs <= 2e-6).mean() >= 0.99, (np.median(errs), (errs <= 2e-6).mean(), errs.max())
+    assert moved > 0.5  # blocks really get pushed around
+
+
 @pytest.mark.parametrize("robot,nq", [("swimmer", 5), ("reacher", 4)])
 def test_swimmer_step_logic(oracle, robot, nq):
     """Swimmer (north_star) and Reacher (its 2-link variant, reacher.py / reacher.xml): the kernel's

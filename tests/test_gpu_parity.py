@@ -287,6 +287,37 @@ def test_point_step_parity_and_bounce(torch, oracle):
     env.close()
 
 
+@pytest.mark.parametrize("env_id,nblock", [("PointPush-v0", 1), ("PointPushMaze-v0", 3)])
+def test_point_with_movable_blocks(torch, oracle, env_id, nblock):
+    """Point + movable XY blocks on the lane-group planar kernel (32 / 64 lanes per env)."""
+    n = 1024
+    env = mm.make(env_id, num_envs=n)
+    cm = env.model
+    assert cm.c.nblock == nblock and env.obs_dim == 7 + 3 * nblock and env.nv == 3 + 2 * nblock
+    st, _ = oracle.reset(cm, n, 1)
+    rng = np.random.default_rng(0)
+    errs, moved = [], 0.0
+    for k in range(81):
+        act = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.25, 0.25, n)], 1).astype(np.float32)
+        if k % 20 == 0:
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], None, s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, _, t = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1))
+            assert np.array_equal(done.cpu().numpy(), ref["done"])
+            assert np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
+            assert np.all(_close(qpos, s64["qpos"], atol=1e-4)) and np.array_equal(t, s64["t"])
+            assert np.all((env.status().cpu().numpy() & ~8) == 0)
+            moved = max(moved, np.abs(s64["qpos"][:, 3:]).max())
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    errs = np.concatenate(errs)
+    assert np.median(errs) < 3e-7 and (errs <= 2e-6).mean() >= 0.99, (np.median(errs), (errs <= 2e-6).mean(), errs.max())
+    assert moved > 0.5
+    env.close()
+
+
 @pytest.mark.parametrize("robot,nq", [("Swimmer", 5), ("Reacher", 4)])
 def test_swimmer_step_parity(torch, oracle, robot, nq):
     """Swimmer and its 2-link variant, the Reacher (reacher.py / reacher.xml), on the planar-chain kernels."""
