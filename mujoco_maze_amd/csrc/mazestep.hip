@@ -409,8 +409,9 @@ __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* 
   if (t) t[env] = S.t[env];
 }
 
-// ------------------------------------------------------------------ Swimmer / Reacher kernels (NL links; SoA: q0..q[NV-1] v0..v[NV-1] | t | episode)
-template <int NL>
+// ------------------------------------------------------------------ Swimmer / Reacher kernels (NL links, NB inert movable blocks;
+// SoA: q0..q[NV-1] v0..v[NV-1] | t | episode with NV = NL + 2 + 2 NB)
+template <int NL, int NB>
 __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __restrict__ Pp, int n, PointState S,
                                                             const float* __restrict__ actions, float* __restrict__ obs,
                                                             float* __restrict__ reward, uint8_t* __restrict__ done,
@@ -418,16 +419,31 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
                                                             int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
-  constexpr int NV = NL + 2, NH = NL - 1, NO = 2 * NV + 1;
+  constexpr int NR = NL + 2, NV = NR + 2 * NB, NH = NL - 1;
   const SwimmerDev& P = *Pp;
-  double q[NV], v[NV], a[NH], inner, inf4[4];
-  for (int k = 0; k < NV; k++) { q[k] = (double)S.qv[(size_t)k * n + env]; v[k] = (double)S.qv[(size_t)(NV + k) * n + env]; }
+  const int nb3 = P.observe_blocks ? 3 * NB : 0, NO = 2 * NR + 1 + nb3;
+  double q[NR], v[NR], a[NH], inner, inf4[4];
+  for (int k = 0; k < NR; k++) { q[k] = (double)S.qv[(size_t)k * n + env]; v[k] = (double)S.qv[(size_t)(NV + k) * n + env]; }
   for (int k = 0; k < NH; k++) a[k] = (double)actions[(size_t)env * NH + k];
   int t_new;
   int st = swimmer_env_step<NL>(P, q, v, a, S.t[env], &inner, inf4, &t_new);
-  float o[NO];
-  for (int k = 0; k < NV; k++) { o[k] = (float)q[k]; o[NV + k] = (float)v[k]; }
-  o[2 * NV] = (float)t_new * 0.001f;
+  // blocks: no contacts (swimmer.xml:3 collision="predefined"), only the medium's drag on a moving box
+  float bq[2 * NB + 1], bv[2 * NB + 1];
+  for (int b = 0; b < NB; b++) {
+    double q2[2] = {(double)S.qv[(size_t)(NR + 2 * b) * n + env], (double)S.qv[(size_t)(NR + 2 * b + 1) * n + env]};
+    double v2[2] = {(double)S.qv[(size_t)(NV + NR + 2 * b) * n + env], (double)S.qv[(size_t)(NV + NR + 2 * b + 1) * n + env]};
+    if (v2[0] != 0.0 || v2[1] != 0.0) swimmer_block_step(P, q2, v2);
+    bq[2 * b] = (float)q2[0]; bq[2 * b + 1] = (float)q2[1]; bv[2 * b] = (float)v2[0]; bv[2 * b + 1] = (float)v2[1];
+  }
+  float o[2 * NR + 1 + 3 * NB];
+  for (int k = 0; k < 3; k++) o[k] = (float)q[k];
+  for (int b = 0; b < NB && nb3; b++) {
+    o[3 + 3 * b] = (float)(P.block_pos0[b][0] + (double)bq[2 * b]); o[4 + 3 * b] = (float)(P.block_pos0[b][1] + (double)bq[2 * b + 1]);
+    o[5 + 3 * b] = (float)P.block_pos0[b][2];
+  }
+  for (int k = 3; k < NR; k++) o[nb3 + k] = (float)q[k];
+  for (int k = 0; k < NR; k++) o[nb3 + NR + k] = (float)v[k];
+  o[nb3 + 2 * NR] = (float)t_new * 0.001f;
   float outer; int tm, gi;
   task_eval_dev(P.task, o, &outer, &tm, &gi);
   uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
@@ -437,37 +453,51 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
   if (goal_idx) goal_idx[env] = gi;
   if (info) for (int k = 0; k < 4; k++) info[(size_t)env * 4 + k] = (float)inf4[k];
   bool badv = false;
-  for (int k = 0; k < 2 * NV; k++) badv = badv || !(fabsf(o[k]) < 1e10f);
+  for (int k = 0; k < NR; k++) badv = badv || !(fabs(q[k]) < 1e10) || !(fabs(v[k]) < 1e10);
   if (badv) st |= MZ_STATUS_BAD_STATE;
   if (st) atomicOr(&status[env], st);
   uint32_t ep = S.ep[env];
-  if (auto_reset && d) {
-    ep += 1;
-    uint64_t es = episode_seed(seed, ep);
-    for (int k = 0; k < NV; k++) { o[k] = reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k); o[NV + k] = reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k); }
-    t_new = 0;
+  const bool rst = auto_reset && d;
+  if (rst) { ep += 1; t_new = 0; }
+  const uint64_t es = episode_seed(seed, ep);
+  for (int k = 0; k < NV; k++) {
+    float qk = k < NR ? (float)q[k] : bq[k - NR], vk = k < NR ? (float)v[k] : bv[k - NR];
+    if (rst) {
+      qk = k < NR ? reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k) : 0.f;
+      vk = k < NR ? reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k) : 0.f;
+    }
+    S.qv[(size_t)k * n + env] = qk;
+    S.qv[(size_t)(NV + k) * n + env] = vk;
   }
-  for (int k = 0; k < 2 * NV; k++) S.qv[(size_t)k * n + env] = o[k];
   S.t[env] = t_new;
   S.ep[env] = ep;
 }
 
-template <int NL>
+template <int NL, int NB>
 __global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
-  constexpr int NV = NL + 2, NO = 2 * NV + 1;
+  constexpr int NR = NL + 2, NV = NR + 2 * NB;
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   if (!mask || mask[env]) {
     for (int k = 0; k < NV; k++) {
-      S.qv[(size_t)k * n + env] = reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k);
-      S.qv[(size_t)(NV + k) * n + env] = reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k);
+      S.qv[(size_t)k * n + env] = k < NR ? reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k) : 0.f;
+      S.qv[(size_t)(NV + k) * n + env] = k < NR ? reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k) : 0.f;
     }
     S.t[env] = 0;
     S.ep[env] = 0;
   }
   if (obs) {
-    for (int k = 0; k < 2 * NV; k++) obs[(size_t)env * NO + k] = S.qv[(size_t)k * n + env];
-    obs[(size_t)env * NO + 2 * NV] = (float)S.t[env] * 0.001f;
+    const int nb3 = Pp->observe_blocks ? 3 * NB : 0, NO = 2 * NR + 1 + nb3;
+    float* o = obs + (size_t)env * NO;
+    for (int k = 0; k < 3; k++) o[k] = S.qv[(size_t)k * n + env];
+    for (int b = 0; b < NB && nb3; b++) {
+      o[3 + 3 * b] = (float)Pp->block_pos0[b][0] + S.qv[(size_t)(NR + 2 * b) * n + env];
+      o[4 + 3 * b] = (float)Pp->block_pos0[b][1] + S.qv[(size_t)(NR + 2 * b + 1) * n + env];
+      o[5 + 3 * b] = (float)Pp->block_pos0[b][2];
+    }
+    for (int k = 3; k < NR; k++) o[nb3 + k] = S.qv[(size_t)k * n + env];
+    for (int k = 0; k < NR; k++) o[nb3 + NR + k] = S.qv[(size_t)(NV + k) * n + env];
+    o[nb3 + 2 * NR] = (float)S.t[env] * 0.001f;
   }
 }
 
@@ -499,6 +529,7 @@ struct mz_handle {
   uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
   char err[256];
   // kernel timing ring (option "time_kernels")
+  int lanes_set;  // lanes_per_env chosen by the caller (else the per-robot default)
   int ntime, itime;
   hipEvent_t* ev;  // 2 * ntime
   long nsteps;
@@ -601,7 +632,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     if (e == hipSuccess) e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3 + 2 * h->point.nblock;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock;
     e = hipMalloc(&h->state, (size_t)num_envs * 2 * kq * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
@@ -659,7 +690,7 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "lanes_per_env")) {
     int g = (int)value;
     if (g != 8 && g != 16 && g != 32 && g != 64) return set_err(h, MZ_ERR_ARG, "lanes_per_env must be 8, 16, 32 or 64", hipSuccess);
-    h->lanes = g;
+    h->lanes = g; h->lanes_set = 1;
     return MZ_OK;
   }
   if (!strcmp(key, "profile_phases")) {
@@ -693,8 +724,10 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
   if (h->robot == MZ_ROBOT_ANT) hipLaunchKernelGGL(ant_reset_kernel, dim3(nb), dim3(256), 0, st, h->ant, h->lay, h->n, h->state, mask_dev, seed, h->env0, obs_dev);
   else if (h->robot == MZ_ROBOT_SWIMMER) {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    if (h->swimmer.nlink == 3) hipLaunchKernelGGL(swimmer_reset_kernel<3>, dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
-    else hipLaunchKernelGGL(swimmer_reset_kernel<2>, dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+#define MZ_SW_RESET(NL, NB) hipLaunchKernelGGL((swimmer_reset_kernel<NL, NB>), dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev)
+    if (h->swimmer.nlink == 3) { if (h->swimmer.nblock) MZ_SW_RESET(3, 1); else MZ_SW_RESET(3, 0); }
+    else { if (h->swimmer.nblock) MZ_SW_RESET(2, 1); else MZ_SW_RESET(2, 0); }
+#undef MZ_SW_RESET
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     switch (h->point.nblock) {
@@ -717,12 +750,13 @@ int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev,
     hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3 + 2 * h->point.nblock;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock;
     const dim3 grid((h->n + 255) / 256), blk(256);
     switch (kq) {
       case 3: hipLaunchKernelGGL(point_set_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
       case 4: hipLaunchKernelGGL(point_set_state_kernel<4>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
       case 5: hipLaunchKernelGGL(point_set_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+      case 6: hipLaunchKernelGGL(point_set_state_kernel<6>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
       case 7: hipLaunchKernelGGL(point_set_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
       default: hipLaunchKernelGGL(point_set_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
     }
@@ -739,12 +773,13 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
     hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 : 3 + 2 * h->point.nblock;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock;
     const dim3 grid((h->n + 255) / 256), blk(256);
     switch (kq) {
       case 3: hipLaunchKernelGGL(point_get_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
       case 4: hipLaunchKernelGGL(point_get_state_kernel<4>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
       case 5: hipLaunchKernelGGL(point_get_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+      case 6: hipLaunchKernelGGL(point_get_state_kernel<6>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
       case 7: hipLaunchKernelGGL(point_get_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
       default: hipLaunchKernelGGL(point_get_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
     }
@@ -771,12 +806,12 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
     HIPCHK(h, le);
   } else if (h->robot == MZ_ROBOT_SWIMMER) {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    if (h->swimmer.nlink == 3)
-      hipLaunchKernelGGL(swimmer_step_kernel<3>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev,
-                         reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
-    else
-      hipLaunchKernelGGL(swimmer_step_kernel<2>, dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev,
-                         reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0);
+#define MZ_SW_STEP(NL, NB)                                                                                                          \
+  hipLaunchKernelGGL((swimmer_step_kernel<NL, NB>), dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev, \
+                     reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0)
+    if (h->swimmer.nlink == 3) { if (h->swimmer.nblock) MZ_SW_STEP(3, 1); else MZ_SW_STEP(3, 0); }
+    else { if (h->swimmer.nblock) MZ_SW_STEP(2, 1); else MZ_SW_STEP(2, 0); }
+#undef MZ_SW_STEP
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     // lanes per env: 16 for the bare robot (18 collision enumerators), 32 / 64 with blocks (bigger contact sets in LDS)
@@ -784,7 +819,11 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   hipLaunchKernelGGL((planar_step_kernel<NB, G>), dim3((h->n + 64 / G - 1) / (64 / G)), dim3(64), 0, st, h->point_dev, h->n, S, actions_dev, \
                      obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0)
     switch (h->point.nblock) {
-      case 0: MZ_PLANAR_LAUNCH(0, 16); break;
+      case 0:
+        if (h->lanes_set && h->lanes == 8) MZ_PLANAR_LAUNCH(0, 8);
+        else if (h->lanes_set && h->lanes == 32) MZ_PLANAR_LAUNCH(0, 32);
+        else MZ_PLANAR_LAUNCH(0, 16);
+        break;
       case 1: MZ_PLANAR_LAUNCH(1, 32); break;
       case 2: MZ_PLANAR_LAUNCH(2, 64); break;
       default: MZ_PLANAR_LAUNCH(3, 64); break;

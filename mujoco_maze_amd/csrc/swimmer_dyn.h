@@ -33,22 +33,39 @@ struct SwimmerDev {
   double lim_lo[2], lim_hi[2], lim_K, lim_B, lim_solimp[5], dofw[2];
   double qpos0[5];
   int nlink;                          // 3 Swimmer, 2 Reacher
+  // movable blocks of the maze: `collision="predefined"` gives the swimmer no contact pairs at all, so a block is a free,
+  // force-free slide-x / slide-y body — it only drifts with whatever velocity it is given and shows up in the observation
+  int nblock, observe_blocks;
+  double block_pos0[1][3], block_mass, block_box[3];  // inertia-box sizes: the medium drags a moving block too
   TaskDev task;
 };
 
 static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char* err, int errlen) {
   memset(p, 0, sizeof(*p));
-  const int nl = m->nbody - 1;
-  bool ok = m->robot == MZ_ROBOT_SWIMMER && (nl == 2 || nl == 3) && m->nv == nl + 2 && m->nq == nl + 2 && m->nu == nl - 1 &&
+  const int nbk = m->nblock, nl = m->nbody - 1 - nbk;
+  if (nbk < 0 || nbk > 1) return ant_fail(err, errlen, "swimmer kernel: at most one movable block");
+  bool ok = m->robot == MZ_ROBOT_SWIMMER && (nl == 2 || nl == 3) && m->nv == nl + 2 + 2 * nbk && m->nq == nl + 2 + 2 * nbk && m->nu == nl - 1 &&
             m->collision_predefined && m->jnt_type[0] == MZ_JNT_SLIDE && m->jnt_type[1] == MZ_JNT_SLIDE;
   for (int j = 2; ok && j < nl + 2; j++) ok = m->jnt_type[j] == MZ_JNT_HINGE;
   for (int a = 0; ok && a < nl - 1; a++) ok = m->act_dofid[a] == 3 + a;
   if (!ok) return ant_fail(err, errlen, "swimmer kernel: model is not the 2- or 3-link planar swimmer / reacher");
-  p->nlink = nl;
+  p->nlink = nl; p->nblock = nbk; p->observe_blocks = m->observe_blocks;
+  for (int k = 0; k < nbk; k++) {
+    int b = m->block_bodyid[k], j0 = m->body_jntadr[b];
+    if (m->body_jntnum[b] != 2 || m->jnt_type[j0] != MZ_JNT_SLIDE || m->jnt_type[j0 + 1] != MZ_JNT_SLIDE || m->body_dofadr[b] != nl + 2 + 2 * k ||
+        fabs(m->jnt_axis[j0][0] - 1.0) > 1e-12 || fabs(m->jnt_axis[j0 + 1][1] - 1.0) > 1e-12 || m->jnt_limited[j0] || m->jnt_limited[j0 + 1])
+      return ant_fail(err, errlen, "swimmer kernel: movable block is not an unlimited slide-x / slide-y body");
+    for (int q = 0; q < 3; q++) p->block_pos0[k][q] = m->body_pos[b][q];
+    const double* I = m->body_inertia[b];
+    p->block_mass = m->body_mass[b];
+    p->block_box[0] = sqrt(fmax(1e-15, I[1] + I[2] - I[0]) / p->block_mass * 6.0);
+    p->block_box[1] = sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / p->block_mass * 6.0);
+    p->block_box[2] = sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / p->block_mass * 6.0);
+  }
   p->h = m->timestep; p->frame_skip = m->frame_skip; p->reset_kind = m->reset_qvel_kind;
   p->gear = m->act_gear[0]; p->ctrl_lo = m->act_ctrlrange[0][0]; p->ctrl_hi = m->act_ctrlrange[0][1];
   p->armature = m->dof_armature[0]; p->density = m->density; p->viscosity = m->viscosity;
-  p->inv_scale = 1.0 / (m->meaninertia * m->nv);
+  p->inv_scale = 1.0 / (m->meaninertia * m->nv);  // MuJoCo scales the solver tolerance with the whole model
   for (int b = 0; b < nl; b++) {
     const double* I = m->body_inertia[b + 1];
     if (fabs(m->body_ipos[b + 1][1]) > 1e-12 || fabs(I[3]) + fabs(I[4]) + fabs(I[5]) > 1e-12)
@@ -234,6 +251,31 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
     for (int i = 0; i < NV; i++) qacc[i] += alpha * sr[i];
   }
   return status;
+}
+
+// A movable block in the swimmer's world: no contacts (collision="predefined"), gravity along z, so the only force on its
+// two slide dofs is the medium's drag on the box (same inertia-box model as the links, axis-aligned, no rotation).
+// One env.step = frame_skip RK4 steps of  dv/dt = -(3 pi mu d v + rho/2 A |v| v) / m  per axis.
+MZS_HD void swimmer_block_step(const SwimmerDev& P, double* q2, double* v2) {
+  const double* bx = P.block_box;
+  const double diam = (bx[0] + bx[1] + bx[2]) / 3.0, lin = 3.0 * P.viscosity * 3.141592653589793 * diam;
+  for (int ax = 0; ax < 2; ax++) {
+    const double area = ax == 0 ? bx[1] * bx[2] : bx[0] * bx[2];
+    double q = q2[ax], v = v2[ax];
+    for (int f = 0; f < P.frame_skip; f++) {
+      double qs = q, vs = v, accv = 0.0, accf = 0.0;
+      for (int st = 0; st < 4; st++) {
+        double a = -(lin * vs + 0.5 * P.density * area * fabs(vs) * vs) / P.block_mass;
+        double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
+        accv += bw * vs; accf += bw * a;
+        double nq = q + P.h * (aw * vs), nv = v + P.h * (aw * a);
+        qs = nq; vs = nv;
+      }
+      q += P.h * accv; v += P.h * accf;
+      (void)qs;
+    }
+    q2[ax] = q; v2[ax] = v;
+  }
 }
 
 // One MazeEnv.step: q, v in/out (fp64 working copy); info4 = x, y, reward_forward, reward_ctrl

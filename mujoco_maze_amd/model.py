@@ -249,7 +249,7 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     structure = task.create_maze()
     world = MazeWorld(structure, scale, maze_height)
     if world.elevated or world.has_balls:
-        raise NotImplementedError("mazes with chasms / object balls are not on the device path yet (SURVEY §8f rank 3)")
+        raise NotImplementedError("mazes with chasms (Fall) or object balls (Billiard) are not on the device path: see DESIGN.md section 8")
     blocks = world.movable_cells()
     if any(cell is not MazeCell.XY_BLOCK for _, _, cell in blocks):
         raise NotImplementedError("only XY_BLOCK movable blocks are supported (no z-moving / half / spin blocks yet)")

@@ -160,23 +160,37 @@ extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* 
 // ---------------------------------------------------------------- Swimmer: the per-lane step function of swimmer_step_kernel
 #include "../../mujoco_maze_amd/csrc/swimmer_dyn.h"
 
-template <int NL>
+template <int NL, int NB>
 static int swimmer_env_step_t(const SwimmerDev& P, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
                               float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
-  constexpr int NV = NL + 2, NH = NL - 1, NO = 2 * NV + 1;
+  constexpr int NR = NL + 2, NV = NR + 2 * NB, NH = NL - 1;
+  const int nb3 = P.observe_blocks ? 3 * NB : 0, NO = 2 * NR + 1 + nb3;
   for (int e = 0; e < n; e++) {
-    double q[NV], v[NV], a[NH], inner, inf4[4];
+    double q[NR], v[NR], a[NH], inner, inf4[4];
     for (int k = 0; k < NH; k++) a[k] = (double)actions[NH * e + k];
-    for (int k = 0; k < NV; k++) { q[k] = (double)qpos[NV * e + k]; v[k] = (double)qvel[NV * e + k]; }
+    for (int k = 0; k < NR; k++) { q[k] = (double)qpos[NV * e + k]; v[k] = (double)qvel[NV * e + k]; }
     int t_new;
     int st = swimmer_env_step<NL>(P, q, v, a, t[e], &inner, inf4, &t_new);
-    float o[NO];
-    for (int k = 0; k < NV; k++) { o[k] = (float)q[k]; o[NV + k] = (float)v[k]; }
-    o[2 * NV] = (float)t_new * 0.001f;
+    float bq[2 * NB + 1], bv[2 * NB + 1];
+    for (int b = 0; b < NB; b++) {
+      double q2[2] = {(double)qpos[NV * e + NR + 2 * b], (double)qpos[NV * e + NR + 2 * b + 1]};
+      double v2[2] = {(double)qvel[NV * e + NR + 2 * b], (double)qvel[NV * e + NR + 2 * b + 1]};
+      if (v2[0] != 0.0 || v2[1] != 0.0) swimmer_block_step(P, q2, v2);
+      bq[2 * b] = (float)q2[0]; bq[2 * b + 1] = (float)q2[1]; bv[2 * b] = (float)v2[0]; bv[2 * b + 1] = (float)v2[1];
+    }
+    float o[2 * NR + 1 + 3 * NB];
+    for (int k = 0; k < 3; k++) o[k] = (float)q[k];
+    for (int b = 0; b < NB && nb3; b++) {
+      o[3 + 3 * b] = (float)(P.block_pos0[b][0] + (double)bq[2 * b]); o[4 + 3 * b] = (float)(P.block_pos0[b][1] + (double)bq[2 * b + 1]);
+      o[5 + 3 * b] = (float)P.block_pos0[b][2];
+    }
+    for (int k = 3; k < NR; k++) o[nb3 + k] = (float)q[k];
+    for (int k = 0; k < NR; k++) o[nb3 + NR + k] = (float)v[k];
+    o[nb3 + 2 * NR] = (float)t_new * 0.001f;
     float outer; int tm, gi;
     task_eval_dev(P.task, o, &outer, &tm, &gi);
     for (int k = 0; k < NO; k++) obs[NO * e + k] = o[k];
-    for (int k = 0; k < NV; k++) { qpos[NV * e + k] = o[k]; qvel[NV * e + k] = o[NV + k]; }
+    for (int k = 0; k < NV; k++) { qpos[NV * e + k] = k < NR ? (float)q[k] : bq[k - NR]; qvel[NV * e + k] = k < NR ? (float)v[k] : bv[k - NR]; }
     reward[e] = (float)(P.task.inner_scale * inner) + outer;
     done[e] = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
     if (goal_idx) goal_idx[e] = gi;
@@ -193,6 +207,8 @@ extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float
   char err[128];
   int rc = swimmer_dev_from_model(&P, m, err, sizeof(err));
   if (rc != MZ_OK) return rc;
-  if (P.nlink == 3) return swimmer_env_step_t<3>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
-  return swimmer_env_step_t<2>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
+  if (P.nlink == 3) return P.nblock ? swimmer_env_step_t<3, 1>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
+                                    : swimmer_env_step_t<3, 0>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
+  return P.nblock ? swimmer_env_step_t<2, 1>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
+                  : swimmer_env_step_t<2, 0>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
 }

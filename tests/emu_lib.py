@@ -83,7 +83,7 @@ def swimmer_env_step(cm, st, actions):
     lib = load()
     n = st["qpos"].shape[0]
     a = np.ascontiguousarray(actions, np.float32)
-    out = dict(obs=np.zeros((n, 2 * cm.c.nv + 1), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+    out = dict(obs=np.zeros((n, cm.c.obs_dim), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
                goal_idx=np.zeros(n, np.int32), info=np.zeros((n, 4), np.float32), status=np.zeros(n, np.int32))
     rc = lib.emu_swimmer_env_step(C.byref(cm.c), n, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["t"]), _vp(a), _vp(out["obs"]),
                                   _vp(out["reward"]), _vp(out["done"]), _vp(out["goal_idx"]), _vp(out["info"]), _vp(out["status"]))

@@ -262,6 +262,41 @@ def test_point_with_movable_blocks(oracle, name, nblock):
     assert moved > 0.5  # blocks really get pushed around
 
 
+@pytest.mark.parametrize("robot", ["swimmer", "reacher"])
+def test_swimmer_world_with_a_movable_block(oracle, robot):
+    """SwimmerPush / ReacherPush: `collision="predefined"` (swimmer.xml:3) leaves the block without any contact pair, so it
+    just sits at its spawn position and appears in the observation (obs[3:6]).  A block that is given a velocity blows up in
+    the reference's medium (0.2 g box, viscous rate ~1.6e4 / s against h = 0.01): both paths must flag that env."""
+    from tests import emu_lib
+
+    cm = model.compile_model(robot, T.DistRewardPush(4.0), 4.0)
+    m = cm.c
+    nr = m.nv_robot
+    assert m.nblock == 1 and m.nv == nr + 2 and m.obs_dim == 2 * nr + 1 + 3
+    n = 64
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(0)
+    for k in range(21):
+        act = rng.uniform(-1.5, 1.5, (n, m.nu)).astype(np.float32)
+        if k in (0, 20):
+            s64 = _f32(st)
+            s32 = emu_lib.f32_state(s64)
+            ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=4)
+            re_ = emu_lib.swimmer_env_step(cm, s32, act)
+            assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 1e-6 + 2e-7 * np.abs(ro["obs"]))
+            assert np.array_equal(re_["obs"][:, 3:6], np.tile(np.array([0.0, 4.0, 1.0], np.float32), (n, 1)))  # block xyz slot
+            assert np.abs(re_["reward"] - ro["reward"]).max() < 1e-7 and np.all(re_["status"] == 0) and np.all(ro["status"] == 0)
+            assert np.all(s32["qpos"][:, nr:] == 0) and np.all(s32["qvel"][:, nr:] == 0)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=4)
+    s64 = _f32(st)
+    s64["qvel"][0, nr] = 0.5
+    s32 = emu_lib.f32_state(s64)
+    ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=4)
+    emu_lib.swimmer_env_step(cm, s32, act)
+    assert (ro["status"][0] & 1) and not np.isfinite(s32["qvel"][0, nr])  # unstable in both
+    assert np.all(ro["status"][1:] == 0) and np.all(np.isfinite(s32["qvel"][1:]))
+
+
 @pytest.mark.parametrize("robot,nq", [("swimmer", 5), ("reacher", 4)])
 def test_swimmer_step_logic(oracle, robot, nq):
     """Swimmer (north_star) and Reacher (its 2-link variant, reacher.py / reacher.xml): the kernel's

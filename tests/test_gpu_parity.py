@@ -351,6 +351,32 @@ def test_swimmer_step_parity(torch, oracle, robot, nq):
     single.close()
 
 
+@pytest.mark.parametrize("env_id", ["SwimmerPush-v0", "ReacherPush-v1"])
+def test_swimmer_world_with_a_movable_block(torch, oracle, env_id):
+    """No contact pairs in the swimmer's world (swimmer.xml:3): the block is inert and only occupies obs[3:6]."""
+    n = 512
+    env = mm.make(env_id, num_envs=n)
+    cm = env.model
+    nr = cm.c.nv_robot
+    assert env.obs_dim == 2 * nr + 4 and env.nv == nr + 2
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(0)
+    for k in range(6):
+        act = rng.uniform(-1.5, 1.5, (n, env.nu)).astype(np.float32)
+        if k in (0, 5):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], None, s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=1e-6, rtol=2e-7))
+            assert np.all(_close(rew.cpu().numpy(), ref["reward"], atol=1e-7))
+            assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.all(env.status().cpu().numpy() == 0)
+            qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+            assert np.all(qpos[:, nr:] == 0) and np.all(qvel[:, nr:] == 0)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    env.close()
+
+
 def test_reset_distribution_and_oracle_rng(torch, oracle):
     n = 2048
     for env_id, nq, nv in (("AntUMaze-v0", 15, 14), ("PointUMaze-v0", 3, 3), ("SwimmerUMaze-v0", 5, 5)):
