@@ -498,3 +498,32 @@ def test_single_env_facade_shapes(torch):
     env = mm.make("Point4Rooms-v2")
     assert len(env._task.goals) > 1
     env.close()
+
+
+@pytest.mark.parametrize("env_id", ["AntUMaze-v0", "AntPush-v0", "PointUMaze-v0", "PointPush-v0", "SwimmerUMaze-v0", "ReacherUMaze-v0"])
+def test_ragged_batch_sizes_and_argument_errors(torch, oracle, env_id):
+    """Batches that do not fill the last workgroup (2 or 4 envs per wavefront) and a batch of one; bad arguments raise."""
+    rng = np.random.default_rng(4)
+    for n in (1, 3, 37):
+        env = mm.make(env_id, num_envs=n, force_vec=True)
+        cm = env.model
+        st, _ = oracle.reset(cm, n, 8)
+        s64 = _f32(st)
+        lo, hi = env.action_space.low, env.action_space.high
+        act = rng.uniform(lo, hi, (n, env.nu)).astype(np.float32)
+        env.set_state(s64["qpos"], s64["qvel"], s64["warm"] if env_id.startswith("Ant") else None, s64["t"])
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+        ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=2)
+        assert obs.shape == (n, env.obs_dim) and rew.shape == (n,) and done.shape == (n,)
+        assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=2e-5))
+        assert np.array_equal(done.cpu().numpy(), ref["done"])
+        assert np.all(env.status().cpu().numpy() == 0)
+        with pytest.raises(ValueError):
+            env.step(torch.zeros((n + 1, env.nu), device=env.device))
+        obs64, *_ = env.step(torch.zeros((n, env.nu), device=env.device, dtype=torch.float64))  # converted, not rejected
+        assert obs64.dtype == torch.float32
+        env.close()
+    with pytest.raises(KeyError):
+        mm.make("AntNoSuchMaze-v0")
+    with pytest.raises(NotImplementedError):
+        mm.make("AntFall-v0", num_envs=2)
