@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZ_ABI_VERSION 1
+#define MZ_ABI_VERSION 2
 
 #define MZ_MAX_BODY 24
 #define MZ_MAX_JNT 24
@@ -200,6 +200,12 @@ typedef struct mz_model {
   int32_t nblock, observe_blocks;
   int32_t block_bodyid[4];
   int32_t block_geomid[4];
+
+  /* object balls (Billiard; maze_env.py:167-191, 489-536: body at z = 0 with slide-x, slide-y and a z hinge, sphere geom
+   * of radius r at height r); observed as body xpos BEFORE the blocks when observe_balls (maze_env.py:360-363) */
+  int32_t nball, observe_balls;
+  int32_t ball_bodyid[4];
+  int32_t ball_geomid[4];
 } mz_model;
 
 typedef struct mz_handle mz_handle;

@@ -299,18 +299,18 @@ __global__ void ant_get_state_kernel(AntLayout L, int n, const float* state, flo
 // ------------------------------------------------------------------ Point kernels (SoA: q0 q1 q2 v0 v1 v2 | t | episode)
 struct PointState { float* qv; int* t; uint32_t* ep; };
 
-// One MazeEnv.step of the Point (+ NB movable blocks): G lanes per env, PlanarScratch in LDS, SoA state in HBM
+// One MazeEnv.step of the Point (+ NB movable blocks or NS object balls): G lanes per env, PlanarScratch in LDS, SoA state in HBM
 // (q_0..q_{NV-1} | v_0..v_{NV-1}, each [n]).
-template <int NB, int G>
+template <int NB, int NS, int G>
 __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
                                                           const float* __restrict__ actions, float* __restrict__ obs,
                                                           float* __restrict__ reward, uint8_t* __restrict__ done,
                                                           int* __restrict__ goal_idx, float* __restrict__ info,
                                                           int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0) {
-  using D = PlanarDims<NB>;
+  using D = PlanarDims<NB, NS>;
   constexpr int NV = D::NV, NOBS = D::NOBS, EPW = 64 / G;
   __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
-  __shared__ PlanarScratch<NB> scr[EPW];
+  __shared__ PlanarScratch<NB, NS> scr[EPW];
   __shared__ float obuf[EPW][MZ_MAX_OBS];
   for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
   __syncthreads();
@@ -319,14 +319,14 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restr
   int env = blockIdx.x * EPW + grp;
   const bool live = env < n;
   if (!live) env = n - 1;  // idle groups shadow the last env (no stores) so that every lane reaches the wave-level votes
-  PlanarScratch<NB>& s = scr[grp];
+  PlanarScratch<NB, NS>& s = scr[grp];
   for (int k = cx.l; k < NV; k += G) { s.q[k] = (double)S.qv[(size_t)k * n + env]; s.v[k] = (double)S.qv[(size_t)(NV + k) * n + env]; }
   double a[2] = {(double)actions[(size_t)env * 2], (double)actions[(size_t)env * 2 + 1]};
   const int t_new = S.t[env] + 1;
   cx.sync();
-  planar_env_step<NB>(cx, P, s, a);
+  planar_env_step<NB, NS>(cx, P, s, a);
   float* o = obuf[grp];
-  for (int i = cx.l; i < NOBS; i += G) o[i] = planar_obs_elem<NB>(P, s, i, t_new);
+  for (int i = cx.l; i < NOBS; i += G) o[i] = planar_obs_elem<NB, NS>(P, s, i, t_new);
   cx.sync();
   float outer; int tm, gi;
   task_eval_dev(P.task, o, &outer, &tm, &gi);  // flags from the fp32 observation that is returned
@@ -361,9 +361,9 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restr
   }
 }
 
-template <int NB>
+template <int NB, int NS>
 __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
-  constexpr int NV = 3 + 2 * NB, NOBS = 7 + 3 * NB;
+  constexpr int NV = 3 + 2 * NB + 3 * NS, NOBS = 7 + 3 * NB + 3 * NS;
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   if (!mask || mask[env]) {
@@ -375,9 +375,13 @@ __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, cons
     S.ep[env] = 0;
   }
   if (obs) {
-    const int nb3 = Pp->observe_blocks ? 3 * NB : 0;
+    const int nb3 = (Pp->observe_blocks ? 3 * NB : 0) + (Pp->observe_balls ? 3 * NS : 0);
     float* o = obs + (size_t)env * NOBS;
     for (int k = 0; k < 3; k++) { o[k] = S.qv[(size_t)k * n + env]; o[3 + nb3 + k] = S.qv[(size_t)(NV + k) * n + env]; }
+    if (NS > 0 && nb3) {
+      o[3] = (float)Pp->ball_pos0[0] + S.qv[(size_t)3 * n + env]; o[4] = (float)Pp->ball_pos0[1] + S.qv[(size_t)4 * n + env];
+      o[5] = (float)Pp->ball_pos0[2];
+    }
     for (int b = 0; b < NB && nb3; b++) {
       o[3 + 3 * b] = (float)Pp->block_pos0[b][0] + S.qv[(size_t)(3 + 2 * b) * n + env];
       o[4 + 3 * b] = (float)Pp->block_pos0[b][1] + S.qv[(size_t)(4 + 2 * b) * n + env];
@@ -632,7 +636,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     if (e == hipSuccess) e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock + 3 * h->point.nball;
     e = hipMalloc(&h->state, (size_t)num_envs * 2 * kq * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
@@ -730,11 +734,12 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
 #undef MZ_SW_RESET
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    switch (h->point.nblock) {
-      case 0: hipLaunchKernelGGL(point_reset_kernel<0>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
-      case 1: hipLaunchKernelGGL(point_reset_kernel<1>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
-      case 2: hipLaunchKernelGGL(point_reset_kernel<2>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
-      default: hipLaunchKernelGGL(point_reset_kernel<3>, dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+    if (h->point.nball) hipLaunchKernelGGL((point_reset_kernel<0, 1>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+    else switch (h->point.nblock) {
+      case 0: hipLaunchKernelGGL((point_reset_kernel<0, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+      case 1: hipLaunchKernelGGL((point_reset_kernel<1, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+      case 2: hipLaunchKernelGGL((point_reset_kernel<2, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+      default: hipLaunchKernelGGL((point_reset_kernel<3, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
     }
   }
   HIPCHK(h, hipGetLastError());
@@ -750,7 +755,7 @@ int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev,
     hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock + 3 * h->point.nball;
     const dim3 grid((h->n + 255) / 256), blk(256);
     switch (kq) {
       case 3: hipLaunchKernelGGL(point_set_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
@@ -773,7 +778,7 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
     hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos_dev, qvel_dev, warmstart_dev, t_dev);
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
-    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock;
+    const int kq = h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock + 3 * h->point.nball;
     const dim3 grid((h->n + 255) / 256), blk(256);
     switch (kq) {
       case 3: hipLaunchKernelGGL(point_get_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
@@ -815,18 +820,19 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   } else {
     PointState S{h->state, h->pt_t, h->pt_ep};
     // lanes per env: 16 for the bare robot (18 collision enumerators), 32 / 64 with blocks (bigger contact sets in LDS)
-#define MZ_PLANAR_LAUNCH(NB, G)                                                                                                     \
-  hipLaunchKernelGGL((planar_step_kernel<NB, G>), dim3((h->n + 64 / G - 1) / (64 / G)), dim3(64), 0, st, h->point_dev, h->n, S, actions_dev, \
+#define MZ_PLANAR_LAUNCH(NB, NS, G)                                                                                                    \
+  hipLaunchKernelGGL((planar_step_kernel<NB, NS, G>), dim3((h->n + 64 / G - 1) / (64 / G)), dim3(64), 0, st, h->point_dev, h->n, S, actions_dev, \
                      obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0)
-    switch (h->point.nblock) {
+    if (h->point.nball) MZ_PLANAR_LAUNCH(0, 1, 32);
+    else switch (h->point.nblock) {
       case 0:
-        if (h->lanes_set && h->lanes == 8) MZ_PLANAR_LAUNCH(0, 8);
-        else if (h->lanes_set && h->lanes == 32) MZ_PLANAR_LAUNCH(0, 32);
-        else MZ_PLANAR_LAUNCH(0, 16);
+        if (h->lanes_set && h->lanes == 8) MZ_PLANAR_LAUNCH(0, 0, 8);
+        else if (h->lanes_set && h->lanes == 32) MZ_PLANAR_LAUNCH(0, 0, 32);
+        else MZ_PLANAR_LAUNCH(0, 0, 16);
         break;
-      case 1: MZ_PLANAR_LAUNCH(1, 32); break;
-      case 2: MZ_PLANAR_LAUNCH(2, 64); break;
-      default: MZ_PLANAR_LAUNCH(3, 64); break;
+      case 1: MZ_PLANAR_LAUNCH(1, 0, 32); break;
+      case 2: MZ_PLANAR_LAUNCH(2, 0, 64); break;
+      default: MZ_PLANAR_LAUNCH(3, 0, 64); break;
     }
 #undef MZ_PLANAR_LAUNCH
   }

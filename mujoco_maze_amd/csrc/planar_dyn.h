@@ -1,6 +1,6 @@
 // planar_dyn.h — the Point robot's MazeEnv.step with NB movable XY blocks, as lane-group SPMD code (fp64).
 //
-// Same programming model as ant_dyn.h: G lanes advance one environment, its working set (PlanarScratch<NB>) lives
+// Same programming model as ant_dyn.h: G lanes advance one environment, its working set (PlanarScratch<NB, NS>) lives
 // in LDS for the whole step, a phase is an MZ_FOR over independent items, cx.sync() is the hand-off.  The
 // single-lane host context (tests/emu) runs the same source on the CPU.
 //
@@ -21,18 +21,21 @@
 #include "ant_dyn.h"    // MZ_FOR, HostCtx, maze_row
 #include "point_dyn.h"  // PointDev, point_detect, pt_impedance
 
-template <int NB>
+template <int NB, int NS>
 struct PlanarDims {
-  static constexpr int NV = 3 + 2 * NB;
-  static constexpr int NC = NB == 0 ? 12 : (NB == 1 ? 40 : (NB == 2 ? 64 : 96));  // contact slots
-  // enumerators: 9 sphere-wall, 9 arrow-wall | per block: sphere-block, arrow-block, 9 block-wall | block pairs
-  static constexpr int NE = 18 + 11 * NB + NB * (NB - 1) / 2;
-  static constexpr int NOBS = 7 + 3 * NB;
+  static_assert(NB == 0 || NS == 0, "no registered maze mixes movable blocks and object balls");
+  static_assert(NS <= 1, "one object ball");
+  static constexpr int NV = 3 + 2 * NB + 3 * NS;  // robot x, y, theta | block x, y ... | ball x, y, spin
+  static constexpr int NC = NB == 0 ? 12 + 4 * NS : (NB == 1 ? 40 : (NB == 2 ? 64 : 96));  // contact slots
+  // enumerators: 9 sphere-wall, 9 arrow-wall | per block: sphere-block, arrow-block, 9 block-wall | block pairs |
+  //              per ball: 9 ball-wall, robot sphere-ball, ball-arrow
+  static constexpr int NE = 18 + 11 * NB + NB * (NB - 1) / 2 + 11 * NS;
+  static constexpr int NOBS = 7 + 3 * NB + 3 * NS;
 };
 
-template <int NB>
+template <int NB, int NS>
 struct alignas(16) PlanarScratch {
-  using D = PlanarDims<NB>;
+  using D = PlanarDims<NB, NS>;
   double q[D::NV], v[D::NV];  // state of the current RK4 stage
   double x0[D::NV], v0[D::NV], accv[D::NV], accf[D::NV];
   double qas[D::NV], qacc[D::NV], grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
@@ -44,12 +47,15 @@ struct alignas(16) PlanarScratch {
 };
 
 // ---- small helpers
+template <int NB>
 MZP_HD double pl_mass(const PointDev& P, const double M3[3][3], int i, int j) {
   if (i < 3 && j < 3) return M3[i][j];
-  return i == j ? P.block_mass : 0.0;
+  if (i != j) return 0.0;
+  if (i < 3 + 2 * NB) return P.block_mass;
+  return (i - 3 - 2 * NB) % 3 == 2 ? P.ball_izz : P.ball_mass;
 }
-template <int NB>
-MZP_HD void pl_block_center(const PointDev& P, const PlanarScratch<NB>& s, int b, double* c) {
+template <int NB, int NS>
+MZP_HD void pl_block_center(const PointDev& P, const PlanarScratch<NB, NS>& s, int b, double* c) {
   c[0] = P.block_pos0[b][0] + s.q[3 + 2 * b]; c[1] = P.block_pos0[b][1] + s.q[4 + 2 * b]; c[2] = P.block_pos0[b][2];
 }
 
@@ -165,8 +171,8 @@ MZP_HD bool pl_wall_cell(const MazeDev& z, double x, double y, int k9, double* w
 }
 
 // Contacts of enumerator e, in a fixed order (identical in the count and the fill pass)
-template <int NB, class Emit>
-MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB>& s, int e, Emit&& emit) {
+template <int NB, int NS, class Emit>
+MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, int e, Emit&& emit) {
   const MazeDev& z = P.maze;
   double wh[3] = {z.half_xy, z.half_xy, z.half_z};
   double arrow[2] = {s.q[0] + P.arr_off * s.co, s.q[1] + P.arr_off * s.si};
@@ -189,12 +195,49 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB>& s, int e
     }
     return;
   }
+  if constexpr (NS > 0) {  // ---- object ball (body 1): 9 wall cells, the robot's sphere, the arrow
+    int k = e - 18;
+    double bc[3] = {P.ball_pos0[0] + s.q[3], P.ball_pos0[1] + s.q[4], P.ball_r};  // sphere centre
+    if (k < 9) {  // ball (sphere, geom1) vs wall (geom2)
+      double wc[3];
+      if (!pl_wall_cell(z, bc[0], bc[1], k, wc)) return;
+      double c[3] = {bc[0] - wc[0], bc[1] - wc[1], bc[2] - wc[2]}, dd, nrm[3];
+      if (!pl_sphere_box(c, P.ball_r, wh, P.pair[4].margin, &dd, nrm)) return;
+      PlContact ct;
+      ct.dist = dd;
+      for (int q = 0; q < 3; q++) { ct.n[q] = nrm[q]; ct.pos[q] = bc[q] + nrm[q] * (P.ball_r + 0.5 * dd); }
+      ct.b1 = 1; ct.b2 = -1; ct.cls = 4;
+      emit(ct);
+    } else if (k == 9) {  // robot sphere (geom1) vs ball (geom2)
+      double dv[3] = {bc[0] - s.q[0], bc[1] - s.q[1], bc[2] - P.sph_z};
+      double cd = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]), dd = cd - P.sph_r - P.ball_r;
+      if (dd > P.pair[5].margin) return;
+      PlContact ct;
+      ct.dist = dd;
+      if (cd < 1e-15) { ct.n[0] = 1.0; ct.n[1] = 0.0; ct.n[2] = 0.0; }
+      else { ct.n[0] = dv[0] / cd; ct.n[1] = dv[1] / cd; ct.n[2] = dv[2] / cd; }
+      ct.pos[0] = s.q[0] + ct.n[0] * (P.sph_r + 0.5 * dd); ct.pos[1] = s.q[1] + ct.n[1] * (P.sph_r + 0.5 * dd); ct.pos[2] = P.sph_z + ct.n[2] * (P.sph_r + 0.5 * dd);
+      ct.b1 = 0; ct.b2 = 1; ct.cls = 5;
+      emit(ct);
+    } else {  // ball (sphere, geom1) vs arrow (box rotated about z, geom2): sphere-box in the arrow's frame
+      double rel[3] = {bc[0] - arrow[0], bc[1] - arrow[1], bc[2] - P.arr_z};
+      double c[3] = {s.co * rel[0] + s.si * rel[1], -s.si * rel[0] + s.co * rel[1], rel[2]}, ah[3] = {P.arr_hx, P.arr_hy, P.arr_hz}, dd, nl[3];
+      if (!pl_sphere_box(c, P.ball_r, ah, P.pair[5].margin, &dd, nl)) return;
+      PlContact ct;
+      ct.dist = dd;
+      ct.n[0] = s.co * nl[0] - s.si * nl[1]; ct.n[1] = s.si * nl[0] + s.co * nl[1]; ct.n[2] = nl[2];
+      for (int q = 0; q < 3; q++) ct.pos[q] = bc[q] + ct.n[q] * (P.ball_r + 0.5 * dd);
+      ct.b1 = 1; ct.b2 = 0; ct.cls = 5;
+      emit(ct);
+    }
+    return;
+  }
   if constexpr (NB > 0) {
     int r = e - 18;
     if (r < 11 * NB) {
       int b = r / 11, k = r - 11 * b;
       double bc[3];
-      pl_block_center<NB>(P, s, b, bc);
+      pl_block_center<NB, NS>(P, s, b, bc);
       if (k == 0) {         // sphere (geom1) vs block (geom2)
         const PtPair& pr = P.pair[1];
         double c[3] = {s.q[0] - bc[0], s.q[1] - bc[1], P.sph_z - bc[2]}, dd, nrm[3];
@@ -219,8 +262,8 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB>& s, int e
       if (p == 1) { a = 0; b = 2; } else if (p == 2) { a = 1; b = 2; }
       if (b < NB) {
         double ca[3], cb[3];
-        pl_block_center<NB>(P, s, a, ca);
-        pl_block_center<NB>(P, s, b, cb);
+        pl_block_center<NB, NS>(P, s, a, ca);
+        pl_block_center<NB, NS>(P, s, b, cb);
         pl_box_box(ca, P.block_half, cb, P.block_half, P.pair[3].margin, 1 + a, 1 + b, 3, emit);
       }
     }
@@ -228,20 +271,24 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB>& s, int e
 }
 
 // Jacobian row of body `body` for a unit force direction f at the world point p
-template <int NB>
-MZP_HD void pl_add_body_row(const PlanarScratch<NB>& s, int body, const double* f, const double* p, double sgn, double* J) {
+template <int NB, int NS>
+MZP_HD void pl_add_body_row(const PointDev& P, const PlanarScratch<NB, NS>& s, int body, const double* f, const double* p, double sgn, double* J) {
   if (body == 0) {
     double rx = p[0] - s.q[0], ry = p[1] - s.q[1];
     J[0] += sgn * f[0]; J[1] += sgn * f[1]; J[2] += sgn * (-f[0] * ry + f[1] * rx);
   } else if (body > 0) {
+    if constexpr (NS > 0) {  // the ball: slide x, slide y, hinge z through the body origin
+      double rx = p[0] - (P.ball_pos0[0] + s.q[3]), ry = p[1] - (P.ball_pos0[1] + s.q[4]);
+      J[3] += sgn * f[0]; J[4] += sgn * f[1]; J[5] += sgn * (-f[0] * ry + f[1] * rx);
+    }
     for (int b = 0; b < NB; b++)
       if (b == body - 1) { J[3 + 2 * b] += sgn * f[0]; J[4 + 2 * b] += sgn * f[1]; }
   }
 }
 
-template <int NB>
-MZP_HD void planar_fill_contact(const PointDev& P, PlanarScratch<NB>& s, int slot, const PlContact& c) {
-  constexpr int NV = PlanarDims<NB>::NV;
+template <int NB, int NS>
+MZP_HD void planar_fill_contact(const PointDev& P, PlanarScratch<NB, NS>& s, int slot, const PlContact& c) {
+  constexpr int NV = PlanarDims<NB, NS>::NV;
   const PtPair& pr = P.pair[c.cls];
   const double* n = c.n;
   double y[3] = {0.0, (n[1] < 0.5 && n[1] > -0.5) ? 1.0 : 0.0, 0.0};
@@ -259,8 +306,8 @@ MZP_HD void planar_fill_contact(const PointDev& P, PlanarScratch<NB>& s, int slo
     double sc = a == 0 ? 1.0 : pr.mu;
     double J[NV];
     for (int i = 0; i < NV; i++) J[i] = 0.0;
-    pl_add_body_row<NB>(s, c.b2, f, c.pos, sc, J);
-    pl_add_body_row<NB>(s, c.b1, f, c.pos, -sc, J);
+    pl_add_body_row<NB, NS>(P, s, c.b2, f, c.pos, sc, J);
+    pl_add_body_row<NB, NS>(P, s, c.b1, f, c.pos, -sc, J);
     double vel = 0.0;
     for (int i = 0; i < NV; i++) { s.cJ[slot][a][i] = J[i]; vel += J[i] * s.v[i]; }
     s.caref[slot][a] = -pr.B * vel - (a == 0 ? pr.K * imp * (c.dist - pr.margin) : 0.0);
@@ -276,9 +323,9 @@ MZP_HD void pl_contact_eval(double D, const double* u, double* g, double* W) {
 }
 
 // ------------------------------------------------------------------ one forward-dynamics evaluation: s.q, s.v -> s.qacc
-template <int NB, class C>
-MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s) {
-  using D = PlanarDims<NB>;
+template <int NB, int NS, class C>
+MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s) {
+  using D = PlanarDims<NB, NS>;
   constexpr int NV = D::NV, NC = D::NC, NE = D::NE;
   MZ_FOR(one, 1) {
     double co = cos(s.q[2]), si = sin(s.q[2]), w2 = s.v[2] * s.v[2], mc = P.mass * P.com_x;
@@ -292,12 +339,12 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s)
   }
   cx.sync();
   MZ_FOR(i, NV) s.qacc[i] = s.qas[i];
-  bool maybe = NB > 0 || s.robot_near != 0;  // group-uniform
+  bool maybe = NB + NS > 0 || s.robot_near != 0;  // group-uniform
   if (!cx.any(maybe)) { cx.sync(); return; }
   // ---- collision: count, prefix, fill
   MZ_FOR(e, NE) {
     int n = 0;
-    if (maybe) planar_contacts<NB>(P, s, e, [&](const PlContact& c) { if (c.dist < P.pair[c.cls].margin) n++; });
+    if (maybe) planar_contacts<NB, NS>(P, s, e, [&](const PlContact& c) { if (c.dist < P.pair[c.cls].margin) n++; });
     s.cnt[e] = n;
   }
   cx.sync();
@@ -313,8 +360,8 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s)
   MZ_FOR(e, NE) {
     if (s.cnt[e] > 0) {
       int slot = s.cbeg[e];
-      planar_contacts<NB>(P, s, e, [&](const PlContact& c) {
-        if (c.dist < P.pair[c.cls].margin) { if (slot < NC) planar_fill_contact<NB>(P, s, slot, c); slot++; }
+      planar_contacts<NB, NS>(P, s, e, [&](const PlContact& c) {
+        if (c.dist < P.pair[c.cls].margin) { if (slot < NC) planar_fill_contact<NB, NS>(P, s, slot, c); slot++; }
       });
     }
   }
@@ -325,7 +372,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s)
   while (cx.any(!done) && it < 50) {
     MZ_FOR(i, NV) {
       double t = 0.0;
-      for (int j = 0; j < NV; j++) t += pl_mass(P, s.M3, i, j) * (s.qacc[j] - s.qas[j]);
+      for (int j = 0; j < NV; j++) t += pl_mass<NB>(P, s.M3, i, j) * (s.qacc[j] - s.qas[j]);
       s.Mx[i] = t;
     }
     MZ_FOR(c, ncon) {
@@ -351,7 +398,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s)
     if (it == 49 && !done) { MZ_FOR(one, 1) s.status |= MZ_STATUS_SOLVER_MAXITER; }
     MZ_FOR(e, NV * NV) {
       int i = e / NV, j = e - NV * i;
-      double acc = pl_mass(P, s.M3, i, j);
+      double acc = pl_mass<NB>(P, s.M3, i, j);
       for (int c = 0; c < ncon; c++) {
         double ni = s.cJ[c][0][i], pi = s.cJ[c][1][i], qi = s.cJ[c][2][i], nj = s.cJ[c][0][j], pj = s.cJ[c][1][j], qj = s.cJ[c][2][j];
         const double* W = s.cW[c];
@@ -381,7 +428,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s)
     double p1p = 0.0, p2p = 0.0;
     MZ_FOR(i, NV) {
       double t = 0.0;
-      for (int j = 0; j < NV; j++) t += pl_mass(P, s.M3, i, j) * s.search[j];
+      for (int j = 0; j < NV; j++) t += pl_mass<NB>(P, s.M3, i, j) * s.search[j];
       p1p += s.search[i] * s.Mx[i]; p2p += s.search[i] * t;
     }
     MZ_FOR(c, ncon) {
@@ -425,9 +472,9 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB>& s)
 }
 
 // ------------------------------------------------------------------ One MazeEnv.step.  s.q / s.v hold the state in and out.
-template <int NB, class C>
-MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB>& s, const double* action) {
-  constexpr int NV = PlanarDims<NB>::NV;
+template <int NB, int NS, class C>
+MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, const double* action) {
+  constexpr int NV = PlanarDims<NB, NS>::NV;
   const double PI = 3.141592653589793;
   double old_x = s.q[0], old_y = s.q[1];  // every lane reads the same values
   cx.sync();
@@ -447,7 +494,7 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB>& s
     MZ_FOR(i, NV) { s.x0[i] = s.q[i]; s.v0[i] = s.v[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; }
     cx.sync();
     for (int st = 0; st < 4; st++) {
-      planar_forward<NB>(cx, P, s);
+      planar_forward<NB, NS>(cx, P, s);
       double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
       MZ_FOR(i, NV) {
         s.accv[i] += bw * s.v[i]; s.accf[i] += bw * s.qacc[i];
@@ -477,11 +524,14 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB>& s
   }
 }
 
-// observation element i of the returned row: qpos[:3] | block xyz ... | qvel[:3] | t * 0.001  (maze_env.py:351-369)
-template <int NB>
-MZP_HD float planar_obs_elem(const PointDev& P, const PlanarScratch<NB>& s, int i, int t) {
-  int nb3 = P.observe_blocks ? 3 * NB : 0;
+// observation element i of the returned row: qpos[:3] | ball xyz | block xyz ... | qvel[:3] | t * 0.001  (maze_env.py:351-369)
+template <int NB, int NS>
+MZP_HD float planar_obs_elem(const PointDev& P, const PlanarScratch<NB, NS>& s, int i, int t) {
+  int nb3 = (P.observe_blocks ? 3 * NB : 0) + (P.observe_balls ? 3 * NS : 0);
   if (i < 3) return (float)s.q[i];
+  if constexpr (NS > 0) {
+    if (i < 3 + nb3) return (float)(i == 5 ? P.ball_pos0[2] : P.ball_pos0[i - 3] + s.q[i]);  // body frame origin: z = 0
+  }
   if (i < 3 + nb3) {
     int b = (i - 3) / 3, c = (i - 3) % 3;
     return (float)(c == 2 ? P.block_pos0[b][2] : P.block_pos0[b][c] + s.q[3 + 2 * b + c]);

@@ -36,13 +36,17 @@ struct PointDev {
   int frame_skip, nseg;
   double seg[MZ_MAX_SEG][4];
   double reach;  // arrow tip distance from the torso origin (wall broad phase)
-  // MuJoCo contact regime: body, geoms, pair classes 0 robot-wall, 1 robot-block, 2 wall-block, 3 block-block
+  // MuJoCo contact regime: body, geoms, pair classes 0 robot-wall, 1 robot-block, 2 wall-block, 3 block-block,
+  // 4 ball-wall, 5 robot-ball
   double mass, izz, inv_scale;
   double sph_r, sph_z, arr_off, arr_hx, arr_hy, arr_hz, arr_z;
-  PtPair pair[4];
+  PtPair pair[6];
   // movable XY blocks (maze_env.py:563-660), all of one size
   int nblock, observe_blocks;
   double block_mass, block_half[3], block_pos0[3][3];
+  // object ball (Billiard, maze_env.py:489-536): slide-x + slide-y + z hinge body, sphere of radius ball_r at height ball_r
+  int nball, observe_balls;
+  double ball_mass, ball_izz, ball_r, ball_pos0[3];
   MazeDev maze;
   TaskDev task;
   double qpos0[3];
@@ -63,8 +67,9 @@ static inline void pt_mix_pair(PtPair* p, double h, double m1, double m2, const 
 
 static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err, int errlen) {
   memset(p, 0, sizeof(*p));
-  const int nb = m->nblock;
-  if (m->robot != MZ_ROBOT_POINT || nb < 0 || nb > 3 || m->nv != 3 + 2 * nb || m->nq != 3 + 2 * nb || m->jnt_type[0] != MZ_JNT_SLIDE ||
+  const int nb = m->nblock, ns = m->nball;
+  if (ns < 0 || ns > 1 || (ns && nb)) return ant_fail(err, errlen, "point kernel: at most one object ball, and not together with movable blocks");
+  if (m->robot != MZ_ROBOT_POINT || nb < 0 || nb > 3 || m->nv != 3 + 2 * nb + 3 * ns || m->nq != 3 + 2 * nb + 3 * ns || m->jnt_type[0] != MZ_JNT_SLIDE ||
       m->jnt_type[1] != MZ_JNT_SLIDE || m->jnt_type[2] != MZ_JNT_HINGE || fabs(m->body_ipos[1][1]) > 1e-12)
     return ant_fail(err, errlen, "point kernel: model is not the slide-slide-hinge point robot (+ up to 3 XY blocks)");
   p->h = m->timestep; p->com_x = m->body_ipos[1][0]; p->vel_limit = m->velocity_limit; p->restitution = m->restitution;
@@ -73,7 +78,7 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
   p->mass = m->body_mass[1];
   p->izz = m->body_inertia[1][2] + m->body_mass[1] * m->body_ipos[1][0] * m->body_ipos[1][0];
   p->inv_scale = 1.0 / (m->meaninertia * m->nv);
-  if (m->ngeom != 3 + nb || m->geom_type[1] != MZ_GEOM_SPHERE || m->geom_type[2] != MZ_GEOM_BOX)
+  if (m->ngeom != 3 + nb + ns || m->geom_type[1] != MZ_GEOM_SPHERE || m->geom_type[2] != MZ_GEOM_BOX)
     return ant_fail(err, errlen, "point kernel: expected floor + sphere + arrow box (+ block) geoms");
   p->sph_r = m->geom_size[1][0]; p->sph_z = m->geom_pos[1][2];
   p->arr_off = m->geom_pos[2][0]; p->arr_hx = m->geom_size[2][0]; p->arr_hy = m->geom_size[2][1]; p->arr_hz = m->geom_size[2][2];
@@ -106,6 +111,23 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
                 m->geom_solref[g], m->wall_solimp, m->geom_solimp[g], bw_block);
     pt_mix_pair(&p->pair[3], m->timestep, m->geom_margin[g], m->geom_margin[g], m->geom_friction[g], m->geom_friction[g], m->geom_solref[g],
                 m->geom_solref[g], m->geom_solimp[g], m->geom_solimp[g], 2.0 * bw_block);
+  }
+  p->nball = ns; p->observe_balls = m->observe_balls;
+  if (ns > 0) {
+    int b = m->ball_bodyid[0], g = m->ball_geomid[0], j0 = m->body_jntadr[b];
+    if (m->body_jntnum[b] != 3 || m->jnt_type[j0] != MZ_JNT_SLIDE || m->jnt_type[j0 + 1] != MZ_JNT_SLIDE || m->jnt_type[j0 + 2] != MZ_JNT_HINGE ||
+        m->geom_type[g] != MZ_GEOM_SPHERE || m->body_dofadr[b] != 3 || fabs(m->jnt_axis[j0][0] - 1.0) > 1e-12 ||
+        fabs(m->jnt_axis[j0 + 1][1] - 1.0) > 1e-12 || fabs(m->jnt_axis[j0 + 2][2] - 1.0) > 1e-12 || m->jnt_limited[j0] || m->jnt_limited[j0 + 1] ||
+        m->jnt_limited[j0 + 2] || m->geom_margin[g] != 0.0 || fabs(m->geom_pos[g][0]) + fabs(m->geom_pos[g][1]) > 1e-12 ||
+        fabs(m->geom_pos[g][2] - m->geom_size[g][0]) > 1e-12 || m->dof_armature[3] != 0.0 || m->dof_damping[3] != 0.0 || m->dof_damping[5] != 0.0)
+      return ant_fail(err, errlen, "point kernel: object ball is not the slide-x / slide-y / hinge-z sphere body resting on the floor");
+    p->ball_mass = m->body_mass[b]; p->ball_izz = m->body_inertia[b][2]; p->ball_r = m->geom_size[g][0];
+    for (int q = 0; q < 3; q++) p->ball_pos0[q] = m->body_pos[b][q];
+    const double bw_ball = m->body_invweight0[b][0];
+    pt_mix_pair(&p->pair[4], m->timestep, m->geom_margin[g], m->wall_margin, m->geom_friction[g], m->wall_friction, m->geom_solref[g],
+                m->wall_solref, m->geom_solimp[g], m->wall_solimp, bw_ball);
+    pt_mix_pair(&p->pair[5], m->timestep, m->geom_margin[1], m->geom_margin[g], m->geom_friction[1], m->geom_friction[g], m->geom_solref[1],
+                m->geom_solref[g], m->geom_solimp[1], m->geom_solimp[g], bw_robot + bw_ball);
   }
   if (m->wall_margin != 0.0) return ant_fail(err, errlen, "point kernel: wall margin must be 0");
   p->reach = 0.0;

@@ -128,6 +128,13 @@ void mzo_task_eval(const mz_model* m, const double* obs, double* reward, int* do
 void mzo_env_obs(const mz_model* m, const mzo_env_state* s, double* obs) {
   int k = 0;
   for (int i = 0; i < 3; i++) obs[k++] = s->qpos[i];
+  if (m->observe_balls) /* balls come before blocks (maze_env.py:360-363); get_body_com = body frame origin: z stays 0 */
+    for (int b = 0; b < m->nball; b++) {
+      int body = m->ball_bodyid[b], j0 = m->body_jntadr[body];
+      obs[k++] = m->body_pos[body][0] + s->qpos[m->jnt_qposadr[j0]] - m->qpos0[m->jnt_qposadr[j0]];
+      obs[k++] = m->body_pos[body][1] + s->qpos[m->jnt_qposadr[j0 + 1]] - m->qpos0[m->jnt_qposadr[j0 + 1]];
+      obs[k++] = m->body_pos[body][2];
+    }
   if (m->observe_blocks) /* body xpos of every movable block (maze_env.py:364-368); XY blocks only translate */
     for (int b = 0; b < m->nblock; b++) {
       int body = m->block_bodyid[b], j0 = m->body_jntadr[body];

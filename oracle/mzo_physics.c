@@ -745,7 +745,16 @@ static void collide_pair(const mz_model* m, mzo_data* d, int ga, int gb) {
              m->geom_condim[g1], m->geom_condim[g2]);
   pp.b1 = m->geom_bodyid[g1]; pp.b2 = m->geom_bodyid[g2]; pp.g1 = g1; pp.g2 = g2;
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-  if (t2 == MZ_GEOM_BOX && t1 == MZ_GEOM_SPHERE) {
+  if (t1 == MZ_GEOM_SPHERE && t2 == MZ_GEOM_SPHERE) { /* the Point's body against an object ball: normal from geom1 to geom2 */
+    double dv[3], pos[3], nrm[3];
+    sub3(dv, d->geom_xpos[g2], d->geom_xpos[g1]);
+    double cd = norm3(dv), r1 = m->geom_size[g1][0], r2 = m->geom_size[g2][0], dist = cd - r1 - r2;
+    if (dist > pp.margin) return;
+    if (cd < MINVAL) { nrm[0] = 1.0; nrm[1] = 0.0; nrm[2] = 0.0; }
+    else { nrm[0] = dv[0] / cd; nrm[1] = dv[1] / cd; nrm[2] = dv[2] / cd; }
+    for (int k = 0; k < 3; k++) pos[k] = d->geom_xpos[g1][k] + nrm[k] * (r1 + 0.5 * dist);
+    add_contact(d, &pp, dist, pos, nrm, NULL);
+  } else if (t2 == MZ_GEOM_BOX && t1 == MZ_GEOM_SPHERE) {
     double dist, pos[3], nrm[3];
     if (sphere_box(d->geom_xpos[g1], m->geom_size[g1][0], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], pp.margin, &dist, pos, nrm))
       add_contact(d, &pp, dist, pos, nrm, NULL);

@@ -113,20 +113,20 @@ int emu_ant_forward(const mz_model* m, int n, const float* qpos, const float* qv
 // ---------------------------------------------------------------- Point (+ movable blocks): the lane-group step of planar_step_kernel
 #include "../../mujoco_maze_amd/csrc/planar_dyn.h"
 
-template <int NB>
+template <int NB, int NS>
 static int planar_env_step_t(const PointDev& P, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
                              float* reward, uint8_t* done, int32_t* goal_idx, int32_t* status) {
-  using D = PlanarDims<NB>;
+  using D = PlanarDims<NB, NS>;
   constexpr int NV = D::NV, NOBS = D::NOBS;
   HostCtx cx;
-  PlanarScratch<NB>* s = (PlanarScratch<NB>*)calloc(1, sizeof(PlanarScratch<NB>));
+  PlanarScratch<NB, NS>* s = (PlanarScratch<NB, NS>*)calloc(1, sizeof(PlanarScratch<NB, NS>));
   for (int e = 0; e < n; e++) {
     double a[2] = {(double)actions[2 * e], (double)actions[2 * e + 1]};
     for (int k = 0; k < NV; k++) { s->q[k] = (double)qpos[NV * e + k]; s->v[k] = (double)qvel[NV * e + k]; }
     const int t_new = t[e] + 1;
-    planar_env_step<NB>(cx, P, *s, a);
+    planar_env_step<NB, NS>(cx, P, *s, a);
     float o[NOBS];
-    for (int i = 0; i < NOBS; i++) o[i] = planar_obs_elem<NB>(P, *s, i, t_new);
+    for (int i = 0; i < NOBS; i++) o[i] = planar_obs_elem<NB, NS>(P, *s, i, t_new);
     float outer; int tm, gi;
     task_eval_dev(P.task, o, &outer, &tm, &gi);
     for (int k = 0; k < NOBS; k++) obs[NOBS * e + k] = o[k];
@@ -147,11 +147,12 @@ extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* 
   char err[128];
   int rc = point_dev_from_model(P, m, err, sizeof(err));
   if (rc != MZ_OK) { free(P); return rc; }
-  switch (P->nblock) {
-    case 0: rc = planar_env_step_t<0>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
-    case 1: rc = planar_env_step_t<1>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
-    case 2: rc = planar_env_step_t<2>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
-    default: rc = planar_env_step_t<3>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
+  if (P->nball) rc = planar_env_step_t<0, 1>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status);
+  else switch (P->nblock) {
+    case 0: rc = planar_env_step_t<0, 0>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
+    case 1: rc = planar_env_step_t<1, 0>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
+    case 2: rc = planar_env_step_t<2, 0>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
+    default: rc = planar_env_step_t<3, 0>(*P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, status); break;
   }
   free(P);
   return rc;

@@ -262,6 +262,40 @@ def test_point_with_movable_blocks(oracle, name, nblock):
     assert moved > 0.5  # blocks really get pushed around
 
 
+@pytest.mark.parametrize("name,idx", [("Billiard", 0), ("Billiard", 3), ("SmallBilliard", 0)])
+def test_point_billiard_object_ball(oracle, name, idx):
+    """PointBilliard / PointSmallBilliard (maze_task.py:627-762): one object ball (slide-x, slide-y, z hinge; 0.1 g) — ball vs wall,
+    robot sphere vs ball, ball vs arrow contacts on the planar code; object-slot reward / termination on obs[3:6]."""
+    from tests import emu_lib
+
+    task_cls = T.TaskRegistry.tasks(name)[idx]
+    scale = task_cls.MAZE_SIZE_SCALING.point
+    cm = model.compile_model("point", task_cls(scale), scale)
+    m = cm.c
+    assert m.nball == 1 and m.nv == 6 and m.obs_dim == 10
+    n = 192
+    st, _ = oracle.reset(cm, n, 1)
+    rng = np.random.default_rng(0)
+    moved, errs, terminated = 0.0, [], 0
+    for k in range(121):
+        act = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.25, 0.25, n)], 1).astype(np.float32)
+        if k % 20 == 0:
+            s64 = _f32(st)
+            s32 = dict(qpos=s64["qpos"].astype(np.float32), qvel=s64["qvel"].astype(np.float32), t=s64["t"].copy())
+            ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            re_ = emu_lib.point_env_step(cm, s32, act)
+            errs.append(np.abs(re_["obs"] - ro["obs"]).max(1))
+            assert np.array_equal(re_["done"], ro["done"]) and np.array_equal(re_["goal_idx"], ro["goal_idx"])
+            assert np.abs(re_["reward"] - ro["reward"]).max() < 1e-6
+            assert np.all((re_["status"] & ~8) == 0) and np.all((ro["status"] & ~8) == 0)
+            moved = max(moved, np.abs(s64["qpos"][:, 3:5]).max())
+            terminated += int((ro["done"] & 1).sum())
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    errs = np.concatenate(errs)
+    assert np.median(errs) < 3e-7 and (errs <= 2e-6).mean() >= 0.99, (np.median(errs), (errs <= 2e-6).mean(), errs.max())
+    assert moved > 0.5  # the ball gets knocked around
+
+
 @pytest.mark.parametrize("robot", ["swimmer", "reacher"])
 def test_swimmer_world_with_a_movable_block(oracle, robot):
     """SwimmerPush / ReacherPush: `collision="predefined"` (swimmer.xml:3) leaves the block without any contact pair, so it

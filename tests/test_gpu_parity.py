@@ -68,7 +68,9 @@ def test_native_library_is_the_in_tree_one(torch):
 
     lib = _capi.load()
     assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
-    assert lib.mz_abi_version() == 1
+    from mujoco_maze_amd.model import MZ_ABI_VERSION
+
+    assert lib.mz_abi_version() == MZ_ABI_VERSION == 2
 
 
 def _rollout_states(oracle, cm, n, seed, checkpoints, robot="ant"):
@@ -287,13 +289,14 @@ def test_point_step_parity_and_bounce(torch, oracle):
     env.close()
 
 
-@pytest.mark.parametrize("env_id,nblock", [("PointPush-v0", 1), ("PointPushMaze-v0", 3)])
+@pytest.mark.parametrize("env_id,nblock", [("PointPush-v0", 1), ("PointPushMaze-v0", 3), ("PointBilliard-v0", 0), ("PointSmallBilliard-v1", 0)])
 def test_point_with_movable_blocks(torch, oracle, env_id, nblock):
-    """Point + movable XY blocks on the lane-group planar kernel (32 / 64 lanes per env)."""
+    """Point + movable XY blocks (or the Billiard's object ball) on the lane-group planar kernel (32 / 64 lanes per env)."""
     n = 1024
     env = mm.make(env_id, num_envs=n)
     cm = env.model
-    assert cm.c.nblock == nblock and env.obs_dim == 7 + 3 * nblock and env.nv == 3 + 2 * nblock
+    nball = cm.c.nball
+    assert cm.c.nblock == nblock and env.obs_dim == 7 + 3 * nblock + 3 * nball and env.nv == 3 + 2 * nblock + 3 * nball
     st, _ = oracle.reset(cm, n, 1)
     rng = np.random.default_rng(0)
     errs, moved = [], 0.0

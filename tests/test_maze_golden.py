@@ -186,7 +186,34 @@ def test_movable_block_world(oracle):
         assert np.array_equal(obs[:, 6:18], st["qpos"][:, 3:15]) and np.array_equal(obs[:, 18:32], st["qvel"][:, :14])
 
 
-@pytest.mark.parametrize("env_id", ["AntFall-v0", "PointBilliard-v0"])
+def test_object_ball_world(oracle):
+    """PointBilliard: ball body, joints, mass, geom and obs layout (maze_env.py:167-191, 489-536, 351-369) against the
+    MJCF the reference generates."""
+    ref = WORLDS["PointBilliard-v0"]
+    spec = mm.REGISTRY["PointBilliard-v0"]
+    scale = spec.kwargs["maze_size_scaling"]
+    cm = model.compile_model("point", spec.kwargs["maze_task"](scale), scale)
+    m = cm.c
+    assert ref["ball_names"] == ["objball_3_3"] and m.nball == 1 and m.nblock == 0
+    assert m.obs_dim == ref["obs_dim"] == 10 and m.nq == 6 and m.nv == 6
+    b, g = m.ball_bodyid[0], m.ball_geomid[0]
+    mv = ref["movable"][0]
+    assert list(m.body_pos[b]) == mv["pos"] and [m.geom_size[g][0]] == mv["geom"]["size"] and list(m.geom_pos[g]) == mv["geom"]["pos"]
+    assert m.body_mass[b] == pytest.approx(mv["geom"]["mass"], rel=1e-12) and m.geom_type[g] == 2  # sphere
+    j0 = m.body_jntadr[b]
+    assert [list(m.jnt_axis[j0 + k]) for k in range(3)] == [j["axis"] for j in mv["joints"]]
+    assert [m.jnt_type[j0 + k] for k in range(3)] == [2, 2, 3] and not any(m.jnt_limited[j0 + k] for k in range(3))  # slide, slide, hinge
+    assert [list(bx) for bx in cm.world.wall_boxes()] == [bb["pos"] + bb["size"] for bb in ref["boxes"]]
+    assert list(cm.world.xy_limits()) == ref["xy_limits"]
+    for gl, st_ in zip(cm.task.goals, ref["sites"]):
+        assert gl.pos.tolist() == st_["pos"][: gl.dim]
+    # obs layout: qpos[:3] | ball xpos (body frame origin: z = 0) | qvel[:3] | t
+    st, obs = oracle.reset(cm, 2, 3)
+    assert np.array_equal(obs[:, 3:6], np.tile(mv["pos"], (2, 1))) and np.array_equal(obs[:, :3], st["qpos"][:, :3])
+    assert np.array_equal(obs[:, 6:9], st["qvel"][:, :3]) and np.all(st["qpos"][:, 3:] == 0) and np.all(st["qvel"][:, 3:] == 0)
+
+
+@pytest.mark.parametrize("env_id", ["AntFall-v0", "PointFall-v0", "AntSmallBilliard-v0"])
 def test_unsupported_mazes_fail_loudly(env_id):
     spec = mm.REGISTRY[env_id]
     scale = spec.kwargs["maze_size_scaling"]
