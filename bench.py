@@ -129,8 +129,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # MZ_BENCH_SINGLE_GPU=1: rehearsal of the N > 1 code path on a one-GPU box (all ranks on cuda:0, gloo instead of
+        # RCCL, which refuses two ranks per device).  Never set by the driver; the line it prints says so.
+        rehearsal = os.environ.get("MZ_BENCH_SINGLE_GPU") == "1"
+        if rehearsal:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -197,7 +205,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{ENV_ID}, {n} envs/GPU, frame_skip 5 x RK4, random actions U(-30,30)^8, auto-reset",
                        "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
-                       "lanes_per_env": args.lanes or 32, "waves_per_block": args.wpb or 1, "bad_envs": bad},
+                       "lanes_per_env": args.lanes or 32, "waves_per_block": args.wpb or 1, "bad_envs": bad,
+                       **({"rehearsal": "all ranks on one GPU over gloo (MZ_BENCH_SINGLE_GPU=1): not a scaling measurement"}
+                          if os.environ.get("MZ_BENCH_SINGLE_GPU") == "1" else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(n),
                          "kernel": "ant_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
