@@ -57,7 +57,7 @@ class VecMazeEnv:
             robot, self._task, maze_size_scaling, inner_reward_scaling=inner_reward_scaling,
             restitution_coef=restitution_coef, maze_height=maze_height, max_episode_steps=max_episode_steps,
             forward_reward_weight=kwargs.pop("forward_reward_weight", 1.0), ctrl_cost_weight=kwargs.pop("ctrl_cost_weight", 1e-4),
-            manual_collision=model_cls.MANUAL_COLLISION, radius=model_cls.RADIUS)
+            manual_collision=model_cls.MANUAL_COLLISION, radius=model_cls.RADIUS, robot_xml=kwargs.pop("robot_xml", None))
         self.wrapped_cls = model_cls
         if not torch.cuda.is_available():
             raise _capi.MazeStepError("no GPU visible: mujoco_maze_amd steps environments on an MI355X only (no CPU fallback)")

@@ -1,0 +1,247 @@
+"""MJCF subset reader / writer for robot assets ("custom AgentModel" XMLs).
+
+The reference keeps its robots as MJCF files next to the package and lets a user point an `AgentModel` subclass at
+another file (`agent_model.py:12-17`, `maze_env.py:97-100`).  Here the built-in robots live as `robots.RobotSpec`
+data; this module converts between that data and the MJCF subset those assets use, so a user's variant of a
+built-in robot — other masses, sizes, gears, limits, contact parameters — loads through the same path:
+
+    env = mm.make("AntUMaze-v0", num_envs=4096, robot_xml="my_ant.xml")
+
+Supported elements: `<compiler angle coordinate inertiafromgeom>`, `<option timestep integrator density viscosity
+collision>`, one top-level `<default>` with `<geom>`, `<joint>`, `<motor>`; `<worldbody>` with one plane geom (the
+floor) and one robot body tree of `<body>`, `<joint type=free|slide|hinge>`, `<freejoint>`,
+`<geom type=sphere|capsule|box>`; `<actuator><motor>`.  Lights, cameras, sites, assets and materials are skipped.
+The device kernels are written for the topologies of the four built-in robots (`csrc/*_dyn.h` check it when the
+model is created), so an XML may change parameters, not structure.
+"""
+import os
+import xml.etree.ElementTree as ET
+from typing import List, Optional, Sequence
+
+from mujoco_maze_amd import robots as R
+
+_GEOM_TYPE = {"plane": R.PLANE, "sphere": R.SPHERE, "capsule": R.CAPSULE, "box": R.BOX}
+_GEOM_NAME = {v: k for k, v in _GEOM_TYPE.items()}
+_JOINT_TYPE = {"free": R.FREE, "slide": R.SLIDE, "hinge": R.HINGE}
+_JOINT_NAME = {v: k for k, v in _JOINT_TYPE.items()}
+
+
+def _floats(text: str) -> tuple:
+    return tuple(float(t) for t in text.split())
+
+
+def _fmt(values: Sequence[float]) -> str:
+    return " ".join(repr(float(v)) for v in values)
+
+
+# ---------------------------------------------------------------- writer
+_GEOM_FIELDS = ("density", "contype", "conaffinity", "condim", "friction", "solref", "solimp", "margin", "gap")
+_JOINT_FIELDS = ("armature", "damping", "margin", "solref", "solimp")
+
+
+def _geom_attrs(g: R.GeomSpec, default: Optional[R.GeomSpec]) -> dict:
+    a = {"name": g.name, "type": _GEOM_NAME[g.type]}
+    if g.fromto is not None:
+        a["fromto"] = _fmt(g.fromto)
+        a["size"] = _fmt(g.size[:1])
+    else:
+        a["size"] = _fmt(g.size)
+        a["pos"] = _fmt(g.pos)
+    if g.mass is not None:
+        a["mass"] = repr(float(g.mass))
+    for f in _GEOM_FIELDS:
+        v = getattr(g, f)
+        if default is not None and getattr(default, f) == v and not (f == "solimp" and g.explicit_solimp):
+            continue
+        a[f] = _fmt(v) if isinstance(v, tuple) else repr(v)
+    return a
+
+
+def spec_to_mjcf(spec: R.RobotSpec) -> str:
+    """MJCF text of a RobotSpec (lossless for `spec_from_mjcf`)."""
+    root = ET.Element("mujoco", model=spec.name)
+    ET.SubElement(root, "compiler", angle="degree", coordinate="local", inertiafromgeom="true")
+    opt = {"integrator": "RK4", "timestep": repr(spec.timestep)}
+    if spec.density or spec.viscosity:
+        opt["density"], opt["viscosity"] = repr(spec.density), repr(spec.viscosity)
+    if spec.collision_predefined:
+        opt["collision"] = "predefined"
+    ET.SubElement(root, "option", **opt)
+    default = ET.SubElement(root, "default")
+    dg = spec.wall_geom_defaults
+    ET.SubElement(default, "geom", **{f: (_fmt(getattr(dg, f)) if isinstance(getattr(dg, f), tuple) else repr(getattr(dg, f)))
+                                      for f in _GEOM_FIELDS})
+    world = ET.SubElement(root, "worldbody")
+    ET.SubElement(world, "geom", **_geom_attrs(spec.floor, dg))
+    elems = []
+    for b in spec.bodies:
+        parent = world if b.parent < 0 else elems[b.parent]
+        e = ET.SubElement(parent, "body", name=b.name, pos=_fmt(b.pos))
+        elems.append(e)
+        for g in b.geoms:
+            ET.SubElement(e, "geom", **_geom_attrs(g, dg))
+        for j in b.joints:
+            a = {"name": j.name, "type": _JOINT_NAME[j.type]}
+            if j.type != R.FREE:
+                a.update(axis=_fmt(j.axis), pos=_fmt(j.pos), limited="true" if j.limited else "false", range=_fmt(j.range))
+            for f in _JOINT_FIELDS:
+                v = getattr(j, f)
+                a[f] = _fmt(v) if isinstance(v, tuple) else repr(v)
+            ET.SubElement(e, "joint", **a)
+    act = ET.SubElement(root, "actuator")
+    for m in spec.actuators:
+        ET.SubElement(act, "motor", joint=m.joint, gear=repr(m.gear), ctrlrange=_fmt(m.ctrlrange),
+                      ctrllimited="true" if m.ctrllimited else "false")
+    ET.indent(root)
+    return ET.tostring(root, encoding="unicode")
+
+
+# ---------------------------------------------------------------- reader
+def _apply_geom(base: R.GeomSpec, e: ET.Element, name: str) -> R.GeomSpec:
+    import dataclasses
+
+    kw = {}
+    a = e.attrib
+    if "type" in a:
+        if a["type"] not in _GEOM_TYPE:
+            raise ValueError(f"geom {name!r}: type {a['type']!r} is not supported (plane, sphere, capsule, box)")
+        kw["type"] = _GEOM_TYPE[a["type"]]
+    if "size" in a:
+        kw["size"] = _floats(a["size"])
+    if "pos" in a:
+        kw["pos"] = _floats(a["pos"])
+    if "fromto" in a:
+        kw["fromto"] = _floats(a["fromto"])
+        if len(kw["fromto"]) != 6:
+            raise ValueError(f"geom {name!r}: fromto needs six numbers")
+    if "mass" in a:
+        kw["mass"] = float(a["mass"])
+    for f in ("density", "margin", "gap"):
+        if f in a:
+            kw[f] = float(a[f])
+    for f in ("contype", "conaffinity", "condim"):
+        if f in a:
+            kw[f] = int(a[f])
+    if "friction" in a:
+        fr = _floats(a["friction"])
+        kw["friction"] = tuple(fr) + tuple(base.friction[len(fr):])
+    if "solref" in a:
+        kw["solref"] = _floats(a["solref"])
+    if "solimp" in a:
+        si = _floats(a["solimp"])
+        kw["solimp"] = tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
+        kw["explicit_solimp"] = True
+    return dataclasses.replace(base, name=name, **kw)
+
+
+def _apply_joint(base: R.JointSpec, e: ET.Element, name: str, radians: bool) -> R.JointSpec:
+    import dataclasses
+    import math
+
+    a = e.attrib
+    kw = {}
+    jt = "free" if e.tag == "freejoint" else a.get("type", "hinge")  # MuJoCo's default joint type is hinge
+    if jt not in _JOINT_TYPE:
+        raise ValueError(f"joint {name!r}: type {jt!r} is not supported (free, slide, hinge)")
+    kw["type"] = _JOINT_TYPE[jt]
+    if "axis" in a:
+        kw["axis"] = _floats(a["axis"])
+    if "pos" in a:
+        kw["pos"] = _floats(a["pos"])
+    if "limited" in a:
+        kw["limited"] = a["limited"] == "true"
+    if "range" in a:
+        rng = _floats(a["range"])
+        if radians and kw["type"] == R.HINGE:
+            rng = tuple(math.degrees(v) for v in rng)
+        kw["range"] = rng
+    for f in ("armature", "damping", "margin"):
+        if f in a:
+            kw[f] = float(a[f])
+    if "solref" in a:
+        kw["solref"] = _floats(a["solref"])
+    if "solimp" in a:
+        si = _floats(a["solimp"])
+        kw["solimp"] = tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
+    return dataclasses.replace(base, name=name, **kw)
+
+
+def spec_from_mjcf(source: str, like: R.RobotSpec) -> R.RobotSpec:
+    """Parse an MJCF file (path) or text into a RobotSpec.  `like` is the built-in spec of the robot family: it supplies
+    what MJCF does not carry (frame_skip, reset distribution, robot coordinate counts — `ant.py`, `point.py`, ...)."""
+    text = source if "<" in source else open(source).read()  # XML text or a file path
+    root = ET.fromstring(text)
+    if root.tag != "mujoco":
+        raise ValueError("not an MJCF document (root element must be <mujoco>)")
+    comp = root.find("compiler")
+    radians = comp is not None and comp.get("angle", "degree") == "radian"
+    if comp is not None and comp.get("coordinate", "local") != "local":
+        raise ValueError("only coordinate=\"local\" is supported")
+    if comp is None or comp.get("inertiafromgeom", "auto") not in ("true", "auto"):
+        raise ValueError("inertiafromgeom must be true (bodies get their inertia from their geoms)")
+    opt = root.find("option")
+    oa = opt.attrib if opt is not None else {}
+    if oa.get("integrator", "Euler") != "RK4":
+        raise ValueError("only integrator=\"RK4\" is implemented on the device (all reference assets use it)")
+    dflt = root.find("default")
+    geom0 = R.GeomSpec(name="", type=R.SPHERE, size=(0.0,))  # MuJoCo's built-in defaults
+    joint0 = R.JointSpec(name="", type=R.HINGE)
+    motor_attrs = {}
+    if dflt is not None:
+        if dflt.find("default") is not None:
+            raise ValueError("nested <default> classes are not supported")
+        if dflt.find("geom") is not None:
+            geom0 = _apply_geom(geom0, dflt.find("geom"), "")
+            geom0.explicit_solimp = False
+        if dflt.find("joint") is not None:
+            joint0 = _apply_joint(joint0, dflt.find("joint"), "", radians)
+        if dflt.find("motor") is not None:
+            motor_attrs = dict(dflt.find("motor").attrib)
+    world = root.find("worldbody")
+    if world is None:
+        raise ValueError("<worldbody> missing")
+    floors = [g for g in world.findall("geom") if g.get("type") == "plane"]
+    if len(floors) != 1:
+        raise ValueError("expected exactly one plane geom (the floor) in <worldbody>")
+    floor = _apply_geom(geom0, floors[0], floors[0].get("name", "floor"))
+    bodies: List[R.BodySpec] = []
+
+    def walk(e: ET.Element, parent: int):
+        name = e.get("name", f"body{len(bodies)}")
+        b = R.BodySpec(name, parent, _floats(e.get("pos", "0 0 0")))
+        idx = len(bodies)
+        bodies.append(b)
+        for k, ch in enumerate(e):
+            if ch.tag == "geom":
+                b.geoms.append(_apply_geom(geom0, ch, ch.get("name", f"{name}_geom{k}")))
+            elif ch.tag == "joint":
+                b.joints.append(_apply_joint(joint0, ch, ch.get("name", f"{name}_joint{k}"), radians))
+            elif ch.tag == "freejoint":  # takes no defaults (MuJoCo: armature = damping = 0, never limited)
+                b.joints.append(_apply_joint(R.JointSpec(name="", type=R.FREE), ch, ch.get("name", f"{name}_joint{k}"), radians))
+        for ch in e.findall("body"):
+            walk(ch, idx)
+
+    roots = world.findall("body")
+    if len(roots) != 1:
+        raise ValueError("expected exactly one robot body tree in <worldbody>")
+    walk(roots[0], -1)
+    acts = []
+    for mtr in (root.find("actuator") if root.find("actuator") is not None else []):
+        if mtr.tag != "motor":
+            raise ValueError(f"actuator <{mtr.tag}> is not supported (motor only)")
+        a = dict(motor_attrs)
+        a.update(mtr.attrib)
+        gear = _floats(a.get("gear", "1"))[0]
+        acts.append(R.ActuatorSpec(a["joint"], gear, _floats(a.get("ctrlrange", "0 0")), a.get("ctrllimited", "false") == "true"))
+    nq = sum(7 if j.type == R.FREE else 1 for b in bodies for j in b.joints)
+    nv = sum(6 if j.type == R.FREE else 1 for b in bodies for j in b.joints)
+    if (nq, nv) != (like.nq_robot, like.nv_robot) or len(acts) != len(like.actuators):
+        raise ValueError(f"{like.name}: the XML has {nq} / {nv} coordinates and {len(acts)} motors; the {like.name} kernels are "
+                         f"written for {like.nq_robot} / {like.nv_robot} and {len(like.actuators)} (parameters may change, structure not)")
+    import dataclasses
+
+    wall_defaults = dataclasses.replace(geom0, name="wall", type=R.BOX, size=(1.0, 1.0, 1.0), contype=1, conaffinity=1)  # maze_env.py:134-135
+    return R.RobotSpec(like.name, bodies, acts, floor, wall_defaults, timestep=float(oa.get("timestep", 0.002)), frame_skip=like.frame_skip,
+                       nq_robot=nq, nv_robot=nv, density=float(oa.get("density", 0.0)), viscosity=float(oa.get("viscosity", 0.0)),
+                       collision_predefined=oa.get("collision", "all") == "predefined", reset_qvel=like.reset_qvel,
+                       torso_z=bodies[0].pos[2])

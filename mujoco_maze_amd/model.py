@@ -249,8 +249,14 @@ def _kinematics_qpos0(nbody, parent, bpos, bquat):
 def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scaling: Optional[float] = None,
                   restitution_coef: float = 0.8, maze_height: float = 0.5, max_episode_steps: int = 1000,
                   forward_reward_weight: float = 1.0, ctrl_cost_weight: float = 1e-4,
-                  manual_collision: Optional[bool] = None, radius: Optional[float] = None) -> CompiledModel:
+                  manual_collision: Optional[bool] = None, radius: Optional[float] = None,
+                  robot_xml: Optional[str] = None) -> CompiledModel:
+    """`robot_xml`: path or text of an MJCF variant of the built-in robot (see `mjcf.py`); default: the built-in asset data."""
     spec = R.robot_spec(robot)
+    if robot_xml is not None:
+        from mujoco_maze_amd import mjcf
+
+        spec = mjcf.spec_from_mjcf(robot_xml, spec)
     structure = task.create_maze()
     world = MazeWorld(structure, scale, maze_height)
     if world.elevated:

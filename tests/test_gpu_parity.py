@@ -530,3 +530,27 @@ def test_ragged_batch_sizes_and_argument_errors(torch, oracle, env_id):
         mm.make("AntNoSuchMaze-v0")
     with pytest.raises(NotImplementedError):
         mm.make("AntFall-v0", num_envs=2)
+
+
+def test_user_robot_xml_on_the_device(torch, oracle):
+    """A parameter variant of the ant given as MJCF (mujoco_maze_amd/mjcf.py) runs on the ant kernel."""
+    from tests.test_mjcf import _heavy_ant_xml
+
+    n = 512
+    env = mm.make("AntUMaze-v0", num_envs=n, robot_xml=_heavy_ant_xml())
+    cm = env.model
+    assert cm.c.act_gear[0] == 1.5 and env.action_space.high[0] == 40.0
+    st, _ = oracle.reset(cm, n, 2)
+    rng = np.random.default_rng(0)
+    for k in range(21):
+        act = rng.uniform(-40, 40, (n, 8)).astype(np.float32)
+        if k in (0, 20):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], s64["warm"], s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.01)
+            assert np.array_equal(done.cpu().numpy(), ref["done"])
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    env.close()
