@@ -1,26 +1,38 @@
 #!/usr/bin/env python3
+"""GPU box helper: single-step parity of the HIP path against the float64 oracle over rollout checkpoints, per config.
+Prints a markdown table (median / 99 % / 99.9 % / max of the per-env max error over qpos and qvel, flag mismatches)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-"""GPU box helper: worst / quantile single-step errors vs the oracle (AntUMaze-v0, rollout checkpoints)."""
 import numpy as np, torch
 import mujoco_maze_amd as mm
 from tests import oracle_lib
+
 oracle = oracle_lib.load()
-n = 1024
-env = mm.make("AntUMaze-v0", num_envs=n)
-cm = env.model
-rng = np.random.default_rng(11)
-st, _ = oracle.reset(cm, n, 11)
-worst_v = worst_q = 0.0; q99 = []
-for k in range(101):
-    act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
-    if k in (0, 1, 10, 50, 100):
-        s = {kk: (v.astype(np.float32).astype(np.float64) if v.dtype != np.int32 else v.copy()) for kk, v in st.items()}
-        env.set_state(s["qpos"], s["qvel"], s["warm"], s["t"])
-        env.step(torch.as_tensor(act, device=env.device))
-        qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
-        oracle.step(cm, s, act.astype(np.float64), nthreads=8)
-        ev = np.abs(qvel - s["qvel"]).max(1); eq = np.abs(qpos - s["qpos"]).max(1)
-        worst_v = max(worst_v, ev.max()); worst_q = max(worst_q, eq.max()); q99.append(np.quantile(ev, 0.99))
-    oracle.step(cm, st, act.astype(np.float64), nthreads=8)
-print(f"worst |dqvel| {worst_v:.2e}  worst |dqpos| {worst_q:.2e}  99% quantile of |dqvel| per checkpoint {['%.1e' % x for x in q99]}")
+CONFIGS = [("AntUMaze-v0", 2048, (0, 1, 10, 50, 100, 200)), ("Ant4Rooms-v0", 2048, (0, 10, 100)), ("AntPush-v0", 1024, (0, 10, 50, 100)),
+           ("AntPushMaze-v0", 512, (0, 10, 50)), ("PointUMaze-v0", 2048, (0, 10, 50, 100)), ("PointPush-v0", 2048, (0, 10, 50, 100)),
+           ("PointBilliard-v0", 2048, (0, 10, 50, 100)), ("SwimmerUMaze-v0", 2048, (0, 10, 100)), ("ReacherUMaze-v0", 2048, (0, 10, 100))]
+print("| config | envs x checkpoints | median | 99 % | 99.9 % | max | envs > 1e-5 | done / goal-index mismatches |")
+print("|---|---|---|---|---|---|---|---|")
+for env_id, n, checks in CONFIGS:
+    env = mm.make(env_id, num_envs=n, force_vec=True)
+    cm = env.model
+    rng = np.random.default_rng(11)
+    st, _ = oracle.reset(cm, n, 11)
+    lo, hi = env.action_space.low, env.action_space.high
+    errs, flags = [], 0
+    for k in range(max(checks) + 1):
+        act = rng.uniform(lo, hi, (n, env.nu)).astype(np.float32)
+        if k in checks:
+            s = {kk: (v.astype(np.float32).astype(np.float64) if v.dtype != np.int32 else v.copy()) for kk, v in st.items()}
+            env.set_state(s["qpos"], s["qvel"], s["warm"] if env_id.startswith("Ant") else None, s["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s, act.astype(np.float64), nthreads=8)
+            e = np.maximum((np.abs(qvel - s["qvel"]) / (1 + np.abs(s["qvel"]))).max(1), (np.abs(qpos - s["qpos"]) / (1 + np.abs(s["qpos"]))).max(1))
+            errs.append(e)
+            flags += int((done.cpu().numpy() != ref["done"]).sum()) + int((info["goal_index"].cpu().numpy() != ref["goal_idx"]).sum())
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    e = np.concatenate(errs)
+    print(f"| {env_id} | {n} x {len(checks)} | {np.median(e):.1e} | {np.quantile(e, 0.99):.1e} | {np.quantile(e, 0.999):.1e} | {e.max():.1e} | "
+          f"{int((e > 1e-5).sum())} ({100.0 * (e > 1e-5).mean():.2f} %) | {flags} |")
+    env.close()
