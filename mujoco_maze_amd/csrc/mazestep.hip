@@ -1,12 +1,14 @@
 // mazestep.hip — HIP kernels (gfx950 / CDNA4) and the C-ABI of include/mazestep.h.
 //
 // Kernels
-//   ant_step_kernel<G>   one MazeEnv.step for the Ant: G lanes per environment, 64/G
-//                        environments per one-wavefront workgroup, the env's whole working
-//                        set (7.7 KB, AntScratch) resident in LDS across the 20 forward-
-//                        dynamics evaluations of the step; HBM is touched once per step
-//                        (192-B state record in, record + obs/reward/done out).
-//   planar_step_kernel   one MazeEnv.step for the Point (+ movable blocks): lane group per env, SoA state.
+//   ant_step_kernel<NB,G>       one MazeEnv.step for the Ant (+ NB movable blocks): G lanes per environment, 64/G
+//                               environments per one-wavefront workgroup, the env's whole working set (7.7 KB for the
+//                               plain ant, AntScratchT<NB>) resident in LDS across the 20 forward-dynamics evaluations
+//                               of the step; HBM is touched once per step (192-B state record in, record +
+//                               obs / reward / done out).
+//   planar_step_kernel<NB,NS,G> one MazeEnv.step for the Point (+ NB movable blocks or NS object balls): lane group
+//                               per env, PlanarScratch in LDS, fp64.
+//   swimmer_step_kernel<NL,NB>  one MazeEnv.step for the Swimmer (NL = 3) / Reacher (NL = 2): one env per lane, fp64.
 //   *_reset / state copy / debug kernels.
 //
 // Data layout in HBM
@@ -14,8 +16,7 @@
 //          (REC = 48 words for the plain ant, 64 with one movable block: AntDims<NB>::REC)
 //          (a lane group reads 48 consecutive words: coalesced for lane-group-per-env kernels;
 //          SoA would scatter a group's loads over 48 cache lines)
-//   Point: SoA  qpos[3][N] | qvel[3][N] fp32, t[N], episode[N] i32 (one env per lane: SoA is
-//          the coalesced layout)
+//   Point / Swimmer / Reacher: SoA  q_0..q_{NV-1} | v_0..v_{NV-1}, each [N] fp32; t[N], episode[N] i32
 //   API arrays are row-major [N, k] as in include/mazestep.h.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
