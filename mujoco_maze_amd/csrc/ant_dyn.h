@@ -113,7 +113,7 @@ struct alignas(16) AntScratchT {
   int cleg[D::NC], ccls[D::NC];      // leg (-1 none) and robot body class (-1 none) of the contact
   alignas(16) float cJ[D::NC][3][D::NCOL];  // [normal, mu*t1, mu*t2] x [hub, hip, ankle]
   alignas(16) float cY[D::NC][3][D::NCOL];  // W * J of the current Newton iterate (also stages contact geometry)
-  float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3], cg[D::NC][3];
+  float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3];
   // joint limits (8 hinges)
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   float red[4];
@@ -943,34 +943,29 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
   bool done = !has;
   int it = 0;
   while (cx.any(!done) && it < K.max_iter) {
-    // (a) M (qacc - qas) = M qacc - qfrc_smooth; per-contact residual u, gradient block g3, curvature W, Y = W J
+    // (a) one dot product per lane: rows of M (qacc - qas) = M qacc - qfrc_smooth | contact residuals u[c][a] | limit residuals
     MZ_FOR(i, NV) s.Mx[i] = arrow_row_mul<NH>(s.M, s.qacc, i) - s.qfs[i];
-    MZ_FOR(c, s.ncon) {
-      float u[3], W[5];
-      for (int a = 0; a < 3; a++) u[a] = contact_Jdot<NB>(s, c, a, s.qacc) - s.caref[c][a];
-      for (int a = 0; a < 3; a++) s.cu[c][a] = u[a];
-      contact_eval(s.cD[c], u, s.cg[c], W);
-      for (int k = 0; k < NCOL; k++) {
-        float n_ = s.cJ[c][0][k], p_ = s.cJ[c][1][k], q_ = s.cJ[c][2][k];
-        s.cY[c][0][k] = W[0] * n_ + W[1] * p_ + W[2] * q_;
-        s.cY[c][1][k] = W[1] * n_ + W[3] * p_;
-        s.cY[c][2][k] = W[2] * n_ + W[4] * q_;
-      }
+    MZ_FOR_AT(e, 3 * s.ncon, NV) {
+      int c = e / 3, a = e - 3 * c;
+      s.cu[c][a] = contact_Jdot<NB>(s, c, a, s.qacc) - s.caref[c][a];
     }
-    MZ_FOR(j, 8) {
+    MZ_FOR_AT(j, 8, NV + 3 * s.ncon) {
       float jar = 0.f, act = 0.f;
       if (s.lsign[j] != 0.f) { jar = s.lsign[j] * s.qacc[6 + j] - s.laref[j]; act = jar < 0.f ? s.lD[j] : 0.f; }
       s.ljar[j] = jar; s.lact[j] = act;
     }
     cx.sync();
-    // (b) gradient; contacts of leg l are the slots [cbeg[l], cbeg[l+1])
+    cx.tick(s, 13);
+    // (b) gradient rows (contacts of leg l are the slots [cbeg[l], cbeg[l+1])) | Y = W J, one (contact, column) per lane
     float gpart = 0.f, apart = 0.f;  // |grad|^2 and the squared magnitude of the terms that cancel in it
     MZ_FOR(i, NV) {
       float g = s.Mx[i], ga = fabsf(g);
       int c0 = 0, c1 = s.ncon, col = i < 6 ? i : i - 8;
       if (i >= 6 && i < 14) { int l = (i - 6) >> 1; c0 = s.cbeg[l]; c1 = s.cbeg[l + 1]; col = NH + ((i - 6) & 1); }
       for (int c = c0; c < c1; c++) {
-        float t = s.cJ[c][0][col] * s.cg[c][0] + s.cJ[c][1][col] * s.cg[c][1] + s.cJ[c][2][col] * s.cg[c][2];
+        float g3[3];
+        contact_eval(s.cD[c], s.cu[c], g3, nullptr);
+        float t = s.cJ[c][0][col] * g3[0] + s.cJ[c][1][col] * g3[1] + s.cJ[c][2][col] * g3[2];
         g += t; ga += fabsf(t);
       }
       if (i >= 6 && i < 14 && s.lsign[i - 6] != 0.f) { float t = s.lsign[i - 6] * s.lact[i - 6] * s.ljar[i - 6]; g += t; ga += fabsf(t); }
@@ -978,10 +973,21 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
       gpart += g * g;
       apart += ga * ga;
     }
+    MZ_FOR_AT(e, NCOL * s.ncon, NV) {
+      int c = e / NCOL, k = e - NCOL * c;
+      float W[5];
+      contact_eval(s.cD[c], s.cu[c], nullptr, W);
+      float n_ = s.cJ[c][0][k], p_ = s.cJ[c][1][k], q_ = s.cJ[c][2][k];
+      s.cY[c][0][k] = W[0] * n_ + W[1] * p_ + W[2] * q_;
+      s.cY[c][1][k] = W[1] * n_ + W[3] * p_;
+      s.cY[c][2][k] = W[2] * n_ + W[4] * q_;
+    }
     float gnorm = sqrtf(cx.gsum(gpart)), anorm = sqrtf(cx.gsum(apart));
     // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
     if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
-    if (!cx.any(!done)) { cx.sync(); cx.tick(s, 5); break; }
+    if (!cx.any(!done)) { cx.sync(); cx.tick(s, 14); break; }
+    cx.tick(s, 14);
+    cx.sync();
     MZ_FOR(e, D::NHESS) {  // Hessian: NH x NH hub (full square) + 8 NH hub-leg + 12 leg-leg arrow entries
       int ci, cj, c0 = 0, c1 = s.ncon;
       float* dst;
@@ -1011,8 +1017,8 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     // (d) exact line search on phi(alpha) = cost(qacc + alpha * search).  The Newton direction makes
     // alpha = 1 the exact minimiser whenever the active set at qacc + search equals the one H was built on:
     // test that first with one ballot; only otherwise find the root of the piecewise-linear phi'.
-    MZ_FOR(c, s.ncon) for (int a = 0; a < 3; a++) s.cjv[c][a] = contact_Jdot<NB>(s, c, a, s.search);
-    MZ_FOR(j, 8) s.ljv[j] = s.lsign[j] * s.search[6 + j];
+    MZ_FOR(e, 3 * s.ncon) { int c = e / 3, a = e - 3 * c; s.cjv[c][a] = contact_Jdot<NB>(s, c, a, s.search); }
+    MZ_FOR_AT(j, 8, 3 * s.ncon) s.ljv[j] = s.lsign[j] * s.search[6 + j];
     cx.sync();
     bool changed = false;
     MZ_FOR(c, s.ncon) {
