@@ -955,7 +955,6 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
       s.ljar[j] = jar; s.lact[j] = act;
     }
     cx.sync();
-    cx.tick(s, 13);
     // (b) gradient rows (contacts of leg l are the slots [cbeg[l], cbeg[l+1])) | Y = W J, one (contact, column) per lane
     float gpart = 0.f, apart = 0.f;  // |grad|^2 and the squared magnitude of the terms that cancel in it
     MZ_FOR(i, NV) {
@@ -985,8 +984,7 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     float gnorm = sqrtf(cx.gsum(gpart)), anorm = sqrtf(cx.gsum(apart));
     // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
     if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
-    if (!cx.any(!done)) { cx.sync(); cx.tick(s, 14); break; }
-    cx.tick(s, 14);
+    if (!cx.any(!done)) { cx.sync(); cx.tick(s, 5); break; }
     cx.sync();
     MZ_FOR(e, D::NHESS) {  // Hessian: NH x NH hub (full square) + 8 NH hub-leg + 12 leg-leg arrow entries
       int ci, cj, c0 = 0, c1 = s.ncon;

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(256, (NB ? 1 : ant_waves_per_simd<G>())) void ant_s
     if (live && threadIdx.x == 0 && prof) {
       unsigned long long tot = 0;
       for (int k = 0; k < 13; k++) tot += s.prof[k];
-      for (int k = 0; k < 16; k++) atomicAdd(&prof[k], (unsigned long long)s.prof[k]);
+      for (int k = 0; k < 16; k++) if (k != 13 && k != 14) atomicAdd(&prof[k], (unsigned long long)s.prof[k]);
+      atomicMax(&prof[13], tot);                  // slowest wave of the accumulation window
+      atomicAdd(&prof[14], (tot >> 8) * (tot >> 8));  // sum of squares of the per-wave totals (units of 256 cycles)
     }
   }
 }

@@ -21,8 +21,12 @@ cyc = env.phase_cycles()
 names = ["P0 kinematics+broadphase", "P1 inertia|contact count", "P2 crb|bias legs|contact fill", "P3 hub M|bias dofs", "solve:init", "solve:grad+H", "solve:factor+dir", "solve:linesearch", "solve:tail",
          "rk4/integrate", "io+epilogue", "P4 M leg inv|contact rows|limits", "P5-7 factor M -> qacc_smooth"]
 wgs = n // (64 // lanes)
-tot = sum(cyc[:15])
+tot = sum(cyc[:13])
 print(f"lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")
-names += ["solve:(a) Mx,u,W,Y", "solve:(b) gradient+norms"]
 for k, nm in enumerate(names):
     print(f"  {nm:36s} {cyc[k]/steps/wgs:10.0f} cycles/step  {100*cyc[k]/tot:5.1f} %")
+import math
+mean = tot / steps / wgs
+sq = cyc[14] * 65536.0 / (steps * wgs)
+std = math.sqrt(max(0.0, sq - mean * mean))
+print(f"  per-wave total: mean {mean:.0f}  std {std:.0f}  max {cyc[13]:.0f}  (max/mean {cyc[13]/mean:.2f}; a launch lasts as long as its slowest wave)")
