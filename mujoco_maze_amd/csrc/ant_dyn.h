@@ -104,7 +104,7 @@ struct alignas(16) AntScratchT {
   float zw[3];                   // hip axis (world) = R0 * ez
   float Sh[4][3], Sa[4][6];      // hip: linear part (angular = zw); ankle: angular, linear
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
-  float fleg[4][6], ftor[6], bias[D::NV], Iall[10];
+  float fbody[13][6], bias[D::NV], Iall[10];  // per-body inertial + velocity-product force (spatial, at c)
   alignas(16) Arrow<D::NH> M, H;
   ArrowFactor<D::NH> F;
   float grad[D::NV], search[D::NV], Mx[D::NV];
@@ -350,42 +350,34 @@ MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
     s.M.rr[i][j] = val; s.M.rr[j][i] = val;
 }
 
+// Recursive Newton-Euler, outward half, one body per lane: body b = 0 torso, 1 + 3l + k (k = 0 welded leg, 1 aux, 2 ankle).
+// Every lane walks its own (at most two-joint) chain from the root, so no hand-off is needed:
+//   f_b = I_b a_b + v_b x* (I_b v_b)   with gravity as base acceleration.
+// The inward half (sums along the chains, projection on the joint axes) is bias_dof_item.
 template <int NB>
-MZ_HD void bias_leg_item(const AntDev& K, AntScratchT<NB>& s, int l) {
-
-    float v0[6], a0[6], ww[3];
+MZ_HD void bias_body_item(const AntDev& K, AntScratchT<NB>& s, int b) {
+    float v[6], a[6], ww[3];
     mat_vecf(ww, s.R0, s.qvel + 3);  // world angular velocity (root angular dofs are body-frame)
-    for (int k = 0; k < 3; k++) { v0[k] = ww[k]; v0[3 + k] = s.qvel[k]; a0[k] = 0.f; }
-    cross3f(a0 + 3, s.qvel, ww);  // sum_k Sdot_k * qvel_k of the root rotation = [0; pdot x w]
-    a0[5] -= K.gz;                // gravity as base acceleration
-    if (l == 4) {                 // torso
-      float Ia[6], Iv[6], vf[6];
-      inertia_mulf(Ia, s.cin[0], a0);
-      inertia_mulf(Iv, s.cin[0], v0);
-      force_crossf(vf, v0, Iv);
-      for (int k = 0; k < 6; k++) s.ftor[k] = Ia[k] + vf[k];
-    } else {
-      float Sh[6], sd[6], v1[6], a1[6], v2[6], a2[6], f[6], ft[6], Ia[6], Iv[6], vf[6];
-      float qdh = s.qvel[6 + 2 * l], qda = s.qvel[7 + 2 * l];
+    for (int k = 0; k < 3; k++) { v[k] = ww[k]; v[3 + k] = s.qvel[k]; a[k] = 0.f; }
+    cross3f(a + 3, s.qvel, ww);  // sum_k Sdot_k * qvel_k of the root rotation = [0; pdot x w]
+    a[5] -= K.gz;                // gravity as base acceleration
+    int l = b > 0 ? (b - 1) / 3 : 0, lev = b > 0 ? (b - 1) % 3 : 0;
+    if (lev >= 1) {  // through the hip
+      float Sh[6], sd[6], qdh = s.qvel[6 + 2 * l];
       for (int k = 0; k < 3; k++) { Sh[k] = s.zw[k]; Sh[3 + k] = s.Sh[l][k]; }
-      // welded leg body moves with the torso
-      inertia_mulf(Ia, s.cin[1 + 3 * l], a0); inertia_mulf(Iv, s.cin[1 + 3 * l], v0); force_crossf(vf, v0, Iv);
-      for (int k = 0; k < 6; k++) ft[k] = Ia[k] + vf[k];
-      // aux body
-      motion_crossf(sd, v0, Sh);
-      for (int k = 0; k < 6; k++) { a1[k] = a0[k] + sd[k] * qdh; v1[k] = v0[k] + Sh[k] * qdh; }
-      inertia_mulf(Ia, s.cin[2 + 3 * l], a1); inertia_mulf(Iv, s.cin[2 + 3 * l], v1); force_crossf(vf, v1, Iv);
-      for (int k = 0; k < 6; k++) f[k] = Ia[k] + vf[k];
-      // ankle body
-      motion_crossf(sd, v1, s.Sa[l]);
-      for (int k = 0; k < 6; k++) { a2[k] = a1[k] + sd[k] * qda; v2[k] = v1[k] + s.Sa[l][k] * qda; }
-      inertia_mulf(Ia, s.cin[3 + 3 * l], a2); inertia_mulf(Iv, s.cin[3 + 3 * l], v2); force_crossf(vf, v2, Iv);
-      float fa[6];
-      for (int k = 0; k < 6; k++) { fa[k] = Ia[k] + vf[k]; f[k] += fa[k]; ft[k] += f[k]; }
-      s.bias[7 + 2 * l] = dot6f(s.Sa[l], fa);
-      s.bias[6 + 2 * l] = dot6f(Sh, f);
-      for (int k = 0; k < 6; k++) s.fleg[l][k] = ft[k];
+      motion_crossf(sd, v, Sh);
+      for (int k = 0; k < 6; k++) { a[k] += sd[k] * qdh; v[k] += Sh[k] * qdh; }
     }
+    if (lev >= 2) {  // through the ankle
+      float sd[6], qda = s.qvel[7 + 2 * l];
+      motion_crossf(sd, v, s.Sa[l]);
+      for (int k = 0; k < 6; k++) { a[k] += sd[k] * qda; v[k] += s.Sa[l][k] * qda; }
+    }
+    float Ia[6], Iv[6], vf[6];
+    inertia_mulf(Ia, s.cin[b], a);
+    inertia_mulf(Iv, s.cin[b], v);
+    force_crossf(vf, v, Iv);
+    for (int k = 0; k < 6; k++) s.fbody[b][k] = Ia[k] + vf[k];
 }
 
 template <int NB>
@@ -393,16 +385,27 @@ MZ_HD void bias_dof_item(const AntDev& K, AntScratchT<NB>& s, int i) {
 
     float frc;
     if (i < 6) {
-      float tot[3];
+      float tot[3] = {0.f, 0.f, 0.f};
       int o = i < 3 ? 3 : 0;  // linear dofs pick the force part, angular dofs the torque part
-      for (int k = 0; k < 3; k++) tot[k] = s.ftor[o + k] + s.fleg[0][o + k] + s.fleg[1][o + k] + s.fleg[2][o + k] + s.fleg[3][o + k];
-      float b;
-      if (i < 3) b = tot[i];
-      else { float ax[3] = {s.R0[i - 3], s.R0[3 + i - 3], s.R0[6 + i - 3]}; b = dot3f(ax, tot); }
-      s.bias[i] = b;
-      frc = -b;
+      for (int b = 0; b < ANT_NBODY; b++) for (int k = 0; k < 3; k++) tot[k] += s.fbody[b][o + k];
+      float bb;
+      if (i < 3) bb = tot[i];
+      else { float ax[3] = {s.R0[i - 3], s.R0[3 + i - 3], s.R0[6 + i - 3]}; bb = dot3f(ax, tot); }
+      s.bias[i] = bb;
+      frc = -bb;
     } else if (i < 14) {
-      frc = -K.damping * s.qvel[i] - s.bias[i] + s.fact[i];
+      int l = (i - 6) >> 1, d = (i - 6) & 1;
+      float f[6], bb;
+      for (int k = 0; k < 6; k++) f[k] = s.fbody[3 + 3 * l][k];  // ankle body
+      if (d == 1) bb = dot6f(s.Sa[l], f);
+      else {  // the hip carries aux + ankle
+        float Sh[6];
+        for (int k = 0; k < 3; k++) { Sh[k] = s.zw[k]; Sh[3 + k] = s.Sh[l][k]; }
+        for (int k = 0; k < 6; k++) f[k] += s.fbody[2 + 3 * l][k];
+        bb = dot6f(Sh, f);
+      }
+      s.bias[i] = bb;
+      frc = -K.damping * s.qvel[i] - bb + s.fact[i];
     } else {  // block slides: horizontal, undamped, unactuated (maze_env.py:600-633)
       s.bias[i] = 0.f;
       frc = 0.f;
@@ -807,6 +810,7 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
     int b = e - NB;
     if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
     int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, slot = off;
+    if (s.cnt[e] == 0) return;  // nothing to store: skip the second enumeration
     geom_contacts<NB>(K, s, e, [&](const ContactGeo& g) {
       if (slot >= NC) { slot++; return; }
       float* q = &s.cY[slot][0][0];
@@ -1086,7 +1090,7 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
 // so one evaluation needs 8 phase boundaries before the solver instead of 13:
 //   P0  leg kinematics (4) | wall broad phase (1)
 //   P1  body inertias (13) | contact count per geom (13 + NB)
-//   P2  leg mass-matrix blocks (4) | composite inertia (10) | leg bias forces (5) | contact geometry fill (13 + NB)
+//   P2  leg mass-matrix blocks (4) | composite inertia (10) | per-body bias forces (13) | contact geometry fill (13 + NB)
 //   P3  hub mass-matrix entries (21 + ..) | bias / smooth force per dof (NV)
 //   P4  2x2 leg inverses of M (4) | contact Jacobian rows (3 ncon) | joint-limit rows (8)
 //   P5  Schur entries + reduced rhs    P6  hub Cholesky (1 lane)    P7  back-substitution -> qacc_smooth
@@ -1104,8 +1108,8 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   cx.tick(s, 1);
   MZ_FOR_AT(l, 4, 0) crb_leg_item<NB>(K, s, l);
   MZ_FOR_AT(k, 10, 4) iall_item<NB>(K, s, k);
-  MZ_FOR_AT(l, 5, 14) bias_leg_item<NB>(K, s, l);
-  MZ_FOR_AT(e, NG, 19) con_fill_item<NB>(K, s, e);
+  MZ_FOR_AT(b, ANT_NBODY, 14) bias_body_item<NB>(K, s, b);
+  MZ_FOR_AT(e, NG, 14 + ANT_NBODY) con_fill_item<NB>(K, s, e);
   cx.sync();
   cx.tick(s, 2);
   MZ_FOR_AT(e, NROOT, 0) crb_root_item<NB>(K, s, e);
