@@ -45,7 +45,7 @@
 // items 0..n-1 on the lanes base, base+1, ... (mod group size): lets unrelated work share one phase
 #define MZ_FOR_AT(i, n, base) for (int i = mz_first_item(cx.lane0(), (base), C::nlanes); i < (n); i += C::nlanes)
 
-MZ_HD int mz_first_item(int lane, int base, int nl) { int r = (lane - base) % nl; return r < 0 ? r + nl : r; }
+MZ_HD int mz_first_item(int lane, int base, int nl) { return (lane - base) & (nl - 1); }  // group sizes are powers of two
 
 struct HostCtx {
   static constexpr int nlanes = 1;
@@ -1246,10 +1246,11 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 }
 
 // ------------------------------------------------------------------ MazeEnv.step for the Ant (maze_env.py:448-481, ant.py:61-73)
-// in: s.qpos/qvel/warm loaded, action[8], t (steps so far).  out: obs[obs_dim], reward, done, goal_idx, info[4]
+// in: s.qpos/qvel/warm loaded, action[8], *t_io = steps so far.  out: obs[obs_dim], reward, done, goal_idx, info[4], *t_io + 1
+// (t travels through memory so that it does not occupy a register across the whole step)
 template <int NB, class C>
-MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const float* action, int t_in, float* obs, float* reward,
-                        uint8_t* done, int* goal_idx, float* info, int* t_out) {
+MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const float* action, float* obs, float* reward,
+                        uint8_t* done, int* goal_idx, float* info, int* t_io) {
   using D = AntDims<NB>;
   MZ_FOR(i, D::NV) s.fact[i] = 0.f;
   MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
@@ -1257,7 +1258,7 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
   MZ_FOR(u, ANT_NU) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(action[u], K.ctrl_lo), K.ctrl_hi);
   cx.sync();
   for (int f = 0; f < K.frame_skip; f++) ant_mj_step<NB>(cx, K, s, f == 0);
-  int t = t_in + 1;
+  int t = *t_io + 1;
   int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
   MZ_FOR(i, obs_dim) obs[i] = ant_obs_elem<NB>(K, s, i, t);
   MZ_FOR(one, 1) {
@@ -1274,11 +1275,12 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
     *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
     if (goal_idx) *goal_idx = gi;
     if (info) { info[0] = s.qpos[0]; info[1] = s.qpos[1]; info[2] = fwd; info[3] = -cc; }
-    *t_out = t;
     bool badv = false;
     for (int i = 0; i < D::NQ; i++) badv = badv || !(fabsf(s.qpos[i]) < 1e10f);
     for (int i = 0; i < D::NV; i++) badv = badv || !(fabsf(s.qvel[i]) < 1e10f);
     if (badv) s.status |= MZ_STATUS_BAD_STATE;
   }
+  cx.sync();
+  MZ_FOR(one, 1) *t_io = t;  // after every lane has read the old value
   cx.sync();
 }

@@ -177,41 +177,54 @@ __global__ __launch_bounds__(256, (NB ? 1 : ant_waves_per_simd<G>())) void ant_s
   float* rec = state + (size_t)env * D::REC;
   ant_load<NB>(cx, s, rec);
   for (int i = cx.l; i < ANT_NU; i += G) act_s[i] = actions[(size_t)env * ANT_NU + i];
-  int t_in = ((const int*)rec)[D::REC_T];
-  uint32_t episode = ((const uint32_t*)rec)[D::REC_T + 1];
-  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
+  if (cx.l == 0) { iout_s[2] = ((const int*)rec)[D::REC_T]; iout_s[3] = ((const int*)rec)[D::REC_T + 1]; }  // t, episode: parked in LDS for the step
   if constexpr (PROF) { if (cx.l == 0) { for (int k = 0; k < 16; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
   cx.sync();
-  uint8_t* dn = (uint8_t*)&iout_s[0];
-  ant_env_step<NB>(cx, K, s, act_s, t_in, obs_s, &out_s[0], dn, &iout_s[1], &out_s[1], &iout_s[2]);
+  ant_env_step<NB>(cx, K, s, act_s, obs_s, &out_s[0], (uint8_t*)&iout_s[0], &iout_s[1], &out_s[1], &iout_s[2]);
   cx.sync();
-  const uint8_t d = *dn;
-  const int t_new = iout_s[2];
-  if (live) {
-    for (int i = cx.l; i < obs_dim; i += G) obs[(size_t)env * obs_dim + i] = obs_s[i];
-    if (cx.l == 0) {
-      reward[env] = out_s[0];
-      done[env] = d;
-      if (goal_idx) goal_idx[env] = iout_s[1];
-      if (s.status) atomicOr(&status[env], s.status);
+  // Epilogue.  Everything it needs is re-derived from the thread index behind an opaque barrier, so that no per-lane
+  // address or index stays live (and gets spilled to scratch) across the 20 forward evaluations above.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int slot2 = tid / G, l2 = tid % G;
+  int env2 = blockIdx.x * EPB + slot2;
+  const bool live2 = env2 < n;
+  if (!live2) env2 = n - 1;
+  AntScratchT<NB>& s2 = lds[slot2].s;
+  const float* obs2 = lds[slot2].io.obs;
+  const float* out2 = lds[slot2].io.out;
+  const int* iout2 = lds[slot2].io.iout;
+  float* rec2 = state + (size_t)env2 * D::REC;
+  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
+  const uint8_t d = *(const uint8_t*)&iout2[0];
+  const int t_new = iout2[2];
+  uint32_t episode = (uint32_t)iout2[3];
+  if (live2) {
+    for (int i = l2; i < obs_dim; i += G) obs[(size_t)env2 * obs_dim + i] = obs2[i];
+    if (l2 == 0) {
+      reward[env2] = out2[0];
+      done[env2] = d;
+      if (goal_idx) goal_idx[env2] = iout2[1];
+      if (s2.status) atomicOr(&status[env2], s2.status);
     }
-    if (info) for (int i = cx.l; i < 4; i += G) info[(size_t)env * 4 + i] = out_s[1 + i];
+    if (info) for (int i = l2; i < 4; i += G) info[(size_t)env2 * 4 + i] = out2[1 + i];
   }
   if (auto_reset && d) {  // masked reset inside the step
     episode += 1;
     uint64_t es = episode_seed(seed, episode);
     // robot coordinates get the reset noise; movable blocks return to their cells (ant.py:84-96)
-    for (int i = cx.l; i < D::NQ; i += G) s.qpos[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env, i) : 0.f;
-    for (int i = cx.l; i < D::NV; i += G) { s.qvel[i] = i < ANT_NV ? reset_qvel(K.reset_kind, D::NQ, es, env0 + (uint64_t)env, i) : 0.f; s.warm[i] = 0.f; }
+    for (int i = l2; i < D::NQ; i += G) s2.qpos[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env2, i) : 0.f;
+    for (int i = l2; i < D::NV; i += G) { s2.qvel[i] = i < ANT_NV ? reset_qvel(K.reset_kind, D::NQ, es, env0 + (uint64_t)env2, i) : 0.f; s2.warm[i] = 0.f; }
   }
   cx.sync();
-  if (live) {
-    ant_store<NB>(cx, s, rec);
-    if (cx.l == 0) { ((int*)rec)[D::REC_T] = (auto_reset && d) ? 0 : t_new; ((uint32_t*)rec)[D::REC_T + 1] = episode; }
+  if (live2) {
+    DevCtx<G, PROF> cx2{l2};
+    ant_store<NB>(cx2, s2, rec2);
+    if (l2 == 0) { ((int*)rec2)[D::REC_T] = (auto_reset && d) ? 0 : t_new; ((uint32_t*)rec2)[D::REC_T + 1] = episode; }
   }
   if constexpr (PROF) {
     cx.tick(s, 10);
-    if (live && threadIdx.x == 0 && prof) {
+    if (live2 && threadIdx.x == 0 && prof) {
       unsigned long long tot = 0;
       for (int k = 0; k < 13; k++) tot += s.prof[k];
       for (int k = 0; k < 16; k++) if (k != 13 && k != 14) atomicAdd(&prof[k], (unsigned long long)s.prof[k]);

@@ -19,9 +19,9 @@ static int env_step_t(const AntDev& K, int n, float* qpos, float* qvel, float* w
   for (int e = 0; e < n; e++) {
     for (int k = 0; k < D::NQ; k++) s->qpos[k] = qpos[e * D::NQ + k];
     for (int k = 0; k < D::NV; k++) { s->qvel[k] = qvel[e * D::NV + k]; s->warm[k] = warm[e * D::NV + k]; }
-    int gi = -1, tout = 0;
+    int gi = -1, tout = t[e];
     s->prof[15] = 0;
-    ant_env_step<NB>(cx, K, *s, actions + e * ANT_NU, t[e], obs + e * obs_dim, reward + e, done + e, &gi, info ? info + 4 * e : nullptr, &tout);
+    ant_env_step<NB>(cx, K, *s, actions + e * ANT_NU, obs + e * obs_dim, reward + e, done + e, &gi, info ? info + 4 * e : nullptr, &tout);
     for (int k = 0; k < D::NQ; k++) qpos[e * D::NQ + k] = s->qpos[k];
     for (int k = 0; k < D::NV; k++) { qvel[e * D::NV + k] = s->qvel[k]; warm[e * D::NV + k] = s->warm[k]; }
     t[e] = tout;
