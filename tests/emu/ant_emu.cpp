@@ -75,7 +75,6 @@ static int make_dev(AntDev* K, const mz_model* m, int max_iter, float tol, float
 
 extern "C" {
 
-int emu_ant_sizeof_scratch(int nblock) { return nblock == 0 ? (int)sizeof(AntScratchT<0>) : nblock == 1 ? (int)sizeof(AntScratchT<1>) : (int)sizeof(AntScratchT<2>); }
 
 // One MazeEnv.step for n envs (row-major arrays as in the C-ABI's get/set_state).
 int emu_ant_env_step(const mz_model* m, int n, float* qpos, float* qvel, float* warm, int32_t* t, const float* actions,
