@@ -66,7 +66,7 @@ struct AntDims {
   static constexpr int NQ = 15 + 2 * NB;
   static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
   // contact slots: a block resting in a corridor holds 4 floor corners + 4 per adjacent wall/block face
-  static constexpr int NC = NB == 0 ? 16 : (NB == 1 ? 28 : (NB == 2 ? 40 : 72));
+  static constexpr int NC = NB == 0 ? 16 : (NB == 1 ? 28 : (NB == 2 ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each)
   static constexpr int NGEOM = 13 + NB;    // contact enumerators: blocks first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;

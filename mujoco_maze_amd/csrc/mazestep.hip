@@ -154,7 +154,7 @@ template <int G>
 constexpr int ant_waves_per_simd() { return G >= 64 ? 4 : (G == 32 ? 2 : 1); }
 
 template <int NB, int G, bool PROF>
-__global__ __launch_bounds__(256, (NB ? 1 : ant_waves_per_simd<G>())) void ant_step_kernel(const AntDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
+__global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G>())) void ant_step_kernel(const AntDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
                                                        float* __restrict__ obs, float* __restrict__ reward,
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
@@ -593,14 +593,17 @@ static hipError_t launch_ant_forward(mz_handle* h, hipStream_t st, const float* 
   hipLaunchKernelGGL((ant_forward_kernel<NB, G>), dim3((h->n + EPB - 1) / EPB), dim3(64), lds, st, h->ant, h->n, h->state, a, qacc, counts);
   return hipSuccess;
 }
-// lane widths: the plain ant is instantiated for 8/16/32/64 lanes per env, mazes with movable blocks for 16/32
+// lane widths: the plain ant is instantiated for 8/16/32/64 lanes per env, mazes with movable blocks for 16/32/64.
+// Default: 32 for the plain ant; 64 with blocks (their contact sets keep 64 lanes busy, and the 2048-env batches of those
+// configs then fill the chip with two waves per SIMD instead of one).
 template <int NB>
 static hipError_t dispatch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   if constexpr (NB == 0) {
-    if (h->lanes == 8) return launch_ant_step<NB, 8>(h, st, a, o, r, d, gi, inf);
-    if (h->lanes == 64) return launch_ant_step<NB, 64>(h, st, a, o, r, d, gi, inf);
+    if (h->lanes_set && h->lanes == 8) return launch_ant_step<NB, 8>(h, st, a, o, r, d, gi, inf);
   }
-  if (h->lanes == 16) return launch_ant_step<NB, 16>(h, st, a, o, r, d, gi, inf);
+  const int lanes = h->lanes_set ? h->lanes : (NB ? 64 : 32);
+  if (lanes == 64) return launch_ant_step<NB, 64>(h, st, a, o, r, d, gi, inf);
+  if (lanes == 16) return launch_ant_step<NB, 16>(h, st, a, o, r, d, gi, inf);
   return launch_ant_step<NB, 32>(h, st, a, o, r, d, gi, inf);
 }
 template <int NB>

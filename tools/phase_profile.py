@@ -6,8 +6,9 @@ import sys, json
 import torch
 import mujoco_maze_amd as mm
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-n = 4096
-env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True, force_vec=True)
+env_id = sys.argv[2] if len(sys.argv) > 2 else "AntUMaze-v0"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
 env.set_option("lanes_per_env", lanes)
 env.reset(seed=1)
 g = torch.Generator(device=env.device).manual_seed(0)
@@ -22,7 +23,7 @@ names = ["P0 kinematics+broadphase", "P1 inertia|contact count", "P2 crb|bias le
          "rk4/integrate", "io+epilogue", "P4 M leg inv|contact rows|limits", "P5-7 factor M -> qacc_smooth"]
 wgs = n // (64 // lanes)
 tot = sum(cyc[:13])
-print(f"lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")
+print(f"{env_id} n={n} lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")
 for k, nm in enumerate(names):
     print(f"  {nm:36s} {cyc[k]/steps/wgs:10.0f} cycles/step  {100*cyc[k]/tot:5.1f} %")
 import math
