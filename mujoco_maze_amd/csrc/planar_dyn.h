@@ -438,10 +438,21 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
         s.cjv[c][a] = t;
       }
     }
-    double p1 = cx.gsum(p1p), p2 = cx.gsum(p2p);
     cx.sync();
+    // The Newton direction makes alpha = 1 the exact minimiser whenever the active set at qacc + search equals the one H
+    // was built on (the cost is quadratic there): one vote, and then neither the line search nor a verification pass.
+    bool changed = false;
+    MZ_FOR(c, ncon) {
+      double u0 = s.cu[c][0], u1 = s.cu[c][1], u2 = s.cu[c][2];
+      double w0 = u0 + s.cjv[c][0], w1 = u1 + s.cjv[c][1], w2 = u2 + s.cjv[c][2];
+      changed = changed || ((u0 + u1 < 0) != (w0 + w1 < 0)) || ((u0 - u1 < 0) != (w0 - w1 < 0)) || ((u0 + u2 < 0) != (w0 + w2 < 0)) ||
+                ((u0 - u2 < 0) != (w0 - w2 < 0));
+    }
+    changed = cx.gany(changed);
     double lo = 0.0, hi = -1.0, alpha = 1.0, prev_d2 = -1.0;
-    for (int ls = 0; ls < 30; ls++) {
+    double p1 = 0.0, p2 = 0.0;
+    if (changed) { p1 = cx.gsum(p1p); p2 = cx.gsum(p2p); }
+    for (int ls = 0; ls < 30 && changed; ls++) {
       double d1 = 0.0, d2 = 0.0;
       MZ_FOR(c, ncon) {
         double Dc = s.cD[c], v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
@@ -466,6 +477,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     cx.sync();
     MZ_FOR(i, NV) s.qacc[i] += alpha * s.search[i];
     cx.sync();
+    if (!changed) done = true;
     it++;
   }
   cx.sync();
