@@ -215,6 +215,11 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
     // robot coordinates get the reset noise; movable blocks return to their cells (ant.py:84-96)
     for (int i = l2; i < D::NQ; i += G) s2.qpos[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env2, i) : 0.f;
     for (int i = l2; i < D::NV; i += G) { s2.qvel[i] = i < ANT_NV ? reset_qvel(K.reset_kind, D::NQ, es, env0 + (uint64_t)env2, i) : 0.f; s2.warm[i] = 0.f; }
+    cx.sync();
+    if (l2 == 0) {  // root quaternion normalised in place, as at mz_reset [ASSUME-8]
+      float qn = 1.0f / sqrtf(s2.qpos[3] * s2.qpos[3] + s2.qpos[4] * s2.qpos[4] + s2.qpos[5] * s2.qpos[5] + s2.qpos[6] * s2.qpos[6]);
+      for (int i = 3; i < 7; i++) s2.qpos[i] *= qn;
+    }
   }
   cx.sync();
   if (live2) {
@@ -270,6 +275,10 @@ __global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, con
   float* rec = state + (size_t)env * L.rec;
   if (!mask || mask[env]) {
     for (int i = 0; i < L.nq; i++) rec[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], seed, env0 + (uint64_t)env, i) : 0.f;
+    {  // set_state -> mj_forward: mj_kinematics normalises the root quaternion in place [ASSUME-8]
+      float qn = 1.0f / sqrtf(rec[3] * rec[3] + rec[4] * rec[4] + rec[5] * rec[5] + rec[6] * rec[6]);
+      for (int i = 3; i < 7; i++) rec[i] *= qn;
+    }
     for (int i = 0; i < L.nv; i++) {
       rec[L.nq + i] = i < ANT_NV ? reset_qvel(K.reset_kind, L.nq, seed, env0 + (uint64_t)env, i) : 0.f;
       rec[L.nq + L.nv + i] = 0.f;

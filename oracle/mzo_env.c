@@ -154,6 +154,11 @@ void mzo_env_reset(const mz_model* m, mzo_env_state* s, uint64_t seed, uint64_t 
     s->qpos[i] = m->qpos0[i];
     if (i < m->nq_robot) s->qpos[i] += -0.1 + 0.2 * u01(seed, env, (uint32_t)i);
   }
+  if (m->njnt > 0 && m->jnt_type[0] == MZ_JNT_FREE) { /* set_state -> mj_forward: mj_kinematics normalises the quaternion in qpos [ASSUME-8] */
+    double* q = s->qpos + m->jnt_qposadr[0] + 3;
+    double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; k++) q[k] /= nn;
+  }
   for (int i = 0; i < m->nv_robot; i++) {
     uint32_t c = (uint32_t)(m->nq + 2 * i);
     if (m->reset_qvel_kind == 0) s->qvel[i] = 0.1 * normal01(seed, env, c);
