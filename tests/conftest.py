@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+NATIVE = [os.path.join(ROOT, "mujoco_maze_amd", "csrc", "libmazestep.so"), os.path.join(ROOT, "oracle", "libmzo.so"),
+          os.path.join(ROOT, "tests", "emu", "libantemu.so")]
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_artefacts():
+    """A fresh checkout has no binaries (they are git-ignored): build them once.  Existing ones are used as they are
+    (the GPU box runs the prebuilt files that travelled with the snapshot)."""
+    if not all(os.path.exists(p) for p in NATIVE):
+        import __graft_entry__
+
+        __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests import oracle_lib
