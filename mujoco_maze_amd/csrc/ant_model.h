@@ -174,7 +174,7 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
   task_dev_from_model(&a->task, m);
   for (int k = 0; k < ANT_NQ; k++) a->qpos0[k] = (float)m->qpos0[k];
   a->reset_kind = m->reset_qvel_kind;
-  a->max_iter = nb ? 24 : 10; a->ls_iter = 12; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
+  a->max_iter = nb ? 50 : 10; a->ls_iter = 12; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
   a->inv_scale = (float)(1.0 / (m->meaninertia * m->nv));
   return MZ_OK;
 }
