@@ -51,7 +51,7 @@ extern "C" {
 /* robot kinds */
 #define MZ_ROBOT_POINT 0
 #define MZ_ROBOT_ANT 1
-#define MZ_ROBOT_SWIMMER 2
+#define MZ_ROBOT_SWIMMER 2 /* planar link chains: Swimmer (3 links) and Reacher (2 links; reacher.xml is <mujoco model="swimmer">) */
 
 /* joint types (MuJoCo numbering) */
 #define MZ_JNT_FREE 0
@@ -227,8 +227,10 @@ int32_t mz_nu(const mz_handle* h);
 
 /* Tunables: "auto_reset" (0/1), "seed", "env_index_offset" (global slot of local env 0 in a
  * sharded run: keys the reset RNG), "solver_iterations", "solver_tolerance", "solver_rtol",
- * "ls_iterations", "lanes_per_env" (8/16/32/64: ant kernel geometry), "time_kernels" (ring of
- * HIP event pairs around the step kernel). Returns MZ_OK or MZ_ERR_ARG. */
+ * "ls_iterations" (Ant solver), "lanes_per_env" (8/16/32/64 lanes of a wavefront per environment; defaults: Ant 32,
+ * Ant with movable blocks 64, Point 16 / 32 / 64 by block count), "waves_per_block" (1/2/4, Ant), "profile_phases" (0/1:
+ * instrumented Ant kernel, see mz_read_phase_cycles), "time_kernels" (n > 0: ring of n HIP event pairs around the step
+ * kernel, see mz_last_kernel_ms). Returns MZ_OK or MZ_ERR_ARG. */
 int32_t mz_set_option(mz_handle* h, const char* key, double value);
 
 /* reset(): envs with mask_dev[i] != 0 (all when NULL) get t = 0 and a fresh state
@@ -262,13 +264,13 @@ int32_t mz_get_status(mz_handle* h, int32_t* status_dev, void* stream);
 int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev, int32_t* counts_dev, void* stream);
 
 /* Kernel-internal phase timers (option "profile_phases" = 1 selects the instrumented kernel build):
- * 16 shader-cycle accumulators (phase ids documented in csrc/ant_dyn.h), summed over the first env group
- * of every workgroup since the last read; out16_host is HOST memory. */
+ * 16 accumulators since the last read — slots 0..12 shader cycles per phase (ids: tools/phase_profile.py), 13 the slowest
+ * wave's total, 14 the sum of squared per-wave totals (units of 256 cycles), 15 Newton iterations — taken from the first env
+ * group of every workgroup; out16_host is HOST memory. */
 int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host);
 
-/* Name and average-duration bookkeeping for bench.py: time (ms) of the last
- * mz_step's dominant kernel measured with hipEvents on `stream` when
- * "time_kernels" option is 1; returns < 0 if not available. */
+/* Average duration (ms) of the step kernel over the launches recorded since "time_kernels" was set (HIP events on
+ * the stream each mz_step was given; synchronises on them); returns < 0 if not available. */
 double mz_last_kernel_ms(const mz_handle* h);
 
 #ifdef __cplusplus
