@@ -146,6 +146,31 @@ def test_constraint_solve_kkt(oracle):
     assert seen_contacts > 50
 
 
+@pytest.mark.parametrize("robot,task,scale,lo,hi", [("ant", "Push", 8.0, -30.0, 30.0), ("ant", "PushMaze", 2.0, -30.0, 30.0),
+                                                    ("point", "Push", 4.0, -1.0, 1.0), ("point", "Billiard", 3.0, -1.0, 1.0)])
+def test_constraint_solve_kkt_with_movable_bodies(oracle, robot, task, scale, lo, hi):
+    """Same optimality conditions with movable blocks / an object ball in the scene (box-box, capsule-box, sphere-sphere and
+    rotated-box rows; 0.1-1 g bodies next to a 56 kg robot): the oracle's Newton solve must still land on the KKT point."""
+    cm = model.compile_model(robot, T.TaskRegistry.tasks(task)[0](scale), scale)
+    n = 24
+    st, _ = oracle.reset(cm, n, 7)
+    rng = np.random.default_rng(4)
+    seen = 0
+    for k in range(80):
+        act = rng.uniform(lo, hi, (n, cm.c.nu))
+        if robot == "point":
+            act[:, 1] *= 0.25
+        oracle.step(cm, st, act)
+        if k % 20 == 19:
+            for e in range(n):
+                rep, _ = oracle.forward_report(cm, st["qpos"][e], st["qvel"][e], ctrl=act[e] if robot == "ant" else None, warm=st["warm"][e])
+                assert rep["status"] == 0
+                scale_f = max(1.0, abs(rep["fsum"]))
+                assert rep["kkt"] < 1e-6 * scale_f and rep["comp"] < 1e-6 * scale_f and rep["fmin"] >= 0.0, rep
+                seen += rep["ncon"]
+    assert seen > 20
+
+
 def test_warmstart_does_not_change_the_solution(oracle):
     cm = ant()
     st, _ = oracle.reset(cm, 4, 11)
