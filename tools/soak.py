@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""GPU box helper: long auto-reset rollouts with random actions; reports status bits seen and non-finite observations."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mujoco_maze_amd as mm
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+for env_id, n in (("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 2048), ("AntPushMaze-v0", 1024), ("PointUMaze-v0", 4096),
+                  ("PointPush-v0", 4096), ("PointBilliard-v0", 4096), ("SwimmerUMaze-v0", 4096), ("ReacherUMaze-v0", 4096)):
+    env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
+    env.reset(seed=3)
+    g = torch.Generator(device=env.device).manual_seed(0)
+    lo = torch.as_tensor(env.action_space.low, device=env.device); hi = torch.as_tensor(env.action_space.high, device=env.device)
+    acts = [lo + (hi - lo) * torch.rand((n, env.nu), device=env.device, generator=g) for _ in range(64)]
+    k = steps if not env_id.startswith("AntPushMaze") else steps // 4
+    bits = torch.zeros(n, dtype=torch.int32, device=env.device); nonfinite = 0; dones = 0
+    t0 = time.perf_counter()
+    for i in range(k):
+        obs, rew, done, info = env.step(acts[i % 64])
+        if i % 500 == 499:
+            bits |= env.status(); nonfinite += int((~torch.isfinite(obs)).sum().item()); dones += int((done != 0).sum().item())
+    bits |= env.status()
+    torch.cuda.synchronize()
+    b = bits.cpu().numpy()
+    print(f"{env_id:18s} n={n} steps={k}: {time.perf_counter()-t0:5.1f} s  envs ever flagged: nan {int((b&1!=0).sum())} overflow {int((b&2!=0).sum())} "
+          f"maxiter {int((b&4!=0).sum())} collinear {int((b&8!=0).sum())}; non-finite obs samples {nonfinite}; dones sampled {dones}")
+    env.close()
