@@ -1,0 +1,78 @@
+"""User-defined tasks (the reference's README "How to customize" flow: subclass MazeTask, give it goals, a maze and a
+reward): known reward kinds run inside the kernel, anything else is evaluated on the host from the returned observations."""
+import numpy as np
+import pytest
+
+import mujoco_maze_amd as mm
+from mujoco_maze_amd import maze_task as T
+from mujoco_maze_amd import model
+from mujoco_maze_amd.maze_env_utils import MazeCell
+from mujoco_maze_amd.maze_task import MazeGoal, MazeTask
+
+
+class GoalRewardCross(MazeTask):
+    """A user maze with a hand-written reward: +1 at the goal, a small living cost that grows with the distance otherwise."""
+
+    REWARD_THRESHOLD = 0.9
+    PENALTY = -0.0001
+
+    def __init__(self, scale: float) -> None:
+        super().__init__(scale)
+        self.goals = [MazeGoal(np.array([2.0 * scale, 0.0]))]
+
+    def reward(self, obs: np.ndarray) -> float:
+        if self.termination(obs):
+            return 1.0
+        return self.PENALTY * (1.0 + float(np.hypot(*(obs[:2] - self.goals[0].pos))))
+
+    @staticmethod
+    def create_maze():
+        E, B, R = MazeCell.EMPTY, MazeCell.BLOCK, MazeCell.ROBOT
+        return [
+            [B, B, B, B, B, B, B],
+            [B, B, B, E, B, B, B],
+            [B, R, E, E, E, E, B],
+            [B, B, B, E, B, B, B],
+            [B, B, B, B, B, B, B],
+        ]
+
+
+class InheritedRewardCross(GoalRewardCross):
+    """Same maze, but the stock goal reward of the reference (`GoalRewardUMaze.reward`, maze_task.py:110-111)."""
+
+    reward = T.GoalRewardUMaze.reward
+
+
+def test_reward_classification():
+    # a stock reward function on a user maze runs inside the kernel; a hand-written one does not
+    assert T.device_reward_descriptor(InheritedRewardCross(4.0)) is not None
+    assert T.device_reward_descriptor(GoalRewardCross(4.0)) is None
+    cm = model.compile_model("point", GoalRewardCross(4.0), 4.0)
+    assert not cm.device_rewards and cm.c.ngoal == 1 and (cm.world.rows, cm.world.cols) == (5, 7)
+    assert model.compile_model("point", InheritedRewardCross(4.0), 4.0).device_rewards
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_cls", [mm.PointEnv, mm.AntEnv])
+def test_user_task_with_python_reward_on_the_device(model_cls):
+    import torch
+
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+
+    n, scale = 64, 4.0
+    env = VecMazeEnv(model_cls, GoalRewardCross, maze_size_scaling=scale, num_envs=n, inner_reward_scaling=0.0)
+    task = GoalRewardCross(scale)
+    env.reset(seed=3)
+    # put a quarter of the envs next to the goal so that termination fires
+    qpos, qvel, warm, t = env.get_state()
+    qpos[: n // 4, 0] = 2.0 * scale - 0.1
+    env.set_state(qpos=qpos)
+    rng = np.random.default_rng(0)
+    lo, hi = env.action_space.low, env.action_space.high
+    obs, rew, done, info = env.step(torch.as_tensor(0.1 * rng.uniform(lo, hi, (n, env.nu)).astype(np.float32), device=env.device))
+    o = obs.double().cpu().numpy()
+    want_r = np.array([task.reward(x) for x in o])
+    want_d = np.array([task.termination(x) for x in o])
+    assert np.allclose(rew.cpu().numpy(), want_r, atol=1e-6)
+    assert np.array_equal((done.cpu().numpy() & 1).astype(bool), want_d) and want_d[: n // 4].all() and not want_d[n // 4:].any()
+    env.close()
