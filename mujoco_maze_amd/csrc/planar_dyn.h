@@ -39,6 +39,7 @@ struct alignas(16) PlanarScratch {
   double q[D::NV], v[D::NV];  // state of the current RK4 stage
   double x0[D::NV], v0[D::NV], accv[D::NV], accf[D::NV];
   double qas[D::NV], qacc[D::NV], grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
+  double wd[D::NV];           // constraint-induced acceleration (qacc - qacc_smooth) of the previous RK4 stage: warm start
   double M3[3][3];            // robot block of the mass matrix (blocks: block_mass on the diagonal)
   double H[D::NV][D::NV];
   double cJ[D::NC][3][D::NV], caref[D::NC][3], cD[D::NC], cu[D::NC][3], cg[D::NC][3], cW[D::NC][5], cjv[D::NC][3];
@@ -324,9 +325,13 @@ MZP_HD void pl_contact_eval(double D, const double* u, double* g, double* W) {
 
 // ------------------------------------------------------------------ one forward-dynamics evaluation: s.q, s.v -> s.qacc
 template <int NB, int NS, class C>
-MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s) {
+MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, bool warm) {
   using D = PlanarDims<NB, NS>;
   constexpr int NV = D::NV, NC = D::NC, NE = D::NE;
+  // Stages 2-4 of RK4 start the Newton solve from the previous stage's solution shifted by the change of qacc_smooth
+  // (the optimum is unique: only the iteration count depends on the start).
+  MZ_FOR(i, NV) s.wd[i] = warm ? s.qacc[i] - s.qas[i] : 0.0;
+  cx.sync();
   MZ_FOR(one, 1) {
     double co = cos(s.q[2]), si = sin(s.q[2]), w2 = s.v[2] * s.v[2], mc = P.mass * P.com_x;
     s.co = co; s.si = si;
@@ -365,6 +370,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       });
     }
   }
+  if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = s.qas[i] + s.wd[i]; }  // envs without contacts keep qacc = qacc_smooth
   cx.sync();
   // ---- Newton on the primal problem (dense), exact line search
   bool done = ncon == 0;
@@ -506,7 +512,7 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
     MZ_FOR(i, NV) { s.x0[i] = s.q[i]; s.v0[i] = s.v[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; }
     cx.sync();
     for (int st = 0; st < 4; st++) {
-      planar_forward<NB, NS>(cx, P, s);
+      planar_forward<NB, NS>(cx, P, s, st > 0);
       double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
       MZ_FOR(i, NV) {
         s.accv[i] += bw * s.v[i]; s.accf[i] += bw * s.qacc[i];
