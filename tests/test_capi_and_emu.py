@@ -197,6 +197,25 @@ def test_wall_broad_phase_small_cells(oracle):
     assert np.all(np.abs(fo["qacc"] - fe["qacc"]) <= 2e-3 + 1e-5 * np.abs(fo["qacc"]))
 
 
+def test_contact_overflow_is_flagged_not_fatal(oracle):
+    """More contacts than slots (ants pressed into the floor of a maze with 2 m cells, legs across the walls): the kernel
+    logic keeps the first 16, raises MZ_STATUS_CONTACT_OVERFLOW for the env and still returns finite numbers."""
+    from tests import emu_lib
+
+    cm = model.compile_model("ant", T.DistRewardUMaze(2.0), 2.0)
+    n = 64
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(0)
+    st["qpos"][:, 2] = rng.uniform(0.02, 0.2, n)
+    st["qpos"][:, 7:15] += rng.uniform(-1, 1, (n, 8))
+    st["qpos"][:, :2] += rng.uniform(-0.6, 0.6, (n, 2))
+    act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+    fe = emu_lib.forward(cm, st["qpos"], st["qvel"], act, st["warm"])
+    assert fe["counts"][:, 0].max() == 16
+    re_ = emu_lib.env_step(cm, emu_lib.f32_state(st), act)
+    assert ((re_["status"] & 2) != 0).sum() >= 5 and np.all((re_["status"] & 1) == 0) and np.isfinite(re_["obs"]).all()
+
+
 def test_point_step_logic_with_mujoco_wall_contacts(oracle):
     """Point (BASELINE config 2): teleport + RK4 + MuJoCo sphere-box / arrow box-box wall contacts + manual bounce,
     over the whole maze (about half of the random states have active MuJoCo contacts)."""
