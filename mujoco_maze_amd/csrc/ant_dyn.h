@@ -107,7 +107,7 @@ struct alignas(16) AntScratchT {
   float fbody[13][6], bias[D::NV], Iall[10];  // per-body inertial + velocity-product force (spatial, at c)
   alignas(16) Arrow<D::NH> M, H;
   ArrowFactor<D::NH> F;
-  float grad[D::NV], search[D::NV], Mx[D::NV];
+  float grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
   // contacts
   int ncon, cnt[D::NGEOM], cbeg[5];  // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); hub-only contacts [0, cbeg[0])
   int cleg[D::NC], ccls[D::NC];      // leg (-1 none) and robot body class (-1 none) of the contact
@@ -947,18 +947,22 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
   bool done = !has;
   int it = 0;
   while (cx.any(!done) && it < K.max_iter) {
-    // (a) one dot product per lane: rows of M (qacc - qas) = M qacc - qfrc_smooth | contact residuals u[c][a] | limit residuals
-    MZ_FOR(i, NV) s.Mx[i] = arrow_row_mul<NH>(s.M, s.qacc, i) - s.qfs[i];
-    MZ_FOR_AT(e, 3 * s.ncon, NV) {
-      int c = e / 3, a = e - 3 * c;
-      s.cu[c][a] = contact_Jdot<NB>(s, c, a, s.qacc) - s.caref[c][a];
+    // (a) one dot product per lane: rows of M (qacc - qas) = M qacc - qfrc_smooth | contact residuals u[c][a] | limit residuals.
+    // Only the first iteration computes them from qacc; afterwards they follow the step: every one of them is affine in
+    // qacc, and M search / J search are already at hand from the line search (see the update at the end of the loop).
+    if (it == 0) {
+      MZ_FOR(i, NV) s.Mx[i] = arrow_row_mul<NH>(s.M, s.qacc, i) - s.qfs[i];
+      MZ_FOR_AT(e, 3 * s.ncon, NV) {
+        int c = e / 3, a = e - 3 * c;
+        s.cu[c][a] = contact_Jdot<NB>(s, c, a, s.qacc) - s.caref[c][a];
+      }
+      MZ_FOR_AT(j, 8, NV + 3 * s.ncon) {
+        float jar = 0.f, act = 0.f;
+        if (s.lsign[j] != 0.f) { jar = s.lsign[j] * s.qacc[6 + j] - s.laref[j]; act = jar < 0.f ? s.lD[j] : 0.f; }
+        s.ljar[j] = jar; s.lact[j] = act;
+      }
+      cx.sync();
     }
-    MZ_FOR_AT(j, 8, NV + 3 * s.ncon) {
-      float jar = 0.f, act = 0.f;
-      if (s.lsign[j] != 0.f) { jar = s.lsign[j] * s.qacc[6 + j] - s.laref[j]; act = jar < 0.f ? s.lD[j] : 0.f; }
-      s.ljar[j] = jar; s.lact[j] = act;
-    }
-    cx.sync();
     // (b) gradient rows (contacts of leg l are the slots [cbeg[l], cbeg[l+1])) | Y = W J, one (contact, column) per lane
     float gpart = 0.f, apart = 0.f;  // |grad|^2 and the squared magnitude of the terms that cancel in it
     MZ_FOR(i, NV) {
@@ -1037,7 +1041,7 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     bool exact = !changed;
     if (changed) {
       float p1 = 0.f, p2 = 0.f;
-      MZ_FOR(i, NV) { float ms = arrow_row_mul<NH>(s.M, s.search, i); p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
+      MZ_FOR(i, NV) { float ms = arrow_row_mul<NH>(s.M, s.search, i); s.Ms[i] = ms; p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
       p1 = cx.gsum(p1); p2 = cx.gsum(p2);
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
       for (int ls = 0; ls < K.ls_iter; ls++) {
@@ -1069,7 +1073,18 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     }
     if (done) alpha = 0.f;
     cx.sync();
-    MZ_FOR(i, NV) s.qacc[i] += alpha * s.search[i];
+    // step, and the affine quantities of phase (a) along with it (an env whose step was exact is done: its M search is
+    // not computed and its residuals are not used again)
+    if (alpha != 0.f) {  // group-uniform; a finished env touches nothing (0 * stale values could still poison qacc)
+      MZ_FOR(i, NV) s.qacc[i] += alpha * s.search[i];
+      if (changed) {
+        MZ_FOR(i, NV) s.Mx[i] += alpha * s.Ms[i];
+        MZ_FOR_AT(e, 3 * s.ncon, NV) { int c = e / 3, a = e - 3 * c; s.cu[c][a] += alpha * s.cjv[c][a]; }
+        MZ_FOR_AT(j, 8, NV + 3 * s.ncon) {
+          if (s.lsign[j] != 0.f) { float jar = s.ljar[j] + alpha * s.ljv[j]; s.ljar[j] = jar; s.lact[j] = jar < 0.f ? s.lD[j] : 0.f; }
+        }
+      }
+    }
     cx.sync();
     // The full Newton step stayed inside one active set: the cost is exactly quadratic there, so the new
     // point is its minimiser — no verification pass needed.
