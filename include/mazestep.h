@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZ_ABI_VERSION 2
+#define MZ_ABI_VERSION 3
 
 #define MZ_MAX_BODY 24
 #define MZ_MAX_JNT 24
@@ -98,7 +98,9 @@ typedef struct mz_model {
   int32_t abi_version;
   int32_t robot; /* MZ_ROBOT_* */
   int32_t nbody, njnt, nq, nv, ngeom, nu;
-  int32_t nq_robot, nv_robot; /* leading robot coordinates (ant 15/14, point 3/3) */
+  int32_t nq_robot, nv_robot; /* leading coordinates the robot's own _get_obs reports and reset_model re-randomises: ant 15/14
+                               * (ant.py:75-96), point 3/3 (point.py:63-81), swimmer / reacher ALL nq / nv, movable blocks
+                               * included (swimmer.py:50-69) */
   int32_t frame_skip;
   int32_t integrator_rk4;
   int32_t collision_predefined; /* swimmer: no dynamic contact pairs */
@@ -219,6 +221,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
 void mz_destroy(mz_handle* h);
 const char* mz_last_error(const mz_handle* h);
 
+/* accessors: the value, or MZ_ERR_ARG for a NULL handle */
 int32_t mz_num_envs(const mz_handle* h);
 int32_t mz_obs_dim(const mz_handle* h);
 int32_t mz_nq(const mz_handle* h);
@@ -232,6 +235,14 @@ int32_t mz_nu(const mz_handle* h);
  * instrumented Ant kernel, see mz_read_phase_cycles), "time_kernels" (n > 0: ring of n HIP event pairs around the step
  * kernel, see mz_last_kernel_ms). Returns MZ_OK or MZ_ERR_ARG. */
 int32_t mz_set_option(mz_handle* h, const char* key, double value);
+
+/* Auto-reset observation convention.  With option "auto_reset" = 1 an env whose step ended its episode (done != 0) is
+ * re-seeded inside the same kernel; mz_step then returns, for that env, the reward / done / goal index of the terminal step
+ * and in obs_dev the FIRST observation of the new episode (t = 0) — what a policy must act on next.  The terminal
+ * observation (the one the reference's MazeEnv.step returns, maze_env.py:474-481) is written to row i of the buffer bound
+ * here ([N, obs_dim] fp32, device, caller-owned; rows of envs that did not finish are left untouched); NULL unbinds.
+ * Without auto-reset obs_dev always holds the step's own observation and this buffer is never written. */
+int32_t mz_bind_final_obs(mz_handle* h, float* final_obs_dev);
 
 /* reset(): envs with mask_dev[i] != 0 (all when NULL) get t = 0 and a fresh state
  * from the reference's reset distribution (counter-based RNG keyed by seed and
@@ -248,7 +259,7 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
 
 /* One MazeEnv.step for every env.
  *  actions_dev [N, nu] fp32 row-major
- *  obs_dev     [N, obs_dim]
+ *  obs_dev     [N, obs_dim]   the step's observation (under auto-reset: see mz_bind_final_obs)
  *  reward_dev  [N]            inner_reward_scaling * inner + task reward
  *  done_dev    [N] u8         bit0 = task termination, bit1 = TimeLimit truncation
  *  goal_idx_dev[N] i32        first matching goal index or -1   (nullable)
@@ -262,6 +273,19 @@ int32_t mz_get_status(mz_handle* h, int32_t* status_dev, void* stream);
 /* Diagnostics for parity tests: one forward-dynamics evaluation at the current
  * state with ctrl = actions; writes qacc [N, nv] and ncon/nefc [N, 2]. */
 int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev, int32_t* counts_dev, void* stream);
+
+/* Parity-test entries for the two places where the reference's float64 DECISIONS must be reproduced bit for bit.
+ * mz_debug_task_eval: MazeTask.reward / termination / first matching goal (maze_task.py:43-47,77-81,110-111,403-407) on
+ *   n_rows observation rows [n_rows, obs_dim] fp32 — the very task_eval_dev instance the handle's step kernel runs:
+ *   reward_dev[n_rows] = task reward only (no inner reward), done_dev[n_rows] u8 = termination, goal_idx_dev (nullable).
+ * mz_debug_detect: CollisionDetector.detect + the bounce / give-up rule of MazeEnv.step (maze_env_utils.py:96-123,186-206;
+ *   maze_env.py:457-464) on n_rows float64 moves old_xy -> new_xy ([n_rows, 2] each): hit_dev[n_rows] = 0 no wall hit,
+ *   1 bounced, 2 gave up (position restored), -1 collinear move (the reference raises ZeroDivisionError);
+ *   point_dev[n_rows, 2] (nullable) = first collision point, final_xy_dev[n_rows, 2] = position after the rule.  Point only. */
+int32_t mz_debug_task_eval(mz_handle* h, int32_t n_rows, const float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                           int32_t* goal_idx_dev, void* stream);
+int32_t mz_debug_detect(mz_handle* h, int32_t n_rows, const double* old_xy_dev, const double* new_xy_dev, int32_t* hit_dev,
+                        double* point_dev, double* final_xy_dev, void* stream);
 
 /* Kernel-internal phase timers (option "profile_phases" = 1 selects the instrumented kernel build):
  * 16 accumulators since the last read — slots 0..12 shader cycles per phase (ids: tools/phase_profile.py), 13 the slowest

@@ -1217,28 +1217,33 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
 }
 
 // ------------------------------------------------------------------ MazeTask reward / termination on the fp32 observation
+// that is returned to the caller (obs[0:3] agent slot, obs[3:6] object slot).  Flags and goal index are the reference's
+// float64 predicate (maze_task.py:43-44 `np.linalg.norm(obs[:dim] - pos) <= threshold`, :77-81 any goal, :403-407 first
+// match) evaluated on float64(obs): differences and squares in fp64, summed in index order without contraction, compared
+// with the squared-threshold bound of TaskDev (bit-exact whatever the build flags of the translation unit).
 MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int* term, int* goal_idx) {
-  float slot_a[3] = {obs[0], obs[1], obs[2]}, slot_o[3] = {obs[3], obs[4], obs[5]};
+#pragma clang fp contract(off)
+  const double slot_a[3] = {(double)obs[0], (double)obs[1], (double)obs[2]}, slot_o[3] = {(double)obs[3], (double)obs[4], (double)obs[5]};
   int tm = 0, first = -1;
   for (int g = 0; g < T.ngoal; g++) {
-    float a = 0.f, b = 0.f;
+    double a = 0.0, b = 0.0;
     for (int k = 0; k < 3; k++)
       if (k < T.goal_dim[g]) {
-        float e = (T.term_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; a += e * e;
-        float f = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; b += f * f;
+        double e = (T.term_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; a += e * e;
+        double f = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; b += f * f;
       }
-    if (!tm && sqrtf(a) <= T.thr[g]) tm = 1;
-    if (first < 0 && sqrtf(b) <= T.thr[g]) first = g;
+    if (!tm && a <= T.thr_sq[g]) tm = 1;
+    if (first < 0 && b <= T.thr_sq[g]) first = g;
   }
-  float r = 0.f;
-  if (T.reward_kind == MZ_REWARD_FIRST_MATCH) r = T.reward_binary ? (tm ? 1.0f : T.penalty) : (first >= 0 ? T.rscale[first] : T.penalty);
+  double r = 0.0;
+  if (T.reward_kind == MZ_REWARD_FIRST_MATCH) r = T.reward_binary ? (tm ? 1.0 : T.penalty) : (first >= 0 ? T.rscale[first] : T.penalty);
   else if (T.reward_kind == MZ_REWARD_NEG_DIST && T.ngoal > 0) {
-    float a = 0.f;
+    double a = 0.0;
     for (int k = 0; k < 3; k++)
-      if (k < T.goal_dim[0]) { float e = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[0][k]; a += e * e; }
-    r = -sqrtf(a) / T.task_scale;
+      if (k < T.goal_dim[0]) { double e = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[0][k]; a += e * e; }
+    r = -sqrt(a) / T.task_scale;
   }
-  *reward = r; *term = tm; *goal_idx = first;
+  *reward = (float)r; *term = tm; *goal_idx = first;
 }
 
 // observation element i (maze_env.py:351-369): qpos[:3] | block xpos (3 each, if observed) | qpos[3:15] | qvel[:14] | t/1000
@@ -1281,12 +1286,12 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
     float vx = (s.qpos[0] - s.red[1]) / dt, vy = (s.qpos[1] - s.red[2]) / dt;
     float fwd = sqrtf(vx * vx + vy * vy), cc = 0.f;
     for (int u = 0; u < ANT_NU; u++) cc += action[u] * action[u];
-    cc *= K.task.ctrl_w;
+    cc *= (float)K.task.ctrl_w;
     float o6[6];
     for (int k = 0; k < 6; k++) o6[k] = ant_obs_elem<NB>(K, s, k, t);
     float outer; int tm, gi;
     task_eval_dev(K.task, o6, &outer, &tm, &gi);
-    *reward = K.task.inner_scale * (K.task.fwd_w * fwd - cc) + outer;
+    *reward = (float)K.task.inner_scale * ((float)K.task.fwd_w * fwd - cc) + outer;
     *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
     if (goal_idx) *goal_idx = gi;
     if (info) { info[0] = s.qpos[0]; info[1] = s.qpos[1]; info[2] = fwd; info[3] = -cc; }

@@ -1,0 +1,342 @@
+// ant_kernels.hip — HIP kernels (gfx950 / CDNA4) of the Ant path and their launchers.
+//
+//   ant_step_kernel<NB,G>  one MazeEnv.step for the Ant (+ NB movable blocks): G lanes per environment, 64/G
+//                          environments per one-wavefront workgroup, the env's whole working set (7.7 KB for the plain
+//                          ant, AntScratchT<NB>) resident in LDS across the 20 forward-dynamics evaluations of the step;
+//                          HBM is touched once per step (192-B state record in, record + obs / reward / done out).
+//   reset / state copy / debug kernels.
+//
+// HBM layout: state[N][REC] fp32 record = qpos[nq] | qvel[nv] | qacc_warmstart[nv] | t | episode | pad
+//   (REC = 48 words for the plain ant, 64 with one movable block: AntDims<NB>::REC).  A lane group reads 48 consecutive
+//   words: coalesced for lane-group-per-env kernels (SoA would scatter a group's loads over 48 cache lines).
+//
+// Built with the relaxed floating-point flags of csrc/Makefile (reciprocal division, approximate transcendentals): the
+// physics is a 1e-5 tolerance quantity.  The task predicates inside (task_eval_dev) are written so that those flags
+// cannot change a flag: fp64, no contraction, squared thresholds instead of sqrt.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ant_dyn.h"
+#include "mz_device.h"
+#include "mz_internal.h"
+
+// ------------------------------------------------------------------ Ant kernels
+template <int NB, int G, bool P>
+__device__ __forceinline__ void ant_load(const DevCtx<G, P>& cx, AntScratchT<NB>& s, const float* rec) {
+  using D = AntDims<NB>;
+  for (int i = cx.l; i < D::REC_T; i += G) {
+    float v = rec[i];
+    if (i < D::NQ) s.qpos[i] = v;
+    else if (i < D::NQ + D::NV) s.qvel[i - D::NQ] = v;
+    else s.warm[i - D::NQ - D::NV] = v;
+  }
+}
+template <int NB, int G, bool P>
+__device__ __forceinline__ void ant_store(const DevCtx<G, P>& cx, const AntScratchT<NB>& s, float* rec) {
+  using D = AntDims<NB>;
+  for (int i = cx.l; i < D::REC_T; i += G) {
+    float v = i < D::NQ ? s.qpos[i] : (i < D::NQ + D::NV ? s.qvel[i - D::NQ] : s.warm[i - D::NQ - D::NV]);
+    rec[i] = v;
+  }
+}
+
+struct AntIO {  // per-env staging of the step's inputs / outputs next to the scratch block
+  float act[ANT_NU], obs[MZ_MAX_OBS], out[8];
+  int iout[4];
+};
+template <int NB>
+struct alignas(16) AntEnvLDS { AntScratchT<NB> s; AntIO io; };
+
+// Register budget per lane-group width: the batch is fixed (4096 envs/GPU), so the wave count is 64*N/G and
+// the kernel must fit  N*G/64 / 1024 SIMDs  waves per SIMD to be resident in one round.
+template <int G>
+constexpr int ant_waves_per_simd() { return G >= 64 ? 4 : (G == 32 ? 2 : 1); }
+
+template <int NB, int G, bool PROF>
+__global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G>())) void ant_step_kernel(const AntDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
+                                                       float* __restrict__ obs, float* __restrict__ reward,
+                                                       uint8_t* __restrict__ done, int* __restrict__ goal_idx,
+                                                       float* __restrict__ info, int* __restrict__ status, int auto_reset,
+                                                       uint64_t seed, uint64_t env0, unsigned long long* __restrict__ prof,
+                                                       float* __restrict__ final_obs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  using D = AntDims<NB>;
+  const AntDev& K = *Kp;  // model constants: scalar loads from a device-resident block (L2 / scalar-cache hits)
+  AntEnvLDS<NB>* lds = reinterpret_cast<AntEnvLDS<NB>*>(lds_raw);
+  const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
+  DevCtx<G, PROF> cx{(int)threadIdx.x % G};
+  const int slot = threadIdx.x / G;
+  int env = blockIdx.x * EPB + slot;
+  const bool live = env < n;
+  if (!live) env = n - 1;  // surplus groups shadow the last env (no stores)
+  AntScratchT<NB>& s = lds[slot].s;
+  float* act_s = lds[slot].io.act;
+  float* obs_s = lds[slot].io.obs;
+  float* out_s = lds[slot].io.out;
+  int* iout_s = lds[slot].io.iout;
+  float* rec = state + (size_t)env * D::REC;
+  ant_load<NB>(cx, s, rec);
+  for (int i = cx.l; i < ANT_NU; i += G) act_s[i] = actions[(size_t)env * ANT_NU + i];
+  if (cx.l == 0) { iout_s[2] = ((const int*)rec)[D::REC_T]; iout_s[3] = ((const int*)rec)[D::REC_T + 1]; }  // t, episode: parked in LDS for the step
+  if constexpr (PROF) { if (cx.l == 0) { for (int k = 0; k < 16; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
+  cx.sync();
+  ant_env_step<NB>(cx, K, s, act_s, obs_s, &out_s[0], (uint8_t*)&iout_s[0], &iout_s[1], &out_s[1], &iout_s[2]);
+  cx.sync();
+  // Epilogue.  Everything it needs is re-derived from the thread index behind an opaque barrier, so that no per-lane
+  // address or index stays live (and gets spilled to scratch) across the 20 forward evaluations above.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int slot2 = tid / G, l2 = tid % G;
+  int env2 = blockIdx.x * EPB + slot2;
+  const bool live2 = env2 < n;
+  if (!live2) env2 = n - 1;
+  AntScratchT<NB>& s2 = lds[slot2].s;
+  const float* obs2 = lds[slot2].io.obs;
+  const float* out2 = lds[slot2].io.out;
+  const int* iout2 = lds[slot2].io.iout;
+  float* rec2 = state + (size_t)env2 * D::REC;
+  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
+  const uint8_t d = *(const uint8_t*)&iout2[0];
+  const int t_new = iout2[2];
+  uint32_t episode = (uint32_t)iout2[3];
+  // Auto-reset follows the vector-env convention: an env that finished returns its reward / done of the
+  // terminal step, the FIRST observation of the new episode in `obs`, and the terminal observation in `final_obs` (when bound).
+  const bool rst = auto_reset && d;
+  if (live2) {
+    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env2 * obs_dim;
+    if (!rst || final_obs) for (int i = l2; i < obs_dim; i += G) orow[i] = obs2[i];
+    if (l2 == 0) {
+      reward[env2] = out2[0];
+      done[env2] = d;
+      if (goal_idx) goal_idx[env2] = iout2[1];
+      if (s2.status) atomicOr(&status[env2], s2.status);
+    }
+    if (info) for (int i = l2; i < 4; i += G) info[(size_t)env2 * 4 + i] = out2[1 + i];
+  }
+  if (rst) {  // masked reset inside the step
+    episode += 1;
+    uint64_t es = episode_seed(seed, episode);
+    // robot coordinates get the reset noise; movable blocks return to their cells (ant.py:84-96)
+    for (int i = l2; i < D::NQ; i += G) s2.qpos[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env2, i) : 0.f;
+    for (int i = l2; i < D::NV; i += G) { s2.qvel[i] = i < ANT_NV ? reset_qvel(K.reset_kind, D::NQ, es, env0 + (uint64_t)env2, i) : 0.f; s2.warm[i] = 0.f; }
+    cx.sync();
+    if (l2 == 0) {  // root quaternion normalised in place, as at mz_reset [ASSUME-8]
+      float qn = 1.0f / sqrtf(s2.qpos[3] * s2.qpos[3] + s2.qpos[4] * s2.qpos[4] + s2.qpos[5] * s2.qpos[5] + s2.qpos[6] * s2.qpos[6]);
+      for (int i = 3; i < 7; i++) s2.qpos[i] *= qn;
+    }
+    cx.sync();
+    if (live2) for (int i = l2; i < obs_dim; i += G) obs[(size_t)env2 * obs_dim + i] = ant_obs_elem<NB>(K, s2, i, 0);
+  }
+  cx.sync();
+  if (live2) {
+    DevCtx<G, PROF> cx2{l2};
+    ant_store<NB>(cx2, s2, rec2);
+    if (l2 == 0) { ((int*)rec2)[D::REC_T] = rst ? 0 : t_new; ((uint32_t*)rec2)[D::REC_T + 1] = episode; }
+  }
+  if constexpr (PROF) {
+    cx.tick(s, 10);
+    if (live2 && threadIdx.x == 0 && prof) {
+      unsigned long long tot = 0;
+      for (int k = 0; k < 13; k++) tot += s.prof[k];
+      for (int k = 0; k < 16; k++) if (k != 13 && k != 14) atomicAdd(&prof[k], (unsigned long long)s.prof[k]);
+      atomicMax(&prof[13], tot);                  // slowest wave of the accumulation window
+      atomicAdd(&prof[14], (tot >> 8) * (tot >> 8));  // sum of squares of the per-wave totals (units of 256 cycles)
+    }
+  }
+}
+
+template <int NB, int G>
+__global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const float* __restrict__ state,
+                                                          const float* __restrict__ actions, float* __restrict__ qacc,
+                                                          int* __restrict__ counts) {
+  using D = AntDims<NB>;
+  constexpr int EPB = 64 / G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  AntScratchT<NB>* sc = reinterpret_cast<AntScratchT<NB>*>(lds_raw);
+  DevCtx<G> cx{(int)threadIdx.x % G};
+  const int slot = threadIdx.x / G;
+  int env = blockIdx.x * EPB + slot;
+  const bool live = env < n;
+  if (!live) env = n - 1;
+  AntScratchT<NB>& s = sc[slot];
+  ant_load<NB>(cx, s, state + (size_t)env * D::REC);
+  for (int i = cx.l; i < D::NV; i += G) s.fact[i] = 0.f;
+  if (cx.l == 0) s.status = 0;
+  cx.sync();
+  if (actions)
+    for (int u = cx.l; u < ANT_NU; u += G) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(actions[(size_t)env * ANT_NU + u], K.ctrl_lo), K.ctrl_hi);
+  cx.sync();
+  ant_forward<NB>(cx, K, s, true);
+  if (live) {
+    for (int i = cx.l; i < D::NV; i += G) qacc[(size_t)env * D::NV + i] = s.qacc[i];
+    if (cx.l == 0 && counts) { counts[2 * env] = s.ncon; counts[2 * env + 1] = s.iters; }
+  }
+}
+
+__global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  float* rec = state + (size_t)env * L.rec;
+  if (!mask || mask[env]) {
+    for (int i = 0; i < L.nq; i++) rec[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], seed, env0 + (uint64_t)env, i) : 0.f;
+    {  // set_state -> mj_forward: mj_kinematics normalises the root quaternion in place [ASSUME-8]
+      float qn = 1.0f / sqrtf(rec[3] * rec[3] + rec[4] * rec[4] + rec[5] * rec[5] + rec[6] * rec[6]);
+      for (int i = 3; i < 7; i++) rec[i] *= qn;
+    }
+    for (int i = 0; i < L.nv; i++) {
+      rec[L.nq + i] = i < ANT_NV ? reset_qvel(K.reset_kind, L.nq, seed, env0 + (uint64_t)env, i) : 0.f;
+      rec[L.nq + L.nv + i] = 0.f;
+    }
+    ((int*)rec)[L.rec_t] = 0;
+    ((uint32_t*)rec)[L.rec_t + 1] = 0;
+  }
+  if (obs) {
+    float* o = obs + (size_t)env * L.obs_dim;
+    int k = 0;
+    for (int i = 0; i < 3; i++) o[k++] = rec[i];
+    for (int b = 0; b < L.nblock3 / 3; b++) { o[k++] = K.block_pos0[b][0] + rec[15 + 2 * b]; o[k++] = K.block_pos0[b][1] + rec[16 + 2 * b]; o[k++] = K.block_pos0[b][2]; }
+    for (int i = 3; i < ANT_NQ; i++) o[k++] = rec[i];
+    for (int i = 0; i < ANT_NV; i++) o[k++] = rec[L.nq + i];
+    o[k] = (float)((int*)rec)[L.rec_t] * 0.001f;
+  }
+}
+
+// row-major API arrays <-> state records
+__global__ void ant_set_state_kernel(AntLayout L, int n, float* state, const float* qpos, const float* qvel, const float* warm, const int* t) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int env = idx / L.rec, i = idx % L.rec;
+  if (env >= n) return;
+  float* rec = state + (size_t)env * L.rec;
+  if (i < L.nq) { if (qpos) rec[i] = qpos[(size_t)env * L.nq + i]; }
+  else if (i < L.nq + L.nv) { if (qvel) rec[i] = qvel[(size_t)env * L.nv + i - L.nq]; }
+  else if (i < L.rec_t) { if (warm) rec[i] = warm[(size_t)env * L.nv + i - L.nq - L.nv]; }
+  else if (i == L.rec_t) { if (t) ((int*)rec)[L.rec_t] = t[env]; }
+}
+__global__ void ant_get_state_kernel(AntLayout L, int n, const float* state, float* qpos, float* qvel, float* warm, int* t) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int env = idx / L.rec, i = idx % L.rec;
+  if (env >= n) return;
+  const float* rec = state + (size_t)env * L.rec;
+  if (i < L.nq) { if (qpos) qpos[(size_t)env * L.nq + i] = rec[i]; }
+  else if (i < L.nq + L.nv) { if (qvel) qvel[(size_t)env * L.nv + i - L.nq] = rec[i]; }
+  else if (i < L.rec_t) { if (warm) warm[(size_t)env * L.nv + i - L.nq - L.nv] = rec[i]; }
+  else if (i == L.rec_t) { if (t) t[env] = ((const int*)rec)[L.rec_t]; }
+}
+
+template <int NB, int G>
+static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
+  int wpb = h->waves_per_block;
+  int epb = wpb * 64 / G;
+  size_t lds = (size_t)epb * sizeof(AntEnvLDS<NB>);
+  while (lds > 160 * 1024 && wpb > 1) { wpb /= 2; epb = wpb * 64 / G; lds = (size_t)epb * sizeof(AntEnvLDS<NB>); }
+  const dim3 grid((h->n + epb - 1) / epb), block(64 * wpb);
+  hipError_t e;
+  if (h->prof) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ant_step_kernel<NB, G, true>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
+                       h->auto_reset, h->seed, h->env0, h->prof, h->final_obs);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ant_step_kernel<NB, G, false>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
+                       h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr, h->final_obs);
+  }
+  return hipSuccess;
+}
+template <int NB, int G>
+static hipError_t launch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
+  constexpr int EPB = 64 / G;
+  const size_t lds = (size_t)EPB * sizeof(AntScratchT<NB>);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_forward_kernel<NB, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ant_forward_kernel<NB, G>), dim3((h->n + EPB - 1) / EPB), dim3(64), lds, st, h->ant, h->n, h->state, a, qacc, counts);
+  return hipSuccess;
+}
+// lane widths: the plain ant is instantiated for 8/16/32/64 lanes per env, mazes with movable blocks for 16/32/64.
+// Default: 32 for the plain ant; 64 with blocks (their contact sets keep 64 lanes busy, and the 2048-env batches of those
+// configs then fill the chip with two waves per SIMD instead of one).
+template <int NB>
+static hipError_t dispatch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
+  if constexpr (NB == 0) {
+    if (h->lanes_set && h->lanes == 8) return launch_ant_step<NB, 8>(h, st, a, o, r, d, gi, inf);
+  }
+  const int lanes = h->lanes_set ? h->lanes : (NB ? 64 : 32);
+  if (lanes == 64) return launch_ant_step<NB, 64>(h, st, a, o, r, d, gi, inf);
+  if (lanes == 16) return launch_ant_step<NB, 16>(h, st, a, o, r, d, gi, inf);
+  return launch_ant_step<NB, 32>(h, st, a, o, r, d, gi, inf);
+}
+template <int NB>
+static hipError_t dispatch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
+  if (h->lanes == 16) return launch_ant_forward<NB, 16>(h, st, a, qacc, counts);
+  return launch_ant_forward<NB, 32>(h, st, a, qacc, counts);
+}
+
+// MazeTask.reward / termination on rows of observations (parity tests: the instance of task_eval_dev that is inlined into
+// the Ant step kernel of THIS translation unit, i.e. compiled with its relaxed floating-point flags)
+__global__ void ant_task_eval_kernel(const AntDev* __restrict__ Kp, int n, int obs_dim, const float* __restrict__ obs,
+                                     float* __restrict__ reward, uint8_t* __restrict__ done, int* __restrict__ goal_idx) {
+  int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float o6[6];
+  for (int k = 0; k < 6; k++) o6[k] = obs[(size_t)row * obs_dim + k];
+  float r; int tm, gi;
+  task_eval_dev(Kp->task, o6, &r, &tm, &gi);
+  reward[row] = r;
+  done[row] = (uint8_t)(tm ? 1 : 0);
+  if (goal_idx) goal_idx[row] = gi;
+}
+
+// ------------------------------------------------------------------ entry points of this translation unit (mz_internal.h)
+static hipError_t ant_sync_constants(mz_handle* h, hipStream_t st) {
+  if (!h->ant_dirty) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(h->ant_dev, &h->ant, sizeof(AntDev), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) h->ant_dirty = 0;
+  return e;
+}
+
+hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
+  hipError_t e = ant_sync_constants(h, st);
+  if (e != hipSuccess) return e;
+  switch (h->ant.nblock) {
+    case 0: return dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
+    case 1: return dispatch_ant_step<1>(h, st, a, o, r, d, gi, inf);
+    case 2: return dispatch_ant_step<2>(h, st, a, o, r, d, gi, inf);
+    default: return dispatch_ant_step<3>(h, st, a, o, r, d, gi, inf);
+  }
+}
+
+hipError_t mzk_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
+  switch (h->ant.nblock) {
+    case 0: return dispatch_ant_forward<0>(h, st, a, qacc, counts);
+    case 1: return dispatch_ant_forward<1>(h, st, a, qacc, counts);
+    case 2: return dispatch_ant_forward<2>(h, st, a, qacc, counts);
+    default: return dispatch_ant_forward<3>(h, st, a, qacc, counts);
+  }
+}
+
+hipError_t mzk_ant_reset(mz_handle* h, hipStream_t st, const uint8_t* mask, uint64_t seed, float* obs) {
+  hipLaunchKernelGGL(ant_reset_kernel, dim3((h->n + 255) / 256), dim3(256), 0, st, h->ant, h->lay, h->n, h->state, mask, seed, h->env0, obs);
+  return hipGetLastError();
+}
+
+hipError_t mzk_ant_set_state(mz_handle* h, hipStream_t st, const float* qpos, const float* qvel, const float* warm, const int* t) {
+  int tot = h->n * h->lay.rec;
+  hipLaunchKernelGGL(ant_set_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos, qvel, warm, t);
+  return hipGetLastError();
+}
+
+hipError_t mzk_ant_get_state(mz_handle* h, hipStream_t st, float* qpos, float* qvel, float* warm, int* t) {
+  int tot = h->n * h->lay.rec;
+  hipLaunchKernelGGL(ant_get_state_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, h->lay, h->n, h->state, qpos, qvel, warm, t);
+  return hipGetLastError();
+}
+
+hipError_t mzk_ant_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx) {
+  hipError_t e = ant_sync_constants(h, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ant_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->ant_dev, n, h->lay.obs_dim, obs, reward, done, goal_idx);
+  return hipGetLastError();
+}

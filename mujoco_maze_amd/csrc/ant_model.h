@@ -26,11 +26,15 @@ struct PairDev {  // mixed contact parameters of one geom-pair class
   float margin, mu, K, B, solimp[5];
 };
 
+// Task constants.  Everything a flag depends on is float64, exactly the reference's values (maze_task.py:26-47): the
+// goal predicate `np.linalg.norm(obs[:dim] - pos) <= threshold` is evaluated in fp64 on the returned observation.
+// thr_sq[g] = the largest double s with sqrt(s) <= threshold (sqrt correctly rounded, as numpy's): `s <= thr_sq` is
+// then the same predicate without a square root, so no floating-point build flag can change a flag.
 struct TaskDev {
   int ngoal, reward_kind, reward_slot, reward_binary, term_slot, max_steps;
   int goal_dim[MZ_MAX_GOAL];
-  float goal_pos[MZ_MAX_GOAL][3], thr[MZ_MAX_GOAL], rscale[MZ_MAX_GOAL];
-  float penalty, task_scale, inner_scale, fwd_w, ctrl_w;
+  double goal_pos[MZ_MAX_GOAL][3], thr[MZ_MAX_GOAL], thr_sq[MZ_MAX_GOAL], rscale[MZ_MAX_GOAL];
+  double penalty, task_scale, inner_scale, fwd_w, ctrl_w;
 };
 
 struct MazeDev {
@@ -83,18 +87,29 @@ static inline void pair_from(PairDev* p, const mz_model* m, const double* f1, co
   for (int k = 0; k < 5; k++) p->solimp[k] = (float)si[k];
 }
 
+// largest double s with sqrt(s) <= thr (host libm sqrt is correctly rounded); -1 for a negative threshold (never matches)
+static inline double mz_sqrt_le_bound(double thr) {
+  if (!(thr >= 0.0)) return -1.0;
+  if (isinf(thr)) return thr;
+  double s = thr * thr;
+  while (sqrt(s) > thr) s = nextafter(s, 0.0);
+  while (sqrt(nextafter(s, INFINITY)) <= thr) s = nextafter(s, INFINITY);
+  return s;
+}
+
 static inline void task_dev_from_model(TaskDev* t, const mz_model* m) {
   memset(t, 0, sizeof(*t));
   t->ngoal = m->ngoal; t->reward_kind = m->reward_kind; t->reward_slot = m->reward_slot;
   t->reward_binary = m->reward_binary; t->term_slot = m->term_slot; t->max_steps = m->max_episode_steps;
   for (int g = 0; g < m->ngoal; g++) {
     t->goal_dim[g] = m->goal_dim[g];
-    for (int k = 0; k < 3; k++) t->goal_pos[g][k] = (float)m->goal_pos[g][k];
-    t->thr[g] = (float)m->goal_threshold[g];
-    t->rscale[g] = (float)m->goal_reward_scale[g];
+    for (int k = 0; k < 3; k++) t->goal_pos[g][k] = m->goal_pos[g][k];
+    t->thr[g] = m->goal_threshold[g];
+    t->thr_sq[g] = mz_sqrt_le_bound(m->goal_threshold[g]);
+    t->rscale[g] = m->goal_reward_scale[g];
   }
-  t->penalty = (float)m->penalty; t->task_scale = (float)m->task_scale; t->inner_scale = (float)m->inner_reward_scaling;
-  t->fwd_w = (float)m->forward_reward_weight; t->ctrl_w = (float)m->ctrl_cost_weight;
+  t->penalty = m->penalty; t->task_scale = m->task_scale; t->inner_scale = m->inner_reward_scaling;
+  t->fwd_w = m->forward_reward_weight; t->ctrl_w = m->ctrl_cost_weight;
 }
 
 static inline void maze_dev_from_model(MazeDev* z, const mz_model* m) {

@@ -1,0 +1,95 @@
+// mz_device.h — device-side pieces shared by the kernel translation units (ant_kernels.hip, planar_kernels.hip):
+// the lane-group context, the counter-based RNG of the reset distribution, episode seeding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ------------------------------------------------------------------ device context of a lane group
+template <int G, bool PROF = false>
+struct DevCtx {
+  static constexpr int nlanes = G;
+  int l;
+  // phase timer (PROF builds only): lane 0 of the group accumulates shader cycles since the previous tick
+  template <class S>
+  __device__ __forceinline__ void tick(S& s, int id) const {
+    if constexpr (PROF) {
+      if (l == 0) {
+        unsigned long long now = __builtin_amdgcn_s_memtime();
+        s.prof[id] += (unsigned)(now - s.prof_t0);
+        s.prof_t0 = now;
+      }
+    }
+  }
+  __device__ __forceinline__ int lane0() const { return l; }
+  // A lane group never spans wavefronts and LDS operations of one wavefront execute in order, so a
+  // hand-off between lanes of a group needs no s_barrier: a wavefront-scope fence (no instruction, it only
+  // pins the compiler's ordering of the LDS stores before and loads after) is a complete phase boundary.
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // All-reduce (sum) inside the lane group.  Rows of 16 lanes reduce with four DPP moves (quad_perm xor 1,
+  // xor 2, row_half_mirror, row_mirror: VALU-rate, no LDS crossbar); only the cross-row steps use ds_bpermute.
+  static __device__ __forceinline__ float dpp_add(float x, const int ctrl_sel) {
+    int xi = __float_as_int(x), yi;
+    switch (ctrl_sel) {
+      case 0: yi = __builtin_amdgcn_mov_dpp(xi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+      case 1: yi = __builtin_amdgcn_mov_dpp(xi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+      case 2: yi = __builtin_amdgcn_mov_dpp(xi, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+      default: yi = __builtin_amdgcn_mov_dpp(xi, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return x + __int_as_float(yi);
+  }
+  __device__ __forceinline__ float gsum(float x) const {
+    if constexpr (G >= 2) x = dpp_add(x, 0);
+    if constexpr (G >= 4) x = dpp_add(x, 1);
+    if constexpr (G >= 8) x = dpp_add(x, 2);
+    if constexpr (G >= 16) x = dpp_add(x, 3);
+    if constexpr (G >= 32) x += __shfl_xor(x, 16, 64);
+    if constexpr (G >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+  }
+  __device__ __forceinline__ double gsum(double x) const {  // fp64 paths (Point): plain butterfly
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) x += __shfl_xor(x, o, 64);
+    return x;
+  }
+  __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+  // any() restricted to this lane group: one ballot, no shuffles
+  __device__ __forceinline__ bool gany(bool p) const {
+    unsigned long long b = __ballot(p);
+    unsigned lane = __lane_id();
+    unsigned long long gm = (G >= 64) ? ~0ULL : (((1ULL << (G & 63)) - 1ULL) << (lane - (unsigned)l));
+    return (b & gm) != 0ULL;
+  }
+};
+
+// ------------------------------------------------------------------ RNG (same definition as the oracle's mzo_rng_u32)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t env, uint32_t counter) {
+  uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (env + 1));
+  z = mix64(z + 0x9E3779B97F4A7C15ULL * ((uint64_t)counter + 1));
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float rng_u01(uint64_t seed, uint64_t env, uint32_t c) { return (float)(rng_u32(seed, env, c) >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float rng_normal(uint64_t seed, uint64_t env, uint32_t c) {
+  float u1 = ((float)(rng_u32(seed, env, c) >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  float u2 = rng_u01(seed, env, c + 1);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+// reset distribution (ant.py:84-96, point.py:71-81): qpos0 + U(-.1,.1); qvel by kind
+__device__ __forceinline__ float reset_qpos(float q0, uint64_t seed, uint64_t env, int i) { return q0 + (-0.1f + 0.2f * rng_u01(seed, env, (uint32_t)i)); }
+__device__ __forceinline__ float reset_qvel(int kind, int nq, uint64_t seed, uint64_t env, int i) {
+  uint32_t c = (uint32_t)(nq + 2 * i);
+  if (kind == 0) return 0.1f * rng_normal(seed, env, c);
+  if (kind == 1) return 0.1f * rng_u01(seed, env, c);
+  return -0.1f + 0.2f * rng_u01(seed, env, c);
+}
+__host__ __device__ __forceinline__ uint64_t episode_seed(uint64_t seed, uint32_t episode) {
+  return episode == 0 ? seed : mix64(seed ^ (0xD6E8FEB86659FD93ULL * (uint64_t)episode));
+}

@@ -1,0 +1,60 @@
+// mz_internal.h — what the three translation units of libmazestep.so share on the HOST side:
+//   mazestep.hip        the C-ABI of include/mazestep.h (handle life cycle, options, argument checks, dispatch)
+//   ant_kernels.hip     Ant kernels (fp32, built with the relaxed floating-point flags of csrc/Makefile)
+//   planar_kernels.hip  Point / Swimmer / Reacher kernels (fp64, built with strict IEEE flags: the Point's manual wall
+//                       detector and every task predicate must reproduce the reference's float64 decisions bit for bit)
+// Kernels never call across translation units, so no relocatable device code is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ant_model.h"
+#include "point_dyn.h"
+#include "swimmer_dyn.h"
+
+struct AntLayout { int nq, nv, rec, rec_t, obs_dim, nblock3; };  // record layout of the instantiated block count
+
+struct mz_handle {
+  mz_model model;
+  int n, device, robot;
+  AntDev ant;
+  AntDev* ant_dev;  // device copy read by the step kernel (refreshed when an option changes it)
+  int ant_dirty;
+  AntLayout lay;
+  PointDev* point_dev;  // device copy
+  PointDev point;
+  SwimmerDev* swimmer_dev;
+  SwimmerDev swimmer;
+  float* state;         // ant: [n][REC]; point / swimmer: SoA [2 NV][n]
+  int* pt_t;
+  uint32_t* pt_ep;
+  int* status;
+  float* final_obs;     // caller's buffer for terminal observations under auto-reset (mz_bind_final_obs), or NULL
+  unsigned long long* prof;  // 16 phase-cycle accumulators (option "profile_phases")
+  int auto_reset, lanes, waves_per_block;
+  uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
+  char err[256];
+  int lanes_set;  // lanes_per_env chosen by the caller (else the per-robot default)
+  // kernel timing ring (option "time_kernels")
+  int ntime, itime;
+  hipEvent_t* ev;  // 2 * ntime
+  long nsteps;
+};
+
+// ---- ant_kernels.hip
+hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* actions, float* obs, float* reward, uint8_t* done, int* goal_idx, float* info);
+hipError_t mzk_ant_forward(mz_handle* h, hipStream_t st, const float* actions, float* qacc, int* counts);
+hipError_t mzk_ant_reset(mz_handle* h, hipStream_t st, const uint8_t* mask, uint64_t seed, float* obs);
+hipError_t mzk_ant_set_state(mz_handle* h, hipStream_t st, const float* qpos, const float* qvel, const float* warm, const int* t);
+hipError_t mzk_ant_get_state(mz_handle* h, hipStream_t st, float* qpos, float* qvel, float* warm, int* t);
+hipError_t mzk_ant_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx);
+
+// ---- planar_kernels.hip (Point, Swimmer, Reacher)
+hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions, float* obs, float* reward, uint8_t* done, int* goal_idx, float* info);
+hipError_t mzk_planar_reset(mz_handle* h, hipStream_t st, const uint8_t* mask, uint64_t seed, float* obs);
+hipError_t mzk_planar_set_state(mz_handle* h, hipStream_t st, const float* qpos, const float* qvel, const int* t);
+hipError_t mzk_planar_get_state(mz_handle* h, hipStream_t st, float* qpos, float* qvel, float* warm, int* t);
+hipError_t mzk_planar_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx);
+hipError_t mzk_point_detect(mz_handle* h, hipStream_t st, int n, const double* old_xy, const double* new_xy, int* hit, double* point,
+                            double* final_xy);
+int mzk_planar_state_width(const mz_handle* h);  // coordinates per env of the SoA state (NV)

@@ -527,16 +527,10 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
   // maze_env.py:454-464: manual wall bounce on the robot's xy
   if (P.nseg > 0) {
     MZ_FOR(one, 1) {
-      double old_xy[2] = {old_x, old_y}, new_xy[2] = {s.q[0], s.q[1]}, pt[2], rf[2];
-      int hit = point_detect(P, old_xy, new_xy, pt, rf);
-      if (hit < 0) s.status |= MZ_STATUS_COLLINEAR;
-      if (hit > 0) {
-        double pos[2] = {pt[0] + P.restitution * (rf[0] - pt[0]), pt[1] + P.restitution * (rf[1] - pt[1])}, p2[2], r2[2];
-        int again = point_detect(P, old_xy, pos, p2, r2);
-        if (again < 0) s.status |= MZ_STATUS_COLLINEAR;
-        if (again > 0) { s.q[0] = old_xy[0]; s.q[1] = old_xy[1]; }
-        else if (again == 0) { s.q[0] = pos[0]; s.q[1] = pos[1]; }
-      }
+      double old_xy[2] = {old_x, old_y}, new_xy[2] = {s.q[0], s.q[1]}, fin[2];
+      int r = point_bounce(P, old_xy, new_xy, fin, nullptr);
+      if (r < 0) s.status |= MZ_STATUS_COLLINEAR;
+      s.q[0] = fin[0]; s.q[1] = fin[1];
     }
     cx.sync();
   }

@@ -1,0 +1,354 @@
+// planar_kernels.hip — HIP kernels (gfx950 / CDNA4) of the Point, Swimmer and Reacher paths and their launchers.
+//
+//   planar_step_kernel<NB,NS,G>  one MazeEnv.step for the Point (+ NB movable blocks or NS object balls): lane group
+//                                per env, PlanarScratch in LDS, fp64.
+//   swimmer_step_kernel<NL,NB>   one MazeEnv.step for the Swimmer (NL = 3) / Reacher (NL = 2): one env per lane, fp64.
+//   reset / state copy kernels; debug kernels for the parity tests (task predicates, the Point's wall detector).
+//
+// HBM layout: SoA  q_0..q_{NV-1} | v_0..v_{NV-1}, each [N] fp32; t[N], episode[N] i32.  API arrays are row-major [N, k].
+//
+// This translation unit is built with STRICT floating-point flags (csrc/Makefile: no -freciprocal-math, no
+// -fapprox-func, no -fno-signed-zeros): the Point's manual wall detector (point_dyn.h: point_detect / point_bounce) and
+// the task predicates reproduce the reference's float64 decisions bit for bit — IEEE division and square root, and no
+// contraction inside those functions (#pragma clang fp contract(off)).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ant_dyn.h"
+#include "point_dyn.h"
+#include "planar_dyn.h"
+#include "swimmer_dyn.h"
+#include "mz_device.h"
+#include "mz_internal.h"
+
+// ------------------------------------------------------------------ Point kernels (SoA: q0 q1 q2 v0 v1 v2 | t | episode)
+struct PointState { float* qv; int* t; uint32_t* ep; };
+
+// One MazeEnv.step of the Point (+ NB movable blocks or NS object balls): G lanes per env, PlanarScratch in LDS, SoA state in HBM
+// (q_0..q_{NV-1} | v_0..v_{NV-1}, each [n]).
+template <int NB, int NS, int G>
+__global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
+                                                          const float* __restrict__ actions, float* __restrict__ obs,
+                                                          float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                          int* __restrict__ goal_idx, float* __restrict__ info,
+                                                          int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
+                                                          float* __restrict__ final_obs) {
+  using D = PlanarDims<NB, NS>;
+  constexpr int NV = D::NV, NOBS = D::NOBS, EPW = 64 / G;
+  __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
+  __shared__ PlanarScratch<NB, NS> scr[EPW];
+  __shared__ float obuf[EPW][MZ_MAX_OBS];
+  for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
+  __syncthreads();
+  DevCtx<G> cx{(int)threadIdx.x % G};
+  const int grp = threadIdx.x / G;
+  int env = blockIdx.x * EPW + grp;
+  const bool live = env < n;
+  if (!live) env = n - 1;  // idle groups shadow the last env (no stores) so that every lane reaches the wave-level votes
+  PlanarScratch<NB, NS>& s = scr[grp];
+  for (int k = cx.l; k < NV; k += G) { s.q[k] = (double)S.qv[(size_t)k * n + env]; s.v[k] = (double)S.qv[(size_t)(NV + k) * n + env]; }
+  double a[2] = {(double)actions[(size_t)env * 2], (double)actions[(size_t)env * 2 + 1]};
+  const int t_new = S.t[env] + 1;
+  cx.sync();
+  planar_env_step<NB, NS>(cx, P, s, a);
+  float* o = obuf[grp];
+  for (int i = cx.l; i < NOBS; i += G) o[i] = planar_obs_elem<NB, NS>(P, s, i, t_new);
+  cx.sync();
+  float outer; int tm, gi;
+  task_eval_dev(P.task, o, &outer, &tm, &gi);  // flags from the fp32 observation that is returned
+  const uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
+  const bool rst = auto_reset && d;  // vector-env convention: obs <- first observation of the new episode, terminal one -> final_obs
+  if (live) {
+    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env * NOBS;
+    if (!rst || final_obs) for (int i = cx.l; i < NOBS; i += G) orow[i] = o[i];
+    if (cx.l == 0) {
+      reward[env] = outer;  // Point inner reward is 0.0 (point.py:61)
+      done[env] = d;
+      if (goal_idx) goal_idx[env] = gi;
+      if (info) { info[(size_t)env * 4] = o[0]; info[(size_t)env * 4 + 1] = o[1]; info[(size_t)env * 4 + 2] = 0.f; info[(size_t)env * 4 + 3] = 0.f; }
+      int st = s.status;
+      bool badv = false;
+      for (int k = 0; k < NV; k++) badv = badv || !(fabs(s.q[k]) < 1e10) || !(fabs(s.v[k]) < 1e10);
+      if (badv) st |= MZ_STATUS_BAD_STATE;
+      if (st) atomicOr(&status[env], st);
+    }
+  }
+  uint32_t ep = S.ep[env];
+  if (rst) {  // point.py:71-81: noise on the robot, blocks / ball back to their spawn state
+    ep += 1;
+    const uint64_t es = episode_seed(seed, ep);
+    cx.sync();
+    for (int k = cx.l; k < NV; k += G) {
+      s.q[k] = k < 3 ? (double)reset_qpos((float)P.qpos0[k], es, env0 + (uint64_t)env, k) : 0.0;
+      s.v[k] = k < 3 ? (double)reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k) : 0.0;
+    }
+    cx.sync();
+    if (live) for (int i = cx.l; i < NOBS; i += G) obs[(size_t)env * NOBS + i] = planar_obs_elem<NB, NS>(P, s, i, 0);
+  }
+  if (live) {
+    for (int k = cx.l; k < NV; k += G) {
+      S.qv[(size_t)k * n + env] = (float)s.q[k];
+      S.qv[(size_t)(NV + k) * n + env] = (float)s.v[k];
+    }
+    if (cx.l == 0) { S.t[env] = rst ? 0 : t_new; S.ep[env] = ep; }
+  }
+}
+
+template <int NB, int NS>
+__global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+  constexpr int NV = 3 + 2 * NB + 3 * NS, NOBS = 7 + 3 * NB + 3 * NS;
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  if (!mask || mask[env]) {
+    for (int k = 0; k < NV; k++) {
+      S.qv[(size_t)k * n + env] = k < 3 ? reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k) : 0.f;
+      S.qv[(size_t)(NV + k) * n + env] = k < 3 ? reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k) : 0.f;
+    }
+    S.t[env] = 0;
+    S.ep[env] = 0;
+  }
+  if (obs) {
+    const int nb3 = (Pp->observe_blocks ? 3 * NB : 0) + (Pp->observe_balls ? 3 * NS : 0);
+    float* o = obs + (size_t)env * NOBS;
+    for (int k = 0; k < 3; k++) { o[k] = S.qv[(size_t)k * n + env]; o[3 + nb3 + k] = S.qv[(size_t)(NV + k) * n + env]; }
+    if (NS > 0 && nb3) {
+      o[3] = (float)Pp->ball_pos0[0] + S.qv[(size_t)3 * n + env]; o[4] = (float)Pp->ball_pos0[1] + S.qv[(size_t)4 * n + env];
+      o[5] = (float)Pp->ball_pos0[2];
+    }
+    for (int b = 0; b < NB && nb3; b++) {
+      o[3 + 3 * b] = (float)Pp->block_pos0[b][0] + S.qv[(size_t)(3 + 2 * b) * n + env];
+      o[4 + 3 * b] = (float)Pp->block_pos0[b][1] + S.qv[(size_t)(4 + 2 * b) * n + env];
+      o[5 + 3 * b] = (float)Pp->block_pos0[b][2];
+    }
+    o[6 + nb3] = (float)S.t[env] * 0.001f;
+  }
+}
+
+template <int KQ>
+__global__ void point_set_state_kernel(int n, PointState S, const float* qpos, const float* qvel, const int* t) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  for (int k = 0; k < KQ; k++) {
+    if (qpos) S.qv[(size_t)k * n + env] = qpos[(size_t)env * KQ + k];
+    if (qvel) S.qv[(size_t)(KQ + k) * n + env] = qvel[(size_t)env * KQ + k];
+  }
+  if (t) S.t[env] = t[env];
+}
+template <int KQ>
+__global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* qvel, float* warm, int* t) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  for (int k = 0; k < KQ; k++) {
+    if (qpos) qpos[(size_t)env * KQ + k] = S.qv[(size_t)k * n + env];
+    if (qvel) qvel[(size_t)env * KQ + k] = S.qv[(size_t)(KQ + k) * n + env];
+    if (warm) warm[(size_t)env * KQ + k] = 0.f;
+  }
+  if (t) t[env] = S.t[env];
+}
+
+// ------------------------------------------------------------------ Swimmer / Reacher kernels (NL links, NB movable blocks;
+// SoA: q0..q[NV-1] v0..v[NV-1] | t | episode with NV = NL + 2 + 2 NB)
+//
+// Observation / reset layout: swimmer_dyn.h (swimmer_obs_row).  Reset (swimmer.py:56-69): U(-0.1, 0.1) noise on ALL nq
+// coordinates and ALL nv velocities, the block's included.
+template <int NL, int NB>
+__global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __restrict__ Pp, int n, PointState S,
+                                                            const float* __restrict__ actions, float* __restrict__ obs,
+                                                            float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                            int* __restrict__ goal_idx, float* __restrict__ info,
+                                                            int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
+                                                            float* __restrict__ final_obs) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  constexpr int NR = NL + 2, NV = NR + 2 * NB, NH = NL - 1;
+  const SwimmerDev& P = *Pp;
+  const int nb3 = P.observe_blocks ? 3 * NB : 0, NO = 2 * NV + 1 + nb3;
+  float qf[NV], vf[NV], af[NH > 0 ? NH : 1], o[2 * NV + 1 + 3 * NB];
+  double inner, inf4[4];
+  for (int k = 0; k < NV; k++) { qf[k] = S.qv[(size_t)k * n + env]; vf[k] = S.qv[(size_t)(NV + k) * n + env]; }
+  for (int k = 0; k < NH; k++) af[k] = actions[(size_t)env * NH + k];
+  int t_new;
+  int st = swimmer_maze_step<NL, NB>(P, qf, vf, af, S.t[env], o, &inner, inf4, &t_new);
+  float outer; int tm, gi;
+  task_eval_dev(P.task, o, &outer, &tm, &gi);
+  uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
+  const bool rst = auto_reset && d;
+  {
+    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env * NO;
+    if (!rst || final_obs) for (int k = 0; k < NO; k++) orow[k] = o[k];
+  }
+  reward[env] = (float)(P.task.inner_scale * inner) + outer;
+  done[env] = d;
+  if (goal_idx) goal_idx[env] = gi;
+  if (info) for (int k = 0; k < 4; k++) info[(size_t)env * 4 + k] = (float)inf4[k];
+  if (st) atomicOr(&status[env], st);
+  uint32_t ep = S.ep[env];
+  if (rst) {
+    ep += 1; t_new = 0;
+    const uint64_t es = episode_seed(seed, ep);
+    for (int k = 0; k < NV; k++) {
+      qf[k] = reset_qpos(k < NR ? (float)P.qpos0[k] : 0.f, es, env0 + (uint64_t)env, k);
+      vf[k] = reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k);
+    }
+    swimmer_obs_row<NL, NB>(P, qf, vf, 0, o);
+    for (int k = 0; k < NO; k++) obs[(size_t)env * NO + k] = o[k];
+  }
+  for (int k = 0; k < NV; k++) {
+    S.qv[(size_t)k * n + env] = qf[k];
+    S.qv[(size_t)(NV + k) * n + env] = vf[k];
+  }
+  S.t[env] = t_new;
+  S.ep[env] = ep;
+}
+
+template <int NL, int NB>
+__global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+  constexpr int NR = NL + 2, NV = NR + 2 * NB;
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  if (!mask || mask[env]) {
+    for (int k = 0; k < NV; k++) {
+      S.qv[(size_t)k * n + env] = reset_qpos(k < NR ? (float)Pp->qpos0[k] : 0.f, seed, env0 + (uint64_t)env, k);
+      S.qv[(size_t)(NV + k) * n + env] = reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k);
+    }
+    S.t[env] = 0;
+    S.ep[env] = 0;
+  }
+  if (obs) {
+    const int nb3 = Pp->observe_blocks ? 3 * NB : 0, NO = 2 * NV + 1 + nb3;
+    float qf[NV], vf[NV], o[2 * NV + 1 + 3 * NB];
+    for (int k = 0; k < NV; k++) { qf[k] = S.qv[(size_t)k * n + env]; vf[k] = S.qv[(size_t)(NV + k) * n + env]; }
+    swimmer_obs_row<NL, NB>(*Pp, qf, vf, S.t[env], o);
+    for (int k = 0; k < NO; k++) obs[(size_t)env * NO + k] = o[k];
+  }
+}
+
+// ------------------------------------------------------------------ parity-test kernels
+// MazeTask.reward / termination on rows of observations: the task_eval_dev instance of this translation unit
+__global__ void planar_task_eval_kernel(const TaskDev* __restrict__ Tp, int n, int obs_dim, const float* __restrict__ obs,
+                                        float* __restrict__ reward, uint8_t* __restrict__ done, int* __restrict__ goal_idx) {
+  int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float o6[6];
+  for (int k = 0; k < 6; k++) o6[k] = obs[(size_t)row * obs_dim + k];
+  float r; int tm, gi;
+  task_eval_dev(*Tp, o6, &r, &tm, &gi);
+  reward[row] = r;
+  done[row] = (uint8_t)(tm ? 1 : 0);
+  if (goal_idx) goal_idx[row] = gi;
+}
+
+// CollisionDetector.detect + the bounce / give-up rule of MazeEnv.step on rows of float64 (old_xy, new_xy) moves: the
+// point_detect / point_bounce instances the Point step kernel runs.  hit: 0 none, 1 bounced, 2 gave up, -1 collinear.
+__global__ void point_detect_kernel(const PointDev* __restrict__ Pp, int n, const double* __restrict__ old_xy,
+                                    const double* __restrict__ new_xy, int* __restrict__ hit, double* __restrict__ point,
+                                    double* __restrict__ final_xy) {
+  __shared__ PointDev P;
+  for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
+  __syncthreads();
+  int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double o[2] = {old_xy[2 * row], old_xy[2 * row + 1]}, nw[2] = {new_xy[2 * row], new_xy[2 * row + 1]}, fin[2], pt[2];
+  int r = point_bounce(P, o, nw, fin, pt);
+  hit[row] = r;
+  if (point) { point[2 * row] = pt[0]; point[2 * row + 1] = pt[1]; }
+  final_xy[2 * row] = fin[0]; final_xy[2 * row + 1] = fin[1];
+}
+
+// ------------------------------------------------------------------ entry points of this translation unit (mz_internal.h)
+int mzk_planar_state_width(const mz_handle* h) {
+  return h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock + 3 * h->point.nball;
+}
+
+hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                           int* goal_idx_dev, float* info_dev) {
+  PointState S{h->state, h->pt_t, h->pt_ep};
+  if (h->robot == MZ_ROBOT_SWIMMER) {
+#define MZ_SW_STEP(NL, NB)                                                                                                          \
+  hipLaunchKernelGGL((swimmer_step_kernel<NL, NB>), dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev, \
+                     reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs)
+    if (h->swimmer.nlink == 3) { if (h->swimmer.nblock) MZ_SW_STEP(3, 1); else MZ_SW_STEP(3, 0); }
+    else { if (h->swimmer.nblock) MZ_SW_STEP(2, 1); else MZ_SW_STEP(2, 0); }
+#undef MZ_SW_STEP
+    return hipGetLastError();
+  }
+  // lanes per env: 16 for the bare robot (18 collision enumerators), 32 / 64 with blocks (bigger contact sets in LDS)
+#define MZ_PLANAR_LAUNCH(NB, NS, G)                                                                                                    \
+  hipLaunchKernelGGL((planar_step_kernel<NB, NS, G>), dim3((h->n + 64 / G - 1) / (64 / G)), dim3(64), 0, st, h->point_dev, h->n, S, actions_dev, \
+                     obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs)
+  if (h->point.nball) MZ_PLANAR_LAUNCH(0, 1, 32);
+  else switch (h->point.nblock) {
+    case 0:
+      if (h->lanes_set && h->lanes == 8) MZ_PLANAR_LAUNCH(0, 0, 8);
+      else if (h->lanes_set && h->lanes == 32) MZ_PLANAR_LAUNCH(0, 0, 32);
+      else MZ_PLANAR_LAUNCH(0, 0, 16);
+      break;
+    case 1: MZ_PLANAR_LAUNCH(1, 0, 32); break;
+    case 2: MZ_PLANAR_LAUNCH(2, 0, 64); break;
+    default: MZ_PLANAR_LAUNCH(3, 0, 64); break;
+  }
+#undef MZ_PLANAR_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t mzk_planar_reset(mz_handle* h, hipStream_t st, const uint8_t* mask_dev, uint64_t seed, float* obs_dev) {
+  PointState S{h->state, h->pt_t, h->pt_ep};
+  const int nb = (h->n + 255) / 256;
+  if (h->robot == MZ_ROBOT_SWIMMER) {
+#define MZ_SW_RESET(NL, NB) hipLaunchKernelGGL((swimmer_reset_kernel<NL, NB>), dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev)
+    if (h->swimmer.nlink == 3) { if (h->swimmer.nblock) MZ_SW_RESET(3, 1); else MZ_SW_RESET(3, 0); }
+    else { if (h->swimmer.nblock) MZ_SW_RESET(2, 1); else MZ_SW_RESET(2, 0); }
+#undef MZ_SW_RESET
+    return hipGetLastError();
+  }
+  if (h->point.nball) hipLaunchKernelGGL((point_reset_kernel<0, 1>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+  else switch (h->point.nblock) {
+    case 0: hipLaunchKernelGGL((point_reset_kernel<0, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+    case 1: hipLaunchKernelGGL((point_reset_kernel<1, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+    case 2: hipLaunchKernelGGL((point_reset_kernel<2, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+    default: hipLaunchKernelGGL((point_reset_kernel<3, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t mzk_planar_set_state(mz_handle* h, hipStream_t st, const float* qpos_dev, const float* qvel_dev, const int* t_dev) {
+  PointState S{h->state, h->pt_t, h->pt_ep};
+  const dim3 grid((h->n + 255) / 256), blk(256);
+  switch (mzk_planar_state_width(h)) {
+    case 3: hipLaunchKernelGGL(point_set_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+    case 4: hipLaunchKernelGGL(point_set_state_kernel<4>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+    case 5: hipLaunchKernelGGL(point_set_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+    case 6: hipLaunchKernelGGL(point_set_state_kernel<6>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+    case 7: hipLaunchKernelGGL(point_set_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+    default: hipLaunchKernelGGL(point_set_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t mzk_planar_get_state(mz_handle* h, hipStream_t st, float* qpos_dev, float* qvel_dev, float* warmstart_dev, int* t_dev) {
+  PointState S{h->state, h->pt_t, h->pt_ep};
+  const dim3 grid((h->n + 255) / 256), blk(256);
+  switch (mzk_planar_state_width(h)) {
+    case 3: hipLaunchKernelGGL(point_get_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+    case 4: hipLaunchKernelGGL(point_get_state_kernel<4>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+    case 5: hipLaunchKernelGGL(point_get_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+    case 6: hipLaunchKernelGGL(point_get_state_kernel<6>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+    case 7: hipLaunchKernelGGL(point_get_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+    default: hipLaunchKernelGGL(point_get_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t mzk_planar_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx) {
+  const TaskDev* Tp = h->robot == MZ_ROBOT_SWIMMER ? &h->swimmer_dev->task : &h->point_dev->task;
+  hipLaunchKernelGGL(planar_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Tp, n, h->model.obs_dim, obs, reward, done, goal_idx);
+  return hipGetLastError();
+}
+
+hipError_t mzk_point_detect(mz_handle* h, hipStream_t st, int n, const double* old_xy, const double* new_xy, int* hit, double* point,
+                            double* final_xy) {
+  hipLaunchKernelGGL(point_detect_kernel, dim3((n + 63) / 64), dim3(64), 0, st, h->point_dev, n, old_xy, new_xy, hit, point, final_xy);
+  return hipGetLastError();
+}

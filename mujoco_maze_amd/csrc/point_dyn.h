@@ -149,12 +149,46 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
 #define MZP_HD inline
 #endif
 
-MZP_HD double cross2d(double ax, double ay, double bx, double by) { return ax * by + (-ay) * bx; }
+// ---- the manual wall detector: float64 arithmetic of the reference, operation for operation.
+// The reference computes with Python complex numbers and floats (maze_env_utils.py:84-123): every product, sum and
+// quotient is a separately rounded IEEE double operation and abs(complex) is C hypot().  The functions below keep that:
+// `#pragma clang fp contract(off)` (no fused multiply-add), exact division and square root (this translation unit is
+// built WITHOUT -freciprocal-math / -fapprox-func, csrc/Makefile), and mz_hypot restates glibc's hypot so that the
+// "nearest collision" comparison sees the same distances.
 
-// CollisionDetector.detect: 1 hit, 0 none, -1 collinear (the reference raises ZeroDivisionError)
+// glibc 2.35 __hypot (sysdeps/ieee754/dbl-64/e_hypot.c, the non-FMA kernel that x86-64 builds use), valid for the
+// magnitudes a maze coordinate can take (no scaling branches: |x|, |y| in [2^-459, 2^511] or zero).  Checked bit for bit
+// against libm hypot on the host (tests/test_maze_golden.py) — CPython's abs(complex) calls exactly that function.
+MZP_HD double mz_hypot(double x, double y) {
+#pragma clang fp contract(off)
+  double ax = fabs(x), ay = fabs(y);
+  if (ax < ay) { double t = ax; ax = ay; ay = t; }
+  if (ax >= ay * 0x1p54) return ax + ay;
+  double h = sqrt(ax * ax + ay * ay), t1, t2;
+  if (h <= 2.0 * ay) {
+    double delta = h - ay;
+    t1 = ax * (2.0 * delta - ax);
+    t2 = (delta - 2.0 * (ax - ay)) * delta;
+  } else {
+    double delta = h - ax;
+    t1 = 2.0 * delta * (ax - 2.0 * ay);
+    t2 = (4.0 * delta - ay) * ay + delta * delta;
+  }
+  h -= (t1 + t2) / (2.0 * h);
+  return h;
+}
+
+// (conj(a) * b).imag of maze_env_utils.py:99 with a = ax + i ay, b = bx + i by:  ax * by + (-ay) * bx
+MZP_HD double cross2d(double ax, double ay, double bx, double by) {
+#pragma clang fp contract(off)
+  return ax * by + (-ay) * bx;
+}
+
+// CollisionDetector.detect (maze_env_utils.py:186-206): 1 hit, 0 none, -1 collinear (the reference raises ZeroDivisionError)
 MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, double* pt, double* rf) {
+#pragma clang fp contract(off)
   double mvx = n[0] - o[0], mvy = n[1] - o[1];
-  if (hypot(mvx, mvy) <= 1e-8) return 0;
+  if (mz_hypot(mvx, mvy) <= 1e-8) return 0;
   int found = 0, degenerate = 0;
   double best = 0.0;
   for (int k = 0; k < P.nseg; k++) {
@@ -167,11 +201,11 @@ MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, dou
     double a = cross2d(wx, wy, mvx, mvy), b = cross2d(wx, wy, s[2] - o[0], s[3] - o[1]);
     if (a == 0.0) { degenerate = 1; continue; }
     double r = b / a, px = o[0] + r * mvx, py = o[1] + r * mvy;
-    double dist = hypot(px - o[0], py - o[1]);
+    double dist = mz_hypot(px - o[0], py - o[1]);
     if (!found || dist < best) {
       found = 1; best = dist;
       pt[0] = px; pt[1] = py;
-      double bx = -wx, by = -wy, n2 = hypot(bx, by);
+      double bx = -wx, by = -wy, n2 = mz_hypot(bx, by);
       n2 = n2 * n2;
       double dx = n[0] - s[0], dy = n[1] - s[1];
       double sc = (dx * bx - (-dy) * by) / n2;
@@ -182,6 +216,23 @@ MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, dou
   }
   if (degenerate && !found) return -1;
   return found;
+}
+
+// Wall bounce of MazeEnv.step (maze_env.py:457-464): 0 no hit, 1 bounced to `fin`, 2 gave up (fin = old position),
+// -1 where the reference would have raised (collinear move; fin = new position)
+MZP_HD int point_bounce(const PointDev& P, const double* old_xy, const double* new_xy, double* fin, double* hit_pt) {
+#pragma clang fp contract(off)
+  double pt[2] = {0.0, 0.0}, rf[2] = {0.0, 0.0};
+  fin[0] = new_xy[0]; fin[1] = new_xy[1];
+  int hit = point_detect(P, old_xy, new_xy, pt, rf);
+  if (hit_pt) { hit_pt[0] = pt[0]; hit_pt[1] = pt[1]; }
+  if (hit <= 0) return hit;
+  double pos[2] = {pt[0] + P.restitution * (rf[0] - pt[0]), pt[1] + P.restitution * (rf[1] - pt[1])}, p2[2], r2[2];
+  int again = point_detect(P, old_xy, pos, p2, r2);
+  if (again < 0) return -1;
+  if (again > 0) { fin[0] = old_xy[0]; fin[1] = old_xy[1]; return 2; }
+  fin[0] = pos[0]; fin[1] = pos[1];
+  return 1;
 }
 
 MZP_HD void point_qacc(const PointDev& P, const double* q, const double* v, double* a) {

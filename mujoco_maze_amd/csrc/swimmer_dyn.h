@@ -312,3 +312,44 @@ MZS_HD int swimmer_env_step(const SwimmerDev& P, double* q, double* v, const dou
   *t_out = t_in + 1;
   return status;
 }
+
+// Observation row (swimmer.py:50-54 returns the WHOLE qpos and qvel — the slides of a movable block included — and
+// MazeEnv._get_obs, maze_env.py:351-369, splices the block positions in after the first three entries):
+//   qpos[0:3] | block xyz (3 each, if observed) | qpos[3:NV] | qvel[0:NV] | t * 0.001        (SwimmerPush: 18 numbers)
+template <int NL, int NB>
+MZS_HD void swimmer_obs_row(const SwimmerDev& P, const float* qf, const float* vf, int t, float* o) {
+  constexpr int NV = NL + 2 + 2 * NB;
+  const int nb3 = P.observe_blocks ? 3 * NB : 0;
+  for (int k = 0; k < 3; k++) o[k] = qf[k];
+  for (int b = 0; b < NB && nb3; b++) {
+    o[3 + 3 * b] = (float)(P.block_pos0[b][0] + (double)qf[NL + 2 + 2 * b]); o[4 + 3 * b] = (float)(P.block_pos0[b][1] + (double)qf[NL + 3 + 2 * b]);
+    o[5 + 3 * b] = (float)P.block_pos0[b][2];
+  }
+  for (int k = 3; k < NV; k++) o[nb3 + k] = qf[k];
+  for (int k = 0; k < NV; k++) o[nb3 + NV + k] = vf[k];
+  o[nb3 + 2 * NV] = (float)t * 0.001f;
+}
+
+// One MazeEnv.step of a swimmer / reacher env with NB movable blocks on the fp32 state (qf, vf: NV = NL + 2 + 2 NB entries,
+// in and out): the chain's step, the blocks' drift, the observation row o[2 NV + 1 + 3 NB] and the inner reward.
+// Returns status bits.  Shared by swimmer_step_kernel and the CPU emulation of tests/emu.
+template <int NL, int NB>
+MZS_HD int swimmer_maze_step(const SwimmerDev& P, float* qf, float* vf, const float* action, int t_in, float* o, double* inner_reward,
+                             double* info4, int* t_out) {
+  constexpr int NR = NL + 2, NH = NL - 1;
+  double q[NR], v[NR], a[NH];
+  for (int k = 0; k < NR; k++) { q[k] = (double)qf[k]; v[k] = (double)vf[k]; }
+  for (int k = 0; k < NH; k++) a[k] = (double)action[k];
+  int st = swimmer_env_step<NL>(P, q, v, a, t_in, inner_reward, info4, t_out);
+  bool badv = false;
+  for (int k = 0; k < NR; k++) { badv = badv || !(fabs(q[k]) < 1e10) || !(fabs(v[k]) < 1e10); qf[k] = (float)q[k]; vf[k] = (float)v[k]; }
+  // blocks: no contacts (swimmer.xml:3 collision="predefined"), only the medium's drag on a moving box
+  for (int b = 0; b < NB; b++) {
+    double q2[2] = {(double)qf[NR + 2 * b], (double)qf[NR + 2 * b + 1]}, v2[2] = {(double)vf[NR + 2 * b], (double)vf[NR + 2 * b + 1]};
+    if (v2[0] != 0.0 || v2[1] != 0.0) swimmer_block_step(P, q2, v2);
+    for (int c = 0; c < 2; c++) { badv = badv || !(fabs(q2[c]) < 1e10) || !(fabs(v2[c]) < 1e10); qf[NR + 2 * b + c] = (float)q2[c]; vf[NR + 2 * b + c] = (float)v2[c]; }
+  }
+  if (badv) st |= MZ_STATUS_BAD_STATE;
+  swimmer_obs_row<NL, NB>(P, qf, vf, *t_out, o);
+  return st;
+}

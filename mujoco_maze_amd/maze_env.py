@@ -79,7 +79,9 @@ class VecMazeEnv:
         self._goal = torch.empty(n, dtype=torch.int32, device=dev)
         self._info = torch.empty((n, 4), dtype=torch.float32, device=dev)
         self._seed = int(seed)
-        self.set_option("auto_reset", 1.0 if auto_reset else 0.0)
+        self._host_rewards = not self.model.device_rewards
+        self._final_obs = None
+        self.set_auto_reset(auto_reset)
         lo = np.array([m.act_ctrlrange[a][0] for a in range(m.nu)], dtype=np.float32)
         hi = np.array([m.act_ctrlrange[a][1] for a in range(m.nu)], dtype=np.float32)
         self.action_space = Box(lo, hi)
@@ -87,14 +89,28 @@ class VecMazeEnv:
         low = -high
         low[0], high[0], low[1], high[1] = self.model.world.xy_limits()
         self.observation_space = Box(low, high)
-        self._host_rewards = not self.model.device_rewards
 
     # -- plumbing ----------------------------------------------------------
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_option(self, key: str, value: float) -> None:
+        if key == "auto_reset":
+            return self.set_auto_reset(value != 0)
         _capi.check(self._lib, self._h, self._lib.mz_set_option(self._h, key.encode(), float(value)), f"mz_set_option({key})")
+
+    def set_auto_reset(self, on: bool) -> None:
+        """Auto-reset follows the vector-env convention: an env whose step ended its episode returns the reward / done of
+        that terminal step, the FIRST observation of the next episode in `obs`, and its terminal observation in
+        `info["final_observation"]` (rows where done != 0).  Tasks whose reward()/termination() are Python overrides are
+        judged on the host, so for them the device's own verdict must not reset anything: the kernel's auto-reset stays
+        off and the host issues the masked reset after it has evaluated the task."""
+        self._auto_reset = bool(on)
+        if self._auto_reset and self._final_obs is None:
+            self._final_obs = self._torch.zeros((self.num_envs, self.obs_dim), dtype=self._torch.float32, device=self.device)
+        device_side = self._auto_reset and not self._host_rewards
+        _capi.check(self._lib, self._h, self._lib.mz_bind_final_obs(self._h, _ptr(self._final_obs) if device_side else None), "mz_bind_final_obs")
+        _capi.check(self._lib, self._h, self._lib.mz_set_option(self._h, b"auto_reset", 1.0 if device_side else 0.0), "mz_set_option(auto_reset)")
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -137,20 +153,34 @@ class VecMazeEnv:
             self._apply_host_task()
         info = {"position": self._info[:, :2], "reward_forward": self._info[:, 2], "reward_ctrl": self._info[:, 3],
                 "goal_index": self._goal}
+        if self._auto_reset:
+            info["final_observation"] = self._final_obs  # valid in the rows where done != 0
         return self._obs, self._reward, self._done, info
 
     def _apply_host_task(self):
-        """User-defined Python reward()/termination(): evaluated on the host from the obs batch
-        (the kernel still supplied the inner reward; the task part is recomputed here)."""
+        """User-defined Python reward()/termination(): evaluated on the host from the obs batch (one device-to-host copy
+        of obs / info / done per step; the kernel supplied the inner reward terms, the task part is computed here).  With
+        auto-reset the host then resets exactly the envs ITS verdict finished (the kernel's auto-reset is off for these
+        tasks, see set_auto_reset)."""
+        torch = self._torch
+        m = self.model.c
         obs = self._obs.double().cpu().numpy()
-        inner = (self._info[:, 2] + self._info[:, 3]).double().cpu().numpy() * self.model.c.inner_reward_scaling
-        if self.model.c.robot == 0:
-            inner[:] = 0.0
+        inf = self._info.double().cpu().numpy()
+        inner = (m.forward_reward_weight * inf[:, 2] + inf[:, 3]) * m.inner_reward_scaling  # ant.py:68, swimmer.py:43
+        if m.robot == 0:
+            inner[:] = 0.0  # point.py:61
         rew = np.array([self._task.reward(o) for o in obs]) + inner
         term = np.array([bool(self._task.termination(o)) for o in obs])
-        trunc = (self._done.cpu().numpy() & 2)
-        self._reward.copy_(self._torch.as_tensor(rew, dtype=self._torch.float32))
-        self._done.copy_(self._torch.as_tensor((term.astype(np.uint8) | trunc).astype(np.uint8)))
+        done = (term.astype(np.uint8) | (self._done.cpu().numpy() & 2)).astype(np.uint8)
+        self._reward.copy_(torch.as_tensor(rew, dtype=torch.float32))
+        self._done.copy_(torch.as_tensor(done))
+        if self._auto_reset and done.any():
+            mask = self._done != 0
+            self._final_obs[mask] = self._obs[mask]
+            rc = self._lib.mz_reset(self._h, _ptr(mask.to(torch.uint8).contiguous()), C.c_uint64(self._seed), _ptr(self._obs), self._stream())
+            _capi.check(self._lib, self._h, rc, "mz_reset (host-judged auto-reset)")
+            torch.cuda.current_stream(self.device).synchronize()  # the mask is a temporary
+            self._seed += 1
 
     def get_state(self):
         torch, n = self._torch, self.num_envs
@@ -191,6 +221,31 @@ class VecMazeEnv:
         a = None if actions is None else torch.as_tensor(actions, device=self.device).to(torch.float32).contiguous()
         _capi.check(self._lib, self._h, self._lib.mz_debug_forward(self._h, _ptr(a), _ptr(qacc), _ptr(counts), self._stream()), "mz_debug_forward")
         return qacc, counts
+
+    def debug_task_eval(self, obs):
+        """Task reward / termination / first matching goal for rows of observations [n, obs_dim] (parity tests)."""
+        torch = self._torch
+        o = torch.as_tensor(obs, device=self.device).to(torch.float32).contiguous()
+        n = o.shape[0]
+        rew = torch.empty(n, dtype=torch.float32, device=self.device)
+        done = torch.empty(n, dtype=torch.uint8, device=self.device)
+        gi = torch.empty(n, dtype=torch.int32, device=self.device)
+        _capi.check(self._lib, self._h, self._lib.mz_debug_task_eval(self._h, n, _ptr(o), _ptr(rew), _ptr(done), _ptr(gi), self._stream()), "mz_debug_task_eval")
+        torch.cuda.current_stream(self.device).synchronize()
+        return rew, done, gi
+
+    def debug_detect(self, old_xy, new_xy):
+        """The Point's manual wall rule on float64 moves [n, 2]: (hit, point, final_xy); hit 0 none, 1 bounce, 2 give-up, -1 collinear."""
+        torch = self._torch
+        o = torch.as_tensor(np.asarray(old_xy, np.float64), device=self.device).contiguous()
+        w = torch.as_tensor(np.asarray(new_xy, np.float64), device=self.device).contiguous()
+        n = o.shape[0]
+        hit = torch.empty(n, dtype=torch.int32, device=self.device)
+        pt = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
+        fin = torch.empty((n, 2), dtype=torch.float64, device=self.device)
+        _capi.check(self._lib, self._h, self._lib.mz_debug_detect(self._h, n, _ptr(o), _ptr(w), _ptr(hit), _ptr(pt), _ptr(fin), self._stream()), "mz_debug_detect")
+        torch.cuda.current_stream(self.device).synchronize()
+        return hit, pt, fin
 
     def phase_cycles(self):
         """Phase timers of the instrumented kernel (set_option('profile_phases', 1) first)."""

@@ -164,33 +164,15 @@ template <int NL, int NB>
 static int swimmer_env_step_t(const SwimmerDev& P, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
                               float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
   constexpr int NR = NL + 2, NV = NR + 2 * NB, NH = NL - 1;
-  const int nb3 = P.observe_blocks ? 3 * NB : 0, NO = 2 * NR + 1 + nb3;
+  const int nb3 = P.observe_blocks ? 3 * NB : 0, NO = 2 * NV + 1 + nb3;
   for (int e = 0; e < n; e++) {
-    double q[NR], v[NR], a[NH], inner, inf4[4];
-    for (int k = 0; k < NH; k++) a[k] = (double)actions[NH * e + k];
-    for (int k = 0; k < NR; k++) { q[k] = (double)qpos[NV * e + k]; v[k] = (double)qvel[NV * e + k]; }
+    float o[2 * NV + 1 + 3 * NB];
+    double inner, inf4[4];
     int t_new;
-    int st = swimmer_env_step<NL>(P, q, v, a, t[e], &inner, inf4, &t_new);
-    float bq[2 * NB + 1], bv[2 * NB + 1];
-    for (int b = 0; b < NB; b++) {
-      double q2[2] = {(double)qpos[NV * e + NR + 2 * b], (double)qpos[NV * e + NR + 2 * b + 1]};
-      double v2[2] = {(double)qvel[NV * e + NR + 2 * b], (double)qvel[NV * e + NR + 2 * b + 1]};
-      if (v2[0] != 0.0 || v2[1] != 0.0) swimmer_block_step(P, q2, v2);
-      bq[2 * b] = (float)q2[0]; bq[2 * b + 1] = (float)q2[1]; bv[2 * b] = (float)v2[0]; bv[2 * b + 1] = (float)v2[1];
-    }
-    float o[2 * NR + 1 + 3 * NB];
-    for (int k = 0; k < 3; k++) o[k] = (float)q[k];
-    for (int b = 0; b < NB && nb3; b++) {
-      o[3 + 3 * b] = (float)(P.block_pos0[b][0] + (double)bq[2 * b]); o[4 + 3 * b] = (float)(P.block_pos0[b][1] + (double)bq[2 * b + 1]);
-      o[5 + 3 * b] = (float)P.block_pos0[b][2];
-    }
-    for (int k = 3; k < NR; k++) o[nb3 + k] = (float)q[k];
-    for (int k = 0; k < NR; k++) o[nb3 + NR + k] = (float)v[k];
-    o[nb3 + 2 * NR] = (float)t_new * 0.001f;
+    int st = swimmer_maze_step<NL, NB>(P, qpos + NV * e, qvel + NV * e, actions + NH * e, t[e], o, &inner, inf4, &t_new);
     float outer; int tm, gi;
     task_eval_dev(P.task, o, &outer, &tm, &gi);
     for (int k = 0; k < NO; k++) obs[NO * e + k] = o[k];
-    for (int k = 0; k < NV; k++) { qpos[NV * e + k] = k < NR ? (float)q[k] : bq[k - NR]; qvel[NV * e + k] = k < NR ? (float)v[k] : bv[k - NR]; }
     reward[e] = (float)(P.task.inner_scale * inner) + outer;
     done[e] = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
     if (goal_idx) goal_idx[e] = gi;
@@ -211,4 +193,35 @@ extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float
                                     : swimmer_env_step_t<3, 0>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
   return P.nblock ? swimmer_env_step_t<2, 1>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
                   : swimmer_env_step_t<2, 0>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
+}
+
+// ---------------------------------------------------------------- the bit-exact pieces, for CPU tests against the golden vectors
+extern "C" double emu_hypot(double x, double y) { return mz_hypot(x, y); }
+
+// CollisionDetector.detect + bounce rule on n moves (the code of point_detect_kernel); hit: 0 / 1 bounce / 2 give-up / -1 collinear
+extern "C" int emu_point_detect(const mz_model* m, int n, const double* old_xy, const double* new_xy, int32_t* hit, double* point, double* final_xy) {
+  PointDev* P = (PointDev*)calloc(1, sizeof(PointDev));
+  char err[128];
+  int rc = point_dev_from_model(P, m, err, sizeof(err));
+  if (rc != MZ_OK) { free(P); return rc; }
+  for (int e = 0; e < n; e++) {
+    double pt[2];
+    hit[e] = point_bounce(*P, old_xy + 2 * e, new_xy + 2 * e, final_xy + 2 * e, pt);
+    if (point) { point[2 * e] = pt[0]; point[2 * e + 1] = pt[1]; }
+  }
+  free(P);
+  return MZ_OK;
+}
+
+// task_eval_dev on n rows of fp32 observations (obs_dim floats per row; only the first six are read)
+extern "C" int emu_task_eval(const mz_model* m, int n, int obs_dim, const float* obs, float* reward, uint8_t* done, int32_t* goal_idx) {
+  TaskDev T;
+  task_dev_from_model(&T, m);
+  for (int e = 0; e < n; e++) {
+    float o6[6], r; int tm, gi;
+    for (int k = 0; k < 6; k++) o6[k] = k < obs_dim ? obs[(size_t)e * obs_dim + k] : 0.f;
+    task_eval_dev(T, o6, &r, &tm, &gi);
+    reward[e] = r; done[e] = (uint8_t)tm; goal_idx[e] = gi;
+  }
+  return MZ_OK;
 }

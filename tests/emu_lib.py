@@ -89,3 +89,33 @@ def swimmer_env_step(cm, st, actions):
                                   _vp(out["reward"]), _vp(out["done"]), _vp(out["goal_idx"]), _vp(out["info"]), _vp(out["status"]))
     assert rc == 0, rc
     return out
+
+
+def hypot(x, y):
+    """mz_hypot of csrc/point_dyn.h (the device's restatement of glibc hypot), element-wise on float64 arrays."""
+    lib = load()
+    lib.emu_hypot.restype = C.c_double
+    lib.emu_hypot.argtypes = [C.c_double, C.c_double]
+    return np.array([lib.emu_hypot(float(a), float(b)) for a, b in zip(np.ravel(x), np.ravel(y))])
+
+
+def point_detect(cm, old_xy, new_xy):
+    """point_bounce of csrc/point_dyn.h on float64 moves [n, 2]: (hit, point, final_xy)."""
+    lib = load()
+    o, w = np.ascontiguousarray(old_xy, np.float64), np.ascontiguousarray(new_xy, np.float64)
+    n = o.shape[0]
+    hit, pt, fin = np.zeros(n, np.int32), np.zeros((n, 2)), np.zeros((n, 2))
+    rc = lib.emu_point_detect(C.byref(cm.c), n, _vp(o), _vp(w), _vp(hit), _vp(pt), _vp(fin))
+    assert rc == 0, rc
+    return hit, pt, fin
+
+
+def task_eval(cm, obs):
+    """task_eval_dev of csrc/ant_dyn.h on fp32 observation rows [n, obs_dim]: (reward, done, goal_idx)."""
+    lib = load()
+    o = np.ascontiguousarray(obs, np.float32)
+    n, d = o.shape
+    rew, done, gi = np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.int32)
+    rc = lib.emu_task_eval(C.byref(cm.c), n, d, _vp(o), _vp(rew), _vp(done), _vp(gi))
+    assert rc == 0, rc
+    return rew, done, gi

@@ -317,37 +317,44 @@ def test_point_billiard_object_ball(oracle, name, idx):
 
 @pytest.mark.parametrize("robot", ["swimmer", "reacher"])
 def test_swimmer_world_with_a_movable_block(oracle, robot):
-    """SwimmerPush / ReacherPush: `collision="predefined"` (swimmer.xml:3) leaves the block without any contact pair, so it
-    just sits at its spawn position and appears in the observation (obs[3:6]).  A block that is given a velocity blows up in
-    the reference's medium (0.2 g box, viscous rate ~1.6e4 / s against h = 0.01): both paths must flag that env."""
+    """SwimmerPush / ReacherPush.  The reference's swimmer `_get_obs` returns the WHOLE qpos / qvel (swimmer.py:50-54), so the
+    block's two slide coordinates and velocities are part of the observation (18 numbers for SwimmerPush; layout pinned by
+    tests/golden/obs_layout.json) and `reset_model` puts U(-0.1, 0.1) noise on them too (swimmer.py:56-69).
+    `collision="predefined"` (swimmer.xml:3) leaves the block without any contact pair: at rest it just sits there; once it
+    has a velocity — i.e. after every reference-style reset — the medium's drag on a 0.2 g box (viscous rate ~1.6e4 / s
+    against h = 0.01) makes the explicit integration blow up, in MuJoCo (mujoco-py raises) as in both of our paths, which
+    flag the env."""
     from tests import emu_lib
 
     cm = model.compile_model(robot, T.DistRewardPush(4.0), 4.0)
     m = cm.c
-    nr = m.nv_robot
-    assert m.nblock == 1 and m.nv == nr + 2 and m.obs_dim == 2 * nr + 1 + 3
+    nr = m.nv - 2
+    assert m.nblock == 1 and m.nv_robot == m.nv and m.nq_robot == m.nq and m.obs_dim == m.nq + m.nv + 1 + 3
     n = 64
-    st, _ = oracle.reset(cm, n, 3)
+    st, obs0 = oracle.reset(cm, n, 3)
+    assert np.ptp(st["qpos"][:, nr]) > 0.1 and np.ptp(st["qvel"][:, nr + 1]) > 0.1  # reset noise reaches the block
+    assert np.array_equal(obs0[:, 6:6 + m.nq - 3], st["qpos"][:, 3:]) and np.array_equal(obs0[:, 3 + m.nq:3 + m.nq + m.nv], st["qvel"])
+    blown = _f32(st)
+    ro = oracle.step(cm, blown, np.zeros((n, m.nu)), nthreads=4)
+    s32 = emu_lib.f32_state(_f32(st))
+    re_ = emu_lib.swimmer_env_step(cm, s32, np.zeros((n, m.nu), np.float32))
+    assert np.all(ro["status"] & 1) and np.all(re_["status"] & 1)  # unstable in both, every env
+    # a block at rest: inert, and the two paths agree on the whole 2 nv + 4 observation
+    st["qvel"][:, nr:] = 0.0
     rng = np.random.default_rng(0)
     for k in range(21):
         act = rng.uniform(-1.5, 1.5, (n, m.nu)).astype(np.float32)
         if k in (0, 20):
             s64 = _f32(st)
             s32 = emu_lib.f32_state(s64)
+            q_block = s64["qpos"][:, nr:].copy()
             ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=4)
             re_ = emu_lib.swimmer_env_step(cm, s32, act)
             assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 1e-6 + 2e-7 * np.abs(ro["obs"]))
-            assert np.array_equal(re_["obs"][:, 3:6], np.tile(np.array([0.0, 4.0, 1.0], np.float32), (n, 1)))  # block xyz slot
+            assert np.allclose(re_["obs"][:, 3:5], np.array([0.0, 4.0]) + q_block, atol=1e-6) and np.all(re_["obs"][:, 5] == 1.0)  # block xyz slot
             assert np.abs(re_["reward"] - ro["reward"]).max() < 1e-7 and np.all(re_["status"] == 0) and np.all(ro["status"] == 0)
-            assert np.all(s32["qpos"][:, nr:] == 0) and np.all(s32["qvel"][:, nr:] == 0)
+            assert np.array_equal(s32["qpos"][:, nr:], q_block.astype(np.float32)) and np.all(s32["qvel"][:, nr:] == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=4)
-    s64 = _f32(st)
-    s64["qvel"][0, nr] = 0.5
-    s32 = emu_lib.f32_state(s64)
-    ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=4)
-    emu_lib.swimmer_env_step(cm, s32, act)
-    assert (ro["status"][0] & 1) and not np.isfinite(s32["qvel"][0, nr])  # unstable in both
-    assert np.all(ro["status"][1:] == 0) and np.all(np.isfinite(s32["qvel"][1:]))
 
 
 @pytest.mark.parametrize("robot,nq", [("swimmer", 5), ("reacher", 4)])
