@@ -9,7 +9,14 @@ One "step" = one MazeEnv.step for every env of the batch (Ant: 5 MuJoCo frames x
 state from the reference's reset distribution, i.i.d. uniform actions in the action
 box, auto-reset on termination / 1000-step truncation.  For N > 1 each rank owns its
 own 4096 envs (weak scaling) and the only collective is the RCCL all-gather of the
-packed [N_local, 32] record (obs | reward | done) that north_star names.
+packed [N_local, obs_dim + 2] record (obs | reward | done) that north_star names.
+
+The measured regime does not depend on --warmup: SETTLE_STEPS untimed batch-steps always
+run first (the ants land and stay on the ground: SURVEY §8d's "100 warm-up" protocol),
+then the caller's --warmup, then the timed --steps.
+
+Other BASELINE configs with the same script: --env Ant4Rooms-v0 (configs[3], with --gpus 8),
+--env AntPush-v0 --envs 2048 (configs[4]), --env PointUMaze-v0 (configs[1]).
 
 Prints ONE JSON line (rank 0) with the fields the driver expects plus
   roofline     : algorithmic HBM bytes per launch / average kernel duration (HIP events on
@@ -29,8 +36,18 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 4096
 ENV_ID = "AntUMaze-v0"
-ALGO_BYTES_PER_ENV_STEP = 509  # 208 B read + 301 B written (fp32 state, action, obs, reward, done)
+SETTLE_STEPS = 100             # untimed, before --warmup: the timed window is the settled regime whatever the caller's --warmup
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: fp32 VALU lane-operations per second
+
+
+def algo_bytes_per_env_step(m):
+    """SURVEY §8d counting: fp32 persistent state read + written once per env-step, action in, obs / reward / done out:
+    reads (nq + nv + nv + nu + 1) words; writes (nq + nv + nv + 1 + obs_dim + 1) words + 1 byte.  The Point / Swimmer
+    kernels keep no warm start (their RK4 stages re-solve from the previous stage): SURVEY counts the same record for them."""
+    rd = (m.nq + 2 * m.nv + m.nu + 1) * 4
+    wr = (m.nq + 2 * m.nv + 1 + m.obs_dim + 1) * 4 + 1
+    return rd + wr
 
 
 def usable_cores():
@@ -45,63 +62,90 @@ def usable_cores():
     return n
 
 
-def pmc_traffic(n_envs):
-    """HBM bytes per launch from the newest committed PMC summary (collected by tools/profile.sh in separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the default bench command, 4096 envs), or None.
-    rocprofv3 reports both in KB; the guide's x2 correction applies to wide (16 B/lane) streaming reads only, these
-    are 4-B-per-lane loads, so the raw sum is reported."""
+def pmc_counters(env_id, n_envs):
+    """Per-launch PMC averages of the step kernel from the newest committed summary (collected by tools/profile.sh in
+    separate `rocprofv3 --pmc ...` passes of the default bench command: AntUMaze-v0, 4096 envs), or {} for any other
+    workload (counters cannot be collected from inside the process)."""
     import glob
-    if n_envs != ENVS_PER_GPU:
-        return None
+    if n_envs != ENVS_PER_GPU or env_id != ENV_ID:
+        return {}
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_ant_step_kernel.csv")))
     if not files:
-        return None
-    vals = {}
+        return {}
+    vals = {"_file": os.path.relpath(files[-1], ROOT)}
     for line in open(files[-1]).read().splitlines()[1:]:
         k, v, _ = line.split(",")
         vals[k] = float(v)
+    return vals
+
+
+def pmc_traffic(vals):
+    """HBM bytes per launch: FETCH_SIZE + WRITE_SIZE (rocprofv3 reports KB).  The guide's x2 correction applies to wide
+    (16 B/lane) streaming reads only; these are 4-B-per-lane loads, so the raw sum is reported."""
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def cpu_baseline(model, seconds_target=12.0):
-    """Oracle (oracle/libmzo.so, kind 'port') on the host cores, OpenMP over envs."""
+def valu_roofline(vals, kernel_ms):
+    """The informative roofline for this latency / VALU-bound path: how busy the vector pipes are and how
+    many of their lanes do work.  SQ_* cycle counters tick once per 4 shader cycles and are summed over the 1024 SIMDs;
+    SQ_THREAD_CYCLES_VALU counts active lanes x cycles."""
+    need = ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU")
+    if not all(k in vals for k in need):
+        return None
+    out = {"bound": "valu", "source": vals.get("_file"),
+           "valu_busy_frac": vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_BUSY_CYCLES"] if vals["SQ_BUSY_CYCLES"] else None,
+           "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
+           "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES (fraction of SIMD-cycles of the launch in which a vector instruction executes); "
+                   "active_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4)"}
+    if "SQ_THREAD_CYCLES_VALU" in vals and vals["SQ_ACTIVE_INST_VALU"]:
+        out["active_lane_frac"] = vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * vals["SQ_ACTIVE_INST_VALU"])
+    if kernel_ms and kernel_ms > 0 and "SQ_THREAD_CYCLES_VALU" in vals:
+        out["achieved_lane_ops_per_s"] = vals["SQ_THREAD_CYCLES_VALU"] / (kernel_ms * 1e-3)
+        out["peak_lane_ops_per_s"] = VALU_LANE_OPS_PER_S
+        out["frac"] = out["achieved_lane_ops_per_s"] / VALU_LANE_OPS_PER_S
+    return out
+
+
+def cpu_baseline(model, env_id, n, lo, hi, seconds_target=12.0):
+    """The CPU oracle's sources built -O3 with AVX2 / FMA code generation (oracle/libmzo_fast.so, kind 'port': a
+    restatement — MuJoCo itself is not available) on the host cores, OpenMP over envs."""
     import numpy as np
 
     from tests import oracle_lib
 
-    oracle = oracle_lib.load()
+    oracle = oracle_lib.load_fast()
     cores = usable_cores()
-    n = ENVS_PER_GPU
+    nu = len(lo)
     st, _ = oracle.reset(model, n, 20260928)
     rng = np.random.default_rng(0)
-    act = rng.uniform(-30, 30, (n, 8))
-    oracle.step(model, st, act, nthreads=cores)  # warm-up (page-in, first contacts)
-    # settle the ants first (the GPU leg is timed after 100 warm-up steps too), untimed
+    oracle.step(model, st, rng.uniform(lo, hi, (n, nu)), nthreads=cores)  # warm-up (page-in, first contacts)
+    # settle first (the GPU leg is timed on settled ants too), untimed
     for _ in range(20):
-        oracle.step(model, st, rng.uniform(-30, 30, (n, 8)), nthreads=cores)
+        oracle.step(model, st, rng.uniform(lo, hi, (n, nu)), nthreads=cores)
     t0 = time.perf_counter()
     steps = 0
     while True:
-        oracle.step(model, st, rng.uniform(-30, 30, (n, 8)), nthreads=cores)
+        oracle.step(model, st, rng.uniform(lo, hi, (n, nu)), nthreads=cores)
         steps += 1
         if time.perf_counter() - t0 > seconds_target or steps >= 200:
             break
     dt = time.perf_counter() - t0
     # one core, a slice of the same batch (SURVEY 8d asks for both)
-    n1 = 512
+    n1 = min(512, n)
     st1 = {k: v[:n1].copy() for k, v in st.items()}
     t1 = time.perf_counter()
     steps1 = 0
     while time.perf_counter() - t1 < 4.0:
-        oracle.step(model, st1, rng.uniform(-30, 30, (n1, 8)), nthreads=1)
+        oracle.step(model, st1, rng.uniform(lo, hi, (n1, nu)), nthreads=1)
         steps1 += 1
     dt1 = time.perf_counter() - t1
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "value_1core": n1 * steps1 / dt1,
-            "sample": f"{ENV_ID}, {n} envs x {steps} batch-steps ({dt:.1f} s) on {cores} cores + {n1} envs x {steps1} batch-steps on 1 core, "
-                      "after 20 untimed settling steps; float64 CPU oracle (restatement, not mujoco-py), OpenMP over envs"}
+            "sample": f"{env_id}, {n} envs x {steps} batch-steps ({dt:.1f} s) on {cores} cores + {n1} envs x {steps1} batch-steps on 1 core, "
+                      "after 20 untimed settling steps; float64 CPU oracle (restatement, not mujoco-py) built -O3 -march=x86-64-v3 "
+                      "(oracle/libmzo_fast.so; the strict-fp libmzo.so is the parity checker, not timed), OpenMP over envs"}
 
 
 def main():
@@ -110,6 +154,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)  # 100 warm-up + >= 1000 timed batch-steps
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--env", type=str, default=ENV_ID, help="registered env id (default: the metric's AntUMaze-v0)")
+    ap.add_argument("--settle", type=int, default=SETTLE_STEPS, help="untimed steps before --warmup (regime independent of --warmup)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (8/16/32/64); 0 = library default")
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup (1/2/4); 0 = library default")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL obs all-gather for N > 1")
@@ -144,7 +190,8 @@ def main():
     dev = torch.device("cuda", local if world > 1 else 0)
 
     n = args.envs
-    env = mm.make(ENV_ID, num_envs=n, auto_reset=True, device=dev, force_vec=True)
+    env_id = args.env
+    env = mm.make(env_id, num_envs=n, auto_reset=True, device=dev, force_vec=True)
     if args.lanes:
         env.set_option("lanes_per_env", args.lanes)
     if args.wpb:
@@ -158,7 +205,9 @@ def main():
     env.set_option("env_index_offset", float(lo))  # reset noise keyed by the global env slot
     env.reset(seed=20260928)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = [(torch.rand((n, 8), device=dev, generator=g) * 60.0 - 30.0) for _ in range(32)]  # U(-30, 30)^8
+    a_lo = torch.as_tensor(env.action_space.low, device=dev)
+    a_hi = torch.as_tensor(env.action_space.high, device=dev)
+    pool = [(a_lo + (a_hi - a_lo) * torch.rand((n, env.nu), device=dev, generator=g)) for _ in range(32)]  # uniform in the action box
     gatherer = sharding.RecordGatherer(n, env.obs_dim, dev) if (world > 1 and not args.no_gather) else None
 
     def one_step(i):
@@ -167,8 +216,10 @@ def main():
             gatherer.wait()                     # previous step's gather must be done before its buffer is reused
             gatherer.start(obs, rew, done)      # async RCCL all-gather, overlaps the next step's kernel
 
-    for i in range(args.warmup):
+    for i in range(args.settle):
         one_step(i)
+    for i in range(args.warmup):
+        one_step(args.settle + i)
     env.set_option("time_kernels", args.steps)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -196,26 +247,35 @@ def main():
     if rank == 0:
         total_env_steps = n * world * args.steps
         value = total_env_steps / dt
-        algo_bytes = ALGO_BYTES_PER_ENV_STEP * n
+        per_env = algo_bytes_per_env_step(env.model.c)
+        algo_bytes = per_env * n
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+        pmc = pmc_counters(env_id, n)
+        robot = env.model.c.robot
+        kernel = {1: "ant_step_kernel", 0: "planar_step_kernel", 2: "swimmer_step_kernel"}[robot]
         out = {
-            "metric": "env-steps/sec (whole node), AntUMaze-v0, 4096 envs/GPU",
+            "metric": f"env-steps/sec (whole node), {env_id}, {n} envs/GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ENV_ID}, {n} envs/GPU, frame_skip 5 x RK4, random actions U(-30,30)^8, auto-reset",
+            "dtype": "f32" if robot == 1 else "f64", "data": "synthetic",
+            "config": {"workload": f"{env_id}, {n} envs/GPU, frame_skip {env.model.c.frame_skip} x RK4, random actions uniform in the action box, auto-reset; "
+                                   f"{args.settle} untimed settle steps + {args.warmup} warm-up steps before the timed window",
                        "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
-                       "lanes_per_env": args.lanes or 32, "waves_per_block": args.wpb or 1, "bad_envs": bad,
+                       "lanes_per_env": args.lanes or "library default", "waves_per_block": args.wpb or 1, "bad_envs": bad,
                        **({"rehearsal": "all ranks on one GPU over gloo (MZ_BENCH_SINGLE_GPU=1): not a scaling measurement"}
                           if os.environ.get("MZ_BENCH_SINGLE_GPU") == "1" else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(n),
-                         "kernel": "ant_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(pmc),
+                         "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_env_step": per_env,
                          "traffic_source": "profiles/*/pmc_ant_step_kernel.csv: FETCH_SIZE + WRITE_SIZE (KB) of the committed rocprofv3 --pmc passes of this command, bytes per launch; not collected live",
                          "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},
         }
+        rv = valu_roofline(pmc, kernel_ms)
+        if rv is not None:
+            out["roofline_valu"] = rv
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env.model)
+            out["cpu_baseline"] = cpu_baseline(env.model, env_id, n, env.action_space.low.astype("float64"), env.action_space.high.astype("float64"))
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:

@@ -36,7 +36,9 @@ def pack_record(obs, reward, done, out):
 class RecordGatherer:
     """Owns the send/receive buffers and issues one all-gather per batch step."""
 
-    def __init__(self, n_local: int, obs_dim: int, device, group=None):
+    def __init__(self, n_local: int, obs_dim: int, device, group=None, always_collective: bool = False):
+        """`always_collective`: issue the all-gather even in a one-rank group (where it degenerates to a copy), so that the
+        collective path itself — RCCL on the GPU box — is what runs; used by the single-GPU RCCL test."""
         import torch
         import torch.distributed as dist
 
@@ -48,11 +50,12 @@ class RecordGatherer:
         self.packed = torch.empty((n_local, self.width), dtype=torch.float32, device=device)
         self.gathered = torch.empty((n_local * self.world, self.width), dtype=torch.float32, device=device)
         self._work = None
+        self._always = bool(always_collective) and dist.is_initialized()
 
     def start(self, obs, reward, done):
         """Pack and launch the all-gather (asynchronous); call wait() before reading `gathered`."""
         pack_record(obs, reward, done, self.packed)
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             self.gathered.copy_(self.packed)
             self._work = None
         else:
@@ -75,7 +78,8 @@ class RecordGatherer:
 class ShardedVecMazeEnv:
     """One rank's shard of a node-wide batch: a local `VecMazeEnv` + the record all-gather."""
 
-    def __init__(self, env_id: str, envs_per_rank: int, device=None, gather: bool = True, group=None, **kwargs):
+    def __init__(self, env_id: str, envs_per_rank: int, device=None, gather: bool = True, group=None, always_collective: bool = False,
+                 **kwargs):
         import torch
         import torch.distributed as dist
 
@@ -86,7 +90,7 @@ class ShardedVecMazeEnv:
         self.env = mm.make(env_id, num_envs=envs_per_rank, device=device, force_vec=True, **kwargs)
         self.lo, self.hi = shard_range(self.rank, self.world, envs_per_rank)
         self.env.set_option("env_index_offset", float(self.lo))
-        self.gatherer: Optional[RecordGatherer] = RecordGatherer(envs_per_rank, self.env.obs_dim, self.env.device, group) if gather else None
+        self.gatherer: Optional[RecordGatherer] = RecordGatherer(envs_per_rank, self.env.obs_dim, self.env.device, group, always_collective) if gather else None
         self._torch = torch
 
     def reset(self, seed: int = 0):

@@ -111,6 +111,8 @@ class Oracle:
 
 
 _cached = None
+_cached_fast = None
+LIB_FAST = os.path.join(ORACLE_DIR, "libmzo_fast.so")
 
 
 def load() -> Oracle:
@@ -120,3 +122,13 @@ def load() -> Oracle:
             build()
         _cached = Oracle(C.CDLL(LIB))
     return _cached
+
+
+def load_fast() -> Oracle:
+    """The -O3 -march=native build of the same sources: bench.py's CPU baseline leg only (never a parity checker)."""
+    global _cached_fast
+    if _cached_fast is None:
+        if not os.path.exists(LIB_FAST):
+            build()
+        _cached_fast = Oracle(C.CDLL(LIB_FAST))
+    return _cached_fast

@@ -76,3 +76,50 @@ def test_user_task_with_python_reward_on_the_device(model_cls):
     assert np.allclose(rew.cpu().numpy(), want_r, atol=1e-6)
     assert np.array_equal((done.cpu().numpy() & 1).astype(bool), want_d) and want_d[: n // 4].all() and not want_d[n // 4:].any()
     env.close()
+
+
+class FarGoalCross(GoalRewardCross):
+    """A user task whose termination() is a Python override that DISAGREES with the stock goal-neighbour rule the kernel
+    knows (it ends the episode three times further out), so a device-side verdict would reset the wrong envs."""
+
+    def termination(self, obs: np.ndarray) -> bool:
+        return bool(np.linalg.norm(obs[:2] - self.goals[0].pos) <= 1.8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_cls", [mm.PointEnv, mm.AntEnv])
+def test_host_judged_task_with_auto_reset(model_cls):
+    """for host-evaluated tasks the envs that reset must be exactly the ones the user's termination() ended —
+    the kernel's own auto-reset is off and the host issues the masked reset; obs holds the new episode's first observation,
+    info["final_observation"] the terminal one; the inner reward uses forward_reward_weight."""
+    import torch
+
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+
+    n, scale = 64, 4.0
+    env = VecMazeEnv(model_cls, FarGoalCross, maze_size_scaling=scale, num_envs=n, auto_reset=True, forward_reward_weight=2.5,
+                     inner_reward_scaling=1.0)
+    task = FarGoalCross(scale)
+    assert env._host_rewards and env._auto_reset
+    env.reset(seed=3)
+    qpos, qvel, warm, t = env.get_state()
+    qpos[: n // 4, 0] = 2.0 * scale - 1.2   # inside the user's radius 1.8, outside the stock threshold 0.6
+    qpos[n // 4: n // 2, 0] = 2.0 * scale - 0.1  # inside both
+    env.set_state(qpos=qpos)
+    act = torch.zeros((n, env.nu), device=env.device)
+    obs, rew, done, info = env.step(act)
+    d = done.cpu().numpy()
+    fin = info["final_observation"].double().cpu().numpy()
+    want = np.array([task.termination(x) for x in fin[: n // 2]])
+    assert want.all() and np.all(d[: n // 2] & 1) and not np.any(d[n // 2:])
+    t_after = env.get_state()[3].cpu().numpy()
+    assert np.all(t_after[: n // 2] == 0) and np.all(t_after[n // 2:] == 1)  # exactly the user's verdict was reset
+    o = obs.cpu().numpy()
+    assert np.all(o[: n // 2, -1] == 0.0) and np.all(np.abs(o[: n // 2, 0]) <= 0.1 + 1e-6)  # first obs of the new episode
+    assert np.allclose(o[n // 2:, -1], 0.001)
+    # reward of the terminal step: user's reward on the terminal obs + inner reward with the forward weight (ant.py:68)
+    inner = 0.0 if model_cls is mm.PointEnv else (2.5 * info["reward_forward"] + info["reward_ctrl"]).double().cpu().numpy()
+    last = np.where((d != 0)[:, None], fin, obs.double().cpu().numpy())
+    want_r = np.array([task.reward(x) for x in last]) + inner
+    assert np.allclose(rew.cpu().numpy(), want_r, atol=1e-5)
+    env.close()

@@ -70,7 +70,7 @@ def test_native_library_is_the_in_tree_one(torch):
     assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
     from mujoco_maze_amd.model import MZ_ABI_VERSION
 
-    assert lib.mz_abi_version() == MZ_ABI_VERSION == 2
+    assert lib.mz_abi_version() == MZ_ABI_VERSION == 3
 
 
 def _rollout_states(oracle, cm, n, seed, checkpoints, robot="ant"):
@@ -357,26 +357,36 @@ def test_swimmer_step_parity(torch, oracle, robot, nq):
 
 @pytest.mark.parametrize("env_id", ["SwimmerPush-v0", "ReacherPush-v1"])
 def test_swimmer_world_with_a_movable_block(torch, oracle, env_id):
-    """No contact pairs in the swimmer's world (swimmer.xml:3): the block is inert and only occupies obs[3:6]."""
+    """The swimmer family observes and re-randomises the WHOLE qpos / qvel, block slides included (swimmer.py:50-69; layout
+    pinned by tests/golden/obs_layout.json: SwimmerPush 18 numbers).  No contact pairs in the swimmer's world
+    (swimmer.xml:3): a block at rest is inert; a block with the reset's velocity noise blows up in the medium exactly as in
+    the reference (explicit drag on a 0.2 g box) and is flagged."""
     n = 512
     env = mm.make(env_id, num_envs=n)
     cm = env.model
-    nr = cm.c.nv_robot
-    assert env.obs_dim == 2 * nr + 4 and env.nv == nr + 2
-    st, _ = oracle.reset(cm, n, 3)
+    nr = env.nv - 2
+    assert env.obs_dim == env.nq + env.nv + 4 and cm.c.nv_robot == env.nv
+    obs0 = env.reset(seed=3).cpu().numpy()
+    ref_st, ref_obs0 = oracle.reset(cm, n, 3)
+    assert np.abs(obs0 - ref_obs0).max() < 2e-6 and np.ptp(obs0[:, 6 + nr - 3]) > 0.1  # block slide carries reset noise
+    env.step(torch.zeros((n, env.nu), device=env.device))
+    assert np.all(env.status().cpu().numpy() & 1)  # every env: block velocity noise -> unstable drag, as in MuJoCo
+    st = ref_st
+    st["qvel"][:, nr:] = 0.0
     rng = np.random.default_rng(0)
     for k in range(6):
         act = rng.uniform(-1.5, 1.5, (n, env.nu)).astype(np.float32)
         if k in (0, 5):
             s64 = _f32(st)
             env.set_state(s64["qpos"], s64["qvel"], None, s64["t"])
+            qb = s64["qpos"][:, nr:].copy()
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=1e-6, rtol=2e-7))
             assert np.all(_close(rew.cpu().numpy(), ref["reward"], atol=1e-7))
             assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.all(env.status().cpu().numpy() == 0)
             qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
-            assert np.all(qpos[:, nr:] == 0) and np.all(qvel[:, nr:] == 0)
+            assert np.array_equal(qpos[:, nr:], qb.astype(np.float32)) and np.all(qvel[:, nr:] == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     env.close()
 
@@ -419,13 +429,15 @@ def test_full_size_properties(torch):
     env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True)
     env.reset(seed=5)
     g = torch.Generator(device=env.device).manual_seed(0)
-    goal = torch.tensor([0.0, 16.0], device=env.device)
+    goal = torch.tensor([0.0, 16.0], device=env.device, dtype=torch.float64)
     for k in range(60):
         act = (torch.rand((n, 8), device=env.device, generator=g) * 60 - 30)
         obs, rew, done, info = env.step(act)
         assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
-        # termination flag is exactly the predicate on the returned observation (maze_task.py:43-44,77-81)
-        pred = ((obs[:, :2] - goal).norm(dim=1) <= 0.6).to(torch.uint8)
+        # termination flag is exactly the reference's FLOAT64 predicate (maze_task.py:43-44,77-81) on the observation the
+        # step produced: `obs` for running envs, info["final_observation"] for the ones that just auto-reset
+        last = torch.where((done != 0)[:, None], info["final_observation"], obs).double()
+        pred = ((last[:, :2] - goal).square().sum(dim=1).sqrt() <= 0.6).to(torch.uint8)
         assert torch.equal(done & 1, pred)
         fresh = done == 0  # envs that have not auto-reset yet carry the global step count
         if k < 5:
@@ -442,6 +454,11 @@ def test_full_size_properties(torch):
     obs, rew, done, info = env.step(torch.zeros((n, 8), device=env.device))
     assert torch.all(done & 2)
     assert torch.all(env.get_state()[3] == 0)
+    # vector-env convention: `obs` is the FIRST observation of the new episode (t = 0, reset distribution around qpos0),
+    # the terminal one (t = 1000) is in final_observation
+    assert torch.all(obs[:, -1] == 0.0) and torch.allclose(info["final_observation"][:, -1], torch.tensor(1.0, device=env.device))
+    qpos = env.get_state()[0]
+    assert torch.equal(obs[:, :3], qpos[:, :3]) and torch.all((obs[:, 2] - 0.75).abs() <= 0.1 + 1e-6)
     env.close()
 
 
