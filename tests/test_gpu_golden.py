@@ -127,13 +127,13 @@ def test_all_golden_observations_through_the_hip_task_eval(torch, tag):
         assert np.array_equal(done.astype(bool), exp_t), (tag, robot)
         assert np.array_equal(gi, exp_g), (tag, robot)
         assert np.array_equal(rew, exp_r) or np.max(np.abs(rew - exp_r)) <= 2e-7 * np.max(np.abs(exp_r)), (tag, robot)
-        if desc[0] != T.REWARD_NEG_DIST:
+        if desc[0] != T.K_NEG_DIST:
             assert np.array_equal(rew, exp_r), (tag, robot)  # goal rewards / penalties are constants: exact
         ran += 1
     if ran == 0:
         pytest.skip("maze not on the device path yet")
     if task.goals:
-        assert exp_t.sum() > 10 and exp_t[390] and exp_g[390 if desc[1] != T.SLOT_OBJECT else 391] == 0
+        assert exp_t.sum() > 10  # (rows 390 / 391 may fall on either side once rounded to fp32: that is the point)
 
 
 def test_threshold_boundary_in_float32(torch):

