@@ -29,27 +29,33 @@ def _f32(st):
     return out
 
 
-def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, atol=ATOL, max_outlier_frac=0.004):
-    """Per-DoF parity after one env.step, robust to the model's own discontinuities.
+def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, atol=ATOL, max_outlier_frac=0.002, hard_atol=None):
+    """Per-DoF parity after one env.step: EVERY env is inside |dev - oracle| <= atol + 1e-5 |oracle| on qpos and qvel, or
+    the float64 oracle is itself discontinuous there.
 
-    MuJoCo's soft constraints switch on at `dist < margin` / `q < limit` with a velocity-dependent (damping)
-    term, so the step map is discontinuous there: an env whose contact crosses the activation distance within
-    fp32 round-off legitimately lands on the other branch (measured: ~0.04 % of env-steps).  Such an env is
-    accepted only if the float64 oracle ITSELF is that sensitive: re-running it from the same state perturbed by
-    about one fp32 ulp must move its answer by more than the tolerance.  Everything else must be inside
-    |dev - oracle| <= atol + 1e-5 |oracle|."""
+    MuJoCo's soft constraints switch on at `dist < margin` / `q < limit` with a velocity-dependent (damping) term, and the
+    box rules pick faces by comparisons, so the step map has jumps: an env whose contact crosses such a threshold within
+    fp32 round-off legitimately lands on the other branch.  Such an env is accepted only if the oracle ITSELF is that
+    sensitive: re-running it from the same state perturbed at the scale of fp32 round-off (2e-7 and 1e-6 relative — the
+    second is what absolute coordinates of ~10 m carry in fp32) must move its own answer by more than the tolerance.
+    `max_outlier_frac` caps how many envs may need that excuse (<= 2x what was measured: profiles/r02/parity.md).
+    `hard_atol` (block mazes only): an outlier inside this looser bound is accepted as round-off of the ~50x stiffer rows
+    (solimp .995, 0.2 g block) without the sensitivity proof; beyond it the proof is required."""
     ok = np.all(_close(dev_qpos, ref_state["qpos"], atol=atol), axis=1) & np.all(_close(dev_qvel, ref_state["qvel"], atol=atol), axis=1)
     bad = np.where(~ok)[0]
-    assert len(bad) <= max(1, int(max_outlier_frac * len(ok))), (len(bad), np.abs(dev_qvel - ref_state["qvel"]).max())
+    assert len(bad) <= max(1, int(max_outlier_frac * len(ok))), (len(bad), len(ok), np.abs(dev_qvel - ref_state["qvel"]).max())
     rng = np.random.default_rng(123)
     for e in bad:
+        if hard_atol is not None and np.all(_close(dev_qpos[e], ref_state["qpos"][e], atol=hard_atol)) and np.all(_close(dev_qvel[e], ref_state["qvel"][e], atol=hard_atol)):
+            continue
         spread = 0.0
-        for _ in range(12):
-            p = {k: v[e:e + 1].copy() for k, v in start.items()}
-            p["qpos"] = p["qpos"] + rng.uniform(-2e-7, 2e-7, p["qpos"].shape) * np.maximum(1.0, np.abs(p["qpos"]))
-            p["qvel"] = p["qvel"] + rng.uniform(-2e-7, 2e-7, p["qvel"].shape) * np.maximum(1.0, np.abs(p["qvel"]))
-            oracle.step(cm, p, act[e:e + 1].astype(np.float64))
-            spread = max(spread, np.abs(p["qvel"] - ref_state["qvel"][e]).max())
+        for scale in (2e-7, 1e-6):
+            for _ in range(12):
+                p = {k: v[e:e + 1].copy() for k, v in start.items()}
+                p["qpos"] = p["qpos"] + rng.uniform(-scale, scale, p["qpos"].shape) * np.maximum(1.0, np.abs(p["qpos"]))
+                p["qvel"] = p["qvel"] + rng.uniform(-scale, scale, p["qvel"].shape) * np.maximum(1.0, np.abs(p["qvel"]))
+                oracle.step(cm, p, act[e:e + 1].astype(np.float64))
+                spread = max(spread, np.abs(p["qvel"] - ref_state["qvel"][e]).max())
         assert spread > atol, f"env {e}: device differs from the oracle by {np.abs(dev_qvel[e] - ref_state['qvel'][e]).max():.2e} " \
                               f"but the oracle is smooth there (spread {spread:.2e})"
     return ok
@@ -127,14 +133,15 @@ def test_ant_forward_dynamics_and_contact_counts(torch, oracle):
     assert np.array_equal(counts.cpu().numpy()[:, 0], ref["counts"][:, 0])  # identical contact sets
     assert ref["counts"][:, 0].sum() > n  # the fixture really has contacts
     err = np.abs(qacc.cpu().numpy() - ref["qacc"])
-    assert np.all(err <= 5e-4 + 2e-6 * np.abs(ref["qacc"])), err.max()  # h * 5e-4 = 1e-5 on qvel
+    assert np.all(err <= 2e-4 + 1e-6 * np.abs(ref["qacc"])), err.max()  # measured 1.1e-4 at |qacc| up to 245 (h * 2e-4 = 4e-6 on qvel)
     env.close()
 
 
 def test_ant_lane_group_widths_agree(torch, oracle):
+    """Every lane-group width (8 / 16 / 32 / 64 lanes per env: different item-to-lane schedules and reduction trees) meets the
+    same per-env bar against the oracle, and the widths agree with each other to round-off."""
     n = 128
-    cmref = None
-    outs = {}
+    cmref, outs = None, {}
     for g in (8, 16, 32, 64):
         env = mm.make("AntUMaze-v0", num_envs=n)
         env.set_option("lanes_per_env", g)
@@ -142,12 +149,16 @@ def test_ant_lane_group_widths_agree(torch, oracle):
         if cmref is None:
             cmref = _rollout_states(oracle, cm, n, 21, {20})[20]
             act = np.random.default_rng(2).uniform(-30, 30, (n, 8)).astype(np.float32)
+            ref_state = {k: v.copy() for k, v in cmref.items()}
+            oracle.step(cm, ref_state, act.astype(np.float64), nthreads=8)
         env.set_state(cmref["qpos"], cmref["qvel"], cmref["warm"], cmref["t"])
         obs, *_ = env.step(torch.as_tensor(act, device=env.device))
+        qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+        _assert_step_parity(oracle, cm, cmref, act, qpos, qvel, ref_state, max_outlier_frac=0.0)
         outs[g] = obs.cpu().numpy().copy()
         env.close()
-    for g in (8, 32, 64):  # summation order differs between widths: identical up to round-off (rare activation flips aside)
-        assert np.all(_close(outs[g], outs[16]), axis=1).mean() >= 0.99, g
+    for g in (8, 32, 64):
+        assert np.all(_close(outs[g], outs[16], atol=4e-6)), g
 
 
 def _place_ant(st, xy, yaw=0.0):
@@ -177,10 +188,13 @@ def test_ant_wall_contacts_and_goal(torch, oracle):
     _, counts = env.debug_forward(act)
     fref = oracle.forward(cm, st["qpos"], st["qvel"], act.astype(np.float64), st["warm"])
     assert np.array_equal(counts.cpu().numpy()[:, 0], fref["counts"][:, 0])
+    start = {k: v.copy() for k, v in st.items()}
     obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+    qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
     ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
-    good = np.all(_close(obs.cpu().numpy(), ref["obs"], atol=2e-5), axis=1)
-    assert good.mean() >= 0.96, good.mean()  # stiff, partly artificial wall penetrations: allow activation flips
+    # stiff, partly artificial wall penetrations: measured 1 env of 64 on an activation flip (oracle-sensitive), the rest inside 1e-5
+    good = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, max_outlier_frac=2 / 64)
+    assert np.all(_close(obs.cpu().numpy()[good], ref["obs"][good]))
     assert np.array_equal(done.cpu().numpy(), ref["done"]) and ref["done"][n // 2:].sum() > 5
     assert np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
     assert np.all(_close(rew.cpu().numpy()[good], ref["reward"][good], atol=1e-6))
@@ -205,20 +219,15 @@ def test_ant_push_movable_block(torch, oracle):
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
-            # Movable-block mazes switch every default geom to solimp .995 (maze_env.py:108-112): contact rows are
-            # ~50x stiffer than in AntUMaze and the block weighs 0.2 g, so fp32 round-off reaches a few 1e-5 on the
-            # torso's angular rates in ~1 % of the envs, and an env whose contact crosses the activation distance
-            # within round-off sees MuJoCo's (discontinuous) damping term switch on a stage earlier or later.
-            # Bar: >= 98.5 % of the envs inside 1e-5 (+1e-5 rel), the rest inside 1e-4 except such flips (< 0.3 %).
-            err = np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))
-            per_env = err.max(1)
-            assert (per_env <= 1e-5).mean() >= 0.985, (per_env <= 1e-5).mean()
-            assert (per_env <= 1e-4).mean() >= 0.997, (per_env <= 1e-4).mean()
+            # Movable-block mazes switch every default geom to solimp .995 (maze_env.py:108-112): contact rows are ~50x stiffer
+            # than in AntUMaze and the block weighs 0.2 g, so the fp32 round-off of the Jacobians is amplified to 1.0-1.4e-5 on
+            # the torso's angular rates in <= 0.25 % of the envs (measured, profiles/r02/parity.md).  Bar: every env inside
+            # 1e-5 (+1e-5 rel) except <= 0.5 %, those inside 2e-5 — or on a discontinuity the float64 oracle shows itself.
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.005, hard_atol=2e-5)
+            per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
             assert np.median(per_env) < 2e-6
-            ok = per_env <= 1e-4
-            assert np.all(_close(qpos[ok], s64["qpos"][ok], atol=2e-5))
-            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=1e-4))
-            assert np.all(_close(rew.cpu().numpy()[ok], ref["reward"][ok], atol=1e-5))
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=2e-5))
+            assert np.all(_close(rew.cpu().numpy()[ok], ref["reward"][ok], atol=1e-6))
             assert np.array_equal(done.cpu().numpy(), ref["done"])
             assert np.array_equal(obs.cpu().numpy()[:, 5], np.full(n, 2.0, np.float32))  # block z in the obs slot
             assert np.all((env.status().cpu().numpy() & 7) == 0)
@@ -247,15 +256,16 @@ def test_ant_multi_block_mazes(torch, oracle, env_id, nblock):
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            # measured: <= 0.6 % of the envs outside 1e-5, each of them inside 2e-5 or on an oracle-visible discontinuity
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.012, hard_atol=2e-5)
             per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
-            worst.append(per_env)
-            ok = per_env <= 1e-4
-            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=1e-4))
+            worst.append(per_env[ok])
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=2e-5))
             assert np.array_equal(done.cpu().numpy(), ref["done"])
             assert np.all((env.status().cpu().numpy() & 7) == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     worst = np.concatenate(worst)
-    assert np.median(worst) < 3e-6 and (worst <= 2e-5).mean() >= 0.97, (np.median(worst), (worst <= 2e-5).mean(), worst.max())
+    assert np.median(worst) < 2e-6 and worst.max() <= 1e-5, (np.median(worst), worst.max())
     env.close()
 
 
@@ -423,27 +433,49 @@ def test_reset_distribution_and_oracle_rng(torch, oracle):
         env.close()
 
 
-def test_full_size_properties(torch):
-    """BASELINE size (4096 envs): size-independent properties over a 60-step rollout with auto-reset."""
-    n = 4096
-    env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True)
+def _goal_predicate_f64(task, slot):
+    """The reference's float64 predicate (maze_task.py:43-44,77-81) on rows of float64 slot coordinates: any goal neighbour."""
+    hit = np.zeros(len(slot), bool)
+    for g in task.goals:
+        hit |= np.sqrt(np.sum(np.square(slot[:, : g.dim] - g.pos), axis=1)) <= g.threshold
+    return hit
+
+
+@pytest.mark.parametrize("env_id,n", [("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 2048)])
+def test_full_size_properties(torch, env_id, n):
+    """BASELINE sizes (configs[2], [3] per GPU, [4]): size-independent properties over a 60-step rollout with auto-reset."""
+    env = mm.make(env_id, num_envs=n, auto_reset=True)
+    task = env._task
     env.reset(seed=5)
     g = torch.Generator(device=env.device).manual_seed(0)
-    goal = torch.tensor([0.0, 16.0], device=env.device, dtype=torch.float64)
+    nb3 = env.obs_dim - 30
+    # start a slice of the envs around the goal so that terminations do happen inside the 60 steps
+    qpos, qvel, warm, t = env.get_state()
+    gp = torch.as_tensor(task.goals[0].pos[:2], device=env.device, dtype=torch.float32)
+    qpos[: n // 8, :2] = gp + (torch.rand((n // 8, 2), device=env.device, generator=g) - 0.5) * 2.5
+    env.set_state(qpos=qpos)
+    nterm = 0
+    ever = torch.zeros(n, dtype=torch.bool, device=env.device)
     for k in range(60):
         act = (torch.rand((n, 8), device=env.device, generator=g) * 60 - 30)
         obs, rew, done, info = env.step(act)
         assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
         # termination flag is exactly the reference's FLOAT64 predicate (maze_task.py:43-44,77-81) on the observation the
         # step produced: `obs` for running envs, info["final_observation"] for the ones that just auto-reset
-        last = torch.where((done != 0)[:, None], info["final_observation"], obs).double()
-        pred = ((last[:, :2] - goal).square().sum(dim=1).sqrt() <= 0.6).to(torch.uint8)
-        assert torch.equal(done & 1, pred)
-        fresh = done == 0  # envs that have not auto-reset yet carry the global step count
+        last = torch.where((done != 0)[:, None], info["final_observation"], obs).double().cpu().numpy()
+        pred = _goal_predicate_f64(task, last[:, :3])
+        d = done.cpu().numpy()
+        assert np.array_equal((d & 1).astype(bool), pred)
+        nterm += int(pred.sum())
+        ever |= done != 0
+        fresh = ~ever  # envs that have not auto-reset yet carry the global step count
         if k < 5:
             assert torch.allclose(obs[:, -1][fresh], torch.tensor((k + 1) * 0.001, device=env.device))
-        qn = obs[:, 3:7].norm(dim=1)
+        qn = obs[:, 3 + nb3:7 + nb3].norm(dim=1)
         assert torch.all((qn - 1).abs() < 1e-5)  # integrated quaternions stay unit
+        if nb3:
+            assert torch.all(obs[:, 5] == 2.0)  # block z slot
+    assert nterm > n // 100
     st = env.status().cpu().numpy()
     assert np.all((st & 1) == 0), "NaN / diverged envs"
     assert (st & 2).mean() < 0.01, "contact buffer overflow"
@@ -459,6 +491,48 @@ def test_full_size_properties(torch):
     assert torch.all(obs[:, -1] == 0.0) and torch.allclose(info["final_observation"][:, -1], torch.tensor(1.0, device=env.device))
     qpos = env.get_state()[0]
     assert torch.equal(obs[:, :3], qpos[:, :3]) and torch.all((obs[:, 2] - 0.75).abs() <= 0.1 + 1e-6)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["Ant4Rooms-v2", "Point4Rooms-v2", "AntTRoom-v2", "PointBilliard-v2"])
+def test_subgoal_first_match_parity(torch, oracle, env_id):
+    """`-v2` sub-goal tasks (maze_task.py:403-407: the FIRST goal in list order that is a neighbour pays its reward_scale —
+    1.0 for the main goal, 0.5 for sub-goals — else PENALTY; termination at any goal): envs placed around every goal, one
+    step on the device against the oracle: reward, done and goal index."""
+    n = 256
+    env = mm.make(env_id, num_envs=n)
+    cm, task = env.model, env._task
+    assert len(task.goals) > 1
+    st, _ = oracle.reset(cm, n, 4)
+    rng = np.random.default_rng(1)
+    object_slot = cm.c.term_slot == 1
+    for gi, g in enumerate(task.goals):
+        sel = slice(gi * 48, gi * 48 + 48)
+        xy = g.pos[:2] + rng.normal(0.0, g.threshold * 0.7, (48, 2))
+        if object_slot:  # Billiard: the ball's slide coordinates (body spawn position + q)
+            b = cm.c.ball_bodyid[0]
+            st["qpos"][sel, 3:5] = xy - np.array(cm.c.body_pos[b][:2])
+            st["qpos"][sel, :2] = xy + np.array([3.0, 0.0])  # robot out of the way
+        else:
+            st["qpos"][sel, :2] = xy
+    s64 = _f32(st)
+    lo, hi = env.action_space.low, env.action_space.high
+    act = (0.05 * rng.uniform(lo, hi, (n, env.nu))).astype(np.float32)
+    env.set_state(s64["qpos"], s64["qvel"], s64["warm"] if env_id.startswith("Ant") else None, s64["t"])
+    obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+    ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+    gidx = info["goal_index"].cpu().numpy()
+    assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(gidx, ref["goal_idx"])
+    for gi in range(len(task.goals)):
+        assert (gidx == gi).sum() >= 8, (gi, (gidx == gi).sum())  # every goal is matched by some envs
+    o = obs.double().cpu().numpy()
+    slot = o[:, 3:6] if object_slot else o[:, :3]
+    assert np.array_equal((done.cpu().numpy() & 1).astype(bool), _goal_predicate_f64(task, slot))
+    near = np.all(_close(obs.cpu().numpy(), ref["obs"], atol=2e-5), axis=1)
+    assert near.mean() > 0.97
+    inner = rew.cpu().numpy() - np.where(gidx >= 0, np.array([g.reward_scale for g in task.goals] + [0.0])[gidx], task.PENALTY)
+    ref_inner = ref["reward"] - np.where(ref["goal_idx"] >= 0, np.array([g.reward_scale for g in task.goals] + [0.0])[ref["goal_idx"]], task.PENALTY)
+    assert np.all(np.abs(inner - ref_inner)[near] <= 1e-5)
     env.close()
 
 
