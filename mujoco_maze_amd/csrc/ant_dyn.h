@@ -49,6 +49,7 @@ MZ_HD int mz_first_item(int lane, int base, int nl) { return (lane - base) & (nl
 
 struct HostCtx {
   static constexpr int nlanes = 1;
+  static constexpr bool row_solver = false;  // the DPP-row Newton solver (ant_newton_rows.h) exists on the device only
   MZ_HD int lane0() const { return 0; }
   MZ_HD void sync() const {}
   MZ_HD float gsum(float x) const { return x; }
@@ -1148,7 +1149,10 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   }
   cx.sync();
   cx.tick(s, 12);
-  ant_solve<NB>(cx, K, s, first);
+  // plain ant on the device: the register-resident Newton solver of ant_newton_rows.h (same mathematics); everything else
+  // (movable blocks, 8-lane groups, the host emulation) runs the lane-group formulation above
+  if constexpr (NB == 0 && C::row_solver) ant_solve_rows(cx, K, s, first);
+  else ant_solve<NB>(cx, K, s, first);
 }
 
 

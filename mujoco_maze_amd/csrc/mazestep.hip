@@ -150,7 +150,10 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
     return MZ_OK;
   }
   if (!strcmp(key, "profile_phases")) {
-    if (value != 0 && !h->prof) { HIPCHK(h, hipMalloc(&h->prof, 16 * sizeof(unsigned long long))); HIPCHK(h, hipMemset(h->prof, 0, 16 * sizeof(unsigned long long))); }
+    if (value != 0 && !h->prof) {  // 16 accumulators + one total per workgroup (at most one workgroup per env)
+      HIPCHK(h, hipMalloc(&h->prof, (16 + (size_t)h->n) * sizeof(unsigned long long)));
+      HIPCHK(h, hipMemset(h->prof, 0, (16 + (size_t)h->n) * sizeof(unsigned long long)));
+    }
     if (value == 0 && h->prof) { (void)hipFree(h->prof); h->prof = nullptr; }
     return MZ_OK;
   }
@@ -265,6 +268,16 @@ int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host) {
   HIPCHK(h, hipDeviceSynchronize());
   HIPCHK(h, hipMemcpy(out16_host, h->prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemset(h->prof, 0, 16 * sizeof(unsigned long long)));
+  return MZ_OK;
+}
+
+// Per-workgroup cycle totals accumulated by the PROF kernel build since the last call (then cleared): n_host entries.
+int32_t mz_read_wave_cycles(mz_handle* h, uint64_t* out_host, int32_t n_host) {
+  if (!h || !out_host || !h->prof || n_host <= 0 || n_host > h->n) return MZ_ERR_ARG;
+  DeviceScope scope(h->device);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(out_host, h->prof + 16, (size_t)n_host * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemset(h->prof + 16, 0, (size_t)h->n * sizeof(unsigned long long)));
   return MZ_OK;
 }
 

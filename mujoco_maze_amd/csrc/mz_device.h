@@ -8,6 +8,7 @@
 template <int G, bool PROF = false>
 struct DevCtx {
   static constexpr int nlanes = G;
+  static constexpr bool row_solver = G >= 16;  // plain ant: Newton iteration resident in one 16-lane DPP row (ant_newton_rows.h)
   int l;
   // phase timer (PROF builds only): lane 0 of the group accumulates shader cycles since the previous tick
   template <class S>
@@ -30,7 +31,7 @@ struct DevCtx {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // All-reduce (sum) inside the lane group.  Rows of 16 lanes reduce with four DPP moves (quad_perm xor 1,
-  // xor 2, row_half_mirror, row_mirror: VALU-rate, no LDS crossbar); only the cross-row steps use ds_bpermute.
+  // xor 2, row_half_mirror, row_mirror: VALU-rate, no LDS crossbar).
   static __device__ __forceinline__ float dpp_add(float x, const int ctrl_sel) {
     int xi = __float_as_int(x), yi;
     switch (ctrl_sel) {
@@ -41,13 +42,26 @@ struct DevCtx {
     }
     return x + __int_as_float(yi);
   }
+  // Cross-row steps stay on the VALU as well (no ds_bpermute round trip through the LDS crossbar, ~100 cycles each on the
+  // serial critical path of the line search): row_bcast:15 adds lane 15 of rows 0 / 2 into every lane of rows 1 / 3,
+  // row_bcast:31 adds lane 31 into rows 2 and 3; the group total then sits in the group's last row and is handed back to
+  // all lanes with one v_readlane per group (scalar registers) and a select.
   __device__ __forceinline__ float gsum(float x) const {
     if constexpr (G >= 2) x = dpp_add(x, 0);
     if constexpr (G >= 4) x = dpp_add(x, 1);
     if constexpr (G >= 8) x = dpp_add(x, 2);
     if constexpr (G >= 16) x = dpp_add(x, 3);
-    if constexpr (G >= 32) x += __shfl_xor(x, 16, 64);
-    if constexpr (G >= 64) x += __shfl_xor(x, 32, 64);
+    if constexpr (G == 32) {
+      x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xA, 0xF, false));  // rows 1, 3 += lane 15 of rows 0, 2
+      const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+      const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+      x = __lane_id() < 32 ? t0 : t1;
+    }
+    if constexpr (G >= 64) {
+      x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xA, 0xF, false));
+      x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xC, 0xF, false));  // rows 2, 3 += lane 31
+      x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    }
     return x;
   }
   __device__ __forceinline__ double gsum(double x) const {  // fp64 paths (Point): plain butterfly

@@ -253,6 +253,12 @@ class VecMazeEnv:
         _capi.check(self._lib, self._h, self._lib.mz_read_phase_cycles(self._h, out), "mz_read_phase_cycles")
         return list(out)
 
+    def wave_cycles(self, n: int):
+        """Per-workgroup cycle totals of the instrumented kernel since the last call (numpy uint64 [n])."""
+        out = np.zeros(n, np.uint64)
+        _capi.check(self._lib, self._h, self._lib.mz_read_wave_cycles(self._h, out.ctypes.data_as(C.c_void_p), n), "mz_read_wave_cycles")
+        return out
+
     def kernel_ms(self) -> float:
         return float(self._lib.mz_last_kernel_ms(self._h))
 
