@@ -162,6 +162,22 @@ MZ_HD void quat_to_matf(float* m, const float* qin) {
   m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
   m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
 }
+// sin and cos together: one Cody-Waite reduction to [-pi/4, pi/4] (k = nearest multiple of pi/2; three-part constant, exact
+// for the |x| < ~1e4 a joint angle or half a rotation step can reach) and the two cephes minimax polynomials (~1 ulp).
+// One call replaces a sinf and a cosf of the math library, each of which reduces its argument separately.
+MZ_HD void mz_sincosf(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.63661977236758134f);  // 2 / pi
+  float y = x - k * 1.5703125f;                      // pi/2 split: 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
+  y -= k * 4.837512969970703125e-4f;
+  y -= k * 7.54978995489188e-8f;
+  const float z = y * y;
+  const float ps = y + y * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+  const float pc = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+  const int q = (int)k & 3;
+  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
 MZ_HD void mat_vecf(float* r, const float* m, const float* v) {
   float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
@@ -240,7 +256,9 @@ MZ_HD void kin_item(const AntDev& K, AntScratchT<NB>& s, int l) {
     float sx = K.sx[l], sy = K.sy[l];
     float u[3] = {sx * isq2, sy * isq2, 0.f}, off[3] = {sx * K.legoff, sy * K.legoff, 0.f};
     float qh = s.qpos[7 + 2 * l], qa = s.qpos[8 + 2 * l];
-    float ch = cosf(qh), sh = sinf(qh), ca = cosf(qa), sa = sinf(qa);
+    float ch, sh, ca, sa;
+    mz_sincosf(qh, &sh, &ch);
+    mz_sincosf(qa, &sa, &ca);
     float t[3], v[3];
     // level 0: welded leg capsule, frame = torso frame
     mat_vecf(s.w[3 * l], R0, u);
@@ -1133,26 +1151,34 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   if (!first) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7
   cx.sync();
   cx.tick(s, 3);
-  MZ_FOR_AT(l, 4, 0) factor_leg_item<NH>(s.M, s.F, l);
-  MZ_FOR_AT(item, 3 * s.ncon, 4) con_row_item<NB>(K, s, item);
-  MZ_FOR_AT(j, 8, 4 + 3 * s.ncon) limit_item<NB>(K, s, j);
-  cx.sync();
-  cx.tick(s, 11);
-  MZ_FOR(e, NH * (NH + 1) / 2 + NH) factor_schur_item<NH>(s.M, s.F, s.qfs, e);
-  cx.sync();
-  MZ_FOR(one, 1) factor_serial_item<NH>(s.F);
-  cx.sync();
-  MZ_FOR(i, NV) {
-    float v = factor_back_item<NH>(s.F, s.qfs, 1.f, i);
-    s.qas[i] = v;
-    if (!first) s.warm[i] += v;
+  if constexpr (NB == 0 && C::row_solver) {
+    // plain ant on the device: constraint rows, then the register-resident solver of ant_newton_rows.h, which also
+    // computes qacc_smooth = M^-1 qfrc_smooth with its row elimination (no Schur / Cholesky phases) — same mathematics
+    MZ_FOR_AT(item, 3 * s.ncon, 0) con_row_item<NB>(K, s, item);
+    MZ_FOR_AT(j, 8, 3 * s.ncon) limit_item<NB>(K, s, j);
+    cx.sync();
+    cx.tick(s, 11);
+    ant_solve_rows(cx, K, s, first);
+  } else {
+    // everything else (movable blocks, 8-lane groups, the host emulation): the lane-group formulation
+    MZ_FOR_AT(l, 4, 0) factor_leg_item<NH>(s.M, s.F, l);
+    MZ_FOR_AT(item, 3 * s.ncon, 4) con_row_item<NB>(K, s, item);
+    MZ_FOR_AT(j, 8, 4 + 3 * s.ncon) limit_item<NB>(K, s, j);
+    cx.sync();
+    cx.tick(s, 11);
+    MZ_FOR(e, NH * (NH + 1) / 2 + NH) factor_schur_item<NH>(s.M, s.F, s.qfs, e);
+    cx.sync();
+    MZ_FOR(one, 1) factor_serial_item<NH>(s.F);
+    cx.sync();
+    MZ_FOR(i, NV) {
+      float v = factor_back_item<NH>(s.F, s.qfs, 1.f, i);
+      s.qas[i] = v;
+      if (!first) s.warm[i] += v;
+    }
+    cx.sync();
+    cx.tick(s, 12);
+    ant_solve<NB>(cx, K, s, first);
   }
-  cx.sync();
-  cx.tick(s, 12);
-  // plain ant on the device: the register-resident Newton solver of ant_newton_rows.h (same mathematics); everything else
-  // (movable blocks, 8-lane groups, the host emulation) runs the lane-group formulation above
-  if constexpr (NB == 0 && C::row_solver) ant_solve_rows(cx, K, s, first);
-  else ant_solve<NB>(cx, K, s, first);
 }
 
 
@@ -1168,7 +1194,9 @@ MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base,
       float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
       for (int k = 0; k < 4; k++) q[k] *= qn;
       if (n > 1e-15f) {
-        float ang = 0.5f * h * n, sn = sinf(ang) / n, c0 = cosf(ang);
+        float ang = 0.5f * h * n, sn, c0;
+        mz_sincosf(ang, &sn, &c0);
+        sn /= n;
         float r[4] = {c0, w[0] * sn, w[1] * sn, w[2] * sn}, o[4];
         o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
         o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];

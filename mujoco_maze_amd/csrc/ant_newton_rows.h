@@ -89,8 +89,9 @@ __device__ __forceinline__ float ceval(float D, float u0, float u1, float u2) {
 
 }  // namespace rows
 
-// The solve.  In: s.M, s.qas, s.qfs, s.warm, contacts (s.cJ, s.caref, s.cD, s.cleg, s.ncon), limits (s.lsign, s.lD, s.laref).
-// Out: s.qacc, s.iters, status bits.  Requires G >= 16.
+// The solve.  In: s.M, s.qfs, s.warm (first evaluation of a step: MuJoCo's qacc_warmstart; later: the previous evaluation's
+// solution minus its qacc_smooth, see ant_forward), contacts (s.cJ, s.caref, s.cD, s.cleg, s.ncon), limits (s.lsign, s.lD,
+// s.laref).  Out: s.qas = M^-1 qfs, s.qacc, s.iters, status bits.  Requires G >= 16.
 template <int G, bool PROF>
 __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<0>& s, bool compare) {
   static_assert(G >= 16, "one DPP row per env at least");
@@ -118,7 +119,17 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     }
   }
   const int ri = isdof ? r : 0;
-  const float qas = isdof ? s.qas[ri] : 0.f, qfs = isdof ? s.qfs[ri] : 0.f, warm = isdof ? s.warm[ri] : 0.f;
+  const float qfs = isdof ? s.qfs[ri] : 0.f;
+  float qas;
+  {  // qacc_smooth = M^-1 qfrc_smooth by the same row elimination
+    float Hq[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) Hq[k] = Mrow[k];
+    qas = solve14(r, Hq, qfs);
+  }
+  if (isdof) s.qas[ri] = qas;
+  const float warm = isdof ? (compare ? s.warm[ri] : s.warm[ri] + qas) : 0.f;  // later stages: shifted by the change of qacc_smooth
+  cx.tick(s, 12);
   const float lsign = ishinge ? s.lsign[ishinge ? r - 6 : 0] : 0.f;
   const float lD = ishinge ? s.lD[ishinge ? r - 6 : 0] : 0.f, laref = ishinge ? s.laref[ishinge ? r - 6 : 0] : 0.f;
   const bool has = ncon > 0 || cx.gany(lsign != 0.f);
@@ -144,6 +155,7 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   // ---- initial guess
   float qacc = warm;
   if (compare) {  // MuJoCo's rule on the first evaluation of a step: the better of warm start and qacc_smooth, by cost
+    cx.sync();  // s.qas is read back by the contact lanes
     const float dw = warm - qas;
     float cw = 0.5f * dw * matvec(Mrow, dw), cs = 0.f;
     float w0, w1, w2, q0, q1, q2;

@@ -36,8 +36,12 @@ def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, a
     MuJoCo's soft constraints switch on at `dist < margin` / `q < limit` with a velocity-dependent (damping) term, and the
     box rules pick faces by comparisons, so the step map has jumps: an env whose contact crosses such a threshold within
     fp32 round-off legitimately lands on the other branch.  Such an env is accepted only if the oracle ITSELF is that
-    sensitive: re-running it from the same state perturbed at the scale of fp32 round-off (2e-7 and 1e-6 relative — the
-    second is what absolute coordinates of ~10 m carry in fp32) must move its own answer by more than the tolerance.
+    sensitive: re-running it from the same state perturbed at the scale of the device's round-off must move its own answer by
+    more than the tolerance.  Scales: 2e-7 (one fp32 ulp of the state), 1e-6 (what absolute coordinates of ~10 m carry in
+    fp32) and 5e-6 (the error the device's intermediate states carry INSIDE the step: a forward evaluation is good to
+    2e-4 in qacc — test_ant_forward_dynamics_and_contact_counts — i.e. 4e-6 in the velocity of the next RK4 stage).  Two
+    fp32 implementations of the step (the 8-lane generic solver and the 16-lane row solver of the same library) part ways
+    at this rate too: 183 of 819 200 env-steps, tools/dbg_outlier.py.
     `max_outlier_frac` caps how many envs may need that excuse (<= 2x what was measured: profiles/r02/parity.md).
     `hard_atol` (block mazes only): an outlier inside this looser bound is accepted as round-off of the ~50x stiffer rows
     (solimp .995, 0.2 g block) without the sensitivity proof; beyond it the proof is required."""
@@ -49,7 +53,7 @@ def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, a
         if hard_atol is not None and np.all(_close(dev_qpos[e], ref_state["qpos"][e], atol=hard_atol)) and np.all(_close(dev_qvel[e], ref_state["qvel"][e], atol=hard_atol)):
             continue
         spread = 0.0
-        for scale in (2e-7, 1e-6):
+        for scale in (2e-7, 1e-6, 5e-6):
             for _ in range(12):
                 p = {k: v[e:e + 1].copy() for k, v in start.items()}
                 p["qpos"] = p["qpos"] + rng.uniform(-scale, scale, p["qpos"].shape) * np.maximum(1.0, np.abs(p["qpos"]))

@@ -1,15 +1,16 @@
 #!/bin/bash
 # GPU box helper: rocprofv3 kernel stats + PMC passes of the bench command -> gpurun_out/prof_$1
 # (counters are collected in their own passes, never together with --kernel-trace/--stats tracing domains)
-tag=${1:-r01}
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-# the default bench command (100 warm-up + 200 timed steps), minus the CPU leg
-CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+# the default bench command (100 settle + 100 warm-up + 1000 timed steps), minus the CPU leg
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $CMD > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $CMD > $out/bench_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $out/pmc_sq -- $CMD > $out/bench_sq.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_lds -- $CMD > $out/bench_lds.log 2>&1
-find $out -name "*.csv" | head -30
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM --output-format csv -d $out/pmc_busy -- $CMD > $out/bench_busy.log 2>&1
+find $out -name "*.csv" | head -40
