@@ -118,6 +118,7 @@ struct alignas(16) AntScratchT {
   // joint limits (8 hinges)
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   float red[4];
+  uint32_t rowmask[MZ_MAX_GRID + 4];  // the maze's cell grid (bit j of word i: BLOCK), copied once per step: one LDS read per row lookup
   int status, iters;
   // optional phase timers (device builds with PROF): cycles per phase id, last timestamp
   unsigned long long prof_t0;
@@ -208,6 +209,10 @@ MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
   return m;
 }
 
+// the same lookup from the env's LDS copy of the grid (ant_fill_tables): one read instead of a 12-way select
+template <class S>
+MZ_HD uint32_t maze_row_lds(const S& s, int i) { return (i >= 0 && i < MZ_MAX_GRID) ? s.rowmask[i] : 0u; }
+
 // body index b in 0..12: 0 torso, else leg l = (b-1)/3, level k = (b-1)%3 (0 welded leg, 1 aux, 2 ankle)
 MZ_HD int body_class(int b) { return b == 0 ? 0 : 1 + (b - 1) % 3; }
 
@@ -227,21 +232,22 @@ MZ_HD void kin_item(const AntDev& K, AntScratchT<NB>& s, int l) {
       int jc = (int)floorf(x * inv + 0.5f), ic = (int)floorf(y * inv + 0.5f);
       float fx = x - jc * z.scale, fy = y - ic * z.scale;  // offset from the centre of the torso's own cell
       bool inside = ic >= 0 && ic < z.rows && jc >= 0 && jc < z.cols;
-      int near = inside ? (int)((maze_row(z, ic) >> jc) & 1u) : 1;  // torso inside a wall cell / off the grid: keep testing
-      if (z.scale < reach) near = 1;  // cells smaller than the reach: more than one ring of neighbours could matter
+      // torso inside a wall cell / off the grid: keep testing; cells smaller than the reach: more than one ring could matter
+      int near = (!inside || z.scale < reach) ? 1 : (int)((maze_row_lds(s, ic) >> jc) & 1u);
+      // distances to the borders shared with the neighbouring rows / columns (0 for the own row / column)
+      const float dlo_y = z.half_xy + fy, dhi_y = z.half_xy - fy, dlo_x = z.half_xy + fx, dhi_x = z.half_xy - fx, r2 = reach * reach;
+#pragma unroll
       for (int di = -1; di <= 1; di++) {
-        int i2 = ic + di;
-        if (i2 < 0 || i2 >= z.rows) continue;
-        uint32_t row = maze_row(z, i2);
-        float dy = di == 0 ? 0.f : z.half_xy - di * fy;  // distance to the border shared with that row
+        const uint32_t row = (ic + di < z.rows) ? maze_row_lds(s, ic + di) : 0u;  // rows beyond the grid hold no BLOCK cell
+        const float dy = di == 0 ? 0.f : (di < 0 ? dlo_y : dhi_y);
+#pragma unroll
         for (int dj = -1; dj <= 1; dj++) {
-          int j2 = jc + dj;
-          if (j2 < 0 || j2 >= z.cols || !((row >> j2) & 1u)) continue;
-          float dx = dj == 0 ? 0.f : z.half_xy - dj * fx;
-          if (dx * dx + dy * dy < reach * reach) near = 1;
+          const int j2 = jc + dj;
+          const bool blk = j2 >= 0 && j2 < z.cols && ((row >> (j2 & 31)) & 1u);
+          const float dx = dj == 0 ? 0.f : (dj < 0 ? dlo_x : dhi_x);
+          if (blk && dx * dx + dy * dy < r2) near = 1;
         }
       }
-      if (!inside) near = 1;
       s.nearwall = near;
       return;
     }
@@ -693,7 +699,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     for (int i = i0; i <= i1; i++)
       for (int j = j0; j <= j1; j++) {
         if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
-        if (!((maze_row(z, i) >> j) & 1u)) continue;
+        if (!((maze_row_lds(s, i) >> j) & 1u)) continue;
         // aligned box-box [ASSUME-12]: geom1 = wall, geom2 = block
         float c1[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
         float gap[3];
@@ -797,7 +803,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
   for (int i = i0; i <= i1; i++)
     for (int j = j0; j <= j1; j++) {
       if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
-      if (!((maze_row(z, i) >> j) & 1u)) continue;
+      if (!((maze_row_lds(s, i) >> j) & 1u)) continue;
       // box centre relative to the torso origin, computed so that the large world coordinates cancel first
       float bc[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
       round_vs_box(b == 0, ctr, ax, hl, r, bc, bs, K.wall.margin, 1, 0, emit);
@@ -1153,9 +1159,9 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   cx.tick(s, 3);
   if constexpr (NB == 0 && C::row_solver) {
     // plain ant on the device: constraint rows, then the register-resident solver of ant_newton_rows.h, which also
-    // computes qacc_smooth = M^-1 qfrc_smooth with its row elimination (no Schur / Cholesky phases) — same mathematics
+    // computes qacc_smooth = M^-1 qfrc_smooth with its row elimination (no Schur / Cholesky phases) and builds the joint-limit
+    // rows on their own dof lanes — same mathematics
     MZ_FOR_AT(item, 3 * s.ncon, 0) con_row_item<NB>(K, s, item);
-    MZ_FOR_AT(j, 8, 3 * s.ncon) limit_item<NB>(K, s, j);
     cx.sync();
     cx.tick(s, 11);
     ant_solve_rows(cx, K, s, first);
@@ -1297,6 +1303,12 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
   return (float)t * 0.001f;
 }
 
+// constant tables of the scratch block, once per step (to be followed by a cx.sync() before the first forward evaluation)
+template <int NB, class C>
+MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
+  MZ_FOR(i, MZ_MAX_GRID) s.rowmask[i] = maze_row(K.maze, i);
+}
+
 // ------------------------------------------------------------------ MazeEnv.step for the Ant (maze_env.py:448-481, ant.py:61-73)
 // in: s.qpos/qvel/warm loaded, action[8], *t_io = steps so far.  out: obs[obs_dim], reward, done, goal_idx, info[4], *t_io + 1
 // (t travels through memory so that it does not occupy a register across the whole step)
@@ -1305,6 +1317,7 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
                         uint8_t* done, int* goal_idx, float* info, int* t_io) {
   using D = AntDims<NB>;
   MZ_FOR(i, D::NV) s.fact[i] = 0.f;
+  ant_fill_tables<NB>(cx, K, s);
   MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
   cx.sync();
   MZ_FOR(u, ANT_NU) s.fact[K.act_dof[u]] = K.gear * fminf(fmaxf(action[u], K.ctrl_lo), K.ctrl_hi);

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const 
   AntScratchT<NB>& s = sc[slot];
   ant_load<NB>(cx, s, state + (size_t)env * D::REC);
   for (int i = cx.l; i < D::NV; i += G) s.fact[i] = 0.f;
+  ant_fill_tables<NB>(cx, K, s);
   if (cx.l == 0) s.status = 0;
   cx.sync();
   if (actions)

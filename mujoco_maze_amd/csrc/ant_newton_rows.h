@@ -90,8 +90,8 @@ __device__ __forceinline__ float ceval(float D, float u0, float u1, float u2) {
 }  // namespace rows
 
 // The solve.  In: s.M, s.qfs, s.warm (first evaluation of a step: MuJoCo's qacc_warmstart; later: the previous evaluation's
-// solution minus its qacc_smooth, see ant_forward), contacts (s.cJ, s.caref, s.cD, s.cleg, s.ncon), limits (s.lsign, s.lD,
-// s.laref).  Out: s.qas = M^-1 qfs, s.qacc, s.iters, status bits.  Requires G >= 16.
+// solution minus its qacc_smooth, see ant_forward), contacts (s.cJ, s.caref, s.cD, s.cleg, s.ncon); the joint-limit rows are built here
+// from s.qpos / s.qvel.  Out: s.qas = M^-1 qfs, s.qacc, s.iters, status bits.  Requires G >= 16.
 template <int G, bool PROF>
 __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<0>& s, bool compare) {
   static_assert(G >= 16, "one DPP row per env at least");
@@ -130,8 +130,21 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   if (isdof) s.qas[ri] = qas;
   const float warm = isdof ? (compare ? s.warm[ri] : s.warm[ri] + qas) : 0.f;  // later stages: shifted by the change of qacc_smooth
   cx.tick(s, 12);
-  const float lsign = ishinge ? s.lsign[ishinge ? r - 6 : 0] : 0.f;
-  const float lD = ishinge ? s.lD[ishinge ? r - 6 : 0] : 0.f, laref = ishinge ? s.laref[ishinge ? r - 6 : 0] : 0.f;
+  // joint-limit row of this lane's own hinge (limit_item of ant_dyn.h, in registers: the row never leaves its lane)
+  float lsign = 0.f, lD = 0.f, laref = 0.f;
+  if (ishinge) {
+    const int j = r - 6, l = j >> 1;
+    const float q = s.qpos[7 + j], lo = (j & 1) ? K.ank_lo[l] : K.hip_lo, hi = (j & 1) ? K.ank_hi[l] : K.hip_hi;
+    float pos = 0.f;
+    if (q - lo < 0.f) { lsign = 1.f; pos = q - lo; }
+    else if (hi - q < 0.f) { lsign = -1.f; pos = hi - q; }
+    if (lsign != 0.f) {
+      const float imp = impedancef(K.lim_solimp, fabsf(pos));
+      const float R = fmaxf(1e-15f, (1.f - imp) / imp * ((j & 1) ? K.dofw_ank : K.dofw_hip));
+      lD = 1.0f / R;
+      laref = -K.lim_B * (lsign * s.qvel[6 + j]) - K.lim_K * imp * pos;
+    }
+  }
   const bool has = ncon > 0 || cx.gany(lsign != 0.f);
   // own contact: 3 x 8 Jacobian rows stay in LDS (row-major, read as needed); constants in registers
   const int cr = iscon ? r : 0;

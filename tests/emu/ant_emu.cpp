@@ -45,6 +45,7 @@ static int forward_t(const AntDev& K, int n, const float* qpos, const float* qve
     if (actions)
       for (int u = 0; u < ANT_NU; u++) s->fact[K.act_dof[u]] = K.gear * fminf(fmaxf(actions[e * ANT_NU + u], K.ctrl_lo), K.ctrl_hi);
     s->status = 0;
+    ant_fill_tables<NB>(cx, K, *s);
     ant_forward<NB>(cx, K, *s, true);
     for (int k = 0; k < D::NV; k++) qacc[e * D::NV + k] = s->qacc[k];
     if (counts) { counts[2 * e] = s->ncon; counts[2 * e + 1] = s->iters; }
