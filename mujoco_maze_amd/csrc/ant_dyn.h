@@ -1260,7 +1260,7 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
 // match) evaluated on float64(obs): differences and squares in fp64, summed in index order without contraction, compared
 // with the squared-threshold bound of TaskDev (bit-exact whatever the build flags of the translation unit).
 MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int* term, int* goal_idx) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
   const double slot_a[3] = {(double)obs[0], (double)obs[1], (double)obs[2]}, slot_o[3] = {(double)obs[3], (double)obs[4], (double)obs[5]};
   int tm = 0, first = -1;
   for (int g = 0; g < T.ngoal; g++) {

@@ -7,10 +7,10 @@
 //
 // HBM layout: SoA  q_0..q_{NV-1} | v_0..v_{NV-1}, each [N] fp32; t[N], episode[N] i32.  API arrays are row-major [N, k].
 //
-// This translation unit is built with STRICT floating-point flags (csrc/Makefile: no -freciprocal-math, no
-// -fapprox-func, no -fno-signed-zeros): the Point's manual wall detector (point_dyn.h: point_detect / point_bounce) and
-// the task predicates reproduce the reference's float64 decisions bit for bit — IEEE division and square root, and no
-// contraction inside those functions (#pragma clang fp contract(off)).
+// This translation unit is built without -fapprox-func / -fno-signed-zeros (csrc/Makefile); the dynamics may use
+// reciprocal division, but the Point's manual wall detector (point_dyn.h: point_detect / point_bounce) and the task
+// predicates reproduce the reference's float64 decisions bit for bit — inside those functions contraction, reciprocal
+// division and reassociation are switched off (#pragma clang fp ...), and sqrt is correctly rounded.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

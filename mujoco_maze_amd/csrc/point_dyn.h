@@ -152,15 +152,15 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
 // ---- the manual wall detector: float64 arithmetic of the reference, operation for operation.
 // The reference computes with Python complex numbers and floats (maze_env_utils.py:84-123): every product, sum and
 // quotient is a separately rounded IEEE double operation and abs(complex) is C hypot().  The functions below keep that:
-// `#pragma clang fp contract(off)` (no fused multiply-add), exact division and square root (this translation unit is
-// built WITHOUT -freciprocal-math / -fapprox-func, csrc/Makefile), and mz_hypot restates glibc's hypot so that the
-// "nearest collision" comparison sees the same distances.
+// `#pragma clang fp contract(off) reciprocal(off) reassociate(off)` — no fused multiply-add, IEEE division whatever the
+// command line says — a correctly rounded square root (this translation unit is built without -fapprox-func,
+// csrc/Makefile), and mz_hypot restates glibc's hypot so that the "nearest collision" comparison sees the same distances.
 
 // glibc 2.35 __hypot (sysdeps/ieee754/dbl-64/e_hypot.c, the non-FMA kernel that x86-64 builds use), valid for the
 // magnitudes a maze coordinate can take (no scaling branches: |x|, |y| in [2^-459, 2^511] or zero).  Checked bit for bit
 // against libm hypot on the host (tests/test_maze_golden.py) — CPython's abs(complex) calls exactly that function.
 MZP_HD double mz_hypot(double x, double y) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
   double ax = fabs(x), ay = fabs(y);
   if (ax < ay) { double t = ax; ax = ay; ay = t; }
   if (ax >= ay * 0x1p54) return ax + ay;
@@ -180,13 +180,13 @@ MZP_HD double mz_hypot(double x, double y) {
 
 // (conj(a) * b).imag of maze_env_utils.py:99 with a = ax + i ay, b = bx + i by:  ax * by + (-ay) * bx
 MZP_HD double cross2d(double ax, double ay, double bx, double by) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
   return ax * by + (-ay) * bx;
 }
 
 // CollisionDetector.detect (maze_env_utils.py:186-206): 1 hit, 0 none, -1 collinear (the reference raises ZeroDivisionError)
 MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, double* pt, double* rf) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
   double mvx = n[0] - o[0], mvy = n[1] - o[1];
   if (mz_hypot(mvx, mvy) <= 1e-8) return 0;
   int found = 0, degenerate = 0;
@@ -221,7 +221,7 @@ MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, dou
 // Wall bounce of MazeEnv.step (maze_env.py:457-464): 0 no hit, 1 bounced to `fin`, 2 gave up (fin = old position),
 // -1 where the reference would have raised (collinear move; fin = new position)
 MZP_HD int point_bounce(const PointDev& P, const double* old_xy, const double* new_xy, double* fin, double* hit_pt) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
   double pt[2] = {0.0, 0.0}, rf[2] = {0.0, 0.0};
   fin[0] = new_xy[0]; fin[1] = new_xy[1];
   int hit = point_detect(P, old_xy, new_xy, pt, rf);
