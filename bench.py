@@ -38,7 +38,8 @@ ENVS_PER_GPU = 4096
 ENV_ID = "AntUMaze-v0"
 SETTLE_STEPS = 100             # untimed, before --warmup: the timed window is the settled regime whatever the caller's --warmup
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: fp32 VALU lane-operations per second
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+N_SIMD = 256 * 4                 # 256 CUs x 4 SIMDs
 
 
 def algo_bytes_per_env_step(m):
@@ -87,25 +88,33 @@ def pmc_traffic(vals):
     return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def valu_roofline(vals, kernel_ms):
-    """The informative roofline for this latency / VALU-bound path: how busy the vector pipes are and how
-    many of their lanes do work.  SQ_* cycle counters tick once per 4 shader cycles and are summed over the 1024 SIMDs;
-    SQ_THREAD_CYCLES_VALU counts active lanes x cycles."""
-    need = ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU")
-    if not all(k in vals for k in need):
-        return None
-    out = {"bound": "valu", "source": vals.get("_file"),
-           "valu_busy_frac": vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_BUSY_CYCLES"] if vals["SQ_BUSY_CYCLES"] else None,
-           "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
-           "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES (fraction of SIMD-cycles of the launch in which a vector instruction executes); "
-                   "active_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4)"}
-    if "SQ_THREAD_CYCLES_VALU" in vals and vals["SQ_ACTIVE_INST_VALU"]:
-        out["active_lane_frac"] = vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * vals["SQ_ACTIVE_INST_VALU"])
-    if kernel_ms and kernel_ms > 0 and "SQ_THREAD_CYCLES_VALU" in vals:
-        out["achieved_lane_ops_per_s"] = vals["SQ_THREAD_CYCLES_VALU"] / (kernel_ms * 1e-3)
-        out["peak_lane_ops_per_s"] = VALU_LANE_OPS_PER_S
-        out["frac"] = out["achieved_lane_ops_per_s"] / VALU_LANE_OPS_PER_S
-    return out
+def valu_roofline(vals, kernel_ms, env_steps_per_s, env_id):
+    """The informative roofline for this latency / VALU-bound path: how busy the vector pipes are, how
+    many of their lanes do work, and the measured floating-point work against the FP32 vector peak.
+    SQ_* cycle counters tick once per 4 shader cycles and are summed over the SIMDs; SQ_THREAD_CYCLES_VALU counts active
+    lanes in the same unit; GRBM_GUI_ACTIVE is summed over the 8 XCDs.  flops/env-step: tools/count_flops.py (gcov
+    execution counts of the float64 oracle x floating-point operators per line)."""
+    out = {"bound": "valu", "source": vals.get("_file")}
+    if "SQ_ACTIVE_INST_VALU" in vals and "SQ_INSTS_VALU" in vals:
+        launch_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 if "GRBM_GUI_ACTIVE" in vals else (kernel_ms or 0.0) * 1e-3 * 2.4e9
+        out.update({"valu_insts_per_launch": vals["SQ_INSTS_VALU"],
+                    "valu_busy_frac": 4.0 * vals["SQ_ACTIVE_INST_VALU"] / (N_SIMD * launch_cycles) if launch_cycles else None,
+                    "wait_frac_of_wave_life": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in vals and vals.get("SQ_WAVE_CYCLES") else None,
+                    "note": "valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x launch cycles): share of the launch in which a SIMD executes a vector "
+                            "instruction (tail included); active_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes enabled per vector instruction"})
+        if "SQ_THREAD_CYCLES_VALU" in vals and vals["SQ_ACTIVE_INST_VALU"]:
+            out["active_lane_frac"] = vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_ACTIVE_INST_VALU"])
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"flops_{env_id}.json")))
+    if files:
+        fl = json.load(open(files[-1]))
+        out["flops_per_env_step"] = fl["flops_per_env_step"]
+        out["flops_source"] = os.path.relpath(files[-1], ROOT) + " (float64 oracle formulation, gcov-counted)"
+        out["achieved"] = fl["flops_per_env_step"] * env_steps_per_s / 1e12
+        out["peak"] = FP32_VECTOR_PEAK_TFLOPS
+        out["unit"] = "TFLOP/s"
+        out["frac"] = out["achieved"] / FP32_VECTOR_PEAK_TFLOPS
+    return out if len(out) > 2 else None
 
 
 def cpu_baseline(model, env_id, n, lo, hi, seconds_target=12.0):
@@ -271,7 +280,7 @@ def main():
                          "traffic_source": "profiles/*/pmc_ant_step_kernel.csv: FETCH_SIZE + WRITE_SIZE (KB) of the committed rocprofv3 --pmc passes of this command, bytes per launch; not collected live",
                          "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},
         }
-        rv = valu_roofline(pmc, kernel_ms)
+        rv = valu_roofline(pmc, kernel_ms, n * args.steps / (kernel_ms * 1e-3 * args.steps) if kernel_ms > 0 else 0.0, env_id)
         if rv is not None:
             out["roofline_valu"] = rv
         if world == 1 and not args.no_cpu_baseline:
