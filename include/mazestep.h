@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZ_ABI_VERSION 3
+#define MZ_ABI_VERSION 4
 
 #define MZ_MAX_BODY 24
 #define MZ_MAX_JNT 24
@@ -208,6 +208,13 @@ typedef struct mz_model {
   int32_t nball, observe_balls;
   int32_t ball_bodyid[4];
   int32_t ball_geomid[4];
+
+  /* elevated mazes (Fall / MultiFall, maze_env.py:102-107,124-137): under every cell that is not a CHASM stands a platform
+   * box of the wall's footprint from z = 0 to z = height_offset (centre wall_half_z, half height wall_half_z); the walls
+   * stand on top of it (wall_center_z = wall_half_z + height_offset) and the robot's torso starts 0.75 above it.
+   * Movable blocks of such mazes slide along z as well (limited joints; block_bodyid / the joint arrays describe them). */
+  int32_t elevated, pad3;
+  double height_offset;
 } mz_model;
 
 typedef struct mz_handle mz_handle;

@@ -59,6 +59,11 @@ class VecMazeEnv:
             forward_reward_weight=kwargs.pop("forward_reward_weight", 1.0), ctrl_cost_weight=kwargs.pop("ctrl_cost_weight", 1e-4),
             manual_collision=model_cls.MANUAL_COLLISION, radius=model_cls.RADIUS, robot_xml=kwargs.pop("robot_xml", None))
         self.wrapped_cls = model_cls
+        from mujoco_maze_amd.model import device_unsupported_reason
+
+        why = device_unsupported_reason(self.model)
+        if why:
+            raise NotImplementedError(why)
         if not torch.cuda.is_available():
             raise _capi.MazeStepError("no GPU visible: mujoco_maze_amd steps environments on an MI355X only (no CPU fallback)")
         self._lib = _capi.load()

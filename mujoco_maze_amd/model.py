@@ -25,7 +25,7 @@ from mujoco_maze_amd import robots as R
 from mujoco_maze_amd.maze_env_utils import CollisionDetector, MazeCell
 from mujoco_maze_amd.maze_task import MazeTask, device_reward_descriptor
 
-MZ_ABI_VERSION = 3
+MZ_ABI_VERSION = 4
 MAX_BODY, MAX_JNT, MAX_DOF, MAX_Q, MAX_GEOM, MAX_ACT = 24, 24, 24, 28, 24, 8
 MAX_GRID, MAX_SEG, MAX_GOAL, MAX_OBS = 12, 96, 8, 48
 
@@ -74,6 +74,7 @@ class MzModel(C.Structure):
         ("forward_reward_weight", f64), ("ctrl_cost_weight", f64),
         ("nblock", i32), ("observe_blocks", i32), ("block_bodyid", i32 * 4), ("block_geomid", i32 * 4),
         ("nball", i32), ("observe_balls", i32), ("ball_bodyid", i32 * 4), ("ball_geomid", i32 * 4),
+        ("elevated", i32), ("pad3", i32), ("height_offset", f64),
     ]
 
 
@@ -223,6 +224,21 @@ class MazeWorld:
                 (imin - 0.5) * s - self.torso_y, (imax + 0.5) * s - self.torso_y)
 
 
+# ---------------------------------------------------------------- what the device kernels can step
+DEVICE_ELEVATED_ROBOTS = set()  # robots whose kernels handle elevated mazes (Fall / MultiFall): filled as kernels gain support
+
+
+def device_unsupported_reason(cm) -> Optional[str]:
+    """None when the HIP kernels can step this compiled model, else why not.  `compile_model` itself accepts every maze
+    the host mirror and the CPU oracle understand (so that exporters and oracle tests work); the device path is narrower."""
+    m = cm.c
+    robot = {v: k for k, v in ROBOT_ID.items()}[m.robot] if m.robot in ROBOT_ID.values() else "?"
+    if m.elevated and cm.spec.name not in DEVICE_ELEVATED_ROBOTS:
+        return (f"elevated mazes (Fall / MultiFall) are not on the device path for the {cm.spec.name} yet: platforms under the robot and "
+                "z-sliding blocks need kernel support (DESIGN.md section 8)")
+    return None
+
+
 # ---------------------------------------------------------------- compile
 class CompiledModel:
     """The `mz_model` struct plus host-side metadata the façade needs."""
@@ -259,8 +275,6 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         spec = mjcf.spec_from_mjcf(robot_xml, spec)
     structure = task.create_maze()
     world = MazeWorld(structure, scale, maze_height)
-    if world.elevated:
-        raise NotImplementedError("mazes with chasms (Fall / MultiFall) are not on the device path: see DESIGN.md section 8")
     balls = world.ball_cells()
     if balls and robot != "point":
         raise NotImplementedError("object balls on a free joint (AntSmallBilliard) are not on the device path: see DESIGN.md section 8")
@@ -269,8 +283,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     blocks = world.movable_cells()
     if balls and blocks:
         raise NotImplementedError("object balls together with movable blocks")
-    if any(cell is not MazeCell.XY_BLOCK for _, _, cell in blocks):
-        raise NotImplementedError("only XY_BLOCK movable blocks are supported (no z-moving / half / spin blocks yet)")
+    if any(cell.can_spin() or cell.is_half_block() for _, _, cell in blocks):
+        raise NotImplementedError("SPIN / half blocks are not supported (no registered task uses them)")
     if len(blocks) > 3:
         raise NotImplementedError("more than 3 movable blocks")
     if world.rows > MAX_GRID or world.cols > MAX_GRID:
@@ -299,16 +313,32 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         for gs in [spec.floor, spec.wall_geom_defaults] + [g for b in spec.bodies for g in b.geoms]:
             if not gs.explicit_solimp:
                 gs.solimp = stiff
+    if world.elevated:
+        # maze_env.py:102-107: the torso is lifted onto the platforms — for EVERY robot, the planar ones included
+        # (`torso.set("pos", f"0 0 {0.75 + height_offset:.2f}")`)
+        spec.bodies[0] = dataclasses.replace(spec.bodies[0], pos=(0.0, 0.0, float(f"{0.75 + world.height_offset:.2f}")))
     block_body_index = []
-    for (bi_, bj_, _cell) in blocks:
+    for (bi_, bj_, cell) in blocks:
+        # maze_env.py:563-660 (_add_movable_block).  "Falling" blocks (z-moving: XZ / YZ / XYZ) are shrunk to 99 %, weigh
+        # 1 g instead of 0.2 g and have LIMITED slides (x, y: +-scale; z: [-height_offset, 0]).  The body is placed at
+        # z = h — NOT h + height_offset: the reference passes height_offset but does not add it — so in an elevated maze
+        # a block spawns INSIDE the platform box of its own cell (DESIGN.md section 8 describes what follows from that).
         bx, by = world.cell_center(bi_, bj_)
-        half = world.scale * 0.5
+        falling = cell.can_move_z()
+        half = world.scale * 0.5 * (0.99 if falling else 1.0)
         geom = dataclasses.replace(spec.wall_geom_defaults, name=f"block_{bi_}_{bj_}", type=R.BOX, size=(half, half, world.half_z),
-                                   pos=(0.0, 0.0, 0.0), fromto=None, mass=0.0002, contype=1, conaffinity=1)
-        body = R.BodySpec(f"movable_{bi_}_{bj_}", -1, (bx, by, world.half_z + world.height_offset),
-                          joints=[R.JointSpec(f"movable_x_{bi_}_{bj_}", R.SLIDE, axis=(1.0, 0.0, 0.0), margin=0.01),
-                                  R.JointSpec(f"movable_y_{bi_}_{bj_}", R.SLIDE, axis=(0.0, 1.0, 0.0), margin=0.01)],
-                          geoms=[geom])
+                                   pos=(0.0, 0.0, 0.0), fromto=None, mass=0.001 if falling else 0.0002, contype=1, conaffinity=1)
+        joints = []
+        if cell.can_move_x():
+            joints.append(R.JointSpec(f"movable_x_{bi_}_{bj_}", R.SLIDE, axis=(1.0, 0.0, 0.0), margin=0.01, limited=falling,
+                                      range=(-world.scale, world.scale) if falling else (0.0, 0.0)))
+        if cell.can_move_y():
+            joints.append(R.JointSpec(f"movable_y_{bi_}_{bj_}", R.SLIDE, axis=(0.0, 1.0, 0.0), margin=0.01, limited=falling,
+                                      range=(-world.scale, world.scale) if falling else (0.0, 0.0)))
+        if cell.can_move_z():
+            joints.append(R.JointSpec(f"movable_z_{bi_}_{bj_}", R.SLIDE, axis=(0.0, 0.0, 1.0), margin=0.01, limited=True,
+                                      range=(-world.height_offset, 0.0)))
+        body = R.BodySpec(f"movable_{bi_}_{bj_}", -1, (bx, by, world.half_z), joints=joints, geoms=[geom])
         block_body_index.append(1 + len(spec.bodies))
         spec.bodies.append(body)
 
@@ -539,6 +569,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     for k, bidx in enumerate(block_body_index):
         m.block_bodyid[k] = bidx
         m.block_geomid[k] = next(gi for gi, (bb, _g) in enumerate(geoms) if bb == bidx)
+    m.elevated = int(world.elevated)
+    m.height_offset = world.height_offset
     m.nball = len(balls)
     m.observe_balls = int(bool(task.OBSERVE_BALLS))
     for k, bidx in enumerate(ball_body_index):

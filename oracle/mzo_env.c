@@ -128,20 +128,21 @@ void mzo_task_eval(const mz_model* m, const double* obs, double* reward, int* do
 void mzo_env_obs(const mz_model* m, const mzo_env_state* s, double* obs) {
   int k = 0;
   for (int i = 0; i < 3; i++) obs[k++] = s->qpos[i];
-  if (m->observe_balls) /* balls come before blocks (maze_env.py:360-363); get_body_com = body frame origin: z stays 0 */
-    for (int b = 0; b < m->nball; b++) {
-      int body = m->ball_bodyid[b], j0 = m->body_jntadr[body];
-      obs[k++] = m->body_pos[body][0] + s->qpos[m->jnt_qposadr[j0]] - m->qpos0[m->jnt_qposadr[j0]];
-      obs[k++] = m->body_pos[body][1] + s->qpos[m->jnt_qposadr[j0 + 1]] - m->qpos0[m->jnt_qposadr[j0 + 1]];
-      obs[k++] = m->body_pos[body][2];
+  /* get_body_com = the body's frame origin: spawn position + its slide coordinates along their axes (maze_env.py:360-368);
+   * balls come before blocks; a ball's z stays 0 (hinge flavour: x / y slides and a z hinge) */
+  for (int pass = 0; pass < 2; pass++) {
+    int n = pass == 0 ? (m->observe_balls ? m->nball : 0) : (m->observe_blocks ? m->nblock : 0);
+    for (int b = 0; b < n; b++) {
+      int body = pass == 0 ? m->ball_bodyid[b] : m->block_bodyid[b];
+      double p[3] = {m->body_pos[body][0], m->body_pos[body][1], m->body_pos[body][2]};
+      for (int j = m->body_jntadr[body]; j < m->body_jntadr[body] + m->body_jntnum[body]; j++)
+        if (m->jnt_type[j] == MZ_JNT_SLIDE) {
+          double q = s->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
+          for (int c = 0; c < 3; c++) p[c] += m->jnt_axis[j][c] * q;
+        }
+      for (int c = 0; c < 3; c++) obs[k++] = p[c];
     }
-  if (m->observe_blocks) /* body xpos of every movable block (maze_env.py:364-368); XY blocks only translate */
-    for (int b = 0; b < m->nblock; b++) {
-      int body = m->block_bodyid[b], j0 = m->body_jntadr[body];
-      obs[k++] = m->body_pos[body][0] + s->qpos[m->jnt_qposadr[j0]] - m->qpos0[m->jnt_qposadr[j0]];
-      obs[k++] = m->body_pos[body][1] + s->qpos[m->jnt_qposadr[j0 + 1]] - m->qpos0[m->jnt_qposadr[j0 + 1]];
-      obs[k++] = m->body_pos[body][2];
-    }
+  }
   for (int i = 3; i < m->nq_robot; i++) obs[k++] = s->qpos[i];
   for (int i = 0; i < m->nv_robot; i++) obs[k++] = s->qvel[i];
   obs[k++] = s->t * 0.001; /* maze_env.py:369 */

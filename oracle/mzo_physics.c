@@ -705,6 +705,7 @@ static void collide_walls(const mz_model* m, mzo_data* d, int g) {
   double s = m->maze_scale, reach = m->geom_rbound[g] + pp.margin;
   const double* gp = d->geom_xpos[g];
   if (gp[2] - reach > m->wall_center_z + m->wall_half_z) return;
+  if (!m->elevated && gp[2] + reach < m->wall_center_z - m->wall_half_z) return;
   int j0 = (int)floor((gp[0] - reach + m->torso_x) / s + 0.5), j1 = (int)floor((gp[0] + reach + m->torso_x) / s + 0.5);
   int i0 = (int)floor((gp[1] - reach + m->torso_y) / s + 0.5), i1 = (int)floor((gp[1] + reach + m->torso_y) / s + 0.5);
   static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -712,25 +713,31 @@ static void collide_walls(const mz_model* m, mzo_data* d, int g) {
   for (int i = i0; i <= i1; i++)
     for (int j = j0; j <= j1; j++) {
       if (i < 0 || j < 0 || i >= m->grid_rows || j >= m->grid_cols) continue;
-      if (m->grid[i][j] != MZ_CELL_BLOCK) continue;
-      double bpos[3] = {j * s - m->torso_x, i * s - m->torso_y, m->wall_center_z};
-      if (m->geom_type[g] == MZ_GEOM_SPHERE) {
-        double dist, pos[3], nrm[3];
-        if (sphere_box(gp, m->geom_size[g][0], bpos, ident, bsize, pp.margin, &dist, pos, nrm))
-          add_contact(d, &pp, dist, pos, nrm, NULL);
-      } else if (m->geom_type[g] == MZ_GEOM_CAPSULE) {
-        capsule_box(d, &pp, gp, d->geom_xmat[g], m->geom_size[g][0], m->geom_size[g][1], bpos, ident, bsize);
-      } else if (m->geom_type[g] == MZ_GEOM_BOX && is_block_geom(m, g) && is_axis_aligned(d->geom_xmat[g])) {
-        /* wall geoms precede the movable bodies' geoms in MuJoCo's geom order: geom1 = wall, geom2 = block */
-        pairparam q = pp;
-        q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
-        box_box_aligned(d, &q, bpos, bsize, gp, m->geom_size[g]);
-      } else if (m->geom_type[g] == MZ_GEOM_BOX && fabs(d->geom_xmat[g][8] - 1.0) < 1e-12) {
-        pairparam q = pp; /* box rotated about z only (the Point's arrow) */
-        q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
-        box_zrot_vs_aabb(d, &q, bpos, bsize, gp, d->geom_xmat[g], m->geom_size[g], 0);
-      } else {
-        d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* generally rotated box vs box: not restated */
+      /* per cell, in the order the reference emits the geoms (maze_env.py:124-152): the platform of an elevated maze
+       * (every cell but the chasms; z from 0 to height_offset), then the wall block standing on it */
+      for (int layer = 0; layer < 2; layer++) {
+        if (layer == 0 && !(m->elevated && m->grid[i][j] != MZ_CELL_CHASM)) continue;
+        if (layer == 1 && m->grid[i][j] != MZ_CELL_BLOCK) continue;
+        double bpos[3] = {j * s - m->torso_x, i * s - m->torso_y, layer == 0 ? m->wall_half_z : m->wall_center_z};
+        if (gp[2] - reach > bpos[2] + m->wall_half_z || gp[2] + reach < bpos[2] - m->wall_half_z) continue;
+        if (m->geom_type[g] == MZ_GEOM_SPHERE) {
+          double dist, pos[3], nrm[3];
+          if (sphere_box(gp, m->geom_size[g][0], bpos, ident, bsize, pp.margin, &dist, pos, nrm))
+            add_contact(d, &pp, dist, pos, nrm, NULL);
+        } else if (m->geom_type[g] == MZ_GEOM_CAPSULE) {
+          capsule_box(d, &pp, gp, d->geom_xmat[g], m->geom_size[g][0], m->geom_size[g][1], bpos, ident, bsize);
+        } else if (m->geom_type[g] == MZ_GEOM_BOX && is_block_geom(m, g) && is_axis_aligned(d->geom_xmat[g])) {
+          /* wall geoms precede the movable bodies' geoms in MuJoCo's geom order: geom1 = wall, geom2 = block */
+          pairparam q = pp;
+          q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
+          box_box_aligned(d, &q, bpos, bsize, gp, m->geom_size[g]);
+        } else if (m->geom_type[g] == MZ_GEOM_BOX && fabs(d->geom_xmat[g][8] - 1.0) < 1e-12) {
+          pairparam q = pp; /* box rotated about z only (the Point's arrow) */
+          q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
+          box_zrot_vs_aabb(d, &q, bpos, bsize, gp, d->geom_xmat[g], m->geom_size[g], 0);
+        } else {
+          d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* generally rotated box vs box: not restated */
+        }
       }
     }
 }

