@@ -41,6 +41,10 @@ struct MazeDev {
   int rows, cols;
   uint32_t rowmask[MZ_MAX_GRID];  // bit j set <=> cell (i, j) is a BLOCK
   float scale, tx, ty, half_xy, half_z, center_z;
+  // elevated mazes (Fall / MultiFall): a platform box (same footprint, z from 0 to 2 half_z, centre half_z) under every cell
+  // of the grid that is not a CHASM; the walls stand on top (center_z = half_z + height offset)
+  int elevated;
+  uint32_t platmask[MZ_MAX_GRID];  // bit j set <=> cell (i, j) carries a platform
 };
 
 struct AntDev {
@@ -118,6 +122,10 @@ static inline void maze_dev_from_model(MazeDev* z, const mz_model* m) {
   for (int i = 0; i < m->grid_rows; i++)
     for (int j = 0; j < m->grid_cols; j++)
       if (m->grid[i][j] == MZ_CELL_BLOCK) z->rowmask[i] |= (1u << j);
+  z->elevated = m->elevated;
+  for (int i = 0; i < m->grid_rows && m->elevated; i++)
+    for (int j = 0; j < m->grid_cols; j++)
+      if (m->grid[i][j] != MZ_CELL_CHASM) z->platmask[i] |= (1u << j);
   z->scale = (float)m->maze_scale; z->tx = (float)m->torso_x; z->ty = (float)m->torso_y;
   z->half_xy = (float)m->wall_half_xy; z->half_z = (float)m->wall_half_z; z->center_z = (float)m->wall_center_z;
 }

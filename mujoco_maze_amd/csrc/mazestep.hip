@@ -83,7 +83,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * h->lay.rec * sizeof(float));
   } else {
     const int kq = mzk_planar_state_width(h);
-    const int nb3 = h->robot == MZ_ROBOT_SWIMMER ? (h->swimmer.observe_blocks ? 3 * h->swimmer.nblock : 0)
+    const int nb3 = h->robot == MZ_ROBOT_SWIMMER ? ((h->swimmer.observe_blocks && h->swimmer.nblock) ? 3 : 0)
                                                  : (h->point.observe_blocks ? 3 * h->point.nblock : 0) + (h->point.observe_balls ? 3 * h->point.nball : 0);
     const int want = h->robot == MZ_ROBOT_SWIMMER ? 2 * kq + 1 + nb3 : 7 + nb3;
     if (want != model->obs_dim || want > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }

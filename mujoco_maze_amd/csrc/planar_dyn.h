@@ -27,9 +27,11 @@ struct PlanarDims {
   static_assert(NS <= 1, "one object ball");
   static constexpr int NV = 3 + 2 * NB + 3 * NS;  // robot x, y, theta | block x, y ... | ball x, y, spin
   static constexpr int NC = NB == 0 ? 12 + 4 * NS : (NB == 1 ? 40 : (NB == 2 ? 64 : 96));  // contact slots
-  // enumerators: 9 sphere-wall, 9 arrow-wall | per block: sphere-block, arrow-block, 9 block-wall | block pairs |
-  //              per ball: 9 ball-wall, robot sphere-ball, ball-arrow
-  static constexpr int NE = 18 + 11 * NB + NB * (NB - 1) / 2 + 11 * NS;
+  // enumerators: 9 sphere-wall, 9 arrow-wall | per block: sphere-block, arrow-block, 9 block-wall, 9 block-platform (elevated
+  //              mazes), block-floor, 2 joint-limit rows (limited slides) | block pairs | per ball: 9 ball-wall, robot
+  //              sphere-ball, ball-arrow
+  static constexpr int EPB = 23;  // enumerators per block
+  static constexpr int NE = 18 + EPB * NB + NB * (NB - 1) / 2 + 11 * NS;
   static constexpr int NOBS = 7 + 3 * NB + 3 * NS;
 };
 
@@ -57,10 +59,14 @@ MZP_HD double pl_mass(const PointDev& P, const double M3[3][3], int i, int j) {
 }
 template <int NB, int NS>
 MZP_HD void pl_block_center(const PointDev& P, const PlanarScratch<NB, NS>& s, int b, double* c) {
-  c[0] = P.block_pos0[b][0] + s.q[3 + 2 * b]; c[1] = P.block_pos0[b][1] + s.q[4 + 2 * b]; c[2] = P.block_pos0[b][2];
+  c[0] = P.block_pos0[b][0]; c[1] = P.block_pos0[b][1]; c[2] = P.block_pos0[b][2];
+  const double q0 = s.q[3 + 2 * b], q1 = s.q[4 + 2 * b];  // the block's two slides, along block_axis[0] < block_axis[1]
+  if (P.block_axis[0] == 0) c[0] += q0; else c[1] += q0;
+  if (P.block_axis[1] == 1) c[1] += q1; else c[2] += q1;
 }
 
 // One contact candidate: dist, position, normal (geom1 -> geom2), bodies (-1 world, 0 robot, 1 + k block k)
+// cls 6: joint-limit row of a block slide — a single frictionless row (n = +- the slide axis, pos unused)
 struct PlContact { double dist, pos[3], n[3]; int b1, b2, cls; };
 
 // sphere (centre c relative to the box centre) vs axis-aligned box; normal from the sphere to the box
@@ -171,6 +177,19 @@ MZP_HD bool pl_wall_cell(const MazeDev& z, double x, double y, int k9, double* w
   return true;
 }
 
+// platform cell of an elevated maze in the 3 x 3 neighbourhood of the cell under (x, y): every cell that is not a chasm
+MZP_HD bool pl_platform_cell(const MazeDev& z, double x, double y, int k9, double* wc) {
+  int jc = (int)floor((x + z.tx) / z.scale + 0.5), ic = (int)floor((y + z.ty) / z.scale + 0.5);
+  int i = ic + k9 / 3 - 1, j = jc + k9 % 3 - 1;
+  if (!z.elevated || i < 0 || j < 0 || i >= z.rows || j >= z.cols) return false;
+  uint32_t row = 0u;
+#pragma unroll
+  for (int r = 0; r < MZ_MAX_GRID; r++) row = (r == i) ? z.platmask[r] : row;
+  if (!((row >> j) & 1u)) return false;
+  wc[0] = j * (double)z.scale - z.tx; wc[1] = i * (double)z.scale - z.ty; wc[2] = z.half_z;
+  return true;
+}
+
 // Contacts of enumerator e, in a fixed order (identical in the count and the fill pass)
 template <int NB, int NS, class Emit>
 MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, int e, Emit&& emit) {
@@ -235,8 +254,9 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, i
   }
   if constexpr (NB > 0) {
     int r = e - 18;
-    if (r < 11 * NB) {
-      int b = r / 11, k = r - 11 * b;
+    constexpr int EPB = PlanarDims<NB, NS>::EPB;
+    if (r < EPB * NB) {
+      int b = r / EPB, k = r - EPB * b;
       double bc[3];
       pl_block_center<NB, NS>(P, s, b, bc);
       if (k == 0) {         // sphere (geom1) vs block (geom2)
@@ -251,15 +271,43 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, i
         emit(ct);
       } else if (k == 1) {  // arrow (geom1) vs block (geom2)
         pl_arrow_box(P, arrow, s.co, s.si, bc, P.block_half, P.pair[1].margin, true, 0, 1 + b, 1, emit);
-      } else {              // wall (geom1) vs block (geom2)
+      } else if (k < 11) {  // wall (geom1) vs block (geom2)
         double wc[3];
         if (!pl_wall_cell(z, bc[0], bc[1], k - 2, wc)) return;
         pl_box_box(wc, wh, bc, P.block_half, P.pair[2].margin, -1, 1 + b, 2, emit);
+      } else if (k < 20) {  // platform of an elevated maze (geom1) vs block (geom2): same box rule, same pair class as a wall
+        double wc[3];
+        if (!pl_platform_cell(z, bc[0], bc[1], k - 11, wc)) return;
+        pl_box_box(wc, wh, bc, P.block_half, P.pair[2].margin, -1, 1 + b, 2, emit);
+      } else if (k == 20) {  // floor plane z = 0 (geom1) vs block (geom2): the corners below the plane, normal +z
+        if (P.block_axis[1] != 2) return;  // a block without a z slide rests on the floor at dist = 0 exactly: never a contact
+        for (int ci = 0; ci < 4; ci++) {
+          PlContact c;
+          c.dist = bc[2] - P.block_half[2];
+          c.n[0] = 0.0; c.n[1] = 0.0; c.n[2] = 1.0;
+          c.pos[0] = bc[0] + ((ci & 1) ? P.block_half[0] : -P.block_half[0]); c.pos[1] = bc[1] + ((ci & 2) ? P.block_half[1] : -P.block_half[1]);
+          c.pos[2] = 0.5 * c.dist;
+          c.b1 = -1; c.b2 = 1 + b; c.cls = 7;
+          emit(c);
+        }
+      } else {              // joint-limit row of slide k - 21 (maze_env.py:607-648: limited slides of falling blocks)
+        if (!P.block_limited) return;
+        const int a = k - 21;
+        const double q = s.q[3 + 2 * b + a];
+        for (int side = -1; side <= 1; side += 2) {
+          PlContact c;
+          c.dist = side < 0 ? q - P.block_lo[a] : P.block_hi[a] - q;
+          c.n[0] = c.n[1] = c.n[2] = 0.0;
+          c.n[P.block_axis[a]] = -(double)side;  // the row's Jacobian: d dist / d q
+          c.pos[0] = c.pos[1] = c.pos[2] = 0.0;
+          c.b1 = -1; c.b2 = 1 + b; c.cls = 6;
+          emit(c);
+        }
       }
       return;
     }
     if constexpr (NB > 1) {  // block pairs (a < b): geom1 = block a, geom2 = block b
-      int p = r - 11 * NB, a = 0, b = 1;
+      int p = r - EPB * NB, a = 0, b = 1;
       if (p == 1) { a = 0; b = 2; } else if (p == 2) { a = 1; b = 2; }
       if (b < NB) {
         double ca[3], cb[3];
@@ -283,7 +331,7 @@ MZP_HD void pl_add_body_row(const PointDev& P, const PlanarScratch<NB, NS>& s, i
       J[3] += sgn * f[0]; J[4] += sgn * f[1]; J[5] += sgn * (-f[0] * ry + f[1] * rx);
     }
     for (int b = 0; b < NB; b++)
-      if (b == body - 1) { J[3 + 2 * b] += sgn * f[0]; J[4 + 2 * b] += sgn * f[1]; }
+      if (b == body - 1) { J[3 + 2 * b] += sgn * (P.block_axis[0] == 0 ? f[0] : f[1]); J[4 + 2 * b] += sgn * (P.block_axis[1] == 1 ? f[1] : f[2]); }
   }
 }
 
@@ -292,6 +340,23 @@ MZP_HD void planar_fill_contact(const PointDev& P, PlanarScratch<NB, NS>& s, int
   constexpr int NV = PlanarDims<NB, NS>::NV;
   const PtPair& pr = P.pair[c.cls];
   const double* n = c.n;
+  if (c.cls == 6) {
+    // joint-limit row: ONE frictionless row  r = J a - aref, cost D/2 min(0, r)^2.  It rides the contact machinery as a
+    // pyramid whose tangential Jacobians vanish: the four edge rows then coincide (u0 +- 0), so cD = D / 4 reproduces
+    // exactly cost, gradient and curvature of the single row.
+    double imp = pt_impedance(pr.solimp, fabs(c.dist - pr.margin));
+    double R = fmax(1e-15, (1.0 - imp) / imp * pr.wsum);
+    s.cD[slot] = 0.25 / R;
+    for (int a = 0; a < 3; a++) {
+      double J[NV];
+      for (int i = 0; i < NV; i++) J[i] = 0.0;
+      if (a == 0) pl_add_body_row<NB, NS>(P, s, c.b2, n, c.pos, 1.0, J);
+      double vel = 0.0;
+      for (int i = 0; i < NV; i++) { s.cJ[slot][a][i] = J[i]; vel += J[i] * s.v[i]; }
+      s.caref[slot][a] = a == 0 ? -pr.B * vel - pr.K * imp * (c.dist - pr.margin) : 0.0;
+    }
+    return;
+  }
   double y[3] = {0.0, (n[1] < 0.5 && n[1] > -0.5) ? 1.0 : 0.0, 0.0};
   y[2] = 1.0 - y[1];
   double dt = n[0] * y[0] + n[1] * y[1] + n[2] * y[2];
@@ -337,6 +402,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     s.co = co; s.si = si;
     s.qas[0] = P.com_x * w2 * co; s.qas[1] = P.com_x * w2 * si; s.qas[2] = 0.0;
     for (int i = 3; i < NV; i++) s.qas[i] = 0.0;
+    if (P.block_axis[1] == 2) { for (int b = 0; b < NB; b++) s.qas[4 + 2 * b] = P.gz; }  // falling blocks: gravity on the z slide
     s.M3[0][0] = P.mass; s.M3[0][1] = 0.0; s.M3[0][2] = -mc * si;
     s.M3[1][0] = 0.0; s.M3[1][1] = P.mass; s.M3[1][2] = mc * co;
     s.M3[2][0] = -mc * si; s.M3[2][1] = mc * co; s.M3[2][2] = P.izz;
@@ -546,7 +612,10 @@ MZP_HD float planar_obs_elem(const PointDev& P, const PlanarScratch<NB, NS>& s, 
   }
   if (i < 3 + nb3) {
     int b = (i - 3) / 3, c = (i - 3) % 3;
-    return (float)(c == 2 ? P.block_pos0[b][2] : P.block_pos0[b][c] + s.q[3 + 2 * b + c]);
+    double v = P.block_pos0[b][c];
+    if (c == P.block_axis[0]) v += s.q[3 + 2 * b];
+    if (c == P.block_axis[1]) v += s.q[4 + 2 * b];
+    return (float)v;
   }
   if (i < 6 + nb3) return (float)s.v[i - 3 - nb3];
   return (float)t * 0.001f;

@@ -118,9 +118,10 @@ __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, cons
       o[5] = (float)Pp->ball_pos0[2];
     }
     for (int b = 0; b < NB && nb3; b++) {
-      o[3 + 3 * b] = (float)Pp->block_pos0[b][0] + S.qv[(size_t)(3 + 2 * b) * n + env];
-      o[4 + 3 * b] = (float)Pp->block_pos0[b][1] + S.qv[(size_t)(4 + 2 * b) * n + env];
-      o[5 + 3 * b] = (float)Pp->block_pos0[b][2];
+      float p3[3] = {(float)Pp->block_pos0[b][0], (float)Pp->block_pos0[b][1], (float)Pp->block_pos0[b][2]};
+      p3[Pp->block_axis[0]] += S.qv[(size_t)(3 + 2 * b) * n + env];
+      p3[Pp->block_axis[1]] += S.qv[(size_t)(4 + 2 * b) * n + env];
+      o[3 + 3 * b] = p3[0]; o[4 + 3 * b] = p3[1]; o[5 + 3 * b] = p3[2];
     }
     o[6 + nb3] = (float)S.t[env] * 0.001f;
   }
@@ -148,8 +149,8 @@ __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* 
   if (t) t[env] = S.t[env];
 }
 
-// ------------------------------------------------------------------ Swimmer / Reacher kernels (NL links, NB movable blocks;
-// SoA: q0..q[NV-1] v0..v[NV-1] | t | episode with NV = NL + 2 + 2 NB)
+// ------------------------------------------------------------------ Swimmer / Reacher kernels (NL links, one movable block with BD
+// slide dofs: 0 none, 2 or 3; SoA: q0..q[NV-1] v0..v[NV-1] | t | episode with NV = NL + 2 + BD)
 //
 // Observation / reset layout: swimmer_dyn.h (swimmer_obs_row).  Reset (swimmer.py:56-69): U(-0.1, 0.1) noise on ALL nq
 // coordinates and ALL nv velocities, the block's included.
@@ -162,10 +163,10 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
                                                             float* __restrict__ final_obs) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
-  constexpr int NR = NL + 2, NV = NR + 2 * NB, NH = NL - 1;
+  constexpr int NR = NL + 2, NV = NR + NB, NH = NL - 1;  // NB: slide dofs of the movable block
   const SwimmerDev& P = *Pp;
-  const int nb3 = P.observe_blocks ? 3 * NB : 0, NO = 2 * NV + 1 + nb3;
-  float qf[NV], vf[NV], af[NH > 0 ? NH : 1], o[2 * NV + 1 + 3 * NB];
+  const int nb3 = (NB && P.observe_blocks) ? 3 : 0, NO = 2 * NV + 1 + nb3;
+  float qf[NV], vf[NV], af[NH > 0 ? NH : 1], o[2 * NV + 4];
   double inner, inf4[4];
   for (int k = 0; k < NV; k++) { qf[k] = S.qv[(size_t)k * n + env]; vf[k] = S.qv[(size_t)(NV + k) * n + env]; }
   for (int k = 0; k < NH; k++) af[k] = actions[(size_t)env * NH + k];
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
 
 template <int NL, int NB>
 __global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
-  constexpr int NR = NL + 2, NV = NR + 2 * NB;
+  constexpr int NR = NL + 2, NV = NR + NB;
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   if (!mask || mask[env]) {
@@ -217,8 +218,8 @@ __global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, 
     S.ep[env] = 0;
   }
   if (obs) {
-    const int nb3 = Pp->observe_blocks ? 3 * NB : 0, NO = 2 * NV + 1 + nb3;
-    float qf[NV], vf[NV], o[2 * NV + 1 + 3 * NB];
+    const int nb3 = (NB && Pp->observe_blocks) ? 3 : 0, NO = 2 * NV + 1 + nb3;
+    float qf[NV], vf[NV], o[2 * NV + 4];
     for (int k = 0; k < NV; k++) { qf[k] = S.qv[(size_t)k * n + env]; vf[k] = S.qv[(size_t)(NV + k) * n + env]; }
     swimmer_obs_row<NL, NB>(*Pp, qf, vf, S.t[env], o);
     for (int k = 0; k < NO; k++) obs[(size_t)env * NO + k] = o[k];
@@ -259,7 +260,7 @@ __global__ void point_detect_kernel(const PointDev* __restrict__ Pp, int n, cons
 
 // ------------------------------------------------------------------ entry points of this translation unit (mz_internal.h)
 int mzk_planar_state_width(const mz_handle* h) {
-  return h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + 2 * h->swimmer.nblock : 3 + 2 * h->point.nblock + 3 * h->point.nball;
+  return h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + (h->swimmer.nblock ? h->swimmer.nbdof : 0) : 3 + 2 * h->point.nblock + 3 * h->point.nball;
 }
 
 hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
@@ -269,8 +270,9 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
 #define MZ_SW_STEP(NL, NB)                                                                                                          \
   hipLaunchKernelGGL((swimmer_step_kernel<NL, NB>), dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev, \
                      reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs)
-    if (h->swimmer.nlink == 3) { if (h->swimmer.nblock) MZ_SW_STEP(3, 1); else MZ_SW_STEP(3, 0); }
-    else { if (h->swimmer.nblock) MZ_SW_STEP(2, 1); else MZ_SW_STEP(2, 0); }
+    const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
+    if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_STEP(3, 3); else if (bd == 2) MZ_SW_STEP(3, 2); else MZ_SW_STEP(3, 0); }
+    else { if (bd == 3) MZ_SW_STEP(2, 3); else if (bd == 2) MZ_SW_STEP(2, 2); else MZ_SW_STEP(2, 0); }
 #undef MZ_SW_STEP
     return hipGetLastError();
   }
@@ -298,8 +300,9 @@ hipError_t mzk_planar_reset(mz_handle* h, hipStream_t st, const uint8_t* mask_de
   const int nb = (h->n + 255) / 256;
   if (h->robot == MZ_ROBOT_SWIMMER) {
 #define MZ_SW_RESET(NL, NB) hipLaunchKernelGGL((swimmer_reset_kernel<NL, NB>), dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev)
-    if (h->swimmer.nlink == 3) { if (h->swimmer.nblock) MZ_SW_RESET(3, 1); else MZ_SW_RESET(3, 0); }
-    else { if (h->swimmer.nblock) MZ_SW_RESET(2, 1); else MZ_SW_RESET(2, 0); }
+    const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
+    if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_RESET(3, 3); else if (bd == 2) MZ_SW_RESET(3, 2); else MZ_SW_RESET(3, 0); }
+    else { if (bd == 3) MZ_SW_RESET(2, 3); else if (bd == 2) MZ_SW_RESET(2, 2); else MZ_SW_RESET(2, 0); }
 #undef MZ_SW_RESET
     return hipGetLastError();
   }
@@ -322,6 +325,7 @@ hipError_t mzk_planar_set_state(mz_handle* h, hipStream_t st, const float* qpos_
     case 5: hipLaunchKernelGGL(point_set_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
     case 6: hipLaunchKernelGGL(point_set_state_kernel<6>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
     case 7: hipLaunchKernelGGL(point_set_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
+    case 8: hipLaunchKernelGGL(point_set_state_kernel<8>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
     default: hipLaunchKernelGGL(point_set_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
   }
   return hipGetLastError();
@@ -336,6 +340,7 @@ hipError_t mzk_planar_get_state(mz_handle* h, hipStream_t st, float* qpos_dev, f
     case 5: hipLaunchKernelGGL(point_get_state_kernel<5>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
     case 6: hipLaunchKernelGGL(point_get_state_kernel<6>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
     case 7: hipLaunchKernelGGL(point_get_state_kernel<7>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
+    case 8: hipLaunchKernelGGL(point_get_state_kernel<8>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
     default: hipLaunchKernelGGL(point_get_state_kernel<9>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
   }
   return hipGetLastError();

@@ -40,10 +40,13 @@ struct PointDev {
   // 4 ball-wall, 5 robot-ball
   double mass, izz, inv_scale;
   double sph_r, sph_z, arr_off, arr_hx, arr_hy, arr_hz, arr_z;
-  PtPair pair[6];
+  PtPair pair[8];  // + 6 joint-limit rows of a block's slides (margin = joint margin), 7 floor plane vs block
   // movable XY blocks (maze_env.py:563-660), all of one size
   int nblock, observe_blocks;
   double block_mass, block_half[3], block_pos0[3][3];
+  // the two slide axes of a block: (x, y) in the Push family, (y, z) — limited, the z slide under gravity — in Fall mazes
+  int block_axis[2], block_limited;
+  double block_lo[2], block_hi[2], gz;
   // object ball (Billiard, maze_env.py:489-536): slide-x + slide-y + z hinge body, sphere of radius ball_r at height ball_r
   int nball, observe_balls;
   double ball_mass, ball_izz, ball_r, ball_pos0[3];
@@ -80,9 +83,9 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
   p->inv_scale = 1.0 / (m->meaninertia * m->nv);
   if (m->ngeom != 3 + nb + ns || m->geom_type[1] != MZ_GEOM_SPHERE || m->geom_type[2] != MZ_GEOM_BOX)
     return ant_fail(err, errlen, "point kernel: expected floor + sphere + arrow box (+ block) geoms");
-  p->sph_r = m->geom_size[1][0]; p->sph_z = m->geom_pos[1][2];
+  p->sph_r = m->geom_size[1][0]; p->sph_z = m->body_pos[1][2] + m->geom_pos[1][2];  // torso body height: 0, or 0.75 + platform height in elevated mazes
   p->arr_off = m->geom_pos[2][0]; p->arr_hx = m->geom_size[2][0]; p->arr_hy = m->geom_size[2][1]; p->arr_hz = m->geom_size[2][2];
-  p->arr_z = m->geom_pos[2][2];
+  p->arr_z = m->body_pos[1][2] + m->geom_pos[2][2];
   for (int k = 0; k < 5; k++)
     if (m->geom_solimp[1][k] != m->geom_solimp[2][k]) return ant_fail(err, errlen, "point kernel: sphere and arrow must share contact parameters");
   if (m->geom_margin[1] != m->geom_margin[2] || m->geom_margin[0] != 0.0 || m->geom_margin[1] != 0.0)
@@ -91,12 +94,25 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
   pt_mix_pair(&p->pair[0], m->timestep, m->geom_margin[1], m->wall_margin, m->geom_friction[1], m->wall_friction, m->geom_solref[1],
               m->wall_solref, m->geom_solimp[1], m->wall_solimp, bw_robot);
   p->nblock = nb; p->observe_blocks = m->observe_blocks;
+  p->gz = m->gravity[2];
   for (int k = 0; k < nb; k++) {
     int b = m->block_bodyid[k], g = m->block_geomid[k], j0 = m->body_jntadr[b];
+    int ax[2] = {-1, -1};
+    for (int a = 0; a < 2 && m->body_jntnum[b] == 2; a++)
+      for (int c = 0; c < 3; c++) if (fabs(m->jnt_axis[j0 + a][c] - 1.0) < 1e-12) ax[a] = c;
     if (m->body_jntnum[b] != 2 || m->jnt_type[j0] != MZ_JNT_SLIDE || m->jnt_type[j0 + 1] != MZ_JNT_SLIDE || m->geom_type[g] != MZ_GEOM_BOX ||
-        fabs(m->jnt_axis[j0][0] - 1.0) > 1e-12 || fabs(m->jnt_axis[j0 + 1][1] - 1.0) > 1e-12 || m->body_dofadr[b] != 3 + 2 * k ||
-        m->jnt_limited[j0] || m->jnt_limited[j0 + 1] || m->geom_margin[g] != 0.0)
-      return ant_fail(err, errlen, "point kernel: movable block is not an unlimited slide-x / slide-y box body with margin 0");
+        ax[0] < 0 || ax[1] <= ax[0] || m->body_dofadr[b] != 3 + 2 * k || m->jnt_limited[j0] != m->jnt_limited[j0 + 1] || m->geom_margin[g] != 0.0 ||
+        (k > 0 && (ax[0] != p->block_axis[0] || ax[1] != p->block_axis[1] || m->jnt_limited[j0] != p->block_limited)))
+      return ant_fail(err, errlen, "point kernel: a movable block is a box body with two slides along increasing coordinate axes (x y, y z or x z), margin 0");
+    p->block_axis[0] = ax[0]; p->block_axis[1] = ax[1]; p->block_limited = m->jnt_limited[j0];
+    for (int a = 0; a < 2; a++) { p->block_lo[a] = m->jnt_range[j0 + a][0]; p->block_hi[a] = m->jnt_range[j0 + a][1]; }
+    if (p->block_limited) {  // limit rows: one-sided single rows with the joint's solref / solimp and margin; R from dof_invweight0
+      PtPair* q = &p->pair[6];
+      double tc = fmax(m->jnt_solref[j0][0], 2.0 * m->timestep), dmax = m->jnt_solimp[j0][1];
+      q->margin = m->jnt_margin[j0]; q->mu = 0.0; q->K = 1.0 / (dmax * dmax * tc * tc * m->jnt_solref[j0][1] * m->jnt_solref[j0][1]);
+      q->B = 2.0 / (dmax * tc); q->wsum = m->dof_invweight0[m->jnt_dofadr[j0]];
+      for (int c = 0; c < 5; c++) q->solimp[c] = m->jnt_solimp[j0][c];
+    }
     for (int q = 0; q < 3; q++) { p->block_pos0[k][q] = m->body_pos[b][q]; p->block_half[q] = m->geom_size[g][q]; }
     p->block_mass = m->body_mass[b];
     if (k > 0 && (m->geom_size[g][0] != m->geom_size[m->block_geomid[0]][0] || m->body_mass[b] != m->body_mass[m->block_bodyid[0]]))
@@ -111,6 +127,8 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
                 m->geom_solref[g], m->wall_solimp, m->geom_solimp[g], bw_block);
     pt_mix_pair(&p->pair[3], m->timestep, m->geom_margin[g], m->geom_margin[g], m->geom_friction[g], m->geom_friction[g], m->geom_solref[g],
                 m->geom_solref[g], m->geom_solimp[g], m->geom_solimp[g], 2.0 * bw_block);
+    pt_mix_pair(&p->pair[7], m->timestep, m->geom_margin[0], m->geom_margin[g], m->geom_friction[0], m->geom_friction[g], m->geom_solref[0],
+                m->geom_solref[g], m->geom_solimp[0], m->geom_solimp[g], bw_block);
   }
   p->nball = ns; p->observe_balls = m->observe_balls;
   if (ns > 0) {
@@ -136,6 +154,13 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
     if (r > p->reach) p->reach = r;
   }
   if (p->reach >= m->maze_scale) return ant_fail(err, errlen, "point kernel: maze cells must be wider than the robot's reach");
+  if (m->elevated) {
+    // the robot has no z dof: lifted with the torso (maze_env.py:102-107) it hovers above the platforms and can touch neither
+    // them nor the floor — the kernel relies on that
+    const double top = m->height_offset, zoff = m->body_pos[1][2];
+    if (zoff + m->geom_pos[1][2] - m->geom_size[1][0] < top || zoff + m->geom_pos[2][2] - m->geom_size[2][2] < top)
+      return ant_fail(err, errlen, "point kernel: in an elevated maze the robot's geoms must stay above the platforms");
+  }
   maze_dev_from_model(&p->maze, m);
   task_dev_from_model(&p->task, m);
   for (int k = 0; k < 3; k++) p->qpos0[k] = m->qpos0[k];

@@ -37,6 +37,10 @@ struct SwimmerDev {
   // force-free slide-x / slide-y body — it only drifts with whatever velocity it is given and shows up in the observation
   int nblock, observe_blocks;
   double block_pos0[1][3], block_mass, block_box[3];  // inertia-box sizes: the medium drags a moving block too
+  // slide dofs of the block: 2 (x, y: Push mazes) or 2 / 3 with a z slide (y, z: Fall; x, y, z: MultiFall), the latter LIMITED
+  // (maze_env.py:607-648) and pulled by gravity
+  int nbdof, bd_axis[3], bd_limited[3];
+  double bd_lo[3], bd_hi[3], bd_margin, bd_K, bd_B, bd_solimp[5], gz;
   TaskDev task;
 };
 
@@ -44,17 +48,31 @@ static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char*
   memset(p, 0, sizeof(*p));
   const int nbk = m->nblock, nl = m->nbody - 1 - nbk;
   if (nbk < 0 || nbk > 1) return ant_fail(err, errlen, "swimmer kernel: at most one movable block");
-  bool ok = m->robot == MZ_ROBOT_SWIMMER && (nl == 2 || nl == 3) && m->nv == nl + 2 + 2 * nbk && m->nq == nl + 2 + 2 * nbk && m->nu == nl - 1 &&
+  const int nbd0 = nbk ? m->body_jntnum[m->block_bodyid[0]] : 0;
+  bool ok = m->robot == MZ_ROBOT_SWIMMER && (nl == 2 || nl == 3) && m->nv == nl + 2 + nbd0 && m->nq == nl + 2 + nbd0 && m->nu == nl - 1 &&
             m->collision_predefined && m->jnt_type[0] == MZ_JNT_SLIDE && m->jnt_type[1] == MZ_JNT_SLIDE;
   for (int j = 2; ok && j < nl + 2; j++) ok = m->jnt_type[j] == MZ_JNT_HINGE;
   for (int a = 0; ok && a < nl - 1; a++) ok = m->act_dofid[a] == 3 + a;
   if (!ok) return ant_fail(err, errlen, "swimmer kernel: model is not the 2- or 3-link planar swimmer / reacher");
   p->nlink = nl; p->nblock = nbk; p->observe_blocks = m->observe_blocks;
+  p->gz = m->gravity[2];
+  const int nbd = nbk ? m->body_jntnum[m->block_bodyid[0]] : 0;
   for (int k = 0; k < nbk; k++) {
     int b = m->block_bodyid[k], j0 = m->body_jntadr[b];
-    if (m->body_jntnum[b] != 2 || m->jnt_type[j0] != MZ_JNT_SLIDE || m->jnt_type[j0 + 1] != MZ_JNT_SLIDE || m->body_dofadr[b] != nl + 2 + 2 * k ||
-        fabs(m->jnt_axis[j0][0] - 1.0) > 1e-12 || fabs(m->jnt_axis[j0 + 1][1] - 1.0) > 1e-12 || m->jnt_limited[j0] || m->jnt_limited[j0 + 1])
-      return ant_fail(err, errlen, "swimmer kernel: movable block is not an unlimited slide-x / slide-y body");
+    if (nbd < 2 || nbd > 3 || m->body_dofadr[b] != nl + 2) return ant_fail(err, errlen, "swimmer kernel: movable block needs 2 or 3 slide joints right after the robot");
+    p->nbdof = nbd;
+    for (int a = 0; a < nbd; a++) {
+      int j = j0 + a, ax = -1;
+      for (int c = 0; c < 3; c++) if (fabs(m->jnt_axis[j][c] - 1.0) < 1e-12) ax = c;
+      if (m->jnt_type[j] != MZ_JNT_SLIDE || ax < 0 || (a > 0 && ax <= p->bd_axis[a - 1])) return ant_fail(err, errlen, "swimmer kernel: block joints must be slides along increasing coordinate axes");
+      p->bd_axis[a] = ax; p->bd_limited[a] = m->jnt_limited[j]; p->bd_lo[a] = m->jnt_range[j][0]; p->bd_hi[a] = m->jnt_range[j][1];
+      if (m->dof_armature[m->jnt_dofadr[j]] != 0.0 || m->dof_damping[m->jnt_dofadr[j]] != 0.0) return ant_fail(err, errlen, "swimmer kernel: block slides must be free of armature and damping");
+    }
+    {  // limit rows share the joint defaults (maze_env.py:607-648 sets only margin)
+      double tc = fmax(m->jnt_solref[j0][0], 2.0 * m->timestep), dr = m->jnt_solref[j0][1], dmax = m->jnt_solimp[j0][1];
+      p->bd_K = 1.0 / (dmax * dmax * tc * tc * dr * dr); p->bd_B = 2.0 / (dmax * tc); p->bd_margin = m->jnt_margin[j0];
+      for (int q = 0; q < 5; q++) p->bd_solimp[q] = m->jnt_solimp[j0][q];
+    }
     for (int q = 0; q < 3; q++) p->block_pos0[k][q] = m->body_pos[b][q];
     const double* I = m->body_inertia[b];
     p->block_mass = m->body_mass[b];
@@ -253,28 +271,47 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
   return status;
 }
 
-// A movable block in the swimmer's world: no contacts (collision="predefined"), gravity along z, so the only force on its
-// two slide dofs is the medium's drag on the box (same inertia-box model as the links, axis-aligned, no rotation).
-// One env.step = frame_skip RK4 steps of  dv/dt = -(3 pi mu d v + rho/2 A |v| v) / m  per axis.
-MZS_HD void swimmer_block_step(const SwimmerDev& P, double* q2, double* v2) {
+// A movable block in the swimmer's world: no contacts (collision="predefined"), so each of its slide dofs evolves on its own:
+//   m a = -(3 pi mu d v + rho/2 A |v| v)   the medium's drag on the box (inertia-box model, axis-aligned, no rotation)
+//         + m g                            on a z slide (Fall / MultiFall blocks)
+//         + f_limit                        soft joint-limit row of a LIMITED slide: one-row problem solved in closed form —
+//                                          minimise m/2 (a - a0)^2 + D/2 min(0, J a - aref)^2  =>  a = (m a0 + D J aref) / (m + D)
+// One env.step = frame_skip RK4 steps per dof.  (The drag on a 0.2 g / 1 g box is far stiffer than 1 / h: once the block
+// moves the explicit integration diverges, in MuJoCo as here — the env is then flagged.)
+MZS_HD double swimmer_block_acc(const SwimmerDev& P, int a, double q, double v) {
   const double* bx = P.block_box;
+  const int ax = P.bd_axis[a];
   const double diam = (bx[0] + bx[1] + bx[2]) / 3.0, lin = 3.0 * P.viscosity * 3.141592653589793 * diam;
-  for (int ax = 0; ax < 2; ax++) {
-    const double area = ax == 0 ? bx[1] * bx[2] : bx[0] * bx[2];
-    double q = q2[ax], v = v2[ax];
+  const double area = ax == 0 ? bx[1] * bx[2] : (ax == 1 ? bx[0] * bx[2] : bx[0] * bx[1]);
+  double a0 = -(lin * v + 0.5 * P.density * area * fabs(v) * v) / P.block_mass + (ax == 2 ? P.gz : 0.0);
+  if (P.bd_limited[a]) {
+    for (int side = -1; side <= 1; side += 2) {
+      const double dist = side < 0 ? q - P.bd_lo[a] : P.bd_hi[a] - q;
+      if (dist < P.bd_margin) {
+        const double J = -(double)side, imp = sw_impedance(P.bd_solimp, fabs(dist - P.bd_margin));
+        const double D = 1.0 / fmax(1e-15, (1.0 - imp) / imp * (1.0 / P.block_mass));  // dof_invweight0 of a free slide = 1 / m
+        const double aref = -P.bd_B * (J * v) - P.bd_K * imp * (dist - P.bd_margin);
+        if (J * a0 - aref < 0.0) a0 = (P.block_mass * a0 + D * J * aref) / (P.block_mass + D);
+      }
+    }
+  }
+  return a0;
+}
+MZS_HD void swimmer_block_step(const SwimmerDev& P, double* qb, double* vb) {
+  for (int a = 0; a < P.nbdof; a++) {
+    double q = qb[a], v = vb[a];
     for (int f = 0; f < P.frame_skip; f++) {
       double qs = q, vs = v, accv = 0.0, accf = 0.0;
       for (int st = 0; st < 4; st++) {
-        double a = -(lin * vs + 0.5 * P.density * area * fabs(vs) * vs) / P.block_mass;
+        double acc = swimmer_block_acc(P, a, qs, vs);
         double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
-        accv += bw * vs; accf += bw * a;
-        double nq = q + P.h * (aw * vs), nv = v + P.h * (aw * a);
+        accv += bw * vs; accf += bw * acc;
+        double nq = q + P.h * (aw * vs), nv = v + P.h * (aw * acc);
         qs = nq; vs = nv;
       }
       q += P.h * accv; v += P.h * accf;
-      (void)qs;
     }
-    q2[ax] = q; v2[ax] = v;
+    qb[a] = q; vb[a] = v;
   }
 }
 
@@ -314,26 +351,28 @@ MZS_HD int swimmer_env_step(const SwimmerDev& P, double* q, double* v, const dou
 }
 
 // Observation row (swimmer.py:50-54 returns the WHOLE qpos and qvel — the slides of a movable block included — and
-// MazeEnv._get_obs, maze_env.py:351-369, splices the block positions in after the first three entries):
-//   qpos[0:3] | block xyz (3 each, if observed) | qpos[3:NV] | qvel[0:NV] | t * 0.001        (SwimmerPush: 18 numbers)
-template <int NL, int NB>
+// MazeEnv._get_obs, maze_env.py:351-369, splices the block position in after the first three entries):
+//   qpos[0:3] | block xyz (if observed) | qpos[3:NV] | qvel[0:NV] | t * 0.001        (SwimmerPush: 18 numbers)
+// BD = slide dofs of the (single) movable block: 0 none, 2 or 3.
+template <int NL, int BD>
 MZS_HD void swimmer_obs_row(const SwimmerDev& P, const float* qf, const float* vf, int t, float* o) {
-  constexpr int NV = NL + 2 + 2 * NB;
-  const int nb3 = P.observe_blocks ? 3 * NB : 0;
+  constexpr int NV = NL + 2 + BD;
+  const int nb3 = (BD && P.observe_blocks) ? 3 : 0;
   for (int k = 0; k < 3; k++) o[k] = qf[k];
-  for (int b = 0; b < NB && nb3; b++) {
-    o[3 + 3 * b] = (float)(P.block_pos0[b][0] + (double)qf[NL + 2 + 2 * b]); o[4 + 3 * b] = (float)(P.block_pos0[b][1] + (double)qf[NL + 3 + 2 * b]);
-    o[5 + 3 * b] = (float)P.block_pos0[b][2];
+  if (nb3) {
+    double p[3] = {P.block_pos0[0][0], P.block_pos0[0][1], P.block_pos0[0][2]};
+    for (int a = 0; a < BD; a++) p[P.bd_axis[a]] += (double)qf[NL + 2 + a];
+    for (int c = 0; c < 3; c++) o[3 + c] = (float)p[c];
   }
   for (int k = 3; k < NV; k++) o[nb3 + k] = qf[k];
   for (int k = 0; k < NV; k++) o[nb3 + NV + k] = vf[k];
   o[nb3 + 2 * NV] = (float)t * 0.001f;
 }
 
-// One MazeEnv.step of a swimmer / reacher env with NB movable blocks on the fp32 state (qf, vf: NV = NL + 2 + 2 NB entries,
-// in and out): the chain's step, the blocks' drift, the observation row o[2 NV + 1 + 3 NB] and the inner reward.
+// One MazeEnv.step of a swimmer / reacher env with a BD-dof movable block on the fp32 state (qf, vf: NV = NL + 2 + BD entries,
+// in and out): the chain's step, the block's own motion, the observation row o[2 NV + 4] and the inner reward.
 // Returns status bits.  Shared by swimmer_step_kernel and the CPU emulation of tests/emu.
-template <int NL, int NB>
+template <int NL, int BD>
 MZS_HD int swimmer_maze_step(const SwimmerDev& P, float* qf, float* vf, const float* action, int t_in, float* o, double* inner_reward,
                              double* info4, int* t_out) {
   constexpr int NR = NL + 2, NH = NL - 1;
@@ -343,13 +382,14 @@ MZS_HD int swimmer_maze_step(const SwimmerDev& P, float* qf, float* vf, const fl
   int st = swimmer_env_step<NL>(P, q, v, a, t_in, inner_reward, info4, t_out);
   bool badv = false;
   for (int k = 0; k < NR; k++) { badv = badv || !(fabs(q[k]) < 1e10) || !(fabs(v[k]) < 1e10); qf[k] = (float)q[k]; vf[k] = (float)v[k]; }
-  // blocks: no contacts (swimmer.xml:3 collision="predefined"), only the medium's drag on a moving box
-  for (int b = 0; b < NB; b++) {
-    double q2[2] = {(double)qf[NR + 2 * b], (double)qf[NR + 2 * b + 1]}, v2[2] = {(double)vf[NR + 2 * b], (double)vf[NR + 2 * b + 1]};
-    if (v2[0] != 0.0 || v2[1] != 0.0) swimmer_block_step(P, q2, v2);
-    for (int c = 0; c < 2; c++) { badv = badv || !(fabs(q2[c]) < 1e10) || !(fabs(v2[c]) < 1e10); qf[NR + 2 * b + c] = (float)q2[c]; vf[NR + 2 * b + c] = (float)v2[c]; }
+  if constexpr (BD > 0) {  // no contacts (swimmer.xml:3 collision="predefined"): drag, gravity on a z slide, joint limits
+    double qb[BD], vb[BD];
+    bool moving = false;
+    for (int c = 0; c < BD; c++) { qb[c] = (double)qf[NR + c]; vb[c] = (double)vf[NR + c]; moving = moving || vb[c] != 0.0 || P.bd_axis[c] == 2; }
+    if (moving) swimmer_block_step(P, qb, vb);
+    for (int c = 0; c < BD; c++) { badv = badv || !(fabs(qb[c]) < 1e10) || !(fabs(vb[c]) < 1e10); qf[NR + c] = (float)qb[c]; vf[NR + c] = (float)vb[c]; }
   }
   if (badv) st |= MZ_STATUS_BAD_STATE;
-  swimmer_obs_row<NL, NB>(P, qf, vf, *t_out, o);
+  swimmer_obs_row<NL, BD>(P, qf, vf, *t_out, o);
   return st;
 }

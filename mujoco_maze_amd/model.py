@@ -225,7 +225,7 @@ class MazeWorld:
 
 
 # ---------------------------------------------------------------- what the device kernels can step
-DEVICE_ELEVATED_ROBOTS = set()  # robots whose kernels handle elevated mazes (Fall / MultiFall): filled as kernels gain support
+DEVICE_ELEVATED_ROBOTS = {"swimmer", "reacher", "point"}  # robots whose kernels handle elevated mazes (Fall / MultiFall): filled as kernels gain support
 
 
 def device_unsupported_reason(cm) -> Optional[str]:

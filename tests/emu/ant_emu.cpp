@@ -164,10 +164,10 @@ extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* 
 template <int NL, int NB>
 static int swimmer_env_step_t(const SwimmerDev& P, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
                               float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
-  constexpr int NR = NL + 2, NV = NR + 2 * NB, NH = NL - 1;
-  const int nb3 = P.observe_blocks ? 3 * NB : 0, NO = 2 * NV + 1 + nb3;
+  constexpr int NR = NL + 2, NV = NR + NB, NH = NL - 1;  // NB: slide dofs of the movable block (0, 2, 3)
+  const int nb3 = (NB && P.observe_blocks) ? 3 : 0, NO = 2 * NV + 1 + nb3;
   for (int e = 0; e < n; e++) {
-    float o[2 * NV + 1 + 3 * NB];
+    float o[2 * NV + 4];
     double inner, inf4[4];
     int t_new;
     int st = swimmer_maze_step<NL, NB>(P, qpos + NV * e, qvel + NV * e, actions + NH * e, t[e], o, &inner, inf4, &t_new);
@@ -190,10 +190,11 @@ extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float
   char err[128];
   int rc = swimmer_dev_from_model(&P, m, err, sizeof(err));
   if (rc != MZ_OK) return rc;
-  if (P.nlink == 3) return P.nblock ? swimmer_env_step_t<3, 1>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
-                                    : swimmer_env_step_t<3, 0>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
-  return P.nblock ? swimmer_env_step_t<2, 1>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
-                  : swimmer_env_step_t<2, 0>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status);
+  const int bd = P.nblock ? P.nbdof : 0;
+#define MZ_SW(NL, BD) swimmer_env_step_t<NL, BD>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
+  if (P.nlink == 3) return bd == 3 ? MZ_SW(3, 3) : (bd == 2 ? MZ_SW(3, 2) : MZ_SW(3, 0));
+  return bd == 3 ? MZ_SW(2, 3) : (bd == 2 ? MZ_SW(2, 2) : MZ_SW(2, 0));
+#undef MZ_SW
 }
 
 // ---------------------------------------------------------------- the bit-exact pieces, for CPU tests against the golden vectors

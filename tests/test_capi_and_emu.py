@@ -357,6 +357,35 @@ def test_swimmer_world_with_a_movable_block(oracle, robot):
         oracle.step(cm, st, act.astype(np.float64), nthreads=4)
 
 
+@pytest.mark.parametrize("robot", ["swimmer", "reacher"])
+def test_swimmer_family_on_the_fall_maze(oracle, robot):
+    """SwimmerFall / ReacherFall: the block has limited y / z slides and gravity pulls on the z slide (maze_env.py:607-648), the
+    torso is lifted with the platforms (a planar chain does not notice), there are no contacts.  The observation carries the
+    block's two slide coordinates and velocities (layout pinned by tests/golden/obs_layout.json: SwimmerFall 18 numbers).
+    Dynamics: the medium's drag on the 1 g block is ~3000 / s against h = 0.01, so ANY motion of the block diverges under the
+    explicit integrator — and gravity makes it move even from rest: the reference's env is unusable (mujoco-py raises), the
+    oracle and the kernel source both flag every env after one step."""
+    from tests import emu_lib
+
+    cm = model.compile_model(robot, T.DistRewardFall(4.0), 4.0)
+    m = cm.c
+    nr = m.nv - 2
+    assert m.elevated == 1 and m.nblock == 1 and m.nv_robot == m.nv and m.obs_dim == m.nq + m.nv + 4 and list(m.body_pos[1]) == [0.0, 0.0, 2.75]
+    n = 32
+    st, obs0 = oracle.reset(cm, n, 3)
+    b = m.block_bodyid[0]
+    assert np.allclose(obs0[:, 3], m.body_pos[b][0]) and np.allclose(obs0[:, 4], m.body_pos[b][1] + st["qpos"][:, nr])
+    assert np.allclose(obs0[:, 5], m.body_pos[b][2] + st["qpos"][:, nr + 1])  # block xyz = spawn position + (y, z) slides
+    for rest in (False, True):
+        s64 = _f32(st)
+        if rest:
+            s64["qvel"][:, nr:] = 0.0
+        s32 = emu_lib.f32_state(s64)
+        ro = oracle.step(cm, s64, np.zeros((n, m.nu)), nthreads=4)
+        re_ = emu_lib.swimmer_env_step(cm, s32, np.zeros((n, m.nu), np.float32))
+        assert np.all(ro["status"] & 1) and np.all(re_["status"] & 1), rest
+
+
 @pytest.mark.parametrize("robot,nq", [("swimmer", 5), ("reacher", 4)])
 def test_swimmer_step_logic(oracle, robot, nq):
     """Swimmer (north_star) and Reacher (its 2-link variant, reacher.py / reacher.xml): the kernel's

@@ -405,6 +405,60 @@ def test_swimmer_world_with_a_movable_block(torch, oracle, env_id):
     env.close()
 
 
+def test_point_fall_maze(torch, oracle):
+    """PointFall-v0 (and PointMultiFall-v2, the same maze): elevated platforms, walls on top, a falling block with limited
+    y / z slides that the reference spawns INSIDE its platform (maze_env.py:563-593 ignores height_offset) — the box rule
+    [ASSUME-12] expels it upwards within a few steps and it ends as an obstacle at the robot's height.  The robot has no z
+    dof: lifted with the torso it hovers above the platforms (and over the chasm).  Single-step parity along a rollout
+    that covers the expulsion, the settled block and robot-block pushes."""
+    n = 1024
+    env = mm.make("PointFall-v0", num_envs=n)
+    cm = env.model
+    assert cm.c.elevated == 1 and env.obs_dim == 10 and env.nv == 5 and list(cm.c.body_pos[1]) == [0.0, 0.0, 2.75]
+    st, _ = oracle.reset(cm, n, 1)
+    rng = np.random.default_rng(0)
+    errs, moved = [], 0.0
+    for k in range(101):
+        act = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.25, 0.25, n)], 1).astype(np.float32)
+        if k in (0, 1, 5, 20, 60, 100):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], None, s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, _, t = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1))
+            assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
+            assert np.all(_close(qpos, s64["qpos"], atol=1e-4), axis=1).mean() >= 0.995 and np.array_equal(t, s64["t"])
+            assert np.all((env.status().cpu().numpy() & ~8) == 0)
+            moved = max(moved, np.abs(s64["qpos"][:, 3]).max())
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    errs = np.concatenate(errs)
+    assert np.median(errs) < 3e-7 and (errs <= 2e-6).mean() >= 0.99, (np.median(errs), (errs <= 2e-6).mean(), errs.max())
+    assert (st["qpos"][:, 4] > 1.5).mean() > 0.9  # the blocks have been expelled onto their platforms (z slide ~ +1.97 for a range of [-2, 0])
+    assert moved > 0.05                    # and some robots have pushed theirs along y
+    env.close()
+    env = mm.make("PointMultiFall-v2", num_envs=8, force_vec=True)
+    assert env.model.c.elevated == 1 and env.obs_dim == 10
+    env.close()
+
+
+def test_swimmer_family_fall_maze(torch, oracle):
+    """SwimmerFall / ReacherFall / *MultiFall-v2: no contacts in the swimmer's world; the falling block's drag diverges as soon
+    as it moves (gravity makes it move): flagged at once on the device as in the oracle (tests/test_capi_and_emu.py has the
+    reasoning); layout 2 nv + 4."""
+    for env_id in ("SwimmerFall-v0", "ReacherFall-v1", "SwimmerMultiFall-v2"):
+        n = 64
+        env = mm.make(env_id, num_envs=n)
+        cm = env.model
+        assert env.obs_dim == env.nq + env.nv + 4 and cm.c.elevated == 1
+        obs0 = env.reset(seed=3).cpu().numpy()
+        _, ref0 = oracle.reset(cm, n, 3)
+        assert np.abs(obs0 - ref0).max() < 2e-6
+        env.step(torch.zeros((n, env.nu), device=env.device))
+        assert np.all(env.status().cpu().numpy() & 1)
+        env.close()
+
+
 def test_reset_distribution_and_oracle_rng(torch, oracle):
     n = 2048
     for env_id, nq, nv in (("AntUMaze-v0", 15, 14), ("PointUMaze-v0", 3, 3), ("SwimmerUMaze-v0", 5, 5)):
@@ -629,7 +683,7 @@ def test_ragged_batch_sizes_and_argument_errors(torch, oracle, env_id):
     with pytest.raises(KeyError):
         mm.make("AntNoSuchMaze-v0")
     with pytest.raises(NotImplementedError):
-        mm.make("AntFall-v0", num_envs=2)
+        mm.make("AntSmallBilliard-v0", num_envs=2)
 
 
 def test_user_robot_xml_on_the_device(torch, oracle):
