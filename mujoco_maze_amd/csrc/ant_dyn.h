@@ -119,6 +119,7 @@ struct alignas(16) AntScratchT {
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   float red[4];
   uint32_t rowmask[MZ_MAX_GRID + 4];  // the maze's cell grid (bit j of word i: BLOCK), copied once per step: one LDS read per row lookup
+  uint32_t platmask[MZ_MAX_GRID + 4]; // elevated mazes: bit j of word i: the cell carries a platform (every cell but the chasms)
   int status, iters;
   // optional phase timers (device builds with PROF): cycles per phase id, last timestamp
   unsigned long long prof_t0;
@@ -212,6 +213,8 @@ MZ_HD uint32_t maze_row(const MazeDev& z, int i) {
 // the same lookup from the env's LDS copy of the grid (ant_fill_tables): one read instead of a 12-way select
 template <class S>
 MZ_HD uint32_t maze_row_lds(const S& s, int i) { return (i >= 0 && i < MZ_MAX_GRID) ? s.rowmask[i] : 0u; }
+template <class S>
+MZ_HD uint32_t plat_row_lds(const S& s, int i) { return (i >= 0 && i < MZ_MAX_GRID) ? s.platmask[i] : 0u; }
 
 // body index b in 0..12: 0 torso, else leg l = (b-1)/3, level k = (b-1)%3 (0 welded leg, 1 aux, 2 ankle)
 MZ_HD int body_class(int b) { return b == 0 ? 0 : 1 + (b - 1) % 3; }
@@ -431,9 +434,10 @@ MZ_HD void bias_dof_item(const AntDev& K, AntScratchT<NB>& s, int i) {
       }
       s.bias[i] = bb;
       frc = -K.damping * s.qvel[i] - bb + s.fact[i];
-    } else {  // block slides: horizontal, undamped, unactuated (maze_env.py:600-633)
-      s.bias[i] = 0.f;
-      frc = 0.f;
+    } else {  // block slides: undamped, unactuated (maze_env.py:600-648); gravity acts on a z slide (falling blocks)
+      const bool zslide = ((i - 14) & 1) == 1 && K.block_ax1 == 2;
+      s.bias[i] = zslide ? -K.block_mass * K.gz : 0.f;
+      frc = -s.bias[i];
     }
     s.qfs[i] = frc;
 }
@@ -666,7 +670,9 @@ MZ_HD void block_center(const AntDev& K, const AntScratchT<NB>& s, int k, float*
 #pragma unroll
   for (int j = 0; j < (NB ? NB : 1); j++)
     if (j == k && j < NB) { p0[0] = K.block_pos0[j][0]; p0[1] = K.block_pos0[j][1]; p0[2] = K.block_pos0[j][2]; qx = s.qpos[15 + 2 * j]; qy = s.qpos[16 + 2 * j]; }
-  bc[0] = (p0[0] - s.qpos[0]) + qx; bc[1] = (p0[1] - s.qpos[1]) + qy; bc[2] = p0[2] - s.cz;
+  // the two slides run along block_ax0 < block_ax1: (x, y), or (y, z) / (x, z) for falling blocks
+  const float q0x = K.block_ax0 == 0 ? qx : 0.f, q0y = K.block_ax0 == 1 ? qx : (K.block_ax1 == 1 ? qy : 0.f), q0z = K.block_ax1 == 2 ? qy : 0.f;
+  bc[0] = (p0[0] - s.qpos[0]) + q0x; bc[1] = (p0[1] - s.qpos[1]) + q0y; bc[2] = (p0[2] - s.cz) + q0z;
 }
 
 // Enumerate the contacts of enumerator e: e < NB -> movable block e (floor corners, walls);
@@ -699,9 +705,11 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     for (int i = i0; i <= i1; i++)
       for (int j = j0; j <= j1; j++) {
         if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
-        if (!((maze_row_lds(s, i) >> j) & 1u)) continue;
-        // aligned box-box [ASSUME-12]: geom1 = wall, geom2 = block
-        float c1[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
+        // per cell: the platform of an elevated maze (z from 0 to 2 half_z), then the wall block standing on it
+        for (int layer = 0; layer < 2; layer++) {
+        if (!(((layer ? maze_row_lds(s, i) : plat_row_lds(s, i)) >> j) & 1u)) continue;
+        // aligned box-box [ASSUME-12]: geom1 = wall / platform, geom2 = block
+        float c1[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], (layer ? z.center_z : z.half_z) - s.cz};
         float gap[3];
         int ax = 0;
         for (int k = 0; k < 3; k++) gap[k] = fabsf(bc[k] - c1[k]) - (bs[k] + hb[k]);
@@ -729,6 +737,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
             for (int k = 0; k < 3; k++) { cg.n[k] = k == ax ? sg : 0.f; cg.hint[k] = 0.f; cg.pos[k] = k == ax ? pa : (k == u ? pu : pv); }
             emit(cg);
           }
+        }
       }
     // lower-numbered movable blocks: aligned box-box [ASSUME-12], geom1 = block k, geom2 = block e
     for (int k = 0; k < e; k++) {
@@ -760,6 +769,24 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
           for (int q = 0; q < 3; q++) { cg.n[q] = q == ax ? sg : 0.f; cg.hint[q] = 0.f; cg.pos[q] = q == ax ? pa : (q == u ? pu : pv); }
           emit(cg);
         }
+    }
+    // joint-limit rows of the block's own slides (falling blocks, maze_env.py:607-648): kind 6, `other` = slide index, n = the
+    // row's Jacobian direction d dist / d q along the slide axis; a single frictionless row (see con_row_item)
+    if (K.block_limited) {
+      float qa = 0.f, qb = 0.f;
+#pragma unroll
+      for (int j = 0; j < (NB ? NB : 1); j++) if (j == e && j < NB) { qa = s.qpos[15 + 2 * j]; qb = s.qpos[16 + 2 * j]; }
+      for (int a = 0; a < 2; a++) {
+        const float q = a ? qb : qa, lo = a ? K.block_lo[1] : K.block_lo[0], hi = a ? K.block_hi[1] : K.block_hi[0];
+        const int axis = a ? K.block_ax1 : K.block_ax0;
+        for (int side = -1; side <= 1; side += 2) {
+          const float dist = side < 0 ? q - lo : hi - q;
+          if (!(dist < K.blim_margin)) continue;
+          cg.kind = 6; cg.blk = e; cg.other = a; cg.dist = dist;
+          for (int k = 0; k < 3; k++) { cg.n[k] = k == axis ? -(float)side : 0.f; cg.hint[k] = 0.f; cg.pos[k] = 0.f; }
+          emit(cg);
+        }
+      }
     }
     return;
   }
@@ -793,8 +820,12 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     float reachb = r + hl + K.wall.margin;
     if (d2 < reachb * reachb) round_vs_box(b == 0, ctr, ax, hl, r, bc, K.block_half, K.wall.margin, 2, k, emit);
   }
-  // maze walls: cells under the bounding square of the geom (skipped when the torso-level broad phase is clear)
-  if (!s.nearwall) return;
+  // maze walls: cells under the bounding square of the geom (skipped when the torso-level broad phase is clear); in an
+  // elevated maze the platforms under those cells as well — they are what the robot stands on
+  // (the platform code exists in the movable-block instantiations only: every registered elevated maze has a falling block,
+  // ant_dev_from_model refuses an elevated maze without one — the plain ant's kernel stays free of it)
+  const bool elevated = NB > 0 && z.elevated;
+  if (!s.nearwall && !elevated) return;
   float reach = r + hl + K.wall.margin;
   float gx = s.qpos[0] + ctr[0], gy = s.qpos[1] + ctr[1], gz = s.cz + ctr[2];
   if (gz - reach > z.center_z + z.half_z) return;
@@ -803,10 +834,15 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
   for (int i = i0; i <= i1; i++)
     for (int j = j0; j <= j1; j++) {
       if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
-      if (!((maze_row_lds(s, i) >> j) & 1u)) continue;
-      // box centre relative to the torso origin, computed so that the large world coordinates cancel first
-      float bc[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
-      round_vs_box(b == 0, ctr, ax, hl, r, bc, bs, K.wall.margin, 1, 0, emit);
+      for (int layer = elevated ? 0 : 1; layer < 2; layer++) {
+        if (layer == 1 && !s.nearwall) continue;
+        if (!(((layer ? maze_row_lds(s, i) : plat_row_lds(s, i)) >> j) & 1u)) continue;
+        const float cz1 = layer ? z.center_z : z.half_z;
+        if (gz - reach > cz1 + z.half_z || gz + reach < cz1 - z.half_z) continue;
+        // box centre relative to the torso origin, computed so that the large world coordinates cancel first
+        float bc[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], cz1 - s.cz};
+        round_vs_box(b == 0, ctr, ax, hl, r, bc, bs, K.wall.margin, 1, 0, emit);
+      }
     }
 }
 
@@ -856,6 +892,27 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     const float* q = &s.cY[c][0][0];
     float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
     int code = (int)q[7], kind = code & 7, blk = (code >> 3) & 7, other = code >> 6;
+    if (kind == 6) {
+      // joint-limit row of slide `other` of block `blk`: ONE frictionless row  r = J a - aref, cost D/2 min(0, r)^2.  It rides
+      // the contact machinery as a pyramid whose tangential rows vanish: the four edge rows coincide (u0 +- 0), so
+      // cD = D / 4 reproduces cost, gradient and curvature of the single row exactly.
+      float J[D::NCOL];
+      for (int k = 0; k < D::NCOL; k++) J[k] = 0.f;
+      float sg = n[0] + n[1] + n[2], vel = 0.f;  // +-1 on the slide axis
+#pragma unroll
+      for (int k = 0; k < NB; k++)
+        if (k == blk) { if (a == 0) J[6 + 2 * k + (other ? 1 : 0)] = sg; vel = sg * s.qvel[14 + 2 * k + (other ? 1 : 0)]; }
+      float aref = 0.f;
+      if (a == 0) {
+        float imp = impedancef(K.blim_solimp, fabsf(dist - K.blim_margin));
+        float R = fmaxf(1e-15f, (1.f - imp) / imp * K.blim_w);
+        s.cD[c] = 0.25f / R;
+        aref = -K.blim_B * vel - K.blim_K * imp * (dist - K.blim_margin);
+      }
+      for (int k = 0; k < D::NCOL; k++) s.cJ[c][a][k] = J[k];
+      s.caref[c][a] = aref;
+      return;
+    }
     const PairDev& P = (kind == 0 || kind == 3) ? K.floor : K.wall;
     int leg = s.cleg[c], cls = s.ccls[c];
     float t1[3], t2[3], f[3];
@@ -868,10 +925,11 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     float J[D::NCOL];
     for (int k = 0; k < 3; k++) { J[k] = sr * f[k]; J[3 + k] = sr * (s.R0[k] * m[0] + s.R0[3 + k] * m[1] + s.R0[6 + k] * m[2]); }
     for (int k = 6; k < NH; k++) J[k] = 0.f;
+    const float fb0 = K.block_ax0 == 0 ? f[0] : f[1], fb1 = K.block_ax1 == 1 ? f[1] : f[2];  // force components along the block's two slides
 #pragma unroll
     for (int k = 0; k < NB; k++) {
-      if (k == blk && kind >= 2) { J[6 + 2 * k] = sb * f[0]; J[7 + 2 * k] = sb * f[1]; }
-      if (kind == 5 && k == other) { J[6 + 2 * k] = -f[0]; J[7 + 2 * k] = -f[1]; }  // geom1 of a block-block pair
+      if (k == blk && kind >= 2) { J[6 + 2 * k] = sb * fb0; J[7 + 2 * k] = sb * fb1; }
+      if (kind == 5 && k == other) { J[6 + 2 * k] = -fb0; J[7 + 2 * k] = -fb1; }  // geom1 of a block-block pair
     }
     J[NH] = cls >= 2 ? sr * (dot3f(s.zw, m) + dot3f(s.Sh[leg < 0 ? 0 : leg], f)) : 0.f;
     J[NH + 1] = cls == 3 ? sr * (dot3f(s.Sa[leg < 0 ? 0 : leg], m) + dot3f(s.Sa[leg < 0 ? 0 : leg] + 3, f)) : 0.f;
@@ -1294,7 +1352,7 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
     float v = 0.f;
 #pragma unroll
     for (int j = 0; j < (NB ? NB : 1); j++)
-      if (j == k && j < NB) v = c == 2 ? K.block_pos0[j][2] : K.block_pos0[j][c] + s.qpos[15 + 2 * j + c];
+      if (j == k && j < NB) v = K.block_pos0[j][c] + (c == K.block_ax0 ? s.qpos[15 + 2 * j] : 0.f) + (c == K.block_ax1 ? s.qpos[16 + 2 * j] : 0.f);
     return v;
   }
   int q = i - nb3;
@@ -1306,7 +1364,15 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 // constant tables of the scratch block, once per step (to be followed by a cx.sync() before the first forward evaluation)
 template <int NB, class C>
 MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
-  MZ_FOR(i, MZ_MAX_GRID) s.rowmask[i] = maze_row(K.maze, i);
+  MZ_FOR(i, MZ_MAX_GRID) {
+    s.rowmask[i] = maze_row(K.maze, i);
+    if constexpr (NB > 0) {
+      uint32_t pm = 0u;
+#pragma unroll
+      for (int r = 0; r < MZ_MAX_GRID; r++) pm = (r == i) ? K.maze.platmask[r] : pm;
+      s.platmask[i] = K.maze.elevated ? pm : 0u;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ MazeEnv.step for the Ant (maze_env.py:448-481, ant.py:61-73)

@@ -199,7 +199,9 @@ __global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, con
     float* o = obs + (size_t)env * L.obs_dim;
     int k = 0;
     for (int i = 0; i < 3; i++) o[k++] = rec[i];
-    for (int b = 0; b < L.nblock3 / 3; b++) { o[k++] = K.block_pos0[b][0] + rec[15 + 2 * b]; o[k++] = K.block_pos0[b][1] + rec[16 + 2 * b]; o[k++] = K.block_pos0[b][2]; }
+    for (int b = 0; b < L.nblock3 / 3; b++)
+      for (int c = 0; c < 3; c++)
+        o[k++] = K.block_pos0[b][c] + (c == K.block_ax0 ? rec[15 + 2 * b] : 0.f) + (c == K.block_ax1 ? rec[16 + 2 * b] : 0.f);
     for (int i = 3; i < ANT_NQ; i++) o[k++] = rec[i];
     for (int i = 0; i < ANT_NV; i++) o[k++] = rec[L.nq + i];
     o[k] = (float)((int*)rec)[L.rec_t] * 0.001f;

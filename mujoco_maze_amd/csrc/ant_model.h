@@ -68,6 +68,9 @@ struct AntDev {
   // movable XY blocks (all the same size: one maze cell); see maze_env.py:563-660
   int nblock, observe_blocks;
   float block_mass, block_bw_tran, block_half[3], block_pos0[4][3];
+  // the two slide axes of a block: (x, y) in the Push family; (y, z) — LIMITED, gravity on the z slide — in the Fall mazes
+  int block_ax0, block_ax1, block_limited;
+  float block_lo[2], block_hi[2], blim_margin, blim_K, blim_B, blim_solimp[5], blim_w;  // joint-limit rows of the slides
   // solver
   int max_iter, ls_iter, trust_exact;
   float tol, rtol, inv_scale;  // inv_scale = 1 / (meaninertia * nv)
@@ -138,12 +141,26 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
       m->ngeom != 14 + nb)
     return ant_fail(err, errlen, "ant kernel: model is not the 14-body / 14-dof ant (+ XY blocks)");
   a->nblock = nb; a->observe_blocks = m->observe_blocks;
+  if (m->elevated && nb == 0) return ant_fail(err, errlen, "ant kernel: an elevated maze needs a movable block (the platform code lives in the block instantiations)");
+  a->block_ax0 = 0; a->block_ax1 = 1;
   for (int k = 0; k < nb; k++) {
     int b = m->block_bodyid[k], g = m->block_geomid[k], j0 = m->body_jntadr[b];
+    int ax[2] = {-1, -1};
+    for (int q = 0; q < 2 && m->body_jntnum[b] == 2; q++)
+      for (int c = 0; c < 3; c++) if (fabs(m->jnt_axis[j0 + q][c] - 1.0) < 1e-12) ax[q] = c;
     if (b != 14 + k || m->body_jntnum[b] != 2 || m->jnt_type[j0] != MZ_JNT_SLIDE || m->jnt_type[j0 + 1] != MZ_JNT_SLIDE ||
-        m->jnt_dofadr[j0] != ANT_NV + 2 * k || fabs(m->jnt_axis[j0][0] - 1.0) > 1e-12 || fabs(m->jnt_axis[j0 + 1][1] - 1.0) > 1e-12 ||
-        m->geom_type[g] != MZ_GEOM_BOX || m->jnt_limited[j0] || m->jnt_limited[j0 + 1])
-      return ant_fail(err, errlen, "ant kernel: movable block is not a slide-x / slide-y box body");
+        m->jnt_dofadr[j0] != ANT_NV + 2 * k || ax[0] < 0 || ax[1] <= ax[0] || m->geom_type[g] != MZ_GEOM_BOX ||
+        m->jnt_limited[j0] != m->jnt_limited[j0 + 1] || (k > 0 && (ax[0] != a->block_ax0 || ax[1] != a->block_ax1 || m->jnt_limited[j0] != a->block_limited)))
+      return ant_fail(err, errlen, "ant kernel: a movable block is a box body with two slides along increasing coordinate axes (x y, y z or x z); "
+                                   "three-slide blocks (MultiFall's XYZ block) are not instantiated");
+    a->block_ax0 = ax[0]; a->block_ax1 = ax[1]; a->block_limited = m->jnt_limited[j0];
+    for (int q = 0; q < 2; q++) { a->block_lo[q] = (float)m->jnt_range[j0 + q][0]; a->block_hi[q] = (float)m->jnt_range[j0 + q][1]; }
+    {
+      double tc = fmax(m->jnt_solref[j0][0], 2.0 * m->timestep), dr = m->jnt_solref[j0][1], dmax = m->jnt_solimp[j0][1];
+      a->blim_K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr)); a->blim_B = (float)(2.0 / (dmax * tc));
+      a->blim_margin = (float)m->jnt_margin[j0]; a->blim_w = (float)m->dof_invweight0[m->jnt_dofadr[j0]];
+      for (int q = 0; q < 5; q++) a->blim_solimp[q] = (float)m->jnt_solimp[j0][q];
+    }
     for (int q = 0; q < 3; q++) { a->block_pos0[k][q] = (float)m->body_pos[b][q]; a->block_half[q] = (float)m->geom_size[g][q]; }
     a->block_mass = (float)m->body_mass[b];
     a->block_bw_tran = (float)m->body_invweight0[b][0];

@@ -80,7 +80,7 @@ def test_native_library_is_the_in_tree_one(torch):
     assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
     from mujoco_maze_amd.model import MZ_ABI_VERSION
 
-    assert lib.mz_abi_version() == MZ_ABI_VERSION == 3
+    assert lib.mz_abi_version() == MZ_ABI_VERSION == 4
 
 
 def _rollout_states(oracle, cm, n, seed, checkpoints, robot="ant"):
@@ -442,6 +442,40 @@ def test_point_fall_maze(torch, oracle):
     env.close()
 
 
+@pytest.mark.parametrize("env_id", ["AntFall-v0", "AntMultiFall-v2"])
+def test_ant_fall_maze(torch, oracle, env_id):
+    """AntFall (and AntMultiFall-v2, which subclasses the Fall maze, maze_task.py:342): the ant stands on the platforms of an
+    elevated maze (capsule-box contacts instead of the floor plane), walls on top of them, chasms to fall into, and a falling
+    block with limited y / z slides which the reference spawns inside its platform: the box rule expels
+    it upwards within three steps (the single-step error is largest there: the block moves 4 m in 0.3 s against a stiff
+    limit row), after which it rests on its platform as an obstacle.  3-D goal (0, 3.375, 4.5) x scale."""
+    n = 1024
+    env = mm.make(env_id, num_envs=n)
+    cm = env.model
+    assert cm.c.elevated == 1 and env.obs_dim == 33 and (env.nq, env.nv) == (17, 16) and cm.c.goal_dim[0] == 3
+    st, _ = oracle.reset(cm, n, 1)
+    rng = np.random.default_rng(0)
+    worst = []
+    for k in range(41):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        if k in (0, 1, 3, 10, 40):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], s64["warm"], s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.02 if k == 1 else 0.012, hard_atol=4e-5 if k == 1 else 2e-5)
+            worst.append((np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)[ok])
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=4e-5))
+            assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
+            assert np.all((env.status().cpu().numpy() & 7) == 0)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    worst = np.concatenate(worst)
+    assert np.median(worst) < 3e-6, np.median(worst)
+    assert np.all(st["qpos"][:, 2] > 4.2) and np.all(st["qpos"][:, 16] > 3.5)  # ants on the platforms, blocks expelled onto theirs
+    env.close()
+
+
 def test_swimmer_family_fall_maze(torch, oracle):
     """SwimmerFall / ReacherFall / *MultiFall-v2: no contacts in the swimmer's world; the falling block's drag diverges as soon
     as it moves (gravity makes it move): flagged at once on the device as in the oracle (tests/test_capi_and_emu.py has the
@@ -711,8 +745,9 @@ def test_user_robot_xml_on_the_device(torch, oracle):
 
 
 def test_every_registered_id_runs_or_refuses(torch):
-    """All 145 ids of the reference's registry (mujoco_maze/__init__.py:17-78): 128 build and step on the device, the
-    Fall / MultiFall family and AntSmallBilliard raise NotImplementedError; nothing else."""
+    """All 145 ids of the reference's registry (mujoco_maze/__init__.py:17-78): 140 build and step on the device; the Ant's
+    free-joint object ball (AntSmallBilliard, 3 ids) and MultiFall's three-slide block (AntMultiFall-v0 / -v1) raise
+    NotImplementedError; nothing else."""
     rng = np.random.default_rng(0)
     ran, refused = 0, []
     for env_id in mm.REGISTRY:
@@ -735,5 +770,5 @@ def test_every_registered_id_runs_or_refuses(torch):
             assert np.all((env.status().cpu().numpy() & 3) == 0), env_id
         env.close()
         ran += 1
-    assert ran == 128 and len(refused) == 17
-    assert all("Fall" in e or e.startswith("AntSmallBilliard") for e in refused), refused
+    assert ran == 140 and len(refused) == 5
+    assert sorted(refused) == ["AntMultiFall-v0", "AntMultiFall-v1", "AntSmallBilliard-v0", "AntSmallBilliard-v1", "AntSmallBilliard-v2"]
