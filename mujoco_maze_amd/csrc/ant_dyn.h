@@ -60,15 +60,19 @@ struct HostCtx {
 };
 
 // ------------------------------------------------------------------ sizes
+// The template parameter NB of everything below is a block CONFIGURATION: 0-3 = that many movable blocks with two slides
+// each (x y in the Push family, y z / x z falling blocks); 4 = ONE block with three slides (MultiFall's XYZ block).
 template <int NB>
 struct AntDims {
-  static constexpr int NH = 6 + 2 * NB;    // hub dofs: root 6 + 2 per block
-  static constexpr int NV = 14 + 2 * NB;   // MuJoCo dof order: root 0-5, legs 6-13, blocks 14..
-  static constexpr int NQ = 15 + 2 * NB;
+  static constexpr int NBLK = NB == 4 ? 1 : NB;  // movable blocks
+  static constexpr int BD = NB == 4 ? 3 : 2;     // slide dofs per block
+  static constexpr int NH = 6 + BD * NBLK;   // hub dofs: root 6 + the blocks' slides
+  static constexpr int NV = 14 + BD * NBLK;  // MuJoCo dof order: root 0-5, legs 6-13, blocks 14..
+  static constexpr int NQ = 15 + BD * NBLK;
   static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
   // contact slots: a block resting in a corridor holds 4 floor corners + 4 per adjacent wall/block face
-  static constexpr int NC = NB == 0 ? 16 : (NB == 1 ? 28 : (NB == 2 ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each)
-  static constexpr int NGEOM = 13 + NB;    // contact enumerators: blocks first, then the 13 robot geoms
+  static constexpr int NC = NB == 0 ? 16 : ((NB == 1 || NB == 4) ? 28 : (NB == 2 ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each)
+  static constexpr int NGEOM = 13 + NBLK;  // contact enumerators: blocks first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;
   static constexpr int REC_T = NQ + 2 * NV;              // state record: qpos | qvel | warm | t | episode
@@ -435,7 +439,7 @@ MZ_HD void bias_dof_item(const AntDev& K, AntScratchT<NB>& s, int i) {
       s.bias[i] = bb;
       frc = -K.damping * s.qvel[i] - bb + s.fact[i];
     } else {  // block slides: undamped, unactuated (maze_env.py:600-648); gravity acts on a z slide (falling blocks)
-      const bool zslide = ((i - 14) & 1) == 1 && K.block_ax1 == 2;
+      const bool zslide = K.block_axis[(i - 14) % AntDims<NB>::BD] == 2;
       s.bias[i] = zslide ? -K.block_mass * K.gz : 0.f;
       frc = -s.bias[i];
     }
@@ -666,13 +670,22 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
 // torso-relative centre of movable block k
 template <int NB>
 MZ_HD void block_center(const AntDev& K, const AntScratchT<NB>& s, int k, float* bc) {
-  float p0[3] = {0.f, 0.f, 0.f}, qx = 0.f, qy = 0.f;
+  using D = AntDims<NB>;
+  float p0[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < (NB ? NB : 1); j++)
-    if (j == k && j < NB) { p0[0] = K.block_pos0[j][0]; p0[1] = K.block_pos0[j][1]; p0[2] = K.block_pos0[j][2]; qx = s.qpos[15 + 2 * j]; qy = s.qpos[16 + 2 * j]; }
-  // the two slides run along block_ax0 < block_ax1: (x, y), or (y, z) / (x, z) for falling blocks
-  const float q0x = K.block_ax0 == 0 ? qx : 0.f, q0y = K.block_ax0 == 1 ? qx : (K.block_ax1 == 1 ? qy : 0.f), q0z = K.block_ax1 == 2 ? qy : 0.f;
-  bc[0] = (p0[0] - s.qpos[0]) + q0x; bc[1] = (p0[1] - s.qpos[1]) + q0y; bc[2] = (p0[2] - s.cz) + q0z;
+  for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
+    if (j == k && j < D::NBLK) {
+      p0[0] = K.block_pos0[j][0]; p0[1] = K.block_pos0[j][1]; p0[2] = K.block_pos0[j][2];
+#pragma unroll
+      for (int a = 0; a < D::BD; a++) q[a] = s.qpos[15 + D::BD * j + a];
+    }
+  // slide a runs along coordinate axis K.block_axis[a] (increasing): (x, y), (y, z) / (x, z) for falling blocks, (x, y, z)
+  float d[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < D::BD; a++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) d[c] += K.block_axis[a] == c ? q[a] : 0.f;
+  bc[0] = (p0[0] - s.qpos[0]) + d[0]; bc[1] = (p0[1] - s.qpos[1]) + d[1]; bc[2] = (p0[2] - s.cz) + d[2];
 }
 
 // Enumerate the contacts of enumerator e: e < NB -> movable block e (floor corners, walls);
@@ -684,10 +697,22 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
   float inv = 1.0f / z.scale;
   float bs[3] = {z.half_xy, z.half_xy, z.half_z};
   ContactGeo cg;
-  if (e < NB) {  // ---- movable block
+  if (e < AntDims<NB>::NBLK) {  // ---- movable block
     float bc[3];
     block_center<NB>(K, s, e, bc);
     const float* hb = K.block_half;
+    double bwd[3] = {0.0, 0.0, 0.0};  // world position of the block centre in float64: spawn position + its slides
+    {
+      using D = AntDims<NB>;
+#pragma unroll
+      for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
+        if (j == e && j < D::NBLK) {
+          for (int c = 0; c < 3; c++) bwd[c] = K.d_block_pos0[j][c];
+#pragma unroll
+          for (int a = 0; a < D::BD; a++)
+            for (int c = 0; c < 3; c++) if (K.block_axis[a] == c) bwd[c] += (double)s.qpos[15 + D::BD * j + a];
+        }
+    }
     float bottom = (bc[2] + s.cz) - hb[2];  // absolute height of the bottom face
     if (bottom < K.floor.margin)
       for (int ci = 0; ci < 4; ci++) {  // plane-box: the four bottom corners
@@ -710,13 +735,18 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         if (!(((layer ? maze_row_lds(s, i) : plat_row_lds(s, i)) >> j) & 1u)) continue;
         // aligned box-box [ASSUME-12]: geom1 = wall / platform, geom2 = block
         float c1[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], (layer ? z.center_z : z.half_z) - s.cz};
-        float gap[3];
+        // the gaps and the activation test in float64 on world coordinates, as the reference's arithmetic has them (AntDev:
+        // a falling block at maze scale 2 sits exactly `margin` away from its neighbours' faces)
+        const double cw[3] = {j * K.d_scale - K.d_tx, i * K.d_scale - K.d_ty, layer ? K.d_center_z : K.d_half_z};
+        const double hs[3] = {K.d_half_xy + K.d_block_half[0], K.d_half_xy + K.d_block_half[1], K.d_half_z + K.d_block_half[2]};
+        double gapd[3];
         int ax = 0;
-        for (int k = 0; k < 3; k++) gap[k] = fabsf(bc[k] - c1[k]) - (bs[k] + hb[k]);
-        if (gap[1] > gap[ax]) ax = 1;
-        if (gap[2] > gap[ax]) ax = 2;
-        float gmax = ax == 0 ? gap[0] : (ax == 1 ? gap[1] : gap[2]);
-        if (!(gmax < K.wall.margin)) continue;
+        for (int k = 0; k < 3; k++) gapd[k] = fabs(bwd[k] - cw[k]) - hs[k];
+        if (gapd[1] > gapd[ax]) ax = 1;
+        if (gapd[2] > gapd[ax]) ax = 2;
+        const double gmaxd = ax == 0 ? gapd[0] : (ax == 1 ? gapd[1] : gapd[2]);
+        if (!(gmaxd < K.d_wall_margin)) continue;
+        float gmax = (float)gmaxd;
         float lo[3], hi[3];
         for (int k = 0; k < 3; k++) {
           lo[k] = fmaxf(c1[k] - bs[k], bc[k] - hb[k]);
@@ -773,12 +803,18 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     // joint-limit rows of the block's own slides (falling blocks, maze_env.py:607-648): kind 6, `other` = slide index, n = the
     // row's Jacobian direction d dist / d q along the slide axis; a single frictionless row (see con_row_item)
     if (K.block_limited) {
-      float qa = 0.f, qb = 0.f;
+      using D = AntDims<NB>;
+      float qs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < (NB ? NB : 1); j++) if (j == e && j < NB) { qa = s.qpos[15 + 2 * j]; qb = s.qpos[16 + 2 * j]; }
-      for (int a = 0; a < 2; a++) {
-        const float q = a ? qb : qa, lo = a ? K.block_lo[1] : K.block_lo[0], hi = a ? K.block_hi[1] : K.block_hi[0];
-        const int axis = a ? K.block_ax1 : K.block_ax0;
+      for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
+        if (j == e && j < D::NBLK) {
+#pragma unroll
+          for (int a = 0; a < D::BD; a++) qs[a] = s.qpos[15 + D::BD * j + a];
+        }
+#pragma unroll
+      for (int a = 0; a < D::BD; a++) {
+        const float q = qs[a], lo = K.block_lo[a], hi = K.block_hi[a];
+        const int axis = K.block_axis[a];
         for (int side = -1; side <= 1; side += 2) {
           const float dist = side < 0 ? q - lo : hi - q;
           if (!(dist < K.blim_margin)) continue;
@@ -791,7 +827,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     return;
   }
   // ---- robot geom
-  int b = e - NB;
+  int b = e - AntDims<NB>::NBLK;
   int c = body_class(b);
   float r = K.radius[c], hl = K.half_len[c];
   float ctr[3] = {0, 0, 0}, ax[3] = {0, 0, 0};
@@ -812,7 +848,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     }
   }
   // movable blocks
-  for (int k = 0; k < NB; k++) {
+  for (int k = 0; k < AntDims<NB>::NBLK; k++) {
     float bc[3];
     block_center<NB>(K, s, k, bc);
     float d2 = 0.f;
@@ -868,7 +904,7 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       s.ncon = tot;
       s.cbeg[4] = tot;
     }
-    int b = e - NB;
+    int b = e - D::NBLK;
     if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
     int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, slot = off;
     if (s.cnt[e] == 0) return;  // nothing to store: skip the second enumeration
@@ -900,8 +936,10 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
       for (int k = 0; k < D::NCOL; k++) J[k] = 0.f;
       float sg = n[0] + n[1] + n[2], vel = 0.f;  // +-1 on the slide axis
 #pragma unroll
-      for (int k = 0; k < NB; k++)
-        if (k == blk) { if (a == 0) J[6 + 2 * k + (other ? 1 : 0)] = sg; vel = sg * s.qvel[14 + 2 * k + (other ? 1 : 0)]; }
+      for (int k = 0; k < D::NBLK; k++)
+#pragma unroll
+        for (int sl = 0; sl < D::BD; sl++)
+          if (k == blk && sl == other) { if (a == 0) J[6 + D::BD * k + sl] = sg; vel = sg * s.qvel[14 + D::BD * k + sl]; }
       float aref = 0.f;
       if (a == 0) {
         float imp = impedancef(K.blim_solimp, fabsf(dist - K.blim_margin));
@@ -925,12 +963,16 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     float J[D::NCOL];
     for (int k = 0; k < 3; k++) { J[k] = sr * f[k]; J[3 + k] = sr * (s.R0[k] * m[0] + s.R0[3 + k] * m[1] + s.R0[6 + k] * m[2]); }
     for (int k = 6; k < NH; k++) J[k] = 0.f;
-    const float fb0 = K.block_ax0 == 0 ? f[0] : f[1], fb1 = K.block_ax1 == 1 ? f[1] : f[2];  // force components along the block's two slides
+    float fb[3];  // force components along the block's slides
 #pragma unroll
-    for (int k = 0; k < NB; k++) {
-      if (k == blk && kind >= 2) { J[6 + 2 * k] = sb * fb0; J[7 + 2 * k] = sb * fb1; }
-      if (kind == 5 && k == other) { J[6 + 2 * k] = -fb0; J[7 + 2 * k] = -fb1; }  // geom1 of a block-block pair
-    }
+    for (int sl = 0; sl < D::BD; sl++) fb[sl] = K.block_axis[sl] == 0 ? f[0] : (K.block_axis[sl] == 1 ? f[1] : f[2]);
+#pragma unroll
+    for (int k = 0; k < D::NBLK; k++)
+#pragma unroll
+      for (int sl = 0; sl < D::BD; sl++) {
+        if (k == blk && kind >= 2) J[6 + D::BD * k + sl] = sb * fb[sl];
+        if (kind == 5 && k == other) J[6 + D::BD * k + sl] = -fb[sl];  // geom1 of a block-block pair
+      }
     J[NH] = cls >= 2 ? sr * (dot3f(s.zw, m) + dot3f(s.Sh[leg < 0 ? 0 : leg], f)) : 0.f;
     J[NH + 1] = cls == 3 ? sr * (dot3f(s.Sa[leg < 0 ? 0 : leg], m) + dot3f(s.Sa[leg < 0 ? 0 : leg] + 3, f)) : 0.f;
     float vel = 0.f;
@@ -1249,7 +1291,7 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
 // qpos <- integrate(qpos, vel, h): free joint on the manifold, hinges and block slides linear (mj_integratePos)
 template <int NB, class C>
 MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base, const float* vel, float h) {
-  MZ_FOR(i, 12 + 2 * NB) {
+  MZ_FOR(i, 12 + AntDims<NB>::BD * AntDims<NB>::NBLK) {
     if (i < 3) s.qpos[i] = base[i] + h * vel[i];
     else if (i == 3) {
       float w[3] = {vel[3], vel[4], vel[5]};
@@ -1345,14 +1387,19 @@ MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int*
 // observation element i (maze_env.py:351-369): qpos[:3] | block xpos (3 each, if observed) | qpos[3:15] | qvel[:14] | t/1000
 template <int NB>
 MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t) {
-  int nb3 = K.observe_blocks ? 3 * NB : 0;
+  using D = AntDims<NB>;
+  int nb3 = K.observe_blocks ? 3 * D::NBLK : 0;
   if (i < 3) return s.qpos[i];
   if (i < 3 + nb3) {
     int k = (i - 3) / 3, c = (i - 3) - 3 * k;
     float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < (NB ? NB : 1); j++)
-      if (j == k && j < NB) v = K.block_pos0[j][c] + (c == K.block_ax0 ? s.qpos[15 + 2 * j] : 0.f) + (c == K.block_ax1 ? s.qpos[16 + 2 * j] : 0.f);
+    for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
+      if (j == k && j < D::NBLK) {
+        v = K.block_pos0[j][c];
+#pragma unroll
+        for (int a = 0; a < D::BD; a++) v += K.block_axis[a] == c ? s.qpos[15 + D::BD * j + a] : 0.f;
+      }
     return v;
   }
   int q = i - nb3;
@@ -1390,7 +1437,7 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
   cx.sync();
   for (int f = 0; f < K.frame_skip; f++) ant_mj_step<NB>(cx, K, s, f == 0);
   int t = *t_io + 1;
-  int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
+  int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * D::NBLK : 0);
   MZ_FOR(i, obs_dim) obs[i] = ant_obs_elem<NB>(K, s, i, t);
   MZ_FOR(one, 1) {
     float dt = K.h * (float)K.frame_skip;

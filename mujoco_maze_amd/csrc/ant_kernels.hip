@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   const float* out2 = lds[slot2].io.out;
   const int* iout2 = lds[slot2].io.iout;
   float* rec2 = state + (size_t)env2 * D::REC;
-  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * NB : 0);
+  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * D::NBLK : 0);
   const uint8_t d = *(const uint8_t*)&iout2[0];
   const int t_new = iout2[2];
   uint32_t episode = (uint32_t)iout2[3];
@@ -201,7 +201,11 @@ __global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, con
     for (int i = 0; i < 3; i++) o[k++] = rec[i];
     for (int b = 0; b < L.nblock3 / 3; b++)
       for (int c = 0; c < 3; c++)
-        o[k++] = K.block_pos0[b][c] + (c == K.block_ax0 ? rec[15 + 2 * b] : 0.f) + (c == K.block_ax1 ? rec[16 + 2 * b] : 0.f);
+      {
+        float v = K.block_pos0[b][c];
+        for (int a = 0; a < K.block_nax; a++) v += K.block_axis[a] == c ? rec[15 + K.block_nax * b + a] : 0.f;
+        o[k++] = v;
+      }
     for (int i = 3; i < ANT_NQ; i++) o[k++] = rec[i];
     for (int i = 0; i < ANT_NV; i++) o[k++] = rec[L.nq + i];
     o[k] = (float)((int*)rec)[L.rec_t] * 0.001f;
@@ -305,19 +309,21 @@ static hipError_t ant_sync_constants(mz_handle* h, hipStream_t st) {
 hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   hipError_t e = ant_sync_constants(h, st);
   if (e != hipSuccess) return e;
-  switch (h->ant.nblock) {
+  switch (h->ant.nblock == 1 && h->ant.block_nax == 3 ? 4 : h->ant.nblock) {  // block configuration (AntDims)
     case 0: return dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
     case 1: return dispatch_ant_step<1>(h, st, a, o, r, d, gi, inf);
     case 2: return dispatch_ant_step<2>(h, st, a, o, r, d, gi, inf);
+    case 4: return dispatch_ant_step<4>(h, st, a, o, r, d, gi, inf);
     default: return dispatch_ant_step<3>(h, st, a, o, r, d, gi, inf);
   }
 }
 
 hipError_t mzk_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
-  switch (h->ant.nblock) {
+  switch (h->ant.nblock == 1 && h->ant.block_nax == 3 ? 4 : h->ant.nblock) {
     case 0: return dispatch_ant_forward<0>(h, st, a, qacc, counts);
     case 1: return dispatch_ant_forward<1>(h, st, a, qacc, counts);
     case 2: return dispatch_ant_forward<2>(h, st, a, qacc, counts);
+    case 4: return dispatch_ant_forward<4>(h, st, a, qacc, counts);
     default: return dispatch_ant_forward<3>(h, st, a, qacc, counts);
   }
 }

@@ -69,8 +69,14 @@ struct AntDev {
   int nblock, observe_blocks;
   float block_mass, block_bw_tran, block_half[3], block_pos0[4][3];
   // the two slide axes of a block: (x, y) in the Push family; (y, z) — LIMITED, gravity on the z slide — in the Fall mazes
-  int block_ax0, block_ax1, block_limited;
-  float block_lo[2], block_hi[2], blim_margin, blim_K, blim_B, blim_solimp[5], blim_w;  // joint-limit rows of the slides
+  // (x, y, z) for MultiFall's three-slide block.  block_axis[a] = coordinate axis of slide a (increasing), block_nax = 2 or 3
+  int block_axis[3], block_nax, block_limited;
+  float block_lo[3], block_hi[3], blim_margin, blim_K, blim_B, blim_solimp[5], blim_w;  // joint-limit rows of the slides
+  // float64 copies of the geometry behind ONE decision that sits on an exact tie in a registered maze: a falling block is
+  // shrunk to 99 % (maze_env.py:579-582), so at maze scale 2 (AntMultiFall) the faces of the neighbouring platforms /
+  // walls are 0.01 away — exactly the contact margin.  `gap < margin` is false in the reference's float64 arithmetic
+  // (2 - 1.99 = 0.010000000000000009); in fp32 it would be true.  The block-vs-cell gaps are therefore evaluated in fp64.
+  double d_scale, d_tx, d_ty, d_half_xy, d_half_z, d_center_z, d_wall_margin, d_block_half[3], d_block_pos0[4][3];
   // solver
   int max_iter, ls_iter, trust_exact;
   float tol, rtol, inv_scale;  // inv_scale = 1 / (meaninertia * nv)
@@ -137,31 +143,39 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
   memset(a, 0, sizeof(*a));
   const int nb = m->nblock;
   if (nb < 0 || nb > 4) return ant_fail(err, errlen, "ant kernel: at most 4 movable blocks");
-  if (m->robot != MZ_ROBOT_ANT || m->nbody != 14 + nb || m->nv != ANT_NV + 2 * nb || m->nq != ANT_NQ + 2 * nb || m->nu != ANT_NU ||
+  int nbdof = 0;
+  for (int k = 0; k < nb; k++) nbdof += m->body_jntnum[m->block_bodyid[k]];
+  if (m->robot != MZ_ROBOT_ANT || m->nbody != 14 + nb || m->nv != ANT_NV + nbdof || m->nq != ANT_NQ + nbdof || m->nu != ANT_NU ||
       m->ngeom != 14 + nb)
     return ant_fail(err, errlen, "ant kernel: model is not the 14-body / 14-dof ant (+ XY blocks)");
   a->nblock = nb; a->observe_blocks = m->observe_blocks;
   if (m->elevated && nb == 0) return ant_fail(err, errlen, "ant kernel: an elevated maze needs a movable block (the platform code lives in the block instantiations)");
-  a->block_ax0 = 0; a->block_ax1 = 1;
+  a->block_axis[0] = 0; a->block_axis[1] = 1; a->block_axis[2] = 2; a->block_nax = 2;
   for (int k = 0; k < nb; k++) {
     int b = m->block_bodyid[k], g = m->block_geomid[k], j0 = m->body_jntadr[b];
-    int ax[2] = {-1, -1};
-    for (int q = 0; q < 2 && m->body_jntnum[b] == 2; q++)
+    const int nax = m->body_jntnum[b];
+    int ax[3] = {-1, -1, -1};
+    bool ok = (nax == 2 || (nax == 3 && nb == 1)) && b == 14 + k && m->geom_type[g] == MZ_GEOM_BOX && m->jnt_dofadr[j0] == ANT_NV + nax * k;
+    for (int q = 0; ok && q < nax; q++) {
       for (int c = 0; c < 3; c++) if (fabs(m->jnt_axis[j0 + q][c] - 1.0) < 1e-12) ax[q] = c;
-    if (b != 14 + k || m->body_jntnum[b] != 2 || m->jnt_type[j0] != MZ_JNT_SLIDE || m->jnt_type[j0 + 1] != MZ_JNT_SLIDE ||
-        m->jnt_dofadr[j0] != ANT_NV + 2 * k || ax[0] < 0 || ax[1] <= ax[0] || m->geom_type[g] != MZ_GEOM_BOX ||
-        m->jnt_limited[j0] != m->jnt_limited[j0 + 1] || (k > 0 && (ax[0] != a->block_ax0 || ax[1] != a->block_ax1 || m->jnt_limited[j0] != a->block_limited)))
-      return ant_fail(err, errlen, "ant kernel: a movable block is a box body with two slides along increasing coordinate axes (x y, y z or x z); "
-                                   "three-slide blocks (MultiFall's XYZ block) are not instantiated");
-    a->block_ax0 = ax[0]; a->block_ax1 = ax[1]; a->block_limited = m->jnt_limited[j0];
-    for (int q = 0; q < 2; q++) { a->block_lo[q] = (float)m->jnt_range[j0 + q][0]; a->block_hi[q] = (float)m->jnt_range[j0 + q][1]; }
+      ok = m->jnt_type[j0 + q] == MZ_JNT_SLIDE && ax[q] >= 0 && (q == 0 || ax[q] > ax[q - 1]) && m->jnt_limited[j0 + q] == m->jnt_limited[j0];
+    }
+    if (ok && k > 0) ok = nax == a->block_nax && ax[0] == a->block_axis[0] && ax[1] == a->block_axis[1] && m->jnt_limited[j0] == a->block_limited;
+    if (!ok)
+      return ant_fail(err, errlen, "ant kernel: a movable block is a box body with two slides along increasing coordinate axes (x y, y z or x z), "
+                                   "or — a single block — with three (x y z)");
+    a->block_nax = nax; a->block_limited = m->jnt_limited[j0];
+    for (int q = 0; q < nax; q++) { a->block_axis[q] = ax[q]; a->block_lo[q] = (float)m->jnt_range[j0 + q][0]; a->block_hi[q] = (float)m->jnt_range[j0 + q][1]; }
     {
       double tc = fmax(m->jnt_solref[j0][0], 2.0 * m->timestep), dr = m->jnt_solref[j0][1], dmax = m->jnt_solimp[j0][1];
       a->blim_K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr)); a->blim_B = (float)(2.0 / (dmax * tc));
       a->blim_margin = (float)m->jnt_margin[j0]; a->blim_w = (float)m->dof_invweight0[m->jnt_dofadr[j0]];
       for (int q = 0; q < 5; q++) a->blim_solimp[q] = (float)m->jnt_solimp[j0][q];
     }
-    for (int q = 0; q < 3; q++) { a->block_pos0[k][q] = (float)m->body_pos[b][q]; a->block_half[q] = (float)m->geom_size[g][q]; }
+    for (int q = 0; q < 3; q++) {
+      a->block_pos0[k][q] = (float)m->body_pos[b][q]; a->block_half[q] = (float)m->geom_size[g][q];
+      a->d_block_pos0[k][q] = m->body_pos[b][q]; a->d_block_half[q] = m->geom_size[g][q];
+    }
     a->block_mass = (float)m->body_mass[b];
     a->block_bw_tran = (float)m->body_invweight0[b][0];
   }
@@ -211,6 +225,8 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
   pair_from(&a->wall, m, m->geom_friction[1], m->geom_solref[1], m->geom_solimp[1], m->geom_margin[1], m->wall_friction,
             m->wall_solref, m->wall_solimp, m->wall_margin);
   maze_dev_from_model(&a->maze, m);
+  a->d_scale = m->maze_scale; a->d_tx = m->torso_x; a->d_ty = m->torso_y; a->d_half_xy = m->wall_half_xy; a->d_half_z = m->wall_half_z;
+  a->d_center_z = m->wall_center_z; a->d_wall_margin = fmax(m->geom_margin[1], m->wall_margin);
   task_dev_from_model(&a->task, m);
   for (int k = 0; k < ANT_NQ; k++) a->qpos0[k] = (float)m->qpos0[k];
   a->reset_kind = m->reset_qvel_kind;

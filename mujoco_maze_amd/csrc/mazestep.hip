@@ -72,7 +72,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   if (h->robot == MZ_ROBOT_ANT) {
     const int nb = h->ant.nblock;
     if (nb > 3) { delete h; return fail("mz_create: more than 3 movable blocks are not instantiated"); }
-    h->lay.nq = ANT_NQ + 2 * nb; h->lay.nv = ANT_NV + 2 * nb; h->lay.rec_t = h->lay.nq + 2 * h->lay.nv;
+    h->lay.nq = ANT_NQ + h->ant.block_nax * nb; h->lay.nv = ANT_NV + h->ant.block_nax * nb; h->lay.rec_t = h->lay.nq + 2 * h->lay.nv;
     h->lay.rec = (h->lay.rec_t + 2 + 15) / 16 * 16;
     h->lay.nblock3 = model->observe_blocks ? 3 * nb : 0;
     h->lay.obs_dim = ANT_OBS + h->lay.nblock3;
