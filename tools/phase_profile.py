@@ -19,8 +19,10 @@ env.step(acts[0]); env.phase_cycles()
 steps = 50
 for i in range(steps): env.step(acts[i % 16])
 cyc = env.phase_cycles()
-names = ["P0 kinematics+broadphase", "P1 inertia|contact count", "P2 crb|bias legs|contact fill", "P3 hub M|bias dofs", "solve:init", "solve:grad+H", "solve:factor+dir", "solve:linesearch", "solve:tail",
-         "rk4/integrate", "io+epilogue", "P4 M leg inv|contact rows|limits", "P5-7 factor M -> qacc_smooth"]
+# plain ant (row solver): slot 4 = limit rows + initial guess, 5 = curvature publish + gradient / Hessian rows, 6 = row elimination,
+# 7 = J search, vote, line search, update; 11 = contact rows; 12 = row of M + qacc_smooth by the row elimination
+names = ["P0 kinematics+broadphase", "P1 inertia|contact count", "P2 crb|bias legs|contact fill", "P3 hub M|bias dofs", "solve:limits+start", "solve:grad+H rows", "solve:elimination", "solve:vote/linesearch/update", "solve:tail",
+         "rk4/integrate", "io+epilogue", "P4 contact rows", "P5 row of M -> qacc_smooth"]
 wgs = n // (64 // lanes)
 tot = sum(cyc[:13])
 print(f"{env_id} n={n} lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")

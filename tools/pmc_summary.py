@@ -4,15 +4,15 @@ import csv, glob, os, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs(f"profiles/{tag}", exist_ok=True)
-lines = [f"# rocprofv3 summary — {tag}", "", "command: `python bench.py --no-cpu-baseline` (= the default bench run: 100 warm-up + 1000 timed steps) (AntUMaze-v0, 4096 envs, 1 x MI355X)", ""]
+lines = [f"# rocprofv3 summary — {tag}", "", "command: `python bench.py --no-cpu-baseline` (= the default bench run: 100 settle + 100 warm-up + 1000 timed steps) (AntUMaze-v0, 4096 envs, 1 x MI355X)", ""]
 for f in glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True):
     lines += ["## kernel stats (`rocprofv3 --kernel-trace --stats`)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(f)):
         name = r["Name"].split("(")[0][:60]
         lines.append(f"| {name} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     lines.append("")
-# the bench line times the launches after the 100 warm-up steps: same window from the kernel trace
-WARM = 100
+# the bench line times the launches after the 100 settle + 100 warm-up steps: same window from the kernel trace
+WARM = 200
 for f in glob.glob(f"{src}/stats/**/*kernel_trace.csv", recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if "ant_step_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -20,7 +20,7 @@ for f in glob.glob(f"{src}/stats/**/*kernel_trace.csv", recursive=True):
     if len(dur) > WARM:
         timed = dur[WARM:]
         lines += [f"`ant_step_kernel` over the timed window (launches {WARM + 1}..{len(dur)}): avg **{sum(timed)/len(timed):.1f} us** "
-                  f"(min {min(timed):.1f}, max {max(timed):.1f}); warm-up launches avg {sum(dur[:WARM])/WARM:.1f} us "
+                  f"(min {min(timed):.1f}, max {max(timed):.1f}); the {WARM} untimed settle / warm-up launches avg {sum(dur[:WARM])/WARM:.1f} us "
                   "(early in the rollout the ants are still airborne / settling: fewer contacts).", ""]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{src}/pmc_*/**/*counter_collection.csv", recursive=True):
