@@ -265,14 +265,18 @@ static hipError_t launch_ant_forward(mz_handle* h, hipStream_t st, const float* 
   return hipSuccess;
 }
 // lane widths: the plain ant is instantiated for 8/16/32/64 lanes per env, mazes with movable blocks for 16/32/64.
-// Default: 32 for the plain ant; 64 with blocks (their contact sets keep 64 lanes busy, and the 2048-env batches of those
-// configs then fill the chip with two waves per SIMD instead of one).
+// Default: 16 for the plain ant — one DPP row per env, four envs per wavefront, one wavefront per SIMD at the 4096-env
+// batch of the metric: since the row solver removed most LDS waits the kernel is bound by vector-instruction count, and
+// at 16 lanes every phase with <= 16 items (dofs, bodies, geoms, the whole Newton iteration) costs half the instructions
+// per env that it costs at 32 (measured: 8.9 vs 8.1 M env-steps/s; round 1, wait-bound, had it the other way round);
+// 64 with blocks (their contact sets keep 64 lanes busy, and the 2048-env batches of those configs then fill the chip with
+// two waves per SIMD instead of one).
 template <int NB>
 static hipError_t dispatch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   if constexpr (NB == 0) {
     if (h->lanes_set && h->lanes == 8) return launch_ant_step<NB, 8>(h, st, a, o, r, d, gi, inf);
   }
-  const int lanes = h->lanes_set ? h->lanes : (NB ? 64 : 32);
+  const int lanes = h->lanes_set ? h->lanes : (NB ? 64 : 16);
   if (lanes == 64) return launch_ant_step<NB, 64>(h, st, a, o, r, d, gi, inf);
   if (lanes == 16) return launch_ant_step<NB, 16>(h, st, a, o, r, d, gi, inf);
   return launch_ant_step<NB, 32>(h, st, a, o, r, d, gi, inf);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, json
 import torch
 import mujoco_maze_amd as mm
-lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 env_id = sys.argv[2] if len(sys.argv) > 2 else "AntUMaze-v0"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
