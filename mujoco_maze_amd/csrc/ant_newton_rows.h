@@ -59,13 +59,15 @@ __device__ __forceinline__ void pivot(int r, float (&Hrow)[14], float& b, float&
 // H x = b, arrow-structured SPD H: leg dofs (6..13) are eliminated first, each touching its partner and the hub columns only
 __device__ __forceinline__ float solve14(int r, float (&Hrow)[14], float b) {
   float dinv = 0.f;
+  // the four legs do not couple: their hip pivots (then their ankle pivots) are independent chains — issued next to each
+  // other so that the reciprocal / broadcast latencies of one hide behind the others
   pivot<6, 7, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<7, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
   pivot<8, 9, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<9, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
   pivot<10, 11, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<11, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
   pivot<12, 13, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<7, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<9, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<11, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
   pivot<13, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
   pivot<0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
   pivot<1, 2, 3, 4, 5>(r, Hrow, b, dinv);

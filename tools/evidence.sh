@@ -8,7 +8,7 @@ mkdir -p $out
 python bench.py > $out/bench_line.json 2> $out/bench_line.err
 tools/profile.sh $tag > $out/profile.log 2>&1
 python tools/pmc_summary.py $tag > $out/pmc_summary.log 2>&1
-python tools/phase_profile.py 32 2>/dev/null > $out/phase_cycles.txt
+python tools/phase_profile.py 16 2>/dev/null > $out/phase_cycles.txt
 python tools/tail_probe.py 2>/dev/null | grep -v Warning | grep -v "c /=" > $out/load_balance.txt
 python tools/parity_stats.py 2>/dev/null > $out/parity.md
 for a in "--env Ant4Rooms-v0" "--env AntPush-v0 --envs 2048" "--env PointUMaze-v0" "--env AntPushMaze-v0 --envs 2048" "--env AntMultiPush-v0 --envs 2048" \

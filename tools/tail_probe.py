@@ -5,28 +5,32 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import mujoco_maze_amd as mm
-n, lanes = 4096, 32
+n = 4096
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 16   # the default lane-group width of the plain ant at this batch size
+EPW = 64 // lanes                                      # envs per wavefront (= per workgroup)
+NW = n // EPW
 env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True, force_vec=True)
+if len(sys.argv) > 1: env.set_option("lanes_per_env", lanes)
 env.reset(seed=1)
 g = torch.Generator(device=env.device).manual_seed(0)
 acts = [(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30) for _ in range(16)]
 for i in range(150): env.step(acts[i % 16])
 env.set_option("profile_phases", 1)
-env.step(acts[0]); env.phase_cycles(); env.wave_cycles(n // 2)
+env.step(acts[0]); env.phase_cycles(); env.wave_cycles(NW)
 rows = []
 for k in range(8):
     qacc, counts = env.debug_forward(acts[(k + 1) % 16])   # ncon / iters of the first forward evaluation of the coming step
     c = counts.cpu().numpy()
     obs, rew, done, info = env.step(acts[(k + 1) % 16])
-    cyc = env.wave_cycles(n // 2).astype(np.float64)
+    cyc = env.wave_cycles(NW).astype(np.float64)
     env.phase_cycles()
-    ncon = c[:, 0].reshape(-1, 2); it = c[:, 1].reshape(-1, 2)
-    d = done.cpu().numpy().reshape(-1, 2)
+    ncon = c[:, 0].reshape(-1, EPW); it = c[:, 1].reshape(-1, EPW)
+    d = done.cpu().numpy().reshape(-1, EPW)
     rows.append(np.stack([cyc, ncon.max(1), ncon.sum(1), it.max(1), (d != 0).any(1)], 1))
 R = np.concatenate(rows)
 cyc = R[:, 0]
 print(f"waves {len(cyc)}: mean {cyc.mean():.0f} std {cyc.std():.0f} min {cyc.min():.0f} q50 {np.median(cyc):.0f} q99 {np.quantile(cyc,0.99):.0f} max {cyc.max():.0f}")
-for name, col in (("max ncon of the pair", 1), ("sum ncon", 2), ("max first-eval iters", 3), ("auto-reset in wave", 4)):
+for name, col in (("max ncon of the wave", 1), ("sum ncon", 2), ("max first-eval iters", 3), ("auto-reset in wave", 4)):
     print(f"  corr(cycles, {name}) = {np.corrcoef(cyc, R[:, col])[0,1]:.3f}")
 for v in range(0, 9):
     m = R[:, 1] == v
