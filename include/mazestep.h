@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZ_ABI_VERSION 4
+#define MZ_ABI_VERSION 5
 
 #define MZ_MAX_BODY 24
 #define MZ_MAX_JNT 24
@@ -46,7 +46,8 @@ extern "C" {
 #define MZ_MAX_GRID 12
 #define MZ_MAX_SEG 96
 #define MZ_MAX_GOAL 8
-#define MZ_MAX_OBS 48
+#define MZ_MAX_OBS 48        /* observation without the top-down view */
+#define MZ_VIEW_DIM 75       /* MazeEnv.get_top_down_view: 5 x 5 cells x (walls, chasms, movable blocks), maze_env.py:95 */
 
 /* robot kinds */
 #define MZ_ROBOT_POINT 0
@@ -213,7 +214,11 @@ typedef struct mz_model {
    * box of the wall's footprint from z = 0 to z = height_offset (centre wall_half_z, half height wall_half_z); the walls
    * stand on top of it (wall_center_z = wall_half_z + height_offset) and the robot's torso starts 0.75 above it.
    * Movable blocks of such mazes slide along z as well (limited joints; block_bodyid / the joint arrays describe them). */
-  int32_t elevated, pad3;
+  int32_t elevated;
+  /* MazeTask.TOP_DOWN_VIEW (maze_env.py:54,351-369): the robot-centred 5 x 5 x 3 occupancy view of get_top_down_view
+   * (maze_env.py:262-349), flattened row-major, sits between the robot's observation and the trailing t * 0.001; obs_dim
+   * counts its MZ_VIEW_DIM entries */
+  int32_t top_down_view;
   double height_offset;
 } mz_model;
 

@@ -1384,6 +1384,21 @@ MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int*
   *reward = (float)r; *term = tm; *goal_idx = first;
 }
 
+// coordinate c of movable block k's body origin (get_body_com, maze_env.py:364-368): spawn position + its slides
+template <int NB>
+MZ_HD float ant_block_coord(const AntDev& K, const AntScratchT<NB>& s, int k, int c) {
+  using D = AntDims<NB>;
+  float v = 0.f;
+#pragma unroll
+  for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
+    if (j == k && j < D::NBLK) {
+      v = K.block_pos0[j][c];
+#pragma unroll
+      for (int a = 0; a < D::BD; a++) v += K.block_axis[a] == c ? s.qpos[15 + D::BD * j + a] : 0.f;
+    }
+  return v;
+}
+
 // observation element i (maze_env.py:351-369): qpos[:3] | block xpos (3 each, if observed) | qpos[3:15] | qvel[:14] | t/1000
 template <int NB>
 MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t) {
@@ -1392,15 +1407,7 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
   if (i < 3) return s.qpos[i];
   if (i < 3 + nb3) {
     int k = (i - 3) / 3, c = (i - 3) - 3 * k;
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
-      if (j == k && j < D::NBLK) {
-        v = K.block_pos0[j][c];
-#pragma unroll
-        for (int a = 0; a < D::BD; a++) v += K.block_axis[a] == c ? s.qpos[15 + D::BD * j + a] : 0.f;
-      }
-    return v;
+    return ant_block_coord<NB>(K, s, k, c);
   }
   int q = i - nb3;
   if (q < ANT_NQ) return s.qpos[q];

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
                                                        uint64_t seed, uint64_t env0, unsigned long long* __restrict__ prof,
-                                                       float* __restrict__ final_obs) {
+                                                       float* __restrict__ final_obs, int ostride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   using D = AntDims<NB>;
   const AntDev& K = *Kp;  // model constants: scalar loads from a device-resident block (L2 / scalar-cache hits)
@@ -106,8 +106,12 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   // terminal step, the FIRST observation of the new episode in `obs`, and the terminal observation in `final_obs` (when bound).
   const bool rst = auto_reset && d;
   if (live2) {
-    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env2 * obs_dim;
-    if (!rst || final_obs) for (int i = l2; i < obs_dim; i += G) orow[i] = obs2[i];
+    // rows are `ostride` floats apart: obs_dim, or obs_dim + MZ_VIEW_DIM with the time entry behind the view (mz_device.h obs_slot)
+    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env2 * ostride;
+    if (!rst || final_obs) {
+      for (int i = l2; i < obs_dim; i += G) orow[obs_slot(i, obs_dim, ostride)] = obs2[i];
+      if (ostride != obs_dim) for (int i = l2; i < 2 * D::NBLK; i += G) orow[obs_dim - 1 + i] = ant_block_coord<NB>(K, s2, i >> 1, i & 1);
+    }
     if (l2 == 0) {
       reward[env2] = out2[0];
       done[env2] = d;
@@ -128,7 +132,11 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
       for (int i = 3; i < 7; i++) s2.qpos[i] *= qn;
     }
     cx.sync();
-    if (live2) for (int i = l2; i < obs_dim; i += G) obs[(size_t)env2 * obs_dim + i] = ant_obs_elem<NB>(K, s2, i, 0);
+    if (live2) {
+      float* orow = obs + (size_t)env2 * ostride;
+      for (int i = l2; i < obs_dim; i += G) orow[obs_slot(i, obs_dim, ostride)] = ant_obs_elem<NB>(K, s2, i, 0);
+      if (ostride != obs_dim) for (int i = l2; i < 2 * D::NBLK; i += G) orow[obs_dim - 1 + i] = ant_block_coord<NB>(K, s2, i >> 1, i & 1);
+    }
   }
   cx.sync();
   if (live2) {
@@ -196,19 +204,21 @@ __global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, con
     ((uint32_t*)rec)[L.rec_t + 1] = 0;
   }
   if (obs) {
-    float* o = obs + (size_t)env * L.obs_dim;
+    float* o = obs + (size_t)env * L.ostride;
     int k = 0;
+    auto block_coord = [&](int b, int c) {
+      float v = K.block_pos0[b][c];
+      for (int a = 0; a < K.block_nax; a++) v += K.block_axis[a] == c ? rec[15 + K.block_nax * b + a] : 0.f;
+      return v;
+    };
     for (int i = 0; i < 3; i++) o[k++] = rec[i];
     for (int b = 0; b < L.nblock3 / 3; b++)
-      for (int c = 0; c < 3; c++)
-      {
-        float v = K.block_pos0[b][c];
-        for (int a = 0; a < K.block_nax; a++) v += K.block_axis[a] == c ? rec[15 + K.block_nax * b + a] : 0.f;
-        o[k++] = v;
-      }
+      for (int c = 0; c < 3; c++) o[k++] = block_coord(b, c);
     for (int i = 3; i < ANT_NQ; i++) o[k++] = rec[i];
     for (int i = 0; i < ANT_NV; i++) o[k++] = rec[L.nq + i];
-    o[k] = (float)((int*)rec)[L.rec_t] * 0.001f;
+    if (L.ostride != L.obs_dim)  // top-down view: block x, y parked for mzk_view_fill, time entry behind the view
+      for (int b = 0; b < K.nblock; b++) { o[k + 2 * b] = block_coord(b, 0); o[k + 2 * b + 1] = block_coord(b, 1); }
+    o[L.ostride - 1] = (float)((int*)rec)[L.rec_t] * 0.001f;
   }
 }
 
@@ -246,12 +256,12 @@ static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, 
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ant_step_kernel<NB, G, true>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
-                       h->auto_reset, h->seed, h->env0, h->prof, h->final_obs);
+                       h->auto_reset, h->seed, h->env0, h->prof, h->final_obs, h->lay.ostride);
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ant_step_kernel<NB, G, false>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
-                       h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr, h->final_obs);
+                       h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr, h->final_obs, h->lay.ostride);
   }
   return hipSuccess;
 }
@@ -353,6 +363,6 @@ hipError_t mzk_ant_get_state(mz_handle* h, hipStream_t st, float* qpos, float* q
 hipError_t mzk_ant_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx) {
   hipError_t e = ant_sync_constants(h, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ant_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->ant_dev, n, h->lay.obs_dim, obs, reward, done, goal_idx);
+  hipLaunchKernelGGL(ant_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->ant_dev, n, h->lay.ostride, obs, reward, done, goal_idx);
   return hipGetLastError();
 }

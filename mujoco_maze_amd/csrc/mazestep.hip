@@ -69,6 +69,9 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   else { rc = MZ_ERR_UNSUPPORTED; snprintf(msg, sizeof(msg), "mz_create: robot kind %d has no device kernel yet", model->robot); }
   if (rc != MZ_OK) { delete h; return fail(msg); }
   hipError_t e = hipSuccess;
+  view_dev_from_model(model, &h->view);
+  const int vdim = model->top_down_view ? MZ_VIEW_DIM : 0;
+  if (model->top_down_view && model->nblock > 4) { delete h; return fail("mz_create: top-down view with more than 4 movable blocks"); }
   if (h->robot == MZ_ROBOT_ANT) {
     const int nb = h->ant.nblock;
     if (nb > 3) { delete h; return fail("mz_create: more than 3 movable blocks are not instantiated"); }
@@ -76,7 +79,9 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     h->lay.rec = (h->lay.rec_t + 2 + 15) / 16 * 16;
     h->lay.nblock3 = model->observe_blocks ? 3 * nb : 0;
     h->lay.obs_dim = ANT_OBS + h->lay.nblock3;
-    if (h->lay.obs_dim != model->obs_dim || h->lay.obs_dim > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }
+    h->base_obs = h->lay.obs_dim;
+    h->lay.ostride = h->lay.obs_dim + vdim;
+    if (h->base_obs + vdim != model->obs_dim || h->base_obs > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }
     e = hipMalloc(&h->ant_dev, sizeof(AntDev));
     h->ant_dirty = 1;
     if (e == hipSuccess) e = hipMalloc(&h->state, (size_t)num_envs * h->lay.rec * sizeof(float));
@@ -86,7 +91,8 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     const int nb3 = h->robot == MZ_ROBOT_SWIMMER ? ((h->swimmer.observe_blocks && h->swimmer.nblock) ? 3 : 0)
                                                  : (h->point.observe_blocks ? 3 * h->point.nblock : 0) + (h->point.observe_balls ? 3 * h->point.nball : 0);
     const int want = h->robot == MZ_ROBOT_SWIMMER ? 2 * kq + 1 + nb3 : 7 + nb3;
-    if (want != model->obs_dim || want > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }
+    h->base_obs = want;
+    if (want + vdim != model->obs_dim || want > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }
     e = hipMalloc(&h->state, (size_t)num_envs * 2 * kq * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
@@ -188,6 +194,7 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
   h->seed = seed;
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_reset(h, st, mask_dev, seed, obs_dev));
   else HIPCHK(h, mzk_planar_reset(h, st, mask_dev, seed, obs_dev));
+  if (h->view.on && obs_dev) HIPCHK(h, mzk_view_fill(h, st, obs_dev, NULL, NULL));
   return MZ_OK;
 }
 
@@ -219,6 +226,7 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   if (h->ntime > 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
   else HIPCHK(h, mzk_planar_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
+  if (h->view.on) HIPCHK(h, mzk_view_fill(h, st, obs_dev, h->auto_reset ? h->final_obs : NULL, done_dev));
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) { HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st)); h->itime++; }
   h->nsteps++;

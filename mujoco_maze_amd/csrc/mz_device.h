@@ -4,6 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Index of base-layout observation element i (0 .. base_dim - 1: the observation without a top-down view, whose last element
+// is t * 0.001) in a row of `ostride` floats: with a view (ostride = base_dim + MZ_VIEW_DIM) the time entry moves behind it
+// (maze_env.py:369); the view's own entries are filled by mzk_view_fill, which finds the movable blocks' x, y parked at
+// row[base_dim - 1 ...].
+__host__ __device__ inline int obs_slot(int i, int base_dim, int ostride) { return i == base_dim - 1 ? ostride - 1 : i; }
+
 // ------------------------------------------------------------------ device context of a lane group
 template <int G, bool PROF = false>
 struct DevCtx {

@@ -9,10 +9,12 @@
 #include <stdint.h>
 
 #include "ant_model.h"
+#include "mz_view.h"
 #include "point_dyn.h"
 #include "swimmer_dyn.h"
 
-struct AntLayout { int nq, nv, rec, rec_t, obs_dim, nblock3; };  // record layout of the instantiated block count
+struct AntLayout { int nq, nv, rec, rec_t, obs_dim, nblock3, ostride; };  // record layout of the instantiated block count; obs_dim: without the
+                                                                          // top-down view, ostride: floats between observation rows
 
 struct mz_handle {
   mz_model model;
@@ -29,6 +31,8 @@ struct mz_handle {
   int* pt_t;
   uint32_t* pt_ep;
   int* status;
+  ViewDev view;         // MazeTask.TOP_DOWN_VIEW: the maze bitmasks the view kernel reads (passed by value)
+  int base_obs;         // observation width without the view; rows are model.obs_dim = base_obs (+ MZ_VIEW_DIM) floats apart
   float* final_obs;     // caller's buffer for terminal observations under auto-reset (mz_bind_final_obs), or NULL
   unsigned long long* prof;  // 16 phase-cycle accumulators (option "profile_phases")
   int auto_reset, lanes, waves_per_block;
@@ -57,4 +61,7 @@ hipError_t mzk_planar_get_state(mz_handle* h, hipStream_t st, float* qpos, float
 hipError_t mzk_planar_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx);
 hipError_t mzk_point_detect(mz_handle* h, hipStream_t st, int n, const double* old_xy, const double* new_xy, int* hit, double* point,
                             double* final_xy);
+// MazeEnv.get_top_down_view into the rows the step / reset kernel just wrote (no-op unless the task has TOP_DOWN_VIEW):
+// every row of obs, and the rows of final_obs of envs that finished (done != NULL: the step under auto-reset)
+hipError_t mzk_view_fill(mz_handle* h, hipStream_t st, float* obs, float* final_obs, const uint8_t* done);
 int mzk_planar_state_width(const mz_handle* h);  // coordinates per env of the SoA state (NV)

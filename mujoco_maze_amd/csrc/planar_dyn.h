@@ -602,6 +602,15 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
   }
 }
 
+// coordinate c of movable block b's body origin (get_body_com, maze_env.py:364-368): spawn position + its two slides
+template <int NB, int NS>
+MZP_HD float planar_block_coord(const PointDev& P, const PlanarScratch<NB, NS>& s, int b, int c) {
+  double v = P.block_pos0[b][c];
+  if (c == P.block_axis[0]) v += s.q[3 + 2 * b];
+  if (c == P.block_axis[1]) v += s.q[4 + 2 * b];
+  return (float)v;
+}
+
 // observation element i of the returned row: qpos[:3] | ball xyz | block xyz ... | qvel[:3] | t * 0.001  (maze_env.py:351-369)
 template <int NB, int NS>
 MZP_HD float planar_obs_elem(const PointDev& P, const PlanarScratch<NB, NS>& s, int i, int t) {
@@ -610,13 +619,7 @@ MZP_HD float planar_obs_elem(const PointDev& P, const PlanarScratch<NB, NS>& s, 
   if constexpr (NS > 0) {
     if (i < 3 + nb3) return (float)(i == 5 ? P.ball_pos0[2] : P.ball_pos0[i - 3] + s.q[i]);  // body frame origin: z = 0
   }
-  if (i < 3 + nb3) {
-    int b = (i - 3) / 3, c = (i - 3) % 3;
-    double v = P.block_pos0[b][c];
-    if (c == P.block_axis[0]) v += s.q[3 + 2 * b];
-    if (c == P.block_axis[1]) v += s.q[4 + 2 * b];
-    return (float)v;
-  }
+  if (i < 3 + nb3) return planar_block_coord<NB, NS>(P, s, (i - 3) / 3, (i - 3) % 3);
   if (i < 6 + nb3) return (float)s.v[i - 3 - nb3];
   return (float)t * 0.001f;
 }

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restr
                                                           float* __restrict__ reward, uint8_t* __restrict__ done,
                                                           int* __restrict__ goal_idx, float* __restrict__ info,
                                                           int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
-                                                          float* __restrict__ final_obs) {
+                                                          float* __restrict__ final_obs, int ostride) {
   using D = PlanarDims<NB, NS>;
   constexpr int NV = D::NV, NOBS = D::NOBS, EPW = 64 / G;
   __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
@@ -61,8 +61,12 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restr
   const uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
   const bool rst = auto_reset && d;  // vector-env convention: obs <- first observation of the new episode, terminal one -> final_obs
   if (live) {
-    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env * NOBS;
-    if (!rst || final_obs) for (int i = cx.l; i < NOBS; i += G) orow[i] = o[i];
+    // rows are `ostride` floats apart: NOBS, or NOBS + MZ_VIEW_DIM with the time entry behind the view (mz_device.h obs_slot)
+    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env * ostride;
+    if (!rst || final_obs) {
+      for (int i = cx.l; i < NOBS; i += G) orow[obs_slot(i, NOBS, ostride)] = o[i];
+      if (ostride != NOBS) for (int i = cx.l; i < 2 * NB; i += G) orow[NOBS - 1 + i] = planar_block_coord<NB, NS>(P, s, i >> 1, i & 1);
+    }
     if (cx.l == 0) {
       reward[env] = outer;  // Point inner reward is 0.0 (point.py:61)
       done[env] = d;
@@ -85,7 +89,11 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restr
       s.v[k] = k < 3 ? (double)reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k) : 0.0;
     }
     cx.sync();
-    if (live) for (int i = cx.l; i < NOBS; i += G) obs[(size_t)env * NOBS + i] = planar_obs_elem<NB, NS>(P, s, i, 0);
+    if (live) {
+      float* orow = obs + (size_t)env * ostride;
+      for (int i = cx.l; i < NOBS; i += G) orow[obs_slot(i, NOBS, ostride)] = planar_obs_elem<NB, NS>(P, s, i, 0);
+      if (ostride != NOBS) for (int i = cx.l; i < 2 * NB; i += G) orow[NOBS - 1 + i] = planar_block_coord<NB, NS>(P, s, i >> 1, i & 1);
+    }
   }
   if (live) {
     for (int k = cx.l; k < NV; k += G) {
@@ -97,7 +105,8 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restr
 }
 
 template <int NB, int NS>
-__global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+__global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs,
+                                   int ostride) {
   constexpr int NV = 3 + 2 * NB + 3 * NS, NOBS = 7 + 3 * NB + 3 * NS;
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
@@ -111,7 +120,7 @@ __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, cons
   }
   if (obs) {
     const int nb3 = (Pp->observe_blocks ? 3 * NB : 0) + (Pp->observe_balls ? 3 * NS : 0);
-    float* o = obs + (size_t)env * NOBS;
+    float* o = obs + (size_t)env * ostride;
     for (int k = 0; k < 3; k++) { o[k] = S.qv[(size_t)k * n + env]; o[3 + nb3 + k] = S.qv[(size_t)(NV + k) * n + env]; }
     if (NS > 0 && nb3) {
       o[3] = (float)Pp->ball_pos0[0] + S.qv[(size_t)3 * n + env]; o[4] = (float)Pp->ball_pos0[1] + S.qv[(size_t)4 * n + env];
@@ -123,7 +132,14 @@ __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, cons
       p3[Pp->block_axis[1]] += S.qv[(size_t)(4 + 2 * b) * n + env];
       o[3 + 3 * b] = p3[0]; o[4 + 3 * b] = p3[1]; o[5 + 3 * b] = p3[2];
     }
-    o[6 + nb3] = (float)S.t[env] * 0.001f;
+    if (ostride != NOBS)  // top-down view: block x, y parked for mzk_view_fill, time entry behind the view
+      for (int b = 0; b < NB; b++) {
+        float p3[3] = {(float)Pp->block_pos0[b][0], (float)Pp->block_pos0[b][1], (float)Pp->block_pos0[b][2]};
+        p3[Pp->block_axis[0]] += S.qv[(size_t)(3 + 2 * b) * n + env];
+        p3[Pp->block_axis[1]] += S.qv[(size_t)(4 + 2 * b) * n + env];
+        o[NOBS - 1 + 2 * b] = p3[0]; o[NOBS + 2 * b] = p3[1];
+      }
+    o[ostride - 1] = (float)S.t[env] * 0.001f;
   }
 }
 
@@ -154,13 +170,28 @@ __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* 
 //
 // Observation / reset layout: swimmer_dyn.h (swimmer_obs_row).  Reset (swimmer.py:56-69): U(-0.1, 0.1) noise on ALL nq
 // coordinates and ALL nv velocities, the block's included.
+// one observation row o[NO] (swimmer_obs_row) into a row of `ostride` floats: NO, or NO + MZ_VIEW_DIM with the time entry behind
+// the view and the movable block's x, y parked for mzk_view_fill (mz_device.h obs_slot)
+template <int NL, int BD>
+__device__ __forceinline__ void swimmer_store_row(const SwimmerDev& P, const float* qf, const float* o, int NO, int ostride, float* row) {
+  for (int k = 0; k < NO; k++) row[obs_slot(k, NO, ostride)] = o[k];
+  if constexpr (BD > 0) {
+    if (ostride != NO) {
+      double p[3] = {P.block_pos0[0][0], P.block_pos0[0][1], P.block_pos0[0][2]};
+      for (int a = 0; a < BD; a++) p[P.bd_axis[a]] += (double)qf[NL + 2 + a];
+      row[NO - 1] = (float)p[0];
+      row[NO] = (float)p[1];
+    }
+  }
+}
+
 template <int NL, int NB>
 __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __restrict__ Pp, int n, PointState S,
                                                             const float* __restrict__ actions, float* __restrict__ obs,
                                                             float* __restrict__ reward, uint8_t* __restrict__ done,
                                                             int* __restrict__ goal_idx, float* __restrict__ info,
                                                             int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
-                                                            float* __restrict__ final_obs) {
+                                                            float* __restrict__ final_obs, int ostride) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   constexpr int NR = NL + 2, NV = NR + NB, NH = NL - 1;  // NB: slide dofs of the movable block
@@ -176,10 +207,7 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
   task_eval_dev(P.task, o, &outer, &tm, &gi);
   uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
   const bool rst = auto_reset && d;
-  {
-    float* orow = ((rst && final_obs) ? final_obs : obs) + (size_t)env * NO;
-    if (!rst || final_obs) for (int k = 0; k < NO; k++) orow[k] = o[k];
-  }
+  if (!rst || final_obs) swimmer_store_row<NL, NB>(P, qf, o, NO, ostride, ((rst && final_obs) ? final_obs : obs) + (size_t)env * ostride);
   reward[env] = (float)(P.task.inner_scale * inner) + outer;
   done[env] = d;
   if (goal_idx) goal_idx[env] = gi;
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
       vf[k] = reset_qvel(P.reset_kind, NV, es, env0 + (uint64_t)env, k);
     }
     swimmer_obs_row<NL, NB>(P, qf, vf, 0, o);
-    for (int k = 0; k < NO; k++) obs[(size_t)env * NO + k] = o[k];
+    swimmer_store_row<NL, NB>(P, qf, o, NO, ostride, obs + (size_t)env * ostride);
   }
   for (int k = 0; k < NV; k++) {
     S.qv[(size_t)k * n + env] = qf[k];
@@ -205,7 +233,8 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
 }
 
 template <int NL, int NB>
-__global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs) {
+__global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, const uint8_t* mask, uint64_t seed, uint64_t env0, float* obs,
+                                     int ostride) {
   constexpr int NR = NL + 2, NV = NR + NB;
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
@@ -222,8 +251,25 @@ __global__ void swimmer_reset_kernel(const SwimmerDev* Pp, int n, PointState S, 
     float qf[NV], vf[NV], o[2 * NV + 4];
     for (int k = 0; k < NV; k++) { qf[k] = S.qv[(size_t)k * n + env]; vf[k] = S.qv[(size_t)(NV + k) * n + env]; }
     swimmer_obs_row<NL, NB>(*Pp, qf, vf, S.t[env], o);
-    for (int k = 0; k < NO; k++) obs[(size_t)env * NO + k] = o[k];
+    swimmer_store_row<NL, NB>(*Pp, qf, o, NO, ostride, obs + (size_t)env * ostride);
   }
+}
+
+// ------------------------------------------------------------------ top-down view (every robot; mz_view.h)
+// One thread per env: fills the MZ_VIEW_DIM view entries of the env's observation row — and of its final_obs row when the env
+// just finished under auto-reset — from the row's own torso position and the block positions the step / reset kernel parked.
+__global__ void view_fill_kernel(ViewDev V, int n, int ostride, int view_off, float* __restrict__ obs, float* __restrict__ final_obs,
+                                 const uint8_t* __restrict__ done) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  mzv_fill_row(V, obs + (size_t)env * ostride, view_off);
+  if (final_obs && done && done[env]) mzv_fill_row(V, final_obs + (size_t)env * ostride, view_off);
+}
+
+hipError_t mzk_view_fill(mz_handle* h, hipStream_t st, float* obs, float* final_obs, const uint8_t* done) {
+  if (!h->view.on) return hipSuccess;
+  hipLaunchKernelGGL(view_fill_kernel, dim3((h->n + 63) / 64), dim3(64), 0, st, h->view, h->n, h->model.obs_dim, h->base_obs - 1, obs, final_obs, done);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ parity-test kernels
@@ -269,7 +315,7 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
   if (h->robot == MZ_ROBOT_SWIMMER) {
 #define MZ_SW_STEP(NL, NB)                                                                                                          \
   hipLaunchKernelGGL((swimmer_step_kernel<NL, NB>), dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev, \
-                     reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs)
+                     reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs, h->model.obs_dim)
     const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
     if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_STEP(3, 3); else if (bd == 2) MZ_SW_STEP(3, 2); else MZ_SW_STEP(3, 0); }
     else { if (bd == 3) MZ_SW_STEP(2, 3); else if (bd == 2) MZ_SW_STEP(2, 2); else MZ_SW_STEP(2, 0); }
@@ -279,7 +325,7 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
   // lanes per env: 16 for the bare robot (18 collision enumerators), 32 / 64 with blocks (bigger contact sets in LDS)
 #define MZ_PLANAR_LAUNCH(NB, NS, G)                                                                                                    \
   hipLaunchKernelGGL((planar_step_kernel<NB, NS, G>), dim3((h->n + 64 / G - 1) / (64 / G)), dim3(64), 0, st, h->point_dev, h->n, S, actions_dev, \
-                     obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs)
+                     obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs, h->model.obs_dim)
   if (h->point.nball) MZ_PLANAR_LAUNCH(0, 1, 32);
   else switch (h->point.nblock) {
     case 0:
@@ -299,19 +345,19 @@ hipError_t mzk_planar_reset(mz_handle* h, hipStream_t st, const uint8_t* mask_de
   PointState S{h->state, h->pt_t, h->pt_ep};
   const int nb = (h->n + 255) / 256;
   if (h->robot == MZ_ROBOT_SWIMMER) {
-#define MZ_SW_RESET(NL, NB) hipLaunchKernelGGL((swimmer_reset_kernel<NL, NB>), dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev)
+#define MZ_SW_RESET(NL, NB) hipLaunchKernelGGL((swimmer_reset_kernel<NL, NB>), dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim)
     const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
     if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_RESET(3, 3); else if (bd == 2) MZ_SW_RESET(3, 2); else MZ_SW_RESET(3, 0); }
     else { if (bd == 3) MZ_SW_RESET(2, 3); else if (bd == 2) MZ_SW_RESET(2, 2); else MZ_SW_RESET(2, 0); }
 #undef MZ_SW_RESET
     return hipGetLastError();
   }
-  if (h->point.nball) hipLaunchKernelGGL((point_reset_kernel<0, 1>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev);
+  if (h->point.nball) hipLaunchKernelGGL((point_reset_kernel<0, 1>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim);
   else switch (h->point.nblock) {
-    case 0: hipLaunchKernelGGL((point_reset_kernel<0, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
-    case 1: hipLaunchKernelGGL((point_reset_kernel<1, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
-    case 2: hipLaunchKernelGGL((point_reset_kernel<2, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
-    default: hipLaunchKernelGGL((point_reset_kernel<3, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev); break;
+    case 0: hipLaunchKernelGGL((point_reset_kernel<0, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim); break;
+    case 1: hipLaunchKernelGGL((point_reset_kernel<1, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim); break;
+    case 2: hipLaunchKernelGGL((point_reset_kernel<2, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim); break;
+    default: hipLaunchKernelGGL((point_reset_kernel<3, 0>), dim3(nb), dim3(256), 0, st, h->point_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim); break;
   }
   return hipGetLastError();
 }

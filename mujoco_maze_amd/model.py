@@ -25,9 +25,10 @@ from mujoco_maze_amd import robots as R
 from mujoco_maze_amd.maze_env_utils import CollisionDetector, MazeCell
 from mujoco_maze_amd.maze_task import MazeTask, device_reward_descriptor
 
-MZ_ABI_VERSION = 4
+MZ_ABI_VERSION = 5
 MAX_BODY, MAX_JNT, MAX_DOF, MAX_Q, MAX_GEOM, MAX_ACT = 24, 24, 24, 28, 24, 8
 MAX_GRID, MAX_SEG, MAX_GOAL, MAX_OBS = 12, 96, 8, 48
+VIEW_DIM = 75  # MZ_VIEW_DIM: the 5 x 5 x 3 top-down view (maze_env.py:95)
 
 i32, f64, u8 = C.c_int32, C.c_double, C.c_uint8
 
@@ -74,7 +75,7 @@ class MzModel(C.Structure):
         ("forward_reward_weight", f64), ("ctrl_cost_weight", f64),
         ("nblock", i32), ("observe_blocks", i32), ("block_bodyid", i32 * 4), ("block_geomid", i32 * 4),
         ("nball", i32), ("observe_balls", i32), ("ball_bodyid", i32 * 4), ("ball_geomid", i32 * 4),
-        ("elevated", i32), ("pad3", i32), ("height_offset", f64),
+        ("elevated", i32), ("top_down_view", i32), ("height_offset", f64),
     ]
 
 
@@ -285,8 +286,10 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     blocks = world.movable_cells()
     if balls and blocks:
         raise NotImplementedError("object balls together with movable blocks")
-    if any(cell.can_spin() or cell.is_half_block() for _, _, cell in blocks):
-        raise NotImplementedError("SPIN / half blocks are not supported (no registered task uses them)")
+    if any(cell.can_spin() for _, _, cell in blocks):
+        raise NotImplementedError("SPIN blocks (ball joint) are not supported (no registered task uses them)")
+    if len({cell.is_half_block() for _, _, cell in blocks}) > 1:
+        raise NotImplementedError("mazes that mix half blocks with full-size blocks (the device keeps one block size per maze)")
     if len(blocks) > 3:
         raise NotImplementedError("more than 3 movable blocks")
     if world.rows > MAX_GRID or world.cols > MAX_GRID:
@@ -327,7 +330,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         # a block spawns INSIDE the platform box of its own cell (DESIGN.md section 8 describes what follows from that).
         bx, by = world.cell_center(bi_, bj_)
         falling = cell.can_move_z()
-        half = world.scale * 0.5 * (0.99 if falling else 1.0)
+        # shrink (maze_env.py:575-586): falling blocks 0.99, XY_HALF_BLOCK 0.5, else 1
+        half = world.scale * 0.5 * (0.99 if falling else 0.5 if cell.is_half_block() else 1.0)
         geom = dataclasses.replace(spec.wall_geom_defaults, name=f"block_{bi_}_{bj_}", type=R.BOX, size=(half, half, world.half_z),
                                    pos=(0.0, 0.0, 0.0), fromto=None, mass=0.001 if falling else 0.0002, contype=1, conaffinity=1)
         joints = []
@@ -582,8 +586,9 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         # swimmer.py:50-69 / reacher.py: _get_obs returns the WHOLE qpos / qvel and reset_model re-randomises all of it —
         # the slide joints of a movable block included (SwimmerPush: obs 18 = 7 + 7 + block xyz + t)
         m.nq_robot, m.nv_robot = m.nq, m.nv
+    m.top_down_view = int(bool(task.TOP_DOWN_VIEW))
     m.obs_dim = (m.nq_robot + m.nv_robot + 1 + (3 * len(blocks) if task.OBSERVE_BLOCKS else 0)
-                 + (3 * len(balls) if task.OBSERVE_BALLS else 0))
+                 + (3 * len(balls) if task.OBSERVE_BALLS else 0) + (VIEW_DIM if task.TOP_DOWN_VIEW else 0))
     cm = CompiledModel(m, spec, world, task, device_rewards)
     cm.extra = extra
     return cm

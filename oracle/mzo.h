@@ -63,6 +63,8 @@ typedef struct {
 void mzo_env_step(const mz_model* m, mzo_env_state* s, const double* action, double* obs, double* reward, uint8_t* done,
                   int32_t* goal_idx, double* info4, double solver_tol);
 void mzo_env_obs(const mz_model* m, const mzo_env_state* s, double* obs);
+/* MazeEnv.get_top_down_view (maze_env.py:262-349): view[MZ_VIEW_DIM] from the torso position and the movable blocks' xy */
+void mzo_top_down_view(const mz_model* m, double robot_x, double robot_y, int nblock, const double* block_xy, double* view);
 /* reset distribution (ant.py:84-96, point.py:71-81) with the library's counter-based RNG */
 void mzo_env_reset(const mz_model* m, mzo_env_state* s, uint64_t seed, uint64_t env_index);
 

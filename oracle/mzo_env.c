@@ -124,7 +124,61 @@ void mzo_task_eval(const mz_model* m, const double* obs, double* reward, int* do
   *goal_idx = first;
 }
 
+/* ---------------------------------------------------------------- top-down view (maze_env.py:262-349) */
+/* Python's `x % 1` for floats (CPython float_rem): fmod, moved into [0, 1) */
+static double py_mod1(double x) {
+  double r = fmod(x, 1.0);
+  if (r != 0.0) { if (r < 0.0) r += 1.0; }
+  else r = 0.0;
+  return r;
+}
+
+/* update_view (maze_env.py:268-320): a source at fractional grid coordinates (row, col) spreads a unit square over the
+ * cell int(row), int(col) — Python's int() truncates towards zero while `% 1` floors, which is what the reference does
+ * for negative coordinates too — and its eight neighbours */
+static void view_splat(double* view, double row, double col, int d) {
+  if (!(fabs(row) < 1e9) || !(fabs(col) < 1e9)) return;
+  int r0 = (int)row, c0 = (int)col;
+  double rf = py_mod1(row), cf = py_mod1(col);
+  double wr[3] = {fmax(0.0, 0.5 - rf), fmin(1.0, rf + 0.5) - fmax(0.0, rf - 0.5), fmax(0.0, rf - 0.5)};
+  double wc[3] = {fmax(0.0, 0.5 - cf), fmin(1.0, cf + 0.5) - fmax(0.0, cf - 0.5), fmax(0.0, cf - 0.5)};
+  for (int a = -1; a <= 1; a++)
+    for (int b = -1; b <= 1; b++) {
+      int r = r0 + a, c = c0 + b;
+      if (r >= 0 && r < 5 && c >= 0 && c < 5) view[(r * 5 + c) * 3 + d] += wr[a + 1] * wc[b + 1];
+    }
+}
+
+/* get_top_down_view: walls -> channel 0, chasms -> channel 1, movable blocks (body positions, creation order) -> channel 2,
+ * all relative to the torso position (robot_x, robot_y); `_xy_to_rowcol` (maze_env.py:90-93) puts the robot at (2.5, 2.5) */
+void mzo_top_down_view(const mz_model* m, double robot_x, double robot_y, int nblock, const double* block_xy, double* view) {
+  const double sc = m->maze_scale;
+  for (int k = 0; k < MZ_VIEW_DIM; k++) view[k] = 0.0;
+  for (int i = 0; i < m->grid_rows; i++)
+    for (int j = 0; j < m->grid_cols; j++) {
+      int cell = m->grid[i][j];
+      if (cell != MZ_CELL_BLOCK && cell != MZ_CELL_CHASM) continue;
+      double x = (double)j * sc - m->torso_x, y = (double)i * sc - m->torso_y;
+      x = x - robot_x;
+      y = y - robot_y;
+      view_splat(view, 2.0 + (y + sc / 2.0) / sc, 2.0 + (x + sc / 2.0) / sc, cell == MZ_CELL_BLOCK ? 0 : 1);
+    }
+  for (int b = 0; b < nblock; b++) {
+    double x = block_xy[2 * b] - robot_x, y = block_xy[2 * b + 1] - robot_y;
+    view_splat(view, 2.0 + (y + sc / 2.0) / sc, 2.0 + (x + sc / 2.0) / sc, 2);
+  }
+}
+
 /* ---------------------------------------------------------------- obs */
+static void body_origin(const mz_model* m, const mzo_env_state* s, int body, double* p) {
+  for (int c = 0; c < 3; c++) p[c] = m->body_pos[body][c];
+  for (int j = m->body_jntadr[body]; j < m->body_jntadr[body] + m->body_jntnum[body]; j++)
+    if (m->jnt_type[j] == MZ_JNT_SLIDE) {
+      double q = s->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
+      for (int c = 0; c < 3; c++) p[c] += m->jnt_axis[j][c] * q;
+    }
+}
+
 void mzo_env_obs(const mz_model* m, const mzo_env_state* s, double* obs) {
   int k = 0;
   for (int i = 0; i < 3; i++) obs[k++] = s->qpos[i];
@@ -133,18 +187,19 @@ void mzo_env_obs(const mz_model* m, const mzo_env_state* s, double* obs) {
   for (int pass = 0; pass < 2; pass++) {
     int n = pass == 0 ? (m->observe_balls ? m->nball : 0) : (m->observe_blocks ? m->nblock : 0);
     for (int b = 0; b < n; b++) {
-      int body = pass == 0 ? m->ball_bodyid[b] : m->block_bodyid[b];
-      double p[3] = {m->body_pos[body][0], m->body_pos[body][1], m->body_pos[body][2]};
-      for (int j = m->body_jntadr[body]; j < m->body_jntadr[body] + m->body_jntnum[body]; j++)
-        if (m->jnt_type[j] == MZ_JNT_SLIDE) {
-          double q = s->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
-          for (int c = 0; c < 3; c++) p[c] += m->jnt_axis[j][c] * q;
-        }
+      double p[3];
+      body_origin(m, s, pass == 0 ? m->ball_bodyid[b] : m->block_bodyid[b], p);
       for (int c = 0; c < 3; c++) obs[k++] = p[c];
     }
   }
   for (int i = 3; i < m->nq_robot; i++) obs[k++] = s->qpos[i];
   for (int i = 0; i < m->nv_robot; i++) obs[k++] = s->qvel[i];
+  if (m->top_down_view) { /* maze_env.py:353-354,369: the view sits before the time entry; torso position = qpos[:2] of every robot */
+    double bxy[8], p[3];
+    for (int b = 0; b < m->nblock; b++) { body_origin(m, s, m->block_bodyid[b], p); bxy[2 * b] = p[0]; bxy[2 * b + 1] = p[1]; }
+    mzo_top_down_view(m, s->qpos[0], s->qpos[1], m->nblock, bxy, obs + k);
+    k += MZ_VIEW_DIM;
+  }
   obs[k++] = s->t * 0.001; /* maze_env.py:369 */
 }
 

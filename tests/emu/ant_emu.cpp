@@ -74,6 +74,8 @@ static int make_dev(AntDev* K, const mz_model* m, int max_iter, float tol, float
   return MZ_OK;
 }
 
+#include "../../mujoco_maze_amd/csrc/mz_view.h"
+
 extern "C" {
 
 
@@ -200,6 +202,19 @@ extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float
 }
 
 // ---------------------------------------------------------------- the bit-exact pieces, for CPU tests against the golden vectors
+// MazeEnv.get_top_down_view exactly as view_fill_kernel evaluates it (csrc/mz_view.h): float64 entries for one torso / block
+// placement, and the in-place fill of fp32 observation rows whose view slots hold the parked block positions
+extern "C" void emu_top_down_view(const mz_model* m, double rx, double ry, const double* bxy, double* view) {
+  ViewDev V;
+  view_dev_from_model(m, &V);
+  for (int idx = 0; idx < MZ_VIEW_DIM; idx++) view[idx] = mzv_entry(V, rx, ry, bxy, idx);
+}
+extern "C" void emu_view_fill_rows(const mz_model* m, int n, int ostride, int view_off, float* rows) {
+  ViewDev V;
+  view_dev_from_model(m, &V);
+  for (int e = 0; e < n; e++) mzv_fill_row(V, rows + (size_t)e * ostride, view_off);
+}
+
 extern "C" double emu_hypot(double x, double y) { return mz_hypot(x, y); }
 
 // CollisionDetector.detect + bounce rule on n moves (the code of point_detect_kernel); hit: 0 / 1 bounce / 2 give-up / -1 collinear

@@ -110,6 +110,28 @@ def point_detect(cm, old_xy, new_xy):
     return hit, pt, fin
 
 
+def top_down_view(cm, robot_xy, block_xy=()):
+    """mzv_entry of csrc/mz_view.h (the code of view_fill_kernel), float64: view [75] for a torso at robot_xy, blocks at block_xy."""
+    lib = load()
+    b = np.zeros(8)
+    flat = np.asarray(block_xy, np.float64).reshape(-1)
+    b[:len(flat)] = flat
+    view = np.zeros(75)
+    lib.emu_top_down_view.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    lib.emu_top_down_view.restype = None
+    lib.emu_top_down_view(C.byref(cm.c), float(robot_xy[0]), float(robot_xy[1]), _vp(b), _vp(view))
+    return view
+
+
+def view_fill_rows(cm, rows, view_off):
+    """mzv_fill_row on fp32 observation rows [n, obs_dim] whose view slots hold the parked block positions (in place)."""
+    lib = load()
+    r = np.ascontiguousarray(rows, np.float32)
+    lib.emu_view_fill_rows.restype = None
+    lib.emu_view_fill_rows(C.byref(cm.c), r.shape[0], r.shape[1], int(view_off), _vp(r))
+    return r
+
+
 def task_eval(cm, obs):
     """task_eval_dev of csrc/ant_dyn.h on fp32 observation rows [n, obs_dim]: (reward, done, goal_idx)."""
     lib = load()

@@ -11,6 +11,10 @@ byte-identical.  Outputs are data only — values the reference's assets hold or
                    (the reference's own `_get_obs` of AntEnv / PointEnv / SwimmerEnv / ReacherEnv + MazeEnv._get_obs run on
                    sentinel-valued qpos / qvel / body positions), and which qpos / qvel entries `reset_model` re-randomises
                    and with which distribution (the reference's reset_model run with a marker RNG).
+  views.json       MazeEnv.get_top_down_view (maze_env.py:262-349) and the observation that carries it (`TOP_DOWN_VIEW` tasks,
+                   maze_env.py:351-369) for custom tasks derived from the reference's UMaze / Push / Fall / 4Rooms tasks: robot
+                   and block positions in, the reference's 5 x 5 x 3 view and full observation out.
+  custom_worlds.json  the world the reference generates for a custom maze with XY_HALF_BLOCK cells (maze_env.py:583-584).
 """
 import json
 import os
@@ -200,6 +204,83 @@ LAYOUT_IDS = ["AntUMaze-v0", "AntPush-v0", "AntMultiPush-v0", "AntFall-v0", "Ant
               "ReacherUMaze-v0", "ReacherPush-v0"]
 
 
+# ---------------------------------------------------------------- views.json / custom_worlds.json
+from mujoco_maze import maze_task  # noqa: E402
+
+
+class _ViewRobot(G._FakeAnt):
+    """Kinematic stand-in whose torso and movable bodies sit wherever the generator puts them."""
+
+    def get_body_com(self, name):
+        if name == "torso":
+            return np.array([self.xy[0], self.xy[1], 0.75])
+        return self.bodies[name].copy()
+
+
+def _view_task(base, name):
+    return type(name, (base,), dict(TOP_DOWN_VIEW=True))
+
+
+VIEW_CASES = [("ViewUMaze", maze_task.GoalRewardUMaze, 8.0), ("ViewPush", maze_task.GoalRewardPush, 8.0),
+              ("ViewFall", maze_task.GoalRewardFall, 8.0), ("View4Rooms", maze_task.GoalReward4Rooms, 4.0),
+              ("ViewMultiPush", maze_task.GoalRewardMultiPush, 4.0)]
+
+
+def dump_views(rng):
+    out = {}
+    for name, base, scale in VIEW_CASES:
+        env = maze_env.MazeEnv(model_cls=_ViewRobot, maze_task=_view_task(base, name), maze_size_scaling=scale)
+        w = env.wrapped_env
+        rows, cols = len(env._maze_structure), len(env._maze_structure[0])
+        lo = np.array([-0.5 * scale - env._init_torso_x, -0.5 * scale - env._init_torso_y])
+        hi = np.array([(cols - 0.5) * scale - env._init_torso_x, (rows - 0.5) * scale - env._init_torso_y])
+        cases = []
+        for k in range(36):
+            # inside the maze mostly; every 6th sample up to two cells outside (negative / beyond-the-grid rows and columns)
+            pad = 2.0 * scale if k % 6 == 5 else 0.0
+            w.xy = rng.uniform(lo - pad, hi + pad)
+            if k == 0:
+                w.xy = np.zeros(2)  # the spawn position: everything sits on cell centres
+            blocks = []
+            for bname in env.movable_blocks:
+                p = w.bodies[bname]
+                p[:2] = rng.uniform(lo, hi) if k else p[:2]
+                blocks.append([float(p[0]), float(p[1])])
+            env.t = k
+            view = env.get_top_down_view().copy()
+            obs = env._get_obs()
+            cases.append(dict(robot_xy=[float(w.xy[0]), float(w.xy[1])], block_xy=blocks, view=[float(v) for v in view.flat],
+                              obs=[float(v) for v in obs]))
+        out[name] = dict(base=base.__name__, scale=scale, grid=G.grid_text(env._maze_structure), obs_dim=len(cases[0]["obs"]),
+                         movable=list(env.movable_blocks), cases=cases)
+    return out
+
+
+class _HalfBlockMaze(maze_task.GoalRewardPush):
+    @staticmethod
+    def create_maze():
+        E, B, R, H, M = (maze_task.MazeCell.EMPTY, maze_task.MazeCell.BLOCK, maze_task.MazeCell.ROBOT, maze_task.MazeCell.XY_HALF_BLOCK,
+                         maze_task.MazeCell.XY_BLOCK)
+        return [[B, B, B, B, B],
+                [B, E, H, E, B],
+                [B, R, E, H, B],
+                [B, E, E, E, B],
+                [B, B, B, B, B]]
+
+
+def dump_custom_worlds():
+    out = {}
+    for fake, tag in ((G._FakeAnt, "ant"), (G._FakePoint, "point")):
+        env = maze_env.MazeEnv(model_cls=fake, maze_task=_HalfBlockMaze, maze_size_scaling=4.0)
+        real_build = G.build_env
+        G.build_env = lambda _id, env=env: env
+        try:
+            out[f"HalfBlockMaze/{tag}"] = dict(G.dump_world("custom"), grid=G.grid_text(env._maze_structure), scale=4.0)
+        finally:
+            G.build_env = real_build
+    return out
+
+
 def main():
     robots = {n: dump_robot(f"{n}.xml") for n in ("ant", "point", "swimmer", "reacher")}
     with open(os.path.join(HERE, "robots.json"), "w") as f:
@@ -209,6 +290,16 @@ def main():
         json.dump(layouts, f, indent=0, sort_keys=True)
     for e, l in layouts.items():
         print(e, l["obs_dim"], l["layout"][:8], "...")
+    views = dump_views(np.random.default_rng(20260929))
+    with open(os.path.join(HERE, "views.json"), "w") as f:
+        json.dump(views, f, indent=0, sort_keys=True)
+    for n, v in views.items():
+        print(n, v["obs_dim"], v["grid"], "nonzero view entries of case 0:", sum(1 for x in v["cases"][0]["view"] if x))
+    worlds = dump_custom_worlds()
+    with open(os.path.join(HERE, "custom_worlds.json"), "w") as f:
+        json.dump(worlds, f, indent=0, sort_keys=True)
+    for n, v in worlds.items():
+        print(n, [(b["name"], b["geom"]["size"]) for b in v["movable"]])
 
 
 if __name__ == "__main__":

@@ -76,6 +76,15 @@ class Oracle:
         self.lib.mzo_task_eval(C.byref(cm.c), np.ascontiguousarray(obs, np.float64), C.byref(r), C.byref(d), C.byref(g))
         return r.value, bool(d.value), g.value
 
+    def top_down_view(self, cm, robot_xy, block_xy=()):
+        """MazeEnv.get_top_down_view for a torso at robot_xy and movable blocks at block_xy [nblock][2] -> view [75]."""
+        view = np.zeros(75)
+        b = np.ascontiguousarray(np.asarray(block_xy, np.float64).reshape(-1))
+        self.lib.mzo_top_down_view.argtypes = [C.POINTER(MzModel), C.c_double, C.c_double, C.c_int, f64p, f64p]
+        self.lib.mzo_top_down_view.restype = None
+        self.lib.mzo_top_down_view(C.byref(cm.c), float(robot_xy[0]), float(robot_xy[1]), len(b) // 2, b if len(b) else np.zeros(2), view)
+        return view
+
     # -- batch
     def reset(self, cm, n, seed, mask=None, env0=0):
         m = cm.c

@@ -80,7 +80,7 @@ def test_native_library_is_the_in_tree_one(torch):
     assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
     from mujoco_maze_amd.model import MZ_ABI_VERSION
 
-    assert lib.mz_abi_version() == MZ_ABI_VERSION == 4
+    assert lib.mz_abi_version() == MZ_ABI_VERSION == 5
 
 
 def _rollout_states(oracle, cm, n, seed, checkpoints, robot="ant"):
