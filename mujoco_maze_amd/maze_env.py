@@ -267,6 +267,23 @@ class VecMazeEnv:
     def kernel_ms(self) -> float:
         return float(self._lib.mz_last_kernel_ms(self._h))
 
+    # -- render / export bridge (render.py; reference: MazeEnv.render, maze_env.py:389-420) ----------------------------
+    def render(self, mode: str = "rgb_array", env_index: int = 0, image_shape: Tuple[int, int] = (600, 480)):
+        """Top view of env `env_index` as an uint8 [H, W, 3] array: its state is pulled from the device and rasterised on the
+        host (render.render_top_down).  There is no GL context or websocket server next to a device batch: every mode
+        returns the array."""
+        from mujoco_maze_amd import render as R
+
+        qpos = self.get_state()[0][env_index].double().cpu().numpy()
+        return R.render_top_down(self.model, qpos, image_shape)
+
+    def state_for_viewer(self, env_index: int = 0) -> dict:
+        """MJCF of the model + the env's qpos / qvel (plain lists) for replay in an external MuJoCo viewer."""
+        from mujoco_maze_amd import render as R
+
+        qpos, qvel, _, _ = self.get_state()
+        return R.state_for_viewer(self.model, qpos[env_index].double().cpu().numpy(), qvel[env_index].double().cpu().numpy())
+
     @property
     def has_extended_obs(self) -> bool:
         return bool(self._task.TOP_DOWN_VIEW or self._task.OBSERVE_BLOCKS or self._task.OBSERVE_BALLS)
@@ -288,6 +305,12 @@ class MazeEnv:
         self.action_space = self.vec.action_space
         self.observation_space = self.vec.observation_space
         self._max_steps = self.vec.model.c.max_episode_steps
+        self._image_shape = image_shape
+
+    def render(self, mode="human", **kwargs):
+        """The reference hands back MuJoCo's camera image (or pushes it to its websocket viewer); here: the host-side top
+        view of the device state (render.py), as an uint8 [H, W, 3] array in every mode."""
+        return self.vec.render(mode, 0, self._image_shape)
 
     @property
     def unwrapped(self):

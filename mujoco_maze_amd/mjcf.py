@@ -245,3 +245,32 @@ def spec_from_mjcf(source: str, like: R.RobotSpec) -> R.RobotSpec:
                        nq_robot=nq, nv_robot=nv, density=float(oa.get("density", 0.0)), viscosity=float(oa.get("viscosity", 0.0)),
                        collision_predefined=oa.get("collision", "all") == "predefined", reset_qvel=like.reset_qvel,
                        torso_z=bodies[0].pos[2])
+
+
+def world_to_mjcf(cm, name: str = "") -> str:
+    """MJCF of a compiled model as this repository steps it: the robot spec (with the movable bodies compile_model appended),
+    the maze boxes and platforms, the goal sites — in the element order of the reference's generator (maze_env.py:97-218).
+    Used by tools/export_mjcf.py, tests/test_mujoco_crosscheck.py and render.state_for_viewer."""
+    root = ET.fromstring(spec_to_mjcf(cm.spec))
+    root.set("model", f"{cm.spec.name}:{name}" if name else cm.spec.name)
+    wb = root.find("worldbody")
+    fmt = lambda v: " ".join(repr(float(x)) for x in v)  # noqa: E731
+    w = cm.world
+    # maze boxes: children of the world body, contype = conaffinity = 1 (maze_env.py:134-135,149-150), everything else
+    # from the asset's <default><geom>
+    for i in range(w.rows):
+        for j in range(w.cols):
+            cell = w.structure[i][j]
+            x, y = w.cell_center(i, j)
+            if w.elevated and not cell.is_chasm():  # platform under every cell that is not a chasm (maze_env.py:124-137)
+                ET.SubElement(wb, "geom", name=f"elevated_{i}_{j}", type="box", pos=fmt((x, y, w.half_z)),
+                              size=fmt((w.scale * 0.5, w.scale * 0.5, w.half_z)), contype="1", conaffinity="1")
+            if cell.is_block():
+                ET.SubElement(wb, "geom", name=f"block_{i}_{j}", type="box", pos=fmt((x, y, w.half_z + w.height_offset)),
+                              size=fmt((w.scale * 0.5, w.scale * 0.5, w.half_z)), contype="1", conaffinity="1")
+    for gi, g in enumerate(cm.task.goals):
+        z = float(g.pos[2]) if g.dim >= 3 else 0.0
+        size = w.scale * 0.1 if g.custom_size is None else g.custom_size
+        ET.SubElement(wb, "site", name=f"goal_site{gi}", pos=fmt((g.pos[0], g.pos[1], z)), size=repr(float(size)))
+    ET.indent(root)
+    return ET.tostring(root, encoding="unicode")

@@ -1,0 +1,81 @@
+"""Render / export bridge: the host-side top view of a device state and the MJCF + state dump."""
+import numpy as np
+import pytest
+
+import mujoco_maze_amd as mm
+from mujoco_maze_amd import model, render
+
+
+def _compiled(env_id):
+    spec = mm.REGISTRY[env_id]
+    kw = spec.kwargs
+    scale = kw["maze_size_scaling"]
+    return model.compile_model(kw["model_cls"].ROBOT, kw["maze_task"](scale), scale)
+
+
+@pytest.mark.parametrize("env_id", ["AntUMaze-v0", "PointPush-v0", "PointBilliard-v0", "SwimmerUMaze-v0", "ReacherUMaze-v0", "AntFall-v0"])
+def test_top_view_shows_walls_goal_robot_and_movables(env_id):
+    cm = _compiled(env_id)
+    m = cm.c
+    qpos = np.array([m.qpos0[i] for i in range(m.nq)])
+    img = render.render_top_down(cm, qpos, (300, 240))
+    assert img.shape == (240, 300, 3) and img.dtype == np.uint8
+    colours = {tuple(c) for c in img.reshape(-1, 3)}
+    assert render.WALL in colours and render.FLOOR in colours and render.ROBOT in colours
+    goal = cm.task.goals[0]
+    assert tuple(int(round(255 * v)) for v in goal.rgb) in colours
+    if m.nblock:
+        assert render.BLOCK in colours
+    if m.nball:
+        assert render.BALL in colours
+    if m.elevated:
+        assert render.CHASM in colours
+    # the robot is drawn where qpos says: move it one cell and the robot-coloured pixels move with it
+    def centroid(im):
+        ys, xs = np.where((im == np.array(render.ROBOT)).all(-1))
+        return xs.mean(), ys.mean()
+    c0 = centroid(img)
+    q2 = qpos.copy()
+    q2[0] += 0.5 * cm.world.scale
+    c1 = centroid(render.render_top_down(cm, q2, (300, 240)))
+    assert c1[0] > c0[0] + 5 and abs(c1[1] - c0[1]) < 2  # +x is to the right, y unchanged
+
+
+def test_block_moves_in_the_image():
+    cm = _compiled("AntPush-v0")
+    m = cm.c
+    qpos = np.array([m.qpos0[i] for i in range(m.nq)])
+    def block_centroid(q):
+        im = render.render_top_down(cm, q, (300, 240))
+        ys, xs = np.where((im == np.array(render.BLOCK)).all(-1))
+        return xs.mean(), ys.mean()
+    c0 = block_centroid(qpos)
+    q2 = qpos.copy()
+    q2[16] += 2.0  # the block's y slide: up in the image (rows grow with y in the world, image row 0 is the top)
+    c1 = block_centroid(q2)
+    assert c1[1] < c0[1] - 3 and abs(c1[0] - c0[0]) < 2
+
+
+def test_state_for_viewer_is_plain_data():
+    import json
+    import xml.etree.ElementTree as ET
+
+    cm = _compiled("PointFall-v0")
+    m = cm.c
+    d = render.state_for_viewer(cm, [m.qpos0[i] for i in range(m.nq)], [0.0] * m.nv)
+    json.dumps(d)
+    root = ET.fromstring(d["mjcf"])
+    assert root.tag == "mujoco" and len(d["qpos"]) == m.nq and len(d["qvel"]) == m.nv
+    assert any(g.get("name", "").startswith("elevated_") for g in root.iter("geom"))
+
+
+@pytest.mark.gpu
+def test_render_pulls_the_device_state():
+    env = mm.make("PointUMaze-v0", num_envs=8)
+    env.reset(seed=0)
+    img = env.render(env_index=3, image_shape=(200, 160))
+    assert img.shape == (160, 200, 3) and (img == np.array(render.ROBOT)).all(-1).any()
+    single = mm.make("AntUMaze-v0")
+    single.reset()
+    assert single.render("rgb_array").shape == (480, 600, 3)
+    assert len(env.state_for_viewer(2)["qpos"]) == env.nq

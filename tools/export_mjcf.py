@@ -35,32 +35,7 @@ def compile_for(env_id, **overrides):
 def export_mjcf(env_id: str, cm=None, **overrides) -> str:
     from mujoco_maze_amd import mjcf
 
-    cm = cm or compile_for(env_id, **overrides)
-    root = ET.fromstring(mjcf.spec_to_mjcf(cm.spec))
-    root.set("model", f"{cm.spec.name}:{env_id}")
-    wb = root.find("worldbody")
-    fmt = lambda v: " ".join(repr(float(x)) for x in v)
-    w = cm.world
-    # maze boxes: children of the world body, contype = conaffinity = 1 (maze_env.py:134-135,149-150), everything else
-    # from the asset's <default><geom>
-    k = 0
-    for i in range(w.rows):
-        for j in range(w.cols):
-            cell = w.structure[i][j]
-            x, y = w.cell_center(i, j)
-            if w.elevated and not cell.is_chasm():  # platform under every cell that is not a chasm (maze_env.py:124-137)
-                ET.SubElement(wb, "geom", name=f"elevated_{i}_{j}", type="box", pos=fmt((x, y, w.half_z)),
-                              size=fmt((w.scale * 0.5, w.scale * 0.5, w.half_z)), contype="1", conaffinity="1")
-            if cell.is_block():
-                ET.SubElement(wb, "geom", name=f"block_{i}_{j}", type="box", pos=fmt((x, y, w.half_z + w.height_offset)),
-                              size=fmt((w.scale * 0.5, w.scale * 0.5, w.half_z)), contype="1", conaffinity="1")
-                k += 1
-    for gi, g in enumerate(cm.task.goals):
-        z = float(g.pos[2]) if g.dim >= 3 else 0.0
-        size = w.scale * 0.1 if g.custom_size is None else g.custom_size
-        ET.SubElement(wb, "site", name=f"goal_site{gi}", pos=fmt((g.pos[0], g.pos[1], z)), size=repr(float(size)))
-    ET.indent(root)
-    return ET.tostring(root, encoding="unicode")
+    return mjcf.world_to_mjcf(cm or compile_for(env_id, **overrides), name=env_id)
 
 
 if __name__ == "__main__":
