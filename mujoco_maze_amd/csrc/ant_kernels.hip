@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
       for (int k = 0; k < 16; k++) if (k != 13 && k != 14) atomicAdd(&prof[k], (unsigned long long)s.prof[k]);
       atomicMax(&prof[13], tot);                  // slowest wave of the accumulation window
       atomicAdd(&prof[14], (tot >> 8) * (tot >> 8));  // sum of squares of the per-wave totals (units of 256 cycles)
-      prof[16 + blockIdx.x] += tot;               // per-workgroup totals (mz_read_wave_cycles)
+      // per-workgroup totals (mz_read_wave_cycles): cycles in the low 40 bits, Newton iterations of the wave above them
+      prof[16 + blockIdx.x] += tot + ((unsigned long long)s.prof[15] << 40);
     }
   }
 }

@@ -279,7 +279,8 @@ int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host) {
   return MZ_OK;
 }
 
-// Per-workgroup cycle totals accumulated by the PROF kernel build since the last call (then cleared): n_host entries.
+// Per-workgroup totals accumulated by the PROF kernel build since the last call (then cleared): n_host entries, each
+// cycles (low 40 bits) + the Newton iterations the workgroup ran (bits 40 and up).
 int32_t mz_read_wave_cycles(mz_handle* h, uint64_t* out_host, int32_t n_host) {
   if (!h || !out_host || !h->prof || n_host <= 0 || n_host > h->n) return MZ_ERR_ARG;
   DeviceScope scope(h->device);

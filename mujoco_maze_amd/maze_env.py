@@ -262,7 +262,8 @@ class VecMazeEnv:
         """Per-workgroup cycle totals of the instrumented kernel since the last call (numpy uint64 [n])."""
         out = np.zeros(n, np.uint64)
         _capi.check(self._lib, self._h, self._lib.mz_read_wave_cycles(self._h, out.ctypes.data_as(C.c_void_p), n), "mz_read_wave_cycles")
-        return out
+        self.last_wave_newton_iters = out >> np.uint64(40)  # Newton iterations the wave ran (packed above the cycle count)
+        return out & np.uint64((1 << 40) - 1)
 
     def kernel_ms(self) -> float:
         return float(self._lib.mz_last_kernel_ms(self._h))
