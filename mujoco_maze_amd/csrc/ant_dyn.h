@@ -60,19 +60,24 @@ struct HostCtx {
 };
 
 // ------------------------------------------------------------------ sizes
-// The template parameter NB of everything below is a block CONFIGURATION: 0-3 = that many movable blocks with two slides
-// each (x y in the Push family, y z / x z falling blocks); 4 = ONE block with three slides (MultiFall's XYZ block).
+// The template parameter NB of everything below is a CONFIGURATION of movable bodies: 0-3 = that many movable blocks with two
+// slides each (x y in the Push family, y z / x z falling blocks); 4 = ONE block with three slides (MultiFall's XYZ block);
+// 5 = one object ball on a free joint (AntSmallBilliard): six more hub dofs (3 linear world-frame, 3 angular body-frame) and a
+// 7-number pose, no blocks.
 template <int NB>
 struct AntDims {
-  static constexpr int NBLK = NB == 4 ? 1 : NB;  // movable blocks
+  static constexpr bool BALL = NB == 5;
+  static constexpr int NBLK = NB == 4 ? 1 : (NB == 5 ? 0 : NB);  // movable blocks
   static constexpr int BD = NB == 4 ? 3 : 2;     // slide dofs per block
-  static constexpr int NH = 6 + BD * NBLK;   // hub dofs: root 6 + the blocks' slides
-  static constexpr int NV = 14 + BD * NBLK;  // MuJoCo dof order: root 0-5, legs 6-13, blocks 14..
-  static constexpr int NQ = 15 + BD * NBLK;
+  static constexpr int NXH = BALL ? 6 : BD * NBLK;  // hub dofs beyond the root's six
+  static constexpr int NMOV = NBLK + (BALL ? 1 : 0);  // movable bodies = the first contact enumerators
+  static constexpr int NH = 6 + NXH;         // hub dofs: root 6 + the blocks' slides / the ball's six
+  static constexpr int NV = 14 + NXH;        // MuJoCo dof order: root 0-5, legs 6-13, movable bodies 14..
+  static constexpr int NQ = 15 + (BALL ? 7 : BD * NBLK);
   static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
   // contact slots: a block resting in a corridor holds 4 floor corners + 4 per adjacent wall/block face
-  static constexpr int NC = NB == 0 ? 16 : ((NB == 1 || NB == 4) ? 28 : (NB == 2 ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each)
-  static constexpr int NGEOM = 13 + NBLK;  // contact enumerators: blocks first, then the 13 robot geoms
+  static constexpr int NC = NB == 0 ? 16 : ((NB == 1 || NB == 4 || NB == 5) ? 28 : (NB == 2 ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each)
+  static constexpr int NGEOM = 13 + NMOV;  // contact enumerators: movable bodies first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;
   static constexpr int REC_T = NQ + 2 * NV;              // state record: qpos | qvel | warm | t | episode
@@ -106,6 +111,7 @@ struct alignas(16) AntScratchT {
   int nearwall;                  // 0: no maze wall within the ant's reach of the torso (wall tests skipped)
   float p1[4][3], p2[4][3];      // aux / ankle body origins
   float w[12][3], com[12][3];    // capsule axis and centre of body 1 + 3l + k
+  float bR[9], bx[3], bc[3];     // object ball (config 5): rotation (row-major), body origin and sphere centre relative to the torso origin
   float zw[3];                   // hip axis (world) = R0 * ez
   float Sh[4][3], Sa[4][6];      // hip: linear part (angular = zw); ankle: angular, linear
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
@@ -258,6 +264,16 @@ MZ_HD void kin_item(const AntDev& K, AntScratchT<NB>& s, int l) {
       s.nearwall = near;
       return;
     }
+    if constexpr (AntDims<NB>::BALL) {
+      if (l == 5) {  // object ball: pose from qpos[15:22] (quaternion normalised as mj_kinematics does), relative to the torso origin
+        float R[9];
+        quat_to_matf(R, s.qpos + 18);
+        for (int k = 0; k < 9; k++) s.bR[k] = R[k];
+        s.bx[0] = s.qpos[15] - s.qpos[0]; s.bx[1] = s.qpos[16] - s.qpos[1]; s.bx[2] = s.qpos[17] - s.qpos[2];
+        for (int k = 0; k < 3; k++) s.bc[k] = s.bx[k] + R[3 * k + 2] * K.ball_h;  // sphere centre = origin + R (0, 0, h)
+        return;
+      }
+    }
     float R0[9];
     quat_to_matf(R0, s.qpos + 3);
     if (l == 0) {
@@ -352,9 +368,23 @@ template <int NB>
 MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
   constexpr int NH = AntDims<NB>::NH;
 
-    if (e >= 21) {  // block rows of the hub: diag(mass), no coupling
+    if (e >= 21) {  // rows of the movable bodies in the hub: separate trees, no coupling with the robot
       int q = e - 21, i = 6 + q / NH, j = q - (i - 6) * NH;
       float val = (i == j) ? K.block_mass : 0.f;
+      if constexpr (AntDims<NB>::BALL) {
+        // Free body whose centre of mass sits c = (0, 0, h) above the frame origin (body frame); dofs: linear velocity of
+        // the origin (world frame), angular velocity (body frame).  T = m/2 |v + R (w x c)|^2 + I/2 |w|^2  =>
+        //   M = [ m 1,  -m R [c]x ;  sym,  I 1 - m [c]x [c]x ],   -R [c]x = h [ -R[:,1], R[:,0], 0 ],   -[c]x[c]x = h^2 diag(1, 1, 0)
+        const int a = i - 6, b = j - 6;
+        const float mh = K.ball_mass * K.ball_h;
+        val = 0.f;
+        if (b >= 0) {
+          const int lo = a < b ? a : b, hi = a < b ? b : a;
+          if (hi < 3) val = a == b ? K.ball_mass : 0.f;
+          else if (lo >= 3) val = a == b ? K.ball_inertia + (a < 5 ? mh * K.ball_h : 0.f) : 0.f;
+          else val = hi == 3 ? -mh * s.bR[3 * lo + 1] : (hi == 4 ? mh * s.bR[3 * lo] : 0.f);
+        }
+      }
       s.M.rr[i][j] = val; s.M.rr[j][i] = val;
       return;
     }
@@ -438,6 +468,27 @@ MZ_HD void bias_dof_item(const AntDev& K, AntScratchT<NB>& s, int i) {
       }
       s.bias[i] = bb;
       frc = -K.damping * s.qvel[i] - bb + s.fact[i];
+    } else if constexpr (AntDims<NB>::BALL) {
+      // free ball, undamped and unactuated: force at the centre of mass f = m (w_w x (w_w x R c) - g), no torque about it (a
+      // sphere), carried to the frame origin: bias = [ f ;  c x R^T f ]   (w_w = R w, the angular dofs are body-frame)
+      const float* R = s.bR;
+      const float w[3] = {s.qvel[17], s.qvel[18], s.qvel[19]};
+      float ww[3], rc[3], t[3], f[3];
+      mat_vecf(ww, R, w);
+      for (int k = 0; k < 3; k++) rc[k] = R[3 * k + 2] * K.ball_h;
+      cross3f(t, ww, rc);
+      cross3f(f, ww, t);
+      for (int k = 0; k < 3; k++) f[k] *= K.ball_mass;
+      f[2] -= K.ball_mass * K.gz;
+      const int k = i - 14;
+      float bb;
+      if (k < 3) bb = f[k];
+      else {
+        const float lx = R[0] * f[0] + R[3] * f[1] + R[6] * f[2], ly = R[1] * f[0] + R[4] * f[1] + R[7] * f[2];  // R^T f
+        bb = k == 3 ? -K.ball_h * ly : (k == 4 ? K.ball_h * lx : 0.f);
+      }
+      s.bias[i] = bb;
+      frc = -bb;
     } else {  // block slides: undamped, unactuated (maze_env.py:600-648); gravity acts on a z slide (falling blocks)
       const bool zslide = K.block_axis[(i - 14) % AntDims<NB>::BD] == 2;
       s.bias[i] = zslide ? -K.block_mass * K.gz : 0.f;
@@ -826,8 +877,36 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     }
     return;
   }
+  if constexpr (AntDims<NB>::BALL) {
+    if (e == AntDims<NB>::NBLK) {  // ---- object ball (kinds 7: floor -> ball, 8: ball -> wall box)
+      const float rb = K.ball_r;
+      const float dist = (s.cz + s.bc[2]) - rb;
+      if (dist < K.ball_floor.margin) {  // plane-sphere: geom1 = floor, normal +z
+        cg.dist = dist; cg.kind = 7; cg.blk = 0; cg.other = 0;
+        cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
+        cg.pos[0] = s.bc[0]; cg.pos[1] = s.bc[1]; cg.pos[2] = s.bc[2] - (rb + 0.5f * dist);
+        cg.hint[0] = cg.hint[1] = cg.hint[2] = 0.f;
+        emit(cg);
+      }
+      // maze walls: the cells under the sphere's bounding square (sphere-box: geom1 = the sphere)
+      const float reach = rb + K.ball_wall.margin;
+      const float gx = s.qpos[0] + s.bc[0], gy = s.qpos[1] + s.bc[1], gz = s.cz + s.bc[2];
+      if (gz - reach > z.center_z + z.half_z) return;
+      const int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
+      const int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
+      const float zero[3] = {0.f, 0.f, 0.f};
+      for (int i = i0; i <= i1; i++)
+        for (int j = j0; j <= j1; j++) {
+          if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
+          if (!((maze_row_lds(s, i) >> j) & 1u)) continue;
+          float wc[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
+          round_vs_box(true, s.bc, zero, 0.f, rb, wc, bs, K.ball_wall.margin, 8, 0, emit);
+        }
+      return;
+    }
+  }
   // ---- robot geom
-  int b = e - AntDims<NB>::NBLK;
+  int b = e - AntDims<NB>::NMOV;
   int c = body_class(b);
   float r = K.radius[c], hl = K.half_len[c];
   float ctr[3] = {0, 0, 0}, ax[3] = {0, 0, 0};
@@ -855,6 +934,26 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     for (int q = 0; q < 3; q++) { float dd = fmaxf(fabsf(ctr[q] - bc[q]) - K.block_half[q], 0.f); d2 += dd * dd; }
     float reachb = r + hl + K.wall.margin;
     if (d2 < reachb * reachb) round_vs_box(b == 0, ctr, ax, hl, r, bc, K.block_half, K.wall.margin, 2, k, emit);
+  }
+  if constexpr (AntDims<NB>::BALL) {
+    // object ball.  MuJoCo orders a pair by geom type, then by geom id: torso sphere (geom1) -> ball sphere, kind 9; ball sphere
+    // (geom1) -> leg capsule, kind 10 (mjc_SphereCapsule: the point of the capsule's axis segment nearest to the ball, then
+    // sphere-sphere).  The normal points from geom1 to geom2.
+    float x = 0.f, pt[3], dv[3];
+    for (int k = 0; k < 3; k++) x += ax[k] * (s.bc[k] - ctr[k]);
+    x = fminf(fmaxf(x, -hl), hl);
+    for (int k = 0; k < 3; k++) { pt[k] = ctr[k] + ax[k] * x; dv[k] = b == 0 ? s.bc[k] - pt[k] : pt[k] - s.bc[k]; }
+    const float cd = sqrtf(dot3f(dv, dv)), r1 = b == 0 ? r : K.ball_r, dist = cd - r - K.ball_r;
+    if (!(dist > K.ball_robot.margin)) {
+      const float icd = cd < 1e-14f ? 0.f : 1.0f / cd;
+      cg.dist = dist; cg.kind = b == 0 ? 9 : 10; cg.blk = 0; cg.other = 0;
+      for (int k = 0; k < 3; k++) {
+        cg.n[k] = cd < 1e-14f ? (k == 0 ? 1.f : 0.f) : dv[k] * icd;
+        cg.pos[k] = (b == 0 ? pt[k] : s.bc[k]) + cg.n[k] * (r1 + 0.5f * dist);
+        cg.hint[k] = 0.f;
+      }
+      emit(cg);
+    }
   }
   // maze walls: cells under the bounding square of the geom (skipped when the torso-level broad phase is clear); in an
   // elevated maze the platforms under those cells as well — they are what the robot stands on
@@ -904,7 +1003,7 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       s.ncon = tot;
       s.cbeg[4] = tot;
     }
-    int b = e - D::NBLK;
+    int b = e - D::NMOV;
     if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
     int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, slot = off;
     if (s.cnt[e] == 0) return;  // nothing to store: skip the second enumeration
@@ -912,7 +1011,7 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       if (slot >= NC) { slot++; return; }
       float* q = &s.cY[slot][0][0];
       for (int k = 0; k < 3; k++) { q[k] = g.pos[k]; q[3 + k] = g.n[k]; q[8 + k] = g.hint[k]; }
-      q[6] = g.dist; q[7] = (float)(g.kind + 8 * g.blk + 64 * g.other);
+      q[6] = g.dist; q[7] = (float)(g.kind + 16 * g.blk + 128 * g.other);
       s.cleg[slot] = leg;
       s.ccls[slot] = cls;
       slot++;
@@ -927,7 +1026,7 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     int c = item / 3, a = item - 3 * c;
     const float* q = &s.cY[c][0][0];
     float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
-    int code = (int)q[7], kind = code & 7, blk = (code >> 3) & 7, other = code >> 6;
+    int code = (int)q[7], kind = code & 15, blk = (code >> 4) & 7, other = code >> 7;
     if (kind == 6) {
       // joint-limit row of slide `other` of block `blk`: ONE frictionless row  r = J a - aref, cost D/2 min(0, r)^2.  It rides
       // the contact machinery as a pyramid whose tangential rows vanish: the four edge rows coincide (u0 +- 0), so
@@ -951,11 +1050,15 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
       s.caref[c][a] = aref;
       return;
     }
-    const PairDev& P = (kind == 0 || kind == 3) ? K.floor : K.wall;
+    // contact kinds: 0 floor -> robot geom, 1 robot geom -> wall box, 2 robot geom -> block, 3 floor -> block, 4 wall box -> block,
+    // 5 block -> block, (6 block slide limit, above), 7 floor -> ball, 8 ball -> wall box, 9 torso -> ball, 10 ball -> leg capsule
+    const PairDev& P = kind == 7 ? K.ball_floor : (kind == 8 ? K.ball_wall : (kind >= 9 ? K.ball_robot : ((kind == 0 || kind == 3) ? K.floor : K.wall)));
     int leg = s.cleg[c], cls = s.ccls[c];
     float t1[3], t2[3], f[3];
     make_tangents(n, hint, t1, t2);
-    float sr = kind == 0 ? 1.f : (kind <= 2 ? -1.f : 0.f), sb = kind >= 2 ? 1.f : 0.f;
+    // sign with which the contact force f (on geom2) acts on the robot / on the movable block / on the ball
+    float sr = (kind == 0 || kind == 10) ? 1.f : ((kind == 1 || kind == 2 || kind == 9) ? -1.f : 0.f), sb = (kind >= 2 && kind <= 5) ? 1.f : 0.f;
+    const float sball = (kind == 7 || kind == 9) ? 1.f : ((kind == 8 || kind == 10) ? -1.f : 0.f);
     float sc = a == 0 ? 1.f : P.mu;
     for (int k = 0; k < 3; k++) f[k] = sc * (a == 0 ? n[k] : (a == 1 ? t1[k] : t2[k]));
     float m[3];
@@ -970,9 +1073,17 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     for (int k = 0; k < D::NBLK; k++)
 #pragma unroll
       for (int sl = 0; sl < D::BD; sl++) {
-        if (k == blk && kind >= 2) J[6 + D::BD * k + sl] = sb * fb[sl];
+        if (k == blk && kind >= 2 && kind <= 5) J[6 + D::BD * k + sl] = sb * fb[sl];
         if (kind == 5 && k == other) J[6 + D::BD * k + sl] = -fb[sl];  // geom1 of a block-block pair
       }
+    if constexpr (D::BALL) {  // the ball's six columns: linear (world) = f, angular (body frame) = R^T ((r - x_ball) x f)
+      float rb[3] = {r[0] - s.bx[0], r[1] - s.bx[1], r[2] - s.bx[2]}, mb[3];
+      cross3f(mb, rb, f);
+      for (int k = 0; k < 3; k++) {
+        J[6 + k] = sball * f[k];
+        J[9 + k] = sball * (s.bR[k] * mb[0] + s.bR[3 + k] * mb[1] + s.bR[6 + k] * mb[2]);
+      }
+    }
     J[NH] = cls >= 2 ? sr * (dot3f(s.zw, m) + dot3f(s.Sh[leg < 0 ? 0 : leg], f)) : 0.f;
     J[NH + 1] = cls == 3 ? sr * (dot3f(s.Sa[leg < 0 ? 0 : leg], m) + dot3f(s.Sa[leg < 0 ? 0 : leg] + 3, f)) : 0.f;
     float vel = 0.f;
@@ -981,7 +1092,8 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     float aref = -P.B * vel;
     if (a == 0) {
       float imp = impedancef(P.solimp, fabsf(dist - P.margin));
-      float tran = (cls >= 0 ? K.bw_tran[cls] : 0.f) + (kind >= 2 ? K.block_bw_tran : 0.f) + (kind == 5 ? K.block_bw_tran : 0.f);
+      float tran = (cls >= 0 ? K.bw_tran[cls] : 0.f) + ((kind >= 2 && kind <= 5) ? K.block_bw_tran : 0.f) + (kind == 5 ? K.block_bw_tran : 0.f) +
+                   (sball != 0.f ? K.ball_bw_tran : 0.f);
       float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
       s.cD[c] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
       aref -= P.K * imp * (dist - P.margin);
@@ -1239,7 +1351,7 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   using D = AntDims<NB>;
   constexpr int NH = D::NH, NV = D::NV, NG = D::NGEOM, NROOT = 21 + (NH - 6) * NH;
   cx.tick(s, 9);
-  MZ_FOR(l, 5) kin_item<NB>(K, s, l);
+  MZ_FOR(l, 5 + (D::BALL ? 1 : 0)) kin_item<NB>(K, s, l);
   cx.sync();
   cx.tick(s, 0);
   MZ_FOR_AT(b, ANT_NBODY, 0) inertia_item<NB>(K, s, b);
@@ -1289,29 +1401,41 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
 
 
 // qpos <- integrate(qpos, vel, h): free joint on the manifold, hinges and block slides linear (mj_integratePos)
+// quaternion of a free joint advanced by the body-frame angular velocity w over h (mju_quatIntegrate), normalised before and after
+MZ_HD void quat_integratef(const float* base, const float* w, float h, float* out) {
+  float n = sqrtf(dot3f(w, w));
+  float q[4] = {base[0], base[1], base[2], base[3]};
+  float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; k++) q[k] *= qn;
+  if (n > 1e-15f) {
+    float ang = 0.5f * h * n, sn, c0;
+    mz_sincosf(ang, &sn, &c0);
+    sn /= n;
+    float r[4] = {c0, w[0] * sn, w[1] * sn, w[2] * sn}, o[4];
+    o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
+    o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
+    o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
+    o[3] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
+    float on = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    for (int k = 0; k < 4; k++) q[k] = o[k] * on;
+  }
+  for (int k = 0; k < 4; k++) out[k] = q[k];
+}
+
 template <int NB, class C>
 MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base, const float* vel, float h) {
-  MZ_FOR(i, 12 + AntDims<NB>::BD * AntDims<NB>::NBLK) {
+  using D = AntDims<NB>;
+  MZ_FOR(i, 12 + (D::BALL ? 4 : D::BD * D::NBLK)) {
     if (i < 3) s.qpos[i] = base[i] + h * vel[i];
     else if (i == 3) {
       float w[3] = {vel[3], vel[4], vel[5]};
-      float n = sqrtf(dot3f(w, w));
-      float q[4] = {base[3], base[4], base[5], base[6]};
-      float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-      for (int k = 0; k < 4; k++) q[k] *= qn;
-      if (n > 1e-15f) {
-        float ang = 0.5f * h * n, sn, c0;
-        mz_sincosf(ang, &sn, &c0);
-        sn /= n;
-        float r[4] = {c0, w[0] * sn, w[1] * sn, w[2] * sn}, o[4];
-        o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
-        o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
-        o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
-        o[3] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
-        float on = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
-        for (int k = 0; k < 4; k++) q[k] = o[k] * on;
+      quat_integratef(base + 3, w, h, s.qpos + 3);
+    } else if (D::BALL && i >= 12) {  // the ball's free joint: qpos[15:18] += h v, quaternion qpos[18:22] on the manifold
+      if (i < 15) s.qpos[15 + (i - 12)] = base[15 + (i - 12)] + h * vel[14 + (i - 12)];
+      else {
+        float w[3] = {vel[17], vel[18], vel[19]};
+        quat_integratef(base + 18, w, h, s.qpos + 18);
       }
-      for (int k = 0; k < 4; k++) s.qpos[3 + k] = q[k];
     } else {
       int j = i - 4;  // hinges 0..7, then block slides
       s.qpos[7 + j] = base[7 + j] + h * vel[6 + j];
@@ -1399,13 +1523,21 @@ MZ_HD float ant_block_coord(const AntDev& K, const AntScratchT<NB>& s, int k, in
   return v;
 }
 
-// observation element i (maze_env.py:351-369): qpos[:3] | block xpos (3 each, if observed) | qpos[3:15] | qvel[:14] | t/1000
+// entries the maze adds to the robot's observation: body positions of the object ball / of the movable blocks, when observed
+template <int NB>
+MZ_HD int ant_obs_extra(const AntDev& K) {
+  using D = AntDims<NB>;
+  return D::BALL ? (K.observe_balls ? 3 : 0) : (K.observe_blocks ? 3 * D::NBLK : 0);
+}
+
+// observation element i (maze_env.py:351-369): qpos[:3] | ball xpos / block xpos (3 each, if observed) | qpos[3:15] | qvel[:14] | t/1000
 template <int NB>
 MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t) {
   using D = AntDims<NB>;
-  int nb3 = K.observe_blocks ? 3 * D::NBLK : 0;
+  int nb3 = ant_obs_extra<NB>(K);
   if (i < 3) return s.qpos[i];
   if (i < 3 + nb3) {
+    if constexpr (D::BALL) return s.qpos[15 + (i - 3)];  // get_body_com of a free-joint body: the frame origin = qpos[15:18]
     int k = (i - 3) / 3, c = (i - 3) - 3 * k;
     return ant_block_coord<NB>(K, s, k, c);
   }
@@ -1444,7 +1576,7 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
   cx.sync();
   for (int f = 0; f < K.frame_skip; f++) ant_mj_step<NB>(cx, K, s, f == 0);
   int t = *t_io + 1;
-  int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * D::NBLK : 0);
+  int obs_dim = ANT_OBS + ant_obs_extra<NB>(K);
   MZ_FOR(i, obs_dim) obs[i] = ant_obs_elem<NB>(K, s, i, t);
   MZ_FOR(one, 1) {
     float dt = K.h * (float)K.frame_skip;

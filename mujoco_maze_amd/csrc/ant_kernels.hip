@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   const float* out2 = lds[slot2].io.out;
   const int* iout2 = lds[slot2].io.iout;
   float* rec2 = state + (size_t)env2 * D::REC;
-  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * D::NBLK : 0);
+  const int obs_dim = ANT_OBS + ant_obs_extra<NB>(K);
   const uint8_t d = *(const uint8_t*)&iout2[0];
   const int t_new = iout2[2];
   uint32_t episode = (uint32_t)iout2[3];
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
     episode += 1;
     uint64_t es = episode_seed(seed, episode);
     // robot coordinates get the reset noise; movable blocks return to their cells (ant.py:84-96)
-    for (int i = l2; i < D::NQ; i += G) s2.qpos[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env2, i) : 0.f;
+    // (an object ball returns to its spawn pose: its qpos entries are a pose, not displacements)
+    for (int i = l2; i < D::NQ; i += G) s2.qpos[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], es, env0 + (uint64_t)env2, i) : (D::BALL ? K.qpos0[i < ANT_NQ + 7 ? i : 0] : 0.f);
     for (int i = l2; i < D::NV; i += G) { s2.qvel[i] = i < ANT_NV ? reset_qvel(K.reset_kind, D::NQ, es, env0 + (uint64_t)env2, i) : 0.f; s2.warm[i] = 0.f; }
     cx.sync();
     if (l2 == 0) {  // root quaternion normalised in place, as at mz_reset [ASSUME-8]
@@ -192,7 +193,7 @@ __global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, con
   if (env >= n) return;
   float* rec = state + (size_t)env * L.rec;
   if (!mask || mask[env]) {
-    for (int i = 0; i < L.nq; i++) rec[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], seed, env0 + (uint64_t)env, i) : 0.f;
+    for (int i = 0; i < L.nq; i++) rec[i] = i < ANT_NQ ? reset_qpos(K.qpos0[i], seed, env0 + (uint64_t)env, i) : (K.nball ? K.qpos0[i < ANT_NQ + 7 ? i : 0] : 0.f);
     {  // set_state -> mj_forward: mj_kinematics normalises the root quaternion in place [ASSUME-8]
       float qn = 1.0f / sqrtf(rec[3] * rec[3] + rec[4] * rec[4] + rec[5] * rec[5] + rec[6] * rec[6]);
       for (int i = 3; i < 7; i++) rec[i] *= qn;
@@ -213,7 +214,8 @@ __global__ void ant_reset_kernel(AntDev K, AntLayout L, int n, float* state, con
       return v;
     };
     for (int i = 0; i < 3; i++) o[k++] = rec[i];
-    for (int b = 0; b < L.nblock3 / 3; b++)
+    if (K.nball && K.observe_balls) for (int c = 0; c < 3; c++) o[k++] = rec[ANT_NQ + c];
+    for (int b = 0; b < L.nblock3 / 3 && !K.nball; b++)
       for (int c = 0; c < 3; c++) o[k++] = block_coord(b, c);
     for (int i = 3; i < ANT_NQ; i++) o[k++] = rec[i];
     for (int i = 0; i < ANT_NV; i++) o[k++] = rec[L.nq + i];
@@ -315,6 +317,8 @@ __global__ void ant_task_eval_kernel(const AntDev* __restrict__ Kp, int n, int o
 }
 
 // ------------------------------------------------------------------ entry points of this translation unit (mz_internal.h)
+// AntDims configuration of the handle's model: 0-3 two-slide blocks, 4 one three-slide block, 5 one free-joint object ball
+static int ant_config(const mz_handle* h) { return h->ant.nball ? 5 : ((h->ant.nblock == 1 && h->ant.block_nax == 3) ? 4 : h->ant.nblock); }
 static hipError_t ant_sync_constants(mz_handle* h, hipStream_t st) {
   if (!h->ant_dirty) return hipSuccess;
   hipError_t e = hipMemcpyAsync(h->ant_dev, &h->ant, sizeof(AntDev), hipMemcpyHostToDevice, st);
@@ -325,21 +329,23 @@ static hipError_t ant_sync_constants(mz_handle* h, hipStream_t st) {
 hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   hipError_t e = ant_sync_constants(h, st);
   if (e != hipSuccess) return e;
-  switch (h->ant.nblock == 1 && h->ant.block_nax == 3 ? 4 : h->ant.nblock) {  // block configuration (AntDims)
+  switch (ant_config(h)) {  // configuration of movable bodies (AntDims)
     case 0: return dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
     case 1: return dispatch_ant_step<1>(h, st, a, o, r, d, gi, inf);
     case 2: return dispatch_ant_step<2>(h, st, a, o, r, d, gi, inf);
     case 4: return dispatch_ant_step<4>(h, st, a, o, r, d, gi, inf);
+    case 5: return dispatch_ant_step<5>(h, st, a, o, r, d, gi, inf);
     default: return dispatch_ant_step<3>(h, st, a, o, r, d, gi, inf);
   }
 }
 
 hipError_t mzk_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
-  switch (h->ant.nblock == 1 && h->ant.block_nax == 3 ? 4 : h->ant.nblock) {
+  switch (ant_config(h)) {
     case 0: return dispatch_ant_forward<0>(h, st, a, qacc, counts);
     case 1: return dispatch_ant_forward<1>(h, st, a, qacc, counts);
     case 2: return dispatch_ant_forward<2>(h, st, a, qacc, counts);
     case 4: return dispatch_ant_forward<4>(h, st, a, qacc, counts);
+    case 5: return dispatch_ant_forward<5>(h, st, a, qacc, counts);
     default: return dispatch_ant_forward<3>(h, st, a, qacc, counts);
   }
 }

@@ -63,8 +63,13 @@ struct AntDev {
   PairDev floor, wall;
   MazeDev maze;
   TaskDev task;
-  float qpos0[ANT_NQ];
+  float qpos0[ANT_NQ + 7];  // robot, then the pose of a free-joint object ball
   int reset_kind;
+  // object ball on a free joint (AntSmallBilliard; AntEnv.OBJBALL_TYPE, maze_env.py:539-560): a sphere of radius ball_r whose
+  // centre sits ball_h above the body origin (the body frame starts on the floor), isotropic inertia about the centre
+  int nball, observe_balls;
+  float ball_mass, ball_inertia, ball_r, ball_h, ball_bw_tran;
+  PairDev ball_floor, ball_wall, ball_robot;
   // movable XY blocks (all the same size: one maze cell); see maze_env.py:563-660
   int nblock, observe_blocks;
   float block_mass, block_bw_tran, block_half[3], block_pos0[4][3];
@@ -141,14 +146,33 @@ static inline void maze_dev_from_model(MazeDev* z, const mz_model* m) {
 
 static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, int errlen) {
   memset(a, 0, sizeof(*a));
-  const int nb = m->nblock;
+  const int nb = m->nblock, nball = m->nball;
   if (nb < 0 || nb > 4) return ant_fail(err, errlen, "ant kernel: at most 4 movable blocks");
+  if (nball < 0 || nball > 1 || (nball && nb)) return ant_fail(err, errlen, "ant kernel: at most one object ball, and not together with movable blocks");
   int nbdof = 0;
   for (int k = 0; k < nb; k++) nbdof += m->body_jntnum[m->block_bodyid[k]];
-  if (m->robot != MZ_ROBOT_ANT || m->nbody != 14 + nb || m->nv != ANT_NV + nbdof || m->nq != ANT_NQ + nbdof || m->nu != ANT_NU ||
-      m->ngeom != 14 + nb)
-    return ant_fail(err, errlen, "ant kernel: model is not the 14-body / 14-dof ant (+ XY blocks)");
+  if (m->robot != MZ_ROBOT_ANT || m->nbody != 14 + nb + nball || m->nv != ANT_NV + nbdof + 6 * nball || m->nq != ANT_NQ + nbdof + 7 * nball ||
+      m->nu != ANT_NU || m->ngeom != 14 + nb + nball)
+    return ant_fail(err, errlen, "ant kernel: model is not the 14-body / 14-dof ant (+ movable blocks or one free-joint ball)");
   a->nblock = nb; a->observe_blocks = m->observe_blocks;
+  a->nball = nball; a->observe_balls = m->observe_balls;
+  if (nball) {
+    const int b = m->ball_bodyid[0], g = m->ball_geomid[0], j = m->body_jntadr[b];
+    const double* I = m->body_inertia[b];
+    if (b != 14 || g != 14 || m->geom_type[g] != MZ_GEOM_SPHERE || m->body_jntnum[b] != 1 || m->jnt_type[j] != MZ_JNT_FREE ||
+        m->jnt_qposadr[j] != ANT_NQ || m->jnt_dofadr[j] != ANT_NV || fabs(I[0] - I[1]) > 1e-12 * I[0] || fabs(I[0] - I[2]) > 1e-12 * I[0] ||
+        fabs(I[3]) + fabs(I[4]) + fabs(I[5]) > 1e-12 * I[0] || fabs(m->body_ipos[b][0]) + fabs(m->body_ipos[b][1]) > 1e-12 ||
+        fabs(m->geom_pos[g][2] - m->body_ipos[b][2]) > 1e-12)
+      return ant_fail(err, errlen, "ant kernel: the object ball is one sphere on a free joint, centred above its body origin");
+    a->ball_mass = (float)m->body_mass[b]; a->ball_inertia = (float)I[0]; a->ball_r = (float)m->geom_size[g][0];
+    a->ball_h = (float)m->body_ipos[b][2]; a->ball_bw_tran = (float)m->body_invweight0[b][0];
+    pair_from(&a->ball_floor, m, m->geom_friction[0], m->geom_solref[0], m->geom_solimp[0], m->geom_margin[0], m->geom_friction[g],
+              m->geom_solref[g], m->geom_solimp[g], m->geom_margin[g]);
+    pair_from(&a->ball_wall, m, m->geom_friction[g], m->geom_solref[g], m->geom_solimp[g], m->geom_margin[g], m->wall_friction,
+              m->wall_solref, m->wall_solimp, m->wall_margin);
+    pair_from(&a->ball_robot, m, m->geom_friction[1], m->geom_solref[1], m->geom_solimp[1], m->geom_margin[1], m->geom_friction[g],
+              m->geom_solref[g], m->geom_solimp[g], m->geom_margin[g]);
+  }
   if (m->elevated && nb == 0) return ant_fail(err, errlen, "ant kernel: an elevated maze needs a movable block (the platform code lives in the block instantiations)");
   a->block_axis[0] = 0; a->block_axis[1] = 1; a->block_axis[2] = 2; a->block_nax = 2;
   for (int k = 0; k < nb; k++) {
@@ -228,9 +252,9 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
   a->d_scale = m->maze_scale; a->d_tx = m->torso_x; a->d_ty = m->torso_y; a->d_half_xy = m->wall_half_xy; a->d_half_z = m->wall_half_z;
   a->d_center_z = m->wall_center_z; a->d_wall_margin = fmax(m->geom_margin[1], m->wall_margin);
   task_dev_from_model(&a->task, m);
-  for (int k = 0; k < ANT_NQ; k++) a->qpos0[k] = (float)m->qpos0[k];
+  for (int k = 0; k < ANT_NQ + 7 * nball; k++) a->qpos0[k] = (float)m->qpos0[k];
   a->reset_kind = m->reset_qvel_kind;
-  a->max_iter = nb ? 50 : 10; a->ls_iter = 12; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
+  a->max_iter = (nb || nball) ? 50 : 10; a->ls_iter = 12; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
   a->inv_scale = (float)(1.0 / (m->meaninertia * m->nv));
   return MZ_OK;
 }

@@ -75,10 +75,11 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   if (h->robot == MZ_ROBOT_ANT) {
     const int nb = h->ant.nblock;
     if (nb > 3) { delete h; return fail("mz_create: more than 3 movable blocks are not instantiated"); }
-    h->lay.nq = ANT_NQ + h->ant.block_nax * nb; h->lay.nv = ANT_NV + h->ant.block_nax * nb; h->lay.rec_t = h->lay.nq + 2 * h->lay.nv;
+    h->lay.nq = ANT_NQ + h->ant.block_nax * nb + 7 * h->ant.nball; h->lay.nv = ANT_NV + h->ant.block_nax * nb + 6 * h->ant.nball;
+    h->lay.rec_t = h->lay.nq + 2 * h->lay.nv;
     h->lay.rec = (h->lay.rec_t + 2 + 15) / 16 * 16;
     h->lay.nblock3 = model->observe_blocks ? 3 * nb : 0;
-    h->lay.obs_dim = ANT_OBS + h->lay.nblock3;
+    h->lay.obs_dim = ANT_OBS + h->lay.nblock3 + ((h->ant.nball && model->observe_balls) ? 3 : 0);
     h->base_obs = h->lay.obs_dim;
     h->lay.ostride = h->lay.obs_dim + vdim;
     if (h->base_obs + vdim != model->obs_dim || h->base_obs > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }

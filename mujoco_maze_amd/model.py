@@ -279,8 +279,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     structure = task.create_maze()
     world = MazeWorld(structure, scale, maze_height)
     balls = world.ball_cells()
-    if balls and robot != "point":
-        raise NotImplementedError("object balls on a free joint (AntSmallBilliard) are not on the device path: see DESIGN.md section 8")
+    if balls and robot not in ("point", "ant"):
+        raise ValueError(f"OBJBALL_TYPE is not registered for the {robot}")  # maze_env.py:189-191: only PointEnv and AntEnv define one
     if len(balls) > 1:
         raise NotImplementedError("more than one object ball")
     blocks = world.movable_cells()
@@ -354,6 +354,17 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     for (bi_, bj_) in balls:
         bx, by = world.cell_center(bi_, bj_)
         r_ = float(task.OBJECT_BALL_SIZE)
+        if robot == "ant":
+            # free-joint flavour (AntEnv.OBJBALL_TYPE; maze_env.py:539-560): body at (x, y, 0) on a <freejoint> (which takes no
+            # defaults: armature = damping = margin = 0), sphere of radius r at height r with the asset's default density
+            # (ant.xml: 5.0 => 5 * 4/3 pi r^3), own solimp
+            geom = dataclasses.replace(spec.wall_geom_defaults, name=f"objball_{bi_}_{bj_}_geom", type=R.SPHERE, size=(r_,), pos=(0.0, 0.0, r_),
+                                       fromto=None, mass=None, contype=1, conaffinity=1,
+                                       solimp=(0.9, 0.99, 0.001, 0.5, 2.0), explicit_solimp=True)
+            body = R.BodySpec(f"objball_{bi_}_{bj_}", -1, (bx, by, 0.0), joints=[R.JointSpec(f"objball_{bi_}_{bj_}_root", R.FREE)], geoms=[geom])
+            ball_body_index.append(1 + len(spec.bodies))
+            spec.bodies.append(body)
+            continue
         geom = dataclasses.replace(spec.wall_geom_defaults, name=f"objball_{bi_}_{bj_}_geom", type=R.SPHERE, size=(r_,), pos=(0.0, 0.0, r_),
                                    fromto=None, mass=0.0001 * r_ ** 3, contype=1, conaffinity=1,
                                    solimp=(0.9, 0.99, 0.001, 0.5, 2.0), explicit_solimp=True)

@@ -171,6 +171,10 @@ void mzo_top_down_view(const mz_model* m, double robot_x, double robot_y, int nb
 
 /* ---------------------------------------------------------------- obs */
 static void body_origin(const mz_model* m, const mzo_env_state* s, int body, double* p) {
+  if (m->body_jntnum[body] == 1 && m->jnt_type[m->body_jntadr[body]] == MZ_JNT_FREE) { /* free-joint object ball: qpos holds the pose */
+    for (int c = 0; c < 3; c++) p[c] = s->qpos[m->jnt_qposadr[m->body_jntadr[body]] + c];
+    return;
+  }
   for (int c = 0; c < 3; c++) p[c] = m->body_pos[body][c];
   for (int j = m->body_jntadr[body]; j < m->body_jntadr[body] + m->body_jntnum[body]; j++)
     if (m->jnt_type[j] == MZ_JNT_SLIDE) {

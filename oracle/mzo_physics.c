@@ -761,6 +761,22 @@ static void collide_pair(const mz_model* m, mzo_data* d, int ga, int gb) {
     else { nrm[0] = dv[0] / cd; nrm[1] = dv[1] / cd; nrm[2] = dv[2] / cd; }
     for (int k = 0; k < 3; k++) pos[k] = d->geom_xpos[g1][k] + nrm[k] * (r1 + 0.5 * dist);
     add_contact(d, &pp, dist, pos, nrm, NULL);
+  } else if (t1 == MZ_GEOM_SPHERE && t2 == MZ_GEOM_CAPSULE) {
+    /* an object ball (free joint) against a leg capsule of the ant: the point of the capsule's axis segment nearest to the
+     * sphere centre, then sphere-sphere; normal from geom1 (the sphere) to geom2 (mjc_SphereCapsule) */
+    const double* cm = d->geom_xmat[g2];
+    double axis[3] = {cm[2], cm[5], cm[8]}, vec[3], pt[3], dv[3], pos[3], nrm[3];
+    sub3(vec, d->geom_xpos[g1], d->geom_xpos[g2]);
+    double hl = m->geom_size[g2][1], x = dot3(axis, vec);
+    x = x < -hl ? -hl : (x > hl ? hl : x);
+    for (int k = 0; k < 3; k++) pt[k] = d->geom_xpos[g2][k] + axis[k] * x;
+    sub3(dv, pt, d->geom_xpos[g1]);
+    double cd = norm3(dv), r1 = m->geom_size[g1][0], r2 = m->geom_size[g2][0], dist = cd - r1 - r2;
+    if (dist > pp.margin) return;
+    if (cd < MINVAL) { nrm[0] = 1.0; nrm[1] = 0.0; nrm[2] = 0.0; }
+    else { nrm[0] = dv[0] / cd; nrm[1] = dv[1] / cd; nrm[2] = dv[2] / cd; }
+    for (int k = 0; k < 3; k++) pos[k] = d->geom_xpos[g1][k] + nrm[k] * (r1 + 0.5 * dist);
+    add_contact(d, &pp, dist, pos, nrm, NULL);
   } else if (t2 == MZ_GEOM_BOX && t1 == MZ_GEOM_SPHERE) {
     double dist, pos[3], nrm[3];
     if (sphere_box(d->geom_xpos[g1], m->geom_size[g1][0], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], pp.margin, &dist, pos, nrm))

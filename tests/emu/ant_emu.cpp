@@ -15,7 +15,7 @@ static int env_step_t(const AntDev& K, int n, float* qpos, float* qvel, float* w
   using D = AntDims<NB>;
   HostCtx cx;
   AntScratchT<NB>* s = (AntScratchT<NB>*)calloc(1, sizeof(AntScratchT<NB>));
-  const int obs_dim = ANT_OBS + (K.observe_blocks ? 3 * D::NBLK : 0);
+  const int obs_dim = ANT_OBS + ant_obs_extra<NB>(K);
   for (int e = 0; e < n; e++) {
     for (int k = 0; k < D::NQ; k++) s->qpos[k] = qpos[e * D::NQ + k];
     for (int k = 0; k < D::NV; k++) { s->qvel[k] = qvel[e * D::NV + k]; s->warm[k] = warm[e * D::NV + k]; }
@@ -86,7 +86,8 @@ int emu_ant_env_step(const mz_model* m, int n, float* qpos, float* qvel, float* 
   AntDev K;
   int rc = make_dev(&K, m, max_iter, tol, rtol);
   if (rc != MZ_OK) return rc;
-  switch (K.nblock == 1 && K.block_nax == 3 ? 4 : K.nblock) {
+  switch (K.nball ? 5 : (K.nblock == 1 && K.block_nax == 3 ? 4 : K.nblock)) {
+    case 5: return env_step_t<5>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
     case 4: return env_step_t<4>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
     case 0: return env_step_t<0>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
     case 1: return env_step_t<1>(K, n, qpos, qvel, warm, t, actions, obs, reward, done, goal_idx, info, status, iters);
@@ -103,7 +104,8 @@ int emu_ant_forward(const mz_model* m, int n, const float* qpos, const float* qv
   AntDev K;
   int rc = make_dev(&K, m, max_iter, tol, rtol);
   if (rc != MZ_OK) return rc;
-  switch (K.nblock == 1 && K.block_nax == 3 ? 4 : K.nblock) {
+  switch (K.nball ? 5 : (K.nblock == 1 && K.block_nax == 3 ? 4 : K.nblock)) {
+    case 5: return forward_t<5>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);
     case 4: return forward_t<4>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);
     case 0: return forward_t<0>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);
     case 1: return forward_t<1>(K, n, qpos, qvel, warm, actions, qacc, counts, Mout, bias, qas);

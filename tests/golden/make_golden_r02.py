@@ -278,6 +278,8 @@ def dump_custom_worlds():
             out[f"HalfBlockMaze/{tag}"] = dict(G.dump_world("custom"), grid=G.grid_text(env._maze_structure), scale=4.0)
         finally:
             G.build_env = real_build
+    # the Ant's object ball hangs on a <freejoint> (AntEnv.OBJBALL_TYPE, maze_env.py:539-560): world of a registered id
+    out["AntSmallBilliard-v0"] = dict(G.dump_world("AntSmallBilliard-v0"), scale=2.0)
     return out
 
 

@@ -144,6 +144,47 @@ def test_kernel_logic_movable_block(oracle):
     assert moved > 0.1  # the block really gets pushed
 
 
+def test_kernel_logic_object_ball_on_a_free_joint(oracle):
+    """AntSmallBilliard (AntEnv.OBJBALL_TYPE = "freejoint", maze_env.py:539-560): the ball's six dofs join the hub (its own
+    mass block, centripetal + gravity bias), contacts floor -> ball, ball -> wall, torso -> ball, ball -> leg capsule, ball xyz
+    (the body origin, which rolls around the centre) in the observation, goal test on the ball."""
+    from tests import emu_lib
+
+    cm = model.compile_model("ant", T.GoalRewardSmallBilliard(2.0), 2.0)
+    assert (cm.c.nq, cm.c.nv, cm.c.obs_dim, cm.c.nball) == (22, 20, 33, 1)
+    n = 96
+    st, obs0 = oracle.reset(cm, n, 5)
+    assert np.array_equal(obs0[:, 3:6], np.tile([0.0, -2.0, 0.0], (n, 1)))  # the ball's cell is one row before the robot's
+    rng = np.random.default_rng(0)
+    st["qpos"][:48, 1] = -0.9 + rng.uniform(-0.1, 0.1, 48)  # half of the ants start next to the ball, walking into it
+    st["qvel"][:48, 1] = -2.0
+    rolled = 0.0
+    for k in range(61):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        if k in (0, 3, 12, 30, 60):
+            s64 = _f32(st)
+            s32 = emu_lib.f32_state(s64)
+            # one forward evaluation: mass matrix (ball block included), bias, contact count, qacc
+            fo = oracle.forward(cm, s64["qpos"], s64["qvel"], act.astype(np.float64), s64["warm"])
+            fe = emu_lib.forward(cm, s32["qpos"], s32["qvel"], act, s32["warm"])
+            assert np.array_equal(fo["counts"][:, 0], fe["counts"][:, 0])
+            assert np.abs(fe["M"] - fo["M"]).max() < 2e-6 and np.abs(fe["bias"] - fo["bias"]).max() < 2e-5
+            assert np.all(np.abs(fe["qacc"] - fo["qacc"]) <= 5e-4 + 2e-4 * np.abs(fo["qacc"]))
+            ro = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            re_ = emu_lib.env_step(cm, s32, act)
+            assert re_["obs"].shape == (n, 33)
+            ok = np.all(np.abs(s32["qvel"] - s64["qvel"]) <= 2e-5 + 1e-5 * np.abs(s64["qvel"]), axis=1) & \
+                np.all(np.abs(s32["qpos"] - s64["qpos"]) <= 1e-5 + 1e-5 * np.abs(s64["qpos"]), axis=1)
+            assert ok.mean() >= 0.98, (k, np.abs(s32["qvel"] - s64["qvel"]).max(1))
+            assert np.all(np.abs(re_["obs"][ok] - ro["obs"][ok]) <= 2e-5 + 1e-5 * np.abs(ro["obs"][ok]))
+            assert np.abs(re_["reward"][ok] - ro["reward"][ok]).max() < 1e-6
+            assert np.array_equal(re_["done"][ok], ro["done"][ok]) and np.all((re_["status"] & 7) == 0)
+            rolled = max(rolled, np.abs(s64["qpos"][:, 18] - 1.0).max())
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    assert rolled > 0.05  # the ball really gets kicked and rolls (quaternion leaves the identity)
+    assert np.abs(st["qpos"][:, 15:17] - [0.0, -2.0]).max() > 0.5
+
+
 @pytest.mark.parametrize("name,nblock,obs_dim", [("MultiPush", 2, 36), ("MultiPushSmall", 3, 39), ("PushMaze", 3, 39)])
 def test_kernel_logic_multi_block_mazes(oracle, name, nblock, obs_dim):
     """Mazes with two / three movable XY blocks (maze_task.py:259-330; scale 2 = the reference's default for

@@ -721,8 +721,11 @@ def test_ragged_batch_sizes_and_argument_errors(torch, oracle, env_id):
         env.close()
     with pytest.raises(KeyError):
         mm.make("AntNoSuchMaze-v0")
-    with pytest.raises(NotImplementedError):
-        mm.make("AntSmallBilliard-v0", num_envs=2)
+    with pytest.raises(ValueError):  # the reference: "OBJBALL_TYPE is not registered" for robots without an object-ball flavour
+        from mujoco_maze_amd import maze_task as T2
+        from mujoco_maze_amd.maze_env import VecMazeEnv
+
+        VecMazeEnv(mm.SwimmerEnv, T2.GoalRewardSmallBilliard, num_envs=2, maze_size_scaling=2.0)
 
 
 def test_user_robot_xml_on_the_device(torch, oracle):
@@ -750,8 +753,7 @@ def test_user_robot_xml_on_the_device(torch, oracle):
 
 
 def test_every_registered_id_runs_or_refuses(torch):
-    """All 145 ids of the reference's registry (mujoco_maze/__init__.py:17-78): 142 build and step on the device; the Ant's
-    free-joint object ball (AntSmallBilliard, 3 ids) raises NotImplementedError; nothing else."""
+    """All 145 ids of the reference's registry (mujoco_maze/__init__.py:17-78) build and step on the device."""
     rng = np.random.default_rng(0)
     ran, refused = 0, []
     for env_id in mm.REGISTRY:
@@ -774,5 +776,43 @@ def test_every_registered_id_runs_or_refuses(torch):
             assert np.all((env.status().cpu().numpy() & 3) == 0), env_id
         env.close()
         ran += 1
-    assert ran == 142 and len(refused) == 3
-    assert sorted(refused) == ["AntSmallBilliard-v0", "AntSmallBilliard-v1", "AntSmallBilliard-v2"]
+    assert ran == 145 and refused == []
+
+
+def test_ant_small_billiard_free_joint_ball(torch, oracle):
+    """AntSmallBilliard-v0/-v1 (maze_task.py:732-762; AntEnv.OBJBALL_TYPE = "freejoint", maze_env.py:539-560): a 1.34 kg ball on
+    a free joint — six more dofs, quaternion, contacts with floor, walls, torso and leg capsules.  Single-step parity from
+    rollout states in which half of the ants were sent into the ball; flags / goal index (judged on the BALL's position)
+    exact; the ball really rolls."""
+    n = 768
+    env = mm.make("AntSmallBilliard-v1", num_envs=n)
+    cm = env.model
+    assert (env.nq, env.nv, env.obs_dim) == (22, 20, 33)
+    st, _ = oracle.reset(cm, n, 17)
+    rng = np.random.default_rng(3)
+    st["qpos"][: n // 2, 1] = -0.9 + rng.uniform(-0.1, 0.1, n // 2)
+    st["qvel"][: n // 2, 1] = -2.0
+    # a few balls start on the goal so that the termination flag and the goal index fire (goal of -v1: (-1, -2) * scale)
+    goal = np.array(cm.task.goals[0].pos[:2])
+    st["qpos"][-16:, 15:17] = goal + rng.uniform(-0.3, 0.3, (16, 2))
+    rolled, kicked, dones = 0.0, 0, 0
+    for k in range(81):
+        act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+        if k in (0, 2, 10, 40, 80):
+            s64 = _f32(st)
+            env.set_state(s64["qpos"], s64["qvel"], s64["warm"], s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.01, hard_atol=1e-4)
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok]))
+            assert np.array_equal(done.cpu().numpy()[ok], ref["done"][ok])
+            assert np.all(_close(rew.cpu().numpy()[ok], ref["reward"][ok], atol=1e-5))
+            assert np.array_equal(obs.cpu().numpy()[:, 3:6], qpos[:, 15:18])  # the ball's body origin is what is observed
+            dones += int((ref["done"] != 0).sum())
+            rolled = max(rolled, float(np.abs(s64["qpos"][:, 18] - 1.0).max()))
+            kicked = max(kicked, int((np.abs(s64["qvel"][:, 14:17]).max(1) > 0.05).sum()))
+            assert np.all((env.status().cpu().numpy() & 3) == 0)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    assert rolled > 0.05 and kicked >= 20 and dones >= 8
+    env.close()

@@ -251,8 +251,37 @@ def test_elevated_world(oracle):
     assert np.all(out["status"] == 0) and np.all(st["qpos"][:, 2] > 4.2) and np.all(st["qpos"][:, 16] > 3.5)
 
 
-def test_only_the_free_joint_ball_is_refused_on_the_host():
-    """compile_model accepts every registered maze except the Ant's free-joint object ball (AntSmallBilliard, 3 ids)."""
+def test_free_joint_object_ball_world(oracle):
+    """AntSmallBilliard (AntEnv.OBJBALL_TYPE = "freejoint"; maze_env.py:167-191, 539-560): ball body, <freejoint> (no defaults:
+    armature / damping / margin 0), sphere of the asset's default density at height r, obs layout — against the MJCF the
+    reference generates (tests/golden/custom_worlds.json)."""
+    import math
+
+    ref = json.load(open(os.path.join(G, "custom_worlds.json")))["AntSmallBilliard-v0"]
+    spec = mm.REGISTRY["AntSmallBilliard-v0"]
+    scale = spec.kwargs["maze_size_scaling"]
+    cm = model.compile_model("ant", spec.kwargs["maze_task"](scale), scale)
+    m = cm.c
+    ball = ref["movable"][0]
+    assert ref["ball_names"] == ["objball_2_2"] and m.nball == 1 and m.nblock == 0 and m.obs_dim == ref["obs_dim"] == 33
+    b, g = m.ball_bodyid[0], m.ball_geomid[0]
+    assert list(m.body_pos[b]) == ball["pos"] and [m.geom_size[g][0]] == ball["geom"]["size"] and list(m.geom_pos[g]) == ball["geom"]["pos"]
+    assert ball["geom"]["mass"] is None and ball["joints"][0]["type"] == "freejoint"
+    r = ball["geom"]["size"][0]
+    assert abs(m.body_mass[b] - 5.0 * 4.0 / 3.0 * math.pi * r ** 3) < 1e-12  # ant.xml default density 5.0 (tests/golden/robots.json)
+    j = m.body_jntadr[b]
+    assert m.jnt_type[j] == 0 and (m.nq, m.nv) == (22, 20) and m.jnt_qposadr[j] == 15 and m.jnt_dofadr[j] == 14
+    assert m.dof_armature[14] == 0.0 and m.dof_damping[14] == 0.0 and m.jnt_margin[j] == 0.0
+    assert [m.qpos0[15 + k] for k in range(7)] == ball["pos"] + [1.0, 0.0, 0.0, 0.0]
+    assert [list(bx) for bx in cm.world.wall_boxes()] == [bb["pos"] + bb["size"] for bb in ref["boxes"]]
+    # obs layout: qpos[:3] | ball body position | qpos[3:15] | qvel[:14] | t  (tests/golden/obs_layout.json pins it as well)
+    st, obs = oracle.reset(cm, 2, 3)
+    assert np.array_equal(obs[:, 3:6], np.tile(ball["pos"], (2, 1))) and np.array_equal(obs[:, 6:18], st["qpos"][:, 3:15])
+    assert np.array_equal(obs[:, 18:32], st["qvel"][:, :14]) and np.all(st["qvel"][:, 14:] == 0.0)
+
+
+def test_every_registered_maze_compiles_on_the_host():
+    """compile_model accepts every registered maze (the Ant's free-joint object ball of AntSmallBilliard included)."""
     ok, refused = 0, []
     for env_id, spec in mm.REGISTRY.items():
         scale = spec.kwargs["maze_size_scaling"]
@@ -261,4 +290,4 @@ def test_only_the_free_joint_ball_is_refused_on_the_host():
             ok += 1
         except NotImplementedError:
             refused.append(env_id)
-    assert ok == 142 and sorted(refused) == ["AntSmallBilliard-v0", "AntSmallBilliard-v1", "AntSmallBilliard-v2"]
+    assert ok == 145 and refused == []

@@ -142,6 +142,8 @@ def test_observation_layout_and_reset_pattern(env_id, oracle):
             body = ids[b]
             c = "xyz".index(axis)
             expect = m.body_pos[body][c]
+            if m.jnt_type[m.body_jntadr[body]] == 0:  # free-joint object ball (AntSmallBilliard): the pose IS qpos
+                expect = 1000.0 + m.jnt_qposadr[m.body_jntadr[body]] + c
             for j in range(m.body_jntadr[body], m.body_jntadr[body] + m.body_jntnum[body]):
                 if m.jnt_type[j] == 2 and m.jnt_axis[j][c] == 1.0:  # slide along this axis
                     expect += 1000.0 + m.jnt_qposadr[j] - m.qpos0[m.jnt_qposadr[j]]
