@@ -11,7 +11,8 @@ oracle = oracle_lib.load()
 CONFIGS = [("AntUMaze-v0", 2048, (0, 1, 10, 50, 100, 200)), ("Ant4Rooms-v0", 2048, (0, 10, 100)), ("AntPush-v0", 1024, (0, 10, 50, 100)),
            ("AntPushMaze-v0", 512, (0, 10, 50)), ("PointUMaze-v0", 2048, (0, 10, 50, 100)), ("PointPush-v0", 2048, (0, 10, 50, 100)),
            ("PointBilliard-v0", 2048, (0, 10, 50, 100)), ("SwimmerUMaze-v0", 2048, (0, 10, 100)), ("ReacherUMaze-v0", 2048, (0, 10, 100)),
-           ("AntFall-v0", 1024, (0, 5, 20, 60)), ("AntMultiFall-v0", 1024, (5, 20, 60)), ("PointFall-v0", 2048, (0, 5, 20, 60))]
+           ("AntFall-v0", 1024, (0, 5, 20, 60)), ("AntMultiFall-v0", 1024, (5, 20, 60)), ("PointFall-v0", 2048, (0, 5, 20, 60)),
+           ("AntSmallBilliard-v0", 1024, (0, 5, 20, 60))]
 print("| config | envs x checkpoints | median | 99 % | 99.9 % | max | envs > 1e-5 | done / goal-index mismatches |")
 print("|---|---|---|---|---|---|---|---|")
 for env_id, n, checks in CONFIGS:
