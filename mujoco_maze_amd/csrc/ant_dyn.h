@@ -122,6 +122,7 @@ struct alignas(16) AntScratchT {
   // contacts
   int ncon, cnt[D::NGEOM], cbeg[5];  // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); hub-only contacts [0, cbeg[0])
   int cleg[D::NC], ccls[D::NC];      // leg (-1 none) and robot body class (-1 none) of the contact
+  int csrc[D::NC], con_over;         // single-pass enumeration (plain ant): staging entry of the contact (-1: geometry in cY[c]); a geom overflowed its staging
   alignas(16) float cJ[D::NC][3][D::NCOL];  // [normal, mu*t1, mu*t2] x [hub, hip, ankle]
   alignas(16) float cY[D::NC][3][D::NCOL];  // W * J of the current Newton iterate (also stages contact geometry)
   float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3];
@@ -262,6 +263,7 @@ MZ_HD void kin_item(const AntDev& K, AntScratchT<NB>& s, int l) {
         }
       }
       s.nearwall = near;
+      s.con_over = 0;
       return;
     }
     if constexpr (AntDims<NB>::BALL) {
@@ -981,6 +983,55 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     }
 }
 
+// ---- single-pass enumeration (plain ant on the device).  The two-pass count / fill scheme below runs every narrow-phase test
+// twice; measured, the second pass is 5 % of a wave's cycles and — being paid only by the envs that touch something — 14 % of
+// a launch (it feeds the slowest waves).  Here a geom's lane keeps the first MZ_STAGE contacts it finds in a staging entry of
+// its own (8 floats: position, normal, distance, kind code; the tangent hint of a capsule-floor contact is the capsule axis
+// and is rebuilt from the geom) inside the not-yet-used cY block, the second phase only maps compact contact slots to staging
+// entries (prefix sums over the counts).  A geom with more contacts than MZ_STAGE (a foot in a wall corner) flags the env,
+// which then runs the two-pass fill: same contacts, same order, always.
+#define MZ_STAGE 3
+template <int NB>
+MZ_HD float* con_stage(AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
+
+template <int NB>
+MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+  static_assert(8 * MZ_STAGE * AntDims<NB>::NGEOM <= 3 * AntDims<NB>::NC * AntDims<NB>::NCOL, "staging lives in the cY block");
+  int n = 0;
+  geom_contacts<NB>(K, s, e, [&](const ContactGeo& g) {
+    if (n < MZ_STAGE) {
+      float* q = con_stage<NB>(s, MZ_STAGE * e + n);
+      for (int k = 0; k < 3; k++) { q[k] = g.pos[k]; q[3 + k] = g.n[k]; }
+      q[6] = g.dist; q[7] = (float)(g.kind + 16 * g.blk + 128 * g.other);
+    }
+    n++;
+  });
+  s.cnt[e] = n;
+  if (n > MZ_STAGE) s.con_over = 1;
+}
+
+template <int NB>
+MZ_HD void con_map_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+  using D = AntDims<NB>;
+  constexpr int NC = D::NC, NG = D::NGEOM;
+  int off = 0;
+  for (int g = 0; g < e; g++) off += s.cnt[g];
+  if (e == NG - 1) {
+    int tot = off + s.cnt[e];
+    if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+    s.ncon = tot;
+    s.cbeg[4] = tot;
+  }
+  const int b = e - D::NMOV;
+  if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
+  if (s.con_over) return;  // the env re-enumerates with con_fill_item
+  const int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, n = s.cnt[e];
+  for (int i = 0; i < n; i++) {
+    const int slot = off + i;
+    if (slot < NC) { s.csrc[slot] = MZ_STAGE * e + i; s.cleg[slot] = leg; s.ccls[slot] = cls; }
+  }
+}
+
 // per-item bodies of the collision / constraint-row phases
 template <int NB>
 MZ_HD void con_count_item(const AntDev& K, AntScratchT<NB>& s, int e) {
@@ -1014,6 +1065,7 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       q[6] = g.dist; q[7] = (float)(g.kind + 16 * g.blk + 128 * g.other);
       s.cleg[slot] = leg;
       s.ccls[slot] = cls;
+      s.csrc[slot] = -1;
       slot++;
     });
 }
@@ -1024,9 +1076,16 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
   constexpr int NH = D::NH;
 
     int c = item / 3, a = item - 3 * c;
-    const float* q = &s.cY[c][0][0];
-    float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
+    const int src = s.csrc[c];
+    const float* q = src >= 0 ? con_stage<NB>(s, src) : &s.cY[c][0][0];
+    float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3], dist = q[6];
     int code = (int)q[7], kind = code & 15, blk = (code >> 4) & 7, other = code >> 7;
+    if (src >= 0) {  // staged contact: the hint of a capsule-floor contact is the capsule's axis (geom_contacts), nothing else has one
+      const int b = src / MZ_STAGE - D::NMOV;
+      for (int k = 0; k < 3; k++) hint[k] = (kind == 0 && b > 0) ? s.w[b > 0 ? b - 1 : 0][k] : 0.f;
+    } else {
+      for (int k = 0; k < 3; k++) hint[k] = q[8 + k];
+    }
     if (kind == 6) {
       // joint-limit row of slide `other` of block `blk`: ONE frictionless row  r = J a - aref, cost D/2 min(0, r)^2.  It rides
       // the contact machinery as a pyramid whose tangential rows vanish: the four edge rows coincide (u0 +- 0), so
@@ -1354,15 +1413,24 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   MZ_FOR(l, 5 + (D::BALL ? 1 : 0)) kin_item<NB>(K, s, l);
   cx.sync();
   cx.tick(s, 0);
+  constexpr bool one_pass = NB == 0 && C::row_solver;  // single-pass contact enumeration (con_enum_item)
   MZ_FOR_AT(b, ANT_NBODY, 0) inertia_item<NB>(K, s, b);
-  MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e);
+  if constexpr (one_pass) { MZ_FOR_AT(e, NG, ANT_NBODY) con_enum_item<NB>(K, s, e); }
+  else { MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e); }
   cx.sync();
   cx.tick(s, 1);
   MZ_FOR_AT(l, 4, 0) crb_leg_item<NB>(K, s, l);
   MZ_FOR_AT(k, 10, 4) iall_item<NB>(K, s, k);
   MZ_FOR_AT(b, ANT_NBODY, 14) bias_body_item<NB>(K, s, b);
-  MZ_FOR_AT(e, NG, 14 + ANT_NBODY) con_fill_item<NB>(K, s, e);
+  if constexpr (one_pass) { MZ_FOR_AT(e, NG, 14 + ANT_NBODY) con_map_item<NB>(K, s, e); }
+  else { MZ_FOR_AT(e, NG, 14 + ANT_NBODY) con_fill_item<NB>(K, s, e); }
   cx.sync();
+  if constexpr (one_pass) {
+    if (s.con_over) {  // some geom found more contacts than its staging holds: this env fills the two-pass way
+      MZ_FOR(e, NG) con_fill_item<NB>(K, s, e);
+      cx.sync();
+    }
+  }
   cx.tick(s, 2);
   MZ_FOR_AT(e, NROOT, 0) crb_root_item<NB>(K, s, e);
   MZ_FOR_AT(i, NV, NROOT) bias_dof_item<NB>(K, s, i);
