@@ -17,8 +17,14 @@ acts = [(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30) for _ in 
 for i in range(150): env.step(acts[i % 16])
 env.set_option("profile_phases", 1)
 env.step(acts[0]); env.phase_cycles(); env.wave_cycles(NW)
+boxes = np.array(env.model.world.wall_boxes())  # x, y, z, hx, hy, hz
+def near_wall(xy, reach=1.25):
+    dx = np.maximum(np.abs(xy[:, None, 0] - boxes[None, :, 0]) - boxes[None, :, 3], 0.0)
+    dy = np.maximum(np.abs(xy[:, None, 1] - boxes[None, :, 1]) - boxes[None, :, 4], 0.0)
+    return ((dx * dx + dy * dy) < reach * reach).any(1)
 rows = []
 for k in range(8):
+    nw = near_wall(env.get_state()[0][:, :2].cpu().numpy()).reshape(-1, EPW)
     qacc, counts = env.debug_forward(acts[(k + 1) % 16])   # ncon / iters of the first forward evaluation of the coming step
     c = counts.cpu().numpy()
     obs, rew, done, info = env.step(acts[(k + 1) % 16])
@@ -27,7 +33,7 @@ for k in range(8):
     env.phase_cycles()
     ncon = c[:, 0].reshape(-1, EPW); it = c[:, 1].reshape(-1, EPW)
     d = done.cpu().numpy().reshape(-1, EPW)
-    rows.append(np.stack([cyc, ncon.max(1), ncon.sum(1), it.max(1), (d != 0).any(1), wit], 1))
+    rows.append(np.stack([cyc, ncon.max(1), ncon.sum(1), it.max(1), (d != 0).any(1), wit, nw.sum(1)], 1))
 R = np.concatenate(rows)
 cyc = R[:, 0]
 print(f"waves {len(cyc)}: mean {cyc.mean():.0f} std {cyc.std():.0f} min {cyc.min():.0f} q50 {np.median(cyc):.0f} q99 {np.quantile(cyc,0.99):.0f} max {cyc.max():.0f}")
@@ -39,6 +45,12 @@ A = np.stack([R[:, 5], np.ones(len(cyc))], 1)
 coef, *_ = np.linalg.lstsq(A, cyc, rcond=None)
 res = cyc - A @ coef
 print(f"  cycles ~ {coef[0]:.0f} * iterations + {coef[1]:.0f};  residual std {res.std():.0f} (of {cyc.std():.0f})")
+for v in range(0, EPW + 1):
+    m = R[:, 6] == v
+    if m.sum() > 5: print(f"  envs of the wave within the wall broad phase == {v}: {m.sum():5d} waves, mean cycles {cyc[m].mean():.0f}  std {cyc[m].std():.0f}")
+A = np.stack([R[:, 5], R[:, 6], R[:, 2], np.ones(len(cyc))], 1)
+coef, *_ = np.linalg.lstsq(A, cyc, rcond=None)
+print(f"  cycles ~ {coef[0]:.0f} * iterations + {coef[1]:.0f} * near-wall envs + {coef[2]:.0f} * contacts + {coef[3]:.0f};  residual std {(cyc - A @ coef).std():.0f}")
 for v in range(0, 9):
     m = R[:, 1] == v
     if m.sum() > 20: print(f"  max ncon == {v}: {m.sum():5d} waves, mean cycles {cyc[m].mean():.0f}  std {cyc[m].std():.0f}")
