@@ -70,7 +70,11 @@ struct AntDims {
   static constexpr int NBLK = NB == 4 ? 1 : (NB == 5 ? 0 : NB);  // movable blocks
   static constexpr int BD = NB == 4 ? 3 : 2;     // slide dofs per block
   static constexpr int NXH = BALL ? 6 : BD * NBLK;  // hub dofs beyond the root's six
-  static constexpr int NMOV = NBLK + (BALL ? 1 : 0);  // movable bodies = the first contact enumerators
+  // A movable block's contacts are enumerated by MZ_BSUB lanes (floor corners | the 3 x 3 grid cells under its bounding square,
+  // platform and wall each | lower-numbered blocks and its own slide limits), in that order: on one lane the block was ten times
+  // the work of any robot geom and the whole phase waited for it (twice: count and fill).
+  static constexpr int BSUB = 11;
+  static constexpr int NMOV = BSUB * NBLK + (BALL ? 1 : 0);  // enumerators of the movable bodies: the first ones
   static constexpr int NH = 6 + NXH;         // hub dofs: root 6 + the blocks' slides / the ball's six
   static constexpr int NV = 14 + NXH;        // MuJoCo dof order: root 0-5, legs 6-13, movable bodies 14..
   static constexpr int NQ = 15 + (BALL ? 7 : BD * NBLK);
@@ -749,8 +753,8 @@ MZ_HD void block_center(const AntDev& K, const AntScratchT<NB>& s, int k, float*
   bc[0] = (p0[0] - s.qpos[0]) + d[0]; bc[1] = (p0[1] - s.qpos[1]) + d[1]; bc[2] = (p0[2] - s.cz) + d[2];
 }
 
-// Enumerate the contacts of enumerator e: e < NB -> movable block e (floor corners, walls);
-// else robot geom (= body) b = e - NB (floor, walls, blocks).  `emit` is called once per contact, in a fixed
+// Enumerate the contacts of enumerator e: e < NMOV -> part e % BSUB of movable block e / BSUB (floor corners | one grid cell |
+// other blocks and slide limits) or the object ball; else robot geom (= body) b = e - NMOV (floor, walls, blocks / ball).  `emit` is called once per contact, in a fixed
 // order, identical in the count and fill passes.
 template <int NB, class Emit>
 MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&& emit) {
@@ -758,7 +762,9 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
   float inv = 1.0f / z.scale;
   float bs[3] = {z.half_xy, z.half_xy, z.half_z};
   ContactGeo cg;
-  if (e < AntDims<NB>::NBLK) {  // ---- movable block
+  if (e < AntDims<NB>::BSUB * AntDims<NB>::NBLK) {  // ---- movable block e / BSUB, part e % BSUB of its enumeration
+    const int sub = e % AntDims<NB>::BSUB;
+    e = e / AntDims<NB>::BSUB;
     float bc[3];
     block_center<NB>(K, s, e, bc);
     const float* hb = K.block_half;
@@ -775,7 +781,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         }
     }
     float bottom = (bc[2] + s.cz) - hb[2];  // absolute height of the bottom face
-    if (bottom < K.floor.margin)
+    if (sub == 0 && bottom < K.floor.margin)
       for (int ci = 0; ci < 4; ci++) {  // plane-box: the four bottom corners
         cg.kind = 3; cg.blk = e; cg.other = 0; cg.dist = bottom;
         cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
@@ -788,8 +794,12 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
     float gx = s.qpos[0] + bc[0], gy = s.qpos[1] + bc[1];
     int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
     int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
-    for (int i = i0; i <= i1; i++)
-      for (int j = j0; j <= j1; j++) {
+    // parts 1..9: cell (i0 + (sub - 1) / 3, j0 + (sub - 1) % 3) — a block is one cell wide (or less), its bounding square with the
+    // margin spans at most three cells per axis (ant_dev_from_model checks the sizes); row-major like the loop it replaces
+    const int ci_ = i0 + (sub - 1) / 3, cj_ = j0 + (sub - 1) % 3;
+    for (int i = ci_; i <= ci_; i++)
+      for (int j = cj_; j <= cj_; j++) {
+        if (sub < 1 || sub > 9 || i > i1 || j > j1) continue;
         if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
         // per cell: the platform of an elevated maze (z from 0 to 2 half_z), then the wall block standing on it
         for (int layer = 0; layer < 2; layer++) {
@@ -830,6 +840,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
           }
         }
       }
+    if (sub != AntDims<NB>::BSUB - 1) return;
     // lower-numbered movable blocks: aligned box-box [ASSUME-12], geom1 = block k, geom2 = block e
     for (int k = 0; k < e; k++) {
       float c1[3];

@@ -202,6 +202,11 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
     }
     a->block_mass = (float)m->body_mass[b];
     a->block_bw_tran = (float)m->body_invweight0[b][0];
+    {  // the enumeration gives a block 3 x 3 grid cells (geom_contacts): its bounding sphere + margin must stay inside that
+      const double* hb = m->geom_size[g];
+      if (sqrt(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]) + fmax(m->geom_margin[g], m->wall_margin) >= m->maze_scale)
+        return ant_fail(err, errlen, "ant kernel: a movable block must be smaller than a maze cell's reach (its bounding sphere < one cell size)");
+    }
   }
   if (m->jnt_type[0] != MZ_JNT_FREE || m->geom_type[0] != MZ_GEOM_PLANE || m->geom_type[1] != MZ_GEOM_SPHERE)
     return ant_fail(err, errlen, "ant kernel: expected free root joint, floor plane, torso sphere");

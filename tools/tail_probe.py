@@ -5,11 +5,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import mujoco_maze_amd as mm
-n = 4096
+env_id = sys.argv[2] if len(sys.argv) > 2 else "AntUMaze-v0"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 16   # the default lane-group width of the plain ant at this batch size
 EPW = 64 // lanes                                      # envs per wavefront (= per workgroup)
 NW = n // EPW
-env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True, force_vec=True)
+env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
 if len(sys.argv) > 1: env.set_option("lanes_per_env", lanes)
 env.reset(seed=1)
 g = torch.Generator(device=env.device).manual_seed(0)
