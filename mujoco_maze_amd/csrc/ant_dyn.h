@@ -1467,7 +1467,7 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   cx.tick(s, 2);
   MZ_FOR_AT(e, NROOT, 0) crb_root_item<NB>(K, s, e);
   MZ_FOR_AT(i, NV, NROOT) bias_dof_item<NB>(K, s, i);
-  if (!first) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7
+  if (!first && !one_pass) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7 (lane-group solver: shifted start)
   cx.sync();
   cx.tick(s, 3);
   if constexpr (NB == 0 && C::row_solver) {

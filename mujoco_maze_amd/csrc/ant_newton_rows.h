@@ -122,15 +122,6 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   }
   const int ri = isdof ? r : 0;
   const float qfs = isdof ? s.qfs[ri] : 0.f;
-  float qas;
-  {  // qacc_smooth = M^-1 qfrc_smooth by the same row elimination
-    float Hq[14];
-#pragma unroll
-    for (int k = 0; k < 14; k++) Hq[k] = Mrow[k];
-    qas = solve14(r, Hq, qfs);
-  }
-  if (isdof) s.qas[ri] = qas;
-  const float warm = isdof ? (compare ? s.warm[ri] : s.warm[ri] + qas) : 0.f;  // later stages: shifted by the change of qacc_smooth
   cx.tick(s, 12);
   // joint-limit row of this lane's own hinge (limit_item of ant_dyn.h, in registers: the row never leaves its lane)
   float lsign = 0.f, lD = 0.f, laref = 0.f;
@@ -148,6 +139,18 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     }
   }
   const bool has = ncon > 0 || cx.gany(lsign != 0.f);
+  // qacc_smooth = M^-1 qfrc_smooth by the same row elimination — only where it is used: on the first evaluation of a step
+  // (MuJoCo's warm-start rule compares against it) and for an env without any constraint (then it is the answer).  The
+  // Newton iteration itself works on M qacc - qfrc_smooth and never needs it.
+  float qas = 0.f;
+  if (compare || cx.any(!has)) {
+    float Hq[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) Hq[k] = Mrow[k];
+    qas = solve14(r, Hq, qfs);
+    if (isdof) s.qas[ri] = qas;
+  }
+  const float warm = isdof ? s.warm[ri] : 0.f;  // later evaluations start from the previous evaluation's solution
   // own contact: 3 x 8 Jacobian rows stay in LDS (row-major, read as needed); constants in registers
   const int cr = iscon ? r : 0;
   const float cD = iscon ? s.cD[cr] : 0.f;
