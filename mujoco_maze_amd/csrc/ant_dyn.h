@@ -121,6 +121,9 @@ struct alignas(16) AntScratchT {
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
   float fbody[13][6], bias[D::NV], Iall[10];  // per-body inertial + velocity-product force (spatial, at c)
   alignas(16) Arrow<D::NH> M, H;
+  // plain ant: M once more as dense rows (16 floats apart, zeros preset per step): lane r of the row solver reads its row with
+  // four wide loads instead of 22 scattered ones and a select chain
+  alignas(16) float Md[NB == 0 ? 16 : 1][16];
   ArrowFactor<D::NH> F;
   float grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
   // contacts
@@ -367,6 +370,15 @@ MZ_HD void crb_leg_item(const AntDev& K, AntScratchT<NB>& s, int l) {
       s.M.rl[l][0][3 + k] = dot3f(ax, Fh);
       s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
     }
+    if constexpr (NB == 0) {  // dense rows of the two leg dofs, and their columns in the root rows
+      const int ph = 6 + 2 * l, pa = 7 + 2 * l;
+      s.Md[ph][ph] = s.M.ll[l][0]; s.Md[ph][pa] = s.M.ll[l][1]; s.Md[pa][ph] = s.M.ll[l][1]; s.Md[pa][pa] = s.M.ll[l][2];
+      for (int k = 0; k < 6; k++) {
+        const float vh = s.M.rl[l][0][k], va = s.M.rl[l][1][k];
+        s.Md[ph][k] = vh; s.Md[k][ph] = vh;
+        s.Md[pa][k] = va; s.Md[k][pa] = va;
+      }
+    }
     for (int k = 6; k < NH; k++) { s.M.rl[l][0][k] = 0.f; s.M.rl[l][1][k] = 0.f; }  // blocks are separate trees
 }
 
@@ -424,6 +436,7 @@ MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       }
     }
     s.M.rr[i][j] = val; s.M.rr[j][i] = val;
+    if constexpr (NB == 0) { s.Md[i][j] = val; s.Md[j][i] = val; }
 }
 
 // Recursive Newton-Euler, outward half, one body per lane: body b = 0 torso, 1 + 3l + k (k = 0 welded leg, 1 aux, 2 ankle).
@@ -1651,6 +1664,7 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 // constant tables of the scratch block, once per step (to be followed by a cx.sync() before the first forward evaluation)
 template <int NB, class C>
 MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
+  if constexpr (NB == 0) { MZ_FOR(i, 256) s.Md[i >> 4][i & 15] = 0.f; }  // entries between different legs stay zero
   MZ_FOR(i, MZ_MAX_GRID) {
     s.rowmask[i] = maze_row(K.maze, i);
     if constexpr (NB > 0) {

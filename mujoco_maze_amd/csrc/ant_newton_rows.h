@@ -107,19 +107,8 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
 
   // ---- row r of M, per-dof vectors, own limit row
   float Mrow[14];
-  {
-    const float* rowp = r < 6 ? &s.M.rr[r < 6 ? r : 0][0] : &s.M.rl[ishinge ? leg : 0][ishinge ? d : 0][0];
 #pragma unroll
-    for (int k = 0; k < 6; k++) Mrow[k] = isdof ? rowp[k] : 0.f;
-#pragma unroll
-    for (int k = 6; k < 14; k++) {
-      const int l2 = (k - 6) >> 1, d2 = (k - 6) & 1;
-      float v = 0.f;
-      if (r < 6) v = s.M.rl[l2][d2][r < 6 ? r : 0];
-      else if (ishinge && leg == l2) v = s.M.ll[l2][d == d2 ? (d ? 2 : 0) : 1];
-      Mrow[k] = v;
-    }
-  }
+  for (int k = 0; k < 14; k++) Mrow[k] = s.Md[r][k];  // dense rows written beside the arrow form (crb_leg_item / crb_root_item); rows 14, 15 are zero
   const int ri = isdof ? r : 0;
   const float qfs = isdof ? s.qfs[ri] : 0.f;
   cx.tick(s, 12);
