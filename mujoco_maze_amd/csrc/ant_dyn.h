@@ -394,8 +394,8 @@ template <int NB>
 MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
   constexpr int NH = AntDims<NB>::NH;
 
-    if (e >= 21) {  // rows of the movable bodies in the hub: separate trees, no coupling with the robot
-      int q = e - 21, i = 6 + q / NH, j = q - (i - 6) * NH;
+    if (e >= 15) {  // rows of the movable bodies in the hub: separate trees, no coupling with the robot
+      int q = e - 15, i = 6 + q / NH, j = q - (i - 6) * NH;
       float val = (i == j) ? K.block_mass : 0.f;
       if constexpr (AntDims<NB>::BALL) {
         // Free body whose centre of mass sits c = (0, 0, h) above the frame origin (body frame); dofs: linear velocity of
@@ -414,14 +414,16 @@ MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       s.M.rr[i][j] = val; s.M.rr[j][i] = val;
       return;
     }
-    // root 6x6 block from the whole-body composite inertia (lower triangle, mirrored)
-    int i = e < 1 ? 0 : e < 3 ? 1 : e < 6 ? 2 : e < 10 ? 3 : e < 15 ? 4 : 5;
-    int j = e - (i * (i + 1)) / 2;
-    float m = s.Iall[0], h[3] = {s.Iall[1], s.Iall[2], s.Iall[3]}, J[6];
+    // root 6x6 block from the whole-body composite inertia: the nine angular-linear entries (e < 9) and the lower triangle of
+    // the angular block (mirrored) — 15 items, one pass of a 16-lane group; the linear block is total mass x identity, constant,
+    // preset once per step by ant_fill_tables
+    int i, j;
+    if (e < 9) { i = 3 + e / 3; j = e - 3 * (i - 3); }
+    else { const int t = e - 9; i = t < 1 ? 3 : (t < 3 ? 4 : 5); j = 3 + t - ((i - 3) * (i - 2)) / 2; }
+    float h[3] = {s.Iall[1], s.Iall[2], s.Iall[3]}, J[6];
     for (int k = 0; k < 6; k++) J[k] = s.Iall[4 + k];
     float val;
-    if (i < 3) val = (i == j) ? m : 0.f;
-    else {
+    {
       float ai[3] = {s.R0[i - 3], s.R0[3 + i - 3], s.R0[6 + i - 3]};
       if (j < 3) {  // angular i with linear j: ai . (h x e_j)
         float ej[3] = {j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f}, hx[3];
@@ -1454,7 +1456,7 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
 template <int NB, class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   using D = AntDims<NB>;
-  constexpr int NH = D::NH, NV = D::NV, NG = D::NGEOM, NROOT = 21 + (NH - 6) * NH;
+  constexpr int NH = D::NH, NV = D::NV, NG = D::NGEOM, NROOT = 15 + (NH - 6) * NH;
   cx.tick(s, 9);
   MZ_FOR(l, 5 + (D::BALL ? 1 : 0)) kin_item<NB>(K, s, l);
   cx.sync();
@@ -1665,6 +1667,14 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 template <int NB, class C>
 MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
   if constexpr (NB == 0) { MZ_FOR(i, 256) s.Md[i >> 4][i & 15] = 0.f; }  // entries between different legs stay zero
+  cx.sync();
+  MZ_FOR(e, 9) {  // linear block of the root's mass matrix: total mass x identity (summed in body order, as the composite inertia is)
+    float m = 0.f;
+    for (int b = 0; b < ANT_NBODY; b++) m += K.mass[body_class(b)];
+    const int i = e / 3, j = e - 3 * i;
+    s.M.rr[i][j] = i == j ? m : 0.f;
+    if constexpr (NB == 0) s.Md[i][j] = i == j ? m : 0.f;
+  }
   MZ_FOR(i, MZ_MAX_GRID) {
     s.rowmask[i] = maze_row(K.maze, i);
     if constexpr (NB > 0) {
