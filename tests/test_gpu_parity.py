@@ -205,6 +205,43 @@ def test_ant_wall_contacts_and_goal(torch, oracle):
     env.close()
 
 
+def test_ant_corner_contacts_overflow_the_staging(torch, oracle):
+    """Single-pass contact enumeration (csrc/ant_dyn.h con_enum_item): a geom keeps its first three contacts in a staging
+    entry; a geom that finds more (a foot in a wall corner: floor + two walls, two contacts each) sends the env through the
+    two-pass fill.  Ants are dropped into the south-east corner of the UMaze's first corridor so that both paths occur:
+    contact counts of the forward evaluation equal the oracle's env by env, and a step agrees with it."""
+    n = 256
+    env = mm.make("AntUMaze-v0", num_envs=n)
+    cm = env.model
+    st = _rollout_states(oracle, cm, n, 8, {40})[40]
+    rng = np.random.default_rng(9)
+    # the corridor east of the start ends at the wall faces x = 20 (east) and y = -4 (south): leg tips reach 1.1 from the torso
+    st["qpos"][:, 0] = 19.0 + rng.uniform(0.0, 0.7, n)
+    st["qpos"][:, 1] = -3.0 - rng.uniform(0.0, 0.7, n)
+    st["qvel"][:, 0] = 1.0
+    st["qvel"][:, 1] = -1.0
+    st = _f32(st)
+    act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
+    env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+    _, counts = env.debug_forward(act)
+    fref = oracle.forward(cm, st["qpos"], st["qvel"], act.astype(np.float64), st["warm"])
+    nc = fref["counts"][:, 0]
+    dc = counts.cpu().numpy()[:, 0]
+    # equal env by env, up to the cap of 16 contact slots (flagged, not fatal) and fp32 / fp64 ties at the activation distance
+    diff = np.where(dc != np.minimum(nc, 16))[0]
+    assert len(diff) <= 3 and np.all(np.abs(dc[diff] - nc[diff]) <= 1), (diff, dc[diff], nc[diff])
+    assert nc.max() >= 8 and (nc >= 6).sum() >= 20 and nc.min() <= 4  # crowded corners and ordinary stances in one batch
+    start = {k: v.copy() for k, v in st.items()}
+    obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+    qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+    ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    good = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, max_outlier_frac=0.08, hard_atol=1e-4)
+    assert np.all(_close(obs.cpu().numpy()[good], ref["obs"][good]))
+    assert np.array_equal(done.cpu().numpy(), ref["done"])
+    assert np.all((env.status().cpu().numpy() & 1) == 0)
+    env.close()
+
+
 def test_ant_push_movable_block(torch, oracle):
     """BASELINE config 5: AntPush-v0, 2048 envs — movable-block contacts, obs (33,) with block xyz at [3:6]."""
     n = 2048
