@@ -1453,6 +1453,9 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
 //   P3  hub mass-matrix entries (21 + ..) | bias / smooth force per dof (NV)
 //   P4  2x2 leg inverses of M (4) | contact Jacobian rows (3 ncon) | joint-limit rows (8)
 //   P5  Schur entries + reduced rhs    P6  hub Cholesky (1 lane)    P7  back-substitution -> qacc_smooth
+// The plain ant on the device differs: contacts are enumerated once (P1 con_enum_item stages them, P2 con_map_item assigns the
+// slots), there is no torso-level wall broad phase, and P4 onwards is the row solver of ant_newton_rows.h (which reads M from
+// the dense copy Md and solves for qacc_smooth only where it is needed).
 template <int NB, class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   using D = AntDims<NB>;
