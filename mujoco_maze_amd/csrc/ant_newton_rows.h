@@ -20,6 +20,8 @@
 // scaled-gradient tolerance or the fp32 cancellation floor.  Rows beyond the first of a lane group (32 / 64 lanes per env)
 // mirror row 0 (same r, same values, duplicate stores): no masking, no divergence.
 #pragma once
+#include <type_traits>
+
 #include "ant_dyn.h"
 #include "mz_device.h"
 
@@ -191,35 +193,50 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     if (lsign != 0.f) { ljar = lsign * qacc - laref; lact = ljar < 0.f ? lD : 0.f; }
   }
   while (cx.any(!done) && it < K.max_iter) {
-    // ---- contact lanes publish gradient block g3 and curvature block W of their contact (parked in the idle Y slot)
+    // ---- contact lanes: gradient block g3 and curvature block W of their contact, in registers; every lane of the row reads
+    // them with `row_newbcast:c` (fold_contact<c>): no LDS publish, no hand-off wait
+    float mycg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (iscon) {
       const float r0 = u0 + u1, r1 = u0 - u1, r2 = u0 + u2, r3 = u0 - u2;
       const float a0 = r0 < 0.f ? 1.f : 0.f, a1 = r1 < 0.f ? 1.f : 0.f, a2 = r2 < 0.f ? 1.f : 0.f, a3 = r3 < 0.f ? 1.f : 0.f;
-      float* cg = &s.cY[cr][0][0];
-      cg[0] = cD * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3); cg[1] = cD * (a0 * r0 - a1 * r1); cg[2] = cD * (a2 * r2 - a3 * r3);
-      cg[3] = cD * (a0 + a1 + a2 + a3); cg[4] = cD * (a0 - a1); cg[5] = cD * (a2 - a3); cg[6] = cD * (a0 + a1); cg[7] = cD * (a2 + a3);
+      mycg[0] = cD * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3); mycg[1] = cD * (a0 * r0 - a1 * r1); mycg[2] = cD * (a2 * r2 - a3 * r3);
+      mycg[3] = cD * (a0 + a1 + a2 + a3); mycg[4] = cD * (a0 - a1); mycg[5] = cD * (a2 - a3); mycg[6] = cD * (a0 + a1); mycg[7] = cD * (a2 + a3);
     }
-    cx.sync();
     // ---- row r of H = M + sum_c Jc^T Wc Jc + limit curvature; gradient entry r
     float Hrow[14];
 #pragma unroll
     for (int k = 0; k < 14; k++) Hrow[k] = Mrow[k];
     float g = Mx, ga = fabsf(Mx);
-    for (int c = 0; c < ncon; c++) {
-      const float* cg = &s.cY[c][0][0];
-      const int lc = s.cleg[c];
-      const int col = r < 6 ? r : ((ishinge && leg == lc) ? 6 + d : -1);
-      const int cc = col >= 0 ? col : 0;
-      const float j0 = col >= 0 ? s.cJ[c][0][cc] : 0.f, j1 = col >= 0 ? s.cJ[c][1][cc] : 0.f, j2 = col >= 0 ? s.cJ[c][2][cc] : 0.f;
-      const float t = j0 * cg[0] + j1 * cg[1] + j2 * cg[2];
-      g += t; ga += fabsf(t);
-      const float t0 = j0 * cg[3] + j1 * cg[4] + j2 * cg[5], t1 = j0 * cg[4] + j1 * cg[6], t2 = j0 * cg[5] + j2 * cg[7];  // (W Jc)[:, col]
+    auto fold = [&](auto Cc) {
+      constexpr int C = decltype(Cc)::value;
+      if (C < ncon) {  // (uniform within the env's row)
+        float cg[8];
 #pragma unroll
-      for (int k = 0; k < 6; k++) Hrow[k] += t0 * s.cJ[c][0][k] + t1 * s.cJ[c][1][k] + t2 * s.cJ[c][2][k];
-      const float h6 = t0 * s.cJ[c][0][6] + t1 * s.cJ[c][1][6] + t2 * s.cJ[c][2][6];
-      const float h7 = t0 * s.cJ[c][0][7] + t1 * s.cJ[c][1][7] + t2 * s.cJ[c][2][7];
+        for (int k = 0; k < 8; k++) cg[k] = bcast<C>(mycg[k]);
+        const int lc = __builtin_amdgcn_update_dpp(0, cl, 0x150 + C, 0xF, 0xF, false);
+        const int col = r < 6 ? r : ((ishinge && leg == lc) ? 6 + d : -1);
+        const int cc = col >= 0 ? col : 0;
+        const float j0 = col >= 0 ? s.cJ[C][0][cc] : 0.f, j1 = col >= 0 ? s.cJ[C][1][cc] : 0.f, j2 = col >= 0 ? s.cJ[C][2][cc] : 0.f;
+        const float t = j0 * cg[0] + j1 * cg[1] + j2 * cg[2];
+        g += t; ga += fabsf(t);
+        const float t0 = j0 * cg[3] + j1 * cg[4] + j2 * cg[5], t1 = j0 * cg[4] + j1 * cg[6], t2 = j0 * cg[5] + j2 * cg[7];  // (W Jc)[:, col]
 #pragma unroll
-      for (int l2 = 0; l2 < 4; l2++) { Hrow[6 + 2 * l2] += lc == l2 ? h6 : 0.f; Hrow[7 + 2 * l2] += lc == l2 ? h7 : 0.f; }
+        for (int k = 0; k < 6; k++) Hrow[k] += t0 * s.cJ[C][0][k] + t1 * s.cJ[C][1][k] + t2 * s.cJ[C][2][k];
+        const float h6 = t0 * s.cJ[C][0][6] + t1 * s.cJ[C][1][6] + t2 * s.cJ[C][2][6];
+        const float h7 = t0 * s.cJ[C][0][7] + t1 * s.cJ[C][1][7] + t2 * s.cJ[C][2][7];
+#pragma unroll
+        for (int l2 = 0; l2 < 4; l2++) { Hrow[6 + 2 * l2] += lc == l2 ? h6 : 0.f; Hrow[7 + 2 * l2] += lc == l2 ? h7 : 0.f; }
+      }
+    };
+    if (cx.any(ncon > 0)) {
+      fold(std::integral_constant<int, 0>{}); fold(std::integral_constant<int, 1>{}); fold(std::integral_constant<int, 2>{}); fold(std::integral_constant<int, 3>{});
+      if (cx.any(ncon > 4)) {
+        fold(std::integral_constant<int, 4>{}); fold(std::integral_constant<int, 5>{}); fold(std::integral_constant<int, 6>{}); fold(std::integral_constant<int, 7>{});
+        if (cx.any(ncon > 8)) {
+          fold(std::integral_constant<int, 8>{}); fold(std::integral_constant<int, 9>{}); fold(std::integral_constant<int, 10>{}); fold(std::integral_constant<int, 11>{});
+          fold(std::integral_constant<int, 12>{}); fold(std::integral_constant<int, 13>{}); fold(std::integral_constant<int, 14>{}); fold(std::integral_constant<int, 15>{});
+        }
+      }
     }
     if (lsign != 0.f) { const float t = lsign * lact * ljar; g += t; ga += fabsf(t); }
 #pragma unroll
