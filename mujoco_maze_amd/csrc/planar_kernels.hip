@@ -318,7 +318,10 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
                      reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs, h->model.obs_dim)
     const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
     if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_STEP(3, 3); else if (bd == 2) MZ_SW_STEP(3, 2); else MZ_SW_STEP(3, 0); }
-    else { if (bd == 3) MZ_SW_STEP(2, 3); else if (bd == 2) MZ_SW_STEP(2, 2); else MZ_SW_STEP(2, 0); }
+    else if (h->swimmer.nlink == 2) { if (bd == 3) MZ_SW_STEP(2, 3); else if (bd == 2) MZ_SW_STEP(2, 2); else MZ_SW_STEP(2, 0); }
+    else if (h->swimmer.nlink == 4) MZ_SW_STEP(4, 0);  // longer chains (user MJCF): no movable blocks
+    else if (h->swimmer.nlink == 5) MZ_SW_STEP(5, 0);
+    else MZ_SW_STEP(6, 0);
 #undef MZ_SW_STEP
     return hipGetLastError();
   }
@@ -348,7 +351,10 @@ hipError_t mzk_planar_reset(mz_handle* h, hipStream_t st, const uint8_t* mask_de
 #define MZ_SW_RESET(NL, NB) hipLaunchKernelGGL((swimmer_reset_kernel<NL, NB>), dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim)
     const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
     if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_RESET(3, 3); else if (bd == 2) MZ_SW_RESET(3, 2); else MZ_SW_RESET(3, 0); }
-    else { if (bd == 3) MZ_SW_RESET(2, 3); else if (bd == 2) MZ_SW_RESET(2, 2); else MZ_SW_RESET(2, 0); }
+    else if (h->swimmer.nlink == 2) { if (bd == 3) MZ_SW_RESET(2, 3); else if (bd == 2) MZ_SW_RESET(2, 2); else MZ_SW_RESET(2, 0); }
+    else if (h->swimmer.nlink == 4) MZ_SW_RESET(4, 0);
+    else if (h->swimmer.nlink == 5) MZ_SW_RESET(5, 0);
+    else MZ_SW_RESET(6, 0);
 #undef MZ_SW_RESET
     return hipGetLastError();
   }

@@ -24,15 +24,19 @@
 
 #include "ant_model.h"
 
+// MZ_SW_MAXL: longest planar chain the kernels are instantiated for (user MJCF: mjcf.py accepts 2..6 links)
+#define MZ_SW_MAXL 6
+
 struct SwimmerDev {
-  double h, gear, ctrl_lo, ctrl_hi, armature, density, viscosity, inv_scale;
+  double h, density, viscosity, inv_scale;
+  double gear[MZ_SW_MAXL - 1], ctrl_lo[MZ_SW_MAXL - 1], ctrl_hi[MZ_SW_MAXL - 1], armature[MZ_SW_MAXL + 2];  // per motor / per dof
   int frame_skip, reset_kind;
-  double mass[3], izz[3], box[3][3];  // per link: mass, inertia about z through the centre, inertia-box sizes
-  double com[3];                      // link centre along the link's local x axis
-  double off[3];                      // origin of link b in its parent's frame, along the parent's local x
-  double lim_lo[2], lim_hi[2], lim_K, lim_B, lim_solimp[5], dofw[2];
-  double qpos0[5];
-  int nlink;                          // 3 Swimmer, 2 Reacher
+  double mass[MZ_SW_MAXL], izz[MZ_SW_MAXL], box[MZ_SW_MAXL][3];  // per link: mass, inertia about z through the centre, inertia-box sizes
+  double com[MZ_SW_MAXL];             // link centre along the link's local x axis
+  double off[MZ_SW_MAXL];             // origin of link b in its parent's frame, along the parent's local x
+  double lim_lo[MZ_SW_MAXL - 1], lim_hi[MZ_SW_MAXL - 1], lim_K, lim_B, lim_solimp[5], dofw[MZ_SW_MAXL - 1];
+  double qpos0[MZ_SW_MAXL + 2];
+  int nlink;                          // 3 Swimmer, 2 Reacher; 4..6: user-supplied chains
   // movable blocks of the maze: `collision="predefined"` gives the swimmer no contact pairs at all, so a block is a free,
   // force-free slide-x / slide-y body — it only drifts with whatever velocity it is given and shows up in the observation
   int nblock, observe_blocks;
@@ -49,11 +53,11 @@ static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char*
   const int nbk = m->nblock, nl = m->nbody - 1 - nbk;
   if (nbk < 0 || nbk > 1) return ant_fail(err, errlen, "swimmer kernel: at most one movable block");
   const int nbd0 = nbk ? m->body_jntnum[m->block_bodyid[0]] : 0;
-  bool ok = m->robot == MZ_ROBOT_SWIMMER && (nl == 2 || nl == 3) && m->nv == nl + 2 + nbd0 && m->nq == nl + 2 + nbd0 && m->nu == nl - 1 &&
+  bool ok = m->robot == MZ_ROBOT_SWIMMER && nl >= 2 && nl <= MZ_SW_MAXL && (nl <= 3 || nbk == 0) && m->nv == nl + 2 + nbd0 && m->nq == nl + 2 + nbd0 && m->nu == nl - 1 &&
             m->collision_predefined && m->jnt_type[0] == MZ_JNT_SLIDE && m->jnt_type[1] == MZ_JNT_SLIDE;
   for (int j = 2; ok && j < nl + 2; j++) ok = m->jnt_type[j] == MZ_JNT_HINGE;
   for (int a = 0; ok && a < nl - 1; a++) ok = m->act_dofid[a] == 3 + a;
-  if (!ok) return ant_fail(err, errlen, "swimmer kernel: model is not the 2- or 3-link planar swimmer / reacher");
+  if (!ok) return ant_fail(err, errlen, "swimmer kernel: model is not a planar chain of 2..6 links on two slides (movable blocks: 2- and 3-link chains only)");
   p->nlink = nl; p->nblock = nbk; p->observe_blocks = m->observe_blocks;
   p->gz = m->gravity[2];
   const int nbd = nbk ? m->body_jntnum[m->block_bodyid[0]] : 0;
@@ -81,8 +85,12 @@ static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char*
     p->block_box[2] = sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / p->block_mass * 6.0);
   }
   p->h = m->timestep; p->frame_skip = m->frame_skip; p->reset_kind = m->reset_qvel_kind;
-  p->gear = m->act_gear[0]; p->ctrl_lo = m->act_ctrlrange[0][0]; p->ctrl_hi = m->act_ctrlrange[0][1];
-  p->armature = m->dof_armature[0]; p->density = m->density; p->viscosity = m->viscosity;
+  for (int a = 0; a < nl - 1; a++) { p->gear[a] = m->act_gear[a]; p->ctrl_lo[a] = m->act_ctrlrange[a][0]; p->ctrl_hi[a] = m->act_ctrlrange[a][1]; }
+  for (int k = 0; k < nl + 2; k++) {
+    p->armature[k] = m->dof_armature[k];
+    if (m->dof_damping[k] != 0.0) return ant_fail(err, errlen, "swimmer kernel: joint damping is not modelled (the assets have none)");
+  }
+  p->density = m->density; p->viscosity = m->viscosity;
   p->inv_scale = 1.0 / (m->meaninertia * m->nv);  // MuJoCo scales the solver tolerance with the whole model
   for (int b = 0; b < nl; b++) {
     const double* I = m->body_inertia[b + 1];
@@ -175,7 +183,7 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
   double M[NV][NV], frc[NV];
   for (int i = 0; i < NV; i++) {
     frc[i] = 0.0;
-    for (int j = 0; j < NV; j++) M[i][j] = i == j ? P.armature : 0.0;
+    for (int j = 0; j < NV; j++) M[i][j] = i == j ? P.armature[i] : 0.0;
   }
   for (int b = 0; b < NL; b++) {
     double m = P.mass[b];
@@ -323,7 +331,7 @@ MZS_HD int swimmer_env_step(const SwimmerDev& P, double* q, double* v, const dou
   double x0 = q[0], y0 = q[1];
   constexpr int NV = NL + 2, NH = NL - 1;
   double tau[NH];
-  for (int k = 0; k < NH; k++) tau[k] = P.gear * fmin(fmax(action[k], P.ctrl_lo), P.ctrl_hi);
+  for (int k = 0; k < NH; k++) tau[k] = P.gear[k] * fmin(fmax(action[k], P.ctrl_lo[k]), P.ctrl_hi[k]);
   for (int f = 0; f < P.frame_skip; f++) {
     const double h = P.h;
     double q0[NV], v0[NV], accv[NV], accf[NV], qs[NV], vs[NV], a[NV];

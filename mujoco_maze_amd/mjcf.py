@@ -235,7 +235,12 @@ def spec_from_mjcf(source: str, like: R.RobotSpec) -> R.RobotSpec:
         acts.append(R.ActuatorSpec(a["joint"], gear, _floats(a.get("ctrlrange", "0 0")), a.get("ctrllimited", "false") == "true"))
     nq = sum(7 if j.type == R.FREE else 1 for b in bodies for j in b.joints)
     nv = sum(6 if j.type == R.FREE else 1 for b in bodies for j in b.joints)
-    if (nq, nv) != (like.nq_robot, like.nv_robot) or len(acts) != len(like.actuators):
+    # The swimmer family's kernels are written for planar chains of 2..6 links (csrc/swimmer_dyn.h is generic in the link count;
+    # Swimmer = 3, Reacher = 2): a user's chain may be longer or shorter than the built-in asset's.  Every other family keeps
+    # its structure (parameters may change, topology not).
+    chain = (like.name in ("swimmer", "reacher") and nq == nv == len(bodies) + 2 and 2 <= len(bodies) <= 6 and len(acts) == len(bodies) - 1
+             and all(b.parent == i - 1 for i, b in enumerate(bodies)))
+    if not chain and ((nq, nv) != (like.nq_robot, like.nv_robot) or len(acts) != len(like.actuators)):
         raise ValueError(f"{like.name}: the XML has {nq} / {nv} coordinates and {len(acts)} motors; the {like.name} kernels are "
                          f"written for {like.nq_robot} / {like.nv_robot} and {len(like.actuators)} (parameters may change, structure not)")
     import dataclasses

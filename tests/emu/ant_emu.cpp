@@ -199,7 +199,10 @@ extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float
   const int bd = P.nblock ? P.nbdof : 0;
 #define MZ_SW(NL, BD) swimmer_env_step_t<NL, BD>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
   if (P.nlink == 3) return bd == 3 ? MZ_SW(3, 3) : (bd == 2 ? MZ_SW(3, 2) : MZ_SW(3, 0));
-  return bd == 3 ? MZ_SW(2, 3) : (bd == 2 ? MZ_SW(2, 2) : MZ_SW(2, 0));
+  if (P.nlink == 2) return bd == 3 ? MZ_SW(2, 3) : (bd == 2 ? MZ_SW(2, 2) : MZ_SW(2, 0));
+  if (P.nlink == 4) return MZ_SW(4, 0);
+  if (P.nlink == 5) return MZ_SW(5, 0);
+  return MZ_SW(6, 0);
 #undef MZ_SW
 }
 

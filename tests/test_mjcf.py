@@ -108,3 +108,101 @@ def test_structural_changes_are_refused():
         model.compile_model("ant", T.DistRewardUMaze(8.0), 8.0, robot_xml=xml.replace('integrator="RK4"', 'integrator="Euler"'))
     with pytest.raises(ValueError, match="not supported"):
         model.compile_model("ant", T.DistRewardUMaze(8.0), 8.0, robot_xml=xml.replace('type="sphere"', 'type="ellipsoid"'))
+
+
+# ------------------------------------------------------------------------------------------------ planar chains of other lengths
+def chain_swimmer_xml(nlink, seg=0.8):
+    """An n-link swimmer in the style of the reference's swimmer.xml (a user-supplied robot of another
+    topology behind the same plugin surface): two slides + a hinge on the head, one limited, motorised hinge per further link."""
+    body_open, body_close, motors = "", "", ""
+    for k in range(1, nlink):
+        pos = "0.5 0 0" if k == 1 else f"{-seg} 0 0"
+        body_open += f"""
+        <body name="link{k}" pos="{pos}">
+          <geom name="g{k}" type="capsule" fromto="0 0 0 {-seg} 0 0" size="{0.1 - 0.01 * k}"/>
+          <joint name="rot{k + 1}" type="hinge" axis="0 0 1" pos="0 0 0" limited="true" range="-80 80"/>"""
+        body_close += "\n        </body>"
+        motors += f'\n    <motor joint="rot{k + 1}" gear="{150 - 10 * k}" ctrllimited="true" ctrlrange="-1 1"/>'
+    return f"""
+<mujoco model="chain{nlink}">
+  <compiler angle="degree" coordinate="local" inertiafromgeom="true"/>
+  <option integrator="RK4" timestep="0.01" density="4000" viscosity="0.1" collision="predefined"/>
+  <default>
+    <geom conaffinity="1" condim="1" contype="1" density="1000"/>
+    <joint armature="0.1"/>
+  </default>
+  <worldbody>
+    <geom name="floor" type="plane" size="40 40 0.1" pos="0 0 -0.1" condim="3"/>
+    <body name="torso" pos="0 0 0">
+      <geom name="head" type="capsule" fromto="1.5 0 0 0.5 0 0" size="0.1"/>
+      <joint name="slider1" type="slide" axis="1 0 0" pos="0 0 0"/>
+      <joint name="slider2" type="slide" axis="0 1 0" pos="0 0 0"/>
+      <joint name="rot" type="hinge" axis="0 0 1" pos="0 0 0"/>{body_open}{body_close}
+    </body>
+  </worldbody>
+  <actuator>{motors}
+  </actuator>
+</mujoco>
+"""
+
+
+@pytest.mark.parametrize("nlink", [4, 5, 6])
+def test_user_chain_of_another_length(nlink, oracle):
+    """The swimmer family takes planar chains of 2..6 links from user MJCF: model constants from the XML, observation = whole
+    qpos / qvel (swimmer.py:50-54), and the kernel's step function (csrc/swimmer_dyn.h through tests/emu) against the float64
+    oracle's generic tree dynamics."""
+    from tests import emu_lib
+
+    cm = model.compile_model("swimmer", T.DistRewardUMaze(4.0), 4.0, robot_xml=chain_swimmer_xml(nlink))
+    m = cm.c
+    assert (m.nq, m.nv, m.nu, m.obs_dim) == (nlink + 2, nlink + 2, nlink - 1, 2 * (nlink + 2) + 1)
+    assert m.act_gear[0] == 140.0 and m.act_gear[nlink - 2] == 150.0 - 10 * (nlink - 1) and m.nbody == nlink + 1
+    n = 64
+    st, obs0 = oracle.reset(cm, n, 3)
+    assert np.array_equal(obs0[:, : nlink + 2], st["qpos"]) and np.array_equal(obs0[:, nlink + 2: -1], st["qvel"])
+    rng = np.random.default_rng(1)
+    moved = 0.0
+    for k in range(61):
+        act = rng.uniform(-1, 1, (n, nlink - 1)).astype(np.float32)
+        if k in (0, 5, 30, 60):
+            s64 = {kk: (v.astype(np.float32).astype(np.float64) if v.dtype == np.float64 else v.copy()) for kk, v in st.items()}
+            s32 = emu_lib.f32_state(s64)
+            ro = oracle.step(cm, s64, act.astype(np.float64))
+            re_ = emu_lib.swimmer_env_step(cm, s32, act)
+            assert np.abs(s32["qpos"] - s64["qpos"]).max() < 2e-6 and np.abs(s32["qvel"] - s64["qvel"]).max() < 2e-5
+            assert np.abs(re_["obs"] - ro["obs"]).max() < 2e-5 and np.abs(re_["reward"] - ro["reward"]).max() < 1e-5
+            assert np.array_equal(re_["done"], ro["done"]) and np.all(re_["status"] == 0)
+        oracle.step(cm, st, act.astype(np.float64))
+        moved = max(moved, np.abs(st["qpos"][:, 3:]).max())
+    assert moved > 0.5  # the joints really bend (limits at +-80 degrees come into play)
+    with pytest.raises(ValueError):
+        model.compile_model("swimmer", T.DistRewardUMaze(4.0), 4.0, robot_xml=chain_swimmer_xml(7))
+
+
+@pytest.mark.gpu
+def test_user_chain_on_the_device(oracle):
+    """A five-link chain from user MJCF on the HIP path (swimmer_step_kernel<5, 0>): single-step parity from rollout states."""
+    import torch
+
+    import mujoco_maze_amd as mm
+
+    n = 512
+    env = mm.make("SwimmerUMaze-v0", num_envs=n, robot_xml=chain_swimmer_xml(5))
+    cm = env.model
+    assert (env.nq, env.nu, env.obs_dim) == (7, 4, 15)
+    st, _ = oracle.reset(cm, n, 7)
+    rng = np.random.default_rng(2)
+    for k in range(41):
+        act = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        if k in (0, 10, 40):
+            s64 = {kk: (v.astype(np.float32).astype(np.float64) if v.dtype == np.float64 else v.copy()) for kk, v in st.items()}
+            env.set_state(s64["qpos"], s64["qvel"], None, s64["t"])
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+            ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+            qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+            assert np.abs(qpos - s64["qpos"]).max() < 2e-6 and np.abs(qvel - s64["qvel"]).max() < 2e-5
+            assert np.abs(obs.cpu().numpy() - ref["obs"]).max() < 2e-5 and np.array_equal(done.cpu().numpy(), ref["done"])
+            assert np.abs(rew.cpu().numpy() - ref["reward"]).max() < 1e-5
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    assert np.all(env.status().cpu().numpy() == 0)
+    env.close()
