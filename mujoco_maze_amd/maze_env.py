@@ -164,19 +164,20 @@ class VecMazeEnv:
 
     def _apply_host_task(self):
         """User-defined Python reward()/termination(): evaluated on the host from the obs batch (one device-to-host copy
-        of obs / info / done per step; the kernel supplied the inner reward terms, the task part is computed here).  With
+        per step; the kernel supplied the inner reward terms, the task part is computed here).  With
         auto-reset the host then resets exactly the envs ITS verdict finished (the kernel's auto-reset is off for these
         tasks, see set_auto_reset)."""
         torch = self._torch
         m = self.model.c
-        obs = self._obs.double().cpu().numpy()
-        inf = self._info.double().cpu().numpy()
+        # one device-to-host copy: obs | info | done packed into one tensor
+        packed = torch.cat([self._obs, self._info, self._done.to(torch.float32).unsqueeze(1)], dim=1).double().cpu().numpy()
+        obs, inf, dev_done = packed[:, : self.obs_dim], packed[:, self.obs_dim: self.obs_dim + 4], packed[:, -1].astype(np.uint8)
         inner = (m.forward_reward_weight * inf[:, 2] + inf[:, 3]) * m.inner_reward_scaling  # ant.py:68, swimmer.py:43
         if m.robot == 0:
             inner[:] = 0.0  # point.py:61
         rew = np.array([self._task.reward(o) for o in obs]) + inner
         term = np.array([bool(self._task.termination(o)) for o in obs])
-        done = (term.astype(np.uint8) | (self._done.cpu().numpy() & 2)).astype(np.uint8)
+        done = (term.astype(np.uint8) | (dev_done & 2)).astype(np.uint8)
         self._reward.copy_(torch.as_tensor(rew, dtype=torch.float32))
         self._done.copy_(torch.as_tensor(done))
         if self._auto_reset and done.any():
