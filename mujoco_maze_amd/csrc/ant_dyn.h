@@ -80,7 +80,7 @@ struct AntDims {
   static constexpr int NQ = 15 + (BALL ? 7 : BD * NBLK);
   static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
   // contact slots: a block resting in a corridor holds 4 floor corners + 4 per adjacent wall/block face
-  static constexpr int NC = NB == 0 ? 16 : ((NB == 1 || NB == 4 || NB == 5) ? 28 : (NB == 2 ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each)
+  static constexpr int NC = NB == 0 ? 16 : ((NB == 1 || NB == 5) ? 28 : ((NB == 2 || NB == 4) ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each); NB = 4: a three-slide block between platforms, walls and the floor filled 28 in long rollouts
   static constexpr int NGEOM = 13 + NMOV;  // contact enumerators: movable bodies first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;

@@ -15,6 +15,11 @@ CONFIGS = [("AntUMaze-v0", 2048, (0, 1, 10, 50, 100, 200)), ("Ant4Rooms-v0", 204
            ("AntSmallBilliard-v0", 1024, (0, 5, 20, 60))]
 print("| config | envs x checkpoints | median | 99 % | 99.9 % | max | envs > 1e-5 | done / goal-index mismatches |")
 print("|---|---|---|---|---|---|---|---|")
+# `parity_stats.py long`: the large-sample version (4 x the envs, a checkpoint every 10 steps of a 300-step rollout; the Push / Fall
+# mazes every 10 steps of 100) — minutes of oracle time on the GPU box's host cores, written to profiles/<round>/parity_long.md
+LONG = len(sys.argv) > 1 and sys.argv[1] == "long"
+if LONG:
+    CONFIGS = [(e, 4 * n, tuple(range(0, (301 if max(c) >= 100 else 101), 10))) for e, n, c in CONFIGS]
 for env_id, n, checks in CONFIGS:
     env = mm.make(env_id, num_envs=n, force_vec=True)
     cm = env.model
@@ -29,11 +34,11 @@ for env_id, n, checks in CONFIGS:
             env.set_state(s["qpos"], s["qvel"], s["warm"] if env_id.startswith("Ant") else None, s["t"])
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
-            ref = oracle.step(cm, s, act.astype(np.float64), nthreads=8)
+            ref = oracle.step(cm, s, act.astype(np.float64), nthreads=16)
             e = np.maximum((np.abs(qvel - s["qvel"]) / (1 + np.abs(s["qvel"]))).max(1), (np.abs(qpos - s["qpos"]) / (1 + np.abs(s["qpos"]))).max(1))
             errs.append(e)
             flags += int((done.cpu().numpy() != ref["done"]).sum()) + int((info["goal_index"].cpu().numpy() != ref["goal_idx"]).sum())
-        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=16)
     e = np.concatenate(errs)
     print(f"| {env_id} | {n} x {len(checks)} | {np.median(e):.1e} | {np.quantile(e, 0.99):.1e} | {np.quantile(e, 0.999):.1e} | {e.max():.1e} | "
           f"{int((e > 1e-5).sum())} ({100.0 * (e > 1e-5).mean():.2f} %) | {flags} |")
