@@ -70,9 +70,36 @@ struct DevCtx {
     }
     return x;
   }
-  __device__ __forceinline__ double gsum(double x) const {  // fp64 paths (Point): plain butterfly
-#pragma unroll
-    for (int o = 1; o < G; o <<= 1) x += __shfl_xor(x, o, 64);
+  // fp64 paths (Point): the same reduction on the two halves of a double — DPP moves instead of `ds_bpermute` round trips
+  // (a butterfly of shuffles cost ~8 LDS-crossbar latencies per sum on the serial path of the Point's Newton iteration)
+  template <int CTRL, int ROW_MASK, bool BOUND>
+  static __device__ __forceinline__ double dpp_movd(double x) {
+    const long long b = __double_as_longlong(x);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    if constexpr (BOUND) { lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xF, true); }
+    else { lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false); }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  static __device__ __forceinline__ double readlaned(double x, int lane) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  __device__ __forceinline__ double gsum(double x) const {
+    if constexpr (G >= 2) x += dpp_movd<0xB1, 0xF, true>(x);
+    if constexpr (G >= 4) x += dpp_movd<0x4E, 0xF, true>(x);
+    if constexpr (G >= 8) x += dpp_movd<0x141, 0xF, true>(x);
+    if constexpr (G >= 16) x += dpp_movd<0x140, 0xF, true>(x);
+    if constexpr (G == 32) {
+      x += dpp_movd<0x142, 0xA, false>(x);  // rows 1, 3 += lane 15 of rows 0, 2 (other rows add zero)
+      const double t0 = readlaned(x, 16), t1 = readlaned(x, 48);
+      x = __lane_id() < 32 ? t0 : t1;
+    }
+    if constexpr (G >= 64) {
+      x += dpp_movd<0x142, 0xA, false>(x);
+      x += dpp_movd<0x143, 0xC, false>(x);  // rows 2, 3 += lane 31
+      x = readlaned(x, 63);
+    }
     return x;
   }
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
