@@ -438,6 +438,108 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
   }
   if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = s.qas[i] + s.wd[i]; }  // envs without contacts keep qacc = qacc_smooth
   cx.sync();
+  if constexpr (NB == 0 && NS == 0) {
+    // The bare Point: 3 dofs.  Everything per dof (qacc, M qacc - qfrc, gradient, the 3 x 3 Hessian, its Cholesky, the search
+    // direction) is carried redundantly in the registers of every lane; the contacts are spread over the lanes and enter
+    // through group sums (DPP) — the same Newton iteration, unit-step vote and exact line search as below, without the LDS
+    // hand-offs that a per-dof distribution of a 3-dof problem consists of.
+    double a[3] = {s.qacc[0], s.qacc[1], s.qacc[2]};
+    const double qs[3] = {s.qas[0], s.qas[1], s.qas[2]};
+    double M[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = s.M3[i][j];
+    bool done = ncon == 0;
+    int it = 0;
+    while (cx.any(!done) && it < 50) {
+      double Mx[3], pg[3] = {0.0, 0.0, 0.0}, pH[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // H entries 00 01 02 11 12 22
+      for (int i = 0; i < 3; i++) { double t = 0.0; for (int j = 0; j < 3; j++) t += M[i][j] * (a[j] - qs[j]); Mx[i] = t; }
+      MZ_FOR(c, ncon) {
+        double J[3][3], u[3], g3[3], W[5];
+        for (int r = 0; r < 3; r++) {
+          double t = -s.caref[c][r];
+          for (int i = 0; i < 3; i++) { J[r][i] = s.cJ[c][r][i]; t += J[r][i] * a[i]; }
+          u[r] = t; s.cu[c][r] = t;
+        }
+        pl_contact_eval(s.cD[c], u, g3, W);
+        int e = 0;
+        for (int i = 0; i < 3; i++) {
+          pg[i] += J[0][i] * g3[0] + J[1][i] * g3[1] + J[2][i] * g3[2];
+          for (int j = i; j < 3; j++, e++)
+            pH[e] += W[0] * J[0][i] * J[0][j] + W[1] * (J[0][i] * J[1][j] + J[1][i] * J[0][j]) + W[2] * (J[0][i] * J[2][j] + J[2][i] * J[0][j]) +
+                     W[3] * J[1][i] * J[1][j] + W[4] * J[2][i] * J[2][j];
+        }
+      }
+      double g[3], H[3][3];
+      for (int i = 0; i < 3; i++) g[i] = Mx[i] + cx.gsum(pg[i]);
+      {
+        int e = 0;
+        for (int i = 0; i < 3; i++) for (int j = i; j < 3; j++, e++) { const double h = M[i][j] + cx.gsum(pH[e]); H[i][j] = h; H[j][i] = h; }
+      }
+      const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+      if (!done && P.inv_scale * gn < 1e-10) done = true;
+      if (!cx.any(!done)) break;
+      if (it == 49 && !done) { MZ_FOR(one, 1) s.status |= MZ_STATUS_SOLVER_MAXITER; }
+      double L[3][3], y[3], sr[3];
+      for (int j = 0; j < 3; j++) {
+        double d = H[j][j];
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+        d = sqrt(fmax(d, 1e-300));
+        L[j][j] = d;
+        for (int i = j + 1; i < 3; i++) {
+          double t = H[i][j];
+          for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+          L[i][j] = t / d;
+        }
+      }
+      for (int i = 0; i < 3; i++) { double t = -g[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
+      for (int i = 2; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 3; k++) t -= L[k][i] * y[k]; y[i] = t / L[i][i]; }
+      for (int i = 0; i < 3; i++) sr[i] = y[i];
+      double p1 = 0.0, p2 = 0.0;
+      for (int i = 0; i < 3; i++) {
+        double t = 0.0;
+        for (int j = 0; j < 3; j++) t += M[i][j] * sr[j];
+        p1 += sr[i] * Mx[i]; p2 += sr[i] * t;
+      }
+      bool changed = false;
+      MZ_FOR(c, ncon) {
+        double v[3];
+        for (int r = 0; r < 3; r++) { v[r] = s.cJ[c][r][0] * sr[0] + s.cJ[c][r][1] * sr[1] + s.cJ[c][r][2] * sr[2]; s.cjv[c][r] = v[r]; }
+        const double u0 = s.cu[c][0], u1 = s.cu[c][1], u2 = s.cu[c][2], w0 = u0 + v[0], w1 = u1 + v[1], w2 = u2 + v[2];
+        changed = changed || ((u0 + u1 < 0) != (w0 + w1 < 0)) || ((u0 - u1 < 0) != (w0 - w1 < 0)) || ((u0 + u2 < 0) != (w0 + w2 < 0)) ||
+                  ((u0 - u2 < 0) != (w0 - w2 < 0));
+      }
+      changed = cx.gany(changed);
+      double lo = 0.0, hi = -1.0, alpha = 1.0, prev_d2 = -1.0;
+      for (int ls = 0; ls < 30 && changed; ls++) {
+        double d1 = 0.0, d2 = 0.0;
+        MZ_FOR(c, ncon) {
+          const double Dc = s.cD[c], v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
+          const double u0 = s.cu[c][0] + alpha * v0, u1 = s.cu[c][1] + alpha * v1, u2 = s.cu[c][2] + alpha * v2;
+          double r, w;
+          r = u0 + u1; w = v0 + v1; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+          r = u0 - u1; w = v0 - v1; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+          r = u0 + u2; w = v0 + v2; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+          r = u0 - u2; w = v0 - v2; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
+        }
+        d1 = cx.gsum(d1) + p1 + alpha * p2;
+        d2 = cx.gsum(d2) + p2;
+        if (d2 == prev_d2) break;
+        prev_d2 = d2;
+        if (d1 < 0) lo = alpha; else hi = alpha;
+        double next = alpha - d1 / d2;
+        if (hi >= 0 && !(next > lo && next < hi)) next = 0.5 * (lo + hi);
+        if (!(next > 0)) next = hi >= 0 ? 0.5 * (lo + hi) : 0.0;
+        if (fabs(next - alpha) <= 1e-15 * fabs(next)) { alpha = next; break; }
+        alpha = next;
+      }
+      if (!done) { for (int i = 0; i < 3; i++) a[i] += alpha * sr[i]; }
+      if (!changed) done = true;
+      it++;
+    }
+    cx.sync();
+    if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+    cx.sync();
+    return;
+  }
   // ---- Newton on the primal problem (dense), exact line search
   bool done = ncon == 0;
   int it = 0;
