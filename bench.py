@@ -15,6 +15,11 @@ The measured regime does not depend on --warmup: SETTLE_STEPS untimed batch-step
 run first (the ants land and stay on the ground: SURVEY §8d's "100 warm-up" protocol),
 then the caller's --warmup, then the timed --steps.
 
+`--gpus N` with N > 1 launches the N ranks itself when it is not already running under torchrun (WORLD_SIZE unset): it re-executes
+this file under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU,
+backend nccl (= RCCL); it refuses (exit code 2) when fewer than N GPUs are visible.  Under the driver's own torchrun the
+ranks are already there and WORLD_SIZE decides.
+
 Other BASELINE configs with the same script: --env Ant4Rooms-v0 (configs[3], with --gpus 8),
 --env AntPush-v0 --envs 2048 (configs[4]), --env PointUMaze-v0 (configs[1]).
 
@@ -64,13 +69,14 @@ def usable_cores():
 
 
 def pmc_counters(env_id, n_envs):
-    """Per-launch PMC averages of the step kernel from the newest committed summary (collected by tools/profile.sh in
-    separate `rocprofv3 --pmc ...` passes of the default bench command: AntUMaze-v0, 4096 envs), or {} for any other
-    workload (counters cannot be collected from inside the process)."""
+    """Per-launch PMC averages of the step kernel of THIS workload from the newest committed summary
+    `profiles/r*/pmc_<env id>_<envs>.csv` (collected by tools/profile.sh in separate `rocprofv3 --pmc ...` passes of the bench
+    command with the same --env / --envs; counters cannot be collected from inside the process), or {} when the workload has
+    no committed counters.  (`pmc_ant_step_kernel.csv` is the round-1/2 name of the default workload's file.)"""
     import glob
-    if n_envs != ENVS_PER_GPU or env_id != ENV_ID:
-        return {}
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_ant_step_kernel.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{env_id}_{n_envs}.csv")))
+    if not files and n_envs == ENVS_PER_GPU and env_id == ENV_ID:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_ant_step_kernel.csv")))
     if not files:
         return {}
     vals = {"_file": os.path.relpath(files[-1], ROOT)}
@@ -157,6 +163,55 @@ def cpu_baseline(model, env_id, n, lo, hi, seconds_target=12.0):
                       "(oracle/libmzo_fast.so; the strict-fp libmzo.so is the parity checker, not timed), OpenMP over envs"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`--gpus N` outside torchrun: start the N ranks (one process per GPU) and pass their output through."""
+    import subprocess
+    rehearsal = os.environ.get("MZ_BENCH_SINGLE_GPU") == "1"
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        need = 1 if rehearsal else args.gpus
+        if have < need:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {need} visible GPU(s), found {have}; refusing to report a "
+                             f"{have}-GPU number as a {args.gpus}-GPU one (MZ_BENCH_SINGLE_GPU=1 rehearses the N > 1 path on one GPU over gloo)\n")
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Launcher / process-group plumbing only (CPU test of the N > 1 launch path; no GPU work, value = null): the ranks
+    rendezvous over gloo, time an empty K-step loop between the same barriers and rank 0 prints the line."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dt = 0.0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.barrier()
+        tm = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": f"env-steps/sec (whole node), {args.env}, {args.envs} envs/GPU", "value": None, "unit": "env-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "barrier_s": dt,
+                          "config": {"workload": "launcher dry run: no environment was stepped"}}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,8 +224,18 @@ def main():
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup (1/2/4); 0 = library default")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL obs all-gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only, no GPU work (CPU test of --gpus N)")
     ap.add_argument("--opt", action="append", default=[], help="extra library option key=value (tuning experiments)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's world size is what runs and what n_gpus reports\n")
+    if args.dry_run:
+        sys.exit(dry_run(args))
 
     import torch
 
@@ -219,39 +284,57 @@ def main():
     pool = [(a_lo + (a_hi - a_lo) * torch.rand((n, env.nu), device=dev, generator=g)) for _ in range(32)]  # uniform in the action box
     gatherer = sharding.RecordGatherer(n, env.obs_dim, dev) if (world > 1 and not args.no_gather) else None
 
-    def one_step(i):
-        obs, rew, done, _ = env.step(pool[i % len(pool)])
-        if gatherer is not None:
-            gatherer.wait()                     # previous step's gather must be done before its buffer is reused
-            gatherer.start(obs, rew, done)      # async RCCL all-gather, overlaps the next step's kernel
+    def one_step(i, gather=True):
+        # kernel -> collective: the step kernel writes the packed record (obs | reward | done) into the send buffer the
+        # previous all-gather is NOT reading; that previous gather overlaps this step's kernel
+        g = gatherer if gather else None
+        if g is not None:
+            env.bind_record(g.flip())
+        env.step(pool[i % len(pool)])
+        if g is not None:
+            g.wait()       # previous step's gather (its receive buffer is reused)
+            g.start()      # async RCCL all-gather of this step's record
+
+    def timed(steps, gather=True):
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(i, gather)
+        if gatherer is not None and gather:
+            gatherer.wait()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
 
     for i in range(args.settle):
         one_step(i)
     for i in range(args.warmup):
         one_step(args.settle + i)
     env.set_option("time_kernels", args.steps)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    if gatherer is not None:
-        gatherer.wait()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    dt = timed(args.steps)
     kernel_ms = env.kernel_ms()
     status = env.status()
     bad = int(((status & 3) != 0).sum().item())
-
+    kernel_ms_ranks, no_gather = [kernel_ms], None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        km = torch.zeros(world, dtype=torch.float64, device=dev)
+        km[rank] = kernel_ms
+        dist.all_reduce(km)
+        kernel_ms_ranks = [float(x) for x in km.tolist()]
+        if gatherer is not None:  # the same K steps once more without the collective
+            env.bind_record(None)
+            dt_ng = timed(args.steps, gather=False)
+            no_gather = {"value": n * world * args.steps / dt_ng, "ms_per_step": dt_ng / args.steps * 1e3}
 
     if rank == 0:
         total_env_steps = n * world * args.steps
@@ -275,14 +358,16 @@ def main():
                           if os.environ.get("MZ_BENCH_SINGLE_GPU") == "1" else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(pmc),
-                         "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "kernel_ms_per_rank": kernel_ms_ranks, "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_per_env_step": per_env,
-                         "traffic_source": "profiles/*/pmc_ant_step_kernel.csv: FETCH_SIZE + WRITE_SIZE (KB) of the committed rocprofv3 --pmc passes of this command, bytes per launch; not collected live",
+                         "traffic_source": (pmc.get("_file", "none committed for this workload") + ": FETCH_SIZE + WRITE_SIZE (KB) of the committed rocprofv3 --pmc passes of this command, bytes per launch; not collected live"),
                          "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},
         }
         rv = valu_roofline(pmc, kernel_ms, n * args.steps / (kernel_ms * 1e-3 * args.steps) if kernel_ms > 0 else 0.0, env_id)
         if rv is not None:
             out["roofline_valu"] = rv
+        if no_gather is not None:
+            out["without_allgather"] = no_gather  # same ranks, same steps, collective off (with / without)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env.model, env_id, n, env.action_space.low.astype("float64"), env.action_space.high.astype("float64"))
         print(json.dumps(out), flush=True)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZ_ABI_VERSION 5
+#define MZ_ABI_VERSION 6
 
 #define MZ_MAX_BODY 24
 #define MZ_MAX_JNT 24
@@ -255,6 +255,14 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value);
  * here ([N, obs_dim] fp32, device, caller-owned; rows of envs that did not finish are left untouched); NULL unbinds.
  * Without auto-reset obs_dev always holds the step's own observation and this buffer is never written. */
 int32_t mz_bind_final_obs(mz_handle* h, float* final_obs_dev);
+
+/* Packed per-env record for sharded runs (the one collective of the path is the all-gather of this tensor).
+ * When bound ([N, obs_dim + 2] fp32, device, caller-owned; NULL unbinds), every mz_step also writes row i =
+ * obs_dev row i (obs_dim floats, i.e. under auto-reset the first observation of the new episode) | reward | done as float,
+ * from inside the step kernel (Ant) or with one extra pack launch (Point / Swimmer / Reacher, top-down-view tasks), so the
+ * caller can hand the buffer to the collective without copy launches of its own.  No reference counterpart (the
+ * reference steps one env per process: mujoco_maze/maze_env.py:448-481 returns the three values separately). */
+int32_t mz_bind_record(mz_handle* h, float* record_dev);
 
 /* reset(): envs with mask_dev[i] != 0 (all when NULL) get t = 0 and a fresh state
  * from the reference's reset distribution (counter-based RNG keyed by seed and

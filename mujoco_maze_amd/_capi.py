@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmazestep.so")
 SYMBOLS = [
     "mz_abi_version", "mz_model_sizeof", "mz_create", "mz_destroy", "mz_last_error", "mz_num_envs", "mz_obs_dim", "mz_nq",
     "mz_nv", "mz_nu", "mz_set_option", "mz_reset", "mz_set_state", "mz_get_state", "mz_step", "mz_get_status",
-    "mz_debug_forward", "mz_last_kernel_ms", "mz_read_phase_cycles", "mz_bind_final_obs", "mz_debug_task_eval", "mz_debug_detect", "mz_read_wave_cycles",
+    "mz_debug_forward", "mz_last_kernel_ms", "mz_read_phase_cycles", "mz_bind_final_obs", "mz_debug_task_eval", "mz_debug_detect", "mz_read_wave_cycles", "mz_bind_record",
 ]
 
 _lib = None
@@ -63,6 +63,8 @@ def load():
     lib.mz_debug_forward.argtypes = [vp, vp, vp, vp, vp]
     lib.mz_bind_final_obs.restype = i32
     lib.mz_bind_final_obs.argtypes = [vp, vp]
+    lib.mz_bind_record.restype = i32
+    lib.mz_bind_record.argtypes = [vp, vp]
     lib.mz_debug_task_eval.restype = i32
     lib.mz_debug_task_eval.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.mz_debug_detect.restype = i32

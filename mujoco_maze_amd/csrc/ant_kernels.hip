@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
                                                        uint64_t seed, uint64_t env0, unsigned long long* __restrict__ prof,
-                                                       float* __restrict__ final_obs, int ostride) {
+                                                       float* __restrict__ final_obs, int ostride, float* __restrict__ record) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   using D = AntDims<NB>;
   const AntDev& K = *Kp;  // model constants: scalar loads from a device-resident block (L2 / scalar-cache hits)
@@ -112,6 +112,13 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
       for (int i = l2; i < obs_dim; i += G) orow[obs_slot(i, obs_dim, ostride)] = obs2[i];
       if (ostride != obs_dim) for (int i = l2; i < 2 * D::NBLK; i += G) orow[obs_dim - 1 + i] = ant_block_coord<NB>(K, s2, i >> 1, i & 1);
     }
+    // packed record [obs | reward | done] for the sharded all-gather (mz_bind_record): written here, by the kernel that
+    // produced it, instead of by three copy launches in front of the collective
+    if (record) {
+      float* rrow = record + (size_t)env2 * (obs_dim + 2);
+      if (!rst) for (int i = l2; i < obs_dim; i += G) rrow[i] = obs2[i];
+      if (l2 == 0) { rrow[obs_dim] = out2[0]; rrow[obs_dim + 1] = (float)d; }
+    }
     if (l2 == 0) {
       reward[env2] = out2[0];
       done[env2] = d;
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
       float* orow = obs + (size_t)env2 * ostride;
       for (int i = l2; i < obs_dim; i += G) orow[obs_slot(i, obs_dim, ostride)] = ant_obs_elem<NB>(K, s2, i, 0);
       if (ostride != obs_dim) for (int i = l2; i < 2 * D::NBLK; i += G) orow[obs_dim - 1 + i] = ant_block_coord<NB>(K, s2, i >> 1, i & 1);
+      if (record) { float* rrow = record + (size_t)env2 * (obs_dim + 2); for (int i = l2; i < obs_dim; i += G) rrow[i] = ant_obs_elem<NB>(K, s2, i, 0); }
     }
   }
   cx.sync();
@@ -254,17 +262,27 @@ static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, 
   size_t lds = (size_t)epb * sizeof(AntEnvLDS<NB>);
   while (lds > 160 * 1024 && wpb > 1) { wpb /= 2; epb = wpb * 64 / G; lds = (size_t)epb * sizeof(AntEnvLDS<NB>); }
   const dim3 grid((h->n + epb - 1) / epb), block(64 * wpb);
+  // the dynamic-LDS attribute is per kernel function: set once per (instantiation, size), not on every step
+  static size_t lds_set[2][32] = {};  // [instrumented build][device]
+  const int dv = h->device & 31;
+  float* rec = h->view.on ? nullptr : h->record;  // with a top-down view the record is packed after mzk_view_fill (mazestep.hip)
   hipError_t e;
   if (h->prof) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    if (lds_set[1][dv] != lds) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      lds_set[1][dv] = lds;
+    }
     hipLaunchKernelGGL((ant_step_kernel<NB, G, true>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
-                       h->auto_reset, h->seed, h->env0, h->prof, h->final_obs, h->lay.ostride);
+                       h->auto_reset, h->seed, h->env0, h->prof, h->final_obs, h->lay.ostride, rec);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    if (lds_set[0][dv] != lds) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      lds_set[0][dv] = lds;
+    }
     hipLaunchKernelGGL((ant_step_kernel<NB, G, false>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
-                       h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr, h->final_obs, h->lay.ostride);
+                       h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr, h->final_obs, h->lay.ostride, rec);
   }
   return hipSuccess;
 }
@@ -285,20 +303,28 @@ static hipError_t launch_ant_forward(mz_handle* h, hipStream_t st, const float* 
 // 64 with blocks (their contact sets keep 64 lanes busy, and the 2048-env batches of those configs then fill the chip with
 // two waves per SIMD instead of one).
 template <int NB>
+static int ant_lanes(const mz_handle* h);
+template <int NB>
 static hipError_t dispatch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   if constexpr (NB == 0) {
     if (h->lanes_set && h->lanes == 8) return launch_ant_step<NB, 8>(h, st, a, o, r, d, gi, inf);
   }
   // (batches beyond 4096 envs put two 16-lane waves on a SIMD; there the 32-lane grouping measured slightly faster again)
-  const int lanes = h->lanes_set ? h->lanes : (NB ? 64 : (h->n <= 4096 ? 16 : 32));
+  const int lanes = ant_lanes<NB>(h);
   if (lanes == 64) return launch_ant_step<NB, 64>(h, st, a, o, r, d, gi, inf);
   if (lanes == 16) return launch_ant_step<NB, 16>(h, st, a, o, r, d, gi, inf);
   return launch_ant_step<NB, 32>(h, st, a, o, r, d, gi, inf);
 }
+// lanes per env of the handle: ONE rule for the step and for mz_debug_forward, so that the diagnostic evaluates the very
+// instantiation that steps (8 lanes exist for the plain ant's step only; the forward diagnostic then uses 16)
+template <int NB>
+static int ant_lanes(const mz_handle* h) { return h->lanes_set ? h->lanes : (NB ? 64 : (h->n <= 4096 ? 16 : 32)); }
 template <int NB>
 static hipError_t dispatch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
-  if (h->lanes == 16) return launch_ant_forward<NB, 16>(h, st, a, qacc, counts);
-  return launch_ant_forward<NB, 32>(h, st, a, qacc, counts);
+  const int lanes = ant_lanes<NB>(h);
+  if (lanes == 64) return launch_ant_forward<NB, 64>(h, st, a, qacc, counts);
+  if (lanes == 32) return launch_ant_forward<NB, 32>(h, st, a, qacc, counts);
+  return launch_ant_forward<NB, 16>(h, st, a, qacc, counts);
 }
 
 // MazeTask.reward / termination on rows of observations (parity tests: the instance of task_eval_dev that is inlined into

@@ -17,6 +17,18 @@ __global__ void fetch_clear_status_kernel(int n, int* status, int* out) {
   status[env] = 0;
 }
 
+// packed record [obs (obs_dim) | reward | done] of one step: the generic path (Point / Swimmer / Reacher, and any robot with a
+// top-down view, whose rows are completed by mzk_view_fill after the step kernel).  The Ant step kernel writes the record
+// itself (ant_kernels.hip epilogue).
+__global__ void pack_record_kernel(int n, int obs_dim, const float* __restrict__ obs, const float* __restrict__ reward,
+                                   const uint8_t* __restrict__ done, float* __restrict__ record) {
+  const int w = obs_dim + 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n * w) return;
+  const int env = (int)(idx / w), i = (int)(idx - (size_t)env * w);
+  record[idx] = i < obs_dim ? obs[(size_t)env * obs_dim + i] : (i == obs_dim ? reward[env] : (float)done[env]);
+}
+
 static int set_err(mz_handle* h, int code, const char* what, hipError_t e) {
   if (h) snprintf(h->err, sizeof(h->err), "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
   return code;
@@ -161,7 +173,10 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
       HIPCHK(h, hipMalloc(&h->prof, (16 + (size_t)h->n) * sizeof(unsigned long long)));
       HIPCHK(h, hipMemset(h->prof, 0, (16 + (size_t)h->n) * sizeof(unsigned long long)));
     }
-    if (value == 0 && h->prof) { (void)hipFree(h->prof); h->prof = nullptr; }
+    if (value == 0 && h->prof) {
+      HIPCHK(h, hipDeviceSynchronize());  // an instrumented step kernel may still be adding to the accumulators
+      (void)hipFree(h->prof); h->prof = nullptr;
+    }
     return MZ_OK;
   }
   if (!strcmp(key, "waves_per_block")) {
@@ -185,6 +200,12 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
 int32_t mz_bind_final_obs(mz_handle* h, float* final_obs_dev) {
   if (!h) return MZ_ERR_ARG;
   h->final_obs = final_obs_dev;
+  return MZ_OK;
+}
+
+int32_t mz_bind_record(mz_handle* h, float* record_dev) {
+  if (!h) return MZ_ERR_ARG;
+  h->record = record_dev;
   return MZ_OK;
 }
 
@@ -228,6 +249,10 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
   else HIPCHK(h, mzk_planar_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
   if (h->view.on) HIPCHK(h, mzk_view_fill(h, st, obs_dev, h->auto_reset ? h->final_obs : NULL, done_dev));
+  if (h->record && (h->robot != MZ_ROBOT_ANT || h->view.on)) {
+    const size_t tot = (size_t)h->n * (h->model.obs_dim + 2);
+    hipLaunchKernelGGL(pack_record_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->n, h->model.obs_dim, obs_dev, reward_dev, done_dev, h->record);
+  }
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) { HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st)); h->itime++; }
   h->nsteps++;

@@ -34,6 +34,7 @@ struct mz_handle {
   ViewDev view;         // MazeTask.TOP_DOWN_VIEW: the maze bitmasks the view kernel reads (passed by value)
   int base_obs;         // observation width without the view; rows are model.obs_dim = base_obs (+ MZ_VIEW_DIM) floats apart
   float* final_obs;     // caller's buffer for terminal observations under auto-reset (mz_bind_final_obs), or NULL
+  float* record;        // caller's [n, obs_dim + 2] buffer for the packed record obs | reward | done (mz_bind_record), or NULL
   unsigned long long* prof;  // 16 phase-cycle accumulators (option "profile_phases")
   int auto_reset, lanes, waves_per_block;
   uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)

@@ -110,6 +110,10 @@ MZV_HD double mzv_entry(const ViewDev& V, double rx, double ry, const double* bx
 
 // Fill the view entries of one observation row: robot position = row[0:2] (every robot's observation starts with the torso's
 // x, y), block positions = the values the step / reset kernel parked at row[view_off ...].
+// Precision: the arithmetic is the reference's float64 arithmetic, but on the DEVICE its inputs are the fp32-rounded positions
+// of the observation row, not the float64 state — the device view differs from the float64 oracle's by ~1e-7 per entry and can
+// pick the other cell for a position within fp32 round-off of a cell boundary.  Bit-for-bit parity with the reference's views
+// (tests/golden/views.json) holds for the host / emulation path, which is handed float64 positions.
 MZV_HD void mzv_fill_row(const ViewDev& V, float* row, int view_off) {
   const double rx = (double)row[0], ry = (double)row[1];
   double bxy[8];

@@ -86,6 +86,8 @@ class VecMazeEnv:
         self._seed = int(seed)
         self._host_rewards = not self.model.device_rewards
         self._final_obs = None
+        self._host_mask = None
+        self._record = None
         self.set_auto_reset(auto_reset)
         lo = np.array([m.act_ctrlrange[a][0] for a in range(m.nu)], dtype=np.float32)
         hi = np.array([m.act_ctrlrange[a][1] for a in range(m.nu)], dtype=np.float32)
@@ -116,6 +118,16 @@ class VecMazeEnv:
         device_side = self._auto_reset and not self._host_rewards
         _capi.check(self._lib, self._h, self._lib.mz_bind_final_obs(self._h, _ptr(self._final_obs) if device_side else None), "mz_bind_final_obs")
         _capi.check(self._lib, self._h, self._lib.mz_set_option(self._h, b"auto_reset", 1.0 if device_side else 0.0), "mz_set_option(auto_reset)")
+
+    def bind_record(self, record) -> None:
+        """Bind (or, with None, unbind) a float32 [N, obs_dim + 2] device tensor that every step fills with the packed record
+        obs | reward | done — the send buffer of the sharded run's all-gather (mz_bind_record); the caller keeps it alive."""
+        if record is not None:
+            if tuple(record.shape) != (self.num_envs, self.obs_dim + 2) or record.dtype != self._torch.float32 or not record.is_contiguous() \
+                    or record.device != self.device:
+                raise ValueError(f"record must be a contiguous float32 tensor of shape {(self.num_envs, self.obs_dim + 2)} on {self.device}")
+        self._record = record
+        _capi.check(self._lib, self._h, self._lib.mz_bind_record(self._h, _ptr(record)), "mz_bind_record")
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -180,12 +192,16 @@ class VecMazeEnv:
         done = (term.astype(np.uint8) | (dev_done & 2)).astype(np.uint8)
         self._reward.copy_(torch.as_tensor(rew, dtype=torch.float32))
         self._done.copy_(torch.as_tensor(done))
+        # the device's first-match goal index belongs to the built-in task descriptor, not to the Python override that just
+        # judged the step: it is not defined for host-judged tasks
+        self._goal.fill_(-1)
         if self._auto_reset and done.any():
-            mask = self._done != 0
-            self._final_obs[mask] = self._obs[mask]
-            rc = self._lib.mz_reset(self._h, _ptr(mask.to(torch.uint8).contiguous()), C.c_uint64(self._seed), _ptr(self._obs), self._stream())
+            if self._host_mask is None:  # persistent: the reset kernel may still read it after this call returns
+                self._host_mask = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+            torch.ne(self._done, 0, out=self._host_mask.view(torch.bool))
+            self._final_obs[self._host_mask.view(torch.bool)] = self._obs[self._host_mask.view(torch.bool)]
+            rc = self._lib.mz_reset(self._h, _ptr(self._host_mask), C.c_uint64(self._seed), _ptr(self._obs), self._stream())
             _capi.check(self._lib, self._h, rc, "mz_reset (host-judged auto-reset)")
-            torch.cuda.current_stream(self.device).synchronize()  # the mask is a temporary
             self._seed += 1
 
     def get_state(self):

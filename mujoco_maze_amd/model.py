@@ -25,7 +25,7 @@ from mujoco_maze_amd import robots as R
 from mujoco_maze_amd.maze_env_utils import CollisionDetector, MazeCell
 from mujoco_maze_amd.maze_task import MazeTask, device_reward_descriptor
 
-MZ_ABI_VERSION = 5
+MZ_ABI_VERSION = 6
 MAX_BODY, MAX_JNT, MAX_DOF, MAX_Q, MAX_GEOM, MAX_ACT = 24, 24, 24, 28, 24, 8
 MAX_GRID, MAX_SEG, MAX_GOAL, MAX_OBS = 12, 96, 8, 48
 VIEW_DIM = 75  # MZ_VIEW_DIM: the 5 x 5 x 3 top-down view (maze_env.py:95)

@@ -75,6 +75,11 @@ def _block_xy(cm: CompiledModel, qpos: np.ndarray, body: int) -> Tuple[float, fl
     m = cm.c
     p = [m.body_pos[body][0], m.body_pos[body][1]]
     for j in range(m.body_jntadr[body], m.body_jntadr[body] + m.body_jntnum[body]):
+        if m.jnt_type[j] == 0:  # free joint (the Ant's object ball): qpos holds the absolute pose, not a displacement
+            a = m.jnt_qposadr[j]
+            return float(qpos[a]), float(qpos[a + 1])
+        if m.jnt_type[j] != 2:  # hinges do not move the body origin
+            continue
         q = float(qpos[m.jnt_qposadr[j]]) - m.qpos0[m.jnt_qposadr[j]]
         p[0] += m.jnt_axis[j][0] * q
         p[1] += m.jnt_axis[j][1] * q
@@ -128,7 +133,7 @@ def render_top_down(cm: CompiledModel, qpos: Sequence[float], image_shape: Tuple
         cv.disc(x, y, 0.5, ROBOT)  # point.xml: sphere size 0.5 (the manual collision radius is 0.4)
         cv.segment(x, y, x + 0.6 * math.cos(th), y + 0.6 * math.sin(th), 0.06, DARK)
     else:  # swimmer (3 links) / reacher (2 links): unit-length capsules chained by the hinge angles
-        nlink = 3 if robot == "swimmer" else 2
+        nlink = m.nbody - 1 - m.nblock - m.nball  # links of the chain: user MJCF may bring 2..6 (mjcf.py)
         th = float(qpos[2])
         ax, ay = x, y
         # swimmer.xml: the first link extends from the torso origin along -x of the body frame

@@ -34,7 +34,11 @@ def pack_record(obs, reward, done, out):
 
 
 class RecordGatherer:
-    """Owns the send/receive buffers and issues one all-gather per batch step."""
+    """Owns the send/receive buffers and issues one all-gather per batch step.
+
+    Two send buffers alternate (`flip()`): while the all-gather of step k reads one of them on RCCL's stream, the step kernel
+    of step k + 1 — which writes its packed record itself (mz_bind_record) — fills the other, so the collective still hides
+    behind the next step's physics."""
 
     def __init__(self, n_local: int, obs_dim: int, device, group=None, always_collective: bool = False):
         """`always_collective`: issue the all-gather even in a one-rank group (where it degenerates to a copy), so that the
@@ -47,19 +51,40 @@ class RecordGatherer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_local, self.width = n_local, record_width(obs_dim)
-        self.packed = torch.empty((n_local, self.width), dtype=torch.float32, device=device)
+        self._bufs = [torch.empty((n_local, self.width), dtype=torch.float32, device=device) for _ in range(2)]
+        self._cur = 0
+        self._buf_work = [None, None]  # the gather that last read each send buffer
         self.gathered = torch.empty((n_local * self.world, self.width), dtype=torch.float32, device=device)
         self._work = None
         self._always = bool(always_collective) and dist.is_initialized()
 
-    def start(self, obs, reward, done):
-        """Pack and launch the all-gather (asynchronous); call wait() before reading `gathered`."""
-        pack_record(obs, reward, done, self.packed)
+    @property
+    def packed(self):
+        """The current send buffer."""
+        return self._bufs[self._cur]
+
+    def flip(self):
+        """Switch to the other send buffer and return it, after the gather that last read it has finished (stream-ordered:
+        the wait blocks the current stream, not the host)."""
+        self._cur ^= 1
+        w = self._buf_work[self._cur]
+        if w is not None:
+            w.wait()
+            self._buf_work[self._cur] = None
+        return self._bufs[self._cur]
+
+    def start(self, obs=None, reward=None, done=None):
+        """Launch the all-gather of `packed` (asynchronous); call wait() before reading `gathered`.  With arguments the record
+        is packed here first (three copies: CPU tensors of the gloo test, host-judged tasks); without, `packed` is the buffer the
+        step kernel itself filled (VecMazeEnv.bind_record -> mz_bind_record): kernel -> collective, no launch in between."""
+        if obs is not None:
+            pack_record(obs, reward, done, self.packed)
         if self.world == 1 and not self._always:
             self.gathered.copy_(self.packed)
             self._work = None
         else:
             self._work = self._dist.all_gather_into_tensor(self.gathered, self.packed, group=self.group, async_op=True)
+        self._buf_work[self._cur] = self._work
         return self
 
     def wait(self):
@@ -91,15 +116,23 @@ class ShardedVecMazeEnv:
         self.lo, self.hi = shard_range(self.rank, self.world, envs_per_rank)
         self.env.set_option("env_index_offset", float(self.lo))
         self.gatherer: Optional[RecordGatherer] = RecordGatherer(envs_per_rank, self.env.obs_dim, self.env.device, group, always_collective) if gather else None
+        # the step kernel writes the packed record straight into the gatherer's send buffer — unless the task is judged by
+        # Python overrides on the host, whose reward / done only exist after the kernel
+        self._device_record = self.gatherer is not None and not self.env._host_rewards
         self._torch = torch
 
     def reset(self, seed: int = 0):
         return self.env.reset(seed=seed)  # same seed on every rank: streams differ through the global slot index
 
     def step(self, actions):
+        if self._device_record:
+            self.env.bind_record(self.gatherer.flip())  # the buffer the previous gather is NOT reading
         obs, rew, done, info = self.env.step(actions)
         if self.gatherer is not None:
-            self.gatherer.start(obs, rew, done)
+            if self._device_record:
+                self.gatherer.start()
+            else:
+                self.gatherer.start(obs, rew, done)
         return obs, rew, done, info
 
     def gathered(self):

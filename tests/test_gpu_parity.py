@@ -80,7 +80,37 @@ def test_native_library_is_the_in_tree_one(torch):
     assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
     from mujoco_maze_amd.model import MZ_ABI_VERSION
 
-    assert lib.mz_abi_version() == MZ_ABI_VERSION == 5
+    assert lib.mz_abi_version() == MZ_ABI_VERSION == 6
+
+
+@pytest.mark.parametrize("env_id", ["Ant4Rooms-v0", "AntPush-v0", "PointUMaze-v0", "SwimmerUMaze-v0", "PointSquareRoom-v0"])
+def test_step_kernel_writes_the_packed_record(torch, env_id):
+    """mz_bind_record: the packed [obs | reward | done] row of the sharded run's all-gather is written by the step itself (the
+    Ant kernel's epilogue; one pack launch for the other robots) — equal, bit for bit, to the three outputs, also for envs
+    that auto-reset inside the step (then `obs` is the new episode's first observation) and after unbinding nothing is written."""
+    n = 200  # not a multiple of the envs per wavefront
+    env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
+    rec = torch.full((n, env.obs_dim + 2), -7.0, device=env.device)
+    env.bind_record(rec)
+    env.reset(seed=2)
+    t = env.get_state()[3]
+    t[::3] = 998  # a third of the envs truncate (and auto-reset) on the second step
+    env.set_state(t=t)
+    g = torch.Generator(device=env.device).manual_seed(0)
+    lo, hi = torch.as_tensor(env.action_space.low, device=env.device), torch.as_tensor(env.action_space.high, device=env.device)
+    resets = 0
+    for k in range(4):
+        obs, rew, done, info = env.step(lo + (hi - lo) * torch.rand((n, env.nu), device=env.device, generator=g))
+        assert torch.equal(rec, torch.cat([obs, rew[:, None], done.float()[:, None]], dim=1)), k
+        resets += int((done != 0).sum())
+    assert resets >= n // 3
+    with pytest.raises(ValueError):
+        env.bind_record(torch.zeros((n, env.obs_dim + 1), device=env.device))
+    env.bind_record(None)
+    rec.fill_(-7.0)
+    env.step(torch.zeros((n, env.nu), device=env.device))
+    assert torch.all(rec == -7.0)
+    env.close()
 
 
 def _rollout_states(oracle, cm, n, seed, checkpoints, robot="ant"):

@@ -36,15 +36,19 @@ for k in range(50):
     assert torch.equal(got, expect), k
     o, r, d = env.gatherer.split()
     assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(d, done.float())
-# overlap: start the gather of step k, launch step k+1 before waiting (what bench.py does)
+assert env._device_record                                   # the step kernel wrote the record the collective sent (mz_bind_record)
+# overlap: the gather of step k is still in flight when the kernel of step k + 1 is launched (what bench.py does); the kernel
+# writes its record into the OTHER send buffer (RecordGatherer.flip)
 gt = env.gatherer
-obs, rew, done, _ = env.env.step(acts[0])
+snap = None
 for k in range(20):
-    gt.wait()
+    env.env.bind_record(gt.flip())
+    obs, rew, done, _ = env.env.step(acts[k %% 8])          # kernel k overlaps gather k - 1
+    if snap is not None:
+        assert torch.equal(gt.wait(), snap), k              # gather k - 1 delivered record k - 1 although kernel k ran meanwhile
     snap = torch.cat([obs, rew[:, None], done.float()[:, None]], dim=1).clone()
-    gt.start(obs, rew, done)
-    obs, rew, done, _ = env.env.step(acts[k %% 8])          # next kernel overlaps the collective (outputs are re-used buffers,
-    assert torch.equal(gt.wait(), snap), k                  # the record was packed before the launch)
+    gt.start()                                              # gather k, straight from the kernel-written buffer
+assert torch.equal(gt.wait(), snap)
 torch.cuda.synchronize()
 env.close()
 dist.destroy_process_group()

@@ -56,6 +56,33 @@ def test_block_moves_in_the_image():
     assert c1[1] < c0[1] - 3 and abs(c1[0] - c0[0]) < 2
 
 
+def test_free_joint_ball_moves_in_the_image():
+    """AntSmallBilliard's object ball sits on a FREE joint: its qpos entries are an absolute pose."""
+    cm = _compiled("AntSmallBilliard-v0")
+    m = cm.c
+    assert m.nball == 1 and m.jnt_type[m.body_jntadr[m.ball_bodyid[0]]] == 0
+    qpos = np.array([m.qpos0[i] for i in range(m.nq)])
+    def ball_centroid(q):
+        im = render.render_top_down(cm, q, (300, 240))
+        ys, xs = np.where((im == np.array(render.BALL)).all(-1))
+        return xs.mean(), ys.mean()
+    c0 = ball_centroid(qpos)
+    q2 = qpos.copy()
+    q2[15] += 1.5  # the ball's x
+    c1 = ball_centroid(q2)
+    assert c1[0] > c0[0] + 5 and abs(c1[1] - c0[1]) < 2
+
+
+def test_chain_length_comes_from_the_model():
+    from tests.test_mjcf import chain_swimmer_xml as _chain_xml
+
+    cm = model.compile_model("swimmer", mm.REGISTRY["SwimmerUMaze-v0"].kwargs["maze_task"](4.0), 4.0, robot_xml=_chain_xml(5))
+    qpos = np.array([cm.c.qpos0[i] for i in range(cm.c.nq)])
+    n5 = int((render.render_top_down(cm, qpos, (300, 240)) == np.array(render.ROBOT)).all(-1).sum())
+    n3 = int((render.render_top_down(_compiled("SwimmerUMaze-v0"), qpos[:5], (300, 240)) == np.array(render.ROBOT)).all(-1).sum())
+    assert n5 > n3  # five links drawn, not three
+
+
 def test_state_for_viewer_is_plain_data():
     import json
     import xml.etree.ElementTree as ET

@@ -1,12 +1,15 @@
 #!/bin/bash
-# GPU box helper: rocprofv3 kernel stats + PMC passes of the bench command -> gpurun_out/prof_$1
+# GPU box helper: rocprofv3 kernel stats + PMC passes of one bench workload -> gpurun_out/prof_<tag>_<env>_<envs>
 # (counters are collected in their own passes, never together with --kernel-trace/--stats tracing domains)
-tag=${1:-r02}
-out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+#   tools/profile.sh <tag> [<env id> [<envs>]]      default: the metric's workload, AntUMaze-v0 / 4096
+tag=${1:-r03}
+envid=${2:-AntUMaze-v0}
+nenv=${3:-4096}
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_${envid}_${nenv}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # the default bench command (100 settle + 100 warm-up + 1000 timed steps), minus the CPU leg
-CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --env $envid --envs $nenv ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $CMD > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $CMD > $out/bench_write.log 2>&1
