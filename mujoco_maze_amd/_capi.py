@@ -10,7 +10,7 @@ import os
 from mujoco_maze_amd.model import MzModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmazestep.so")
+LIB_PATH = os.environ.get("MZ_LIBMAZESTEP_EXPERIMENT") or os.path.join(_HERE, "csrc", "libmazestep.so")  # the override is for tools/ A/B timing only
 
 # every entry point declared in include/mazestep.h
 SYMBOLS = [

@@ -80,7 +80,7 @@ struct AntDims {
   static constexpr int NQ = 15 + (BALL ? 7 : BD * NBLK);
   static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
   // contact slots: a block resting in a corridor holds 4 floor corners + 4 per adjacent wall/block face
-  static constexpr int NC = NB == 0 ? 16 : ((NB == 1 || NB == 5) ? 28 : ((NB == 2 || NB == 4) ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each); NB = 4: a three-slide block between platforms, walls and the floor filled 28 in long rollouts
+  static constexpr int NC = NB == 0 ? 16 : (NB == 1 ? 40 : NB == 5 ? 28 : ((NB == 2 || NB == 4) ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each); NB = 4: a three-slide block between platforms, walls and the floor filled 28 in long rollouts
   static constexpr int NGEOM = 13 + NMOV;  // contact enumerators: movable bodies first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;
@@ -709,8 +709,109 @@ MZ_HD float seg_box_t(const float* a, const float* b, const float* bs) {
 }
 
 
-// sphere / capsule (centre ctr, axis ax, half length hl, radius r; torso-relative) against an axis-aligned box
-// (centre bc torso-relative, half sizes bs): up to two contacts [ASSUME-6], normal from the robot geom to the box
+MZ_HD float sel3f(const float* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }  // no dynamically indexed private array (scratch)
+
+// Second support point of a capsule against a box — MuJoCo's mjc_CapsuleBox as restated in oracle/mzo_physics.c capsule_box
+// (DESIGN.md section 5), in region form: the closest segment point t (in [-1, 1] along MuJoCo's half axis h = geom z * half
+// length) and the box feature it faces are known from the closest-point computation instead of the search over two face
+// candidates and twelve edges — the same feature wherever the closest point is unique.
+//   type 0: a face (axis clface, -1 when the point is inside the box)   1: the interior of an edge (axis cledge)   2: a corner
+//   corner: bit k set = the +k side of the box (for an edge: the bits of the two axes across it)
+// Returns the offset of the second sphere along the segment (0: none).
+MZ_HD float capsule_box_second(const float* cl, const float* h, const float* bs, float t, int type, int clface, int cledge, int corner,
+                               float boxpos) {
+  const int axisdir = (h[0] > 0.f ? 1 : 0) + (h[1] > 0.f ? 2 : 0) + (h[2] > 0.f ? 4 : 0);
+  const float hx = fabsf(h[0]), hy = fabsf(h[1]), hz = fabsf(h[2]), habs[3] = {hx, hy, hz};
+  const float n2 = hx * hx + hy * hy + hz * hz;
+  if (type == 2) {
+    int c1 = axisdir ^ corner;
+    if (c1 == 0 || c1 == 7) return 0.f;  // pointing at / away from the corner
+    float mul = 1.f;
+    if (!(c1 == 1 || c1 == 2 || c1 == 4)) { mul = -1.f; c1 = 7 - c1; }
+    const int ax = c1 == 1 ? 0 : (c1 == 2 ? 1 : 2), ax1 = ax == 2 ? 0 : ax + 1, ax2 = ax == 0 ? 2 : ax - 1;
+    const float ha = sel3f(habs, ax);
+    if (ha * ha > 0.5f * n2) return mul * fminf(1.f - mul * t, 2.f * sel3f(bs, ax) / ha);  // along the edge through the corner
+    const float m = fminf(2.f * sel3f(bs, ax1) / sel3f(habs, ax1), 2.f * sel3f(bs, ax2) / sel3f(habs, ax2));
+    return -mul * fminf(1.f + mul * t, m);                                               // back across the face
+  }
+  if (type == 1) {
+    const int c1 = (axisdir ^ corner) & (7 - (1 << cledge));
+    if (!(c1 == 1 || c1 == 2 || c1 == 4)) return 0.f;  // T configuration
+    int ax1 = cledge == 2 ? 0 : cledge + 1, ax2 = cledge == 0 ? 2 : cledge - 1;
+    if (sel3f(habs, ax1) > sel3f(habs, ax2)) { const int q = ax1; ax1 = ax2; ax2 = q; }  // ax1: normal of the flatter face, ax2: across it
+    const float mul = (c1 & (1 << ax2)) ? 1.f : -1.f;
+    float sp = 1.f - mul * t;
+    sp = fminf(sp, 2.f * sel3f(bs, ax2) / sel3f(habs, ax2));
+    const float e2 = (mul * sel3f(h, cledge) > 0.f) ? 1.f - boxpos : 1.f + boxpos;
+    sp = fminf(sp, sel3f(bs, cledge) * e2 / sel3f(habs, cledge));
+    return mul * sp;
+  }
+  // a face: towards the other end, pulled in so that it stays over the face
+  const float travel = t <= 0.f ? 1.f - t : -1.f - t;  // (an end: -2 t)
+  float frac = 1.f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k == clface) continue;
+    const float p0 = cl[k] + h[k] * t, v = h[k] * travel;
+    if (v > 0.f && p0 + v > bs[k]) frac = fminf(frac, (bs[k] - p0) / v);
+    if (v < 0.f && p0 + v < -bs[k]) frac = fminf(frac, (-bs[k] - p0) / v);
+  }
+  return travel * fmaxf(frac, 0.f);
+}
+
+// The feature search of mjc_CapsuleBox as the oracle restates it (two segment ends against the faces, then the twelve edges
+// by clamped line-line distance; oracle/mzo_physics.c capsule_box), for the case the region form above cannot decide: the
+// segment runs THROUGH the box (distance zero on a stretch — a state only a teleport or a violent impact produces), where
+// "the closest point" is not unique and MuJoCo's answer is whatever its search order yields.  Same outputs as the region
+// form.  Rarely executed; the closest-point reject in round_vs_box runs first.
+MZ_HD void capsule_box_search(const float* cl, const float* h, float hl, const float* bs, float* t_out, int* type, int* clface, int* cledge,
+                              int* corner, float* boxpos) {
+  float best = 3.4e38f, bt = 0.f, bbp = 0.f;
+  int cltype = -4, face = -1, ccorner = 0, cedge = 0;
+  for (int i = -1; i <= 1; i += 2) {
+    int nout = 0, f = -1;
+    float dist = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float e = cl[k] + h[k] * (float)i;
+      if (e < -bs[k]) { nout++; f = k; dist += (e + bs[k]) * (e + bs[k]); }
+      else if (e > bs[k]) { nout++; f = k; dist += (e - bs[k]) * (e - bs[k]); }
+    }
+    if (nout > 1) continue;
+    if (dist < best) { best = dist; bt = (float)i; cltype = -2 + i; face = f; }
+  }
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (i & (1 << j)) continue;
+      float mid[3] = {(i & 1) ? bs[0] : -bs[0], (i & 2) ? bs[1] : -bs[1], (i & 4) ? bs[2] : -bs[2]};
+      mid[j] = 0.f;
+      const float d0 = mid[0] - cl[0], d1 = mid[1] - cl[1], d2 = mid[2] - cl[2];
+      const float dj = j == 0 ? d0 : (j == 1 ? d1 : d2);
+      const float u = -bs[j] * dj, v = h[0] * d0 + h[1] * d1 + h[2] * d2;
+      const float ma = bs[j] * bs[j], mb = -bs[j] * h[j], mc = hl * hl, det = ma * mc - mb * mb;
+      if (fabsf(det) < 1e-15f) continue;
+      float x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+      int s1 = 1, s2 = 1;
+      if (x1 > 1.f) { x1 = 1.f; s1 = 2; x2 = (v - mb) / mc; }
+      else if (x1 < -1.f) { x1 = -1.f; s1 = 0; x2 = (v + mb) / mc; }
+      if (x2 > 1.f) { x2 = 1.f; s2 = 2; x1 = (u - mb) / ma; if (x1 > 1.f) { x1 = 1.f; s1 = 2; } else if (x1 < -1.f) { x1 = -1.f; s1 = 0; } else s1 = 1; }
+      else if (x2 < -1.f) { x2 = -1.f; s2 = 0; x1 = (u + mb) / ma; if (x1 > 1.f) { x1 = 1.f; s1 = 2; } else if (x1 < -1.f) { x1 = -1.f; s1 = 0; } else s1 = 1; }
+      float f0 = d0 - h[0] * x2, f1 = d1 - h[1] * x2, f2 = d2 - h[2] * x2;
+      if (j == 0) f0 += bs[0] * x1; else if (j == 1) f1 += bs[1] * x1; else f2 += bs[2] * x1;
+      const float dist = f0 * f0 + f1 * f1 + f2 * f2;
+      if (dist < best - 1e-15f) {
+        best = dist; bt = x2; bbp = x1;
+        cltype = 3 * s1 + s2; ccorner = i + (s1 == 2 ? (1 << j) : 0); cedge = j;
+      }
+    }
+  *t_out = bt; *boxpos = bbp; *clface = face; *cledge = cedge; *corner = ccorner;
+  *type = cltype < 0 ? 0 : (cltype / 3 == 1 ? 1 : 2);
+}
+
+// sphere / capsule (centre ctr, axis ax = the capsule's from -> to direction, half length hl, radius r; torso-relative) against an
+// axis-aligned box (centre bc torso-relative, half sizes bs): up to two sphere-box contacts (mjc_CapsuleBox), normal from the
+// robot geom to the box
 template <class Emit>
 MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl, float r, const float* bc, const float* bs,
                         float margin, int kind, int blk, Emit&& emit) {
@@ -727,24 +828,79 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
     }
     return;
   }
-  float e1[3], e2[3];
-  for (int k = 0; k < 3; k++) { e1[k] = cl[k] - ax[k] * hl; e2[k] = cl[k] + ax[k] * hl; }  // e1 = +geom-z end
-  float t = seg_box_t(e1, e2, bs), p[3];
-  for (int k = 0; k < 3; k++) p[k] = e1[k] + t * (e2[k] - e1[k]);
-  if (sphere_aabb(p, r, bs, margin, &dist, pos, n) && dist < margin) {
-    cg.dist = dist;
-    for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.pos[k] = pos[k] + bc[k]; }
-    emit(cg);
+  // MuJoCo's half axis: the geom z axis of a fromto capsule points from `to` to `from`, i.e. along -ax
+  const float h[3] = {-ax[0] * hl, -ax[1] * hl, -ax[2] * hl};
+  float em[3], ep[3];
+  bool in_m = true, in_p = true;
+  for (int k = 0; k < 3; k++) {
+    em[k] = cl[k] - h[k]; ep[k] = cl[k] + h[k];
+    in_m = in_m && fabsf(em[k]) <= bs[k]; in_p = in_p && fabsf(ep[k]) <= bs[k];
   }
-  float tf = t <= 0.5f ? 1.f : 0.f;
-  float far[3];
-  for (int k = 0; k < 3; k++) far[k] = t <= 0.5f ? e2[k] : e1[k];
-  if (fabsf(tf - t) * 2.f * hl > 1e-6f)
-    if (sphere_aabb(far, r, bs, margin, &dist, pos, n) && dist < margin) {
+  float t, boxpos = 0.f;
+  int type = 0, clface = -1, cledge = 0, corner = 0;
+  if (in_m || in_p) t = in_m ? -1.f : 1.f;  // an end inside the box (end -1 first): the face case without a face
+  else {
+    t = 2.f * seg_box_t(em, ep, bs) - 1.f;
+    int nout = 0, lastout = 0, inaxis = 0;
+    float pin = 0.f, d2c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float pk = cl[k] + t * h[k];
+      if (pk > bs[k]) { nout++; corner |= 1 << k; lastout = k; d2c += (pk - bs[k]) * (pk - bs[k]); }
+      else if (pk < -bs[k]) { nout++; lastout = k; d2c += (pk + bs[k]) * (pk + bs[k]); }
+      else { inaxis = k; pin = pk / bs[k]; }
+    }
+    // the closest point of the segment is farther than radius + margin from the box: no contact from this pair
+    if (d2c > (r + margin) * (r + margin)) return;
+    type = nout <= 1 ? 0 : (nout == 2 ? 1 : 2);
+    clface = nout == 1 ? lastout : -1;
+    cledge = inaxis; boxpos = pin;
+    // the segment runs through the box with both ends outside: MuJoCo's answer is its search order's
+    if (nout == 0) { corner = 0; capsule_box_search(cl, h, hl, bs, &t, &type, &clface, &cledge, &corner, &boxpos); }
+  }
+  const float second = capsule_box_second(cl, h, bs, t, type, clface, cledge, corner, boxpos);
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1 && !(fabsf(second) > 1e-12f)) break;
+    const float tt = t + (pass ? second : 0.f);
+    float p[3] = {cl[0] + tt * h[0], cl[1] + tt * h[1], cl[2] + tt * h[2]};
+    if (sphere_aabb(p, r, bs, margin, &dist, pos, n) && dist < margin) {
       cg.dist = dist;
       for (int k = 0; k < 3; k++) { cg.n[k] = n[k]; cg.pos[k] = pos[k] + bc[k]; }
       emit(cg);
     }
+  }
+}
+
+// Two axis-aligned boxes (movable blocks never rotate, maze cells are grid-aligned): MuJoCo's mjc_BoxBox as restated in
+// oracle/mzo_physics.c box_box, specialised to parallel axes, in float64 on WORLD coordinates (grid-aligned boxes sit on exact
+// ties — a block at its spawn position shares border lines with the diagonal wall cells, its z extent equals the walls' —
+// which fp32 torso-relative coordinates would decide at random).  Separating axis = the face axis of least penetration
+// (first of x, y, z on ties; an edge-edge axis never wins between parallel boxes), dist = -penetration; contact points = the
+// corners of the intersection of the two facing faces, which may have collapsed to a segment or a point (inclusive tests:
+// boxes that share only a border line do touch), a collapsed direction giving one position instead of two.
+// Box 1 = geom1: the normal points from box 1 to box 2.
+struct AlignedBB { int ax, nu, nv; double dist, sg, pa, pu[2], pv[2]; };
+MZ_HD bool aligned_box_box(const double* c1, const double* h1, const double* c2, const double* h2, double margin, AlignedBB& o) {
+  double pen[3];
+  for (int k = 0; k < 3; k++) { pen[k] = h1[k] + h2[k] - fabs(c2[k] - c1[k]); if (pen[k] < -margin) return false; }
+  int ax = 0;
+  if (pen[1] < pen[ax]) ax = 1;
+  if (pen[2] < pen[ax]) ax = 2;
+  const int u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) { lo[k] = fmax(c1[k] - h1[k], c2[k] - h2[k]); hi[k] = fmin(c1[k] + h1[k], c2[k] + h2[k]); }
+  const double h1u = u == 0 ? h1[0] : (u == 1 ? h1[1] : h1[2]), h1v = v == 0 ? h1[0] : (v == 1 ? h1[1] : h1[2]);
+  const double tol = 1e-12 * (1.0 + h1u + h1v), dtol = 1e-9 * (1.0 + h1u + h1v);  // inside test / coincident candidates (oracle: same)
+  const double lou = u == 0 ? lo[0] : (u == 1 ? lo[1] : lo[2]), hiu = u == 0 ? hi[0] : (u == 1 ? hi[1] : hi[2]);
+  const double lov = v == 0 ? lo[0] : (v == 1 ? lo[1] : lo[2]), hiv = v == 0 ? hi[0] : (v == 1 ? hi[1] : hi[2]);
+  if (hiu - lou < -tol || hiv - lov < -tol) return false;
+  const double c1a = ax == 0 ? c1[0] : (ax == 1 ? c1[1] : c1[2]), c2a = ax == 0 ? c2[0] : (ax == 1 ? c2[1] : c2[2]);
+  const double h1a = ax == 0 ? h1[0] : (ax == 1 ? h1[1] : h1[2]), pa = ax == 0 ? pen[0] : (ax == 1 ? pen[1] : pen[2]);
+  o.ax = ax; o.sg = c2a >= c1a ? 1.0 : -1.0; o.dist = -pa;
+  o.pa = c1a + o.sg * (h1a + 0.5 * o.dist);
+  o.nu = hiu - lou > dtol ? 2 : 1; o.nv = hiv - lov > dtol ? 2 : 1;
+  o.pu[0] = lou; o.pu[1] = hiu; o.pv[0] = lov; o.pv[1] = hiv;
+  return true;
 }
 
 // torso-relative centre of movable block k
@@ -819,71 +975,56 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         // per cell: the platform of an elevated maze (z from 0 to 2 half_z), then the wall block standing on it
         for (int layer = 0; layer < 2; layer++) {
         if (!(((layer ? maze_row_lds(s, i) : plat_row_lds(s, i)) >> j) & 1u)) continue;
-        // aligned box-box [ASSUME-12]: geom1 = wall / platform, geom2 = block
-        float c1[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], (layer ? z.center_z : z.half_z) - s.cz};
-        // the gaps and the activation test in float64 on world coordinates, as the reference's arithmetic has them (AntDev:
-        // a falling block at maze scale 2 sits exactly `margin` away from its neighbours' faces)
+        // aligned box-box (aligned_box_box above): geom1 = wall / platform, geom2 = block; decided in float64 on world
+        // coordinates, as the reference's arithmetic has them (AntDev: a falling block at maze scale 2 sits exactly `margin` away
+        // from its neighbours' faces; a block at its spawn position shares border lines with the diagonal cells)
         const double cw[3] = {j * K.d_scale - K.d_tx, i * K.d_scale - K.d_ty, layer ? K.d_center_z : K.d_half_z};
-        const double hs[3] = {K.d_half_xy + K.d_block_half[0], K.d_half_xy + K.d_block_half[1], K.d_half_z + K.d_block_half[2]};
-        double gapd[3];
-        int ax = 0;
-        for (int k = 0; k < 3; k++) gapd[k] = fabs(bwd[k] - cw[k]) - hs[k];
-        if (gapd[1] > gapd[ax]) ax = 1;
-        if (gapd[2] > gapd[ax]) ax = 2;
-        const double gmaxd = ax == 0 ? gapd[0] : (ax == 1 ? gapd[1] : gapd[2]);
-        if (!(gmaxd < K.d_wall_margin)) continue;
-        float gmax = (float)gmaxd;
-        float lo[3], hi[3];
-        for (int k = 0; k < 3; k++) {
-          lo[k] = fmaxf(c1[k] - bs[k], bc[k] - hb[k]);
-          hi[k] = fminf(c1[k] + bs[k], bc[k] + hb[k]);
-        }
-        int u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
-        if (ax == 1) { u = 2; v = 0; }
-        float c1a = ax == 0 ? c1[0] : (ax == 1 ? c1[1] : c1[2]), bca = ax == 0 ? bc[0] : (ax == 1 ? bc[1] : bc[2]);
-        float bsa = ax == 0 ? bs[0] : (ax == 1 ? bs[1] : bs[2]);
-        float sg = bca >= c1a ? 1.f : -1.f;
-        float lou = u == 0 ? lo[0] : (u == 1 ? lo[1] : lo[2]), hiu = u == 0 ? hi[0] : (u == 1 ? hi[1] : hi[2]);
-        float lov = v == 0 ? lo[0] : (v == 1 ? lo[1] : lo[2]), hiv = v == 0 ? hi[0] : (v == 1 ? hi[1] : hi[2]);
-        if (!(hiu - lou > 1e-6f) || !(hiv - lov > 1e-6f)) continue;  // edge / corner touch: no face contact
-        for (int iu = 0; iu < 2; iu++)
-          for (int iv = 0; iv < 2; iv++) {
-            cg.kind = 4; cg.blk = e; cg.other = 0; cg.dist = gmax;
-            float pa = c1a + sg * (bsa + 0.5f * gmax), pu = iu ? hiu : lou, pv = iv ? hiv : lov;
-            for (int k = 0; k < 3; k++) { cg.n[k] = k == ax ? sg : 0.f; cg.hint[k] = 0.f; cg.pos[k] = k == ax ? pa : (k == u ? pu : pv); }
+        const double hw[3] = {K.d_half_xy, K.d_half_xy, K.d_half_z};
+        AlignedBB bb;
+        if (!aligned_box_box(cw, hw, bwd, K.d_block_half, K.d_wall_margin, bb)) continue;
+        if (!(bb.dist < K.d_wall_margin)) continue;  // not active: no row (mj_instantiateContact)
+        const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
+        const double org[3] = {(double)s.qpos[0], (double)s.qpos[1], (double)s.cz};  // torso origin: positions go back to torso-relative fp32
+        for (int iu = 0; iu < bb.nu; iu++)
+          for (int iv = 0; iv < bb.nv; iv++) {
+            cg.kind = 4; cg.blk = e; cg.other = 0; cg.dist = (float)bb.dist;
+            for (int k = 0; k < 3; k++) {
+              const double pw = k == ax ? bb.pa : (k == u ? bb.pu[iu] : bb.pv[iv]);
+              cg.n[k] = k == ax ? (float)bb.sg : 0.f; cg.hint[k] = 0.f;
+              cg.pos[k] = (float)(pw - (k == 0 ? org[0] : (k == 1 ? org[1] : org[2])));
+            }
             emit(cg);
           }
         }
       }
     if (sub != AntDims<NB>::BSUB - 1) return;
-    // lower-numbered movable blocks: aligned box-box [ASSUME-12], geom1 = block k, geom2 = block e
+    // lower-numbered movable blocks: aligned box-box, geom1 = block k, geom2 = block e
     for (int k = 0; k < e; k++) {
-      float c1[3];
-      block_center<NB>(K, s, k, c1);
-      float gap[3];
-      int ax = 0;
-      for (int q = 0; q < 3; q++) gap[q] = fabsf(bc[q] - c1[q]) - 2.f * hb[q];
-      if (gap[1] > gap[ax]) ax = 1;
-      if (gap[2] > gap[ax]) ax = 2;
-      float gmax = ax == 0 ? gap[0] : (ax == 1 ? gap[1] : gap[2]);
-      if (!(gmax < K.wall.margin)) continue;
-      float lo[3], hi[3];
-      for (int q = 0; q < 3; q++) {
-        lo[q] = fmaxf(c1[q] - hb[q], bc[q] - hb[q]);
-        hi[q] = fminf(c1[q] + hb[q], bc[q] + hb[q]);
+      double c1w[3] = {0.0, 0.0, 0.0};
+      {
+        using D = AntDims<NB>;
+#pragma unroll
+        for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
+          if (j == k && j < D::NBLK) {
+            for (int c = 0; c < 3; c++) c1w[c] = K.d_block_pos0[j][c];
+#pragma unroll
+            for (int a = 0; a < D::BD; a++)
+              for (int c = 0; c < 3; c++) if (K.block_axis[a] == c) c1w[c] += (double)s.qpos[15 + D::BD * j + a];
+          }
       }
-      int u = ax == 0 ? 1 : (ax == 1 ? 2 : 0), v = ax == 0 ? 2 : (ax == 1 ? 0 : 1);
-      float c1a = ax == 0 ? c1[0] : (ax == 1 ? c1[1] : c1[2]), bca = ax == 0 ? bc[0] : (ax == 1 ? bc[1] : bc[2]);
-      float hba = ax == 0 ? hb[0] : (ax == 1 ? hb[1] : hb[2]);
-      float sg = bca >= c1a ? 1.f : -1.f;
-      float lou = u == 0 ? lo[0] : (u == 1 ? lo[1] : lo[2]), hiu = u == 0 ? hi[0] : (u == 1 ? hi[1] : hi[2]);
-      float lov = v == 0 ? lo[0] : (v == 1 ? lo[1] : lo[2]), hiv = v == 0 ? hi[0] : (v == 1 ? hi[1] : hi[2]);
-      if (!(hiu - lou > 1e-6f) || !(hiv - lov > 1e-6f)) continue;
-      for (int iu = 0; iu < 2; iu++)
-        for (int iv = 0; iv < 2; iv++) {
-          cg.kind = 5; cg.blk = e; cg.other = k; cg.dist = gmax;
-          float pa = c1a + sg * (hba + 0.5f * gmax), pu = iu ? hiu : lou, pv = iv ? hiv : lov;
-          for (int q = 0; q < 3; q++) { cg.n[q] = q == ax ? sg : 0.f; cg.hint[q] = 0.f; cg.pos[q] = q == ax ? pa : (q == u ? pu : pv); }
+      AlignedBB bb;
+      if (!aligned_box_box(c1w, K.d_block_half, bwd, K.d_block_half, K.d_wall_margin, bb)) continue;
+      if (!(bb.dist < K.d_wall_margin)) continue;
+      const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
+      const double org[3] = {(double)s.qpos[0], (double)s.qpos[1], (double)s.cz};
+      for (int iu = 0; iu < bb.nu; iu++)
+        for (int iv = 0; iv < bb.nv; iv++) {
+          cg.kind = 5; cg.blk = e; cg.other = k; cg.dist = (float)bb.dist;
+          for (int q = 0; q < 3; q++) {
+            const double pw = q == ax ? bb.pa : (q == u ? bb.pu[iu] : bb.pv[iv]);
+            cg.n[q] = q == ax ? (float)bb.sg : 0.f; cg.hint[q] = 0.f;
+            cg.pos[q] = (float)(pw - (q == 0 ? org[0] : (q == 1 ? org[1] : org[2])));
+          }
           emit(cg);
         }
     }

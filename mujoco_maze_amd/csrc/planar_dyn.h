@@ -26,7 +26,7 @@ struct PlanarDims {
   static_assert(NB == 0 || NS == 0, "no registered maze mixes movable blocks and object balls");
   static_assert(NS <= 1, "one object ball");
   static constexpr int NV = 3 + 2 * NB + 3 * NS;  // robot x, y, theta | block x, y ... | ball x, y, spin
-  static constexpr int NC = NB == 0 ? 12 + 4 * NS : (NB == 1 ? 40 : (NB == 2 ? 64 : 96));  // contact slots
+    static constexpr int NC = NB == 0 ? 24 + 4 * NS : (NB == 1 ? 40 : (NB == 2 ? 64 : 96));  // contact slots (mjc_BoxBox gives the arrow up to 8 contacts per wall cell)
   // enumerators: 9 sphere-wall, 9 arrow-wall | per block: sphere-block, arrow-block, 9 block-wall, 9 block-platform (elevated
   //              mazes), block-floor, 2 joint-limit rows (limited slides) | block pairs | per ball: 9 ball-wall, robot
   //              sphere-ball, ball-arrow
@@ -92,76 +92,197 @@ MZP_HD bool pl_sphere_box(const double* c, double r, const double* hb, double ma
   return true;
 }
 
-// z-rotated box (the arrow: centre bc, axes ex / ey, half sizes ahx / ahy, height az) vs an axis-aligned box (centre
-// wc, half sizes wh) [ASSUME-13]; `flip`: report the normal from the arrow to the box (movable block = geom2)
+MZP_HD double sel3d(const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }  // no dynamically indexed private array
+
+// box (geom1: centre pos1, axes = columns of the row-major mat1, half sizes size1) vs box (geom2): MuJoCo's mjc_BoxBox as
+// restated in oracle/mzo_physics.c box_box, face case: least-penetration face axis in MuJoCo's order
+// (per axis index the face of box 1, then of box 2; strict improvement), incident face = the face of the other box most
+// anti-parallel to it, contact candidates = the vertices of the intersection of the incident rectangle with the reference
+// rectangle (incident corners inside | incident edges against the border lines | reference corners inside, on the incident
+// plane; inclusive tests, coincident candidates once), each with its own distance to the reference face, midway position,
+// normal from geom1 to geom2, at most 8.  The edge-edge axes are not searched: the boxes of the Point's world (the arrow,
+// walls, movable blocks) are rotated about z only, where every edge-edge axis coincides with a face axis and loses the tie
+// (point_dev_from_model admits nothing else).  Written with constant array indices throughout (the dynamic choices go
+// through selects), so that nothing lands in scratch memory.
 template <class Emit>
-MZP_HD void pl_arrow_box(const PointDev& P, const double* bc, double co, double si, const double* wc, const double* wh, double margin,
-                         bool flip, int b1, int b2, int cls, Emit&& emit) {
-  if (fabs(P.arr_z - wc[2]) > P.arr_hz + wh[2] + margin) return;
-  double ex[2] = {co, si}, ey[2] = {-si, co}, dx = bc[0] - wc[0], dy = bc[1] - wc[1];
-  int best = -1; double bestsep = -1e30, bestsign = 1.0;
-  for (int a = 0; a < 4; a++) {
-    double nx = a == 0 ? 1.0 : (a == 1 ? 0.0 : (a == 2 ? ex[0] : ey[0])), ny = a == 0 ? 0.0 : (a == 1 ? 1.0 : (a == 2 ? ex[1] : ey[1]));
-    double proj = dx * nx + dy * ny;
-    double ra = wh[0] * fabs(nx) + wh[1] * fabs(ny);
-    double rb = P.arr_hx * fabs(ex[0] * nx + ex[1] * ny) + P.arr_hy * fabs(ey[0] * nx + ey[1] * ny);
-    double sep = fabs(proj) - (ra + rb);
-    if (sep > bestsep) { bestsep = sep; best = a; bestsign = proj >= 0.0 ? 1.0 : -1.0; }
+MZP_HD void pl_box_box(const double* pos1, const double* mat1, const double* size1, const double* pos2, const double* mat2, const double* size2,
+                       double margin, int b1id, int b2id, int cls, Emit&& emit) {
+  double rot[9], pos21[3], pos12[3];
+  const double d0 = pos2[0] - pos1[0], d1 = pos2[1] - pos1[1], d2 = pos2[2] - pos1[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) rot[3 * i + j] = mat1[i] * mat2[j] + mat1[3 + i] * mat2[3 + j] + mat1[6 + i] * mat2[6 + j];
+    pos21[i] = mat1[i] * d0 + mat1[3 + i] * d1 + mat1[6 + i] * d2;
+    pos12[i] = -(mat2[i] * d0 + mat2[3 + i] * d1 + mat2[6 + i] * d2);
   }
-  if (bestsep > margin) return;
-  double nx = best == 0 ? 1.0 : (best == 1 ? 0.0 : (best == 2 ? ex[0] : ey[0])), ny = best == 0 ? 0.0 : (best == 1 ? 1.0 : (best == 2 ? ex[1] : ey[1]));
-  double n[3] = {nx * bestsign, ny * bestsign, 0.0};  // box -> arrow
-  double vx[4], vy[4], dep[4], dmin = 1e30;
-  for (int k = 0; k < 4; k++) {
-    double sx = (k & 1) ? 1.0 : -1.0, sy = (k & 2) ? 1.0 : -1.0;
-    if (best < 2) {
-      vx[k] = bc[0] + sx * P.arr_hx * ex[0] + sy * P.arr_hy * ey[0];
-      vy[k] = bc[1] + sx * P.arr_hx * ex[1] + sy * P.arr_hy * ey[1];
-      dep[k] = (vx[k] - wc[0]) * n[0] + (vy[k] - wc[1]) * n[1] - (wh[0] * fabs(n[0]) + wh[1] * fabs(n[1]));
-    } else {
-      vx[k] = wc[0] + sx * wh[0];
-      vy[k] = wc[1] + sy * wh[1];
-      dep[k] = (bc[0] - vx[k]) * n[0] + (bc[1] - vy[k]) * n[1] - (best == 2 ? P.arr_hx : P.arr_hy);
-    }
-    if (dep[k] < dmin) dmin = dep[k];
+  double penetration = margin + 3.0 * (size1[0] + size1[1] + size1[2] + size2[0] + size2[1] + size2[2]);
+  int code = -1;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double plen2 = fabs(rot[3 * i]) * size2[0] + fabs(rot[3 * i + 1]) * size2[1] + fabs(rot[3 * i + 2]) * size2[2];
+    const double plen1 = fabs(rot[i]) * size1[0] + fabs(rot[3 + i]) * size1[1] + fabs(rot[6 + i]) * size1[2];
+    const double c1 = -fabs(pos21[i]) + size1[i] + plen2, c2 = -fabs(pos12[i]) + size2[i] + plen1;
+    if (c1 < -margin || c2 < -margin) return;
+    if (c1 < penetration) { penetration = c1; code = i; }
+    if (c2 < penetration) { penetration = c2; code = 3 + i; }
   }
-  for (int k = 0; k < 4; k++)
-    if (dep[k] <= dmin + 1e-9) {
-      double sg = best < 2 ? -0.5 : 0.5;
-      PlContact c;
-      c.dist = dep[k];
-      c.pos[0] = vx[k] + sg * n[0] * dep[k]; c.pos[1] = vy[k] + sg * n[1] * dep[k]; c.pos[2] = P.arr_z;
-      c.n[0] = flip ? -n[0] : n[0]; c.n[1] = flip ? -n[1] : n[1]; c.n[2] = 0.0;
-      c.b1 = b1; c.b2 = b2; c.cls = cls;
-      emit(c);
+  if (code < 0) return;
+  const bool fromB = code >= 3;
+  const int a = fromB ? code - 3 : code, a1 = a == 2 ? 0 : a + 1, a2 = a == 0 ? 2 : a - 1;
+  double R[9], pBA[3], sA[3], sB[3];  // the reference box A's frame: R[k][j] = axis k of A . axis j of B
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) R[3 * k + j] = fromB ? rot[3 * j + k] : rot[3 * k + j];
+    pBA[k] = fromB ? pos12[k] : pos21[k];
+    sA[k] = fromB ? size2[k] : size1[k];
+    sB[k] = fromB ? size1[k] : size2[k];
+  }
+  const double sg = sel3d(pBA, a) < 0.0 ? -1.0 : 1.0;
+  const double* posA = fromB ? pos2 : pos1;
+  const double* matA = fromB ? mat2 : mat1;
+  if (a != 2 && R[8] > 1.0 - 1e-12) {
+    // Fast path — both boxes upright (rotated about z only) and a HORIZONTAL reference normal, i.e. every arrow-wall /
+    // arrow-block contact short of a deep overlap: the incident face is a vertical rectangle whose projection on the
+    // reference face is an axis-aligned rectangle in (h, z) — h the horizontal axis of the reference face — so the
+    // intersection the enumeration below would assemble from its 24 candidates is simply [hlo, hhi] x [zlo, zhi], its
+    // corners carrying the depth of the incident edge at their h.  Same vertices, same tolerances.
+    const int ah = 1 - a;
+    const double Ra0 = a == 0 ? R[0] : R[3], Ra1 = a == 0 ? R[1] : R[4];       // row a of R, horizontal part
+    const int b = fabs(Ra1) > fabs(Ra0) ? 1 : 0, bh = 1 - b;
+    const double sb = (b == 0 ? Ra0 : Ra1) * sg > 0.0 ? -1.0 : 1.0;
+    const double sBb = b == 0 ? sB[0] : sB[1], sBh = b == 0 ? sB[1] : sB[0];
+    // incident face centre and its horizontal half edge, components along (ah, a)
+    const double Rhb = ah == 0 ? (b == 0 ? R[0] : R[1]) : (b == 0 ? R[3] : R[4]), Rab = b == 0 ? Ra0 : Ra1;
+    const double Rhh = ah == 0 ? (bh == 0 ? R[0] : R[1]) : (bh == 0 ? R[3] : R[4]), Rah = bh == 0 ? Ra0 : Ra1;
+    const double Ph = (ah == 0 ? pBA[0] : pBA[1]) + sb * sBb * Rhb, P3 = (a == 0 ? pBA[0] : pBA[1]) + sb * sBb * Rab, Pz = pBA[2];
+    const double Uh = sBh * Rhh, U3 = sBh * Rah;
+    const double Sh = ah == 0 ? sA[0] : sA[1], S3 = a == 0 ? sA[0] : sA[1], Sz = sA[2];
+    const double tol = 1e-12 * (1.0 + Sh + Sz), dtol = 1e-9 * (1.0 + Sh + Sz);
+    const double hlo = fmax(-Sh, Ph - fabs(Uh)), hhi = fmin(Sh, Ph + fabs(Uh)), zlo = fmax(-Sz, Pz - sB[2]), zhi = fmin(Sz, Pz + sB[2]);
+    if (hhi - hlo < -tol || zhi - zlo < -tol) return;
+    const int nh = hhi - hlo > dtol ? 2 : 1, nz = zhi - zlo > dtol ? 2 : 1;
+    for (int ih = 0; ih < nh; ih++) {
+      const double hh = ih ? hhi : hlo, x3 = P3 + (hh - Ph) / Uh * U3, dist = sg * x3 - S3;
+      if (dist > margin) continue;
+      const double x3m = x3 - sg * 0.5 * dist;
+      for (int iz = 0; iz < nz; iz++) {
+        const double zz = iz ? zhi : zlo;
+        const double pl0 = a == 0 ? x3m : hh, pl1 = a == 0 ? hh : x3m, nl0 = a == 0 ? (fromB ? -sg : sg) : 0.0, nl1 = a == 0 ? 0.0 : (fromB ? -sg : sg);
+        PlContact c;
+        c.dist = dist;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          c.pos[k] = matA[3 * k] * pl0 + matA[3 * k + 1] * pl1 + matA[3 * k + 2] * zz + posA[k];
+          c.n[k] = matA[3 * k] * nl0 + matA[3 * k + 1] * nl1;
+        }
+        c.b1 = b1id; c.b2 = b2id; c.cls = cls;
+        emit(c);
+      }
     }
+    return;
+  }
+  const double Ra[3] = {a == 0 ? R[0] : (a == 1 ? R[3] : R[6]), a == 0 ? R[1] : (a == 1 ? R[4] : R[7]), a == 0 ? R[2] : (a == 1 ? R[5] : R[8])};
+  int b = 0;
+  if (fabs(Ra[1]) > fabs(Ra[b])) b = 1;
+  if (fabs(Ra[2]) > fabs(sel3d(Ra, b))) b = 2;
+  const double sb = sel3d(Ra, b) * sg > 0.0 ? -1.0 : 1.0;
+  const int bb1 = b == 2 ? 0 : b + 1, bb2 = b == 0 ? 2 : b - 1;
+  double cf[3], u[3], v[3];
+  const double sBb = sel3d(sB, b), sB1 = sel3d(sB, bb1), sB2 = sel3d(sB, bb2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double row[3] = {R[3 * k], R[3 * k + 1], R[3 * k + 2]};
+    cf[k] = pBA[k] + sb * sBb * sel3d(row, b);
+    u[k] = sB1 * sel3d(row, bb1);
+    v[k] = sB2 * sel3d(row, bb2);
+  }
+  // coordinates permuted to (a1, a2, a): the reference rectangle is |x1| <= S1, |x2| <= S2 in the plane x3 = sg * S3
+  const double P1 = sel3d(cf, a1), P2 = sel3d(cf, a2), P3 = sel3d(cf, a), U1 = sel3d(u, a1), U2 = sel3d(u, a2), U3 = sel3d(u, a);
+  const double V1 = sel3d(v, a1), V2 = sel3d(v, a2), V3 = sel3d(v, a), S1 = sel3d(sA, a1), S2 = sel3d(sA, a2), S3 = sel3d(sA, a);
+  const double tol = 1e-12 * (1.0 + S1 + S2), dtol = 1e-9 * (1.0 + S1 + S2);
+  double k1[8], k2[8], k3[8];  // candidates kept so far (constant indices only)
+  int nk = 0, nemit = 0;
+  // Candidates can coincide only when an incident corner lies on a border line of the reference rectangle: structurally so
+  // when the incident edges run parallel to the reference axes (aligned boxes), otherwise only by a coincidence at the 1e-9
+  // level, which is ignored here — the comparison against the kept candidates runs for aligned rectangles only.
+  const bool aligned = fabs(U1 * U2) + fabs(V1 * V2) <= 1e-9 * (U1 * U1 + U2 * U2 + V1 * V1 + V2 * V2);
+  auto consider = [&](double x1, double x2, double x3) {
+    if (aligned) {
+      bool dup = false;
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        if (e < nk && fabs(x1 - k1[e]) <= dtol && fabs(x2 - k2[e]) <= dtol && fabs(x3 - k3[e]) <= dtol) dup = true;
+      if (dup || nk >= 8) return;  // (a ninth distinct vertex cannot exist: two rectangles intersect in at most an octagon)
+#pragma unroll
+      for (int e = 0; e < 8; e++) if (e == nk) { k1[e] = x1; k2[e] = x2; k3[e] = x3; }
+      nk++;
+    }
+    const double dist = sg * x3 - S3;
+    if (dist > margin || nemit >= 8) return;
+    nemit++;
+    const double x3m = x3 - sg * 0.5 * dist;
+    double pl[3], nl[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pl[k] = k == a1 ? x1 : (k == a2 ? x2 : x3m); nl[k] = k == a ? (fromB ? -sg : sg) : 0.0; }
+    PlContact c;
+    c.dist = dist;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      c.pos[k] = matA[3 * k] * pl[0] + matA[3 * k + 1] * pl[1] + matA[3 * k + 2] * pl[2] + posA[k];
+      c.n[k] = matA[3 * k] * nl[0] + matA[3 * k + 1] * nl[1] + matA[3 * k + 2] * nl[2];
+    }
+    c.b1 = b1id; c.b2 = b2id; c.cls = cls;
+    emit(c);
+  };
+  // The 24 candidates in the oracle's order — 4 incident corners inside the reference rectangle | 4 incident edges x 2 border
+  // directions x 2 sides | 4 reference corners inside the incident rectangle (on the incident plane) — as ONE rolled loop: this
+  // path is rare (a deep overlap, whose least-penetration axis is vertical), and 24 inlined copies of `consider` with the
+  // caller's emit in each cost every launch a third of its time in instruction fetch alone (measured).
+  const double det = U1 * V2 - U2 * V1;
+#pragma unroll 1
+  for (int c = 0; c < 24; c++) {
+    double x1 = 0.0, x2 = 0.0, x3 = 0.0;
+    bool valid = false;
+    if (c < 4) {
+      const double su = (c & 1) ? 1.0 : -1.0, sv = (c & 2) ? 1.0 : -1.0;
+      x1 = P1 + su * U1 + sv * V1; x2 = P2 + su * U2 + sv * V2; x3 = P3 + su * U3 + sv * V3;
+      valid = fabs(x1) <= S1 + tol && fabs(x2) <= S2 + tol;
+    } else if (c < 20) {
+      const int k = c - 4, e = k >> 2, w = (k >> 1) & 1;
+      const double side = (k & 1) ? 1.0 : -1.0, sgn = (e & 1) ? 1.0 : -1.0;
+      const double p1 = e < 2 ? P1 + sgn * V1 : P1 + sgn * U1, p2 = e < 2 ? P2 + sgn * V2 : P2 + sgn * U2, p3 = e < 2 ? P3 + sgn * V3 : P3 + sgn * U3;
+      const double q1 = e < 2 ? U1 : V1, q2 = e < 2 ? U2 : V2, q3 = e < 2 ? U3 : V3;
+      const double pc = w ? p2 : p1, qc = w ? q2 : q1, po = w ? p1 : p2, qo = w ? q1 : q2, Sc = w ? S2 : S1, So = w ? S1 : S2;
+      if (fabs(qc) >= 1e-15) {
+        const double t = (side * Sc - pc) / qc;
+        valid = t >= -1.0 && t <= 1.0 && fabs(po + t * qo) <= So + tol;
+        x1 = p1 + t * q1; x2 = p2 + t * q2; x3 = p3 + t * q3;
+      }
+    } else if (fabs(det) > 1e-15) {
+      const int k = c - 20;
+      const double x = ((k & 1) ? S1 : -S1) - P1, y = ((k & 2) ? S2 : -S2) - P2;
+      const double al = (x * V2 - y * V1) / det, be = (U1 * y - U2 * x) / det;
+      valid = fabs(al) <= 1.0 + 1e-12 && fabs(be) <= 1.0 + 1e-12;
+      x1 = P1 + al * U1 + be * V1; x2 = P2 + al * U2 + be * V2; x3 = P3 + al * U3 + be * V3;
+    }
+    if (valid) consider(x1, x2, x3);
+  }
 }
 
-// axis-aligned box (geom1: centre c1, half h1) vs axis-aligned box (geom2: centre c2, half h2) [ASSUME-12]
+// axis-aligned box (geom1: centre c1, half h1) vs axis-aligned box (geom2: centre c2, half h2): aligned_box_box (ant_dyn.h)
 template <class Emit>
-MZP_HD void pl_box_box(const double* c1, const double* h1, const double* c2, const double* h2, double margin, int b1, int b2, int cls,
-                       Emit&& emit) {
-  double gap[3];
-  int ax = 0;
-  for (int k = 0; k < 3; k++) gap[k] = fabs(c2[k] - c1[k]) - (h1[k] + h2[k]);
-  if (gap[1] > gap[ax]) ax = 1;
-  if (gap[2] > gap[ax]) ax = 2;
-  double gmax = ax == 0 ? gap[0] : (ax == 1 ? gap[1] : gap[2]);
-  if (gmax > margin) return;
-  double lo[3], hi[3];
-  for (int k = 0; k < 3; k++) { lo[k] = fmax(c1[k] - h1[k], c2[k] - h2[k]); hi[k] = fmin(c1[k] + h1[k], c2[k] + h2[k]); }
-  int u = (ax + 1) % 3, w = (ax + 2) % 3;
-  if (!(hi[u] - lo[u] > 1e-6) || !(hi[w] - lo[w] > 1e-6)) return;  // edge / corner touch: no face contact
-  double sg = c2[ax] >= c1[ax] ? 1.0 : -1.0;
-  for (int iu = 0; iu < 2; iu++)
-    for (int iw = 0; iw < 2; iw++) {
+MZP_HD void pl_box_box_aligned(const double* c1, const double* h1, const double* c2, const double* h2, double margin, int b1, int b2, int cls,
+                               Emit&& emit) {
+  AlignedBB bb;
+  if (!aligned_box_box(c1, h1, c2, h2, margin, bb)) return;
+  const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1, w = ax == 0 ? 2 : ax - 1;
+  for (int iu = 0; iu < bb.nu; iu++)
+    for (int iw = 0; iw < bb.nv; iw++) {
       PlContact c;
-      c.dist = gmax;
-      for (int k = 0; k < 3; k++) c.n[k] = 0.0;
-      c.n[ax] = sg;
-      c.pos[ax] = c1[ax] + sg * (h1[ax] + 0.5 * gmax);
-      c.pos[u] = iu ? hi[u] : lo[u];
-      c.pos[w] = iw ? hi[w] : lo[w];
+      c.dist = bb.dist;
+      for (int k = 0; k < 3; k++) { c.n[k] = k == ax ? bb.sg : 0.0; c.pos[k] = k == ax ? bb.pa : (k == u ? bb.pu[iu] : bb.pv[iw]); }
       c.b1 = b1; c.b2 = b2; c.cls = cls;
       emit(c);
     }
@@ -211,7 +332,12 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, i
       ct.b1 = 0; ct.b2 = -1; ct.cls = 0;
       emit(ct);
     } else {      // wall (geom1) vs arrow (geom2)
-      pl_arrow_box(P, arrow, s.co, s.si, wc, wh, pr.margin, false, -1, 0, 0, emit);
+      // the arrow lies within its circumscribed circle: a cell farther than that from its centre cannot touch it
+      const double ex = fmax(fabs(arrow[0] - wc[0]) - wh[0], 0.0), ey = fmax(fabs(arrow[1] - wc[1]) - wh[1], 0.0), rr = P.arr_rxy + pr.margin;
+      if (ex * ex + ey * ey > rr * rr) return;
+      const double am[9] = {s.co, -s.si, 0.0, s.si, s.co, 0.0, 0.0, 0.0, 1.0}, ac[3] = {arrow[0], arrow[1], P.arr_z}, ah[3] = {P.arr_hx, P.arr_hy, P.arr_hz};
+      const double id[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+      pl_box_box(wc, id, wh, ac, am, ah, pr.margin, -1, 0, 0, emit);
     }
     return;
   }
@@ -270,15 +396,17 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, i
         ct.b1 = 0; ct.b2 = 1 + b; ct.cls = 1;
         emit(ct);
       } else if (k == 1) {  // arrow (geom1) vs block (geom2)
-        pl_arrow_box(P, arrow, s.co, s.si, bc, P.block_half, P.pair[1].margin, true, 0, 1 + b, 1, emit);
+        const double am[9] = {s.co, -s.si, 0.0, s.si, s.co, 0.0, 0.0, 0.0, 1.0}, ac[3] = {arrow[0], arrow[1], P.arr_z}, ah[3] = {P.arr_hx, P.arr_hy, P.arr_hz};
+        const double id[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+        pl_box_box(ac, am, ah, bc, id, P.block_half, P.pair[1].margin, 0, 1 + b, 1, emit);
       } else if (k < 11) {  // wall (geom1) vs block (geom2)
         double wc[3];
         if (!pl_wall_cell(z, bc[0], bc[1], k - 2, wc)) return;
-        pl_box_box(wc, wh, bc, P.block_half, P.pair[2].margin, -1, 1 + b, 2, emit);
+        pl_box_box_aligned(wc, wh, bc, P.block_half, P.pair[2].margin, -1, 1 + b, 2, emit);
       } else if (k < 20) {  // platform of an elevated maze (geom1) vs block (geom2): same box rule, same pair class as a wall
         double wc[3];
         if (!pl_platform_cell(z, bc[0], bc[1], k - 11, wc)) return;
-        pl_box_box(wc, wh, bc, P.block_half, P.pair[2].margin, -1, 1 + b, 2, emit);
+        pl_box_box_aligned(wc, wh, bc, P.block_half, P.pair[2].margin, -1, 1 + b, 2, emit);
       } else if (k == 20) {  // floor plane z = 0 (geom1) vs block (geom2): the corners below the plane, normal +z
         if (P.block_axis[1] != 2) return;  // a block without a z slide rests on the floor at dist = 0 exactly: never a contact
         for (int ci = 0; ci < 4; ci++) {
@@ -313,7 +441,7 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, i
         double ca[3], cb[3];
         pl_block_center<NB, NS>(P, s, a, ca);
         pl_block_center<NB, NS>(P, s, b, cb);
-        pl_box_box(ca, P.block_half, cb, P.block_half, P.pair[3].margin, 1 + a, 1 + b, 3, emit);
+        pl_box_box_aligned(ca, P.block_half, cb, P.block_half, P.pair[3].margin, 1 + a, 1 + b, 3, emit);
       }
     }
   }

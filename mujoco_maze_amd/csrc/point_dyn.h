@@ -39,7 +39,7 @@ struct PointDev {
   // MuJoCo contact regime: body, geoms, pair classes 0 robot-wall, 1 robot-block, 2 wall-block, 3 block-block,
   // 4 ball-wall, 5 robot-ball
   double mass, izz, inv_scale;
-  double sph_r, sph_z, arr_off, arr_hx, arr_hy, arr_hz, arr_z;
+  double sph_r, sph_z, arr_off, arr_hx, arr_hy, arr_hz, arr_z, arr_rxy;  // arr_rxy: radius of the arrow's circumscribed circle (top view)
   PtPair pair[8];  // + 6 joint-limit rows of a block's slides (margin = joint margin), 7 floor plane vs block
   // movable XY blocks (maze_env.py:563-660), all of one size
   int nblock, observe_blocks;
@@ -86,6 +86,7 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
   p->sph_r = m->geom_size[1][0]; p->sph_z = m->body_pos[1][2] + m->geom_pos[1][2];  // torso body height: 0, or 0.75 + platform height in elevated mazes
   p->arr_off = m->geom_pos[2][0]; p->arr_hx = m->geom_size[2][0]; p->arr_hy = m->geom_size[2][1]; p->arr_hz = m->geom_size[2][2];
   p->arr_z = m->body_pos[1][2] + m->geom_pos[2][2];
+  p->arr_rxy = sqrt(p->arr_hx * p->arr_hx + p->arr_hy * p->arr_hy);
   for (int k = 0; k < 5; k++)
     if (m->geom_solimp[1][k] != m->geom_solimp[2][k]) return ant_fail(err, errlen, "point kernel: sphere and arrow must share contact parameters");
   if (m->geom_margin[1] != m->geom_margin[2] || m->geom_margin[0] != 0.0 || m->geom_margin[1] != 0.0)

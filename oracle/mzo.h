@@ -80,6 +80,9 @@ void mzo_batch_forward(const mz_model* m, int n, const double* qpos, const doubl
 
 void mzo_forward_report(const mz_model* m, const double* qpos, const double* qvel, const double* warm, const double* ctrl,
                         double* report, double* qacc_out);
+int mzo_probe_pair(int kind, const double* pos1, const double* mat1, const double* size1, const double* pos2, const double* mat2,
+                   const double* size2, double margin, int max_con, double* out);
+int mzo_contacts(const mz_model* m, const double* qpos, int max_con, double* out);
 void mzo_raw_steps(const mz_model* m, double* qpos, double* qvel, const double* ctrl, int nsteps, double* energy_out);
 
 /* RNG shared by oracle and kernels: 64-bit counter hash -> uniform [0,1) */

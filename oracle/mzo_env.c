@@ -371,6 +371,23 @@ void mzo_forward_report(const mz_model* m, const double* qpos, const double* qve
   if (qacc_out) memcpy(qacc_out, d.qacc, sizeof(double) * m->nv);
 }
 
+/* contact set of one configuration (parity tests, tests/test_mujoco_crosscheck.py): per contact 10 doubles
+ * dist | pos[3] | normal[3] (geom1 -> geom2) | geom1 | geom2 (-1: an implicit maze box) | active (dist < margin - gap);
+ * returns the number of contacts (at most max_con rows are written) */
+int mzo_contacts(const mz_model* m, const double* qpos, int max_con, double* out) {
+  mzo_data d;
+  memset(&d, 0, sizeof(d));
+  memcpy(d.qpos, qpos, sizeof(double) * m->nq);
+  mzo_forward(m, &d, NULL);
+  for (int c = 0; c < d.ncon && c < max_con; c++) {
+    double* o = out + 10 * c;
+    o[0] = d.con[c].dist;
+    for (int k = 0; k < 3; k++) { o[1 + k] = d.con[c].pos[k]; o[4 + k] = d.con[c].frame[k]; }
+    o[7] = d.con[c].geom1; o[8] = d.con[c].geom2; o[9] = d.con[c].dist < d.con[c].includemargin;
+  }
+  return d.ncon;
+}
+
 /* raw mj_step x n on one state (no maze logic) + energy, for invariants tests */
 void mzo_raw_steps(const mz_model* m, double* qpos, double* qvel, const double* ctrl, int nsteps, double* energy_out) {
   mzo_data d;

@@ -485,156 +485,292 @@ static int sphere_box(const double* cs, double r, const double* bpos, const doub
   return dd <= margin;
 }
 
-/* squared-distance derivative helper for segment-vs-box: f'(t)/2 */
-static double seg_box_dfdt(const double* a, const double* dir, const double* s, double t) {
-  double g = 0;
-  for (int k = 0; k < 3; k++) {
-    double p = a[k] + t * dir[k];
-    if (p > s[k]) g += (p - s[k]) * dir[k];
-    else if (p < -s[k]) g += (p + s[k]) * dir[k];
-  }
-  return g;
-}
-/* parameter t in [0,1] of the segment point closest to the box (box frame): root of the monotone
- * piecewise-linear derivative, bracketed by the slab-crossing candidates (smallest t on a flat stretch) */
-static double seg_box_closest_t(const double* a, const double* b, const double* s) {
-  double dir[3];
-  sub3(dir, b, a);
-  double tlo = 0.0, glo = seg_box_dfdt(a, dir, s, 0.0);
-  if (glo >= 0) return 0.0;
-  double thi = 1.0, ghi = seg_box_dfdt(a, dir, s, 1.0);
-  if (ghi < 0) return 1.0;
-  for (int k = 0; k < 3; k++)
-    if (fabs(dir[k]) > 1e-300)
-      for (int sgn = 0; sgn < 2; sgn++) {
-        double t = ((sgn ? -s[k] : s[k]) - a[k]) / dir[k];
-        if (t > tlo && t < thi) {
-          double g = seg_box_dfdt(a, dir, s, t);
-          if (g < 0) { tlo = t; glo = g; } else { thi = t; ghi = g; }
-        }
-      }
-  return tlo - glo * (thi - tlo) / (ghi - glo);
-}
-
-/* capsule (geom1) vs box (geom2).  [ASSUME-6] MuJoCo's mjc_CapsuleBox feature
- * search is not reproduced; contact A sits at the segment point closest to the
- * box, contact B at the segment end farther from A when that end is itself
- * within the margin. */
+/* capsule (geom1) vs box (geom2): restatement of MuJoCo's mjc_CapsuleBox (engine_collision_box.c; the library is not in
+ * /root/reference, DESIGN.md section 5 says what is followed from the published source and what is reconstructed).
+ *
+ * Followed: (1) the capsule's axis segment is brought into the box frame; (2) the box feature closest to the segment is
+ * searched in MuJoCo's order — the two segment ends against the box faces (an end with at most one coordinate outside the
+ * box), then the 12 box edges against the segment by clamped line-line distance, a later candidate winning only when it
+ * is closer by more than MINVAL; the result is encoded as in MuJoCo: cltype -3 / -1 = a face with segment end -1 / +1,
+ * cltype = 3 * s1 + s2 for an edge with s1 (edge) and s2 (segment) in {0 lower end, 1 interior, 2 upper end}; (3) at most
+ * TWO contacts come out, each of them a sphere-box contact (mjraw_SphereBox: position, normal, distance, margin test) of a
+ * sphere of the capsule's radius centred on the segment: the first at the closest segment point `bestsegmentpos`, the
+ * second `secondpos` further along the segment, chosen by the feature type so that it is the far support point of a capsule
+ * lying along a face or an edge: never beyond the segment's end, never beyond the extent of the face / edge it runs over.
+ * Reconstructed (the published routine's case analysis is restated from its geometry, not line by line): the exact
+ * expressions of `secondpos` in the corner / edge / face cases below; a second point that coincides with the first
+ * (secondpos = 0) is not emitted. */
 static void capsule_box(mzo_data* d, const pairparam* pp, const double* cpos, const double* cmat, double r, double hl,
                         const double* bpos, const double* bmat, const double* bsize) {
-  double axis[3] = {cmat[2], cmat[5], cmat[8]}, e1[3], e2[3], rel[3], a[3], b[3];
-  for (int k = 0; k < 3; k++) { e1[k] = cpos[k] + axis[k] * hl; e2[k] = cpos[k] - axis[k] * hl; }
-  sub3(rel, e1, bpos); mulmat3Tvec(a, bmat, rel);
-  sub3(rel, e2, bpos); mulmat3Tvec(b, bmat, rel);
-  double t = seg_box_closest_t(a, b, bsize);
-  double p[3], dist, pos[3], nrm[3];
-  for (int k = 0; k < 3; k++) p[k] = e1[k] + t * (e2[k] - e1[k]);
-  if (sphere_box(p, r, bpos, bmat, bsize, pp->margin, &dist, pos, nrm)) add_contact(d, pp, dist, pos, nrm, NULL);
-  const double* far = (t <= 0.5) ? e2 : e1;
-  double tf = (t <= 0.5) ? 1.0 : 0.0;
-  if (fabs(tf - t) * 2.0 * hl > 1e-6)
-    if (sphere_box(far, r, bpos, bmat, bsize, pp->margin, &dist, pos, nrm)) add_contact(d, pp, dist, pos, nrm, NULL);
+  double tmp1[3], tmp2[3], pos[3], axis[3], halfaxis[3], dif[3];
+  const double caxis[3] = {cmat[2], cmat[5], cmat[8]};
+  sub3(tmp1, cpos, bpos);
+  mulmat3Tvec(pos, bmat, tmp1);      /* capsule centre in the box frame */
+  mulmat3Tvec(axis, bmat, caxis);    /* capsule axis in the box frame */
+  for (int k = 0; k < 3; k++) halfaxis[k] = axis[k] * hl;
+  const int axisdir = (halfaxis[0] > 0 ? 1 : 0) + (halfaxis[1] > 0 ? 2 : 0) + (halfaxis[2] > 0 ? 4 : 0);
+  const double bestdistmax = pp->margin + 2.0 * (r + hl + bsize[0] + bsize[1] + bsize[2]);
+  double bestdist = bestdistmax * bestdistmax, bestsegmentpos = 0.0, bestboxpos = 0.0, secondpos = -4.0;
+  int cltype = -4, clface = -1, clcorner = 0, cledge = -1;
+  /* segment ends against the faces */
+  for (int i = -1; i <= 1; i += 2) {
+    int nout = 0, face = -1;
+    for (int k = 0; k < 3; k++) {
+      tmp1[k] = pos[k] + halfaxis[k] * i;
+      tmp2[k] = tmp1[k];
+      if (tmp1[k] < -bsize[k]) { nout++; face = k; tmp1[k] = -bsize[k]; }
+      else if (tmp1[k] > bsize[k]) { nout++; face = k; tmp1[k] = bsize[k]; }
+    }
+    if (nout > 1) continue;  /* closest box feature of this end is an edge or a corner: found by the edge loop */
+    sub3(dif, tmp1, tmp2);
+    const double dist = dot3(dif, dif);
+    if (dist < bestdist) { bestdist = dist; bestsegmentpos = i; cltype = -2 + i; clface = face; }
+  }
+  /* the 12 edges: edge j of the corner i whose bit j is clear (the edge runs from corner i to corner i + (1 << j)) */
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 3; j++) {
+      if (i & (1 << j)) continue;
+      double mid[3] = {(i & 1 ? 1 : -1) * bsize[0], (i & 2 ? 1 : -1) * bsize[1], (i & 4 ? 1 : -1) * bsize[2]};
+      mid[j] = 0.0;  /* middle of the edge; edge point = mid + x1 * bsize[j] * e_j, segment point = pos + x2 * halfaxis */
+      sub3(dif, mid, pos);
+      const double u = -bsize[j] * dif[j], v = dot3(halfaxis, dif);
+      const double ma = bsize[j] * bsize[j], mb = -bsize[j] * halfaxis[j], mc = hl * hl;
+      const double det = ma * mc - mb * mb;
+      if (fabs(det) < MINVAL) continue;  /* parallel: the ends already took part in the face test / other edges */
+      double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+      int s1 = 1, s2 = 1;
+      if (x1 > 1) { x1 = 1; s1 = 2; x2 = (v - mb) / mc; }
+      else if (x1 < -1) { x1 = -1; s1 = 0; x2 = (v + mb) / mc; }
+      if (x2 > 1) { x2 = 1; s2 = 2; x1 = (u - mb) / ma; if (x1 > 1) { x1 = 1; s1 = 2; } else if (x1 < -1) { x1 = -1; s1 = 0; } else s1 = 1; }
+      else if (x2 < -1) { x2 = -1; s2 = 0; x1 = (u + mb) / ma; if (x1 > 1) { x1 = 1; s1 = 2; } else if (x1 < -1) { x1 = -1; s1 = 0; } else s1 = 1; }
+      for (int k = 0; k < 3; k++) dif[k] = mid[k] - (pos[k] + halfaxis[k] * x2);
+      dif[j] += bsize[j] * x1;
+      const double dist = dot3(dif, dif);
+      if (dist < bestdist - MINVAL) {
+        bestdist = dist; bestsegmentpos = x2; bestboxpos = x1;
+        cltype = 3 * s1 + s2;
+        clcorner = i + (s1 == 2 ? (1 << j) : 0);
+        cledge = j;
+      }
+    }
+  if (cltype == -4) return;
+  if (cltype >= 0 && cltype / 3 != 1) {
+    /* closest to a CORNER of the box.  c1 = the coordinates in which the segment direction disagrees with the corner's
+     * octant: none or all three = pointing at / away from the corner (no second contact); otherwise, along +-halfaxis
+     * (mul), exactly one coordinate `ax` runs into the box's extent and the other two run out of it */
+    int c1 = axisdir ^ clcorner;
+    if (c1 != 0 && c1 != 7) {
+      double mul = 1.0;
+      if (!(c1 == 1 || c1 == 2 || c1 == 4)) { mul = -1.0; c1 = 7 - c1; }
+      const int ax = c1 == 1 ? 0 : (c1 == 2 ? 1 : 2), ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (axis[ax] * axis[ax] > 0.5) { /* lying along the box edge through this corner: go on in direction mul */
+        secondpos = mul * fmin(1.0 - mul * bestsegmentpos, 2.0 * bsize[ax] / fabs(halfaxis[ax]));
+      } else {                         /* lying across the face: go back in direction -mul, over the face */
+        double m = fmin(2.0 * bsize[ax1] / fabs(halfaxis[ax1]), 2.0 * bsize[ax2] / fabs(halfaxis[ax2]));
+        secondpos = -mul * fmin(1.0 + mul * bestsegmentpos, m);
+      }
+    }
+  } else if (cltype >= 0) {
+    /* closest to the interior of an EDGE (axis cledge).  Masked to the two axes across the edge, c1 has one bit when the
+     * segment passes the edge tangentially (over one face on either side): second contact over the face the segment makes
+     * the smaller angle with; no bit or both bits = pointing at / away from the edge (T configuration): none */
+    int c1 = (axisdir ^ clcorner) & (7 - (1 << cledge));
+    if (c1 == 1 || c1 == 2 || c1 == 4) {
+      const int ax = cledge;
+      int ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (fabs(axis[ax1]) > fabs(axis[ax2])) { int t = ax1; ax1 = ax2; ax2 = t; }  /* ax1: normal of the face, ax2: across it */
+      const double mul = (c1 & (1 << ax2)) ? 1.0 : -1.0;  /* direction along the segment that runs in over the face */
+      double sp = 1.0 - mul * bestsegmentpos;                         /* to the segment's end */
+      sp = fmin(sp, 2.0 * bsize[ax2] / fabs(halfaxis[ax2]));          /* to the far side of the face */
+      const double e2 = (mul * halfaxis[ax] > 0) ? 1.0 - bestboxpos : 1.0 + bestboxpos;
+      sp = fmin(sp, bsize[ax] * e2 / fabs(halfaxis[ax]));             /* to the end of the edge it runs along */
+      secondpos = mul * sp;
+    }
+  } else {
+    /* closest to a FACE with a segment end: the second point is the other end, pulled in so that it stays over the face */
+    double travel = -2.0 * bestsegmentpos, frac = 1.0;
+    for (int k = 0; k < 3; k++) {
+      if (k == clface) continue;
+      const double p0 = pos[k] + halfaxis[k] * bestsegmentpos, v = halfaxis[k] * travel;
+      if (v > 0 && p0 + v > bsize[k]) frac = fmin(frac, (bsize[k] - p0) / v);
+      if (v < 0 && p0 + v < -bsize[k]) frac = fmin(frac, (-bsize[k] - p0) / v);
+    }
+    secondpos = travel * fmax(frac, 0.0);
+  }
+  /* the contacts: spheres on the segment against the box */
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1 && !(secondpos > -3.0 && fabs(secondpos) > 1e-12)) break;
+    const double t = bestsegmentpos + (pass ? secondpos : 0.0);
+    double ctr[3], dist, cp[3], nrm[3];
+    for (int k = 0; k < 3; k++) ctr[k] = cpos[k] + caxis[k] * hl * t;
+    if (sphere_box(ctr, r, bpos, bmat, bsize, pp->margin, &dist, cp, nrm)) add_contact(d, pp, dist, cp, nrm, NULL);
+  }
 }
 
-/* Two axis-aligned boxes (movable XY blocks never rotate; maze walls are grid-aligned).  [ASSUME-12] MuJoCo's
- * mjc_BoxBox is not reproduced: the contact normal is the axis of largest gap (first axis on ties), the contact
- * points are the distinct corners of the overlap rectangle of the two facing faces, placed midway between them.
- * Normal points from box 1 to box 2. */
-static void box_box_aligned(mzo_data* d, const pairparam* pp, const double* c1, const double* h1, const double* c2,
-                            const double* h2) {
-  double gap[3];
-  int ax = 0;
-  for (int k = 0; k < 3; k++) { gap[k] = fabs(c2[k] - c1[k]) - (h1[k] + h2[k]); if (gap[k] > gap[ax]) ax = k; }
-  if (gap[ax] > pp->margin) return;
-  double dist = gap[ax], sg = c2[ax] >= c1[ax] ? 1.0 : -1.0;
-  int u = (ax + 1) % 3, v = (ax + 2) % 3;
-  double lo[3], hi[3];
+/* box (geom1) vs box (geom2): restatement of MuJoCo's mjc_BoxBox (engine_collision_box.c), face case.
+ *
+ * Followed: separating-axis search over the 15 axes in MuJoCo's order — per axis index i the face normal of box 1, then
+ * that of box 2, a later axis winning only when its penetration is strictly smaller; then the 9 edge-edge axes, which win
+ * only when clearly smaller (MuJoCo biases the comparison towards the face axes); any axis with penetration < -margin separates the pair (no contact).  For
+ * a face axis the reference face is the winning face, the incident face is the face of the other box most anti-parallel
+ * to it, and the contact candidates are the vertices of the intersection of the incident rectangle (projected along the
+ * normal) with the reference rectangle: incident corners inside the reference rectangle, crossings of incident edges
+ * with the reference rectangle's border lines, reference corners inside the incident rectangle (taken on the incident
+ * plane).  Each candidate carries its own distance to the reference face; candidates beyond the margin are dropped; a
+ * contact sits midway between the candidate and the reference face; the normal is the reference normal oriented from
+ * geom1 to geom2; at most 8 contacts.
+ * Reconstructed: all inside / crossing tests are inclusive (faces that share a border line — grid-aligned boxes — do
+ * collide along it), and a candidate that coincides with an earlier one is emitted once (MuJoCo's enumeration can list such
+ * a vertex twice).  The edge-edge case (no registered maze can reach it: every box here is rotated about z only, where
+ * each edge-edge axis coincides with a face axis and loses the tie) yields one contact midway between the closest points of
+ * the two edges. */
+static void box_box(mzo_data* d, const pairparam* pp, const double* pos1, const double* mat1, const double* size1,
+                    const double* pos2, const double* mat2, const double* size2) {
+  double rot[9], rotabs[9], pos21[3], pos12[3], tmp[3], plen1[3], plen2[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {  /* rot[i][j] = axis i of box 1 . axis j of box 2 */
+      rot[3 * i + j] = mat1[i] * mat2[j] + mat1[3 + i] * mat2[3 + j] + mat1[6 + i] * mat2[6 + j];
+      rotabs[3 * i + j] = fabs(rot[3 * i + j]);
+    }
+  sub3(tmp, pos2, pos1); mulmat3Tvec(pos21, mat1, tmp);
+  sub3(tmp, pos1, pos2); mulmat3Tvec(pos12, mat2, tmp);
+  for (int i = 0; i < 3; i++) {
+    plen2[i] = rotabs[3 * i] * size2[0] + rotabs[3 * i + 1] * size2[1] + rotabs[3 * i + 2] * size2[2];
+    plen1[i] = rotabs[i] * size1[0] + rotabs[3 + i] * size1[1] + rotabs[6 + i] * size1[2];
+  }
+  const double margin = pp->margin;
+  double penetration = margin;
+  for (int i = 0; i < 3; i++) penetration += 3.0 * (size1[i] + size2[i]);
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    const double c1 = -fabs(pos21[i]) + size1[i] + plen2[i], c2 = -fabs(pos12[i]) + size2[i] + plen1[i];
+    if (c1 < -margin || c2 < -margin) return;
+    if (c1 < penetration) { penetration = c1; code = i + 3 * (pos21[i] < 0) ; }
+    if (c2 < penetration) { penetration = c2; code = 6 + i + 3 * (pos12[i] < 0); }
+  }
+  double en[3] = {0, 0, 0};  /* edge-edge axis (frame of box 1, pointing from box 1 to box 2) */
+  int ei = -1, ej = -1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double ei3[3] = {i == 0, i == 1, i == 2}, aj[3] = {rot[j], rot[3 + j], rot[6 + j]};
+      double cr[3];
+      cross3(cr, ei3, aj);
+      const double len = norm3(cr);
+      if (len < 1e-10) continue;
+      for (int k = 0; k < 3; k++) cr[k] /= len;
+      double r1 = 0, r2 = 0;
+      for (int k = 0; k < 3; k++) {
+        r1 += size1[k] * fabs(cr[k]);
+        r2 += size2[k] * fabs(cr[0] * rot[k] + cr[1] * rot[3 + k] + cr[2] * rot[6 + k]);
+      }
+      const double sep = dot3(pos21, cr), c3 = r1 + r2 - fabs(sep);
+      if (c3 < -margin) return;
+      /* wins only when clearly better than the best face axis (whatever the sign of the penetration): an edge-edge axis
+       * that coincides with a face axis (parallel boxes, rotation about one axis) must lose the tie, round-off included */
+      if (c3 < penetration - 1e-10 * (fabs(penetration) + r1 + r2)) {
+        penetration = c3; code = 12 + 3 * i + j; ei = i; ej = j;
+        for (int k = 0; k < 3; k++) en[k] = sep >= 0 ? cr[k] : -cr[k];
+      }
+    }
+  if (code < 0) return;
+  if (code >= 12) {
+    /* edge-edge: the edge of box 1 along axis ei that is farthest along en, the edge of box 2 along axis ej farthest against it */
+    double p1[3], p2[3], d1[3] = {ei == 0, ei == 1, ei == 2}, d2[3] = {rot[ej], rot[3 + ej], rot[6 + ej]};
+    for (int k = 0; k < 3; k++) p1[k] = k == ei ? 0.0 : (en[k] >= 0 ? size1[k] : -size1[k]);
+    cpy3(p2, pos21);
+    for (int k = 0; k < 3; k++) {
+      if (k == ej) continue;
+      const double ak[3] = {rot[k], rot[3 + k], rot[6 + k]};
+      addscl3(p2, ak, dot3(ak, en) >= 0 ? -size2[k] : size2[k]);
+    }
+    /* closest points of the two lines p1 + s d1, p2 + t d2 */
+    double w[3]; sub3(w, p1, p2);
+    const double b = dot3(d1, d2), dd = dot3(d1, w), e = dot3(d2, w), den = 1.0 - b * b;
+    const double sc = den > 1e-12 ? (b * e - dd) / den : 0.0, tc = den > 1e-12 ? (e - b * dd) / den : 0.0;
+    double q1[3], q2[3], mid[3], nw[3], pw[3];
+    for (int k = 0; k < 3; k++) { q1[k] = p1[k] + sc * d1[k]; q2[k] = p2[k] + tc * d2[k]; mid[k] = 0.5 * (q1[k] + q2[k]); }
+    mulmat3vec(nw, mat1, en); mulmat3vec(pw, mat1, mid); add3(pw, pw, pos1);
+    add_contact(d, pp, -penetration, pw, nw, NULL);
+    return;
+  }
+  /* face case, worked in the frame of the reference box A */
+  const int fromB = code >= 6, a = code % 3;
+  const double* posA = fromB ? pos2 : pos1; const double* matA = fromB ? mat2 : mat1;
+  const double* sA = fromB ? size2 : size1; const double* sB = fromB ? size1 : size2;
+  const double* pBA = fromB ? pos12 : pos21;
+  double R[9];  /* R[k][j] = axis k of A . axis j of B */
+  for (int k = 0; k < 3; k++) for (int j = 0; j < 3; j++) R[3 * k + j] = fromB ? rot[3 * j + k] : rot[3 * k + j];
+  const double sg = pBA[a] < 0 ? -1.0 : 1.0;  /* the reference normal sg * e_a points from A to B */
+  int b = 0;
+  for (int j = 1; j < 3; j++) if (fabs(R[3 * a + j]) > fabs(R[3 * a + b])) b = j;
+  const double sb = R[3 * a + b] * sg > 0 ? -1.0 : 1.0;  /* incident face: the one of B whose outward normal opposes the reference normal */
+  const int b1 = (b + 1) % 3, b2 = (b + 2) % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+  double cf[3], u[3], v[3];
   for (int k = 0; k < 3; k++) {
-    lo[k] = fmax(c1[k] - h1[k], c2[k] - h2[k]);
-    hi[k] = fmin(c1[k] + h1[k], c2[k] + h2[k]);
+    cf[k] = pBA[k] + sb * sB[b] * R[3 * k + b];
+    u[k] = sB[b1] * R[3 * k + b1];
+    v[k] = sB[b2] * R[3 * k + b2];
   }
-  /* faces must overlap by a positive area: boxes that only share an edge or a corner (a block at its spawn
-   * position against the diagonal wall cells) make no contact, so that the grid-aligned rest state is not a tie */
-  if (!(hi[u] - lo[u] > 1e-6) || !(hi[v] - lo[v] > 1e-6)) return;
-  double nrm[3] = {0, 0, 0};
-  nrm[ax] = sg;
-  const int nu = 2, nvv = 2;
-  for (int iu = 0; iu < nu; iu++)
-    for (int iv = 0; iv < nvv; iv++) {
-      double pos[3];
-      pos[ax] = c1[ax] + sg * (h1[ax] + 0.5 * dist);
-      pos[u] = iu ? hi[u] : lo[u];
-      pos[v] = iv ? hi[v] : lo[v];
-      add_contact(d, pp, dist, pos, nrm, NULL);
-    }
-}
-
-/* Box rotated about the vertical axis (the Point's arrow, point.xml:22) against a grid-aligned wall box.
- * [ASSUME-13] MuJoCo's mjc_BoxBox is not reproduced.  Both boxes overlap in z, so this is a 2-D
- * rectangle-rectangle test: separating-axis search over the four face normals (wall x, wall y, arrow x, arrow y;
- * first axis on ties), distance = largest separation, contact points = the deepest vertex / vertices of the
- * incident rectangle (within 1e-9 of the minimum), placed midway between the surfaces at the arrow's height.
- * geom1 = wall (world geoms precede the robot's), geom2 = arrow: normal from the wall to the arrow.
- * The same rule serves the arrow against a movable block (an axis-aligned box that comes AFTER the arrow in the
- * geom order): `flip` = 1 reports the normal from the rotated box to the aligned one. */
-static void box_zrot_vs_aabb(mzo_data* d, const pairparam* pp, const double* wc, const double* wh, const double* bc,
-                             const double* bmat, const double* bh, int flip) {
-  if (fabs(bc[2] - wc[2]) > bh[2] + wh[2] + pp->margin) return;
-  double ex[2] = {bmat[0], bmat[3]}, ey[2] = {bmat[1], bmat[4]};
-  double dx = bc[0] - wc[0], dy = bc[1] - wc[1];
-  double axes[4][2] = {{1, 0}, {0, 1}, {ex[0], ex[1]}, {ey[0], ey[1]}};
-  int best = -1;
-  double bestsep = -1e30, bestsign = 1;
-  for (int a = 0; a < 4; a++) {
-    double nx = axes[a][0], ny = axes[a][1];
-    double proj = dx * nx + dy * ny;
-    double ra = wh[0] * fabs(nx) + wh[1] * fabs(ny);
-    double rb = bh[0] * fabs(ex[0] * nx + ex[1] * ny) + bh[1] * fabs(ey[0] * nx + ey[1] * ny);
-    double sep = fabs(proj) - (ra + rb);
-    if (sep > bestsep) { bestsep = sep; best = a; bestsign = proj >= 0 ? 1.0 : -1.0; }
+  double cand[24][3];  /* 4 incident corners + 4 edges x 2 border lines x 2 sides... at most 4 + 16 + 4 */
+  int nc = 0;
+  const double tol = 1e-12 * (1.0 + sA[a1] + sA[a2]);
+  /* incident corners inside the reference rectangle */
+  for (int c = 0; c < 4; c++) {
+    const double su = (c & 1) ? 1.0 : -1.0, sv = (c & 2) ? 1.0 : -1.0;
+    double p[3];
+    for (int k = 0; k < 3; k++) p[k] = cf[k] + su * u[k] + sv * v[k];
+    if (fabs(p[a1]) <= sA[a1] + tol && fabs(p[a2]) <= sA[a2] + tol) { cpy3(cand[nc], p); nc++; }
   }
-  if (bestsep > pp->margin) return;
-  double n[3] = {axes[best][0] * bestsign, axes[best][1] * bestsign, 0.0}; /* wall -> arrow */
-  double vx[4], vy[4], depth[4], dmin = 1e30;
-  if (best < 2) { /* reference face on the wall: incident vertices are the arrow's corners */
-    for (int k = 0; k < 4; k++) {
-      double sx = (k & 1) ? 1.0 : -1.0, sy = (k & 2) ? 1.0 : -1.0;
-      vx[k] = bc[0] + sx * bh[0] * ex[0] + sy * bh[1] * ey[0];
-      vy[k] = bc[1] + sx * bh[0] * ex[1] + sy * bh[1] * ey[1];
-      depth[k] = (vx[k] - wc[0]) * n[0] + (vy[k] - wc[1]) * n[1] - (wh[0] * fabs(n[0]) + wh[1] * fabs(n[1]));
-      if (depth[k] < dmin) dmin = depth[k];
+  /* incident edges against the border lines of the reference rectangle */
+  for (int e = 0; e < 4; e++) {
+    double p[3], q[3];  /* edge = p + t q, t in [-1, 1] */
+    for (int k = 0; k < 3; k++) {
+      if (e < 2) { p[k] = cf[k] + (e ? v[k] : -v[k]); q[k] = u[k]; }
+      else { p[k] = cf[k] + (e == 3 ? u[k] : -u[k]); q[k] = v[k]; }
     }
-    for (int k = 0; k < 4; k++)
-      if (depth[k] <= dmin + 1e-9) {
-        double pos[3] = {vx[k] - n[0] * 0.5 * depth[k], vy[k] - n[1] * 0.5 * depth[k], bc[2]};
-        double nn[3] = {flip ? -n[0] : n[0], flip ? -n[1] : n[1], 0.0};
-        add_contact(d, pp, depth[k], pos, nn, NULL);
+    for (int w = 0; w < 2; w++) {
+      const int c = w ? a2 : a1, o = w ? a1 : a2;
+      if (fabs(q[c]) < MINVAL) continue;
+      for (int side = -1; side <= 1; side += 2) {
+        const double t = (side * sA[c] - p[c]) / q[c];
+        if (t < -1.0 || t > 1.0) continue;
+        if (fabs(p[o] + t * q[o]) > sA[o] + tol) continue;
+        for (int k = 0; k < 3; k++) cand[nc][k] = p[k] + t * q[k];
+        nc++;
       }
-  } else { /* reference face on the arrow: incident vertices are the wall's corners */
-    double href = best == 2 ? bh[0] : bh[1];
-    for (int k = 0; k < 4; k++) {
-      vx[k] = wc[0] + ((k & 1) ? wh[0] : -wh[0]);
-      vy[k] = wc[1] + ((k & 2) ? wh[1] : -wh[1]);
-      depth[k] = (bc[0] - vx[k]) * n[0] + (bc[1] - vy[k]) * n[1] - href;
-      if (depth[k] < dmin) dmin = depth[k];
     }
-    for (int k = 0; k < 4; k++)
-      if (depth[k] <= dmin + 1e-9) {
-        double pos[3] = {vx[k] + n[0] * 0.5 * depth[k], vy[k] + n[1] * 0.5 * depth[k], bc[2]};
-        double nn[3] = {flip ? -n[0] : n[0], flip ? -n[1] : n[1], 0.0};
-        add_contact(d, pp, depth[k], pos, nn, NULL);
+  }
+  /* reference corners inside the incident rectangle, on the incident plane */
+  {
+    const double det = u[a1] * v[a2] - u[a2] * v[a1];
+    if (fabs(det) > MINVAL)
+      for (int c = 0; c < 4; c++) {
+        const double x = ((c & 1) ? sA[a1] : -sA[a1]) - cf[a1], y = ((c & 2) ? sA[a2] : -sA[a2]) - cf[a2];
+        const double al = (x * v[a2] - y * v[a1]) / det, be = (u[a1] * y - u[a2] * x) / det;
+        if (fabs(al) <= 1.0 + 1e-12 && fabs(be) <= 1.0 + 1e-12) {
+          for (int k = 0; k < 3; k++) cand[nc][k] = cf[k] + al * u[k] + be * v[k];
+          nc++;
+        }
       }
   }
-}
-
-static int is_block_geom(const mz_model* m, int g) {
-  for (int k = 0; k < m->nblock; k++)
-    if (m->block_geomid[k] == g) return 1;
-  return 0;
-}
-
-static int is_axis_aligned(const double* mat) {
-  return fabs(mat[0] - 1.0) < 1e-12 && fabs(mat[4] - 1.0) < 1e-12 && fabs(mat[8] - 1.0) < 1e-12;
+  int emitted = 0;
+  const double dtol = 1e-9 * (1.0 + sA[a1] + sA[a2]);  /* candidates closer than this (max norm) are one vertex */
+  for (int c = 0; c < nc && emitted < 8; c++) {
+    int dup = 0;
+    for (int e = 0; e < c && !dup; e++)
+      if (fabs(cand[c][0] - cand[e][0]) <= dtol && fabs(cand[c][1] - cand[e][1]) <= dtol && fabs(cand[c][2] - cand[e][2]) <= dtol) dup = 1;
+    if (dup) continue;
+    const double dist = sg * cand[c][a] - sA[a];
+    if (dist > margin) continue;
+    double pl[3], pw[3], nl[3] = {0, 0, 0}, nw[3];
+    cpy3(pl, cand[c]);
+    pl[a] -= sg * 0.5 * dist;
+    nl[a] = fromB ? -sg : sg;  /* reported from geom1 to geom2 */
+    mulmat3vec(pw, matA, pl); add3(pw, pw, posA);
+    mulmat3vec(nw, matA, nl);
+    add_contact(d, pp, dist, pw, nw, NULL);
+    emitted++;
+  }
 }
 
 static void mix_params(pairparam* pp, double m1, double m2, double g1, double g2, const double* f1, const double* f2,
@@ -678,19 +814,24 @@ static void collide_plane(const mz_model* m, mzo_data* d, int gp, int g) {
       add_contact(d, &pp, dist, pos, n, axis);
     }
   } else if (m->geom_type[g] == MZ_GEOM_BOX) {
-    /* plane-box: corners below the margin (up to 4 deepest in MuJoCo; all 8 candidates tested here) */
+    /* plane-box (mjc_PlaneBox): the corners in index order (bit 0 x, bit 1 y, bit 2 z); a corner is skipped when it lies
+     * beyond the margin or on the far side of the box centre (its offset along the plane normal is positive); at most 4 */
     const double* bm = d->geom_xmat[g];
     const double* sz = m->geom_size[g];
-    for (int cidx = 0; cidx < 8; cidx++) {
+    sub3(rel, d->geom_xpos[g], d->geom_xpos[gp]);
+    const double cdist = dot3(rel, n);
+    int cnt = 0;
+    for (int cidx = 0; cidx < 8 && cnt < 4; cidx++) {
       double loc[3] = {(cidx & 1 ? 1 : -1) * sz[0], (cidx & 2 ? 1 : -1) * sz[1], (cidx & 4 ? 1 : -1) * sz[2]}, w[3], e[3];
       mulmat3vec(w, bm, loc);
+      const double ldist = dot3(n, w);
+      if (cdist + ldist > pp.margin || ldist > 0) continue;
+      const double dist = cdist + ldist;
       add3(e, d->geom_xpos[g], w);
-      sub3(rel, e, d->geom_xpos[gp]);
-      double dist = dot3(rel, n);
-      if (dist > pp.margin) continue;
       double pos[3];
       for (int k = 0; k < 3; k++) pos[k] = e[k] - n[k] * (0.5 * dist);
       add_contact(d, &pp, dist, pos, n, NULL);
+      cnt++;
     }
   }
 }
@@ -726,15 +867,11 @@ static void collide_walls(const mz_model* m, mzo_data* d, int g) {
             add_contact(d, &pp, dist, pos, nrm, NULL);
         } else if (m->geom_type[g] == MZ_GEOM_CAPSULE) {
           capsule_box(d, &pp, gp, d->geom_xmat[g], m->geom_size[g][0], m->geom_size[g][1], bpos, ident, bsize);
-        } else if (m->geom_type[g] == MZ_GEOM_BOX && is_block_geom(m, g) && is_axis_aligned(d->geom_xmat[g])) {
-          /* wall geoms precede the movable bodies' geoms in MuJoCo's geom order: geom1 = wall, geom2 = block */
+        } else if (m->geom_type[g] == MZ_GEOM_BOX) {
+          /* wall geoms precede the robot's and the movable bodies' geoms in MuJoCo's geom order: geom1 = wall, geom2 = box */
           pairparam q = pp;
           q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
-          box_box_aligned(d, &q, bpos, bsize, gp, m->geom_size[g]);
-        } else if (m->geom_type[g] == MZ_GEOM_BOX && fabs(d->geom_xmat[g][8] - 1.0) < 1e-12) {
-          pairparam q = pp; /* box rotated about z only (the Point's arrow) */
-          q.b1 = 0; q.b2 = m->geom_bodyid[g]; q.g1 = -1; q.g2 = g;
-          box_zrot_vs_aabb(d, &q, bpos, bsize, gp, d->geom_xmat[g], m->geom_size[g], 0);
+          box_box(d, &q, bpos, ident, bsize, gp, d->geom_xmat[g], m->geom_size[g]);
         } else {
           d->status |= MZO_STATUS_UNSUPPORTED_PAIR; /* generally rotated box vs box: not restated */
         }
@@ -784,11 +921,8 @@ static void collide_pair(const mz_model* m, mzo_data* d, int ga, int gb) {
   } else if (t2 == MZ_GEOM_BOX && t1 == MZ_GEOM_CAPSULE) {
     capsule_box(d, &pp, d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1][0], m->geom_size[g1][1], d->geom_xpos[g2],
                 d->geom_xmat[g2], m->geom_size[g2]);
-  } else if (t1 == MZ_GEOM_BOX && t2 == MZ_GEOM_BOX && is_axis_aligned(d->geom_xmat[g1]) && is_axis_aligned(d->geom_xmat[g2])) {
-    box_box_aligned(d, &pp, d->geom_xpos[g1], m->geom_size[g1], d->geom_xpos[g2], m->geom_size[g2]);
-  } else if (t1 == MZ_GEOM_BOX && t2 == MZ_GEOM_BOX && is_axis_aligned(d->geom_xmat[g2]) && fabs(d->geom_xmat[g1][8] - 1.0) < 1e-12) {
-    /* the Point's arrow (rotated about z, geom1) against a movable block (aligned, geom2) [ASSUME-13] */
-    box_zrot_vs_aabb(d, &pp, d->geom_xpos[g2], m->geom_size[g2], d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], 1);
+  } else if (t1 == MZ_GEOM_BOX && t2 == MZ_GEOM_BOX) {  /* same type: geom1 = the lower geom id (the Point's arrow before a movable block) */
+    box_box(d, &pp, d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2]);
   } else {
     d->status |= MZO_STATUS_UNSUPPORTED_PAIR;
   }
@@ -809,6 +943,32 @@ static void collision(const mz_model* m, mzo_data* d) {
     }
   for (int g = 1; g < m->ngeom; g++)
     if (m->geom_bodyid[g] != 0) collide_walls(m, d, g);
+}
+
+/* Narrow-phase probes (tests/test_narrowphase_probes.py, tests/test_mujoco_crosscheck.py): one routine on one hand-made pose.
+ * kind 0 capsule (geom1: pos, mat, size = radius, half length) vs box (geom2); 1 box vs box; 2 sphere (size[0]) vs box.
+ * out: per contact 7 doubles dist | pos | normal (geom1 -> geom2); returns the contact count. */
+int mzo_probe_pair(int kind, const double* pos1, const double* mat1, const double* size1, const double* pos2, const double* mat2,
+                   const double* size2, double margin, int max_con, double* out) {
+  static const double sr[2] = {0.02, 1.0}, si[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+  mzo_data* d = (mzo_data*)calloc(1, sizeof(mzo_data));
+  pairparam pp;
+  memset(&pp, 0, sizeof(pp));
+  pp.margin = margin; pp.mu = 1.0; pp.condim = 3;
+  memcpy(pp.solref, sr, sizeof(sr)); memcpy(pp.solimp, si, sizeof(si));
+  if (kind == 0) capsule_box(d, &pp, pos1, mat1, size1[0], size1[1], pos2, mat2, size2);
+  else if (kind == 1) box_box(d, &pp, pos1, mat1, size1, pos2, mat2, size2);
+  else {
+    double dist, cp[3], nrm[3];
+    if (sphere_box(pos1, size1[0], pos2, mat2, size2, margin, &dist, cp, nrm)) add_contact(d, &pp, dist, cp, nrm, NULL);
+  }
+  const int n = d->ncon;
+  for (int c = 0; c < n && c < max_con; c++) {
+    out[7 * c] = d->con[c].dist;
+    for (int k = 0; k < 3; k++) { out[7 * c + 1 + k] = d->con[c].pos[k]; out[7 * c + 4 + k] = d->con[c].frame[k]; }
+  }
+  free(d);
+  return n;
 }
 
 /* ------------------------------------------------------------------ constraints */

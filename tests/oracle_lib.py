@@ -50,6 +50,24 @@ class Oracle:
         keys = ["ncon", "nefc", "iters", "kkt", "fsum", "fmin", "comp", "status"]
         return dict(zip(keys, rep)), qacc
 
+    def probe_pair(self, kind, pos1, mat1, size1, pos2, mat2, size2, margin):
+        """One narrow-phase routine on one pose ('capsule_box' | 'box_box' | 'sphere_box'): array [ncon, 7] = dist | pos | normal."""
+        k = {"capsule_box": 0, "box_box": 1, "sphere_box": 2}[kind]
+        a = [np.ascontiguousarray(x, np.float64).ravel() for x in (pos1, mat1, size1, pos2, mat2, size2)]
+        a[2] = np.resize(a[2], 3) if a[2].size < 3 else a[2]
+        out = np.zeros((16, 7))
+        self.lib.mzo_probe_pair.restype = C.c_int
+        n = self.lib.mzo_probe_pair(C.c_int(k), *[x.ctypes.data_as(C.c_void_p) for x in a], C.c_double(margin), C.c_int(16), out.ctypes.data_as(C.c_void_p))
+        return out[:n]
+
+    def contacts(self, cm, qpos):
+        """Contact set at one configuration: array [ncon, 10] = dist | pos | normal (geom1 -> geom2) | geom1 | geom2 | active."""
+        qp = np.ascontiguousarray(qpos, np.float64)
+        out = np.zeros((96, 10))
+        self.lib.mzo_contacts.restype = C.c_int
+        n = self.lib.mzo_contacts(C.byref(cm.c), qp.ctypes.data_as(C.c_void_p), 96, out.ctypes.data_as(C.c_void_p))
+        return out[:n]
+
     def raw_steps(self, cm, qpos, qvel, ctrl, nsteps, energy=True):
         m = cm.c
         qp, qv = np.array(qpos, np.float64), np.array(qvel, np.float64)

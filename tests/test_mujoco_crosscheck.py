@@ -90,15 +90,46 @@ def test_forward_dynamics_stage_by_stage(env_id, oracle):
             np.testing.assert_allclose(ref["bias"][0], data.qfrc_bias, rtol=1e-8, atol=1e-10, err_msg="bias forces (RNE)")
             assert ref["counts"][0, 0] == data.ncon, f"contact count: oracle {ref['counts'][0, 0]} vs MuJoCo {data.ncon} [ASSUME-5/6/7/12/13]"
             assert ref["counts"][0, 1] == data.nefc, f"constraint rows: oracle {ref['counts'][0, 1]} vs MuJoCo {data.nefc} [ASSUME-7]"
-            ncon = oracle.lib.mzo_list_contacts
-            buf = np.zeros((96, 9))
-            k = ncon(__import__("ctypes").byref(m), np.ascontiguousarray(st["qpos"][e]).ctypes.data_as(__import__("ctypes").c_void_p),
-                     np.ascontiguousarray(st["qvel"][e]).ctypes.data_as(__import__("ctypes").c_void_p),
-                     buf.ctypes.data_as(__import__("ctypes").c_void_p), 96)
-            mine = sorted((round(float(buf[c, 2]), 9), tuple(np.round(buf[c, 3:6], 7))) for c in range(k))
+            cons = oracle.contacts(cm, st["qpos"][e])
+            mine = sorted((round(float(c[0]), 9), tuple(np.round(c[1:4], 7))) for c in cons)
             theirs = sorted((round(float(data.contact[c].dist), 9), tuple(np.round(data.contact[c].pos, 7))) for c in range(data.ncon))
             assert mine == theirs, "contact distances / positions [ASSUME-5 capsule-plane, 6 capsule-box, 12 box-box, 13 rotated box]"
             np.testing.assert_allclose(ref["qacc"][0], data.qacc, rtol=1e-6, atol=1e-7, err_msg="qacc of mj_forward [ASSUME-2/3/4 rows, 11 solver]")
+
+
+def _probe_geom_xml(name, kind_is_capsule, g):
+    pos, mat, size = g
+    q = np.zeros(4)
+    mujoco.mju_mat2Quat(q, np.asarray(mat, float).ravel())
+    if kind_is_capsule:
+        return f'<geom name="{name}" type="capsule" size="{size[0]} {size[1]}" pos="{pos[0]} {pos[1]} {pos[2]}" quat="{q[0]} {q[1]} {q[2]} {q[3]}"/>'
+    return f'<geom name="{name}" type="box" size="{size[0]} {size[1]} {size[2]}" pos="{pos[0]} {pos[1]} {pos[2]}" quat="{q[0]} {q[1]} {q[2]} {q[3]}"/>'
+
+
+def test_narrowphase_probes_against_mujoco():
+    """Per-routine verdict on the restated narrow phase: the hand-derived contact sets of tests/narrowphase_probes.py (which the
+    oracle reproduces exactly, tests/test_narrowphase_probes.py) against mjc_CapsuleBox / mjc_BoxBox themselves.  Each probe is
+    a two-geom model: geom1 on a free body, geom2 in the world (both static for mj_forward's collision stage)."""
+    from tests import narrowphase_probes as NP
+
+    verdict = {}
+    for name, kind, g1, g2, margin, want in NP.probes():
+        xml = f"""<mujoco><option gravity="0 0 0"/><default><geom margin="{margin}" contype="1" conaffinity="1"/></default><worldbody>
+          <body name="a">{_probe_geom_xml("g1", kind == "capsule_box", g1)}<freejoint/></body>
+          {_probe_geom_xml("g2", False, g2)}</worldbody></mujoco>"""
+        model = mujoco.MjModel.from_xml_string(xml)
+        data = mujoco.MjData(model)
+        mujoco.mj_forward(model, data)
+        got = []
+        for c in range(data.ncon):
+            con = data.contact[c]
+            n = np.array(con.frame[:3])
+            if con.geom1 != mujoco.mj_name2id(model, mujoco.mjtObj.mjOBJ_GEOM, "g1"):
+                n = -n
+            got.append([con.dist, *con.pos, *n])
+        verdict[name] = NP.same_contact_set(got, want, tol=1e-7)
+    bad = [k for k, v in verdict.items() if not v]
+    assert not bad, "restatement differs from MuJoCo on: " + "; ".join(bad)
 
 
 @pytest.mark.parametrize("env_id", ENVS)

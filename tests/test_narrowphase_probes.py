@@ -1,0 +1,48 @@
+"""The oracle's restatements of MuJoCo's narrow phase (mjc_CapsuleBox, mjc_BoxBox) on hand-made poses whose contact sets are
+derived by hand in tests/narrowphase_probes.py — contact count, positions, normals, distances per routine.
+The kernels are compared with the oracle elsewhere (tests/test_capi_and_emu.py on the CPU emulation, tests/test_gpu_parity.py on
+the device); real MuJoCo, where installed, is compared with the same probes in tests/test_mujoco_crosscheck.py."""
+import numpy as np
+import pytest
+
+from tests import narrowphase_probes as NP
+
+
+@pytest.mark.parametrize("probe", NP.probes(), ids=lambda p: p[0][:60])
+def test_probe_contact_set(oracle, probe):
+    name, kind, g1, g2, margin, want = probe
+    got = oracle.probe_pair(kind, *g1, *g2, margin)
+    assert NP.same_contact_set(got, want), f"{name}\n got:\n{np.round(got, 6)}\n want:\n{np.round(np.asarray(want, float), 6)}"
+
+
+def test_probe_sets_are_rotation_invariant(oracle):
+    """The routines work in the box frame: turning the whole scene turns the contacts with it (no hidden axis-aligned shortcut)."""
+    Q = NP._z_to([0.3, -0.5, 0.8]) @ NP.rotz(0.7)
+    off = np.array([3.0, -2.0, 1.5])
+    for name, kind, g1, g2, margin, want in NP.probes():
+        if not want or "sharing only an edge" in name:  # (an exact tie between two face axes: round-off decides it once turned)
+            continue
+        a = (Q @ np.asarray(g1[0], float) + off, Q @ np.asarray(g1[1], float), g1[2])
+        b = (Q @ np.asarray(g2[0], float) + off, Q @ np.asarray(g2[1], float), g2[2])
+        got = oracle.probe_pair(kind, *a, *b, margin)
+        w = np.asarray(want, float)
+        turned = np.concatenate([w[:, :1], w[:, 1:4] @ Q.T + off, w[:, 4:7] @ Q.T], axis=1)
+        assert NP.same_contact_set(got, turned, tol=1e-8), name
+
+
+def test_plane_box_corner_rule(oracle):
+    """mjc_PlaneBox through the model path: a block resting on the floor gives its four bottom corners (dist = height of the
+    bottom face, position midway); corners above the box centre never count."""
+    from mujoco_maze_amd import maze_task as T
+    from mujoco_maze_amd import model
+
+    cm = model.compile_model("ant", T.DistRewardPush(8.0), 8.0)
+    q = np.array(cm.c.qpos0[: cm.c.nq])
+    q[2] = 30.0  # the ant far above
+    c = oracle.contacts(cm, q)
+    floor = c[(c[:, 7] == 0) & (c[:, 8] == 14)]
+    assert len(floor) == 4 and np.allclose(floor[:, 0], 0.0) and np.allclose(floor[:, 4:7], [0, 0, 1])
+    assert sorted(map(tuple, np.round(floor[:, 1:3], 9))) == sorted((x, y) for x in (-4.0, 4.0) for y in (4.0, 12.0))
+    # the three wall cells diagonal to the block's spawn cell share a vertical border line with it: two contacts each at dist 0
+    walls = c[(c[:, 7] == -1) & (c[:, 8] == 14)]
+    assert len(walls) == 6 and np.allclose(walls[:, 0], 0.0) and np.all(np.abs(walls[:, 4]) == 1.0)
