@@ -123,11 +123,12 @@ struct alignas(16) AntScratchT {
   alignas(16) Arrow<D::NH> M, H;
   // plain ant: M once more as dense rows (16 floats apart, zeros preset per step): lane r of the row solver reads its row with
   // four wide loads instead of 22 scattered ones and a select chain
-  alignas(16) float Md[NB == 0 ? 16 : 1][16];
+  alignas(16) float Md[NB <= 1 ? 16 : 1][16];  // (one movable block: dofs 14, 15 = its slides — still one 16-lane row)
   ArrowFactor<D::NH> F;
   float grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
   // contacts
   int ncon, cnt[D::NGEOM], cbeg[5];  // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); hub-only contacts [0, cbeg[0])
+  int nblkcon;                       // the first nblkcon slots hold the contacts of the movable bodies' own enumerators (no robot geom involved)
   int cleg[D::NC], ccls[D::NC];      // leg (-1 none) and robot body class (-1 none) of the contact
   int csrc[D::NC], con_over;         // single-pass enumeration (plain ant): staging entry of the contact (-1: geometry in cY[c]); a geom overflowed its staging
   alignas(16) float cJ[D::NC][3][D::NCOL];  // [normal, mu*t1, mu*t2] x [hub, hip, ankle]
@@ -370,7 +371,7 @@ MZ_HD void crb_leg_item(const AntDev& K, AntScratchT<NB>& s, int l) {
       s.M.rl[l][0][3 + k] = dot3f(ax, Fh);
       s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
     }
-    if constexpr (NB == 0) {  // dense rows of the two leg dofs, and their columns in the root rows
+    if constexpr (NB <= 1) {  // dense rows of the two leg dofs, and their columns in the root rows
       const int ph = 6 + 2 * l, pa = 7 + 2 * l;
       s.Md[ph][ph] = s.M.ll[l][0]; s.Md[ph][pa] = s.M.ll[l][1]; s.Md[pa][ph] = s.M.ll[l][1]; s.Md[pa][pa] = s.M.ll[l][2];
       for (int k = 0; k < 6; k++) {
@@ -438,7 +439,7 @@ MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       }
     }
     s.M.rr[i][j] = val; s.M.rr[j][i] = val;
-    if constexpr (NB == 0) { s.Md[i][j] = val; s.Md[j][i] = val; }
+    if constexpr (NB <= 1) { s.Md[i][j] = val; s.Md[j][i] = val; }
 }
 
 // Recursive Newton-Euler, outward half, one body per lane: body b = 0 torso, 1 + 3l + k (k = 0 welded leg, 1 aux, 2 ankle).
@@ -876,9 +877,10 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
 // ties — a block at its spawn position shares border lines with the diagonal wall cells, its z extent equals the walls' —
 // which fp32 torso-relative coordinates would decide at random).  Separating axis = the face axis of least penetration
 // (first of x, y, z on ties; an edge-edge axis never wins between parallel boxes), dist = -penetration; contact points = the
-// corners of the intersection of the two facing faces, which may have collapsed to a segment or a point (inclusive tests:
-// boxes that share only a border line do touch), a collapsed direction giving one position instead of two.
+// corners of the intersection of the two facing faces (inclusive border tests); an intersection without area — boxes that share
+// only a border line: a block at its spawn position and the diagonal wall cells — makes no contact [ASSUME-12].
 // Box 1 = geom1: the normal points from box 1 to box 2.
+#define MZ_BOX_MINOVERLAP 1e-6
 struct AlignedBB { int ax, nu, nv; double dist, sg, pa, pu[2], pv[2]; };
 MZ_HD bool aligned_box_box(const double* c1, const double* h1, const double* c2, const double* h2, double margin, AlignedBB& o) {
   double pen[3];
@@ -890,10 +892,10 @@ MZ_HD bool aligned_box_box(const double* c1, const double* h1, const double* c2,
   double lo[3], hi[3];
   for (int k = 0; k < 3; k++) { lo[k] = fmax(c1[k] - h1[k], c2[k] - h2[k]); hi[k] = fmin(c1[k] + h1[k], c2[k] + h2[k]); }
   const double h1u = u == 0 ? h1[0] : (u == 1 ? h1[1] : h1[2]), h1v = v == 0 ? h1[0] : (v == 1 ? h1[1] : h1[2]);
-  const double tol = 1e-12 * (1.0 + h1u + h1v), dtol = 1e-9 * (1.0 + h1u + h1v);  // inside test / coincident candidates (oracle: same)
+  const double dtol = 1e-9 * (1.0 + h1u + h1v);  // coincident candidates (oracle: same)
   const double lou = u == 0 ? lo[0] : (u == 1 ? lo[1] : lo[2]), hiu = u == 0 ? hi[0] : (u == 1 ? hi[1] : hi[2]);
   const double lov = v == 0 ? lo[0] : (v == 1 ? lo[1] : lo[2]), hiv = v == 0 ? hi[0] : (v == 1 ? hi[1] : hi[2]);
-  if (hiu - lou < -tol || hiv - lov < -tol) return false;
+  if (hiu - lou <= MZ_BOX_MINOVERLAP || hiv - lov <= MZ_BOX_MINOVERLAP) return false;  // the faces must overlap by a positive area (oracle: MZO_BOX_MINOVERLAP)
   const double c1a = ax == 0 ? c1[0] : (ax == 1 ? c1[1] : c1[2]), c2a = ax == 0 ? c2[0] : (ax == 1 ? c2[1] : c2[2]);
   const double h1a = ax == 0 ? h1[0] : (ax == 1 ? h1[1] : h1[2]), pa = ax == 0 ? pen[0] : (ax == 1 ? pen[1] : pen[2]);
   o.ax = ax; o.sg = c2a >= c1a ? 1.0 : -1.0; o.dist = -pa;
@@ -1179,12 +1181,15 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
 // and is rebuilt from the geom) inside the not-yet-used cY block, the second phase only maps compact contact slots to staging
 // entries (prefix sums over the counts).  A geom with more contacts than MZ_STAGE (a foot in a wall corner) flags the env,
 // which then runs the two-pass fill: same contacts, same order, always.
-#define MZ_STAGE 3
+#define MZ_STAGE_OF(NB) ((NB) == 0 ? 3 : 4)  // a block's cell enumerator finds up to 2 x 2 contacts
 template <int NB>
 MZ_HD float* con_stage(AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
+template <int NB>
+MZ_HD const float* con_stage(const AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
 
 template <int NB>
 MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+  constexpr int MZ_STAGE = MZ_STAGE_OF(NB);
   static_assert(8 * MZ_STAGE * AntDims<NB>::NGEOM <= 3 * AntDims<NB>::NC * AntDims<NB>::NCOL, "staging lives in the cY block");
   int n = 0;
   geom_contacts<NB>(K, s, e, [&](const ContactGeo& g) {
@@ -1202,7 +1207,7 @@ MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
 template <int NB>
 MZ_HD void con_map_item(const AntDev& K, AntScratchT<NB>& s, int e) {
   using D = AntDims<NB>;
-  constexpr int NC = D::NC, NG = D::NGEOM;
+  constexpr int NC = D::NC, NG = D::NGEOM, MZ_STAGE = MZ_STAGE_OF(NB);
   int off = 0;
   for (int g = 0; g < e; g++) off += s.cnt[g];
   if (e == NG - 1) {
@@ -1212,6 +1217,7 @@ MZ_HD void con_map_item(const AntDev& K, AntScratchT<NB>& s, int e) {
     s.cbeg[4] = tot;
   }
   const int b = e - D::NMOV;
+  if (b == 0) s.nblkcon = off < NC ? off : NC;  // the torso's enumerator follows those of the movable bodies
   if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
   if (s.con_over) return;  // the env re-enumerates with con_fill_item
   const int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, n = s.cnt[e];
@@ -1244,6 +1250,7 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       s.cbeg[4] = tot;
     }
     int b = e - D::NMOV;
+    if (b == 0) s.nblkcon = off < NC ? off : NC;
     if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
     int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, slot = off;
     if (s.cnt[e] == 0) return;  // nothing to store: skip the second enumeration
@@ -1270,7 +1277,7 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3], dist = q[6];
     int code = (int)q[7], kind = code & 15, blk = (code >> 4) & 7, other = code >> 7;
     if (src >= 0) {  // staged contact: the hint of a capsule-floor contact is the capsule's axis (geom_contacts), nothing else has one
-      const int b = src / MZ_STAGE - D::NMOV;
+      const int b = src / MZ_STAGE_OF(NB) - D::NMOV;
       for (int k = 0; k < 3; k++) hint[k] = (kind == 0 && b > 0) ? s.w[b > 0 ? b - 1 : 0][k] : 0.f;
     } else {
       for (int k = 0; k < 3; k++) hint[k] = q[8 + k];
@@ -1605,7 +1612,7 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   MZ_FOR(l, 5 + (D::BALL ? 1 : 0)) kin_item<NB>(K, s, l);
   cx.sync();
   cx.tick(s, 0);
-  constexpr bool one_pass = NB == 0 && C::row_solver;  // single-pass contact enumeration (con_enum_item)
+  constexpr bool one_pass = NB <= 1 && C::row_solver;  // single-pass contact enumeration (con_enum_item)
   MZ_FOR_AT(b, ANT_NBODY, 0) inertia_item<NB>(K, s, b);
   if constexpr (one_pass) { MZ_FOR_AT(e, NG, ANT_NBODY) con_enum_item<NB>(K, s, e); }
   else { MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e); }
@@ -1629,11 +1636,14 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   if (!first && !one_pass) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7 (lane-group solver: shifted start)
   cx.sync();
   cx.tick(s, 3);
-  if constexpr (NB == 0 && C::row_solver) {
-    // plain ant on the device: constraint rows, then the register-resident solver of ant_newton_rows.h, which also
+  if constexpr (NB <= 1 && C::row_solver) {
+    // plain ant (and the ant with ONE movable block: 16 dofs, still one DPP row) on the device: constraint rows, then the register-resident solver of ant_newton_rows.h, which also
     // computes qacc_smooth = M^-1 qfrc_smooth with its row elimination (no Schur / Cholesky phases) and builds the joint-limit
     // rows on their own dof lanes — same mathematics
-    MZ_FOR_AT(item, 3 * s.ncon, 0) con_row_item<NB>(K, s, item);
+    // (one movable block: the rows of the block's own contacts — the first nblkcon slots — are built inside the solver, by the
+    // lanes that own them: ant_newton_rows.h block_rows_direct)
+    const int nb0 = NB == 1 ? s.nblkcon : 0;
+    MZ_FOR_AT(item, 3 * (s.ncon - nb0), 0) con_row_item<NB>(K, s, 3 * nb0 + item);
     cx.sync();
     cx.tick(s, 11);
     ant_solve_rows(cx, K, s, first);
@@ -1810,14 +1820,14 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 // constant tables of the scratch block, once per step (to be followed by a cx.sync() before the first forward evaluation)
 template <int NB, class C>
 MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
-  if constexpr (NB == 0) { MZ_FOR(i, 256) s.Md[i >> 4][i & 15] = 0.f; }  // entries between different legs stay zero
+  if constexpr (NB <= 1) { MZ_FOR(i, 256) s.Md[i >> 4][i & 15] = (NB == 1 && (i == 14 * 17 || i == 15 * 17)) ? K.block_mass : 0.f; }  // entries between different legs stay zero; a block's slides: its mass
   cx.sync();
   MZ_FOR(e, 9) {  // linear block of the root's mass matrix: total mass x identity (summed in body order, as the composite inertia is)
     float m = 0.f;
     for (int b = 0; b < ANT_NBODY; b++) m += K.mass[body_class(b)];
     const int i = e / 3, j = e - 3 * i;
     s.M.rr[i][j] = i == j ? m : 0.f;
-    if constexpr (NB == 0) s.Md[i][j] = i == j ? m : 0.f;
+    if constexpr (NB <= 1) s.Md[i][j] = i == j ? m : 0.f;
   }
   MZ_FOR(i, MZ_MAX_GRID) {
     s.rowmask[i] = maze_row(K.maze, i);

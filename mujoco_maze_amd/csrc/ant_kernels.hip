@@ -318,7 +318,11 @@ static hipError_t dispatch_ant_step(mz_handle* h, hipStream_t st, const float* a
 // lanes per env of the handle: ONE rule for the step and for mz_debug_forward, so that the diagnostic evaluates the very
 // instantiation that steps (8 lanes exist for the plain ant's step only; the forward diagnostic then uses 16)
 template <int NB>
-static int ant_lanes(const mz_handle* h) { return h->lanes_set ? h->lanes : (NB ? 64 : (h->n <= 4096 ? 16 : 32)); }
+static int ant_lanes(const mz_handle* h) {
+  // one movable block: the row solver (16 dofs in one DPP row, the block's own contacts spread over the group) at 32 lanes per env
+  // — 2048 envs then put exactly one wave on every SIMD; more blocks / the ball: the lane-group solver at 64
+  return h->lanes_set ? h->lanes : (NB == 1 ? 32 : (NB ? 64 : (h->n <= 4096 ? 16 : 32)));
+}
 template <int NB>
 static hipError_t dispatch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
   const int lanes = ant_lanes<NB>(h);

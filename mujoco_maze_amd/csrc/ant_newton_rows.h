@@ -40,16 +40,16 @@ __device__ __forceinline__ float rsum(float x) {  // all-reduce over the 16 lane
 }
 
 // y_r = sum_k A[r][k] x_k with row r of A in registers (Arow) and x distributed one entry per lane
-template <int K = 0>
-__device__ __forceinline__ float matvec(const float (&Arow)[14], float x) {
-  if constexpr (K == 14) return 0.f;
-  else return Arow[K] * bcast<K>(x) + matvec<K + 1>(Arow, x);
+template <int N, int K = 0>
+__device__ __forceinline__ float matvec(const float (&Arow)[N], float x) {
+  if constexpr (K == N) return 0.f;
+  else return Arow[K] * bcast<K>(x) + matvec<N, K + 1>(Arow, x);
 }
 
 // one Gauss-Jordan pivot P on the row-distributed system (Hrow | b): every other row gets rid of column P.
 // COLS... = the columns that can still be non-zero in the pivot row (compile-time list: the arrow structure).
-template <int P, int... COLS>
-__device__ __forceinline__ void pivot(int r, float (&Hrow)[14], float& b, float& dinv) {
+template <int P, int N, int... COLS>
+__device__ __forceinline__ void pivot(int r, float (&Hrow)[N], float& b, float& dinv) {
   const float d = bcast<P>(Hrow[P]);
   const float ri = 1.0f / fmaxf(d, 1e-30f);
   const float li = (r == P) ? 0.f : Hrow[P] * ri;
@@ -59,24 +59,46 @@ __device__ __forceinline__ void pivot(int r, float (&Hrow)[14], float& b, float&
 }
 
 // H x = b, arrow-structured SPD H: leg dofs (6..13) are eliminated first, each touching its partner and the hub columns only
-__device__ __forceinline__ float solve14(int r, float (&Hrow)[14], float b) {
+__device__ __forceinline__ float solve_rows(int r, float (&Hrow)[14], float b) {
   float dinv = 0.f;
   // the four legs do not couple: their hip pivots (then their ankle pivots) are independent chains — issued next to each
   // other so that the reciprocal / broadcast latencies of one hide behind the others
-  pivot<6, 7, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<8, 9, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<10, 11, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<12, 13, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<7, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<9, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<11, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<13, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<3, 4, 5>(r, Hrow, b, dinv);
-  pivot<4, 5>(r, Hrow, b, dinv);
-  pivot<5>(r, Hrow, b, dinv);
+  pivot<6, 14, 7, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<8, 14, 9, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<10, 14, 11, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<12, 14, 13, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<7, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<9, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<11, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<13, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<0, 14, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<1, 14, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<2, 14, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<3, 14, 4, 5>(r, Hrow, b, dinv);
+  pivot<4, 14, 5>(r, Hrow, b, dinv);
+  pivot<5, 14>(r, Hrow, b, dinv);
+  return b * dinv;
+}
+// the same with one movable block: its two slides (dofs 14, 15) belong to the hub (a robot-block contact couples them with the
+// root and with one leg), eliminated between the legs and the root
+__device__ __forceinline__ float solve_rows(int r, float (&Hrow)[16], float b) {
+  float dinv = 0.f;
+  pivot<6, 16, 7, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<8, 16, 9, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<10, 16, 11, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<12, 16, 13, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<7, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<9, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<11, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<13, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
+  pivot<14, 16, 15, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<15, 16, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<0, 16, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<1, 16, 2, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<2, 16, 3, 4, 5>(r, Hrow, b, dinv);
+  pivot<3, 16, 4, 5>(r, Hrow, b, dinv);
+  pivot<4, 16, 5>(r, Hrow, b, dinv);
+  pivot<5, 16>(r, Hrow, b, dinv);
   return b * dinv;
 }
 
@@ -93,24 +115,86 @@ __device__ __forceinline__ float ceval(float D, float u0, float u1, float u2) {
 
 }  // namespace rows
 
-// The solve.  In: s.M, s.qfs, s.warm (first evaluation of a step: MuJoCo's qacc_warmstart; later: the previous evaluation's
-// solution minus its qacc_smooth, see ant_forward), contacts (s.cJ, s.caref, s.cD, s.cleg, s.ncon); the joint-limit rows are built here
-// from s.qpos / s.qvel.  Out: s.qas = M^-1 qfs, s.qacc, s.iters, status bits.  Requires G >= 16.
-template <int G, bool PROF>
-__device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<0>& s, bool compare) {
+// Constraint rows of a contact of the block's OWN enumerators (floor -> block, maze box -> block, slide limit; kinds 3, 4, 6 of
+// con_row_item in ant_dyn.h — the same arithmetic) straight from the contact's staged geometry into the owner lane's registers:
+// only the block's two columns of the Jacobian exist, so the generic 3 x (hub + 2) row builder and its LDS round trip are skipped.
+template <int NB>
+__device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScratchT<NB>& s, int c, float (&jb)[3][2], float (&ar)[3], float& Dout) {
+  using D = AntDims<NB>;
+  const int src = s.csrc[c];
+  const float* q = src >= 0 ? con_stage<NB>(s, src) : &s.cY[c][0][0];
+  const float n[3] = {q[3], q[4], q[5]}, dist = q[6];
+  const int code = (int)q[7], kind = code & 15, other = code >> 7;
+  const float v0 = s.qvel[14], v1 = s.qvel[15];
+  if (kind == 6) {  // slide limit: one frictionless row riding as a pyramid with vanishing tangents (cD = D / 4)
+    const float sg = n[0] + n[1] + n[2];
+    jb[0][0] = other == 0 ? sg : 0.f; jb[0][1] = other == 1 ? sg : 0.f;
+    jb[1][0] = jb[1][1] = jb[2][0] = jb[2][1] = 0.f;
+    const float vel = sg * (other == 0 ? v0 : v1);
+    const float imp = impedancef(K.blim_solimp, fabsf(dist - K.blim_margin));
+    const float R = fmaxf(1e-15f, (1.f - imp) / imp * K.blim_w);
+    Dout = 0.25f / R;
+    ar[0] = -K.blim_B * vel - K.blim_K * imp * (dist - K.blim_margin); ar[1] = 0.f; ar[2] = 0.f;
+    return;
+  }
+  const PairDev& P = kind == 3 ? K.floor : K.wall;
+  const float hint[3] = {0.f, 0.f, 0.f};
+  float t1[3], t2[3];
+  make_tangents(n, hint, t1, t2);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float sc = a == 0 ? 1.f : P.mu;
+    const float* dir = a == 0 ? n : (a == 1 ? t1 : t2);
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) jb[a][sl] = sc * (K.block_axis[sl] == 0 ? dir[0] : (K.block_axis[sl] == 1 ? dir[1] : dir[2]));
+    ar[a] = -P.B * (jb[a][0] * v0 + jb[a][1] * v1);
+  }
+  const float imp = impedancef(P.solimp, fabsf(dist - P.margin));
+  const float tran = K.block_bw_tran;
+  const float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
+  Dout = 1.0f / (2.f * P.mu * P.mu * R);
+  ar[0] -= P.K * imp * (dist - P.margin);
+  (void)sizeof(D);
+}
+
+// The solve.  In: s.Md (dense rows of M), s.qfs, s.warm (first evaluation of a step: MuJoCo's qacc_warmstart; later: the previous
+// evaluation's solution), contacts (s.cJ, s.caref, s.cD, s.cleg, s.ncon, s.nblkcon); the joint-limit rows of the robot's hinges
+// are built here from s.qpos / s.qvel.  Out: s.qas = M^-1 qfs (where needed), s.qacc, s.iters, status bits.  Requires G >= 16.
+//
+// NB = 1 (one movable block, 16 dofs: the row is full).  The contact list starts with the block's OWN contacts — floor corners,
+// maze cells, slide limits: s.nblkcon of them, typically 10-25, none touching the robot — followed by the robot's (<= 16, owned
+// by the row's lanes as for the plain ant; a robot-block contact has the block's two columns in its hub part).  A block-own
+// contact sees two dofs only: its 3 x 2 Jacobian, residuals and J search live in the registers of ONE lane of the group (lane l
+// owns the contacts l, l + G, ...), its gradient (2) and curvature (3 numbers) enter the rows of dofs 14 / 15 through group
+// sums, and the line search adds its terms the same way.  Twenty contacts of the block thus cost five group sums per
+// iteration instead of twenty folds into sixteen Hessian rows.
+template <int NB, int G, bool PROF>
+__device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare) {
   static_assert(G >= 16, "one DPP row per env at least");
+  static_assert(NB <= 1, "one 16-lane row holds 14 dofs + one block's two slides");
   using namespace rows;
-  const int r = cx.l & 15;                       // dof of this lane; 14, 15: spare lanes (zero rows, never pivots)
-  const bool isdof = r < 14, ishinge = r >= 6 && r < 14;
+  using D = AntDims<NB>;
+  constexpr int NR = 14 + 2 * NB;                 // dofs = lanes of the row that own one
+  constexpr int NHC = D::NH;                      // hub columns of a contact Jacobian: root 6 (+ block 2); then hip, ankle
+  constexpr int MB = NB ? (D::NC + G - 1) / G : 0; // block-own contacts per lane
+  constexpr int MA = NB ? 2 : 1;                   // robot contacts per lane of the row (16 MA in all)
+  const int r = cx.l & 15;                       // dof of this lane; beyond NR: spare lanes (zero rows, never pivots)
+  const bool isdof = r < NR, ishinge = r >= 6 && r < 14;
   const int leg = (r - 6) >> 1, d = (r - 6) & 1;  // hinge lanes: own leg, 0 hip / 1 ankle
-  const int ncon = s.ncon;
-  const bool iscon = r < ncon;                   // this lane owns contact r
-  const int cl = iscon ? s.cleg[iscon ? r : 0] : -1;
+  const int nB = NB ? s.nblkcon : 0;             // block-own contacts: slots [0, nB)
+  int nA = s.ncon - nB;                          // robot contacts: slots [nB, ncon), owned by the lanes 0 .. nA - 1 of the row
+  if (nA > 16 * MA) { nA = 16 * MA; if (cx.l == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+  const int ncon = nA;
+  const bool any2 = MA > 1 && cx.any(nA > 16);   // some env of the wave uses the second contact slot of its lanes (wave-uniform: the slot's code is skipped otherwise)
+  bool iscon[MA];                                // this lane owns robot contact r (+ 16: second slot)
+  int cr[MA], cl[MA];
+#pragma unroll
+  for (int m = 0; m < MA; m++) { iscon[m] = r + 16 * m < ncon; cr[m] = nB + (iscon[m] ? r + 16 * m : 0); cl[m] = iscon[m] ? s.cleg[cr[m]] : -1; }
 
   // ---- row r of M, per-dof vectors, own limit row
-  float Mrow[14];
+  float Mrow[NR];
 #pragma unroll
-  for (int k = 0; k < 14; k++) Mrow[k] = s.Md[r][k];  // dense rows written beside the arrow form (crb_leg_item / crb_root_item); rows 14, 15 are zero
+  for (int k = 0; k < NR; k++) Mrow[k] = s.Md[r][k];  // dense rows written beside the arrow form (crb_leg_item / crb_root_item); spare rows are zero
   const int ri = isdof ? r : 0;
   const float qfs = isdof ? s.qfs[ri] : 0.f;
   cx.tick(s, 12);
@@ -129,36 +213,66 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
       laref = -K.lim_B * (lsign * s.qvel[6 + j]) - K.lim_K * imp * pos;
     }
   }
-  const bool has = ncon > 0 || cx.gany(lsign != 0.f);
+  const bool has = s.ncon > 0 || cx.gany(lsign != 0.f);
   // qacc_smooth = M^-1 qfrc_smooth by the same row elimination — only where it is used: on the first evaluation of a step
   // (MuJoCo's warm-start rule compares against it) and for an env without any constraint (then it is the answer).  The
   // Newton iteration itself works on M qacc - qfrc_smooth and never needs it.
   float qas = 0.f;
   if (compare || cx.any(!has)) {
-    float Hq[14];
+    float Hq[NR];
 #pragma unroll
-    for (int k = 0; k < 14; k++) Hq[k] = Mrow[k];
-    qas = solve14(r, Hq, qfs);
+    for (int k = 0; k < NR; k++) Hq[k] = Mrow[k];
+    qas = solve_rows(r, Hq, qfs);
     if (isdof) s.qas[ri] = qas;
   }
   const float warm = isdof ? s.warm[ri] : 0.f;  // later evaluations start from the previous evaluation's solution
-  // own contact: 3 x 8 Jacobian rows stay in LDS (row-major, read as needed); constants in registers
-  const int cr = iscon ? r : 0;
-  const float cD = iscon ? s.cD[cr] : 0.f;
-  const float ar0 = iscon ? s.caref[cr][0] : 0.f, ar1 = iscon ? s.caref[cr][1] : 0.f, ar2 = iscon ? s.caref[cr][2] : 0.f;
-
-  // J[c][a] . x for the lane's own contact, x read from an LDS vector in MuJoCo dof order
-  auto jdot3 = [&](const float* x, float& o0, float& o1, float& o2) {
-    o0 = o1 = o2 = 0.f;
-    if (iscon) {
-      float xv[8];
+  // own robot contact: 3 x (NHC + 2) Jacobian rows stay in LDS (row-major, read as needed); constants in registers
+  float cD[MA], ar[MA][3];
 #pragma unroll
-      for (int k = 0; k < 6; k++) xv[k] = x[k];
-      xv[6] = cl >= 0 ? x[6 + 2 * (cl >= 0 ? cl : 0)] : 0.f;
-      xv[7] = cl >= 0 ? x[7 + 2 * (cl >= 0 ? cl : 0)] : 0.f;
+  for (int m = 0; m < MA; m++) {
+    cD[m] = iscon[m] ? s.cD[cr[m]] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; k++) { o0 += s.cJ[cr][0][k] * xv[k]; o1 += s.cJ[cr][1][k] * xv[k]; o2 += s.cJ[cr][2][k] * xv[k]; }
+    for (int a = 0; a < 3; a++) ar[m][a] = iscon[m] ? s.caref[cr[m]][a] : 0.f;
+  }
+  // own block contacts (NB = 1): slots cx.l + m G < nB
+  float bj[MB ? MB : 1][3][2], bar[MB ? MB : 1][3], bD[MB ? MB : 1], bu[MB ? MB : 1][3], bv[MB ? MB : 1][3];
+  if constexpr (NB == 1) {
+#pragma unroll
+    for (int m = 0; m < MB; m++) {
+      const int c = cx.l + m * G;
+      const bool on = c < nB;
+      bD[m] = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; a++) { bj[m][a][0] = 0.f; bj[m][a][1] = 0.f; bar[m][a] = 0.f; bu[m][a] = 0.f; bv[m][a] = 0.f; }
+      if (on) block_rows_direct<NB>(K, s, c, bj[m], bar[m], bD[m]);
     }
+  }
+
+  // J[c][a] . x for the lane's own robot contact, x read from an LDS vector in MuJoCo dof order
+  auto jdot3 = [&](const float* x, float (&o)[MA][3]) {
+#pragma unroll
+    for (int m = 0; m < MA; m++) {
+      o[m][0] = o[m][1] = o[m][2] = 0.f;
+      if (m == 1 && !any2) continue;
+      if (iscon[m]) {
+        float xv[NHC + 2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) xv[k] = x[k];
+        if constexpr (NB == 1) { xv[6] = x[14]; xv[7] = x[15]; }
+        const int lg = cl[m] >= 0 ? cl[m] : 0;
+        xv[NHC] = cl[m] >= 0 ? x[6 + 2 * lg] : 0.f;
+        xv[NHC + 1] = cl[m] >= 0 ? x[7 + 2 * lg] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NHC + 2; k++) { o[m][0] += s.cJ[cr[m]][0][k] * xv[k]; o[m][1] += s.cJ[cr[m]][1][k] * xv[k]; o[m][2] += s.cJ[cr[m]][2][k] * xv[k]; }
+      }
+    }
+  };
+  // block contacts: residual rows from the two block entries (b0, b1) of a row-distributed vector
+  auto bdot = [&](float b0, float b1, float (&o)[MB ? MB : 1][3]) {
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+      for (int a = 0; a < 3; a++) o[m][a] = bj[m][a][0] * b0 + bj[m][a][1] * b1;
   };
 
   // ---- initial guess
@@ -166,64 +280,127 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   if (compare) {  // MuJoCo's rule on the first evaluation of a step: the better of warm start and qacc_smooth, by cost
     cx.sync();  // s.qas is read back by the contact lanes
     const float dw = warm - qas;
-    float cw = 0.5f * dw * matvec(Mrow, dw), cs = 0.f;
-    float w0, w1, w2, q0, q1, q2;
-    jdot3(s.warm, w0, w1, w2);
-    jdot3(s.qas, q0, q1, q2);
-    if (iscon) { cw += ceval(cD, w0 - ar0, w1 - ar1, w2 - ar2); cs += ceval(cD, q0 - ar0, q1 - ar1, q2 - ar2); }
+    float cw = 0.5f * dw * matvec<NR>(Mrow, dw), cs = 0.f;
+    float jw3[MA][3], jq3[MA][3];
+    jdot3(s.warm, jw3);
+    jdot3(s.qas, jq3);
+#pragma unroll
+    for (int m = 0; m < MA; m++)
+      if (iscon[m]) {
+        cw += ceval(cD[m], jw3[m][0] - ar[m][0], jw3[m][1] - ar[m][1], jw3[m][2] - ar[m][2]);
+        cs += ceval(cD[m], jq3[m][0] - ar[m][0], jq3[m][1] - ar[m][1], jq3[m][2] - ar[m][2]);
+      }
     if (lsign != 0.f) {
       const float jw = lsign * warm - laref, js = lsign * qas - laref;
       if (jw < 0.f) cw += 0.5f * lD * jw * jw;
       if (js < 0.f) cs += 0.5f * lD * js * js;
     }
     cw = rsum(cw); cs = rsum(cs);
+    if constexpr (NB == 1) {
+      float bw[MB][3], bs[MB][3], cwb = 0.f, csb = 0.f;
+      bdot(bcast<14>(warm), bcast<15>(warm), bw);
+      bdot(bcast<14>(qas), bcast<15>(qas), bs);
+#pragma unroll
+      for (int m = 0; m < MB; m++) {
+        cwb += ceval(bD[m], bw[m][0] - bar[m][0], bw[m][1] - bar[m][1], bw[m][2] - bar[m][2]);
+        csb += ceval(bD[m], bs[m][0] - bar[m][0], bs[m][1] - bar[m][1], bs[m][2] - bar[m][2]);
+      }
+      cw += cx.gsum(cwb); cs += cx.gsum(csb);
+    }
     qacc = cw < cs ? warm : qas;
   }
   if (!has) qacc = qas;
   cx.tick(s, 4);
   bool done = !has;
   int it = 0;
-  float Mx = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, ljar = 0.f, lact = 0.f;
+  float Mx = 0.f, ljar = 0.f, lact = 0.f, u[MA][3], v[MA][3];
+#pragma unroll
+  for (int m = 0; m < MA; m++) { u[m][0] = u[m][1] = u[m][2] = 0.f; v[m][0] = v[m][1] = v[m][2] = 0.f; }
   if (cx.any(!done)) {  // residuals at the starting point; afterwards they follow the step
     if (isdof) s.qacc[ri] = qacc;
     cx.sync();
-    Mx = matvec(Mrow, qacc) - qfs;
-    jdot3(s.qacc, u0, u1, u2);
-    u0 -= ar0; u1 -= ar1; u2 -= ar2;
+    Mx = matvec<NR>(Mrow, qacc) - qfs;
+    jdot3(s.qacc, u);
+#pragma unroll
+    for (int m = 0; m < MA; m++) { u[m][0] -= ar[m][0]; u[m][1] -= ar[m][1]; u[m][2] -= ar[m][2]; }
     if (lsign != 0.f) { ljar = lsign * qacc - laref; lact = ljar < 0.f ? lD : 0.f; }
+    if constexpr (NB == 1) {
+      bdot(bcast<14>(qacc), bcast<15>(qacc), bu);
+#pragma unroll
+      for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) bu[m][a] -= bar[m][a];
+    }
   }
   while (cx.any(!done) && it < K.max_iter) {
     // ---- contact lanes: gradient block g3 and curvature block W of their contact, in registers; every lane of the row reads
     // them with `row_newbcast:c` (fold_contact<c>): no LDS publish, no hand-off wait
-    float mycg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (iscon) {
-      const float r0 = u0 + u1, r1 = u0 - u1, r2 = u0 + u2, r3 = u0 - u2;
-      const float a0 = r0 < 0.f ? 1.f : 0.f, a1 = r1 < 0.f ? 1.f : 0.f, a2 = r2 < 0.f ? 1.f : 0.f, a3 = r3 < 0.f ? 1.f : 0.f;
-      mycg[0] = cD * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3); mycg[1] = cD * (a0 * r0 - a1 * r1); mycg[2] = cD * (a2 * r2 - a3 * r3);
-      mycg[3] = cD * (a0 + a1 + a2 + a3); mycg[4] = cD * (a0 - a1); mycg[5] = cD * (a2 - a3); mycg[6] = cD * (a0 + a1); mycg[7] = cD * (a2 + a3);
+    float mycg[MA][8];
+#pragma unroll
+    for (int m = 0; m < MA; m++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) mycg[m][k] = 0.f;
+      if (m == 1 && !any2) continue;
+      if (iscon[m]) {
+        const float u0 = u[m][0], u1 = u[m][1], u2 = u[m][2], Dm = cD[m];
+        const float r0 = u0 + u1, r1 = u0 - u1, r2 = u0 + u2, r3 = u0 - u2;
+        const float a0 = r0 < 0.f ? 1.f : 0.f, a1 = r1 < 0.f ? 1.f : 0.f, a2 = r2 < 0.f ? 1.f : 0.f, a3 = r3 < 0.f ? 1.f : 0.f;
+        mycg[m][0] = Dm * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3); mycg[m][1] = Dm * (a0 * r0 - a1 * r1); mycg[m][2] = Dm * (a2 * r2 - a3 * r3);
+        mycg[m][3] = Dm * (a0 + a1 + a2 + a3); mycg[m][4] = Dm * (a0 - a1); mycg[m][5] = Dm * (a2 - a3); mycg[m][6] = Dm * (a0 + a1); mycg[m][7] = Dm * (a2 + a3);
+      }
+    }
+    // ---- the block's own contacts: gradient (2), |terms| (2) and curvature (3) on the block's two dofs, summed over the group
+    float bg0 = 0.f, bg1 = 0.f, bga0 = 0.f, bga1 = 0.f, bh00 = 0.f, bh01 = 0.f, bh11 = 0.f;
+    if constexpr (NB == 1) {
+#pragma unroll
+      for (int m = 0; m < MB; m++) {
+        const float x0 = bu[m][0], x1 = bu[m][1], x2 = bu[m][2], Dm = bD[m];
+        const float r0 = x0 + x1, r1 = x0 - x1, r2 = x0 + x2, r3 = x0 - x2;
+        const float a0 = r0 < 0.f ? 1.f : 0.f, a1 = r1 < 0.f ? 1.f : 0.f, a2 = r2 < 0.f ? 1.f : 0.f, a3 = r3 < 0.f ? 1.f : 0.f;
+        const float g0 = Dm * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3), g1 = Dm * (a0 * r0 - a1 * r1), g2 = Dm * (a2 * r2 - a3 * r3);
+        const float W0 = Dm * (a0 + a1 + a2 + a3), W1 = Dm * (a0 - a1), W2 = Dm * (a2 - a3), W3 = Dm * (a0 + a1), W4 = Dm * (a2 + a3);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const float j0 = bj[m][0][c], j1 = bj[m][1][c], j2 = bj[m][2][c];
+          const float t = j0 * g0 + j1 * g1 + j2 * g2;
+          if (c == 0) { bg0 += t; bga0 += fabsf(t); } else { bg1 += t; bga1 += fabsf(t); }
+          const float t0 = j0 * W0 + j1 * W1 + j2 * W2, t1 = j0 * W1 + j1 * W3, t2 = j0 * W2 + j2 * W4;  // (W J)[:, c]
+          if (c == 0) { bh00 += t0 * j0 + t1 * j1 + t2 * j2; bh01 += t0 * bj[m][0][1] + t1 * bj[m][1][1] + t2 * bj[m][2][1]; }
+          else bh11 += t0 * j0 + t1 * j1 + t2 * j2;
+        }
+      }
+      bg0 = cx.gsum(bg0); bg1 = cx.gsum(bg1); bga0 = cx.gsum(bga0); bga1 = cx.gsum(bga1);
+      bh00 = cx.gsum(bh00); bh01 = cx.gsum(bh01); bh11 = cx.gsum(bh11);
     }
     // ---- row r of H = M + sum_c Jc^T Wc Jc + limit curvature; gradient entry r
-    float Hrow[14];
+    float Hrow[NR];
 #pragma unroll
-    for (int k = 0; k < 14; k++) Hrow[k] = Mrow[k];
+    for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
     float g = Mx, ga = fabsf(Mx);
     auto fold = [&](auto Cc) {
       constexpr int C = decltype(Cc)::value;
       if (C < ncon) {  // (uniform within the env's row)
         float cg[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) cg[k] = bcast<C>(mycg[k]);
-        const int lc = __builtin_amdgcn_update_dpp(0, cl, 0x150 + C, 0xF, 0xF, false);
-        const int col = r < 6 ? r : ((ishinge && leg == lc) ? 6 + d : -1);
+        for (int k = 0; k < 8; k++) cg[k] = bcast<(C & 15)>(mycg[C / 16][k]);
+        const int lc = __builtin_amdgcn_update_dpp(0, cl[C / 16], 0x150 + (C & 15), 0xF, 0xF, false);
+        const int col = r < 6 ? r : ((ishinge && leg == lc) ? NHC + d : ((NB == 1 && r >= 14 && r < 16) ? r - 8 : -1));
         const int cc = col >= 0 ? col : 0;
-        const float j0 = col >= 0 ? s.cJ[C][0][cc] : 0.f, j1 = col >= 0 ? s.cJ[C][1][cc] : 0.f, j2 = col >= 0 ? s.cJ[C][2][cc] : 0.f;
+        const float* J0 = s.cJ[nB + C][0];
+        const float* J1 = s.cJ[nB + C][1];
+        const float* J2 = s.cJ[nB + C][2];
+        const float j0 = col >= 0 ? J0[cc] : 0.f, j1 = col >= 0 ? J1[cc] : 0.f, j2 = col >= 0 ? J2[cc] : 0.f;
         const float t = j0 * cg[0] + j1 * cg[1] + j2 * cg[2];
         g += t; ga += fabsf(t);
         const float t0 = j0 * cg[3] + j1 * cg[4] + j2 * cg[5], t1 = j0 * cg[4] + j1 * cg[6], t2 = j0 * cg[5] + j2 * cg[7];  // (W Jc)[:, col]
 #pragma unroll
-        for (int k = 0; k < 6; k++) Hrow[k] += t0 * s.cJ[C][0][k] + t1 * s.cJ[C][1][k] + t2 * s.cJ[C][2][k];
-        const float h6 = t0 * s.cJ[C][0][6] + t1 * s.cJ[C][1][6] + t2 * s.cJ[C][2][6];
-        const float h7 = t0 * s.cJ[C][0][7] + t1 * s.cJ[C][1][7] + t2 * s.cJ[C][2][7];
+        for (int k = 0; k < 6; k++) Hrow[k] += t0 * J0[k] + t1 * J1[k] + t2 * J2[k];
+        if constexpr (NB == 1) {
+          Hrow[14] += t0 * J0[6] + t1 * J1[6] + t2 * J2[6];
+          Hrow[15] += t0 * J0[7] + t1 * J1[7] + t2 * J2[7];
+        }
+        const float h6 = t0 * J0[NHC] + t1 * J1[NHC] + t2 * J2[NHC];
+        const float h7 = t0 * J0[NHC + 1] + t1 * J1[NHC + 1] + t2 * J2[NHC + 1];
 #pragma unroll
         for (int l2 = 0; l2 < 4; l2++) { Hrow[6 + 2 * l2] += lc == l2 ? h6 : 0.f; Hrow[7 + 2 * l2] += lc == l2 ? h7 : 0.f; }
       }
@@ -235,8 +412,20 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
         if (cx.any(ncon > 8)) {
           fold(std::integral_constant<int, 8>{}); fold(std::integral_constant<int, 9>{}); fold(std::integral_constant<int, 10>{}); fold(std::integral_constant<int, 11>{});
           fold(std::integral_constant<int, 12>{}); fold(std::integral_constant<int, 13>{}); fold(std::integral_constant<int, 14>{}); fold(std::integral_constant<int, 15>{});
+          if constexpr (MA > 1) {
+            if (any2) {  // second slot of the contact lanes: a robot lying against block and walls at once
+              fold(std::integral_constant<int, 16>{}); fold(std::integral_constant<int, 17>{}); fold(std::integral_constant<int, 18>{}); fold(std::integral_constant<int, 19>{});
+              fold(std::integral_constant<int, 20>{}); fold(std::integral_constant<int, 21>{}); fold(std::integral_constant<int, 22>{}); fold(std::integral_constant<int, 23>{});
+              fold(std::integral_constant<int, 24>{}); fold(std::integral_constant<int, 25>{}); fold(std::integral_constant<int, 26>{}); fold(std::integral_constant<int, 27>{});
+              fold(std::integral_constant<int, 28>{}); fold(std::integral_constant<int, 29>{}); fold(std::integral_constant<int, 30>{}); fold(std::integral_constant<int, 31>{});
+            }
+          }
         }
       }
+    }
+    if constexpr (NB == 1) {
+      if (r == 14) { g += bg0; ga += bga0; Hrow[14] += bh00; Hrow[15] += bh01; }
+      if (r == 15) { g += bg1; ga += bga1; Hrow[14] += bh01; Hrow[15] += bh11; }
     }
     if (lsign != 0.f) { const float t = lsign * lact * ljar; g += t; ga += fabsf(t); }
 #pragma unroll
@@ -248,41 +437,68 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     if (!cx.any(!done)) { cx.tick(s, 5); break; }
     cx.tick(s, 5);
     // ---- Newton direction: H search = -grad
-    const float search = solve14(r, Hrow, -g);
+    const float search = solve_rows(r, Hrow, -g);
     if (isdof) s.search[ri] = search;
     cx.sync();
     cx.tick(s, 6);
     // ---- J search on the contact lanes, limit rows on their own dofs; vote on the active set
-    float v0, v1, v2;
-    jdot3(s.search, v0, v1, v2);
+    jdot3(s.search, v);
     const float ljv = lsign * search;
     bool changed = false;
-    if (iscon) {
-      const float w0 = u0 + v0, w1 = u1 + v1, w2 = u2 + v2;
-      changed = ((u0 + u1 < 0.f) != (w0 + w1 < 0.f)) || ((u0 - u1 < 0.f) != (w0 - w1 < 0.f)) || ((u0 + u2 < 0.f) != (w0 + w2 < 0.f)) ||
-                ((u0 - u2 < 0.f) != (w0 - w2 < 0.f));
-    }
+#pragma unroll
+    for (int m = 0; m < MA; m++)
+      if ((m == 0 || any2) && iscon[m]) {
+        const float u0 = u[m][0], u1 = u[m][1], u2 = u[m][2], w0 = u0 + v[m][0], w1 = u1 + v[m][1], w2 = u2 + v[m][2];
+        changed = changed || ((u0 + u1 < 0.f) != (w0 + w1 < 0.f)) || ((u0 - u1 < 0.f) != (w0 - w1 < 0.f)) || ((u0 + u2 < 0.f) != (w0 + w2 < 0.f)) ||
+                  ((u0 - u2 < 0.f) != (w0 - w2 < 0.f));
+      }
     if (lsign != 0.f) changed = changed || ((ljar < 0.f) != (ljar + ljv < 0.f));
+    if constexpr (NB == 1) {
+      bdot(bcast<14>(search), bcast<15>(search), bv);
+#pragma unroll
+      for (int m = 0; m < MB; m++) {
+        const float x0 = bu[m][0], x1 = bu[m][1], x2 = bu[m][2], w0 = x0 + bv[m][0], w1 = x1 + bv[m][1], w2 = x2 + bv[m][2];
+        changed = changed || ((x0 + x1 < 0.f) != (w0 + w1 < 0.f)) || ((x0 - x1 < 0.f) != (w0 - w1 < 0.f)) || ((x0 + x2 < 0.f) != (w0 + w2 < 0.f)) ||
+                  ((x0 - x2 < 0.f) != (w0 - w2 < 0.f));
+      }
+    }
     changed = cx.gany(changed);
     float alpha = 1.f, Ms = 0.f;
     const bool exact = !changed;
     if (changed) {  // exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on the piecewise-linear phi'
-      Ms = matvec(Mrow, search);
+      Ms = matvec<NR>(Mrow, search);
       const float p1 = rsum(search * Mx), p2 = rsum(search * Ms);
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
       for (int ls = 0; ls < K.ls_iter; ls++) {
         float d1 = 0.f, d2 = 0.f;
-        if (iscon) {
-          const float x0 = u0 + alpha * v0, x1 = u1 + alpha * v1, x2 = u2 + alpha * v2;
-          float rr, vv;
-          rr = x0 + x1; vv = v0 + v1; if (rr < 0.f) { d1 += cD * rr * vv; d2 += cD * vv * vv; }
-          rr = x0 - x1; vv = v0 - v1; if (rr < 0.f) { d1 += cD * rr * vv; d2 += cD * vv * vv; }
-          rr = x0 + x2; vv = v0 + v2; if (rr < 0.f) { d1 += cD * rr * vv; d2 += cD * vv * vv; }
-          rr = x0 - x2; vv = v0 - v2; if (rr < 0.f) { d1 += cD * rr * vv; d2 += cD * vv * vv; }
-        }
+#pragma unroll
+        for (int m = 0; m < MA; m++)
+          if ((m == 0 || any2) && iscon[m]) {
+            const float v0 = v[m][0], v1 = v[m][1], v2 = v[m][2], Dm = cD[m];
+            const float x0 = u[m][0] + alpha * v0, x1 = u[m][1] + alpha * v1, x2 = u[m][2] + alpha * v2;
+            float rr, vv;
+            rr = x0 + x1; vv = v0 + v1; if (rr < 0.f) { d1 += Dm * rr * vv; d2 += Dm * vv * vv; }
+            rr = x0 - x1; vv = v0 - v1; if (rr < 0.f) { d1 += Dm * rr * vv; d2 += Dm * vv * vv; }
+            rr = x0 + x2; vv = v0 + v2; if (rr < 0.f) { d1 += Dm * rr * vv; d2 += Dm * vv * vv; }
+            rr = x0 - x2; vv = v0 - v2; if (rr < 0.f) { d1 += Dm * rr * vv; d2 += Dm * vv * vv; }
+          }
         if (lsign != 0.f) { const float rr = ljar + alpha * ljv; if (rr < 0.f) { d1 += lD * rr * ljv; d2 += lD * ljv * ljv; } }
         d1 = rsum(d1) + p1 + alpha * p2;
         d2 = rsum(d2) + p2;
+        if constexpr (NB == 1) {
+          float e1 = 0.f, e2 = 0.f;
+#pragma unroll
+          for (int m = 0; m < MB; m++) {
+            const float y0 = bv[m][0], y1 = bv[m][1], y2 = bv[m][2], Dm = bD[m];
+            const float x0 = bu[m][0] + alpha * y0, x1 = bu[m][1] + alpha * y1, x2 = bu[m][2] + alpha * y2;
+            float rr, vv;
+            rr = x0 + x1; vv = y0 + y1; if (rr < 0.f) { e1 += Dm * rr * vv; e2 += Dm * vv * vv; }
+            rr = x0 - x1; vv = y0 - y1; if (rr < 0.f) { e1 += Dm * rr * vv; e2 += Dm * vv * vv; }
+            rr = x0 + x2; vv = y0 + y2; if (rr < 0.f) { e1 += Dm * rr * vv; e2 += Dm * vv * vv; }
+            rr = x0 - x2; vv = y0 - y2; if (rr < 0.f) { e1 += Dm * rr * vv; e2 += Dm * vv * vv; }
+          }
+          d1 += cx.gsum(e1); d2 += cx.gsum(e2);
+        }
         if (d2 == prev_d2) break;  // same slope as at the previous iterate: same linear piece, alpha is its root
         prev_d2 = d2;
         if (d1 < 0.f) lo = alpha; else hi = alpha;
@@ -299,8 +515,15 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
       qacc += alpha * search;
       if (changed) {
         Mx += alpha * Ms;
-        u0 += alpha * v0; u1 += alpha * v1; u2 += alpha * v2;
+#pragma unroll
+        for (int m = 0; m < MA; m++) { u[m][0] += alpha * v[m][0]; u[m][1] += alpha * v[m][1]; u[m][2] += alpha * v[m][2]; }
         if (lsign != 0.f) { ljar += alpha * ljv; lact = ljar < 0.f ? lD : 0.f; }
+        if constexpr (NB == 1) {
+#pragma unroll
+          for (int m = 0; m < MB; m++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) bu[m][a] += alpha * bv[m][a];
+        }
       }
     }
     if (exact && K.trust_exact) done = true;

@@ -159,9 +159,9 @@ MZP_HD void pl_box_box(const double* pos1, const double* mat1, const double* siz
     const double Ph = (ah == 0 ? pBA[0] : pBA[1]) + sb * sBb * Rhb, P3 = (a == 0 ? pBA[0] : pBA[1]) + sb * sBb * Rab, Pz = pBA[2];
     const double Uh = sBh * Rhh, U3 = sBh * Rah;
     const double Sh = ah == 0 ? sA[0] : sA[1], S3 = a == 0 ? sA[0] : sA[1], Sz = sA[2];
-    const double tol = 1e-12 * (1.0 + Sh + Sz), dtol = 1e-9 * (1.0 + Sh + Sz);
+    const double dtol = 1e-9 * (1.0 + Sh + Sz);
     const double hlo = fmax(-Sh, Ph - fabs(Uh)), hhi = fmin(Sh, Ph + fabs(Uh)), zlo = fmax(-Sz, Pz - sB[2]), zhi = fmin(Sz, Pz + sB[2]);
-    if (hhi - hlo < -tol || zhi - zlo < -tol) return;
+    if (hhi - hlo <= MZ_BOX_MINOVERLAP || zhi - zlo <= MZ_BOX_MINOVERLAP) return;  // positive overlap area [ASSUME-12]
     const int nh = hhi - hlo > dtol ? 2 : 1, nz = zhi - zlo > dtol ? 2 : 1;
     for (int ih = 0; ih < nh; ih++) {
       const double hh = ih ? hhi : hlo, x3 = P3 + (hh - Ph) / Uh * U3, dist = sg * x3 - S3;
@@ -241,33 +241,41 @@ MZP_HD void pl_box_box(const double* pos1, const double* mat1, const double* siz
   // path is rare (a deep overlap, whose least-penetration axis is vertical), and 24 inlined copies of `consider` with the
   // caller's emit in each cost every launch a third of its time in instruction fetch alone (measured).
   const double det = U1 * V2 - U2 * V1;
+  // no area -> no contact [ASSUME-12]: only rectangles with parallel edges can intersect in a segment (a border line shared);
+  // their intersection is the rectangle of the overlapping extents — measured directly (the oracle measures its candidates)
+  if (aligned) {
+    const double e1 = fabs(U1) + fabs(V1), e2 = fabs(U2) + fabs(V2);
+    if (fmin(S1, P1 + e1) - fmax(-S1, P1 - e1) <= MZ_BOX_MINOVERLAP || fmin(S2, P2 + e2) - fmax(-S2, P2 - e2) <= MZ_BOX_MINOVERLAP) return;
+  }
+  {
 #pragma unroll 1
-  for (int c = 0; c < 24; c++) {
-    double x1 = 0.0, x2 = 0.0, x3 = 0.0;
-    bool valid = false;
-    if (c < 4) {
-      const double su = (c & 1) ? 1.0 : -1.0, sv = (c & 2) ? 1.0 : -1.0;
-      x1 = P1 + su * U1 + sv * V1; x2 = P2 + su * U2 + sv * V2; x3 = P3 + su * U3 + sv * V3;
-      valid = fabs(x1) <= S1 + tol && fabs(x2) <= S2 + tol;
-    } else if (c < 20) {
-      const int k = c - 4, e = k >> 2, w = (k >> 1) & 1;
-      const double side = (k & 1) ? 1.0 : -1.0, sgn = (e & 1) ? 1.0 : -1.0;
-      const double p1 = e < 2 ? P1 + sgn * V1 : P1 + sgn * U1, p2 = e < 2 ? P2 + sgn * V2 : P2 + sgn * U2, p3 = e < 2 ? P3 + sgn * V3 : P3 + sgn * U3;
-      const double q1 = e < 2 ? U1 : V1, q2 = e < 2 ? U2 : V2, q3 = e < 2 ? U3 : V3;
-      const double pc = w ? p2 : p1, qc = w ? q2 : q1, po = w ? p1 : p2, qo = w ? q1 : q2, Sc = w ? S2 : S1, So = w ? S1 : S2;
-      if (fabs(qc) >= 1e-15) {
-        const double t = (side * Sc - pc) / qc;
-        valid = t >= -1.0 && t <= 1.0 && fabs(po + t * qo) <= So + tol;
-        x1 = p1 + t * q1; x2 = p2 + t * q2; x3 = p3 + t * q3;
+    for (int c = 0; c < 24; c++) {
+      double x1 = 0.0, x2 = 0.0, x3 = 0.0;
+      bool valid = false;
+      if (c < 4) {
+        const double su = (c & 1) ? 1.0 : -1.0, sv = (c & 2) ? 1.0 : -1.0;
+        x1 = P1 + su * U1 + sv * V1; x2 = P2 + su * U2 + sv * V2; x3 = P3 + su * U3 + sv * V3;
+        valid = fabs(x1) <= S1 + tol && fabs(x2) <= S2 + tol;
+      } else if (c < 20) {
+        const int k = c - 4, e = k >> 2, w = (k >> 1) & 1;
+        const double side = (k & 1) ? 1.0 : -1.0, sgn = (e & 1) ? 1.0 : -1.0;
+        const double p1 = e < 2 ? P1 + sgn * V1 : P1 + sgn * U1, p2 = e < 2 ? P2 + sgn * V2 : P2 + sgn * U2, p3 = e < 2 ? P3 + sgn * V3 : P3 + sgn * U3;
+        const double q1 = e < 2 ? U1 : V1, q2 = e < 2 ? U2 : V2, q3 = e < 2 ? U3 : V3;
+        const double pc = w ? p2 : p1, qc = w ? q2 : q1, po = w ? p1 : p2, qo = w ? q1 : q2, Sc = w ? S2 : S1, So = w ? S1 : S2;
+        if (fabs(qc) >= 1e-15) {
+          const double t = (side * Sc - pc) / qc;
+          valid = t >= -1.0 && t <= 1.0 && fabs(po + t * qo) <= So + tol;
+          x1 = p1 + t * q1; x2 = p2 + t * q2; x3 = p3 + t * q3;
+        }
+      } else if (fabs(det) > 1e-15) {
+        const int k = c - 20;
+        const double x = ((k & 1) ? S1 : -S1) - P1, y = ((k & 2) ? S2 : -S2) - P2;
+        const double al = (x * V2 - y * V1) / det, be = (U1 * y - U2 * x) / det;
+        valid = fabs(al) <= 1.0 + 1e-12 && fabs(be) <= 1.0 + 1e-12;
+        x1 = P1 + al * U1 + be * V1; x2 = P2 + al * U2 + be * V2; x3 = P3 + al * U3 + be * V3;
       }
-    } else if (fabs(det) > 1e-15) {
-      const int k = c - 20;
-      const double x = ((k & 1) ? S1 : -S1) - P1, y = ((k & 2) ? S2 : -S2) - P2;
-      const double al = (x * V2 - y * V1) / det, be = (U1 * y - U2 * x) / det;
-      valid = fabs(al) <= 1.0 + 1e-12 && fabs(be) <= 1.0 + 1e-12;
-      x1 = P1 + al * U1 + be * V1; x2 = P2 + al * U2 + be * V2; x3 = P3 + al * U3 + be * V3;
+      if (valid) consider(x1, x2, x3);
     }
-    if (valid) consider(x1, x2, x3);
   }
 }
 

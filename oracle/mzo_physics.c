@@ -35,6 +35,7 @@
 #define NB MZ_MAX_BODY
 #define ND MZ_MAX_DOF
 #define MINVAL 1e-15
+#define MZO_BOX_MINOVERLAP 1e-6 /* box-box: smallest width of the face intersection that still makes contacts (box_box) */
 
 /* ------------------------------------------------------------------ vec helpers */
 static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -619,9 +620,10 @@ static void capsule_box(mzo_data* d, const pairparam* pp, const double* cpos, co
  * plane).  Each candidate carries its own distance to the reference face; candidates beyond the margin are dropped; a
  * contact sits midway between the candidate and the reference face; the normal is the reference normal oriented from
  * geom1 to geom2; at most 8 contacts.
- * Reconstructed: all inside / crossing tests are inclusive (faces that share a border line — grid-aligned boxes — do
- * collide along it), and a candidate that coincides with an earlier one is emitted once (MuJoCo's enumeration can list such
- * a vertex twice).  The edge-edge case (no registered maze can reach it: every box here is rotated about z only, where
+ * Reconstructed: all inside / crossing tests are inclusive (a candidate ON a border line of the reference rectangle counts:
+ * the movable blocks have exactly the walls' z extent), a candidate that coincides with an earlier one is emitted once
+ * (MuJoCo's enumeration can list such a vertex twice), and — the one deliberate deviation — an intersection without area makes
+ * no contact (see MZO_BOX_MINOVERLAP below).  The edge-edge case (no registered maze can reach it: every box here is rotated about z only, where
  * each edge-edge axis coincides with a face axis and loses the tie) yields one contact midway between the closest points of
  * the two edges. */
 static void box_box(mzo_data* d, const pairparam* pp, const double* pos1, const double* mat1, const double* size1,
@@ -755,6 +757,19 @@ static void box_box(mzo_data* d, const pairparam* pp, const double* pos1, const 
   }
   int emitted = 0;
   const double dtol = 1e-9 * (1.0 + sA[a1] + sA[a2]);  /* candidates closer than this (max norm) are one vertex */
+  {
+    /* The faces must overlap by a positive area: an intersection that has collapsed to a segment or a point (narrower than
+     * MZO_BOX_MINOVERLAP in a face direction) makes no contact.  This is the one deliberate deviation from the inclusive
+     * enumeration [ASSUME-12]: grid-aligned boxes that share only a border line — every movable block at its spawn position
+     * against the diagonal wall cells — would otherwise sit on a knife edge (zero-width contact strips that appear and
+     * vanish with the sign of a 1e-16 displacement), in the reference as much as here. */
+    double lo1 = 1e300, hi1 = -1e300, lo2 = 1e300, hi2 = -1e300;
+    for (int c = 0; c < nc; c++) {
+      lo1 = fmin(lo1, cand[c][a1]); hi1 = fmax(hi1, cand[c][a1]);
+      lo2 = fmin(lo2, cand[c][a2]); hi2 = fmax(hi2, cand[c][a2]);
+    }
+    if (nc == 0 || hi1 - lo1 <= MZO_BOX_MINOVERLAP || hi2 - lo2 <= MZO_BOX_MINOVERLAP) return;
+  }
   for (int c = 0; c < nc && emitted < 8; c++) {
     int dup = 0;
     for (int e = 0; e < c && !dup; e++)

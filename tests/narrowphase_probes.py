@@ -61,8 +61,10 @@ def probes():
     # ---- mjc_BoxBox
     out.append(("aligned cubes, face to face, partial overlap: the corners of the overlap rectangle", "box_box", ([0, 0, 0], I3, CUBE), ([0.99, 0.3, 0], I3, CUBE), 0.02,
                 [[-0.01, 0.495, y, z, 1, 0, 0] for y in (-0.2, 0.5) for z in (-0.5, 0.5)]))
-    out.append(("aligned cubes sharing only an edge (grid-aligned diagonal neighbours): they touch along it", "box_box", ([0, 0, 0], I3, CUBE), ([1, 1, 0], I3, CUBE), 0.02,
-                [[0.0, 0.5, 0.5, z, 1, 0, 0] for z in (-0.5, 0.5)]))
+    out.append(("aligned cubes sharing only an edge (grid-aligned diagonal neighbours): an intersection without area, no contact [ASSUME-12]", "box_box",
+                ([0, 0, 0], I3, CUBE), ([1, 1, 0], I3, CUBE), 0.02, []))
+    out.append(("aligned cubes overlapping by a hair past the edge: the strip's four corners", "box_box", ([0, 0, 0], I3, CUBE), ([1.0, 0.99, 0], I3, CUBE), 0.02,
+                [[0.0, 0.5, y, z, 1, 0, 0] for y in (0.49, 0.5) for z in (-0.5, 0.5)]))
     out.append(("aligned cubes separated by less than the margin", "box_box", ([0, 0, 0], I3, CUBE), ([0.2, -1.015, 0.1], I3, CUBE), 0.02,
                 [[0.015, x, -0.5075, z, 0, -1, 0] for x in (-0.3, 0.5) for z in (-0.4, 0.5)]))
     out.append(("aligned cubes beyond the margin: nothing", "box_box", ([0, 0, 0], I3, CUBE), ([1.03, 0, 0], I3, CUBE), 0.02, []))

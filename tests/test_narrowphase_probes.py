@@ -20,7 +20,7 @@ def test_probe_sets_are_rotation_invariant(oracle):
     Q = NP._z_to([0.3, -0.5, 0.8]) @ NP.rotz(0.7)
     off = np.array([3.0, -2.0, 1.5])
     for name, kind, g1, g2, margin, want in NP.probes():
-        if not want or "sharing only an edge" in name:  # (an exact tie between two face axes: round-off decides it once turned)
+        if not want or "past the edge" in name:  # (an exact tie between two face axes: round-off decides it once turned)
             continue
         a = (Q @ np.asarray(g1[0], float) + off, Q @ np.asarray(g1[1], float), g1[2])
         b = (Q @ np.asarray(g2[0], float) + off, Q @ np.asarray(g2[1], float), g2[2])
@@ -43,6 +43,11 @@ def test_plane_box_corner_rule(oracle):
     floor = c[(c[:, 7] == 0) & (c[:, 8] == 14)]
     assert len(floor) == 4 and np.allclose(floor[:, 0], 0.0) and np.allclose(floor[:, 4:7], [0, 0, 1])
     assert sorted(map(tuple, np.round(floor[:, 1:3], 9))) == sorted((x, y) for x in (-4.0, 4.0) for y in (4.0, 12.0))
-    # the three wall cells diagonal to the block's spawn cell share a vertical border line with it: two contacts each at dist 0
+    # the three wall cells diagonal to the block's spawn cell share only a vertical border line with it: no contact [ASSUME-12]
     walls = c[(c[:, 7] == -1) & (c[:, 8] == 14)]
-    assert len(walls) == 6 and np.allclose(walls[:, 0], 0.0) and np.all(np.abs(walls[:, 4]) == 1.0)
+    assert len(walls) == 0
+    q[15] = 0.001  # pushed 1 mm towards +x: a 1 mm strip of its -y / +y faces now lies against the two diagonal cells on that side
+    walls = oracle.contacts(cm, q)
+    walls = walls[(walls[:, 7] == -1) & (walls[:, 8] == 14)]
+    assert len(walls) == 8 and np.allclose(walls[:, 0], 0.0) and np.all(np.abs(walls[:, 5]) == 1.0)  # least penetration: y (0 < 1 mm)
+    assert np.allclose(sorted(set(np.round(walls[:, 1], 9))), [4.0, 4.001])
