@@ -257,15 +257,25 @@ def test_ant_corner_contacts_overflow_the_staging(torch, oracle):
     fref = oracle.forward(cm, st["qpos"], st["qvel"], act.astype(np.float64), st["warm"])
     nc = fref["counts"][:, 0]
     dc = counts.cpu().numpy()[:, 0]
-    # equal env by env, up to the cap of 16 contact slots (flagged, not fatal) and fp32 / fp64 ties at the activation distance
+    # equal env by env (up to the cap of 16 contact slots: flagged, not fatal) — or the env sits on a tie at the activation distance
+    # that the float64 oracle shows itself: its own count changes under a perturbation of the state at fp32 round-off scale
     diff = np.where(dc != np.minimum(nc, 16))[0]
-    assert len(diff) <= 3 and np.all(np.abs(dc[diff] - nc[diff]) <= 1), (diff, dc[diff], nc[diff])
+    assert len(diff) <= 3, (diff, dc[diff], nc[diff])
+    prng = np.random.default_rng(77)
+    for e in diff:
+        counts_seen = set()
+        for _ in range(24):
+            q = st["qpos"][e:e + 1] + prng.uniform(-1e-6, 1e-6, (1, 15)) * np.maximum(1.0, np.abs(st["qpos"][e:e + 1]))
+            counts_seen.add(int(oracle.forward(cm, q, st["qvel"][e:e + 1], act[e:e + 1].astype(np.float64), st["warm"][e:e + 1])["counts"][0, 0]))
+        assert len(counts_seen) > 1, f"env {e}: device {dc[e]} contacts, oracle {nc[e]}, and the oracle's count is stable under perturbation"
     assert nc.max() >= 8 and (nc >= 6).sum() >= 20 and nc.min() <= 4  # crowded corners and ordinary stances in one batch
     start = {k: v.copy() for k, v in st.items()}
     obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
     qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
     ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
-    good = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, max_outlier_frac=0.08, hard_atol=1e-4)
+    # ants dropped INTO a wall corner (leg segments through the boxes): far more activation flips than any rollout state has — every
+    # outlier must still be proven on the oracle
+    good = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, max_outlier_frac=0.08)
     assert np.all(_close(obs.cpu().numpy()[good], ref["obs"][good]))
     assert np.array_equal(done.cpu().numpy(), ref["done"])
     assert np.all((env.status().cpu().numpy() & 1) == 0)
@@ -328,7 +338,7 @@ def test_ant_multi_block_mazes(torch, oracle, env_id, nblock):
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             # measured: <= 0.6 % of the envs outside 1e-5, each of them inside 2e-5 or on an oracle-visible discontinuity
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.012, hard_atol=2e-5)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.006, hard_atol=2e-5)
             per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
             worst.append(per_env[ok])
             assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=2e-5))
@@ -359,8 +369,12 @@ def test_point_step_parity_and_bounce(torch, oracle):
     g = oracle.forward(cm, st["qpos"], st["qvel"])
     assert (g["counts"][:, 1] > 0).sum() > n // 4  # MuJoCo sphere-box / arrow box-box rows active in the fixture
     ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
-    free = ((status & ~8) == 0) & ((ref["status"] & ~8) == 0)  # 8 = collinear move (reference raises there)
-    assert free.mean() > 0.999 and np.all((ref["status"] & 256) == 0)
+    # status bit 8 = collinear move (the reference raises ZeroDivisionError there, maze_env_utils.py:119-123): the SAME envs on
+    # both sides, a handful at most; no other status bit anywhere
+    coll = (ref["status"] & 8) != 0
+    assert np.array_equal((status & 8) != 0, coll) and coll.sum() <= 4
+    assert np.all((status & ~8) == 0) and np.all((ref["status"] & ~8) == 0)
+    free = ~coll
     o = obs.cpu().numpy()
     assert np.all(_close(o[free], ref["obs"][free], atol=1e-6, rtol=2e-7))
     assert np.array_equal(done.cpu().numpy()[free], ref["done"][free])
@@ -389,16 +403,18 @@ def test_point_with_movable_blocks(torch, oracle, env_id, nblock):
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, _, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
-            errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1))
             assert np.array_equal(done.cpu().numpy(), ref["done"])
             assert np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
-            # a robot teleported onto a block's diagonal sits on a tie between two faces: allow a few such envs
-            assert np.all(_close(qpos, s64["qpos"], atol=1e-4), axis=1).mean() >= 0.995 and np.array_equal(t, s64["t"])
+            # every env inside 2e-6 (the kernel computes in float64; what separates it from the oracle is the fp32 state it stores), or —
+            # a robot teleported onto a block's diagonal sits on a tie between two faces — on a discontinuity the oracle shows itself
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-6, max_outlier_frac=0.004)
+            errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1)[ok])
+            assert np.array_equal(t, s64["t"])
             assert np.all((env.status().cpu().numpy() & ~8) == 0)
             moved = max(moved, np.abs(s64["qpos"][:, 3:]).max())
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     errs = np.concatenate(errs)
-    assert np.median(errs) < 3e-7 and (errs <= 2e-6).mean() >= 0.99, (np.median(errs), (errs <= 2e-6).mean(), errs.max())
+    assert np.median(errs) < 3e-7 and errs.max() <= 2e-6 + 1e-5 * 20.0, (np.median(errs), errs.max())
     assert moved > 0.5
     env.close()
 
@@ -493,14 +509,15 @@ def test_point_fall_maze(torch, oracle):
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, _, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
-            errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1))
             assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
-            assert np.all(_close(qpos, s64["qpos"], atol=1e-4), axis=1).mean() >= 0.995 and np.array_equal(t, s64["t"])
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-6, max_outlier_frac=0.004)
+            errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1)[ok])
+            assert np.array_equal(t, s64["t"])
             assert np.all((env.status().cpu().numpy() & ~8) == 0)
             moved = max(moved, np.abs(s64["qpos"][:, 3]).max())
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     errs = np.concatenate(errs)
-    assert np.median(errs) < 3e-7 and (errs <= 2e-6).mean() >= 0.99, (np.median(errs), (errs <= 2e-6).mean(), errs.max())
+    assert np.median(errs) < 3e-7 and errs.max() <= 2e-6 + 1e-5 * 20.0, (np.median(errs), errs.max())
     assert (st["qpos"][:, 4] > 1.5).mean() > 0.9  # the blocks have been expelled onto their platforms (z slide ~ +1.97 for a range of [-2, 0])
     assert moved > 0.05                    # and some robots have pushed theirs along y
     env.close()
@@ -534,8 +551,11 @@ def test_ant_fall_maze(torch, oracle, env_id):
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             # at maze scale 2 the ant straddles the seams between platform boxes and walls all the time (as in the scale-2
             # multi-block mazes): more envs sit on a contact-activation discontinuity, each of them proven on the oracle
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=(0.04 if multi else 0.012) * (2 if k == 1 else 1),
-                                     hard_atol=4e-5 if k == 1 else 2e-5)
+            # caps = 2 x the measured share of envs beyond 1e-5 per checkpoint (profiles/r03/fall_outliers.txt, tools/fall_outliers.py:
+            # at most 5 of 1024 — except k = 1, the step in which the block is being expelled from its platform, 4 m in 0.3 s against a
+            # stiff limit row: 18 (Fall) / 32 (MultiFall) of 1024, none of them beyond 4.2e-5)
+            cap = (0.064 if multi else 0.036) if k == 1 else 0.01
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=cap, hard_atol=4.5e-5 if k == 1 else 2e-5)
             worst.append((np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)[ok])
             assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=4e-5))
             assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
@@ -680,10 +700,12 @@ def test_subgoal_first_match_parity(torch, oracle, env_id):
         else:
             st["qpos"][sel, :2] = xy
     s64 = _f32(st)
+    start = {k: v.copy() for k, v in s64.items()}
     lo, hi = env.action_space.low, env.action_space.high
     act = (0.05 * rng.uniform(lo, hi, (n, env.nu))).astype(np.float32)
     env.set_state(s64["qpos"], s64["qvel"], s64["warm"] if env_id.startswith("Ant") else None, s64["t"])
     obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+    qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
     ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
     gidx = info["goal_index"].cpu().numpy()
     assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(gidx, ref["goal_idx"])
@@ -692,8 +714,9 @@ def test_subgoal_first_match_parity(torch, oracle, env_id):
     o = obs.double().cpu().numpy()
     slot = o[:, 3:6] if object_slot else o[:, :3]
     assert np.array_equal((done.cpu().numpy() & 1).astype(bool), _goal_predicate_f64(task, slot))
-    near = np.all(_close(obs.cpu().numpy(), ref["obs"], atol=2e-5), axis=1)
-    assert near.mean() > 0.97
+    # placed by hand around the goals, ants land on / in walls: every env inside the tolerance or on a discontinuity of the oracle
+    near = _assert_step_parity(oracle, cm, start, act, qpos, qvel, s64, atol=1e-5 if env_id.startswith("Ant") else 2e-6, max_outlier_frac=0.03)
+    assert np.all(_close(obs.cpu().numpy()[near], ref["obs"][near], atol=1e-5))
     inner = rew.cpu().numpy() - np.where(gidx >= 0, np.array([g.reward_scale for g in task.goals] + [0.0])[gidx], task.PENALTY)
     ref_inner = ref["reward"] - np.where(ref["goal_idx"] >= 0, np.array([g.reward_scale for g in task.goals] + [0.0])[ref["goal_idx"]], task.PENALTY)
     assert np.all(np.abs(inner - ref_inner)[near] <= 1e-5)
@@ -701,8 +724,7 @@ def test_subgoal_first_match_parity(torch, oracle, env_id):
 
 
 def test_rollout_tracks_oracle_and_long_run_is_clean(torch, oracle):
-    """(1) 10-step rollouts with identical actions stay close to the float64 oracle for the bulk of the envs
-    (contact dynamics amplify round-off, so this is a statistical statement); (2) 1500 auto-reset steps at the
+    """(1) every step of a 10-step rollout meets the single-step bar from the oracle's state; (2) 1500 auto-reset steps at the
     BASELINE size produce no NaN / overflow status and episode bookkeeping stays consistent."""
     n = 512
     env = mm.make("AntUMaze-v0", num_envs=n)
@@ -711,12 +733,18 @@ def test_rollout_tracks_oracle_and_long_run_is_clean(torch, oracle):
     st = _f32(st)
     env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
     rng = np.random.default_rng(6)
+    # ten consecutive steps of one rollout, the device re-synchronised to the oracle's state before each (trajectories are chaotic:
+    # what can be asserted env by env is every single step of the way)
     for k in range(10):
         act = rng.uniform(-30, 30, (n, 8)).astype(np.float32)
-        obs, *_ = env.step(torch.as_tensor(act, device=env.device))
-        ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
-    err = np.abs(obs.cpu().numpy() - ref["obs"]).max(1)
-    assert np.median(err) < 1e-4 and np.quantile(err, 0.9) < 1e-2, (np.median(err), np.quantile(err, 0.9))
+        s64 = _f32(st)
+        env.set_state(s64["qpos"], s64["qvel"], s64["warm"], s64["t"])
+        env.step(torch.as_tensor(act, device=env.device))
+        qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+        start = {kk: v.copy() for kk, v in s64.items()}
+        oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+        _assert_step_parity(oracle, cm, start, act, qpos, qvel, s64)
+        oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     env.close()
     n = 4096
     env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True)
