@@ -53,6 +53,7 @@ extern "C" {
 #define MZ_ROBOT_POINT 0
 #define MZ_ROBOT_ANT 1
 #define MZ_ROBOT_SWIMMER 2 /* planar link chains: Swimmer (3 links) and Reacher (2 links; reacher.xml is <mujoco model="swimmer">) */
+#define MZ_ROBOT_GENERIC 3 /* a user's AgentModel of any tree topology (agent_model.py:12-41, README.md:127): stepped by walking the compiled tree */
 
 /* joint types (MuJoCo numbering) */
 #define MZ_JNT_FREE 0

@@ -12,8 +12,14 @@ from typing import Optional
 
 
 class AgentModel:
+    """Subclass it for a robot of your own (reference README.md:127): `ROBOT = "generic"`, `FILE` = path (or text) of its MJCF —
+    free / slide / hinge joints, sphere / capsule geoms without self-collision, motors — plus `FRAME_SKIP` and, optionally,
+    `RESET_QVEL` ("normal" | "uniform01" | "uniform_sym": the reset noise of ant.py / point.py / swimmer.py).  Such a robot is
+    stepped on the device by the generic tree kernel (csrc/generic_dyn.h) with the ant's step shape: clamped motors, forward
+    reward |dxy| / dt, control cost; observation qpos | qvel | t / 1000."""
+
     FILE: str
-    ROBOT: str  # key into robots.ROBOTS
+    ROBOT: str  # key into robots.ROBOTS, or "generic"
     MANUAL_COLLISION: bool
     ORI_IND: Optional[int] = None
     RADIUS: Optional[float] = None

@@ -1,0 +1,934 @@
+// generic_dyn.h — MazeEnv.step for a robot of ANY tree topology (a user's AgentModel; reference plugin
+// surface mujoco_maze/agent_model.py:12-41, README.md:127 "you can define your own robot"), as lane-group SPMD code in float64.
+//
+// The specialised kernels (ant_dyn.h, planar_dyn.h, swimmer_dyn.h) hard-wire the reference's four robots.  A robot whose MJCF
+// compiles to another shape — a two-legged ant, a branching swimmer, a hopper — steps here instead of being refused: the
+// kernel walks the kinematic tree of the compiled `mz_model` itself (bodies, joints, dofs, geoms, motors; at most GN_NB bodies,
+// GN_NV dofs).  Slower than the specialised paths by design — tree walks are serial, the mass matrix and the Newton system are
+// dense — but the same physics: what the reference gets from `do_simulation(action, frame_skip)` (ant.py:61-63,
+// swimmer.py:37-39), i.e. frame_skip x mj_step with RK4:
+//   kinematics -> spatial inertias, composite rigid bodies, dense M -> collision (floor plane and maze boxes against the robot's
+//   spheres / capsules; mjc_CapsuleBox as restated in DESIGN.md section 5) -> joint-limit and pyramidal contact rows ->
+//   recursive Newton-Euler bias, joint damping, MuJoCo's inertia-box fluid forces, clamped motors -> qacc_smooth (dense
+//   Cholesky) -> primal Newton with exact line search -> RK4 with manifold quaternion update.
+// One env per lane group; its working set (GenScratch, ~32 KB) lives in LDS for the whole step.  Serial tree walks run on the
+// group's first lane, everything indexed by body / dof / geom / constraint row is an MZ_FOR over the lanes.
+//
+// Scope: robot geoms are spheres and capsules, no robot self-collision (contype / conaffinity must exclude it, as in every
+// reference asset), mazes without movable blocks / balls / platforms — gen_dev_from_model refuses the rest by name.
+#pragma once
+#include "ant_dyn.h"  // MZ_FOR, MZ_HD, HostCtx, TaskDev / MazeDev, task_eval_dev
+
+#define GN_NB 16  // bodies, world included
+#define GN_NJ 20
+#define GN_NV 20
+#define GN_NQ 24
+#define GN_NG 16
+#define GN_NC 16  // simultaneous contacts
+#define GN_NL 20  // joint-limit rows
+#define GN_STAGE 4  // contacts one geom can hold (floor: 2 capsule ends; a wall corner: 2 + 2)
+
+struct GenPair { double margin, gap, mu, K, B, solimp[5]; int condim, pad; };
+
+struct GenDev {
+  mz_model m;   // the compiled model as it is (float64): read with uniform (scalar) loads
+  TaskDev task;
+  MazeDev maze;
+  GenPair pf[GN_NG], pw[GN_NG];  // robot geom g against the floor / against a maze box
+  double lim_K[GN_NJ], lim_B[GN_NJ];
+  int max_iter, ls_iter;
+  double tol, inv_scale;
+  int dof_parent[GN_NV];
+};
+
+static inline int gen_fail(char* err, int n, const char* msg) {
+  if (err && n > 0) { strncpy(err, msg, (size_t)n - 1); err[n - 1] = 0; }
+  return MZ_ERR_UNSUPPORTED;
+}
+
+static inline void gen_pair(GenPair* p, const mz_model* m, const double* f1, const double* sr1, const double* si1, double mg1, double gp1, int cd1,
+                            const double* f2, const double* sr2, const double* si2, double mg2, double gp2, int cd2) {
+  double sr[2], si[5];
+  for (int k = 0; k < 2; k++) sr[k] = 0.5 * (sr1[k] + sr2[k]);
+  for (int k = 0; k < 5; k++) si[k] = 0.5 * (si1[k] + si2[k]);
+  p->margin = fmax(mg1, mg2); p->gap = fmax(gp1, gp2); p->mu = fmax(f1[0], f2[0]);
+  const double tc = fmax(sr[0], 2.0 * m->timestep), dr = sr[1], dmax = si[1];
+  p->K = 1.0 / fmax(1e-15, dmax * dmax * tc * tc * dr * dr);
+  p->B = 2.0 / fmax(1e-15, dmax * tc);
+  for (int k = 0; k < 5; k++) p->solimp[k] = si[k];
+  p->condim = cd1 > cd2 ? cd1 : cd2; p->pad = 0;
+}
+
+static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, int errlen) {
+  memset(g, 0, sizeof(*g));
+  if (m->nbody > GN_NB || m->njnt > GN_NJ || m->nv > GN_NV || m->nq > GN_NQ || m->ngeom > GN_NG)
+    return gen_fail(err, errlen, "generic robot kernel: at most 15 bodies, 20 joints / dofs, 24 coordinates, 16 geoms");
+  if (m->nblock || m->nball || m->elevated || m->top_down_view || m->manual_collision)
+    return gen_fail(err, errlen, "generic robot kernel: mazes with movable blocks, object balls, platforms, a top-down view or the manual wall bounce "
+                                 "are on the device for the built-in robots only");
+  if (m->geom_type[0] != MZ_GEOM_PLANE) return gen_fail(err, errlen, "generic robot kernel: geom 0 must be the floor plane");
+  for (int a = 1; a < m->ngeom; a++) {
+    if (m->geom_type[a] != MZ_GEOM_SPHERE && m->geom_type[a] != MZ_GEOM_CAPSULE)
+      return gen_fail(err, errlen, "generic robot kernel: robot geoms must be spheres or capsules");
+    for (int b = a + 1; b < m->ngeom && !m->collision_predefined; b++) {  // (collision="predefined": no dynamic pairs at all, swimmer.xml:3)
+      const int ba = m->geom_bodyid[a], bb = m->geom_bodyid[b];
+      if (ba == bb || m->body_parent[ba] == bb || m->body_parent[bb] == ba) continue;
+      if ((m->geom_contype[a] & m->geom_conaffinity[b]) || (m->geom_contype[b] & m->geom_conaffinity[a]))
+        return gen_fail(err, errlen, "generic robot kernel: robot self-collision is not implemented (give the robot's geoms conaffinity 0, as the reference assets do)");
+    }
+  }
+  for (int j = 0; j < m->njnt; j++)
+    if (m->jnt_type[j] == MZ_JNT_BALL) return gen_fail(err, errlen, "generic robot kernel: ball joints are not implemented");
+  for (int b = 1; b < m->nbody; b++)
+    if (m->body_parent[b] >= b) return gen_fail(err, errlen, "generic robot kernel: bodies must be listed parents first");
+  g->m = *m;
+  task_dev_from_model(&g->task, m);
+  maze_dev_from_model(&g->maze, m);
+  for (int a = 1; a < m->ngeom; a++) {
+    gen_pair(&g->pf[a], m, m->geom_friction[0], m->geom_solref[0], m->geom_solimp[0], m->geom_margin[0], m->geom_gap[0], m->geom_condim[0],
+             m->geom_friction[a], m->geom_solref[a], m->geom_solimp[a], m->geom_margin[a], m->geom_gap[a], m->geom_condim[a]);
+    gen_pair(&g->pw[a], m, m->geom_friction[a], m->geom_solref[a], m->geom_solimp[a], m->geom_margin[a], m->geom_gap[a], m->geom_condim[a],
+             m->wall_friction, m->wall_solref, m->wall_solimp, m->wall_margin, m->wall_gap, m->wall_condim);
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    const double tc = fmax(m->jnt_solref[j][0], 2.0 * m->timestep), dr = m->jnt_solref[j][1], dmax = m->jnt_solimp[j][1];
+    g->lim_K[j] = 1.0 / fmax(1e-15, dmax * dmax * tc * tc * dr * dr);
+    g->lim_B[j] = 2.0 / fmax(1e-15, dmax * tc);
+  }
+  for (int i = 0; i < m->nv; i++) {  // previous dof up the tree, -1 at a root
+    const int b = m->dof_bodyid[i];
+    int p = -1;
+    if (i > m->body_dofadr[b]) p = i - 1;
+    else
+      for (int a = m->body_parent[b]; a > 0; a = m->body_parent[a])
+        if (m->body_dofnum[a] > 0) { p = m->body_dofadr[a] + m->body_dofnum[a] - 1; break; }
+    g->dof_parent[i] = p;
+  }
+  g->max_iter = 100; g->ls_iter = 50; g->tol = 1e-10;
+  g->inv_scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
+  return MZ_OK;
+}
+
+struct alignas(16) GenScratch {
+  double qpos[GN_NQ], qvel[GN_NV], warm[GN_NV], fact[GN_NV], x0q[GN_NQ], x0v[GN_NV], accv[GN_NV], accf[GN_NV], dxv[GN_NV];
+  double qacc[GN_NV], qas[GN_NV], qfs[GN_NV], bias[GN_NV], passive[GN_NV];
+  double xpos[GN_NB][3], xquat[GN_NB][4], xmat[GN_NB][9], xipos[GN_NB][3];
+  double cinert[GN_NB][10], crb[GN_NB][10], cvel[GN_NB][6], cacc[GN_NB][6], cfrc[GN_NB][6], ffl[GN_NB][6];
+  double xanchor[GN_NJ][3], xaxis[GN_NJ][3];
+  double gpos[GN_NG][3], gmat[GN_NG][9];
+  double S[GN_NV][6], refpoint[3];
+  double M[GN_NV][GN_NV], H[GN_NV][GN_NV];
+  // contacts: staged per geom, then compacted
+  int scnt[GN_NG];
+  double sdist[GN_NG][GN_STAGE], spos[GN_NG][GN_STAGE][3], snrm[GN_NG][GN_STAGE][3], shint[GN_NG][GN_STAGE][3];
+  int skind[GN_NG][GN_STAGE];  // 0: floor (geom1) -> robot geom; 1: robot geom (geom1) -> maze box
+  int ncon, nlim, status, iters;
+  int cgeom[GN_NC], ckind[GN_NC];
+  double cdist[GN_NC], cpos[GN_NC][3], cnrm[GN_NC][3], chint[GN_NC][3];
+  double cJ[GN_NC][3][GN_NV], caref[GN_NC][3], cD[GN_NC], cu[GN_NC][3], cjv[GN_NC][3];
+  int ldof[GN_NL];
+  double lsign[GN_NL], lD[GN_NL], laref[GN_NL], ljar[GN_NL], ljv[GN_NL];
+  double grad[GN_NV], search[GN_NV], Mx[GN_NV], Ms[GN_NV], red[8];
+};
+
+// ------------------------------------------------------------------ small float64 helpers
+MZ_HD double gd_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+MZ_HD void gd_cross(double* r, const double* a, const double* b) {
+  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MZ_HD void gd_mulmat(double* r, const double* m, const double* v) {
+  const double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MZ_HD void gd_mulmatT(double* r, const double* m, const double* v) {
+  const double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MZ_HD void gd_quat_mul(double* r, const double* a, const double* b) {
+  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+MZ_HD void gd_quat_norm(double* q) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < 1e-15) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+MZ_HD void gd_quat2mat(double* m, const double* q) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+MZ_HD void gd_inertia_mul(double* r, const double* I, const double* v) {  // compact spatial inertia [m, h(3), Ibar(6)] times motion vector
+  const double* h = I + 1;
+  const double* J = I + 4;
+  double a[3], b[3];
+  gd_cross(a, h, v + 3);
+  gd_cross(b, v, h);
+  r[0] = J[0] * v[0] + J[3] * v[1] + J[4] * v[2] + a[0];
+  r[1] = J[3] * v[0] + J[1] * v[1] + J[5] * v[2] + a[1];
+  r[2] = J[4] * v[0] + J[5] * v[1] + J[2] * v[2] + a[2];
+  r[3] = I[0] * v[3] + b[0]; r[4] = I[0] * v[4] + b[1]; r[5] = I[0] * v[5] + b[2];
+}
+MZ_HD void gd_motion_cross(double* r, const double* v, const double* s) {
+  double a[3], b[3], c[3];
+  gd_cross(a, v, s); gd_cross(b, v, s + 3); gd_cross(c, v + 3, s);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+MZ_HD void gd_force_cross(double* r, const double* v, const double* f) {
+  double a[3], b[3], c[3];
+  gd_cross(a, v, f); gd_cross(b, v + 3, f + 3); gd_cross(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+MZ_HD double gd_dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+MZ_HD double gd_impedance(const double* si, double x) {
+  const double d0 = si[0], dmax = si[1], width = si[2], mid = si[3], power = si[4];
+  if (d0 == dmax || width <= 1e-15) return 0.5 * (d0 + dmax);
+  const double xn = x / width;
+  if (xn >= 1.0) return dmax;
+  if (xn <= 0.0) return d0;
+  double y;
+  if (power <= 1.0 + 1e-12) y = xn;
+  else if (xn <= mid) y = pow(xn, power) / pow(mid, power - 1.0);
+  else y = 1.0 - pow(1.0 - xn, power) / pow(1.0 - mid, power - 1.0);
+  return d0 + y * (dmax - d0);
+}
+
+// ------------------------------------------------------------------ kinematics (serial: parents before children)
+MZ_HD void gen_kinematics(const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  for (int k = 0; k < 3; k++) s.xpos[0][k] = 0.0;
+  s.xquat[0][0] = 1.0; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.0;
+  gd_quat2mat(s.xmat[0], s.xquat[0]);
+  for (int b = 1; b < m.nbody; b++) {
+    const int p = m.body_parent[b], j0 = m.body_jntadr[b], jn = m.body_jntnum[b];
+    double pos[3], quat[4];
+    if (jn == 1 && m.jnt_type[j0] == MZ_JNT_FREE) {
+      const int qa = m.jnt_qposadr[j0];
+      for (int k = 0; k < 3; k++) pos[k] = s.qpos[qa + k];
+      for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
+      gd_quat_norm(quat);
+      for (int k = 0; k < 3; k++) { s.xanchor[j0][k] = pos[k]; s.xaxis[j0][k] = m.jnt_axis[j0][k]; }
+    } else {
+      double t[3];
+      gd_mulmat(t, s.xmat[p], m.body_pos[b]);
+      for (int k = 0; k < 3; k++) pos[k] = s.xpos[p][k] + t[k];
+      gd_quat_mul(quat, s.xquat[p], m.body_quat[b]);
+      for (int j = j0; j < j0 + jn; j++) {
+        double mat[9], axis[3], anchor[3];
+        gd_quat2mat(mat, quat);
+        gd_mulmat(axis, mat, m.jnt_axis[j]);
+        gd_mulmat(anchor, mat, m.jnt_pos[j]);
+        for (int k = 0; k < 3; k++) anchor[k] += pos[k];
+        const double q = s.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]];
+        if (m.jnt_type[j] == MZ_JNT_SLIDE) {
+          for (int k = 0; k < 3; k++) pos[k] += axis[k] * q;
+        } else {  // hinge: rotate about the joint axis through the anchor
+          const double sh = sin(0.5 * q), ql[4] = {cos(0.5 * q), m.jnt_axis[j][0] * sh, m.jnt_axis[j][1] * sh, m.jnt_axis[j][2] * sh};
+          double qn[4], v[3];
+          gd_quat_mul(qn, quat, ql);
+          for (int k = 0; k < 4; k++) quat[k] = qn[k];
+          gd_quat2mat(mat, quat);
+          gd_mulmat(v, mat, m.jnt_pos[j]);
+          for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
+        }
+        for (int k = 0; k < 3; k++) { s.xaxis[j][k] = axis[k]; s.xanchor[j][k] = anchor[k]; }
+      }
+    }
+    gd_quat_norm(quat);
+    for (int k = 0; k < 3; k++) s.xpos[b][k] = pos[k];
+    for (int k = 0; k < 4; k++) s.xquat[b][k] = quat[k];
+    gd_quat2mat(s.xmat[b], quat);
+    double t[3];
+    gd_mulmat(t, s.xmat[b], m.body_ipos[b]);
+    for (int k = 0; k < 3; k++) s.xipos[b][k] = s.xpos[b][k] + t[k];
+  }
+  for (int k = 0; k < 3; k++) s.refpoint[k] = s.xpos[1][k];
+}
+
+// geom poses, motion axes, body spatial inertias about the reference point (one item per geom / joint / body)
+MZ_HD void gen_geom_item(const GenDev& K, GenScratch& s, int g) {
+  const mz_model& m = K.m;
+  const int b = m.geom_bodyid[g];
+  double t[3], q[4];
+  gd_mulmat(t, s.xmat[b], m.geom_pos[g]);
+  for (int k = 0; k < 3; k++) s.gpos[g][k] = s.xpos[b][k] + t[k];
+  gd_quat_mul(q, s.xquat[b], m.geom_quat[g]);
+  gd_quat2mat(s.gmat[g], q);
+}
+MZ_HD void gen_axis_item(const GenDev& K, GenScratch& s, int j) {
+  const mz_model& m = K.m;
+  const int b = m.jnt_bodyid[j], d0 = m.jnt_dofadr[j];
+  const double* c = s.refpoint;
+  double off[3];
+  if (m.jnt_type[j] == MZ_JNT_FREE) {
+    for (int k = 0; k < 3; k++) {
+      for (int e = 0; e < 6; e++) s.S[d0 + k][e] = 0.0;
+      s.S[d0 + k][3 + k] = 1.0;
+      const double ax[3] = {s.xmat[b][k], s.xmat[b][3 + k], s.xmat[b][6 + k]};
+      for (int e = 0; e < 3; e++) { off[e] = c[e] - s.xpos[b][e]; s.S[d0 + 3 + k][e] = ax[e]; }
+      gd_cross(s.S[d0 + 3 + k] + 3, ax, off);
+    }
+  } else if (m.jnt_type[j] == MZ_JNT_SLIDE) {
+    for (int e = 0; e < 3; e++) { s.S[d0][e] = 0.0; s.S[d0][3 + e] = s.xaxis[j][e]; }
+  } else {
+    for (int e = 0; e < 3; e++) { off[e] = c[e] - s.xanchor[j][e]; s.S[d0][e] = s.xaxis[j][e]; }
+    gd_cross(s.S[d0] + 3, s.xaxis[j], off);
+  }
+}
+MZ_HD void gen_inertia_item(const GenDev& K, GenScratch& s, int b) {
+  const mz_model& m = K.m;
+  const double* I6 = m.body_inertia[b];
+  const double Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+  const double* R = s.xmat[b];
+  double tmp[9], Iw[9], r[3];
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) tmp[3 * i + k] = R[3 * i] * Ib[k] + R[3 * i + 1] * Ib[3 + k] + R[3 * i + 2] * Ib[6 + k];
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) Iw[3 * i + k] = tmp[3 * i] * R[3 * k] + tmp[3 * i + 1] * R[3 * k + 1] + tmp[3 * i + 2] * R[3 * k + 2];
+  for (int k = 0; k < 3; k++) r[k] = s.xipos[b][k] - s.refpoint[k];
+  const double ms = m.body_mass[b], rr = gd_dot3(r, r);
+  double* I = s.cinert[b];
+  I[0] = ms; I[1] = ms * r[0]; I[2] = ms * r[1]; I[3] = ms * r[2];
+  I[4] = Iw[0] + ms * (rr - r[0] * r[0]); I[5] = Iw[4] + ms * (rr - r[1] * r[1]); I[6] = Iw[8] + ms * (rr - r[2] * r[2]);
+  I[7] = Iw[1] - ms * r[0] * r[1]; I[8] = Iw[2] - ms * r[0] * r[2]; I[9] = Iw[5] - ms * r[1] * r[2];
+  for (int k = 0; k < 10; k++) s.crb[b][k] = I[k];
+}
+// row i of the joint-space inertia: M[i][j] for the dofs j on the path from i to its root
+MZ_HD void gen_mass_item(const GenDev& K, GenScratch& s, int i) {
+  const mz_model& m = K.m;
+  double F[6];
+  for (int j = 0; j < m.nv; j++) s.M[i][j] = 0.0;
+  gd_inertia_mul(F, s.crb[m.dof_bodyid[i]], s.S[i]);
+  s.M[i][i] = gd_dot6(s.S[i], F) + m.dof_armature[i];
+  for (int j = K.dof_parent[i]; j >= 0; j = K.dof_parent[j]) s.M[i][j] = gd_dot6(s.S[j], F);
+}
+
+// ------------------------------------------------------------------ collision
+// sphere (centre c in box coordinates) vs axis-aligned box; normal from the sphere to the box (mjraw_SphereBox)
+MZ_HD bool gen_sphere_box(const double* c, double r, const double* bs, double margin, double* dist, double* pos, double* nrm) {
+  double q[3], dd;
+  bool inside = true;
+  for (int k = 0; k < 3; k++) { q[k] = fmin(fmax(c[k], -bs[k]), bs[k]); if (q[k] != c[k]) inside = false; }
+  if (!inside) {
+    const double v[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+    dd = sqrt(gd_dot3(v, v));
+    if (dd - r > margin) return false;
+    for (int k = 0; k < 3; k++) nrm[k] = v[k] / dd;
+    dd -= r;
+  } else {
+    int kb = 0; double best = 1e30;
+    for (int k = 0; k < 3; k++) { const double e = bs[k] - fabs(c[k]); if (e < best) { best = e; kb = k; } }
+    nrm[0] = nrm[1] = nrm[2] = 0.0;
+    nrm[kb] = c[kb] >= 0.0 ? -1.0 : 1.0;
+    dd = -best - r;
+  }
+  *dist = dd;
+  for (int k = 0; k < 3; k++) pos[k] = c[k] + nrm[k] * (r + 0.5 * dd);
+  return dd <= margin;
+}
+
+// capsule (centre cl in box coordinates, half axis h = geom z * half length) vs axis-aligned box: mjc_CapsuleBox as restated in
+// oracle/mzo_physics.c capsule_box — the literal feature search (two segment ends against the faces, then the twelve edges).
+// Returns the closest segment parameter t in [-1, 1] and the offset of the second sphere (0: none).
+MZ_HD void gen_capsule_box_features(const double* pos, const double* halfaxis, double hl, const double* bsize, double margin, double r,
+                                    bool* found, double* t_out, double* second) {
+  const double axis[3] = {halfaxis[0] / hl, halfaxis[1] / hl, halfaxis[2] / hl};
+  const int axisdir = (halfaxis[0] > 0 ? 1 : 0) + (halfaxis[1] > 0 ? 2 : 0) + (halfaxis[2] > 0 ? 4 : 0);
+  const double bestdistmax = margin + 2.0 * (r + hl + bsize[0] + bsize[1] + bsize[2]);
+  double bestdist = bestdistmax * bestdistmax, bestsegmentpos = 0.0, bestboxpos = 0.0, secondpos = -4.0;
+  int cltype = -4, clface = -1, clcorner = 0, cledge = -1;
+  for (int i = -1; i <= 1; i += 2) {
+    int nout = 0, face = -1;
+    double dist = 0.0;
+    for (int k = 0; k < 3; k++) {
+      const double e = pos[k] + halfaxis[k] * i;
+      if (e < -bsize[k]) { nout++; face = k; dist += (e + bsize[k]) * (e + bsize[k]); }
+      else if (e > bsize[k]) { nout++; face = k; dist += (e - bsize[k]) * (e - bsize[k]); }
+    }
+    if (nout > 1) continue;
+    if (dist < bestdist) { bestdist = dist; bestsegmentpos = i; cltype = -2 + i; clface = face; }
+  }
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 3; j++) {
+      if (i & (1 << j)) continue;
+      double mid[3] = {(i & 1 ? 1 : -1) * bsize[0], (i & 2 ? 1 : -1) * bsize[1], (i & 4 ? 1 : -1) * bsize[2]}, dif[3];
+      mid[j] = 0.0;
+      for (int k = 0; k < 3; k++) dif[k] = mid[k] - pos[k];
+      const double u = -bsize[j] * dif[j], v = gd_dot3(halfaxis, dif);
+      const double ma = bsize[j] * bsize[j], mb = -bsize[j] * halfaxis[j], mc = hl * hl, det = ma * mc - mb * mb;
+      if (fabs(det) < 1e-15) continue;
+      double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+      int s1 = 1, s2 = 1;
+      if (x1 > 1) { x1 = 1; s1 = 2; x2 = (v - mb) / mc; }
+      else if (x1 < -1) { x1 = -1; s1 = 0; x2 = (v + mb) / mc; }
+      if (x2 > 1) { x2 = 1; s2 = 2; x1 = (u - mb) / ma; if (x1 > 1) { x1 = 1; s1 = 2; } else if (x1 < -1) { x1 = -1; s1 = 0; } else s1 = 1; }
+      else if (x2 < -1) { x2 = -1; s2 = 0; x1 = (u + mb) / ma; if (x1 > 1) { x1 = 1; s1 = 2; } else if (x1 < -1) { x1 = -1; s1 = 0; } else s1 = 1; }
+      for (int k = 0; k < 3; k++) dif[k] = mid[k] - (pos[k] + halfaxis[k] * x2);
+      dif[j] += bsize[j] * x1;
+      const double dist = gd_dot3(dif, dif);
+      if (dist < bestdist - 1e-15) {
+        bestdist = dist; bestsegmentpos = x2; bestboxpos = x1;
+        cltype = 3 * s1 + s2; clcorner = i + (s1 == 2 ? (1 << j) : 0); cledge = j;
+      }
+    }
+  *found = cltype != -4;
+  if (cltype == -4) return;
+  if (cltype >= 0 && cltype / 3 != 1) {
+    int c1 = axisdir ^ clcorner;
+    if (c1 != 0 && c1 != 7) {
+      double mul = 1.0;
+      if (!(c1 == 1 || c1 == 2 || c1 == 4)) { mul = -1.0; c1 = 7 - c1; }
+      const int ax = c1 == 1 ? 0 : (c1 == 2 ? 1 : 2), ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (axis[ax] * axis[ax] > 0.5) secondpos = mul * fmin(1.0 - mul * bestsegmentpos, 2.0 * bsize[ax] / fabs(halfaxis[ax]));
+      else secondpos = -mul * fmin(1.0 + mul * bestsegmentpos, fmin(2.0 * bsize[ax1] / fabs(halfaxis[ax1]), 2.0 * bsize[ax2] / fabs(halfaxis[ax2])));
+    }
+  } else if (cltype >= 0) {
+    const int c1 = (axisdir ^ clcorner) & (7 - (1 << cledge));
+    if (c1 == 1 || c1 == 2 || c1 == 4) {
+      const int ax = cledge;
+      int ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (fabs(axis[ax1]) > fabs(axis[ax2])) { const int q = ax1; ax1 = ax2; ax2 = q; }
+      const double mul = (c1 & (1 << ax2)) ? 1.0 : -1.0;
+      double sp = fmin(1.0 - mul * bestsegmentpos, 2.0 * bsize[ax2] / fabs(halfaxis[ax2]));
+      const double e2 = (mul * halfaxis[ax] > 0) ? 1.0 - bestboxpos : 1.0 + bestboxpos;
+      sp = fmin(sp, bsize[ax] * e2 / fabs(halfaxis[ax]));
+      secondpos = mul * sp;
+    }
+  } else {
+    const double travel = -2.0 * bestsegmentpos;
+    double frac = 1.0;
+    for (int k = 0; k < 3; k++) {
+      if (k == clface) continue;
+      const double p0 = pos[k] + halfaxis[k] * bestsegmentpos, v = halfaxis[k] * travel;
+      if (v > 0 && p0 + v > bsize[k]) frac = fmin(frac, (bsize[k] - p0) / v);
+      if (v < 0 && p0 + v < -bsize[k]) frac = fmin(frac, (-bsize[k] - p0) / v);
+    }
+    secondpos = travel * fmax(frac, 0.0);
+  }
+  *t_out = bestsegmentpos;
+  *second = (secondpos > -3.0 && fabs(secondpos) > 1e-12) ? secondpos : 0.0;
+}
+
+// contacts of robot geom g into its staging entry: the floor plane (geom1 = floor), then the maze boxes under its bounding
+// square in row-major cell order (geom1 = the robot geom) — the oracle's pair order
+MZ_HD void gen_collide_item(const GenDev& K, GenScratch& s, int g) {
+  const mz_model& m = K.m;
+  int n = 0;
+  auto put = [&](int kind, double dist, const double* pos, const double* nrm, const double* hint) {
+    if (n < GN_STAGE) {
+      s.sdist[g][n] = dist; s.skind[g][n] = kind;
+      for (int k = 0; k < 3; k++) { s.spos[g][n][k] = pos[k]; s.snrm[g][n][k] = nrm[k]; s.shint[g][n][k] = hint ? hint[k] : 0.0; }
+    }
+    n++;
+  };
+  if (m.collision_predefined || m.geom_bodyid[g] == 0) { s.scnt[g] = 0; return; }
+  const double* gp = s.gpos[g];
+  const double* gm = s.gmat[g];
+  const double r = m.geom_size[g][0], hl = m.geom_type[g] == MZ_GEOM_CAPSULE ? m.geom_size[g][1] : 0.0;
+  const double axis[3] = {gm[2], gm[5], gm[8]};
+  if ((m.geom_contype[0] & m.geom_conaffinity[g]) || (m.geom_contype[g] & m.geom_conaffinity[0])) {  // floor plane (geom 0)
+    const double* pm = s.gmat[0];
+    const double nz[3] = {pm[2], pm[5], pm[8]};
+    const int nend = m.geom_type[g] == MZ_GEOM_CAPSULE ? 2 : 1;
+    for (int e = 0; e < nend; e++) {
+      const double sg = nend == 1 ? 0.0 : (e == 0 ? 1.0 : -1.0);
+      double c[3], rel[3], pos[3];
+      for (int k = 0; k < 3; k++) { c[k] = gp[k] + sg * axis[k] * hl; rel[k] = c[k] - s.gpos[0][k]; }
+      const double dist = gd_dot3(rel, nz) - r;
+      if (dist > K.pf[g].margin) continue;
+      for (int k = 0; k < 3; k++) pos[k] = c[k] - nz[k] * (r + 0.5 * dist);
+      put(0, dist, pos, nz, nend == 2 ? axis : nullptr);
+    }
+  }
+  if ((m.geom_contype[g] & m.wall_conaffinity) || (m.wall_contype & m.geom_conaffinity[g])) {
+    const double sc = m.maze_scale, reach = m.geom_rbound[g] + K.pw[g].margin, margin = K.pw[g].margin;
+    if (!(gp[2] - reach > m.wall_center_z + m.wall_half_z) && !(gp[2] + reach < m.wall_center_z - m.wall_half_z)) {
+      const int j0 = (int)floor((gp[0] - reach + m.torso_x) / sc + 0.5), j1 = (int)floor((gp[0] + reach + m.torso_x) / sc + 0.5);
+      const int i0 = (int)floor((gp[1] - reach + m.torso_y) / sc + 0.5), i1 = (int)floor((gp[1] + reach + m.torso_y) / sc + 0.5);
+      const double bs[3] = {m.wall_half_xy, m.wall_half_xy, m.wall_half_z};
+      for (int i = i0; i <= i1; i++)
+        for (int j = j0; j <= j1; j++) {
+          if (i < 0 || j < 0 || i >= m.grid_rows || j >= m.grid_cols || m.grid[i][j] != MZ_CELL_BLOCK) continue;
+          const double bpos[3] = {j * sc - m.torso_x, i * sc - m.torso_y, m.wall_center_z};
+          const double cl[3] = {gp[0] - bpos[0], gp[1] - bpos[1], gp[2] - bpos[2]};
+          double dist, pos[3], nrm[3];
+          if (m.geom_type[g] == MZ_GEOM_SPHERE) {
+            if (gen_sphere_box(cl, r, bs, margin, &dist, pos, nrm)) { for (int k = 0; k < 3; k++) pos[k] += bpos[k]; put(1, dist, pos, nrm, nullptr); }
+            continue;
+          }
+          const double h[3] = {axis[0] * hl, axis[1] * hl, axis[2] * hl};
+          bool found; double t = 0.0, second = 0.0;
+          gen_capsule_box_features(cl, h, hl, bs, margin, r, &found, &t, &second);
+          if (!found) continue;
+          for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && second == 0.0) break;
+            const double tt = t + (pass ? second : 0.0), c[3] = {cl[0] + tt * h[0], cl[1] + tt * h[1], cl[2] + tt * h[2]};
+            if (gen_sphere_box(c, r, bs, margin, &dist, pos, nrm)) { for (int k = 0; k < 3; k++) pos[k] += bpos[k]; put(1, dist, pos, nrm, nullptr); }
+          }
+        }
+    }
+  }
+  s.scnt[g] = n;
+}
+
+// staging -> compact list (serial: prefix sums), then one item per (contact, row): frame, Jacobian, reference acceleration
+MZ_HD void gen_compact_contacts(const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  int c = 0;
+  for (int g = 1; g < m.ngeom; g++) {
+    if (s.scnt[g] > GN_STAGE) s.status |= MZ_STATUS_CONTACT_OVERFLOW;
+    for (int k = 0; k < s.scnt[g] && k < GN_STAGE; k++) {
+      const GenPair& P = s.skind[g][k] == 0 ? K.pf[g] : K.pw[g];
+      if (!(s.sdist[g][k] < P.margin - P.gap)) continue;  // not active: no row
+      if (c >= GN_NC) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; continue; }
+      s.cgeom[c] = g; s.ckind[c] = s.skind[g][k]; s.cdist[c] = s.sdist[g][k];
+      for (int e = 0; e < 3; e++) { s.cpos[c][e] = s.spos[g][k][e]; s.cnrm[c][e] = s.snrm[g][k][e]; s.chint[c][e] = s.shint[g][k][e]; }
+      c++;
+    }
+  }
+  s.ncon = c;
+  // joint limits (hinge / slide)
+  int nl = 0;
+  for (int j = 0; j < m.njnt; j++) {
+    if (!m.jnt_limited[j] || (m.jnt_type[j] != MZ_JNT_HINGE && m.jnt_type[j] != MZ_JNT_SLIDE)) continue;
+    const double q = s.qpos[m.jnt_qposadr[j]];
+    for (int side = -1; side <= 1; side += 2) {
+      const double dist = side < 0 ? q - m.jnt_range[j][0] : m.jnt_range[j][1] - q;
+      if (!(dist < m.jnt_margin[j]) || nl >= GN_NL) continue;
+      const int dof = m.jnt_dofadr[j];
+      const double imp = gd_impedance(m.jnt_solimp[j], fabs(dist - m.jnt_margin[j]));
+      const double R = fmax(1e-15, (1.0 - imp) * m.dof_invweight0[dof] / imp), sg = -(double)side;
+      s.ldof[nl] = dof; s.lsign[nl] = sg; s.lD[nl] = 1.0 / R;
+      s.laref[nl] = -K.lim_B[j] * (sg * s.qvel[dof]) - K.lim_K[j] * imp * (dist - m.jnt_margin[j]);
+      nl++;
+    }
+  }
+  s.nlim = nl;
+}
+
+MZ_HD void gen_contact_row_item(const GenDev& K, GenScratch& s, int item) {
+  const mz_model& m = K.m;
+  const int c = item / 3, a = item - 3 * c, g = s.cgeom[c], kind = s.ckind[c];
+  const GenPair& P = kind == 0 ? K.pf[g] : K.pw[g];
+  // frame (mju_makeFrame): the normal, a tangent from the hint (capsule axis for capsule-plane) or the default rule
+  double n[3] = {s.cnrm[c][0], s.cnrm[c][1], s.cnrm[c][2]}, y[3] = {s.chint[c][0], s.chint[c][1], s.chint[c][2]}, t1[3], t2[3];
+  {
+    const double nn = sqrt(gd_dot3(n, n));
+    for (int k = 0; k < 3; k++) n[k] /= nn;
+    if (sqrt(gd_dot3(y, y)) < 0.5) { y[0] = 0.0; y[1] = (n[1] < 0.5 && n[1] > -0.5) ? 1.0 : 0.0; y[2] = 1.0 - y[1]; }
+    double d = gd_dot3(n, y);
+    for (int k = 0; k < 3; k++) y[k] -= n[k] * d;
+    double yn = sqrt(gd_dot3(y, y));
+    if (yn < 1e-10) {
+      y[0] = 0.0; y[1] = (n[1] < 0.5 && n[1] > -0.5) ? 1.0 : 0.0; y[2] = 1.0 - y[1];
+      d = gd_dot3(n, y);
+      for (int k = 0; k < 3; k++) y[k] -= n[k] * d;
+      yn = sqrt(gd_dot3(y, y));
+    }
+    for (int k = 0; k < 3; k++) t1[k] = y[k] / yn;
+    gd_cross(t2, n, t1);
+  }
+  const double* dir = a == 0 ? n : (a == 1 ? t1 : t2);
+  const double sc = a == 0 ? 1.0 : P.mu;
+  // the contact force acts on geom2: the robot for a floor contact (+), the maze box for a wall contact (robot = geom1: -)
+  const double sgn = kind == 0 ? 1.0 : -1.0;
+  double off[3], J[GN_NV];
+  for (int k = 0; k < 3; k++) off[k] = s.cpos[c][k] - s.refpoint[k];
+  for (int i = 0; i < m.nv; i++) J[i] = 0.0;
+  for (int b = m.geom_bodyid[g]; b > 0; b = m.body_parent[b])
+    for (int i = m.body_dofadr[b]; i >= 0 && i < m.body_dofadr[b] + m.body_dofnum[b]; i++) {
+      double wx[3];
+      gd_cross(wx, s.S[i], off);
+      J[i] = sgn * sc * ((s.S[i][3] + wx[0]) * dir[0] + (s.S[i][4] + wx[1]) * dir[1] + (s.S[i][5] + wx[2]) * dir[2]);
+    }
+  double vel = 0.0;
+  for (int i = 0; i < m.nv; i++) { s.cJ[c][a][i] = J[i]; vel += J[i] * s.qvel[i]; }
+  double aref = -P.B * vel;
+  if (a == 0) {
+    const double imp = gd_impedance(P.solimp, fabs(s.cdist[c] - (P.margin - P.gap)));
+    const int b = m.geom_bodyid[g];
+    const double tran = m.body_invweight0[b][0] + m.body_invweight0[0][0];
+    if (P.condim == 1) {
+      s.cD[c] = -1.0 / fmax(1e-15, (1.0 - imp) * tran / imp);  // (negative: a single frictionless row, see gen_contact_eval)
+    } else {
+      const double R = fmax(1e-15, (1.0 - imp) * (tran + P.mu * P.mu * tran) / imp);
+      s.cD[c] = 1.0 / (2.0 * P.mu * P.mu * R);
+    }
+    aref -= P.K * imp * (s.cdist[c] - (P.margin - P.gap));
+  }
+  s.caref[c][a] = aref;
+}
+
+// pyramidal contact rows u0 +- u1, u0 +- u2 (D > 0) or the single frictionless row u0 (stored as D < 0): cost, gradient block
+// g[3] and curvature block W[5] (W0 = d2/du0^2, W1 = du0du1, W2 = du0du2, W3 = du1^2, W4 = du2^2)
+MZ_HD double gen_contact_eval(double D, const double* u, double* g, double* W) {
+  if (D < 0.0) {
+    const double Dm = -D, act = u[0] < 0.0 ? 1.0 : 0.0;
+    if (g) { g[0] = Dm * act * u[0]; g[1] = 0.0; g[2] = 0.0; }
+    if (W) { W[0] = Dm * act; W[1] = W[2] = W[3] = W[4] = 0.0; }
+    return 0.5 * Dm * act * u[0] * u[0];
+  }
+  const double r0 = u[0] + u[1], r1 = u[0] - u[1], r2 = u[0] + u[2], r3 = u[0] - u[2];
+  const double a0 = r0 < 0.0 ? 1.0 : 0.0, a1 = r1 < 0.0 ? 1.0 : 0.0, a2 = r2 < 0.0 ? 1.0 : 0.0, a3 = r3 < 0.0 ? 1.0 : 0.0;
+  if (g) { g[0] = D * (a0 * r0 + a1 * r1 + a2 * r2 + a3 * r3); g[1] = D * (a0 * r0 - a1 * r1); g[2] = D * (a2 * r2 - a3 * r3); }
+  if (W) { W[0] = D * (a0 + a1 + a2 + a3); W[1] = D * (a0 - a1); W[2] = D * (a2 - a3); W[3] = D * (a0 + a1); W[4] = D * (a2 + a3); }
+  return 0.5 * D * (a0 * r0 * r0 + a1 * r1 * r1 + a2 * r2 * r2 + a3 * r3 * r3);
+}
+MZ_HD bool gen_rows_flip(double D, const double* u, const double* w) {  // does any row change its active state between u and w?
+  if (D < 0.0) return (u[0] < 0.0) != (w[0] < 0.0);
+  return ((u[0] + u[1] < 0.0) != (w[0] + w[1] < 0.0)) || ((u[0] - u[1] < 0.0) != (w[0] - w[1] < 0.0)) || ((u[0] + u[2] < 0.0) != (w[0] + w[2] < 0.0)) ||
+         ((u[0] - u[2] < 0.0) != (w[0] - w[2] < 0.0));
+}
+MZ_HD void gen_rows_slope(double D, const double* u, const double* v, double alpha, double* d1, double* d2) {  // phi'(alpha), phi''(alpha) terms
+  const double x0 = u[0] + alpha * v[0], x1 = u[1] + alpha * v[1], x2 = u[2] + alpha * v[2];
+  if (D < 0.0) { if (x0 < 0.0) { *d1 += -D * x0 * v[0]; *d2 += -D * v[0] * v[0]; } return; }
+  double r, w;
+  r = x0 + x1; w = v[0] + v[1]; if (r < 0.0) { *d1 += D * r * w; *d2 += D * w * w; }
+  r = x0 - x1; w = v[0] - v[1]; if (r < 0.0) { *d1 += D * r * w; *d2 += D * w * w; }
+  r = x0 + x2; w = v[0] + v[2]; if (r < 0.0) { *d1 += D * r * w; *d2 += D * w * w; }
+  r = x0 - x2; w = v[0] - v[2]; if (r < 0.0) { *d1 += D * r * w; *d2 += D * w * w; }
+}
+
+// ------------------------------------------------------------------ velocities, bias (RNE), passive (damping + fluid), actuation
+MZ_HD void gen_rne_serial(const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  for (int e = 0; e < 6; e++) { s.cvel[0][e] = 0.0; s.cacc[0][e] = 0.0; }
+  s.cacc[0][3] = -m.gravity[0]; s.cacc[0][4] = -m.gravity[1]; s.cacc[0][5] = -m.gravity[2];
+  for (int b = 1; b < m.nbody; b++) {
+    const int p = m.body_parent[b], j0 = m.body_jntadr[b];
+    double v[6], a[6];
+    for (int e = 0; e < 6; e++) { v[e] = s.cvel[p][e]; a[e] = s.cacc[p][e]; }
+    for (int j = j0; j < j0 + m.body_jntnum[b]; j++) {
+      const int d0 = m.jnt_dofadr[j];
+      if (m.jnt_type[j] == MZ_JNT_FREE) {
+        for (int k = 0; k < 3; k++)
+          for (int e = 0; e < 6; e++) v[e] += s.S[d0 + k][e] * s.qvel[d0 + k];
+        double sd[3][6];
+        for (int k = 0; k < 3; k++) gd_motion_cross(sd[k], v, s.S[d0 + 3 + k]);
+        for (int k = 0; k < 3; k++)
+          for (int e = 0; e < 6; e++) { a[e] += sd[k][e] * s.qvel[d0 + 3 + k]; v[e] += s.S[d0 + 3 + k][e] * s.qvel[d0 + 3 + k]; }
+      } else {
+        double sd[6];
+        gd_motion_cross(sd, v, s.S[d0]);
+        for (int e = 0; e < 6; e++) { a[e] += sd[e] * s.qvel[d0]; v[e] += s.S[d0][e] * s.qvel[d0]; }
+      }
+    }
+    double Ia[6], Iv[6], vf[6];
+    gd_inertia_mul(Ia, s.cinert[b], a);
+    gd_inertia_mul(Iv, s.cinert[b], v);
+    gd_force_cross(vf, v, Iv);
+    for (int e = 0; e < 6; e++) { s.cvel[b][e] = v[e]; s.cacc[b][e] = a[e]; s.cfrc[b][e] = Ia[e] + vf[e]; }
+  }
+  for (int b = m.nbody - 1; b >= 1; b--) {
+    const int p = m.body_parent[b];
+    if (p > 0) for (int e = 0; e < 6; e++) s.cfrc[p][e] += s.cfrc[b][e];
+  }
+}
+// MuJoCo's inertia-box fluid model (option density / viscosity; swimmer.xml:3): wrench of body b about the reference point
+MZ_HD void gen_fluid_item(const GenDev& K, GenScratch& s, int b) {
+  const mz_model& m = K.m;
+  for (int e = 0; e < 6; e++) s.ffl[b][e] = 0.0;
+  const double mass = m.body_mass[b];
+  if (b == 0 || mass < 1e-15 || !(m.density > 0.0 || m.viscosity > 0.0)) return;
+  const double* I6 = m.body_inertia[b];
+  const double I[3] = {I6[0], I6[1], I6[2]};
+  const double bx[3] = {sqrt(fmax(1e-15, I[1] + I[2] - I[0]) / mass * 6.0), sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / mass * 6.0),
+                        sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / mass * 6.0)};
+  const double w[3] = {s.cvel[b][0], s.cvel[b][1], s.cvel[b][2]};
+  double r[3], wr[3], vc[3], lw[3], lv[3];
+  for (int k = 0; k < 3; k++) r[k] = s.xipos[b][k] - s.refpoint[k];
+  gd_cross(wr, w, r);
+  for (int k = 0; k < 3; k++) vc[k] = s.cvel[b][3 + k] + wr[k];
+  gd_mulmatT(lw, s.xmat[b], w);
+  gd_mulmatT(lv, s.xmat[b], vc);
+  double lf[3] = {0, 0, 0}, lt[3] = {0, 0, 0};
+  const double pi = 3.14159265358979323846;
+  if (m.viscosity > 0.0) {
+    const double diam = (bx[0] + bx[1] + bx[2]) / 3.0, sv = -3.0 * m.viscosity * pi * diam, tv = -m.viscosity * pi * diam * diam * diam;
+    for (int k = 0; k < 3; k++) { lf[k] += sv * lv[k]; lt[k] += tv * lw[k]; }
+  }
+  if (m.density > 0.0) {
+    lf[0] -= 0.5 * m.density * bx[1] * bx[2] * fabs(lv[0]) * lv[0];
+    lf[1] -= 0.5 * m.density * bx[0] * bx[2] * fabs(lv[1]) * lv[1];
+    lf[2] -= 0.5 * m.density * bx[0] * bx[1] * fabs(lv[2]) * lv[2];
+    auto p4 = [](double x) { return x * x * x * x; };
+    lt[0] -= m.density * bx[0] * (p4(bx[1]) + p4(bx[2])) * fabs(lw[0]) * lw[0] / 64.0;
+    lt[1] -= m.density * bx[1] * (p4(bx[0]) + p4(bx[2])) * fabs(lw[1]) * lw[1] / 64.0;
+    lt[2] -= m.density * bx[2] * (p4(bx[0]) + p4(bx[1])) * fabs(lw[2]) * lw[2] / 64.0;
+  }
+  double f[3], t[3], rf[3];
+  gd_mulmat(f, s.xmat[b], lf);
+  gd_mulmat(t, s.xmat[b], lt);
+  gd_cross(rf, r, f);
+  for (int k = 0; k < 3; k++) { s.ffl[b][k] = t[k] + rf[k]; s.ffl[b][3 + k] = f[k]; }
+}
+MZ_HD void gen_force_item(const GenDev& K, GenScratch& s, int i) {
+  const mz_model& m = K.m;
+  const double bias = gd_dot6(s.S[i], s.cfrc[m.dof_bodyid[i]]);
+  double pas = -m.dof_damping[i] * s.qvel[i];
+  if (m.density > 0.0 || m.viscosity > 0.0)
+    for (int b = 1; b < m.nbody; b++) {  // dof i moves body b iff body(i) is b or an ancestor of b
+      bool hit = false;
+      for (int a = b; a > 0; a = m.body_parent[a]) if (a == m.dof_bodyid[i]) { hit = true; break; }
+      if (hit) pas += gd_dot6(s.S[i], s.ffl[b]);
+    }
+  s.bias[i] = bias; s.passive[i] = pas;
+  s.qfs[i] = pas - bias + s.fact[i];
+}
+
+// dense Cholesky + solve on one lane (A = L L^T in the lower triangle of H)
+MZ_HD bool gen_chol_solve(double (*A)[GN_NV], int n, double* x) {
+  for (int j = 0; j < n; j++) {
+    double d = A[j][j];
+    for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+    if (d < 1e-15) return false;
+    A[j][j] = sqrt(d);
+    for (int i = j + 1; i < n; i++) {
+      double t = A[i][j];
+      for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
+      A[i][j] = t / A[j][j];
+    }
+  }
+  for (int i = 0; i < n; i++) { double t = x[i]; for (int k = 0; k < i; k++) t -= A[i][k] * x[k]; x[i] = t / A[i][i]; }
+  for (int i = n - 1; i >= 0; i--) { double t = x[i]; for (int k = i + 1; k < n; k++) t -= A[k][i] * x[k]; x[i] = t / A[i][i]; }
+  return true;
+}
+
+// ------------------------------------------------------------------ constraint solve: primal Newton, exact line search
+template <class C>
+MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
+  const int nv = K.m.nv, ncon = s.ncon, nlim = s.nlim;
+  if (ncon == 0 && nlim == 0) { MZ_FOR(i, nv) s.qacc[i] = s.qas[i]; MZ_FOR(one, 1) s.iters = 0; cx.sync(); return; }
+  auto cost_at = [&](const double* x) {  // partial cost over this lane's rows (+ the smooth part on its dofs)
+    double c = 0.0;
+    MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * (x[j] - s.qas[j]); c += 0.5 * t * (x[i] - s.qas[i]); }
+    MZ_FOR(k, ncon) {
+      double u[3];
+      for (int a = 0; a < 3; a++) { double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += s.cJ[k][a][i] * x[i]; u[a] = t; }
+      c += gen_contact_eval(s.cD[k], u, nullptr, nullptr);
+    }
+    MZ_FOR(l, nlim) { const double jar = s.lsign[l] * x[s.ldof[l]] - s.laref[l]; if (jar < 0.0) c += 0.5 * s.lD[l] * jar * jar; }
+    return cx.gsum(c);
+  };
+  // warm start: the better of qacc_warmstart and qacc_smooth, by cost (mj_fwdConstraint)
+  const double cw = cost_at(s.warm), cs = cost_at(s.qas);
+  cx.sync();
+  MZ_FOR(i, nv) s.qacc[i] = cw < cs ? s.warm[i] : s.qas[i];
+  cx.sync();
+  bool done = false;
+  int it = 0;
+  double prev_cost = cw < cs ? cw : cs;
+  while (!done && it < K.max_iter) {
+    MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * (s.qacc[j] - s.qas[j]); s.Mx[i] = t; }
+    MZ_FOR(e, 3 * ncon) { const int k = e / 3, a = e - 3 * k; double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += s.cJ[k][a][i] * s.qacc[i]; s.cu[k][a] = t; }
+    MZ_FOR(l, nlim) s.ljar[l] = s.lsign[l] * s.qacc[s.ldof[l]] - s.laref[l];
+    cx.sync();
+    double gpart = 0.0;
+    MZ_FOR(i, nv) {
+      double g = s.Mx[i];
+      for (int k = 0; k < ncon; k++) { double g3[3]; gen_contact_eval(s.cD[k], s.cu[k], g3, nullptr); g += s.cJ[k][0][i] * g3[0] + s.cJ[k][1][i] * g3[1] + s.cJ[k][2][i] * g3[2]; }
+      for (int l = 0; l < nlim; l++) if (s.ldof[l] == i && s.ljar[l] < 0.0) g += s.lsign[l] * s.lD[l] * s.ljar[l];
+      s.grad[i] = g; gpart += g * g;
+    }
+    const double gn = sqrt(cx.gsum(gpart));
+    if (K.inv_scale * gn < K.tol) break;
+    MZ_FOR(e, nv * nv) {
+      const int i = e / nv, j = e - nv * i;
+      double acc = s.M[i][j];
+      for (int k = 0; k < ncon; k++) {
+        double W[5];
+        gen_contact_eval(s.cD[k], s.cu[k], nullptr, W);
+        const double ni = s.cJ[k][0][i], pi = s.cJ[k][1][i], qi = s.cJ[k][2][i], nj = s.cJ[k][0][j], pj = s.cJ[k][1][j], qj = s.cJ[k][2][j];
+        acc += W[0] * ni * nj + W[1] * (ni * pj + pi * nj) + W[2] * (ni * qj + qi * nj) + W[3] * pi * pj + W[4] * qi * qj;
+      }
+      if (i == j) for (int l = 0; l < nlim; l++) if (s.ldof[l] == i && s.ljar[l] < 0.0) acc += s.lD[l];
+      s.H[i][j] = acc;
+    }
+    cx.sync();
+    MZ_FOR(one, 1) {
+      for (int i = 0; i < nv; i++) s.search[i] = -s.grad[i];
+      if (!gen_chol_solve(s.H, nv, s.search)) { s.status |= MZ_STATUS_BAD_STATE; s.red[0] = 1.0; } else s.red[0] = 0.0;
+    }
+    cx.sync();
+    if (s.red[0] != 0.0) break;
+    // line search on phi(alpha) = cost(qacc + alpha search): unit step when no row changes state, else safeguarded Newton on phi'
+    MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * s.search[j]; s.Ms[i] = t; }
+    MZ_FOR(e, 3 * ncon) { const int k = e / 3, a = e - 3 * k; double t = 0.0; for (int i = 0; i < nv; i++) t += s.cJ[k][a][i] * s.search[i]; s.cjv[k][a] = t; }
+    MZ_FOR(l, nlim) s.ljv[l] = s.lsign[l] * s.search[s.ldof[l]];
+    cx.sync();
+    bool changed = false;
+    MZ_FOR(k, ncon) { const double w[3] = {s.cu[k][0] + s.cjv[k][0], s.cu[k][1] + s.cjv[k][1], s.cu[k][2] + s.cjv[k][2]}; changed = changed || gen_rows_flip(s.cD[k], s.cu[k], w); }
+    MZ_FOR(l, nlim) changed = changed || ((s.ljar[l] < 0.0) != (s.ljar[l] + s.ljv[l] < 0.0));
+    changed = cx.gany(changed);
+    double alpha = 1.0;
+    if (changed) {
+      double p1 = 0.0, p2 = 0.0;
+      MZ_FOR(i, nv) { p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * s.Ms[i]; }
+      p1 = cx.gsum(p1); p2 = cx.gsum(p2);
+      double lo = 0.0, hi = -1.0, prev_d2 = -1.0;
+      for (int ls = 0; ls < K.ls_iter; ls++) {
+        double d1 = 0.0, d2 = 0.0;
+        MZ_FOR(k, ncon) gen_rows_slope(s.cD[k], s.cu[k], s.cjv[k], alpha, &d1, &d2);
+        MZ_FOR(l, nlim) { const double r = s.ljar[l] + alpha * s.ljv[l]; if (r < 0.0) { d1 += s.lD[l] * r * s.ljv[l]; d2 += s.lD[l] * s.ljv[l] * s.ljv[l]; } }
+        d1 = cx.gsum(d1) + p1 + alpha * p2;
+        d2 = cx.gsum(d2) + p2;
+        if (d2 == prev_d2) break;
+        prev_d2 = d2;
+        if (d1 < 0.0) lo = alpha; else hi = alpha;
+        double next = alpha - d1 / d2;
+        if (hi >= 0.0 && !(next > lo && next < hi)) next = 0.5 * (lo + hi);
+        if (!(next > 0.0)) next = hi >= 0.0 ? 0.5 * (lo + hi) : 0.0;
+        if (fabs(next - alpha) <= 1e-15 * fabs(next)) { alpha = next; break; }
+        alpha = next;
+      }
+    }
+    cx.sync();
+    if (!(alpha > 0.0)) break;
+    MZ_FOR(i, nv) s.qacc[i] += alpha * s.search[i];
+    cx.sync();
+    it++;
+    if (!changed) break;  // the unit Newton step stayed inside one active set: exact minimiser
+    const double cnow = cost_at(s.qacc);
+    if (!(K.inv_scale * (prev_cost - cnow) > 0.0)) break;  // round-off floor
+    prev_cost = cnow;
+    if (it >= K.max_iter) { MZ_FOR(one, 1) s.status |= MZ_STATUS_SOLVER_MAXITER; }
+  }
+  MZ_FOR(one, 1) s.iters = it;
+  cx.sync();
+}
+
+// ------------------------------------------------------------------ one forward-dynamics evaluation
+template <class C>
+MZ_HD void gen_forward(const C& cx, const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  MZ_FOR(one, 1) gen_kinematics(K, s);
+  cx.sync();
+  MZ_FOR(g, m.ngeom) gen_geom_item(K, s, g);
+  MZ_FOR(j, m.njnt) gen_axis_item(K, s, j);
+  MZ_FOR(b, m.nbody) if (b > 0) gen_inertia_item(K, s, b);
+  cx.sync();
+  MZ_FOR(g, m.ngeom) gen_collide_item(K, s, g);
+  MZ_FOR(one, 1) {
+    for (int b = m.nbody - 1; b >= 1; b--) { const int p = m.body_parent[b]; if (p > 0) for (int k = 0; k < 10; k++) s.crb[p][k] += s.crb[b][k]; }
+    gen_rne_serial(K, s);
+  }
+  cx.sync();
+  MZ_FOR(i, m.nv) gen_mass_item(K, s, i);
+  MZ_FOR(b, m.nbody) gen_fluid_item(K, s, b);
+  MZ_FOR(one, 1) gen_compact_contacts(K, s);
+  cx.sync();
+  MZ_FOR(i, m.nv) gen_force_item(K, s, i);
+  MZ_FOR(e, m.nv * m.nv) { const int i = e / m.nv, j = e - m.nv * i; if (i < j) s.M[i][j] = s.M[j][i]; }  // gen_mass_item wrote the lower triangle
+  MZ_FOR(item, 3 * s.ncon) gen_contact_row_item(K, s, item);
+  cx.sync();
+  MZ_FOR(one, 1) {  // qacc_smooth = M^-1 qfrc_smooth (H is free until the solver assembles the Hessian)
+    for (int i = 0; i < m.nv; i++) { for (int j = 0; j <= i; j++) s.H[i][j] = s.M[i][j]; s.qas[i] = s.qfs[i]; }
+    if (!gen_chol_solve(s.H, m.nv, s.qas)) s.status |= MZ_STATUS_BAD_STATE;
+  }
+  cx.sync();
+  gen_solve(cx, K, s);
+}
+
+MZ_HD void gen_integrate_pos(const GenDev& K, GenScratch& s, const double* base, const double* vel, double h) {  // serial (one lane)
+  const mz_model& m = K.m;
+  for (int j = 0; j < m.njnt; j++) {
+    const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    if (m.jnt_type[j] == MZ_JNT_FREE) {
+      for (int k = 0; k < 3; k++) s.qpos[qa + k] = base[qa + k] + h * vel[da + k];
+      const double w[3] = {vel[da + 3], vel[da + 4], vel[da + 5]}, n = sqrt(gd_dot3(w, w));
+      double q[4] = {base[qa + 3], base[qa + 4], base[qa + 5], base[qa + 6]};
+      if (n > 1e-15) {
+        const double sh = sin(0.5 * h * n) / n, qr[4] = {cos(0.5 * h * n), w[0] * sh, w[1] * sh, w[2] * sh};
+        double qn[4];
+        gd_quat_mul(qn, q, qr);
+        for (int k = 0; k < 4; k++) q[k] = qn[k];
+      }
+      gd_quat_norm(q);
+      for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = q[k];
+    } else {
+      s.qpos[qa] = base[qa] + h * vel[da];
+    }
+  }
+}
+
+// one mj_step with RK4; state in s.qpos / s.qvel / s.warm, actuator forces in s.fact
+template <class C>
+MZ_HD void gen_mj_step(const C& cx, const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  const double h = m.timestep;
+  MZ_FOR(i, m.nq) s.x0q[i] = s.qpos[i];
+  MZ_FOR(i, m.nv) { s.x0v[i] = s.qvel[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; }
+  cx.sync();
+  for (int st = 0; st < 4; st++) {
+    gen_forward(cx, K, s);
+    const double bw = (st == 0 || st == 3) ? 1.0 / 6.0 : 1.0 / 3.0, aw = st == 2 ? 1.0 : 0.5;
+    MZ_FOR(i, m.nv) {
+      s.accv[i] += bw * s.qvel[i]; s.accf[i] += bw * s.qacc[i];
+      s.dxv[i] = aw * s.qvel[i];
+      s.Mx[i] = s.x0v[i] + h * aw * s.qacc[i];
+    }
+    cx.sync();
+    if (st < 3) {
+      MZ_FOR(one, 1) gen_integrate_pos(K, s, s.x0q, s.dxv, h);
+      MZ_FOR(i, m.nv) s.qvel[i] = s.Mx[i];
+      cx.sync();
+    }
+  }
+  MZ_FOR(one, 1) gen_integrate_pos(K, s, s.x0q, s.accv, h);
+  MZ_FOR(i, m.nv) { s.qvel[i] = s.x0v[i] + h * s.accf[i]; s.warm[i] = s.qacc[i]; }  // qacc_warmstart: the last stage's qacc (mj_advance)
+  cx.sync();
+}
+
+// observation element i (maze_env.py:351-369): qpos[:3] | qpos[3:nq_robot] | qvel[:nv_robot] | t / 1000
+MZ_HD float gen_obs_elem(const GenDev& K, const GenScratch& s, int i, int t) {
+  const mz_model& m = K.m;
+  if (i < m.nq_robot) return (float)s.qpos[i];
+  if (i < m.nq_robot + m.nv_robot) return (float)s.qvel[i - m.nq_robot];
+  return (float)t * 0.001f;
+}
+
+// MazeEnv.step for a generic robot: the ant's / swimmer's step shape (ant.py:61-73, swimmer.py:37-48) — clamped motors,
+// frame_skip x mj_step, forward reward |dxy| / dt, control cost on the raw action
+template <class C>
+MZ_HD void gen_env_step(const C& cx, const GenDev& K, GenScratch& s, const float* action, float* obs, float* reward, uint8_t* done, int* goal_idx,
+                        float* info, int* t_io) {
+  const mz_model& m = K.m;
+  MZ_FOR(i, m.nv) s.fact[i] = 0.0;
+  MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
+  cx.sync();
+  MZ_FOR(one, 1)
+    for (int u = 0; u < m.nu; u++) {
+      double c = (double)action[u];
+      if (m.act_ctrllimited[u]) c = fmin(fmax(c, m.act_ctrlrange[u][0]), m.act_ctrlrange[u][1]);
+      s.fact[m.act_dofid[u]] += m.act_gear[u] * c;
+    }
+  cx.sync();
+  for (int f = 0; f < m.frame_skip; f++) gen_mj_step(cx, K, s);
+  const int t = *t_io + 1, obs_dim = m.obs_dim;
+  MZ_FOR(i, obs_dim) obs[i] = gen_obs_elem(K, s, i, t);
+  cx.sync();
+  MZ_FOR(one, 1) {
+    const double dt = m.timestep * m.frame_skip, vx = (s.qpos[0] - s.red[1]) / dt, vy = (s.qpos[1] - s.red[2]) / dt, fwd = sqrt(vx * vx + vy * vy);
+    double cc = 0.0;
+    for (int u = 0; u < m.nu; u++) cc += (double)action[u] * (double)action[u];
+    cc *= K.task.ctrl_w;
+    float o6[6];
+    for (int k = 0; k < 6; k++) o6[k] = k < obs_dim ? obs[k] : 0.f;
+    float outer; int tm, gi;
+    task_eval_dev(K.task, o6, &outer, &tm, &gi);
+    *reward = (float)(K.task.inner_scale * (K.task.fwd_w * fwd - cc) + (double)outer);
+    *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
+    if (goal_idx) *goal_idx = gi;
+    if (info) { info[0] = (float)s.qpos[0]; info[1] = (float)s.qpos[1]; info[2] = (float)fwd; info[3] = (float)-cc; }
+    bool badv = false;
+    for (int i = 0; i < m.nq; i++) badv = badv || !(fabs(s.qpos[i]) < 1e10);
+    for (int i = 0; i < m.nv; i++) badv = badv || !(fabs(s.qvel[i]) < 1e10);
+    if (badv) s.status |= MZ_STATUS_BAD_STATE;
+  }
+  cx.sync();
+  MZ_FOR(one, 1) *t_io = t;
+  cx.sync();
+}

@@ -78,13 +78,21 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   if (model->robot == MZ_ROBOT_ANT) rc = ant_dev_from_model(&h->ant, model, msg, sizeof(msg));
   else if (model->robot == MZ_ROBOT_POINT) rc = point_dev_from_model(&h->point, model, msg, sizeof(msg));
   else if (model->robot == MZ_ROBOT_SWIMMER) rc = swimmer_dev_from_model(&h->swimmer, model, msg, sizeof(msg));
+  else if (model->robot == MZ_ROBOT_GENERIC) rc = MZ_OK;  // checked by mzk_generic_create below (it needs the device)
   else { rc = MZ_ERR_UNSUPPORTED; snprintf(msg, sizeof(msg), "mz_create: robot kind %d has no device kernel yet", model->robot); }
   if (rc != MZ_OK) { delete h; return fail(msg); }
   hipError_t e = hipSuccess;
   view_dev_from_model(model, &h->view);
   const int vdim = model->top_down_view ? MZ_VIEW_DIM : 0;
   if (model->top_down_view && model->nblock > 4) { delete h; return fail("mz_create: top-down view with more than 4 movable blocks"); }
-  if (h->robot == MZ_ROBOT_ANT) {
+  if (h->robot == MZ_ROBOT_GENERIC) {
+    rc = mzk_generic_create(h, msg, sizeof(msg));
+    if (rc != MZ_OK) { mz_destroy(h); return fail(msg); }
+    h->base_obs = model->obs_dim;
+    const size_t rec = (size_t)model->nq + 2 * model->nv + 2;
+    e = hipMalloc(&h->state, (size_t)num_envs * rec * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * rec * sizeof(float));
+  } else if (h->robot == MZ_ROBOT_ANT) {
     const int nb = h->ant.nblock;
     if (nb > 3) { delete h; return fail("mz_create: more than 3 movable blocks are not instantiated"); }
     h->lay.nq = ANT_NQ + h->ant.block_nax * nb + 7 * h->ant.nball; h->lay.nv = ANT_NV + h->ant.block_nax * nb + 6 * h->ant.nball;
@@ -139,6 +147,7 @@ void mz_destroy(mz_handle* h) {
   if (h->point_dev) (void)hipFree(h->point_dev);
   if (h->swimmer_dev) (void)hipFree(h->swimmer_dev);
   if (h->ant_dev) (void)hipFree(h->ant_dev);
+  mzk_generic_destroy(h);
   if (h->status) (void)hipFree(h->status);
   if (h->prof) (void)hipFree(h->prof);
   if (h->ev) { for (int i = 0; i < 2 * h->ntime; i++) (void)hipEventDestroy(h->ev[i]); free(h->ev); }
@@ -215,6 +224,7 @@ int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* ob
   hipStream_t st = (hipStream_t)stream;
   h->seed = seed;
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_reset(h, st, mask_dev, seed, obs_dev));
+  else if (h->robot == MZ_ROBOT_GENERIC) HIPCHK(h, mzk_generic_reset(h, st, mask_dev, seed, obs_dev));
   else HIPCHK(h, mzk_planar_reset(h, st, mask_dev, seed, obs_dev));
   if (h->view.on && obs_dev) HIPCHK(h, mzk_view_fill(h, st, obs_dev, NULL, NULL));
   return MZ_OK;
@@ -226,6 +236,7 @@ int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev,
   DeviceScope scope(h->device);
   hipStream_t st = (hipStream_t)stream;
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_set_state(h, st, qpos_dev, qvel_dev, warmstart_dev, t_dev));
+  else if (h->robot == MZ_ROBOT_GENERIC) HIPCHK(h, mzk_generic_set_state(h, st, qpos_dev, qvel_dev, warmstart_dev, t_dev));
   else HIPCHK(h, mzk_planar_set_state(h, st, qpos_dev, qvel_dev, t_dev));
   return MZ_OK;
 }
@@ -235,6 +246,7 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
   DeviceScope scope(h->device);
   hipStream_t st = (hipStream_t)stream;
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_get_state(h, st, qpos_dev, qvel_dev, warmstart_dev, t_dev));
+  else if (h->robot == MZ_ROBOT_GENERIC) HIPCHK(h, mzk_generic_get_state(h, st, qpos_dev, qvel_dev, warmstart_dev, t_dev));
   else HIPCHK(h, mzk_planar_get_state(h, st, qpos_dev, qvel_dev, warmstart_dev, t_dev));
   return MZ_OK;
 }
@@ -247,9 +259,10 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   int slot = -1;
   if (h->ntime > 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
+  else if (h->robot == MZ_ROBOT_GENERIC) HIPCHK(h, mzk_generic_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
   else HIPCHK(h, mzk_planar_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
   if (h->view.on) HIPCHK(h, mzk_view_fill(h, st, obs_dev, h->auto_reset ? h->final_obs : NULL, done_dev));
-  if (h->record && (h->robot != MZ_ROBOT_ANT || h->view.on)) {
+  if (h->record && ((h->robot != MZ_ROBOT_ANT && h->robot != MZ_ROBOT_GENERIC) || h->view.on)) {
     const size_t tot = (size_t)h->n * (h->model.obs_dim + 2);
     hipLaunchKernelGGL(pack_record_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->n, h->model.obs_dim, obs_dev, reward_dev, done_dev, h->record);
   }
@@ -281,6 +294,7 @@ int32_t mz_debug_task_eval(mz_handle* h, int32_t n_rows, const float* obs_dev, f
   if (!h || n_rows <= 0 || !obs_dev || !reward_dev || !done_dev) return h ? set_err(h, MZ_ERR_ARG, "mz_debug_task_eval: bad arguments", hipSuccess) : MZ_ERR_ARG;
   DeviceScope scope(h->device);
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_task_eval(h, (hipStream_t)stream, n_rows, obs_dev, reward_dev, done_dev, goal_idx_dev));
+  else if (h->robot == MZ_ROBOT_GENERIC) HIPCHK(h, mzk_generic_task_eval(h, (hipStream_t)stream, n_rows, obs_dev, reward_dev, done_dev, goal_idx_dev));
   else HIPCHK(h, mzk_planar_task_eval(h, (hipStream_t)stream, n_rows, obs_dev, reward_dev, done_dev, goal_idx_dev));
   return MZ_OK;
 }

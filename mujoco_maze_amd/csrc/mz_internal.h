@@ -13,6 +13,8 @@
 #include "point_dyn.h"
 #include "swimmer_dyn.h"
 
+struct GenDev;  // generic_dyn.h (the generic-robot path keeps its float64 constant block out of the other translation units)
+
 struct AntLayout { int nq, nv, rec, rec_t, obs_dim, nblock3, ostride; };  // record layout of the instantiated block count; obs_dim: without the
                                                                           // top-down view, ostride: floats between observation rows
 
@@ -27,6 +29,7 @@ struct mz_handle {
   PointDev point;
   SwimmerDev* swimmer_dev;
   SwimmerDev swimmer;
+  GenDev* gen_dev;      // generic robot (MZ_ROBOT_GENERIC): device copy of the constant block (mz_model + pair tables)
   float* state;         // ant: [n][REC]; point / swimmer: SoA [2 NV][n]
   int* pt_t;
   uint32_t* pt_ep;
@@ -66,3 +69,12 @@ hipError_t mzk_point_detect(mz_handle* h, hipStream_t st, int n, const double* o
 // every row of obs, and the rows of final_obs of envs that finished (done != NULL: the step under auto-reset)
 hipError_t mzk_view_fill(mz_handle* h, hipStream_t st, float* obs, float* final_obs, const uint8_t* done);
 int mzk_planar_state_width(const mz_handle* h);  // coordinates per env of the SoA state (NV)
+
+// ---- generic_kernels.hip (a user robot of any tree topology, csrc/generic_dyn.h)
+int mzk_generic_create(mz_handle* h, char* err, int errlen);  // builds + uploads the constant block; MZ_OK or MZ_ERR_*
+void mzk_generic_destroy(mz_handle* h);
+hipError_t mzk_generic_step(mz_handle* h, hipStream_t st, const float* actions, float* obs, float* reward, uint8_t* done, int* goal_idx, float* info);
+hipError_t mzk_generic_reset(mz_handle* h, hipStream_t st, const uint8_t* mask, uint64_t seed, float* obs);
+hipError_t mzk_generic_set_state(mz_handle* h, hipStream_t st, const float* qpos, const float* qvel, const float* warm, const int* t);
+hipError_t mzk_generic_get_state(mz_handle* h, hipStream_t st, float* qpos, float* qvel, float* warm, int* t);
+hipError_t mzk_generic_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx);

@@ -51,13 +51,20 @@ class VecMazeEnv:
         self.num_envs = int(num_envs)
         self._task = maze_task(maze_size_scaling, **(task_kwargs or {}))
         robot = getattr(model_cls, "ROBOT", None)
-        if robot not in ("ant", "point", "swimmer", "reacher"):
-            raise NotImplementedError(f"robot {model_cls.__name__} has no device kernel yet (SURVEY §8f)")
+        if robot not in ("ant", "point", "swimmer", "reacher", "generic"):
+            raise NotImplementedError(f"robot {model_cls.__name__}: set ROBOT to one of the built-in families or to \"generic\" (any tree "
+                                      "topology, stepped from its MJCF: AgentModel.FILE)")
+        if robot == "generic":  # the user's own robot (agent_model.py:12-41, README.md:127): its MJCF, frame_skip, reset distribution
+            kwargs.setdefault("robot_xml", getattr(model_cls, "FILE", None))
+            gen_kw = dict(frame_skip=int(getattr(model_cls, "FRAME_SKIP", 1)), reset_qvel=getattr(model_cls, "RESET_QVEL", "normal"))
+        else:
+            gen_kw = {}
         self.model: CompiledModel = compile_model(
             robot, self._task, maze_size_scaling, inner_reward_scaling=inner_reward_scaling,
             restitution_coef=restitution_coef, maze_height=maze_height, max_episode_steps=max_episode_steps,
             forward_reward_weight=kwargs.pop("forward_reward_weight", 1.0), ctrl_cost_weight=kwargs.pop("ctrl_cost_weight", 1e-4),
-            manual_collision=model_cls.MANUAL_COLLISION, radius=model_cls.RADIUS, robot_xml=kwargs.pop("robot_xml", None))
+            manual_collision=getattr(model_cls, "MANUAL_COLLISION", False), radius=getattr(model_cls, "RADIUS", None),
+            robot_xml=kwargs.pop("robot_xml", None), **gen_kw)
         self.wrapped_cls = model_cls
         from mujoco_maze_amd.model import device_unsupported_reason
 

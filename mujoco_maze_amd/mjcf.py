@@ -166,9 +166,11 @@ def _apply_joint(base: R.JointSpec, e: ET.Element, name: str, radians: bool) -> 
     return dataclasses.replace(base, name=name, **kw)
 
 
-def spec_from_mjcf(source: str, like: R.RobotSpec) -> R.RobotSpec:
+def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1, reset_qvel: str = "normal") -> R.RobotSpec:
     """Parse an MJCF file (path) or text into a RobotSpec.  `like` is the built-in spec of the robot family: it supplies
-    what MJCF does not carry (frame_skip, reset distribution, robot coordinate counts — `ant.py`, `point.py`, ...)."""
+    what MJCF does not carry (frame_skip, reset distribution, robot coordinate counts — `ant.py`, `point.py`, ...).
+    `like = None`: a robot of the user's own (any tree of free / slide / hinge joints with sphere / capsule geoms and motors);
+    it is stepped by the generic device kernel (csrc/generic_dyn.h), frame_skip / reset distribution as given."""
     text = source if "<" in source else open(source).read()  # XML text or a file path
     root = ET.fromstring(text)
     if root.tag != "mujoco":
@@ -238,6 +240,13 @@ def spec_from_mjcf(source: str, like: R.RobotSpec) -> R.RobotSpec:
     # The swimmer family's kernels are written for planar chains of 2..6 links (csrc/swimmer_dyn.h is generic in the link count;
     # Swimmer = 3, Reacher = 2): a user's chain may be longer or shorter than the built-in asset's.  Every other family keeps
     # its structure (parameters may change, topology not).
+    if like is None:
+        import dataclasses
+
+        wall_defaults = dataclasses.replace(geom0, name="wall", type=R.BOX, size=(1.0, 1.0, 1.0), contype=1, conaffinity=1)
+        return R.RobotSpec("generic", bodies, acts, floor, wall_defaults, timestep=float(oa.get("timestep", 0.002)), frame_skip=int(frame_skip),
+                           nq_robot=nq, nv_robot=nv, density=float(oa.get("density", 0.0)), viscosity=float(oa.get("viscosity", 0.0)),
+                           collision_predefined=oa.get("collision", "all") == "predefined", reset_qvel=reset_qvel, torso_z=bodies[0].pos[2])
     chain = (like.name in ("swimmer", "reacher") and nq == nv == len(bodies) + 2 and 2 <= len(bodies) <= 6 and len(acts) == len(bodies) - 1
              and all(b.parent == i - 1 for i, b in enumerate(bodies)))
     if not chain and ((nq, nv) != (like.nq_robot, like.nv_robot) or len(acts) != len(like.actuators)):

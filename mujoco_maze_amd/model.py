@@ -79,7 +79,7 @@ class MzModel(C.Structure):
     ]
 
 
-ROBOT_ID = {"point": 0, "ant": 1, "swimmer": 2, "reacher": 2}  # the Reacher is the 2-link member of the swimmer family
+ROBOT_ID = {"point": 0, "ant": 1, "swimmer": 2, "reacher": 2, "generic": 3}  # the Reacher is the 2-link member of the swimmer family; "generic": a user robot of any tree topology
 RESET_KIND = {"normal": 0, "uniform01": 1, "uniform_sym": 2}
 CELL_CODE = {MazeCell.EMPTY: 0, MazeCell.BLOCK: 1, MazeCell.CHASM: 2, MazeCell.ROBOT: 255}
 
@@ -269,16 +269,28 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
                   restitution_coef: float = 0.8, maze_height: float = 0.5, max_episode_steps: int = 1000,
                   forward_reward_weight: float = 1.0, ctrl_cost_weight: float = 1e-4,
                   manual_collision: Optional[bool] = None, radius: Optional[float] = None,
-                  robot_xml: Optional[str] = None) -> CompiledModel:
+                  robot_xml: Optional[str] = None, frame_skip: Optional[int] = None, reset_qvel: Optional[str] = None) -> CompiledModel:
     """`robot_xml`: path or text of an MJCF variant of the built-in robot (see `mjcf.py`); default: the built-in asset data."""
-    spec = R.robot_spec(robot)
-    if robot_xml is not None:
+    if robot == "generic":
+        # a user's AgentModel (agent_model.py:12-41): nothing built in — the MJCF is the robot; frame_skip and the reset
+        # distribution come from the AgentModel class (kwargs below)
+        if robot_xml is None:
+            raise ValueError("a generic robot needs its MJCF (AgentModel.FILE or robot_xml=...)")
         from mujoco_maze_amd import mjcf
 
-        spec = mjcf.spec_from_mjcf(robot_xml, spec)
+        spec = mjcf.spec_from_mjcf(robot_xml, None, frame_skip=frame_skip or 1, reset_qvel=reset_qvel or "normal")
+    else:
+        spec = R.robot_spec(robot)
+        if robot_xml is not None:
+            from mujoco_maze_amd import mjcf
+
+            spec = mjcf.spec_from_mjcf(robot_xml, spec)
     structure = task.create_maze()
     world = MazeWorld(structure, scale, maze_height)
     balls = world.ball_cells()
+    if (balls or world.movable_cells() or world.elevated) and robot == "generic":
+        raise NotImplementedError("generic robots run in mazes without movable blocks, object balls or platforms (the device kernel of a user "
+                                  "robot collides it with the floor and the maze walls only)")
     if balls and robot not in ("point", "ant"):
         raise ValueError(f"OBJBALL_TYPE is not registered for the {robot}")  # maze_env.py:189-191: only PointEnv and AntEnv define one
     if len(balls) > 1:
@@ -546,8 +558,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
 
     # ---- Point manual collision
     from mujoco_maze_amd.agent_model import ROBOT_CLASSES  # late import (cycle)
-    rcls = ROBOT_CLASSES[robot]
-    manual = rcls.MANUAL_COLLISION if manual_collision is None else manual_collision
+    rcls = ROBOT_CLASSES.get(robot)  # None: a user's generic robot (no manual collision, no velocity clip)
+    manual = (rcls.MANUAL_COLLISION if rcls is not None else False) if manual_collision is None else manual_collision
     m.manual_collision = int(bool(manual))
     m.restitution = restitution_coef
     m.velocity_limit = getattr(rcls, "VELOCITY_LIMITS", 0.0)

@@ -249,3 +249,29 @@ extern "C" int emu_task_eval(const mz_model* m, int n, int obs_dim, const float*
   }
   return MZ_OK;
 }
+
+// ---------------------------------------------------------------- generic robot (any tree topology): csrc/generic_dyn.h on one lane
+#include "../../mujoco_maze_amd/csrc/generic_dyn.h"
+
+extern "C" int emu_generic_env_step(const mz_model* m, int n, float* qpos, float* qvel, float* warm, int32_t* t, const float* actions, float* obs,
+                                    float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status, char* err, int errlen) {
+  GenDev* K = (GenDev*)calloc(1, sizeof(GenDev));
+  int rc = gen_dev_from_model(K, m, err, errlen);
+  if (rc != MZ_OK) { free(K); return rc; }
+  HostCtx cx;
+  GenScratch* s = (GenScratch*)calloc(1, sizeof(GenScratch));
+  for (int e = 0; e < n; e++) {
+    for (int i = 0; i < m->nq; i++) s->qpos[i] = (double)qpos[(size_t)e * m->nq + i];
+    for (int i = 0; i < m->nv; i++) { s->qvel[i] = (double)qvel[(size_t)e * m->nv + i]; s->warm[i] = (double)warm[(size_t)e * m->nv + i]; }
+    int tt = t[e], gi = -1;
+    uint8_t d = 0;
+    float r = 0.f, inf[4];
+    gen_env_step(cx, *K, *s, actions + (size_t)e * m->nu, obs + (size_t)e * m->obs_dim, &r, &d, &gi, inf, &tt);
+    for (int i = 0; i < m->nq; i++) qpos[(size_t)e * m->nq + i] = (float)s->qpos[i];
+    for (int i = 0; i < m->nv; i++) { qvel[(size_t)e * m->nv + i] = (float)s->qvel[i]; warm[(size_t)e * m->nv + i] = (float)s->warm[i]; }
+    t[e] = tt; reward[e] = r; done[e] = d; goal_idx[e] = gi; status[e] = s->status;
+    if (info) for (int k = 0; k < 4; k++) info[(size_t)e * 4 + k] = inf[k];
+  }
+  free(s); free(K);
+  return MZ_OK;
+}

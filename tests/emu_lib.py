@@ -141,3 +141,18 @@ def task_eval(cm, obs):
     rc = lib.emu_task_eval(C.byref(cm.c), n, d, _vp(o), _vp(rew), _vp(done), _vp(gi))
     assert rc == 0, rc
     return rew, done, gi
+
+
+def generic_env_step(cm, st, actions):
+    """A user robot of any tree topology on the generic kernel code (csrc/generic_dyn.h, one lane): st = dict of float32
+    qpos [n,nq], qvel [n,nv], warm [n,nv], int32 t [n] (updated in place)."""
+    lib = load()
+    n = st["qpos"].shape[0]
+    a = np.ascontiguousarray(actions, np.float32)
+    out = dict(obs=np.zeros((n, cm.c.obs_dim), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+               goal_idx=np.zeros(n, np.int32), info=np.zeros((n, 4), np.float32), status=np.zeros(n, np.int32))
+    err = C.create_string_buffer(256)
+    rc = lib.emu_generic_env_step(C.byref(cm.c), n, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["warm"]), _vp(st["t"]), _vp(a), _vp(out["obs"]),
+                                  _vp(out["reward"]), _vp(out["done"]), _vp(out["goal_idx"]), _vp(out["info"]), _vp(out["status"]), err, 256)
+    assert rc == 0, (rc, err.value.decode())
+    return out
