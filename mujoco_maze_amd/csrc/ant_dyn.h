@@ -985,7 +985,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         AlignedBB bb;
         if (!aligned_box_box(cw, hw, bwd, K.d_block_half, K.d_wall_margin, bb)) continue;
         if (!(bb.dist < K.d_wall_margin)) continue;  // not active: no row (mj_instantiateContact)
-        const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
+        const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1;
         const double org[3] = {(double)s.qpos[0], (double)s.qpos[1], (double)s.cz};  // torso origin: positions go back to torso-relative fp32
         for (int iu = 0; iu < bb.nu; iu++)
           for (int iv = 0; iv < bb.nv; iv++) {
@@ -1017,7 +1017,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
       AlignedBB bb;
       if (!aligned_box_box(c1w, K.d_block_half, bwd, K.d_block_half, K.d_wall_margin, bb)) continue;
       if (!(bb.dist < K.d_wall_margin)) continue;
-      const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1, v = ax == 0 ? 2 : ax - 1;
+      const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1;
       const double org[3] = {(double)s.qpos[0], (double)s.qpos[1], (double)s.cz};
       for (int iu = 0; iu < bb.nu; iu++)
         for (int iv = 0; iv < bb.nv; iv++) {
@@ -1254,8 +1254,14 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
     if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
     int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, slot = off;
     if (s.cnt[e] == 0) return;  // nothing to store: skip the second enumeration
+    // The slots [off, end) belong to this enumerator, whatever the second enumeration yields: the two passes are two
+    // instantiations of geom_contacts, and under the relaxed floating-point flags of the Ant build the compiler is free to
+    // round an intermediate differently in each — a capsule whose closest box feature sits on a face / edge border can then
+    // emit its second support point in one pass only (soak, round 3: a slot left unwritten turned into NaN).  A contact
+    // beyond the count is dropped, a counted one that does not come is replaced by an inert one (below).
+    const int end = off + s.cnt[e];
     geom_contacts<NB>(K, s, e, [&](const ContactGeo& g) {
-      if (slot >= NC) { slot++; return; }
+      if (slot >= NC || slot >= end) { slot++; return; }
       float* q = &s.cY[slot][0][0];
       for (int k = 0; k < 3; k++) { q[k] = g.pos[k]; q[3 + k] = g.n[k]; q[8 + k] = g.hint[k]; }
       q[6] = g.dist; q[7] = (float)(g.kind + 16 * g.blk + 128 * g.other);
@@ -1264,6 +1270,17 @@ MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       s.csrc[slot] = -1;
       slot++;
     });
+    // inert contact: a separation of a kilometre — its rows are never active (r = J a - aref > 0 for any acceleration the
+    // solver can produce), so cost, gradient and Hessian of the Newton problem do not see it
+    for (; slot < end && slot < NC; slot++) {
+      float* q = &s.cY[slot][0][0];
+      for (int k = 0; k < 3; k++) { q[k] = 0.f; q[3 + k] = k == 2 ? 1.f : 0.f; q[8 + k] = 0.f; }
+      const int kind = b >= 0 ? 1 : (D::BALL && e == D::NMOV - 1 ? 7 : 3), blk = (b >= 0 || D::NBLK == 0) ? 0 : (e / D::BSUB < D::NBLK ? e / D::BSUB : 0);
+      q[6] = 1e3f; q[7] = (float)(kind + 16 * blk);
+      s.cleg[slot] = leg;
+      s.ccls[slot] = cls;
+      s.csrc[slot] = -1;
+    }
 }
 
 template <int NB>
@@ -1612,7 +1629,10 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   MZ_FOR(l, 5 + (D::BALL ? 1 : 0)) kin_item<NB>(K, s, l);
   cx.sync();
   cx.tick(s, 0);
-  constexpr bool one_pass = NB <= 1 && C::row_solver;  // single-pass contact enumeration (con_enum_item)
+  // single-pass contact enumeration (con_enum_item) on the device: the narrow phase runs ONCE per evaluation, so count and
+  // geometry cannot disagree; only an env whose enumerator overflows its staging re-enumerates (con_fill_item)
+  constexpr bool one_pass = C::row_solver;
+  constexpr bool rows = NB <= 1 && C::row_solver;  // the DPP-row Newton solver (ant_newton_rows.h)
   MZ_FOR_AT(b, ANT_NBODY, 0) inertia_item<NB>(K, s, b);
   if constexpr (one_pass) { MZ_FOR_AT(e, NG, ANT_NBODY) con_enum_item<NB>(K, s, e); }
   else { MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e); }
@@ -1633,10 +1653,10 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   cx.tick(s, 2);
   MZ_FOR_AT(e, NROOT, 0) crb_root_item<NB>(K, s, e);
   MZ_FOR_AT(i, NV, NROOT) bias_dof_item<NB>(K, s, i);
-  if (!first && !one_pass) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7 (lane-group solver: shifted start)
+  if (!first && !rows) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7 (lane-group solver: shifted start)
   cx.sync();
   cx.tick(s, 3);
-  if constexpr (NB <= 1 && C::row_solver) {
+  if constexpr (rows) {
     // plain ant (and the ant with ONE movable block: 16 dofs, still one DPP row) on the device: constraint rows, then the register-resident solver of ant_newton_rows.h, which also
     // computes qacc_smooth = M^-1 qfrc_smooth with its row elimination (no Schur / Cholesky phases) and builds the joint-limit
     // rows on their own dof lanes — same mathematics

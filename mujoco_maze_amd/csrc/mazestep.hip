@@ -171,6 +171,7 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "solver_tolerance")) { h->ant_dirty = 1; h->ant.tol = (float)value; return MZ_OK; }
   if (!strcmp(key, "solver_rtol")) { h->ant_dirty = 1; h->ant.rtol = (float)value; return MZ_OK; }
   if (!strcmp(key, "ls_iterations")) { h->ant_dirty = 1; h->ant.ls_iter = (int)value; return MZ_OK; }
+  if (!strcmp(key, "debug_frame_skip")) { h->ant_dirty = 1; h->ant.frame_skip = (int)value; return MZ_OK; }  // diagnostics: mj_steps per env.step (Ant)
   if (!strcmp(key, "lanes_per_env")) {
     int g = (int)value;
     if (g != 8 && g != 16 && g != 32 && g != 64) return set_err(h, MZ_ERR_ARG, "lanes_per_env must be 8, 16, 32 or 64", hipSuccess);

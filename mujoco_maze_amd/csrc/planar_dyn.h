@@ -285,7 +285,7 @@ MZP_HD void pl_box_box_aligned(const double* c1, const double* h1, const double*
                                Emit&& emit) {
   AlignedBB bb;
   if (!aligned_box_box(c1, h1, c2, h2, margin, bb)) return;
-  const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1, w = ax == 0 ? 2 : ax - 1;
+  const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1;
   for (int iu = 0; iu < bb.nu; iu++)
     for (int iw = 0; iw < bb.nv; iw++) {
       PlContact c;
@@ -566,10 +566,17 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
   if (!cx.any(ncon > 0)) return;
   MZ_FOR(e, NE) {
     if (s.cnt[e] > 0) {
+      // the slots [cbeg, cbeg + cnt) belong to this enumerator whatever the second enumeration yields (two instantiations of
+      // planar_contacts need not round alike): a contact beyond the count is dropped, a missing one becomes an empty row
       int slot = s.cbeg[e];
+      const int end = slot + s.cnt[e];
       planar_contacts<NB, NS>(P, s, e, [&](const PlContact& c) {
-        if (c.dist < P.pair[c.cls].margin) { if (slot < NC) planar_fill_contact<NB, NS>(P, s, slot, c); slot++; }
+        if (c.dist < P.pair[c.cls].margin) { if (slot < NC && slot < end) planar_fill_contact<NB, NS>(P, s, slot, c); slot++; }
       });
+      for (; slot < end && slot < NC; slot++) {
+        s.cD[slot] = 0.0;
+        for (int a = 0; a < 3; a++) { s.caref[slot][a] = 0.0; for (int i = 0; i < PlanarDims<NB, NS>::NV; i++) s.cJ[slot][a][i] = 0.0; }
+      }
     }
   }
   if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = s.qas[i] + s.wd[i]; }  // envs without contacts keep qacc = qacc_smooth

@@ -2,7 +2,7 @@
 //
 //   planar_step_kernel<NB,NS,G>  one MazeEnv.step for the Point (+ NB movable blocks or NS object balls): lane group
 //                                per env, PlanarScratch in LDS, fp64.
-//   swimmer_step_kernel<NL,NB>   one MazeEnv.step for the Swimmer (NL = 3) / Reacher (NL = 2): one env per lane, fp64.
+//   swimmer_step_kernel<NL,NB,G> one MazeEnv.step for the Swimmer (NL = 3) / Reacher (NL = 2): G = 4 lanes per env (lane b = link b), fp64.
 //   reset / state copy kernels; debug kernels for the parity tests (task predicates, the Point's wall detector).
 //
 // HBM layout: SoA  q_0..q_{NV-1} | v_0..v_{NV-1}, each [N] fp32; t[N], episode[N] i32.  API arrays are row-major [N, k].
@@ -185,15 +185,31 @@ __device__ __forceinline__ void swimmer_store_row(const SwimmerDev& P, const flo
   }
 }
 
-template <int NL, int NB>
+// lane-group context of the chain kernels (swimmer_dyn.h): G = 4 lanes per env for chains of up to four links, 8 beyond
+template <int G>
+struct SwimmerCtx {
+  static constexpr int nlanes = G;
+  int l;
+  __device__ __forceinline__ int lane0() const { return l; }
+  __device__ __forceinline__ double gsum(double x) const { return DevCtx<G>{l}.gsum(x); }
+  // value of lane k of this lane's group (ds_bpermute on the two halves of the double; a handful per forward evaluation)
+  __device__ __forceinline__ double from_lane(double x, int k) const { return __shfl(x, (int)(threadIdx.x & 63u) - l + k, 64); }
+};
+
+template <int NL, int NB, int G>
 __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __restrict__ Pp, int n, PointState S,
                                                             const float* __restrict__ actions, float* __restrict__ obs,
                                                             float* __restrict__ reward, uint8_t* __restrict__ done,
                                                             int* __restrict__ goal_idx, float* __restrict__ info,
                                                             int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
                                                             float* __restrict__ final_obs, int ostride) {
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= n) return;
+  // G adjacent lanes advance one env (lane b owns link b of the chain); everything outside the forward dynamics' per-link part
+  // is computed redundantly by the G lanes, the group's first lane stores
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int env = gid / G;
+  const SwimmerCtx<G> cx{(int)(threadIdx.x % G)};
+  const bool live = env < n && cx.l == 0;
+  if (env >= n) env = n - 1;  // surplus groups shadow the last env (no stores): every lane reaches the group sums
   constexpr int NR = NL + 2, NV = NR + NB, NH = NL - 1;  // NB: slide dofs of the movable block
   const SwimmerDev& P = *Pp;
   const int nb3 = (NB && P.observe_blocks) ? 3 : 0, NO = 2 * NV + 1 + nb3;
@@ -202,7 +218,8 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
   for (int k = 0; k < NV; k++) { qf[k] = S.qv[(size_t)k * n + env]; vf[k] = S.qv[(size_t)(NV + k) * n + env]; }
   for (int k = 0; k < NH; k++) af[k] = actions[(size_t)env * NH + k];
   int t_new;
-  int st = swimmer_maze_step<NL, NB>(P, qf, vf, af, S.t[env], o, &inner, inf4, &t_new);
+  int st = swimmer_maze_step<NL, NB>(P, qf, vf, af, S.t[env], o, &inner, inf4, &t_new, cx);
+  if (!live) return;
   float outer; int tm, gi;
   task_eval_dev(P.task, o, &outer, &tm, &gi);
   uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
@@ -314,8 +331,9 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
   PointState S{h->state, h->pt_t, h->pt_ep};
   if (h->robot == MZ_ROBOT_SWIMMER) {
 #define MZ_SW_STEP(NL, NB)                                                                                                          \
-  hipLaunchKernelGGL((swimmer_step_kernel<NL, NB>), dim3((h->n + 255) / 256), dim3(256), 0, st, h->swimmer_dev, h->n, S, actions_dev, obs_dev, \
-                     reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs, h->model.obs_dim)
+  hipLaunchKernelGGL((swimmer_step_kernel<NL, NB, (NL <= 4 ? 4 : 8)>), dim3((unsigned)(((size_t)h->n * (NL <= 4 ? 4 : 8) + 255) / 256)), dim3(256), 0, st, \
+                     h->swimmer_dev, h->n, S, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed,    \
+                     h->env0, h->final_obs, h->model.obs_dim)
     const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
     if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_STEP(3, 3); else if (bd == 2) MZ_SW_STEP(3, 2); else MZ_SW_STEP(3, 0); }
     else if (h->swimmer.nlink == 2) { if (bd == 3) MZ_SW_STEP(2, 3); else if (bd == 2) MZ_SW_STEP(2, 2); else MZ_SW_STEP(2, 0); }

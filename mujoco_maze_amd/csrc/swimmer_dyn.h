@@ -1,4 +1,4 @@
-// swimmer_dyn.h — the Swimmer robot's (and the Reacher's) MazeEnv.step, one environment per lane (fp64).
+// swimmer_dyn.h — the Swimmer robot's (and the Reacher's) MazeEnv.step, one environment per group of 4 (8) lanes (fp64).
 //
 // The Reacher (mujoco_maze/reacher.py:15-80, assets/reacher.xml — whose <mujoco model="swimmer">) is the same
 // planar chain with TWO links and one motor, same medium, same step/reward code: the functions below are
@@ -155,45 +155,69 @@ MZS_HD void sw_solve(const double A[NV][NV], const double* b, double* x) {
   for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k]; x[i] = t / L[i][i]; }
 }
 
+// Execution context of the chain's forward dynamics.  On the device a group of G adjacent lanes (4 for chains of up to four
+// links, 8 beyond) advances ONE environment: lane b of the group owns link b — its orientation's sine / cosine, its centre's
+// Jacobian, its fluid wrench, its share of M and of the force vector — and the shares meet in group sums (DPP moves on the two
+// halves of a double, mz_device.h); the 5 x 5 solve and the joint-limit Newton then run redundantly on every lane of the group,
+// as does the RK4 bookkeeping (state in registers: nothing is handed through memory).  The one-lane context (host emulation,
+// tests/emu) walks all links itself.
+struct SwimmerOneLane {
+  static constexpr int nlanes = 1;
+  MZS_HD int lane0() const { return 0; }
+  MZS_HD double gsum(double x) const { return x; }
+  MZS_HD double from_lane(double x, int) const { return x; }
+};
+
 // forward dynamics: qacc from (q, v, motor torques tau[NL - 1]); returns status bits
-template <int NL>
-MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v, const double* tau, double* qacc) {
+template <int NL, class C>
+MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, const double* v, const double* tau, double* qacc) {
   constexpr int NV = NL + 2, NH = NL - 1;
   // link orientation angles and rates
   double phi[NL], om[NL], c[NL], s[NL];
   phi[0] = q[2]; om[0] = v[2];
   for (int b = 1; b < NL; b++) { phi[b] = phi[b - 1] + q[2 + b]; om[b] = om[b - 1] + v[2 + b]; }
-  for (int b = 0; b < NL; b++) { c[b] = cos(phi[b]); s[b] = sin(phi[b]); }
-  // position Jacobians of the link centres: p_b = p0 + sum_{k<b} off[k+1] e(phi_k) + com[b] e(phi_b)
-  double Jx[NL][NV], Jy[NL][NV], ax[NL], ay[NL], vx[NL], vy[NL];
-  for (int b = 0; b < NL; b++) {
-    for (int k = 0; k < NV; k++) { Jx[b][k] = 0.0; Jy[b][k] = 0.0; }
-    Jx[b][0] = 1.0; Jy[b][1] = 1.0;
-    ax[b] = 0.0; ay[b] = 0.0;
-    for (int k = 0; k <= b; k++) {
-      double len = k < b ? P.off[k + 1] : P.com[b];  // segment carried by the frame of link k
-      double ex = c[k] * len, ey = s[k] * len;
-      // d/d(phi_k) of the segment = (-ey, ex); phi_k depends on the hinge dofs 2..2+k
-      for (int d = 2; d <= 2 + k; d++) { Jx[b][d] += -ey; Jy[b][d] += ex; }
-      ax[b] += -om[k] * om[k] * ex; ay[b] += -om[k] * om[k] * ey;  // centripetal acceleration at qacc = 0
-    }
-    vx[b] = 0.0; vy[b] = 0.0;
-    for (int k = 0; k < NV; k++) { vx[b] += Jx[b][k] * v[k]; vy[b] += Jy[b][k] * v[k]; }
+  if constexpr (C::nlanes == 1) {
+    for (int b = 0; b < NL; b++) { c[b] = cos(phi[b]); s[b] = sin(phi[b]); }
+  } else {  // each lane evaluates the sine / cosine of its own link's angle; the others come from their lanes
+    const int me = cx.lane0() < NL ? cx.lane0() : NL - 1;
+    double pm = phi[0];
+#pragma unroll
+    for (int b = 1; b < NL; b++) pm = me == b ? phi[b] : pm;
+    const double cm = cos(pm), sm = sin(pm);
+#pragma unroll
+    for (int b = 0; b < NL; b++) { c[b] = cx.from_lane(cm, b); s[b] = cx.from_lane(sm, b); }
   }
+  // position Jacobians of the link centres: p_b = p0 + sum_{k<b} off[k+1] e(phi_k) + com[b] e(phi_b); link b on lane b
   double M[NV][NV], frc[NV];
   for (int i = 0; i < NV; i++) {
     frc[i] = 0.0;
-    for (int j = 0; j < NV; j++) M[i][j] = i == j ? P.armature[i] : 0.0;
+    for (int j = 0; j < NV; j++) M[i][j] = 0.0;
   }
+#pragma unroll
   for (int b = 0; b < NL; b++) {
-    double m = P.mass[b];
+    if (C::nlanes > 1 && b != cx.lane0()) continue;  // (lanes beyond the chain's length contribute zeros)
+    double Jx[NV], Jy[NV], ax = 0.0, ay = 0.0;
+    for (int k = 0; k < NV; k++) { Jx[k] = 0.0; Jy[k] = 0.0; }
+    Jx[0] = 1.0; Jy[1] = 1.0;
+#pragma unroll
+    for (int k = 0; k <= b; k++) {
+      const double len = k < b ? P.off[k + 1] : P.com[b];  // segment carried by the frame of link k
+      const double ex = c[k] * len, ey = s[k] * len;
+      // d/d(phi_k) of the segment = (-ey, ex); phi_k depends on the hinge dofs 2..2+k
+#pragma unroll
+      for (int d = 2; d <= 2 + k; d++) { Jx[d] += -ey; Jy[d] += ex; }
+      ax += -om[k] * om[k] * ex; ay += -om[k] * om[k] * ey;  // centripetal acceleration at qacc = 0
+    }
+    double vx = 0.0, vy = 0.0;
+    for (int k = 0; k < NV; k++) { vx += Jx[k] * v[k]; vy += Jy[k] * v[k]; }
+    const double m = P.mass[b];
     // fluid forces in the link frame at its centre (MuJoCo inertia-box model)
-    double lvx = c[b] * vx[b] + s[b] * vy[b], lvy = -s[b] * vx[b] + c[b] * vy[b], w = om[b];
+    const double lvx = c[b] * vx + s[b] * vy, lvy = -s[b] * vx + c[b] * vy, w = om[b];
     const double* bx = P.box[b];
     double fx = 0.0, fy = 0.0, tz = 0.0;
     if (P.viscosity > 0.0) {
-      double diam = (bx[0] + bx[1] + bx[2]) / 3.0;
-      double sl = -3.0 * P.viscosity * 3.141592653589793 * diam, sa = -P.viscosity * 3.141592653589793 * diam * diam * diam;
+      const double diam = (bx[0] + bx[1] + bx[2]) / 3.0;
+      const double sl = -3.0 * P.viscosity * 3.141592653589793 * diam, sa = -P.viscosity * 3.141592653589793 * diam * diam * diam;
       fx += sl * lvx; fy += sl * lvy; tz += sa * w;
     }
     if (P.density > 0.0) {
@@ -201,15 +225,24 @@ MZS_HD int swimmer_forward(const SwimmerDev& P, const double* q, const double* v
       fy -= 0.5 * P.density * bx[0] * bx[2] * fabs(lvy) * lvy;
       tz -= P.density * bx[2] * (bx[0] * bx[0] * bx[0] * bx[0] + bx[1] * bx[1] * bx[1] * bx[1]) * fabs(w) * w / 64.0;
     }
-    double Fx = c[b] * fx - s[b] * fy, Fy = s[b] * fx + c[b] * fy;
+    const double Fx = c[b] * fx - s[b] * fy, Fy = s[b] * fx + c[b] * fy;
+#pragma unroll
     for (int i = 0; i < NV; i++) {
-      double jw_i = (i >= 2 && i <= 2 + b) ? 1.0 : 0.0;
-      frc[i] += Jx[b][i] * (Fx - m * ax[b]) + Jy[b][i] * (Fy - m * ay[b]) + jw_i * tz;
-      for (int j = 0; j < NV; j++) {
-        double jw_j = (j >= 2 && j <= 2 + b) ? 1.0 : 0.0;
-        M[i][j] += m * (Jx[b][i] * Jx[b][j] + Jy[b][i] * Jy[b][j]) + P.izz[b] * jw_i * jw_j;
+      const double jw_i = (i >= 2 && i <= 2 + b) ? 1.0 : 0.0;
+      frc[i] += Jx[i] * (Fx - m * ax) + Jy[i] * (Fy - m * ay) + jw_i * tz;
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        const double jw_j = (j >= 2 && j <= 2 + b) ? 1.0 : 0.0;
+        M[i][j] += m * (Jx[i] * Jx[j] + Jy[i] * Jy[j]) + P.izz[b] * jw_i * jw_j;
       }
     }
+  }
+  // the links' shares meet: sums over the lane group (identity on one lane), then the symmetric half and the armature
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    frc[i] = cx.gsum(frc[i]);
+#pragma unroll
+    for (int j = 0; j <= i; j++) { const double t = cx.gsum(M[i][j]) + (i == j ? P.armature[i] : 0.0); M[i][j] = t; M[j][i] = t; }
   }
   for (int k = 0; k < NH; k++) frc[3 + k] += tau[k];
   double qas[NV];
@@ -324,8 +357,8 @@ MZS_HD void swimmer_block_step(const SwimmerDev& P, double* qb, double* vb) {
 }
 
 // One MazeEnv.step: q, v in/out (fp64 working copy); info4 = x, y, reward_forward, reward_ctrl
-template <int NL>
-MZS_HD int swimmer_env_step(const SwimmerDev& P, double* q, double* v, const double* action, int t_in, double* inner_reward,
+template <int NL, class C>
+MZS_HD int swimmer_env_step(const C& cx, const SwimmerDev& P, double* q, double* v, const double* action, int t_in, double* inner_reward,
                             double* info4, int* t_out) {
   int status = 0;
   double x0 = q[0], y0 = q[1];
@@ -337,7 +370,7 @@ MZS_HD int swimmer_env_step(const SwimmerDev& P, double* q, double* v, const dou
     double q0[NV], v0[NV], accv[NV], accf[NV], qs[NV], vs[NV], a[NV];
     for (int k = 0; k < NV; k++) { q0[k] = q[k]; v0[k] = v[k]; accv[k] = 0.0; accf[k] = 0.0; qs[k] = q[k]; vs[k] = v[k]; }
     for (int st = 0; st < 4; st++) {
-      status |= swimmer_forward<NL>(P, qs, vs, tau, a);
+      status |= swimmer_forward<NL>(cx, P, qs, vs, tau, a);
       double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
       for (int k = 0; k < NV; k++) {
         accv[k] += bw * vs[k]; accf[k] += bw * a[k];
@@ -380,14 +413,14 @@ MZS_HD void swimmer_obs_row(const SwimmerDev& P, const float* qf, const float* v
 // One MazeEnv.step of a swimmer / reacher env with a BD-dof movable block on the fp32 state (qf, vf: NV = NL + 2 + BD entries,
 // in and out): the chain's step, the block's own motion, the observation row o[2 NV + 4] and the inner reward.
 // Returns status bits.  Shared by swimmer_step_kernel and the CPU emulation of tests/emu.
-template <int NL, int BD>
+template <int NL, int BD, class C = SwimmerOneLane>
 MZS_HD int swimmer_maze_step(const SwimmerDev& P, float* qf, float* vf, const float* action, int t_in, float* o, double* inner_reward,
-                             double* info4, int* t_out) {
+                             double* info4, int* t_out, const C& cx = C()) {
   constexpr int NR = NL + 2, NH = NL - 1;
   double q[NR], v[NR], a[NH];
   for (int k = 0; k < NR; k++) { q[k] = (double)qf[k]; v[k] = (double)vf[k]; }
   for (int k = 0; k < NH; k++) a[k] = (double)action[k];
-  int st = swimmer_env_step<NL>(P, q, v, a, t_in, inner_reward, info4, t_out);
+  int st = swimmer_env_step<NL>(cx, P, q, v, a, t_in, inner_reward, info4, t_out);
   bool badv = false;
   for (int k = 0; k < NR; k++) { badv = badv || !(fabs(q[k]) < 1e10) || !(fabs(v[k]) < 1e10); qf[k] = (float)q[k]; vf[k] = (float)v[k]; }
   if constexpr (BD > 0) {  // no contacts (swimmer.xml:3 collision="predefined"): drag, gravity on a z slide, joint limits

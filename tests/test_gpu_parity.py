@@ -913,6 +913,42 @@ def test_ant_small_billiard_free_joint_ball(torch, oracle):
     env.close()
 
 
+def test_captured_state_where_the_two_enumeration_passes_diverged(torch, oracle):
+    """Regression fixture of round 3's soak (tests/golden/antpushmaze_count_fill_case.npz, captured on the device by
+    tools/catch_nan.py): an AntPushMaze state in which the count pass and the fill pass of the kernel's contact enumeration —
+    two instantiations of one template under relaxed floating-point flags — disagreed about the second support point of an
+    ankle capsule against a box.  The counted slot stayed unwritten and the step went NaN.  The fill pass now owns exactly the
+    counted slots (an uncounted contact is dropped, a missing one is inert, ant_dyn.h con_fill_item) and the device kernels
+    enumerate once (con_enum_item); the step must be finite and agree with the oracle."""
+    c = np.load(os.path.join(os.path.dirname(__file__), "golden", "antpushmaze_count_fill_case.npz"))
+    env = mm.make("AntPushMaze-v0", num_envs=1, force_vec=True)
+    cm = env.model
+    st = dict(qpos=c["qpos"][None].astype(np.float64), qvel=c["qvel"][None].astype(np.float64), warm=c["warm"][None].astype(np.float64),
+              t=np.array([int(c["t"])], np.int32))
+    env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+    obs, rew, done, info = env.step(torch.as_tensor(c["act"][None], device=env.device))
+    qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+    assert np.isfinite(qpos).all() and np.isfinite(qvel).all() and np.isfinite(obs.cpu().numpy()).all()
+    assert (int(env.status().cpu().numpy()[0]) & 1) == 0
+    # The state sits ON the discontinuity that made the passes differ — whether mjc_CapsuleBox's second support point exists:
+    # the float64 oracle lands 1.6e-3 away from itself when the state moves by one fp32 ulp.  The device must land on one of
+    # the oracle's two branches.
+    rng = np.random.default_rng(0)
+    branches = []
+    for k in range(25):
+        p = {kk: v.copy() for kk, v in st.items()}
+        if k:
+            p["qpos"] += rng.uniform(-2e-7, 2e-7, p["qpos"].shape) * np.maximum(1.0, np.abs(p["qpos"]))
+            p["qvel"] += rng.uniform(-2e-7, 2e-7, p["qvel"].shape) * np.maximum(1.0, np.abs(p["qvel"]))
+        oracle.step(cm, p, c["act"][None].astype(np.float64))
+        branches.append(p["qpos"][0])
+    branches = np.array(branches)
+    gap = np.abs(branches - qpos[0]).max(1)
+    assert np.abs(branches - branches[0]).max() > 1e-3, "fixture no longer on the discontinuity"
+    assert gap.min() < 2e-5, gap.min()
+    env.close()
+
+
 @pytest.mark.parametrize("which", ["biped_ant", "y_swimmer"])
 def test_user_robot_of_another_topology_on_the_device(torch, oracle, which):
     """SURVEY 8f rank 4 / VERDICT r02 #8: a user's AgentModel whose MJCF is NOT one of the built-in shapes — a two-legged ant with a
