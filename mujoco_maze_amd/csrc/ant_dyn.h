@@ -1181,6 +1181,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
 // and is rebuilt from the geom) inside the not-yet-used cY block, the second phase only maps compact contact slots to staging
 // entries (prefix sums over the counts).  A geom with more contacts than MZ_STAGE (a foot in a wall corner) flags the env,
 // which then runs the two-pass fill: same contacts, same order, always.
+#define MZ_NEWTON_STALL 2e-6f  // relative step below which a line-searched Newton step counts as no step (fp32: 6e-8 per operation)
 #define MZ_STAGE_OF(NB) ((NB) == 0 ? 3 : 4)  // a block's cell enumerator finds up to 2 x 2 contacts
 template <int NB>
 MZ_HD float* con_stage(AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
@@ -1546,12 +1547,17 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
       if (s.lsign[j] != 0.f) changed = changed || ((s.ljar[j] < 0.f) != (s.ljar[j] + s.ljv[j] < 0.f));
     }
     changed = cx.gany(changed);
-    float alpha = 1.f;
+    float alpha = 1.f, sn = 1.f, qn = 0.f;
     bool exact = !changed;
     if (changed) {
       float p1 = 0.f, p2 = 0.f;
       MZ_FOR(i, NV) { float ms = arrow_row_mul<NH>(s.M, s.search, i); s.Ms[i] = ms; p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
       p1 = cx.gsum(p1); p2 = cx.gsum(p2);
+      {
+        float sp = 0.f, qp = 0.f;
+        MZ_FOR(i, NV) { sp += s.search[i] * s.search[i]; qp += s.qacc[i] * s.qacc[i]; }
+        sn = cx.gsum(sp); qn = cx.gsum(qp);
+      }
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
       for (int ls = 0; ls < K.ls_iter; ls++) {
         float d1 = 0.f, d2 = 0.f;
@@ -1598,6 +1604,10 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     // The full Newton step stayed inside one active set: the cost is exactly quadratic there, so the new
     // point is its minimiser — no verification pass needed.
     if (exact && K.trust_exact) done = true;
+    // stationary at fp32 resolution: a line-searched step that moves qacc by less than MZ_NEWTON_STALL of its norm.  Active-set
+    // flips of rows whose residual is zero within round-off otherwise keep the iteration alive until the cap (soak, round 3:
+    // such envs jittered by 3e-7 |qacc| per iteration for 50 iterations, 1e-7 from the oracle's answer all along).
+    if (changed && alpha * alpha * sn <= MZ_NEWTON_STALL * MZ_NEWTON_STALL * qn) done = true;
     cx.tick(s, 7);
     it++;
   }

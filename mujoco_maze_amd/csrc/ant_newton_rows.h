@@ -463,11 +463,12 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
       }
     }
     changed = cx.gany(changed);
-    float alpha = 1.f, Ms = 0.f;
+    float alpha = 1.f, Ms = 0.f, sn = 1.f, qn = 0.f;
     const bool exact = !changed;
     if (changed) {  // exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on the piecewise-linear phi'
       Ms = matvec<NR>(Mrow, search);
       const float p1 = rsum(search * Mx), p2 = rsum(search * Ms);
+      sn = rsum(isdof ? search * search : 0.f); qn = rsum(isdof ? qacc * qacc : 0.f);
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
       for (int ls = 0; ls < K.ls_iter; ls++) {
         float d1 = 0.f, d2 = 0.f;
@@ -527,6 +528,7 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
       }
     }
     if (exact && K.trust_exact) done = true;
+    if (changed && alpha * alpha * sn <= MZ_NEWTON_STALL * MZ_NEWTON_STALL * qn) done = true;  // stationary at fp32 resolution (ant_dyn.h ant_solve)
     cx.tick(s, 7);
     it++;
   }

@@ -11,6 +11,7 @@ for env_id, n in (("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 
                   ("AntFall-v0", 2048), ("AntMultiFall-v0", 1024), ("PointFall-v0", 4096), ("AntSmallBilliard-v0", 2048)):
     if ONLY and env_id not in ONLY: continue
     env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
+    if os.environ.get("MZ_SOAK_RTOL") and env_id.startswith("Ant"): env.set_option("solver_rtol", float(os.environ["MZ_SOAK_RTOL"]))
     env.reset(seed=3)
     g = torch.Generator(device=env.device).manual_seed(0)
     lo = torch.as_tensor(env.action_space.low, device=env.device); hi = torch.as_tensor(env.action_space.high, device=env.device)
