@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   }
 }
 
+#ifdef MZ_ISA_ONLY
+// developer aid (tools/isa_one.sh): compile ONE instantiation of the step kernel to look at its ISA / run the DPP hazard check
+// in seconds instead of building all of them:  hipcc ... -DMZ_ISA_ONLY -DMZ_ISA_NB=0 -DMZ_ISA_G=16 -S ant_kernels.hip
+template __global__ void ant_step_kernel<MZ_ISA_NB, MZ_ISA_G, false>(const AntDev*, int, float*, const float*, float*, float*, uint8_t*, int*, float*, int*, int,
+                                                                     uint64_t, uint64_t, unsigned long long*, float*, int, float*);
+#else
 template <int NB, int G>
 __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const float* __restrict__ state,
                                                           const float* __restrict__ actions, float* __restrict__ qacc,
@@ -403,3 +409,4 @@ hipError_t mzk_ant_task_eval(mz_handle* h, hipStream_t st, int n, const float* o
   hipLaunchKernelGGL(ant_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->ant_dev, n, h->lay.ostride, obs, reward, done, goal_idx);
   return hipGetLastError();
 }
+#endif  // MZ_ISA_ONLY

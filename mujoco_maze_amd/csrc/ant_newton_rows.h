@@ -39,11 +39,103 @@ __device__ __forceinline__ float rsum(float x) {  // all-reduce over the 16 lane
   return x;
 }
 
-// y_r = sum_k A[r][k] x_k with row r of A in registers (Arow) and x distributed one entry per lane
-template <int N, int K = 0>
-__device__ __forceinline__ float matvec(const float (&Arow)[N], float x) {
-  if constexpr (K == N) return 0.f;
-  else return Arow[K] * bcast<K>(x) + matvec<N, K + 1>(Arow, x);
+// ---- DPP operands fused into the arithmetic (hand-placed: the compiler's DPP combiner does not fuse a `row_newbcast` move into
+// an FMA on gfx950 — V_FMA_F32 is still three-address when the combiner runs — and emits  v_mov 0 ; s_nop 1 ; v_mov_dpp ; v_fma,
+// five issue slots, for what the hardware does in one:  v_fmac_f32_dpp acc, x, m row_newbcast:P  =  acc += x[lane P of my row] * m).
+// Hazard rule kept by construction and checked on the built code by tools/check_dpp_hazards.py (tests/test_capi_and_emu.py):
+// a VGPR read by a DPP instruction — any operand — must not have been written by the two preceding VALU issue slots.  Every
+// block below therefore opens with `s_nop 1` (its inputs may be fresh) and never reads a register it wrote less than three
+// instructions earlier.
+#define MZ_DPP_TAIL " row_mask:0xf bank_mask:0xf\n\t"
+// matvec: three accumulators round-robin (a dependent fmac_dpp chain would need two idle slots per link)
+#define MZ_MV_MUL(acc, k) "v_mul_f32_dpp %" #acc ", %[x], %[a" #k "] row_newbcast:" #k MZ_DPP_TAIL
+#define MZ_MV_FMA(acc, k) "v_fmac_f32_dpp %" #acc ", %[x], %[a" #k "] row_newbcast:" #k MZ_DPP_TAIL
+
+// y_r = sum_k A[r][k] x_k with row r of A in registers (Arow) and x distributed one entry per lane: 14 / 16 instructions
+__device__ __forceinline__ float matvec(const float (&A)[14], float x) {
+  float s0, s1, s2;
+  asm("s_nop 1\n\t" MZ_MV_MUL(0, 0) MZ_MV_MUL(1, 1) MZ_MV_MUL(2, 2) MZ_MV_FMA(0, 3) MZ_MV_FMA(1, 4) MZ_MV_FMA(2, 5) MZ_MV_FMA(0, 6) MZ_MV_FMA(1, 7)
+      MZ_MV_FMA(2, 8) MZ_MV_FMA(0, 9) MZ_MV_FMA(1, 10) MZ_MV_FMA(2, 11) MZ_MV_FMA(0, 12) MZ_MV_FMA(1, 13)
+      : "=&v"(s0), "=&v"(s1), "=&v"(s2)
+      : [x] "v"(x), [a0] "v"(A[0]), [a1] "v"(A[1]), [a2] "v"(A[2]), [a3] "v"(A[3]), [a4] "v"(A[4]), [a5] "v"(A[5]), [a6] "v"(A[6]), [a7] "v"(A[7]),
+        [a8] "v"(A[8]), [a9] "v"(A[9]), [a10] "v"(A[10]), [a11] "v"(A[11]), [a12] "v"(A[12]), [a13] "v"(A[13]));
+  return (s0 + s1) + s2;
+}
+__device__ __forceinline__ float matvec(const float (&A)[16], float x) {
+  float s0, s1, s2;
+  asm("s_nop 1\n\t" MZ_MV_MUL(0, 0) MZ_MV_MUL(1, 1) MZ_MV_MUL(2, 2) MZ_MV_FMA(0, 3) MZ_MV_FMA(1, 4) MZ_MV_FMA(2, 5) MZ_MV_FMA(0, 6) MZ_MV_FMA(1, 7)
+      MZ_MV_FMA(2, 8) MZ_MV_FMA(0, 9) MZ_MV_FMA(1, 10) MZ_MV_FMA(2, 11) MZ_MV_FMA(0, 12) MZ_MV_FMA(1, 13) MZ_MV_FMA(2, 14) MZ_MV_FMA(0, 15)
+      : "=&v"(s0), "=&v"(s1), "=&v"(s2)
+      : [x] "v"(x), [a0] "v"(A[0]), [a1] "v"(A[1]), [a2] "v"(A[2]), [a3] "v"(A[3]), [a4] "v"(A[4]), [a5] "v"(A[5]), [a6] "v"(A[6]), [a7] "v"(A[7]),
+        [a8] "v"(A[8]), [a9] "v"(A[9]), [a10] "v"(A[10]), [a11] "v"(A[11]), [a12] "v"(A[12]), [a13] "v"(A[13]), [a14] "v"(A[14]), [a15] "v"(A[15]));
+  return (s0 + s1) + s2;
+}
+
+// elimination step of one pivot: h_k += nli * h_k[lane P] for the right-hand side and every column that can still be non-zero
+// in the pivot row — one instruction per column, the columns independent of each other (overloads by column count)
+#define MZ_EL(i) "v_fmac_f32_dpp %" #i ", %" #i ", %[li] row_newbcast:%[p]" MZ_DPP_TAIL
+#define MZ_EL_IN [li] "v"(nli), [p] "n"(P)
+template <int P> __device__ __forceinline__ void elim(float nli, float& b) { asm("s_nop 1\n\t" MZ_EL(0) : "+v"(b) : MZ_EL_IN); }
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0) { asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) : "+v"(b), "+v"(h0) : MZ_EL_IN); }
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) : "+v"(b), "+v"(h0), "+v"(h1) : MZ_EL_IN);
+}
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1, float& h2) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) MZ_EL(3) : "+v"(b), "+v"(h0), "+v"(h1), "+v"(h2) : MZ_EL_IN);
+}
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1, float& h2, float& h3) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) MZ_EL(3) MZ_EL(4) : "+v"(b), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : MZ_EL_IN);
+}
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1, float& h2, float& h3, float& h4) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) MZ_EL(3) MZ_EL(4) MZ_EL(5) : "+v"(b), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : MZ_EL_IN);
+}
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1, float& h2, float& h3, float& h4, float& h5) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) MZ_EL(3) MZ_EL(4) MZ_EL(5) MZ_EL(6)
+      : "+v"(b), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5) : MZ_EL_IN);
+}
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1, float& h2, float& h3, float& h4, float& h5, float& h6) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) MZ_EL(3) MZ_EL(4) MZ_EL(5) MZ_EL(6) MZ_EL(7)
+      : "+v"(b), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(h6) : MZ_EL_IN);
+}
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1, float& h2, float& h3, float& h4, float& h5, float& h6, float& h7) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) MZ_EL(3) MZ_EL(4) MZ_EL(5) MZ_EL(6) MZ_EL(7) MZ_EL(8)
+      : "+v"(b), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(h6), "+v"(h7) : MZ_EL_IN);
+}
+template <int P> __device__ __forceinline__ void elim(float nli, float& b, float& h0, float& h1, float& h2, float& h3, float& h4, float& h5, float& h6, float& h7, float& h8) {
+  asm("s_nop 1\n\t" MZ_EL(0) MZ_EL(1) MZ_EL(2) MZ_EL(3) MZ_EL(4) MZ_EL(5) MZ_EL(6) MZ_EL(7) MZ_EL(8) MZ_EL(9)
+      : "+v"(b), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(h6), "+v"(h7), "+v"(h8) : MZ_EL_IN);
+}
+
+// contribution of contact C (owner: lane P of the row) to row r of the Hessian and to the gradient.  cg[8] = the contact's gradient
+// block (3) and curvature block (5), read on the owner lane; (j0, j1, j2) = this lane's own column of the contact's Jacobian.
+//   fold_t:  t = g . j,  (t0, t1, t2) = (W j)         ten instructions, four independent chains
+//   fold_h:  Hrow[k] += t0 j0[lane k] + t1 j1[lane k] + t2 j2[lane k]   three instructions per column, the columns independent
+#define MZ_FA_MUL(o, c, j) "v_mul_f32_dpp %" #o ", %[" #c "], %[" #j "] row_newbcast:%[p]" MZ_DPP_TAIL
+#define MZ_FA_FMA(o, c, j) "v_fmac_f32_dpp %" #o ", %[" #c "], %[" #j "] row_newbcast:%[p]" MZ_DPP_TAIL
+template <int P>
+__device__ __forceinline__ void fold_t(const float (&cg)[8], float j0, float j1, float j2, float& t, float& t0, float& t1, float& t2) {
+  asm("s_nop 1\n\t" MZ_FA_MUL(0, c0, j0) MZ_FA_MUL(1, c3, j0) MZ_FA_MUL(2, c4, j0) MZ_FA_MUL(3, c5, j0) MZ_FA_FMA(0, c1, j1) MZ_FA_FMA(1, c4, j1)
+      MZ_FA_FMA(2, c6, j1) MZ_FA_FMA(3, c7, j2) MZ_FA_FMA(0, c2, j2) MZ_FA_FMA(1, c5, j2)
+      : "=&v"(t), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+      : [c0] "v"(cg[0]), [c1] "v"(cg[1]), [c2] "v"(cg[2]), [c3] "v"(cg[3]), [c4] "v"(cg[4]), [c5] "v"(cg[5]), [c6] "v"(cg[6]), [c7] "v"(cg[7]),
+        [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [p] "n"(P));
+}
+#define MZ_FH(k, j, t) "v_fmac_f32_dpp %" #k ", %[" #j "], %[" #t "] row_newbcast:" #k MZ_DPP_TAIL
+#define MZ_FH14(j, t) MZ_FH(0, j, t) MZ_FH(1, j, t) MZ_FH(2, j, t) MZ_FH(3, j, t) MZ_FH(4, j, t) MZ_FH(5, j, t) MZ_FH(6, j, t) MZ_FH(7, j, t) \
+                      MZ_FH(8, j, t) MZ_FH(9, j, t) MZ_FH(10, j, t) MZ_FH(11, j, t) MZ_FH(12, j, t) MZ_FH(13, j, t)
+#define MZ_FH16(j, t) MZ_FH14(j, t) MZ_FH(14, j, t) MZ_FH(15, j, t)
+#define MZ_FH_IN [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2)
+__device__ __forceinline__ void fold_h(float (&H)[14], float j0, float j1, float j2, float t0, float t1, float t2) {
+  asm("s_nop 1\n\t" MZ_FH14(j0, t0) MZ_FH14(j1, t1) MZ_FH14(j2, t2)
+      : "+v"(H[0]), "+v"(H[1]), "+v"(H[2]), "+v"(H[3]), "+v"(H[4]), "+v"(H[5]), "+v"(H[6]), "+v"(H[7]), "+v"(H[8]), "+v"(H[9]), "+v"(H[10]),
+        "+v"(H[11]), "+v"(H[12]), "+v"(H[13])
+      : MZ_FH_IN);
+}
+__device__ __forceinline__ void fold_h(float (&H)[16], float j0, float j1, float j2, float t0, float t1, float t2) {
+  asm("s_nop 1\n\t" MZ_FH16(j0, t0) MZ_FH16(j1, t1) MZ_FH16(j2, t2)
+      : "+v"(H[0]), "+v"(H[1]), "+v"(H[2]), "+v"(H[3]), "+v"(H[4]), "+v"(H[5]), "+v"(H[6]), "+v"(H[7]), "+v"(H[8]), "+v"(H[9]), "+v"(H[10]),
+        "+v"(H[11]), "+v"(H[12]), "+v"(H[13]), "+v"(H[14]), "+v"(H[15])
+      : MZ_FH_IN);
 }
 
 // one Gauss-Jordan pivot P on the row-distributed system (Hrow | b): every other row gets rid of column P.
@@ -52,9 +144,8 @@ template <int P, int N, int... COLS>
 __device__ __forceinline__ void pivot(int r, float (&Hrow)[N], float& b, float& dinv) {
   const float d = bcast<P>(Hrow[P]);
   const float ri = 1.0f / fmaxf(d, 1e-30f);
-  const float li = (r == P) ? 0.f : Hrow[P] * ri;
-  ((Hrow[COLS] -= li * bcast<P>(Hrow[COLS])), ...);
-  b -= li * bcast<P>(b);
+  const float nli = (r == P) ? 0.f : -(Hrow[P] * ri);
+  elim<P>(nli, b, Hrow[COLS]...);
   dinv = (r == P) ? ri : dinv;
 }
 
@@ -248,23 +339,68 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     }
   }
 
-  // J[c][a] . x for the lane's own robot contact, x read from an LDS vector in MuJoCo dof order
-  auto jdot3 = [&](const float* x, float (&o)[MA][3]) {
+  // ---- the robot contacts' Jacobians, in registers for the whole solve (read from LDS once per evaluation):
+  //   jown[C][a]  this lane's own COLUMN of contact C (zero when the contact does not see this dof) — the Hessian folds;
+  //   Jf[m][a][k] the ROW a of this lane's own contact over all dofs k (zero outside hub + its leg) — J x as three DPP matvecs.
+  // With them a Newton iteration touches no memory at all.
+  auto each_contact = [&](auto&& f) {  // f(C) for the contact slots some env of the wave uses (wave-uniform guards)
+    if (cx.any(ncon > 0)) {
+      f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
+      if (cx.any(ncon > 4)) {
+        f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
+        if (cx.any(ncon > 8)) {
+          f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
+          f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{});
+          if constexpr (MA > 1) {
+            if (any2) {  // second slot of the contact lanes: a robot lying against block and walls at once
+              f(std::integral_constant<int, 16>{}); f(std::integral_constant<int, 17>{}); f(std::integral_constant<int, 18>{}); f(std::integral_constant<int, 19>{});
+              f(std::integral_constant<int, 20>{}); f(std::integral_constant<int, 21>{}); f(std::integral_constant<int, 22>{}); f(std::integral_constant<int, 23>{});
+              f(std::integral_constant<int, 24>{}); f(std::integral_constant<int, 25>{}); f(std::integral_constant<int, 26>{}); f(std::integral_constant<int, 27>{});
+              f(std::integral_constant<int, 28>{}); f(std::integral_constant<int, 29>{}); f(std::integral_constant<int, 30>{}); f(std::integral_constant<int, 31>{});
+            }
+          }
+        }
+      }
+    }
+  };
+  float jown[16 * MA][3];
+  each_contact([&](auto Cc) {
+    constexpr int C = decltype(Cc)::value;
+    jown[C][0] = jown[C][1] = jown[C][2] = 0.f;
+    if (C < ncon) {  // (uniform within the env's row)
+      const int lc = s.cleg[nB + C];
+      const int col = r < 6 ? r : ((ishinge && leg == lc) ? NHC + d : ((NB == 1 && r >= 14 && r < 16) ? r - 8 : -1));
+      if (col >= 0) { jown[C][0] = s.cJ[nB + C][0][col]; jown[C][1] = s.cJ[nB + C][1][col]; jown[C][2] = s.cJ[nB + C][2][col]; }
+    }
+  });
+  float Jf[MA][3][NR];
+#pragma unroll
+  for (int m = 0; m < MA; m++) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int k = 0; k < NR; k++) Jf[m][a][k] = 0.f;
+    if (m == 1 && !any2) continue;
+    if (iscon[m]) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float* Jr = s.cJ[cr[m]][a];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jf[m][a][k] = Jr[k];
+        if constexpr (NB == 1) { Jf[m][a][14] = Jr[6]; Jf[m][a][15] = Jr[7]; }
+        const float jh = Jr[NHC], ja = Jr[NHC + 1];
+#pragma unroll
+        for (int l2 = 0; l2 < 4; l2++) { Jf[m][a][6 + 2 * l2] = cl[m] == l2 ? jh : 0.f; Jf[m][a][7 + 2 * l2] = cl[m] == l2 ? ja : 0.f; }
+      }
+    }
+  }
+  // J[c][a] . x for the lane's own robot contact(s), x row-distributed (one entry per dof lane; spare lanes are never read)
+  auto jdot3 = [&](float x, float (&o)[MA][3]) {
 #pragma unroll
     for (int m = 0; m < MA; m++) {
       o[m][0] = o[m][1] = o[m][2] = 0.f;
       if (m == 1 && !any2) continue;
-      if (iscon[m]) {
-        float xv[NHC + 2];
-#pragma unroll
-        for (int k = 0; k < 6; k++) xv[k] = x[k];
-        if constexpr (NB == 1) { xv[6] = x[14]; xv[7] = x[15]; }
-        const int lg = cl[m] >= 0 ? cl[m] : 0;
-        xv[NHC] = cl[m] >= 0 ? x[6 + 2 * lg] : 0.f;
-        xv[NHC + 1] = cl[m] >= 0 ? x[7 + 2 * lg] : 0.f;
-#pragma unroll
-        for (int k = 0; k < NHC + 2; k++) { o[m][0] += s.cJ[cr[m]][0][k] * xv[k]; o[m][1] += s.cJ[cr[m]][1][k] * xv[k]; o[m][2] += s.cJ[cr[m]][2][k] * xv[k]; }
-      }
+      o[m][0] = matvec(Jf[m][0], x); o[m][1] = matvec(Jf[m][1], x); o[m][2] = matvec(Jf[m][2], x);
     }
   };
   // block contacts: residual rows from the two block entries (b0, b1) of a row-distributed vector
@@ -278,12 +414,11 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   // ---- initial guess
   float qacc = warm;
   if (compare) {  // MuJoCo's rule on the first evaluation of a step: the better of warm start and qacc_smooth, by cost
-    cx.sync();  // s.qas is read back by the contact lanes
     const float dw = warm - qas;
-    float cw = 0.5f * dw * matvec<NR>(Mrow, dw), cs = 0.f;
+    float cw = 0.5f * dw * matvec(Mrow, dw), cs = 0.f;
     float jw3[MA][3], jq3[MA][3];
-    jdot3(s.warm, jw3);
-    jdot3(s.qas, jq3);
+    jdot3(warm, jw3);
+    jdot3(qas, jq3);
 #pragma unroll
     for (int m = 0; m < MA; m++)
       if (iscon[m]) {
@@ -317,10 +452,8 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
 #pragma unroll
   for (int m = 0; m < MA; m++) { u[m][0] = u[m][1] = u[m][2] = 0.f; v[m][0] = v[m][1] = v[m][2] = 0.f; }
   if (cx.any(!done)) {  // residuals at the starting point; afterwards they follow the step
-    if (isdof) s.qacc[ri] = qacc;
-    cx.sync();
-    Mx = matvec<NR>(Mrow, qacc) - qfs;
-    jdot3(s.qacc, u);
+    Mx = matvec(Mrow, qacc) - qfs;
+    jdot3(qacc, u);
 #pragma unroll
     for (int m = 0; m < MA; m++) { u[m][0] -= ar[m][0]; u[m][1] -= ar[m][1]; u[m][2] -= ar[m][2]; }
     if (lsign != 0.f) { ljar = lsign * qacc - laref; lact = ljar < 0.f ? lD : 0.f; }
@@ -377,52 +510,15 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
 #pragma unroll
     for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
     float g = Mx, ga = fabsf(Mx);
-    auto fold = [&](auto Cc) {
+    each_contact([&](auto Cc) {
       constexpr int C = decltype(Cc)::value;
       if (C < ncon) {  // (uniform within the env's row)
-        float cg[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) cg[k] = bcast<(C & 15)>(mycg[C / 16][k]);
-        const int lc = __builtin_amdgcn_update_dpp(0, cl[C / 16], 0x150 + (C & 15), 0xF, 0xF, false);
-        const int col = r < 6 ? r : ((ishinge && leg == lc) ? NHC + d : ((NB == 1 && r >= 14 && r < 16) ? r - 8 : -1));
-        const int cc = col >= 0 ? col : 0;
-        const float* J0 = s.cJ[nB + C][0];
-        const float* J1 = s.cJ[nB + C][1];
-        const float* J2 = s.cJ[nB + C][2];
-        const float j0 = col >= 0 ? J0[cc] : 0.f, j1 = col >= 0 ? J1[cc] : 0.f, j2 = col >= 0 ? J2[cc] : 0.f;
-        const float t = j0 * cg[0] + j1 * cg[1] + j2 * cg[2];
+        float t, t0, t1, t2;
+        fold_t<(C & 15)>(mycg[C / 16], jown[C][0], jown[C][1], jown[C][2], t, t0, t1, t2);
         g += t; ga += fabsf(t);
-        const float t0 = j0 * cg[3] + j1 * cg[4] + j2 * cg[5], t1 = j0 * cg[4] + j1 * cg[6], t2 = j0 * cg[5] + j2 * cg[7];  // (W Jc)[:, col]
-#pragma unroll
-        for (int k = 0; k < 6; k++) Hrow[k] += t0 * J0[k] + t1 * J1[k] + t2 * J2[k];
-        if constexpr (NB == 1) {
-          Hrow[14] += t0 * J0[6] + t1 * J1[6] + t2 * J2[6];
-          Hrow[15] += t0 * J0[7] + t1 * J1[7] + t2 * J2[7];
-        }
-        const float h6 = t0 * J0[NHC] + t1 * J1[NHC] + t2 * J2[NHC];
-        const float h7 = t0 * J0[NHC + 1] + t1 * J1[NHC + 1] + t2 * J2[NHC + 1];
-#pragma unroll
-        for (int l2 = 0; l2 < 4; l2++) { Hrow[6 + 2 * l2] += lc == l2 ? h6 : 0.f; Hrow[7 + 2 * l2] += lc == l2 ? h7 : 0.f; }
+        fold_h(Hrow, jown[C][0], jown[C][1], jown[C][2], t0, t1, t2);
       }
-    };
-    if (cx.any(ncon > 0)) {
-      fold(std::integral_constant<int, 0>{}); fold(std::integral_constant<int, 1>{}); fold(std::integral_constant<int, 2>{}); fold(std::integral_constant<int, 3>{});
-      if (cx.any(ncon > 4)) {
-        fold(std::integral_constant<int, 4>{}); fold(std::integral_constant<int, 5>{}); fold(std::integral_constant<int, 6>{}); fold(std::integral_constant<int, 7>{});
-        if (cx.any(ncon > 8)) {
-          fold(std::integral_constant<int, 8>{}); fold(std::integral_constant<int, 9>{}); fold(std::integral_constant<int, 10>{}); fold(std::integral_constant<int, 11>{});
-          fold(std::integral_constant<int, 12>{}); fold(std::integral_constant<int, 13>{}); fold(std::integral_constant<int, 14>{}); fold(std::integral_constant<int, 15>{});
-          if constexpr (MA > 1) {
-            if (any2) {  // second slot of the contact lanes: a robot lying against block and walls at once
-              fold(std::integral_constant<int, 16>{}); fold(std::integral_constant<int, 17>{}); fold(std::integral_constant<int, 18>{}); fold(std::integral_constant<int, 19>{});
-              fold(std::integral_constant<int, 20>{}); fold(std::integral_constant<int, 21>{}); fold(std::integral_constant<int, 22>{}); fold(std::integral_constant<int, 23>{});
-              fold(std::integral_constant<int, 24>{}); fold(std::integral_constant<int, 25>{}); fold(std::integral_constant<int, 26>{}); fold(std::integral_constant<int, 27>{});
-              fold(std::integral_constant<int, 28>{}); fold(std::integral_constant<int, 29>{}); fold(std::integral_constant<int, 30>{}); fold(std::integral_constant<int, 31>{});
-            }
-          }
-        }
-      }
-    }
+    });
     if constexpr (NB == 1) {
       if (r == 14) { g += bg0; ga += bga0; Hrow[14] += bh00; Hrow[15] += bh01; }
       if (r == 15) { g += bg1; ga += bga1; Hrow[14] += bh01; Hrow[15] += bh11; }
@@ -438,11 +534,9 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     cx.tick(s, 5);
     // ---- Newton direction: H search = -grad
     const float search = solve_rows(r, Hrow, -g);
-    if (isdof) s.search[ri] = search;
-    cx.sync();
     cx.tick(s, 6);
     // ---- J search on the contact lanes, limit rows on their own dofs; vote on the active set
-    jdot3(s.search, v);
+    jdot3(search, v);
     const float ljv = lsign * search;
     bool changed = false;
 #pragma unroll
@@ -466,7 +560,7 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     float alpha = 1.f, Ms = 0.f, sn = 1.f, qn = 0.f;
     const bool exact = !changed;
     if (changed) {  // exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on the piecewise-linear phi'
-      Ms = matvec<NR>(Mrow, search);
+      Ms = matvec(Mrow, search);
       const float p1 = rsum(search * Mx), p2 = rsum(search * Ms);
       sn = rsum(isdof ? search * search : 0.f); qn = rsum(isdof ? qacc * qacc : 0.f);
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
