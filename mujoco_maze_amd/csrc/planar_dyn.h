@@ -35,8 +35,22 @@ struct PlanarDims {
   static constexpr int NOBS = 7 + 3 * NB + 3 * NS;
 };
 
+// Staging of the bare Point's single-pass contact enumeration (planar_forward): geometry of the contacts an enumerator found,
+// 1 entry for a sphere-wall cell enumerator, 8 for an arrow-wall cell one (mjc_BoxBox's maximum).
+struct PlStageEntry { double dist, pos[3], n[3]; };
 template <int NB, int NS>
-struct alignas(16) PlanarScratch {
+struct PlStage {};
+template <>
+struct PlStage<0, 0> {
+  static constexpr int NSTAGE = 9 + 8 * 9;
+  PlStageEntry stage[NSTAGE];
+  int csrc[24];  // contact slot -> staging entry
+  static MZP_HD int base(int e) { return e < 9 ? e : 9 + 8 * (e - 9); }
+  static MZP_HD int cap(int e) { return e < 9 ? 1 : 8; }
+};
+
+template <int NB, int NS>
+struct alignas(16) PlanarScratch : PlStage<NB, NS> {
   using D = PlanarDims<NB, NS>;
   double q[D::NV], v[D::NV];  // state of the current RK4 stage
   double x0[D::NV], v0[D::NV], accv[D::NV], accf[D::NV];
@@ -548,6 +562,53 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
   MZ_FOR(i, NV) s.qacc[i] = s.qas[i];
   bool maybe = NB + NS > 0 || s.robot_near != 0;  // group-uniform
   if (!cx.any(maybe)) { cx.sync(); return; }
+  if constexpr (NB == 0 && NS == 0) {
+    // ---- the bare Point: ONE enumeration.  The narrow phase runs once per evaluation and parks what it finds in the staging
+    // block (the two-pass scheme ran mjc_BoxBox twice and built up to eight constraint rows serially on the enumerator's lane);
+    // one lane turns the counts into slots, then every contact's rows are built on a lane of its own.  Contact order = slot
+    // order = enumerator order, as before.  Items are dealt so that the nine arrow enumerators share the first round of a
+    // 16-lane group and the second round holds two sphere enumerators only (lanes that run different code serialise).
+    static_assert(NE == 18 && NC == 24, "staging layout of the bare Point");
+    MZ_FOR(i, NE) {
+      const int e = i < 9 ? i + 9 : i - 9;
+      int n = 0;
+      if (maybe)
+        planar_contacts<NB, NS>(P, s, e, [&](const PlContact& c) {
+          if (c.dist < P.pair[c.cls].margin) {
+            if (n < PlStage<0, 0>::cap(e)) {
+              PlStageEntry& q = s.stage[PlStage<0, 0>::base(e) + n];
+              q.dist = c.dist;
+              for (int k = 0; k < 3; k++) { q.pos[k] = c.pos[k]; q.n[k] = c.n[k]; }
+            }
+            n++;
+          }
+        });
+      s.cnt[e] = n < PlStage<0, 0>::cap(e) ? n : PlStage<0, 0>::cap(e);
+    }
+    cx.sync();
+    MZ_FOR(one, 1) {
+      int tot = 0;
+      for (int e = 0; e < NE; e++) {
+        s.cbeg[e] = tot;
+        for (int k = 0; k < s.cnt[e]; k++) { if (tot < NC) s.csrc[tot] = PlStage<0, 0>::base(e) + k; tot++; }
+      }
+      if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+      s.ncon = tot;
+    }
+    cx.sync();
+    const int ncon1 = s.ncon;
+    if (!cx.any(ncon1 > 0)) return;
+    MZ_FOR(slot, ncon1) {
+      const int src = s.csrc[slot];
+      const PlStageEntry& q = s.stage[src];
+      PlContact c;
+      c.dist = q.dist;
+      for (int k = 0; k < 3; k++) { c.pos[k] = q.pos[k]; c.n[k] = q.n[k]; }
+      const bool sphere = src < 9;  // sphere (geom1, robot) -> wall | wall (geom1) -> arrow (robot)
+      c.b1 = sphere ? 0 : -1; c.b2 = sphere ? -1 : 0; c.cls = 0;
+      planar_fill_contact<NB, NS>(P, s, slot, c);
+    }
+  } else {
   // ---- collision: count, prefix, fill
   MZ_FOR(e, NE) {
     int n = 0;
@@ -562,8 +623,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     s.ncon = tot;
   }
   cx.sync();
-  const int ncon = s.ncon;
-  if (!cx.any(ncon > 0)) return;
+  if (!cx.any(s.ncon > 0)) return;
   MZ_FOR(e, NE) {
     if (s.cnt[e] > 0) {
       // the slots [cbeg, cbeg + cnt) belong to this enumerator whatever the second enumeration yields (two instantiations of
@@ -579,6 +639,8 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       }
     }
   }
+  }
+  const int ncon = s.ncon;
   if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = s.qas[i] + s.wd[i]; }  // envs without contacts keep qacc = qacc_smooth
   cx.sync();
   if constexpr (NB == 0 && NS == 0) {
