@@ -35,6 +35,14 @@ struct PlanarDims {
   static constexpr int NOBS = 7 + 3 * NB + 3 * NS;
 };
 
+// developer aid (tools/exp_point.sh): -DMZ_EXP_PROF builds an experiment library whose bare-Point kernel times its phases with
+// s_memtime (lane 0 of a group; planar_kernels.hip prints one workgroup's totals) — compiled out otherwise
+#if defined(MZ_EXP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define MZP_TICK(id) do { if constexpr (NB == 0 && NS == 0) { if (cx.lane0() == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); s.prof[id] += now_ - s.prof_t0; s.prof_t0 = now_; } } } while (0)
+#else
+#define MZP_TICK(id) do { } while (0)
+#endif
+
 // Staging of the bare Point's single-pass contact enumeration (planar_forward): geometry of the contacts an enumerator found,
 // 1 entry for a sphere-wall cell enumerator, 8 for an arrow-wall cell one (mjc_BoxBox's maximum).
 struct PlStageEntry { double dist, pos[3], n[3]; };
@@ -45,6 +53,9 @@ struct PlStage<0, 0> {
   static constexpr int NSTAGE = 9 + 8 * 9;
   PlStageEntry stage[NSTAGE];
   int csrc[24];  // contact slot -> staging entry
+#ifdef MZ_EXP_PROF
+  unsigned long long prof[12], prof_t0;
+#endif
   static MZP_HD int base(int e) { return e < 9 ? e : 9 + 8 * (e - 9); }
   static MZP_HD int cap(int e) { return e < 9 ? 1 : 8; }
 };
@@ -90,7 +101,9 @@ MZP_HD bool pl_sphere_box(const double* c, double r, const double* hb, double ma
   for (int k = 0; k < 3; k++) { cl[k] = fmin(fmax(c[k], -hb[k]), hb[k]); if (cl[k] != c[k]) inside = false; }
   if (!inside) {
     double w[3] = {cl[0] - c[0], cl[1] - c[1], cl[2] - c[2]};
-    dd = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double ww = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], rm = r + margin + 1e-9;
+    if (ww > rm * rm) return false;  // clearly apart: no square root (the exact test follows)
+    dd = sqrt(ww);
     if (dd - r > margin) return false;
     for (int k = 0; k < 3; k++) nrm[k] = w[k] / dd;
     dd -= r;
@@ -293,6 +306,90 @@ MZP_HD void pl_box_box(const double* pos1, const double* mat1, const double* siz
   }
 }
 
+// pl_box_box for the pair every Point step meets: an axis-aligned box and a box rotated about z by the heading (co, si) — the
+// arrow against a wall cell (geom1 = the aligned box) or against a movable block (`rot_first`: geom1 = the rotated box).  Same
+// routine, written out for these two rotation matrices: the products with the exact zeros and ones of an identity / z rotation
+// are dropped (they change no value), which leaves a 2-D separating-axis test, the z overlap, and pl_box_box's fast path in
+// scalars — about a quarter of the general routine's instructions.  A vertical least-penetration axis (deep overlap) hands
+// over to the general routine.
+template <class Emit>
+MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const double* pos2, const double* size2, double co, double si, bool rot_first,
+                               double margin, int b1id, int b2id, int cls, Emit&& emit) {
+  const double d0 = pos2[0] - pos1[0], d1 = pos2[1] - pos1[1], d2 = pos2[2] - pos1[2];
+  // rot[i][j] = axis i of box 1 . axis j of box 2 (upper-left 2 x 2; rot[2][2] = 1, the rest 0)
+  const double r00 = co, r11 = co, r01 = rot_first ? si : -si, r10 = rot_first ? -si : si;
+  const double e0 = co * d0 + si * d1, e1 = -si * d0 + co * d1;  // d in the rotated box's frame
+  const double p21x = rot_first ? e0 : d0, p21y = rot_first ? e1 : d1, p12x = rot_first ? -d0 : -e0, p12y = rot_first ? -d1 : -e1;
+  double penetration = margin + 3.0 * (size1[0] + size1[1] + size1[2] + size2[0] + size2[1] + size2[2]);
+  int code = -1;
+  {
+    const double plen2 = fabs(r00) * size2[0] + fabs(r01) * size2[1], plen1 = fabs(r00) * size1[0] + fabs(r10) * size1[1];
+    const double c1 = -fabs(p21x) + size1[0] + plen2, c2 = -fabs(p12x) + size2[0] + plen1;
+    if (c1 < -margin || c2 < -margin) return;
+    if (c1 < penetration) { penetration = c1; code = 0; }
+    if (c2 < penetration) { penetration = c2; code = 3; }
+  }
+  {
+    const double plen2 = fabs(r10) * size2[0] + fabs(r11) * size2[1], plen1 = fabs(r01) * size1[0] + fabs(r11) * size1[1];
+    const double c1 = -fabs(p21y) + size1[1] + plen2, c2 = -fabs(p12y) + size2[1] + plen1;
+    if (c1 < -margin || c2 < -margin) return;
+    if (c1 < penetration) { penetration = c1; code = 1; }
+    if (c2 < penetration) { penetration = c2; code = 4; }
+  }
+  {
+    const double c1 = -fabs(d2) + size1[2] + size2[2], c2 = -fabs(d2) + size2[2] + size1[2];
+    if (c1 < -margin || c2 < -margin) return;
+    if (c1 < penetration || c2 < penetration) {  // vertical reference normal: the general routine (rare: a deep overlap)
+      const double m1[9] = {rot_first ? co : 1.0, rot_first ? -si : 0.0, 0.0, rot_first ? si : 0.0, rot_first ? co : 1.0, 0.0, 0.0, 0.0, 1.0};
+      const double m2[9] = {rot_first ? 1.0 : co, rot_first ? 0.0 : -si, 0.0, rot_first ? 0.0 : si, rot_first ? 1.0 : co, 0.0, 0.0, 0.0, 1.0};
+      pl_box_box(pos1, m1, size1, pos2, m2, size2, margin, b1id, b2id, cls, emit);
+      return;
+    }
+  }
+  if (code < 0) return;
+  const bool fromB = code >= 3;
+  const int a = fromB ? code - 3 : code;  // 0 or 1
+  // the reference box A's frame: R[k][j] = axis k of A . axis j of B
+  const double R00 = r00, R01 = fromB ? r10 : r01, R10 = fromB ? r01 : r10, R11 = r11;
+  const double pB0 = fromB ? p12x : p21x, pB1 = fromB ? p12y : p21y, pB2 = fromB ? -d2 : d2;
+  const double sA0 = fromB ? size2[0] : size1[0], sA1 = fromB ? size2[1] : size1[1], sA2 = fromB ? size2[2] : size1[2];
+  const double sB0 = fromB ? size1[0] : size2[0], sB1 = fromB ? size1[1] : size2[1], sB2 = fromB ? size1[2] : size2[2];
+  const double sg = (a == 0 ? pB0 : pB1) < 0.0 ? -1.0 : 1.0;
+  const double* posA = fromB ? pos2 : pos1;
+  const bool rotA = fromB != rot_first;  // A is the rotated box
+  const int ah = 1 - a;
+  const double Ra0 = a == 0 ? R00 : R10, Ra1 = a == 0 ? R01 : R11;  // row a of R
+  const int b = fabs(Ra1) > fabs(Ra0) ? 1 : 0, bh = 1 - b;
+  const double sb = (b == 0 ? Ra0 : Ra1) * sg > 0.0 ? -1.0 : 1.0;
+  const double sBb = b == 0 ? sB0 : sB1, sBh = b == 0 ? sB1 : sB0;
+  const double Rhb = ah == 0 ? (b == 0 ? R00 : R01) : (b == 0 ? R10 : R11), Rab = b == 0 ? Ra0 : Ra1;
+  const double Rhh = ah == 0 ? (bh == 0 ? R00 : R01) : (bh == 0 ? R10 : R11), Rah = bh == 0 ? Ra0 : Ra1;
+  const double Ph = (ah == 0 ? pB0 : pB1) + sb * sBb * Rhb, P3 = (a == 0 ? pB0 : pB1) + sb * sBb * Rab, Pz = pB2;
+  const double Uh = sBh * Rhh, U3 = sBh * Rah;
+  const double Sh = ah == 0 ? sA0 : sA1, S3 = a == 0 ? sA0 : sA1, Sz = sA2;
+  const double dtol = 1e-9 * (1.0 + Sh + Sz);
+  const double hlo = fmax(-Sh, Ph - fabs(Uh)), hhi = fmin(Sh, Ph + fabs(Uh)), zlo = fmax(-Sz, Pz - sB2), zhi = fmin(Sz, Pz + sB2);
+  if (hhi - hlo <= MZ_BOX_MINOVERLAP || zhi - zlo <= MZ_BOX_MINOVERLAP) return;  // positive overlap area [ASSUME-12]
+  const int nh = hhi - hlo > dtol ? 2 : 1, nz = zhi - zlo > dtol ? 2 : 1;
+  const double nsg = fromB ? -sg : sg, nl0 = a == 0 ? nsg : 0.0, nl1 = a == 0 ? 0.0 : nsg;
+  const double nx = rotA ? co * nl0 - si * nl1 : nl0, ny = rotA ? si * nl0 + co * nl1 : nl1;
+  for (int ih = 0; ih < nh; ih++) {
+    const double hh = ih ? hhi : hlo, x3 = P3 + (hh - Ph) / Uh * U3, dist = sg * x3 - S3;
+    if (dist > margin) continue;
+    const double x3m = x3 - sg * 0.5 * dist;
+    const double pl0 = a == 0 ? x3m : hh, pl1 = a == 0 ? hh : x3m;
+    const double wx = rotA ? co * pl0 - si * pl1 : pl0, wy = rotA ? si * pl0 + co * pl1 : pl1;
+    for (int iz = 0; iz < nz; iz++) {
+      PlContact c;
+      c.dist = dist;
+      c.pos[0] = wx + posA[0]; c.pos[1] = wy + posA[1]; c.pos[2] = (iz ? zhi : zlo) + posA[2];
+      c.n[0] = nx; c.n[1] = ny; c.n[2] = 0.0;
+      c.b1 = b1id; c.b2 = b2id; c.cls = cls;
+      emit(c);
+    }
+  }
+}
+
 // axis-aligned box (geom1: centre c1, half h1) vs axis-aligned box (geom2: centre c2, half h2): aligned_box_box (ant_dyn.h)
 template <class Emit>
 MZP_HD void pl_box_box_aligned(const double* c1, const double* h1, const double* c2, const double* h2, double margin, int b1, int b2, int cls,
@@ -354,12 +451,14 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, i
       ct.b1 = 0; ct.b2 = -1; ct.cls = 0;
       emit(ct);
     } else {      // wall (geom1) vs arrow (geom2)
+#ifdef MZ_EXP_NOARROW
+      return;
+#endif
       // the arrow lies within its circumscribed circle: a cell farther than that from its centre cannot touch it
       const double ex = fmax(fabs(arrow[0] - wc[0]) - wh[0], 0.0), ey = fmax(fabs(arrow[1] - wc[1]) - wh[1], 0.0), rr = P.arr_rxy + pr.margin;
       if (ex * ex + ey * ey > rr * rr) return;
-      const double am[9] = {s.co, -s.si, 0.0, s.si, s.co, 0.0, 0.0, 0.0, 1.0}, ac[3] = {arrow[0], arrow[1], P.arr_z}, ah[3] = {P.arr_hx, P.arr_hy, P.arr_hz};
-      const double id[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
-      pl_box_box(wc, id, wh, ac, am, ah, pr.margin, -1, 0, 0, emit);
+      const double ac[3] = {arrow[0], arrow[1], P.arr_z}, ah[3] = {P.arr_hx, P.arr_hy, P.arr_hz};
+      pl_box_box_upright(wc, wh, ac, ah, s.co, s.si, false, pr.margin, -1, 0, 0, emit);
     }
     return;
   }
@@ -418,9 +517,8 @@ MZP_HD void planar_contacts(const PointDev& P, const PlanarScratch<NB, NS>& s, i
         ct.b1 = 0; ct.b2 = 1 + b; ct.cls = 1;
         emit(ct);
       } else if (k == 1) {  // arrow (geom1) vs block (geom2)
-        const double am[9] = {s.co, -s.si, 0.0, s.si, s.co, 0.0, 0.0, 0.0, 1.0}, ac[3] = {arrow[0], arrow[1], P.arr_z}, ah[3] = {P.arr_hx, P.arr_hy, P.arr_hz};
-        const double id[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
-        pl_box_box(ac, am, ah, bc, id, P.block_half, P.pair[1].margin, 0, 1 + b, 1, emit);
+        const double ac[3] = {arrow[0], arrow[1], P.arr_z}, ah[3] = {P.arr_hx, P.arr_hy, P.arr_hz};
+        pl_box_box_upright(ac, ah, bc, P.block_half, s.co, s.si, true, P.pair[1].margin, 0, 1 + b, 1, emit);
       } else if (k < 11) {  // wall (geom1) vs block (geom2)
         double wc[3];
         if (!pl_wall_cell(z, bc[0], bc[1], k - 2, wc)) return;
@@ -548,7 +646,9 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
   MZ_FOR(i, NV) s.wd[i] = warm ? s.qacc[i] - s.qas[i] : 0.0;
   cx.sync();
   MZ_FOR(one, 1) {
-    double co = cos(s.q[2]), si = sin(s.q[2]), w2 = s.v[2] * s.v[2], mc = P.mass * P.com_x;
+    double co, si;
+    sincos(s.q[2], &si, &co);  // one argument reduction for both
+    const double w2 = s.v[2] * s.v[2], mc = P.mass * P.com_x;
     s.co = co; s.si = si;
     s.qas[0] = P.com_x * w2 * co; s.qas[1] = P.com_x * w2 * si; s.qas[2] = 0.0;
     for (int i = 3; i < NV; i++) s.qas[i] = 0.0;
@@ -560,7 +660,11 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
   }
   cx.sync();
   MZ_FOR(i, NV) s.qacc[i] = s.qas[i];
+  MZP_TICK(0);
   bool maybe = NB + NS > 0 || s.robot_near != 0;  // group-uniform
+#ifdef MZ_EXP_NOCOLLISION
+  maybe = false;
+#endif
   if (!cx.any(maybe)) { cx.sync(); return; }
   if constexpr (NB == 0 && NS == 0) {
     // ---- the bare Point: ONE enumeration.  The narrow phase runs once per evaluation and parks what it finds in the staging
@@ -586,16 +690,21 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       s.cnt[e] = n < PlStage<0, 0>::cap(e) ? n : PlStage<0, 0>::cap(e);
     }
     cx.sync();
-    MZ_FOR(one, 1) {
-      int tot = 0;
-      for (int e = 0; e < NE; e++) {
-        s.cbeg[e] = tot;
-        for (int k = 0; k < s.cnt[e]; k++) { if (tot < NC) s.csrc[tot] = PlStage<0, 0>::base(e) + k; tot++; }
+    MZP_TICK(1);
+    MZ_FOR(e, NE) {  // every enumerator finds its own first slot (18 independent loads, no serial walk) and maps its contacts
+      int off = 0;
+      for (int g = 0; g < NE; g++) off += g < e ? s.cnt[g] : 0;
+      s.cbeg[e] = off;
+      const int n = s.cnt[e];
+      for (int k = 0; k < n; k++) if (off + k < NC) s.csrc[off + k] = PlStage<0, 0>::base(e) + k;
+      if (e == NE - 1) {
+        int tot = off + n;
+        if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+        s.ncon = tot;
       }
-      if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
-      s.ncon = tot;
     }
     cx.sync();
+    MZP_TICK(2);
     const int ncon1 = s.ncon;
     if (!cx.any(ncon1 > 0)) return;
     MZ_FOR(slot, ncon1) {
@@ -608,6 +717,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       c.b1 = sphere ? 0 : -1; c.b2 = sphere ? -1 : 0; c.cls = 0;
       planar_fill_contact<NB, NS>(P, s, slot, c);
     }
+    MZP_TICK(3);
   } else {
   // ---- collision: count, prefix, fill
   MZ_FOR(e, NE) {
@@ -653,6 +763,9 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     double M[3][3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = s.M3[i][j];
     bool done = ncon == 0;
+#ifdef MZ_EXP_NONEWTON
+    done = true;
+#endif
     int it = 0;
     while (cx.any(!done) && it < 50) {
       double Mx[3], pg[3] = {0.0, 0.0, 0.0}, pH[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // H entries 00 01 02 11 12 22
@@ -743,6 +856,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     cx.sync();
     if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
     cx.sync();
+    MZP_TICK(4);
     return;
   }
   // ---- Newton on the primal problem (dense), exact line search
@@ -862,6 +976,59 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
   cx.sync();
 }
 
+// CollisionDetector.detect on a lane group: lane l examines the segments l, l + G, ... (point_detect_range), parks its nearest
+// collision in LDS (the contact arrays are free between steps), and every lane then picks the group's nearest — the first
+// segment among equal distances, as the reference's loop does.  All lanes return the same answer.
+template <int NB, int NS, class C>
+MZP_HD int point_detect_group(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, const double* o, const double* n, double* pt, double* rf) {
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
+  // hand-off buffer: the contact arrays cJ ... cjv (one declaration, contiguous), free between the RK4 step and the next env.step
+  static_assert(sizeof(s.cJ) + sizeof(s.caref) + sizeof(s.cD) + sizeof(s.cu) + sizeof(s.cg) + sizeof(s.cW) + sizeof(s.cjv) >= sizeof(double) * 8 * C::nlanes,
+                "the detector's hand-off buffer lives in the contact arrays");
+  const double mvx = n[0] - o[0], mvy = n[1] - o[1];
+  if (mz_hypot(mvx, mvy) <= 1e-8) return 0;
+  PtCand c;
+  c.found = 0; c.degenerate = 0; c.k = 0; c.dist = 0.0; c.pt[0] = c.pt[1] = c.rf[0] = c.rf[1] = 0.0;
+  point_detect_range(P, o, n, mvx, mvy, cx.lane0(), C::nlanes, c);
+  double* buf = &s.cJ[0][0][0];
+  {
+    double* q = buf + 8 * cx.lane0();
+    q[0] = (double)(c.found + 2 * c.degenerate); q[1] = c.dist; q[2] = (double)c.k; q[3] = c.pt[0]; q[4] = c.pt[1]; q[5] = c.rf[0]; q[6] = c.rf[1];
+  }
+  cx.sync();
+  int found = 0, degenerate = 0, bestk = 0;
+  double best = 0.0;
+  for (int j = 0; j < C::nlanes; j++) {
+    const double* q = buf + 8 * j;
+    const int fl = (int)q[0], k = (int)q[2];
+    if (fl & 2) degenerate = 1;
+    if ((fl & 1) && (!found || q[1] < best || (q[1] == best && k < bestk))) {
+      found = 1; best = q[1]; bestk = k;
+      pt[0] = q[3]; pt[1] = q[4]; rf[0] = q[5]; rf[1] = q[6];
+    }
+  }
+  cx.sync();  // the buffer is reused by the second detection of a bounce
+  if (degenerate && !found) return -1;
+  return found;
+}
+
+// point_bounce (point_dyn.h) on a lane group
+template <int NB, int NS, class C>
+MZP_HD int point_bounce_group(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, const double* old_xy, const double* new_xy, double* fin) {
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
+  double pt[2] = {0.0, 0.0}, rf[2] = {0.0, 0.0};
+  fin[0] = new_xy[0]; fin[1] = new_xy[1];
+  const int hit = point_detect_group<NB, NS>(cx, P, s, old_xy, new_xy, pt, rf);
+  if (hit <= 0) return hit;
+  const double pos[2] = {pt[0] + P.restitution * (rf[0] - pt[0]), pt[1] + P.restitution * (rf[1] - pt[1])};
+  double p2[2], r2[2];
+  const int again = point_detect_group<NB, NS>(cx, P, s, old_xy, pos, p2, r2);
+  if (again < 0) return -1;
+  if (again > 0) { fin[0] = old_xy[0]; fin[1] = old_xy[1]; return 2; }
+  fin[0] = pos[0]; fin[1] = pos[1];
+  return 1;
+}
+
 // ------------------------------------------------------------------ One MazeEnv.step.  s.q / s.v hold the state in and out.
 template <int NB, int NS, class C>
 MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, const double* action) {
@@ -880,12 +1047,14 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
   }
   MZ_FOR(i, NV) s.v[i] = fmin(fmax(s.v[i], -P.vel_limit), P.vel_limit);  // the clip covers the whole qvel (point.py:54-55)
   cx.sync();
+  MZP_TICK(5);
   for (int f = 0; f < P.frame_skip; f++) {  // mj_step, RK4 (point.xml:3)
     const double h = P.h;
     MZ_FOR(i, NV) { s.x0[i] = s.q[i]; s.v0[i] = s.v[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; }
     cx.sync();
     for (int st = 0; st < 4; st++) {
       planar_forward<NB, NS>(cx, P, s, st > 0);
+      MZP_TICK(8);
       double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
       MZ_FOR(i, NV) {
         s.accv[i] += bw * s.v[i]; s.accf[i] += bw * s.qacc[i];
@@ -896,17 +1065,23 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
     }
     MZ_FOR(i, NV) { s.q[i] = s.x0[i] + h * s.accv[i]; s.v[i] = s.v0[i] + h * s.accf[i]; }
     cx.sync();
+    MZP_TICK(6);
   }
   // maze_env.py:454-464: manual wall bounce on the robot's xy
+#ifndef MZ_EXP_NODETECT
   if (P.nseg > 0) {
+    const double old_xy[2] = {old_x, old_y}, new_xy[2] = {s.q[0], s.q[1]};
+    double fin[2];
+    cx.sync();  // every lane has read the new position before the hand-off buffer (and later s.q) is written
+    const int r = point_bounce_group<NB, NS>(cx, P, s, old_xy, new_xy, fin);
     MZ_FOR(one, 1) {
-      double old_xy[2] = {old_x, old_y}, new_xy[2] = {s.q[0], s.q[1]}, fin[2];
-      int r = point_bounce(P, old_xy, new_xy, fin, nullptr);
       if (r < 0) s.status |= MZ_STATUS_COLLINEAR;
       s.q[0] = fin[0]; s.q[1] = fin[1];
     }
     cx.sync();
+    MZP_TICK(7);
   }
+#endif
 }
 
 // coordinate c of movable block b's body origin (get_body_com, maze_env.py:364-368): spawn position + its two slides

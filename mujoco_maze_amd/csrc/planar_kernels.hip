@@ -52,7 +52,17 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restr
   double a[2] = {(double)actions[(size_t)env * 2], (double)actions[(size_t)env * 2 + 1]};
   const int t_new = S.t[env] + 1;
   cx.sync();
+#ifdef MZ_EXP_PROF
+  if constexpr (NB == 0 && NS == 0) { if (cx.l == 0) { for (int k = 0; k < 12; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
+#endif
   planar_env_step<NB, NS>(cx, P, s, a);
+#ifdef MZ_EXP_PROF
+  if constexpr (NB == 0 && NS == 0) {
+    if (blockIdx.x % 97 == 5 && threadIdx.x == 0)
+      printf("PROF %d setup %llu enum %llu prefix %llu fill %llu newton %llu pre %llu rk4 %llu detect %llu fwdtail %llu\n", (int)blockIdx.x, s.prof[0], s.prof[1], s.prof[2],
+             s.prof[3], s.prof[4], s.prof[5], s.prof[6], s.prof[7], s.prof[8]);
+  }
+#endif
   float* o = obuf[grp];
   for (int i = cx.l; i < NOBS; i += G) o[i] = planar_obs_elem<NB, NS>(P, s, i, t_new);
   cx.sync();

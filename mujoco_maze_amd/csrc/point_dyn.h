@@ -210,14 +210,15 @@ MZP_HD double cross2d(double ax, double ay, double bx, double by) {
   return ax * by + (-ay) * bx;
 }
 
-// CollisionDetector.detect (maze_env_utils.py:186-206): 1 hit, 0 none, -1 collinear (the reference raises ZeroDivisionError)
-MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, double* pt, double* rf) {
+// CollisionDetector.detect (maze_env_utils.py:186-206).  The loop over the wall segments keeps the nearest collision, the first
+// one among equals (`dist < best`, strict).  point_detect_range is that loop body over the segments k0, k0 + kstep, ...: the whole
+// table for the serial form (point_detect: the golden-vector kernel mz_debug_detect, the host emulation), one residue class per
+// lane for the step kernel's lane groups (planar_dyn.h point_detect_group, which then takes the minimum by (dist, k) — the same
+// winner).  The arithmetic of a segment is the same function either way.
+struct PtCand { int found, degenerate, k; double dist, pt[2], rf[2]; };
+MZP_HD void point_detect_range(const PointDev& P, const double* o, const double* n, double mvx, double mvy, int k0, int kstep, PtCand& c) {
 #pragma clang fp contract(off) reciprocal(off) reassociate(off)
-  double mvx = n[0] - o[0], mvy = n[1] - o[1];
-  if (mz_hypot(mvx, mvy) <= 1e-8) return 0;
-  int found = 0, degenerate = 0;
-  double best = 0.0;
-  for (int k = 0; k < P.nseg; k++) {
+  for (int k = k0; k < P.nseg; k += kstep) {
     const double* s = P.seg[k];
     double wx = s[2] - s[0], wy = s[3] - s[1];
     double c1 = cross2d(wx, wy, o[0] - s[0], o[1] - s[1]), c2 = cross2d(wx, wy, n[0] - s[0], n[1] - s[1]);
@@ -225,23 +226,34 @@ MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, dou
     double c3 = cross2d(mvx, mvy, s[0] - o[0], s[1] - o[1]), c4 = cross2d(mvx, mvy, s[2] - o[0], s[3] - o[1]);
     if (!(c3 * c4 <= 0.0)) continue;
     double a = cross2d(wx, wy, mvx, mvy), b = cross2d(wx, wy, s[2] - o[0], s[3] - o[1]);
-    if (a == 0.0) { degenerate = 1; continue; }
+    if (a == 0.0) { c.degenerate = 1; continue; }
     double r = b / a, px = o[0] + r * mvx, py = o[1] + r * mvy;
     double dist = mz_hypot(px - o[0], py - o[1]);
-    if (!found || dist < best) {
-      found = 1; best = dist;
-      pt[0] = px; pt[1] = py;
+    if (!c.found || dist < c.dist) {
+      c.found = 1; c.dist = dist; c.k = k;
+      c.pt[0] = px; c.pt[1] = py;
       double bx = -wx, by = -wy, n2 = mz_hypot(bx, by);
       n2 = n2 * n2;
       double dx = n[0] - s[0], dy = n[1] - s[1];
       double sc = (dx * bx - (-dy) * by) / n2;
       double qx = s[0] + bx * sc, qy = s[1] + by * sc;
-      rf[0] = n[0] + 2.0 * (qx - n[0]);
-      rf[1] = n[1] + 2.0 * (qy - n[1]);
+      c.rf[0] = n[0] + 2.0 * (qx - n[0]);
+      c.rf[1] = n[1] + 2.0 * (qy - n[1]);
     }
   }
-  if (degenerate && !found) return -1;
-  return found;
+}
+
+// 1 hit, 0 none, -1 collinear (the reference raises ZeroDivisionError)
+MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, double* pt, double* rf) {
+#pragma clang fp contract(off) reciprocal(off) reassociate(off)
+  double mvx = n[0] - o[0], mvy = n[1] - o[1];
+  if (mz_hypot(mvx, mvy) <= 1e-8) return 0;
+  PtCand c;
+  c.found = 0; c.degenerate = 0; c.k = 0; c.dist = 0.0; c.pt[0] = c.pt[1] = c.rf[0] = c.rf[1] = 0.0;
+  point_detect_range(P, o, n, mvx, mvy, 0, 1, c);
+  if (c.found) { pt[0] = c.pt[0]; pt[1] = c.pt[1]; rf[0] = c.rf[0]; rf[1] = c.rf[1]; }
+  if (c.degenerate && !c.found) return -1;
+  return c.found;
 }
 
 // Wall bounce of MazeEnv.step (maze_env.py:457-464): 0 no hit, 1 bounced to `fin`, 2 gave up (fin = old position),
@@ -295,6 +307,7 @@ MZP_HD double pt_impedance(const double* si, double x) {
   if (xn <= 0.0) return d0;
   double y;
   if (power <= 1.0 + 1e-12) y = xn;
+  else if (power == 2.0) y = xn <= mid ? xn * xn / mid : 1.0 - (1.0 - xn) * (1.0 - xn) / (1.0 - mid);  // MuJoCo's default power: no pow()
   else if (xn <= mid) y = pow(xn, power) / pow(mid, power - 1.0);
   else y = 1.0 - pow(1.0 - xn, power) / pow(1.0 - mid, power - 1.0);
   return d0 + y * (dmax - d0);
