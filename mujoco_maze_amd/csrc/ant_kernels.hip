@@ -315,7 +315,6 @@ static hipError_t dispatch_ant_step(mz_handle* h, hipStream_t st, const float* a
   if constexpr (NB == 0) {
     if (h->lanes_set && h->lanes == 8) return launch_ant_step<NB, 8>(h, st, a, o, r, d, gi, inf);
   }
-  // (batches beyond 4096 envs put two 16-lane waves on a SIMD; there the 32-lane grouping measured slightly faster again)
   const int lanes = ant_lanes<NB>(h);
   if (lanes == 64) return launch_ant_step<NB, 64>(h, st, a, o, r, d, gi, inf);
   if (lanes == 16) return launch_ant_step<NB, 16>(h, st, a, o, r, d, gi, inf);
@@ -327,7 +326,9 @@ template <int NB>
 static int ant_lanes(const mz_handle* h) {
   // one movable block: the row solver (16 dofs in one DPP row, the block's own contacts spread over the group) at 32 lanes per env
   // — 2048 envs then put exactly one wave on every SIMD; more blocks / the ball: the lane-group solver at 64
-  return h->lanes_set ? h->lanes : (NB == 1 ? 32 : (NB ? 64 : (h->n <= 4096 ? 16 : 32)));
+  // (the plain ant: 16 at every batch size since the solver's DPP operands were fused, round 3 — 8192 / 16384 / 32768 envs run
+  // 12.8 / 13.4 / 13.8 M env-steps/s at 16 lanes against 11.6 / 12.4 / 13.1 M at 32)
+  return h->lanes_set ? h->lanes : (NB == 1 ? 32 : (NB ? 64 : 16));
 }
 template <int NB>
 static hipError_t dispatch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {

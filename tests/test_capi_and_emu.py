@@ -32,6 +32,22 @@ def test_capi_exports_every_declared_symbol():
     assert lib.mz_model_sizeof() == model.C.sizeof(model.MzModel)
 
 
+def test_dpp_hazards_of_the_built_library():
+    """The row solver's hand-written `asm` blocks (csrc/ant_newton_rows.h: v_fmac_f32_dpp / v_mul_f32_dpp row_newbcast) are
+    outside the compiler's hazard recogniser.  tools/check_dpp_hazards.py disassembles the built library and checks, on every
+    path into every DPP instruction of every kernel, that no operand was written in the two preceding issue slots."""
+    import subprocess
+    import sys
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump of the ROCm toolchain not present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), "--so", _capi.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"(\d+) DPP instructions checked, 0 hazard", out.stdout)
+    assert m and int(m.group(1)) > 10000, out.stdout[-500:]  # the fused row solver alone holds ~1000 per instantiation
+
+
 def test_no_cpu_fallback():
     import torch
 
