@@ -31,7 +31,15 @@ template <int P>
 __device__ __forceinline__ float bcast(float x) {  // value of lane P of this 16-lane row, on every lane of the row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + P, 0xF, 0xF, false));
 }
+// Every lane must end up with the SAME BITS: alpha, the convergence tests and the active-set votes are computed redundantly by the
+// lanes of a row from these sums, and a row whose lanes disagree in the last bit can part ways at a branch (round 3 soak: one env
+// in 2.5e8 env-steps — a line search whose Newton step landed exactly on its bracket on one lane and one ulp inside it on the
+// others; that lane bisected, took alpha = 3e-7, declared itself done, and the row iterated to the cap on an inconsistent
+// qacc).  The butterfly is symmetric — partners add the same two partial sums, and a + b == b + a — but only if the additions
+// stay additions: with contraction on, `rsum(p * q)` became fma(p, q, partner's ROUNDED product) on each lane, which is not
+// symmetric.  Hence contract(off) here and in DevCtx's group sums (mz_device.h).
 __device__ __forceinline__ float rsum(float x) {  // all-reduce over the 16 lanes of the row
+#pragma clang fp contract(off)
   x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
   x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
   x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true));  // row_half_mirror
@@ -621,6 +629,9 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
         }
       }
     }
+#ifdef MZ_EXP_TRACE  // developer aid (tools/replay_trace.py): one line per Newton iteration of the first env of a wave
+    if (cx.l == 0) printf("TRACE it %d ncon %d gnorm %g anorm %g changed %d alpha %g sn %g qn %g exact %d done %d u %g %g %g v %g %g %g D %g\n", it, ncon, gnorm, anorm, (int)changed, alpha, sn, qn, (int)exact, (int)done, u[0][0], u[0][1], u[0][2], v[0][0], v[0][1], v[0][2], cD[0]);
+#endif
     if (exact && K.trust_exact) done = true;
     if (changed && alpha * alpha * sn <= MZ_NEWTON_STALL * MZ_NEWTON_STALL * qn) done = true;  // stationary at fp32 resolution (ant_dyn.h ant_solve)
     cx.tick(s, 7);

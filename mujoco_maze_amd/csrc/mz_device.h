@@ -38,7 +38,11 @@ struct DevCtx {
   }
   // All-reduce (sum) inside the lane group.  Rows of 16 lanes reduce with four DPP moves (quad_perm xor 1,
   // xor 2, row_half_mirror, row_mirror: VALU-rate, no LDS crossbar).
+  // (contract(off): partners of a butterfly step must add the same two numbers — x + y, never fma(p, q, y) with x = p * q still
+  // open — or the lanes of a group end up with sums that differ in the last bit and part ways at the next branch:
+  // ant_newton_rows.h rsum)
   static __device__ __forceinline__ float dpp_add(float x, const int ctrl_sel) {
+#pragma clang fp contract(off)
     int xi = __float_as_int(x), yi;
     switch (ctrl_sel) {
       case 0: yi = __builtin_amdgcn_mov_dpp(xi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
@@ -53,6 +57,7 @@ struct DevCtx {
   // row_bcast:31 adds lane 31 into rows 2 and 3; the group total then sits in the group's last row and is handed back to
   // all lanes with one v_readlane per group (scalar registers) and a select.
   __device__ __forceinline__ float gsum(float x) const {
+#pragma clang fp contract(off)
     if constexpr (G >= 2) x = dpp_add(x, 0);
     if constexpr (G >= 4) x = dpp_add(x, 1);
     if constexpr (G >= 8) x = dpp_add(x, 2);
@@ -86,6 +91,7 @@ struct DevCtx {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
   }
   __device__ __forceinline__ double gsum(double x) const {
+#pragma clang fp contract(off)
     if constexpr (G >= 2) x += dpp_movd<0xB1, 0xF, true>(x);
     if constexpr (G >= 4) x += dpp_movd<0x4E, 0xF, true>(x);
     if constexpr (G >= 8) x += dpp_movd<0x141, 0xF, true>(x);

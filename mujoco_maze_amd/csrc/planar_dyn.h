@@ -740,13 +740,34 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       // planar_contacts need not round alike): a contact beyond the count is dropped, a missing one becomes an empty row
       int slot = s.cbeg[e];
       const int end = slot + s.cnt[e];
+      // the second enumeration only PARKS a contact's geometry in its slot (dist | pos | n in cD / cu / cg, bodies and class in
+      // cjv — all rewritten later); the constraint rows are then built one contact per lane (below) instead of up to eight in a
+      // row on the enumerator's lane
       planar_contacts<NB, NS>(P, s, e, [&](const PlContact& c) {
-        if (c.dist < P.pair[c.cls].margin) { if (slot < NC && slot < end) planar_fill_contact<NB, NS>(P, s, slot, c); slot++; }
+        if (c.dist < P.pair[c.cls].margin) {
+          if (slot < NC && slot < end) {
+            s.cD[slot] = c.dist;
+            for (int k = 0; k < 3; k++) { s.cu[slot][k] = c.pos[k]; s.cg[slot][k] = c.n[k]; }
+            s.cjv[slot][0] = (double)c.b1; s.cjv[slot][1] = (double)c.b2; s.cjv[slot][2] = (double)c.cls;
+          }
+          slot++;
+        }
       });
-      for (; slot < end && slot < NC; slot++) {
-        s.cD[slot] = 0.0;
-        for (int a = 0; a < 3; a++) { s.caref[slot][a] = 0.0; for (int i = 0; i < PlanarDims<NB, NS>::NV; i++) s.cJ[slot][a][i] = 0.0; }
-      }
+      for (; slot < end && slot < NC; slot++) s.cjv[slot][2] = -1.0;  // counted, not found again: an empty row
+    }
+  }
+  cx.sync();
+  MZ_FOR(slot, s.ncon) {
+    const int cls = (int)s.cjv[slot][2];
+    if (cls < 0) {
+      s.cD[slot] = 0.0;
+      for (int a = 0; a < 3; a++) { s.caref[slot][a] = 0.0; for (int i = 0; i < PlanarDims<NB, NS>::NV; i++) s.cJ[slot][a][i] = 0.0; }
+    } else {
+      PlContact c;
+      c.dist = s.cD[slot];
+      for (int k = 0; k < 3; k++) { c.pos[k] = s.cu[slot][k]; c.n[k] = s.cg[slot][k]; }
+      c.b1 = (int)s.cjv[slot][0]; c.b2 = (int)s.cjv[slot][1]; c.cls = cls;
+      planar_fill_contact<NB, NS>(P, s, slot, c);
     }
   }
   }

@@ -949,6 +949,27 @@ def test_captured_state_where_the_two_enumeration_passes_diverged(torch, oracle)
     env.close()
 
 
+def test_captured_state_where_the_lanes_of_a_row_parted_ways(torch, oracle):
+    """Regression fixture of round 3's 60 000-step soak (tests/golden/antumaze_lane_divergence_case.npz, captured on the device
+    by tools/catch_soak.py; one env in 2.5e8 env-steps): an AntUMaze state whose Newton line search starts with phi'(1) = +1e-5.
+    The lanes of a 16-lane row compute alpha redundantly from group sums; with FMA contraction reaching into the butterfly
+    (`rsum(p * q)` -> fma(p, q, partner's rounded product)) the sums differed in the last bit between lanes, one lane's Newton
+    step on phi' rounded onto its bracket, that lane bisected to alpha = 3e-7 and declared itself done, and the row iterated
+    to the cap on an inconsistent qacc: MAXITER, 2e-3 off the oracle.  The group sums are now bitwise identical on every lane
+    (contract(off) in rsum / DevCtx::dpp_add / gsum); the step must converge and agree with the oracle."""
+    c = np.load(os.path.join(os.path.dirname(__file__), "golden", "antumaze_lane_divergence_case.npz"))
+    env = mm.make("AntUMaze-v0", num_envs=1, force_vec=True)
+    st = dict(qpos=c["qpos"][None].astype(np.float64), qvel=c["qvel"][None].astype(np.float64), warm=c["warm"][None].astype(np.float64),
+              t=np.array([int(c["t"])], np.int32))
+    env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+    env.step(torch.as_tensor(c["act"][None], device=env.device))
+    qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+    assert int(env.status().cpu().numpy()[0]) == 0
+    oracle.step(env.model, st, c["act"][None].astype(np.float64))
+    assert np.abs(qpos - st["qpos"]).max() < 1e-5 and np.abs(qvel - st["qvel"]).max() < 1e-4, (np.abs(qpos - st["qpos"]).max(), np.abs(qvel - st["qvel"]).max())
+    env.close()
+
+
 @pytest.mark.parametrize("which", ["biped_ant", "y_swimmer"])
 def test_user_robot_of_another_topology_on_the_device(torch, oracle, which):
     """SURVEY 8f rank 4 / VERDICT r02 #8: a user's AgentModel whose MJCF is NOT one of the built-in shapes — a two-legged ant with a
