@@ -12,8 +12,9 @@ for env_id, n in (("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 
     if ONLY and env_id not in ONLY: continue
     env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
     if os.environ.get("MZ_SOAK_RTOL") and env_id.startswith("Ant"): env.set_option("solver_rtol", float(os.environ["MZ_SOAK_RTOL"]))
-    env.reset(seed=3)
-    g = torch.Generator(device=env.device).manual_seed(0)
+    seed = int(os.environ.get("MZ_SOAK_SEED", "3"))  # reset seed; the action stream is seeded with seed - 3 (default run: 3 / 0)
+    env.reset(seed=seed)
+    g = torch.Generator(device=env.device).manual_seed(seed - 3)
     lo = torch.as_tensor(env.action_space.low, device=env.device); hi = torch.as_tensor(env.action_space.high, device=env.device)
     acts = [lo + (hi - lo) * torch.rand((n, env.nu), device=env.device, generator=g) for _ in range(64)]
     k = steps if not (env_id.startswith("AntPushMaze") or "Fall" in env_id) else steps // 4
