@@ -191,6 +191,7 @@ MZ_HD double gd_impedance(const double* si, double x) {
   if (xn <= 0.0) return d0;
   double y;
   if (power <= 1.0 + 1e-12) y = xn;
+  else if (power == 2.0) y = xn <= mid ? xn * xn / mid : 1.0 - (1.0 - xn) * (1.0 - xn) / (1.0 - mid);  // MuJoCo's default power: no pow()
   else if (xn <= mid) y = pow(xn, power) / pow(mid, power - 1.0);
   else y = 1.0 - pow(1.0 - xn, power) / pow(1.0 - mid, power - 1.0);
   return d0 + y * (dmax - d0);

@@ -130,6 +130,7 @@ MZS_HD double sw_impedance(const double* si, double x) {
   if (xn <= 0.0) return d0;
   double y;
   if (power <= 1.0 + 1e-12) y = xn;
+  else if (power == 2.0) y = xn <= mid ? xn * xn / mid : 1.0 - (1.0 - xn) * (1.0 - xn) / (1.0 - mid);  // MuJoCo's default power: no pow()
   else if (xn <= mid) y = pow(xn, power) / pow(mid, power - 1.0);
   else y = 1.0 - pow(1.0 - xn, power) / pow(1.0 - mid, power - 1.0);
   return d0 + y * (dmax - d0);
@@ -183,7 +184,8 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
     double pm = phi[0];
 #pragma unroll
     for (int b = 1; b < NL; b++) pm = me == b ? phi[b] : pm;
-    const double cm = cos(pm), sm = sin(pm);
+    double cm, sm;
+    sincos(pm, &sm, &cm);  // one argument reduction for both
 #pragma unroll
     for (int b = 0; b < NL; b++) { c[b] = cx.from_lane(cm, b); s[b] = cx.from_lane(sm, b); }
   }
