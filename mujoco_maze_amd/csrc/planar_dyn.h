@@ -817,20 +817,23 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       if (!done && P.inv_scale * gn < 1e-10) done = true;
       if (!cx.any(!done)) break;
       if (it == 49 && !done) { MZ_FOR(one, 1) s.status |= MZ_STATUS_SOLVER_MAXITER; }
-      double L[3][3], y[3], sr[3];
+      double L[3][3], y[3], sr[3], inv[3];  // Cholesky with one reciprocal square root per column, no division
       for (int j = 0; j < 3; j++) {
         double d = H[j][j];
         for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-        d = sqrt(fmax(d, 1e-300));
-        L[j][j] = d;
+#if defined(__HIP_DEVICE_COMPILE__)
+        inv[j] = rsqrt(fmax(d, 1e-300));
+#else
+        inv[j] = 1.0 / sqrt(fmax(d, 1e-300));
+#endif
         for (int i = j + 1; i < 3; i++) {
           double t = H[i][j];
           for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-          L[i][j] = t / d;
+          L[i][j] = t * inv[j];
         }
       }
-      for (int i = 0; i < 3; i++) { double t = -g[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
-      for (int i = 2; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 3; k++) t -= L[k][i] * y[k]; y[i] = t / L[i][i]; }
+      for (int i = 0; i < 3; i++) { double t = -g[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
+      for (int i = 2; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 3; k++) t -= L[k][i] * y[k]; y[i] = t * inv[i]; }
       for (int i = 0; i < 3; i++) sr[i] = y[i];
       double p1 = 0.0, p2 = 0.0;
       for (int i = 0; i < 3; i++) {

@@ -137,23 +137,31 @@ MZS_HD double sw_impedance(const double* si, double x) {
 }
 
 // dense symmetric positive definite solve A x = b (n = NV <= 5), Cholesky in registers
+// (one reciprocal square root per column and no division: the columns are scaled by 1 / L_jj, which is also all the two
+// substitutions need — on the device v_rsq_f64 + refinement instead of five square roots and ten reciprocals in float64)
+MZS_HD double sw_rsqrt(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(d);
+#else
+  return 1.0 / sqrt(d);
+#endif
+}
 template <int NV>
 MZS_HD void sw_solve(const double A[NV][NV], const double* b, double* x) {
-  double L[NV][NV];
+  double L[NV][NV], inv[NV];
   for (int j = 0; j < NV; j++) {
     double d = A[j][j];
     for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-    d = sqrt(fmax(d, 1e-300));
-    L[j][j] = d;
+    inv[j] = sw_rsqrt(fmax(d, 1e-300));
     for (int i = j + 1; i < NV; i++) {
       double t = A[i][j];
       for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-      L[i][j] = t / d;
+      L[i][j] = t * inv[j];
     }
   }
   double y[NV];
-  for (int i = 0; i < NV; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
-  for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k]; x[i] = t / L[i][i]; }
+  for (int i = 0; i < NV; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
+  for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k]; x[i] = t * inv[i]; }
 }
 
 // Execution context of the chain's forward dynamics.  On the device a group of G adjacent lanes (4 for chains of up to four
