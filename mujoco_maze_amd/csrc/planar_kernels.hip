@@ -204,6 +204,12 @@ struct SwimmerCtx {
   __device__ __forceinline__ double gsum(double x) const { return DevCtx<G>{l}.gsum(x); }
   // value of lane k of this lane's group (ds_bpermute on the two halves of the double; a handful per forward evaluation)
   __device__ __forceinline__ double from_lane(double x, int k) const { return __shfl(x, (int)(threadIdx.x & 63u) - l + k, 64); }
+#ifdef MZ_EXP_SWPROF
+  mutable unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+  __device__ __forceinline__ void stamp(int k) const { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); prof[k] += t - t0; t0 = t; }
+#else
+  __device__ __forceinline__ void stamp(int) const {}
+#endif
 };
 
 template <int NL, int NB, int G>
@@ -218,6 +224,9 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   int env = gid / G;
   const SwimmerCtx<G> cx{(int)(threadIdx.x % G)};
+#ifdef MZ_EXP_SWPROF
+  cx.t0 = __builtin_amdgcn_s_memtime();
+#endif
   const bool live = env < n && cx.l == 0;
   if (env >= n) env = n - 1;  // surplus groups shadow the last env (no stores): every lane reaches the group sums
   constexpr int NR = NL + 2, NV = NR + NB, NH = NL - 1;  // NB: slide dofs of the movable block
@@ -229,6 +238,12 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
   for (int k = 0; k < NH; k++) af[k] = actions[(size_t)env * NH + k];
   int t_new;
   int st = swimmer_maze_step<NL, NB>(P, qf, vf, af, S.t[env], o, &inner, inf4, &t_new, cx);
+#ifdef MZ_EXP_SWPROF
+  cx.stamp(6);
+  if (blockIdx.x == 3 && threadIdx.x == 0)
+    printf("PROF %d sincos %llu links %llu gsum %llu solve %llu limits %llu rk4 %llu rest %llu\n", (int)blockIdx.x, cx.prof[0], cx.prof[1], cx.prof[2], cx.prof[3], cx.prof[4],
+           cx.prof[5], cx.prof[6]);
+#endif
   if (!live) return;
   float outer; int tm, gi;
   task_eval_dev(P.task, o, &outer, &tm, &gi);

@@ -37,6 +37,7 @@ struct SwimmerDev {
   double lim_lo[MZ_SW_MAXL - 1], lim_hi[MZ_SW_MAXL - 1], lim_K, lim_B, lim_solimp[5], dofw[MZ_SW_MAXL - 1];
   double qpos0[MZ_SW_MAXL + 2];
   int nlink;                          // 3 Swimmer, 2 Reacher; 4..6: user-supplied chains
+  double mtot[2], inv_l[2];           // M00 / M11 = total mass + armature of the slide, and 1 / sqrt of them (sw_factor_slides)
   // movable blocks of the maze: `collision="predefined"` gives the swimmer no contact pairs at all, so a block is a free,
   // force-free slide-x / slide-y body — it only drifts with whatever velocity it is given and shows up in the observation
   int nblock, observe_blocks;
@@ -112,6 +113,11 @@ static inline int swimmer_dev_from_model(SwimmerDev* p, const mz_model* m, char*
   p->lim_B = 2.0 / (dmax * tc);
   for (int k = 0; k < 5; k++) p->lim_solimp[k] = m->jnt_solimp[3][k];
   for (int k = 0; k < nl + 2; k++) p->qpos0[k] = m->qpos0[k];
+  for (int a = 0; a < 2; a++) {
+    double t = p->armature[a];
+    for (int b = 0; b < nl; b++) t += p->mass[b];
+    p->mtot[a] = t; p->inv_l[a] = 1.0 / sqrt(t);
+  }
   task_dev_from_model(&p->task, m);
   return MZ_OK;
 }
@@ -147,9 +153,27 @@ MZS_HD double sw_rsqrt(double d) {
 #endif
 }
 template <int NV>
-MZS_HD void sw_solve(const double A[NV][NV], const double* b, double* x) {
-  double L[NV][NV], inv[NV];
-  for (int j = 0; j < NV; j++) {
+MZS_HD void sw_subst(const double L[NV][NV], const double* inv, const double* b, double* x) {
+  double y[NV];
+  for (int i = 0; i < NV; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
+  for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k]; x[i] = t * inv[i]; }
+}
+// x = A^-1 e_R from the factor (the forward substitution starts at row R: the rows before it are zeros)
+template <int NV, int R>
+MZS_HD void sw_unit_solve(const double L[NV][NV], const double* inv, double* x) {
+  double y[NV];
+  y[R] = inv[R];
+  for (int i = R + 1; i < NV; i++) { double t = 0.0; for (int k = R; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
+  for (int i = NV - 1; i >= 0; i--) {
+    double t = i >= R ? y[i] : 0.0;
+    for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k];
+    x[i] = t * inv[i];
+  }
+}
+// columns J0 .. NV-1 of the factor (the columns before them are taken as they stand in L / inv)
+template <int NV, int J0>
+MZS_HD void sw_factor_from(const double A[NV][NV], double L[NV][NV], double* inv) {
+  for (int j = J0; j < NV; j++) {
     double d = A[j][j];
     for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
     inv[j] = sw_rsqrt(fmax(d, 1e-300));
@@ -159,9 +183,22 @@ MZS_HD void sw_solve(const double A[NV][NV], const double* b, double* x) {
       L[i][j] = t * inv[j];
     }
   }
-  double y[NV];
-  for (int i = 0; i < NV; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
-  for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k]; x[i] = t * inv[i]; }
+}
+template <int NV>
+MZS_HD void sw_solve(const double A[NV][NV], const double* b, double* x) {
+  double L[NV][NV], inv[NV];
+  sw_factor_from<NV, 0>(A, L, inv);
+  sw_subst<NV>(L, inv, b, x);
+}
+// The chain's mass matrix has a fixed corner: the two slides carry the whole mass and do not couple (M00 = M11 = total mass +
+// armature, M10 = 0), so the first two columns of the factor need no square root — inv0 / inv1 come from the host — and the
+// second column no elimination.  Used by the lane-group path; the generic sw_solve stays the one-lane path's.
+template <int NV>
+MZS_HD void sw_factor_slides(const double A[NV][NV], double inv0, double inv1, double L[NV][NV], double* inv) {
+  inv[0] = inv0; inv[1] = inv1;
+  L[1][0] = 0.0;
+  for (int i = 2; i < NV; i++) { L[i][0] = A[i][0] * inv0; L[i][1] = A[i][1] * inv1; }
+  sw_factor_from<NV, 2>(A, L, inv);
 }
 
 // Execution context of the chain's forward dynamics.  On the device a group of G adjacent lanes (4 for chains of up to four
@@ -175,16 +212,19 @@ struct SwimmerOneLane {
   MZS_HD int lane0() const { return 0; }
   MZS_HD double gsum(double x) const { return x; }
   MZS_HD double from_lane(double x, int) const { return x; }
+  MZS_HD void stamp(int) const {}  // phase timers of experiment builds (planar_kernels.hip, MZ_EXP_SWPROF)
 };
 
 // forward dynamics: qacc from (q, v, motor torques tau[NL - 1]); returns status bits
 template <int NL, class C>
 MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, const double* v, const double* tau, double* qacc) {
   constexpr int NV = NL + 2, NH = NL - 1;
+  cx.stamp(5);
   // link orientation angles and rates
   double phi[NL], om[NL], c[NL], s[NL];
   phi[0] = q[2]; om[0] = v[2];
   for (int b = 1; b < NL; b++) { phi[b] = phi[b - 1] + q[2 + b]; om[b] = om[b - 1] + v[2 + b]; }
+  double cm = 1.0, sm = 0.0;  // lane-group path: cosine / sine of this lane's own link
   if constexpr (C::nlanes == 1) {
     for (int b = 0; b < NL; b++) { c[b] = cos(phi[b]); s[b] = sin(phi[b]); }
   } else {  // each lane evaluates the sine / cosine of its own link's angle; the others come from their lanes
@@ -192,29 +232,90 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
     double pm = phi[0];
 #pragma unroll
     for (int b = 1; b < NL; b++) pm = me == b ? phi[b] : pm;
-    double cm, sm;
     sincos(pm, &sm, &cm);  // one argument reduction for both
 #pragma unroll
     for (int b = 0; b < NL; b++) { c[b] = cx.from_lane(cm, b); s[b] = cx.from_lane(sm, b); }
   }
-  // position Jacobians of the link centres: p_b = p0 + sum_{k<b} off[k+1] e(phi_k) + com[b] e(phi_b); link b on lane b
-  double M[NV][NV], frc[NV];
+  cx.stamp(0);
+  double M[NV][NV], frc[NV], L[NV][NV], inv[NV];
+  if constexpr (C::nlanes > 1) {
+    // Lane-group path: ONE instruction stream for every link — lane b holds link b's constants and chain length in registers
+    // (selected once; a per-link `if (b != lane) continue` would make the wave walk all NL bodies one after the other with a
+    // quarter of its lanes enabled each time).  p_b = p0 + sum_{k<b} off[k+1] e(phi_k) + com[b] e(phi_b): segment k of lane b
+    // has length off[k+1] (k < b), com[b] (k == b) or 0 (k > b), so the loop below is the same for all lanes.  Lanes beyond
+    // the chain's end carry a massless, sizeless copy of the last link: their shares are zeros.
+    const int ln = cx.lane0(), lb = ln < NL ? ln : NL - 1;
+    const bool act = ln < NL;
+    double m = P.mass[0], izz = P.izz[0], com = P.com[0], bx0 = P.box[0][0], bx1 = P.box[0][1], bx2 = P.box[0][2], w = om[0];
+#pragma unroll
+    for (int b = 1; b < NL; b++) {
+      const bool me = lb == b;
+      m = me ? P.mass[b] : m; izz = me ? P.izz[b] : izz; com = me ? P.com[b] : com; w = me ? om[b] : w;
+      bx0 = me ? P.box[b][0] : bx0; bx1 = me ? P.box[b][1] : bx1; bx2 = me ? P.box[b][2] : bx2;
+    }
+    if (!act) { m = 0.0; izz = 0.0; bx0 = 0.0; bx1 = 0.0; bx2 = 0.0; }
+    double Jx[NL], Jy[NL], ax = 0.0, ay = 0.0;  // columns of the hinge dofs 2 .. NV-1 (the slides' columns are unit vectors)
+#pragma unroll
+    for (int j = 0; j < NL; j++) { Jx[j] = 0.0; Jy[j] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      const double len = k < lb ? P.off[k + 1 < NL ? k + 1 : 0] : (k == lb ? com : 0.0);
+      const double ex = c[k] * len, ey = s[k] * len;
+#pragma unroll
+      for (int j = 0; j <= k; j++) { Jx[j] -= ey; Jy[j] += ex; }
+      ax -= om[k] * om[k] * ex; ay -= om[k] * om[k] * ey;  // centripetal acceleration at qacc = 0
+    }
+    double vx = v[0], vy = v[1];
+#pragma unroll
+    for (int j = 0; j < NL; j++) { vx += Jx[j] * v[2 + j]; vy += Jy[j] * v[2 + j]; }
+    const double co = cm, so = sm;  // the fluid forces act in the link frame at its centre (MuJoCo inertia-box model)
+    const double lvx = co * vx + so * vy, lvy = -so * vx + co * vy;
+    double fx = 0.0, fy = 0.0, tz = 0.0;
+    if (P.viscosity > 0.0) {
+      const double diam = (bx0 + bx1 + bx2) / 3.0;
+      const double sl = -3.0 * P.viscosity * 3.141592653589793 * diam, sa = -P.viscosity * 3.141592653589793 * diam * diam * diam;
+      fx += sl * lvx; fy += sl * lvy; tz += sa * w;
+    }
+    if (P.density > 0.0) {
+      fx -= 0.5 * P.density * bx1 * bx2 * fabs(lvx) * lvx;
+      fy -= 0.5 * P.density * bx0 * bx2 * fabs(lvy) * lvy;
+      tz -= P.density * bx2 * (bx0 * bx0 * bx0 * bx0 + bx1 * bx1 * bx1 * bx1) * fabs(w) * w / 64.0;
+    }
+    const double Gx = (co * fx - so * fy) - m * ax, Gy = (so * fx + co * fy) - m * ay;
+    cx.stamp(1);
+    // shares -> group sums; the slides' corner of M is constant (SwimmerDev::mtot)
+    frc[0] = cx.gsum(Gx); frc[1] = cx.gsum(Gy);
+    M[0][0] = P.mtot[0]; M[1][1] = P.mtot[1]; M[1][0] = 0.0; M[0][1] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const bool on = i <= lb;  // hinge i turns this lane's link
+      frc[2 + i] = cx.gsum(Jx[i] * Gx + Jy[i] * Gy + (on ? tz : 0.0));
+      const double t0 = cx.gsum(m * Jx[i]), t1 = cx.gsum(m * Jy[i]);
+      M[2 + i][0] = t0; M[0][2 + i] = t0; M[2 + i][1] = t1; M[1][2 + i] = t1;
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double t = cx.gsum(m * (Jx[i] * Jx[j] + Jy[i] * Jy[j]) + (on ? izz : 0.0));
+        if (i == j) t += P.armature[2 + i];
+        M[2 + i][2 + j] = t; M[2 + j][2 + i] = t;
+      }
+    }
+    for (int k = 0; k < NH; k++) frc[3 + k] += tau[k];
+    cx.stamp(2);
+    sw_factor_slides<NV>(M, P.inv_l[0], P.inv_l[1], L, inv);
+  } else {
+  // position Jacobians of the link centres: p_b = p0 + sum_{k<b} off[k+1] e(phi_k) + com[b] e(phi_b)
   for (int i = 0; i < NV; i++) {
     frc[i] = 0.0;
     for (int j = 0; j < NV; j++) M[i][j] = 0.0;
   }
-#pragma unroll
   for (int b = 0; b < NL; b++) {
-    if (C::nlanes > 1 && b != cx.lane0()) continue;  // (lanes beyond the chain's length contribute zeros)
     double Jx[NV], Jy[NV], ax = 0.0, ay = 0.0;
     for (int k = 0; k < NV; k++) { Jx[k] = 0.0; Jy[k] = 0.0; }
     Jx[0] = 1.0; Jy[1] = 1.0;
-#pragma unroll
     for (int k = 0; k <= b; k++) {
       const double len = k < b ? P.off[k + 1] : P.com[b];  // segment carried by the frame of link k
       const double ex = c[k] * len, ey = s[k] * len;
       // d/d(phi_k) of the segment = (-ey, ex); phi_k depends on the hinge dofs 2..2+k
-#pragma unroll
       for (int d = 2; d <= 2 + k; d++) { Jx[d] += -ey; Jy[d] += ex; }
       ax += -om[k] * om[k] * ex; ay += -om[k] * om[k] * ey;  // centripetal acceleration at qacc = 0
     }
@@ -236,28 +337,24 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
       tz -= P.density * bx[2] * (bx[0] * bx[0] * bx[0] * bx[0] + bx[1] * bx[1] * bx[1] * bx[1]) * fabs(w) * w / 64.0;
     }
     const double Fx = c[b] * fx - s[b] * fy, Fy = s[b] * fx + c[b] * fy;
-#pragma unroll
     for (int i = 0; i < NV; i++) {
       const double jw_i = (i >= 2 && i <= 2 + b) ? 1.0 : 0.0;
       frc[i] += Jx[i] * (Fx - m * ax) + Jy[i] * (Fy - m * ay) + jw_i * tz;
-#pragma unroll
       for (int j = 0; j <= i; j++) {
         const double jw_j = (j >= 2 && j <= 2 + b) ? 1.0 : 0.0;
         M[i][j] += m * (Jx[i] * Jx[j] + Jy[i] * Jy[j]) + P.izz[b] * jw_i * jw_j;
       }
     }
   }
-  // the links' shares meet: sums over the lane group (identity on one lane), then the symmetric half and the armature
-#pragma unroll
-  for (int i = 0; i < NV; i++) {
-    frc[i] = cx.gsum(frc[i]);
-#pragma unroll
-    for (int j = 0; j <= i; j++) { const double t = cx.gsum(M[i][j]) + (i == j ? P.armature[i] : 0.0); M[i][j] = t; M[j][i] = t; }
-  }
+  for (int i = 0; i < NV; i++)
+    for (int j = 0; j <= i; j++) { const double t = M[i][j] + (i == j ? P.armature[i] : 0.0); M[i][j] = t; M[j][i] = t; }
   for (int k = 0; k < NH; k++) frc[3 + k] += tau[k];
+  sw_factor_from<NV, 0>(M, L, inv);
+  }
   double qas[NV];
-  sw_solve<NV>(M, frc, qas);
+  sw_subst<NV>(L, inv, frc, qas);
   for (int i = 0; i < NV; i++) qacc[i] = qas[i];
+  cx.stamp(3);
   // joint limits on the inner hinges
   double sg[NH], D[NH], aref[NH];
   for (int k = 0; k < NH; k++) { sg[k] = 0.0; D[k] = 0.0; aref[k] = 0.0; }
@@ -273,7 +370,47 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
       any = true;
     }
   }
+  cx.stamp(4);
   if (!any) return 0;
+  if constexpr (NH <= 2) {
+    // One or two limit rows, each on a single dof (J_k = sg_k e_{3+k}): the minimiser of
+    //   1/2 (a - a_s)^T M (a - a_s) + sum_k D_k / 2 min(0, sg_k a_{3+k} - aref_k)^2
+    // is a = a_s + M^-1 sum_k sg_k lam_k e_{3+k} with lam_k = D_k max(0, -r_k) >= 0, r = r0 + G lam, r0_k = sg_k a_s[3+k] - aref_k,
+    // G = S (M^-1)_hinge S: a piecewise linear system in at most two unknowns, solved by trying its active sets (both rows, one
+    // row, none — strict convexity makes exactly one of them consistent).  Same optimum as the Newton iteration below (which the
+    // longer chains keep, and which the oracle runs to 1e-10), without its factorisations and line searches.
+    double X0[NV], r0[NH], Rk[NH];
+    bool val[NH];
+    for (int k = 0; k < NH; k++) { val[k] = sg[k] != 0.0; r0[k] = val[k] ? sg[k] * qas[3 + k] - aref[k] : 0.0; Rk[k] = val[k] ? 1.0 / D[k] : 1.0; }
+    sw_unit_solve<NV, 3>(L, inv, X0);
+    if constexpr (NH == 1) {
+      const double lam = (val[0] && r0[0] < 0.0) ? -r0[0] / (X0[3] + Rk[0]) : 0.0;  // G00 = sg^2 (M^-1)_33
+      for (int i = 0; i < NV; i++) qacc[i] = qas[i] + (sg[0] * lam) * X0[i];
+    } else {
+      double X1[NV];
+      sw_unit_solve<NV, 4>(L, inv, X1);
+      const double g00 = X0[3] + Rk[0], g11 = X1[4] + Rk[1], g01 = sg[0] * sg[1] * X1[3];
+      const double idet = 1.0 / (g00 * g11 - g01 * g01);
+      const double lb0 = (-r0[0] * g11 + r0[1] * g01) * idet, lb1 = (-r0[1] * g00 + r0[0] * g01) * idet;  // both rows active
+      const double ls0 = -r0[0] / g00, ls1 = -r0[1] / g11;                                              // one row active
+      const bool both = val[0] && val[1] && lb0 > 0.0 && lb1 > 0.0;
+      const bool only0 = val[0] && r0[0] < 0.0 && (!val[1] || r0[1] + g01 * ls0 >= 0.0);
+      const bool only1 = val[1] && r0[1] < 0.0 && (!val[0] || r0[0] + g01 * ls1 >= 0.0);
+      const bool none = !(val[0] && r0[0] < 0.0) && !(val[1] && r0[1] < 0.0);
+      double l0, l1;
+      if (both) { l0 = lb0; l1 = lb1; }
+      else if (only0) { l0 = ls0; l1 = 0.0; }
+      else if (only1) { l0 = 0.0; l1 = ls1; }
+      else if (none) { l0 = 0.0; l1 = 0.0; }
+      else {  // on the boundary between two active sets (rounding): their solutions agree there
+        l0 = val[0] ? fmax(0.0, val[1] ? lb0 : ls0) : 0.0;
+        l1 = val[1] ? fmax(0.0, val[0] ? lb1 : ls1) : 0.0;
+      }
+      for (int i = 0; i < NV; i++) qacc[i] = qas[i] + (sg[0] * l0) * X0[i] + (sg[1] * l1) * X1[i];
+    }
+    cx.stamp(4);
+    return 0;
+  }
   int status = 0;
   for (int it = 0; it < 50; it++) {
     double grad[NV], H[NV][NV], jar[NH], act[NH];
@@ -293,7 +430,8 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
     if (it == 49) status |= MZ_STATUS_SOLVER_MAXITER;
     double sr[NV], ng[NV];
     for (int i = 0; i < NV; i++) ng[i] = -grad[i];
-    sw_solve<NV>(H, ng, sr);
+    sw_factor_from<NV, 3>(H, L, inv);  // H = M + diag on the inner hinges (dofs 3 .. NV-1): columns 0..2 of the factor are M's
+    sw_subst<NV>(L, inv, ng, sr);
     double p1 = 0.0, p2 = 0.0;
     for (int i = 0; i < NV; i++) {
       double ms = 0.0, mx = 0.0;
@@ -319,6 +457,7 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
     }
     for (int i = 0; i < NV; i++) qacc[i] += alpha * sr[i];
   }
+  cx.stamp(4);
   return status;
 }
 
