@@ -158,18 +158,6 @@ MZS_HD void sw_subst(const double L[NV][NV], const double* inv, const double* b,
   for (int i = 0; i < NV; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
   for (int i = NV - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k]; x[i] = t * inv[i]; }
 }
-// x = A^-1 e_R from the factor (the forward substitution starts at row R: the rows before it are zeros)
-template <int NV, int R>
-MZS_HD void sw_unit_solve(const double L[NV][NV], const double* inv, double* x) {
-  double y[NV];
-  y[R] = inv[R];
-  for (int i = R + 1; i < NV; i++) { double t = 0.0; for (int k = R; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
-  for (int i = NV - 1; i >= 0; i--) {
-    double t = i >= R ? y[i] : 0.0;
-    for (int k = i + 1; k < NV; k++) t -= L[k][i] * x[k];
-    x[i] = t * inv[i];
-  }
-}
 // columns J0 .. NV-1 of the factor (the columns before them are taken as they stand in L / inv)
 template <int NV, int J0>
 MZS_HD void sw_factor_from(const double A[NV][NV], double L[NV][NV], double* inv) {
@@ -301,7 +289,7 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
     }
     for (int k = 0; k < NH; k++) frc[3 + k] += tau[k];
     cx.stamp(2);
-    sw_factor_slides<NV>(M, P.inv_l[0], P.inv_l[1], L, inv);
+    if constexpr (NL > 3) sw_factor_slides<NV>(M, P.inv_l[0], P.inv_l[1], L, inv);
   } else {
   // position Jacobians of the link centres: p_b = p0 + sum_{k<b} off[k+1] e(phi_k) + com[b] e(phi_b)
   for (int i = 0; i < NV; i++) {
@@ -349,10 +337,41 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
   for (int i = 0; i < NV; i++)
     for (int j = 0; j <= i; j++) { const double t = M[i][j] + (i == j ? P.armature[i] : 0.0); M[i][j] = t; M[j][i] = t; }
   for (int k = 0; k < NH; k++) frc[3 + k] += tau[k];
-  sw_factor_from<NV, 0>(M, L, inv);
+  if constexpr (NL > 3) sw_factor_from<NV, 0>(M, L, inv);
   }
   double qas[NV];
-  sw_subst<NV>(L, inv, frc, qas);
+  // Swimmer / Reacher (two or three links): the slides are eliminated by hand (their block of M is diagonal) and the NL x NL
+  // Schur complement of the hinges is inverted by cofactors — one reciprocal, independent products — instead of a factorisation
+  // whose columns wait for one another; Si = (M^-1) restricted to the hinges is also what the limit rows below need.
+  double Si[NL <= 3 ? NL : 1][NL <= 3 ? NL : 1], i0 = 0.0, i1 = 0.0;
+  if constexpr (NL <= 3) {
+    if constexpr (C::nlanes > 1) { i0 = P.inv_l[0] * P.inv_l[0]; i1 = P.inv_l[1] * P.inv_l[1]; }
+    else { i0 = 1.0 / M[0][0]; i1 = 1.0 / M[1][1]; }
+    double S[NL][NL], g[NL];
+    for (int i = 0; i < NL; i++) {
+      g[i] = frc[2 + i] - M[2 + i][0] * (frc[0] * i0) - M[2 + i][1] * (frc[1] * i1);
+      for (int j = 0; j <= i; j++) S[i][j] = M[2 + i][2 + j] - (M[2 + i][0] * i0) * M[2 + j][0] - (M[2 + i][1] * i1) * M[2 + j][1];
+    }
+    if constexpr (NL == 3) {
+      const double c00 = S[1][1] * S[2][2] - S[2][1] * S[2][1], c10 = S[2][1] * S[2][0] - S[1][0] * S[2][2], c20 = S[1][0] * S[2][1] - S[1][1] * S[2][0];
+      const double c11 = S[0][0] * S[2][2] - S[2][0] * S[2][0], c21 = S[1][0] * S[2][0] - S[0][0] * S[2][1], c22 = S[0][0] * S[1][1] - S[1][0] * S[1][0];
+      const double id = 1.0 / (S[0][0] * c00 + S[1][0] * c10 + S[2][0] * c20);
+      Si[0][0] = c00 * id; Si[1][1] = c11 * id; Si[2][2] = c22 * id;
+      Si[1][0] = Si[0][1] = c10 * id; Si[2][0] = Si[0][2] = c20 * id; Si[2][1] = Si[1][2] = c21 * id;
+    } else {
+      const double id = 1.0 / (S[0][0] * S[1][1] - S[1][0] * S[1][0]);
+      Si[0][0] = S[1][1] * id; Si[1][1] = S[0][0] * id; Si[1][0] = Si[0][1] = -S[1][0] * id;
+    }
+    double s0 = frc[0], s1 = frc[1];
+    for (int i = 0; i < NL; i++) {
+      double t = 0.0;
+      for (int j = 0; j < NL; j++) t += Si[i][j] * g[j];
+      qas[2 + i] = t; s0 -= M[2 + i][0] * t; s1 -= M[2 + i][1] * t;
+    }
+    qas[0] = s0 * i0; qas[1] = s1 * i1;
+  } else {
+    sw_subst<NV>(L, inv, frc, qas);
+  }
   for (int i = 0; i < NV; i++) qacc[i] = qas[i];
   cx.stamp(3);
   // joint limits on the inner hinges
@@ -382,13 +401,19 @@ MZS_HD int swimmer_forward(const C& cx, const SwimmerDev& P, const double* q, co
     double X0[NV], r0[NH], Rk[NH];
     bool val[NH];
     for (int k = 0; k < NH; k++) { val[k] = sg[k] != 0.0; r0[k] = val[k] ? sg[k] * qas[3 + k] - aref[k] : 0.0; Rk[k] = val[k] ? 1.0 / D[k] : 1.0; }
-    sw_unit_solve<NV, 3>(L, inv, X0);
+    // X_k = M^-1 e_{3+k}: hinge part = column 1 + k of Si, slide part from the eliminated rows
+    auto unit = [&](int col, double* X) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int i = 0; i < NL; i++) { X[2 + i] = Si[i][col]; t0 -= M[2 + i][0] * Si[i][col]; t1 -= M[2 + i][1] * Si[i][col]; }
+      X[0] = t0 * i0; X[1] = t1 * i1;
+    };
+    unit(1, X0);
     if constexpr (NH == 1) {
       const double lam = (val[0] && r0[0] < 0.0) ? -r0[0] / (X0[3] + Rk[0]) : 0.0;  // G00 = sg^2 (M^-1)_33
       for (int i = 0; i < NV; i++) qacc[i] = qas[i] + (sg[0] * lam) * X0[i];
     } else {
       double X1[NV];
-      sw_unit_solve<NV, 4>(L, inv, X1);
+      unit(2, X1);
       const double g00 = X0[3] + Rk[0], g11 = X1[4] + Rk[1], g01 = sg[0] * sg[1] * X1[3];
       const double idet = 1.0 / (g00 * g11 - g01 * g01);
       const double lb0 = (-r0[0] * g11 + r0[1] * g01) * idet, lb1 = (-r0[1] * g00 + r0[0] * g01) * idet;  // both rows active
