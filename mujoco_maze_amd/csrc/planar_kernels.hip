@@ -28,8 +28,10 @@ struct PointState { float* qv; int* t; uint32_t* ep; };
 
 // One MazeEnv.step of the Point (+ NB movable blocks or NS object balls): G lanes per env, PlanarScratch in LDS, SoA state in HBM
 // (q_0..q_{NV-1} | v_0..v_{NV-1}, each [n]).
+// The bare Point at 32 lanes per env runs two waves per SIMD (4096 envs = 2048 waves on 1024 SIMDs): its register budget is pinned
+// to 256 so that a few registers more do not silently halve the occupancy and send half the waves into a second round.
 template <int NB, int NS, int G>
-__global__ __launch_bounds__(64) void planar_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && NS == 0 && G == 32) ? 2 : 1))) void planar_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
                                                           const float* __restrict__ actions, float* __restrict__ obs,
                                                           float* __restrict__ reward, uint8_t* __restrict__ done,
                                                           int* __restrict__ goal_idx, float* __restrict__ info,

@@ -23,6 +23,14 @@ for l in rows:
         if k.isdigit(): continue
         tot[k] = tot.get(k, 0) + int(v)
 n = max(1, len(rows))
+# per-sample totals: a launch lasts as long as its slowest wave
+import statistics
+tots = sorted(sum(int(v) for k, v in re.findall(r"(\w+) (\d+)", l[5:]) if not k.isdigit()) for l in rows)
+if tots:
+    q = lambda f: tots[min(len(tots) - 1, int(f * len(tots)))]
+    print(f"per-sample total cycles: median {q(0.5)}  q90 {q(0.9)}  q99 {q(0.99)}  max {tots[-1]}")
+    heavy = [l for l in rows if sum(int(v) for k, v in re.findall(r"(\w+) (\d+)", l[5:]) if not k.isdigit()) >= q(0.99)]
+    for l in heavy[:3]: print("  heavy sample:", l)
 s = sum(tot.values())
 print(f"{len(rows)} samples; cycles per step per wave: {s / n:.0f}")
 for k, v in tot.items():
