@@ -206,6 +206,104 @@ extern "C" int emu_swimmer_env_step(const mz_model* m, int n, float* qpos, float
 #undef MZ_SW
 }
 
+// ---------------------------------------------------------------- Swimmer, lane-group form: the code path swimmer_step_kernel runs
+// The kernel advances one env on G adjacent lanes (lane b = link b; swimmer_dyn.h, `C::nlanes > 1` branches: per-lane link
+// constants, group sums, the slides' constant corner of M, the structured factor of the longer chains) — a different branch of
+// swimmer_forward than the one-lane form above.  Here the G lanes of a group are G host threads in lock step: a group sum /
+// a read of another lane's value is a slot array between two barriers, added up in the order of the device's DPP butterfly
+// (pairs, pairs of pairs, ...).  Slow, exact in structure; test infrastructure only.
+#include <pthread.h>
+template <int G>
+struct LaneGroupShared { pthread_barrier_t bar; double slot[G]; };
+template <int G>
+struct SwimmerLanesEmu {
+  static constexpr int nlanes = G;
+  int l;
+  LaneGroupShared<G>* sh;
+  int lane0() const { return l; }
+  double gsum(double x) const {
+    sh->slot[l] = x;
+    pthread_barrier_wait(&sh->bar);
+    double t[G];
+    for (int i = 0; i < G; i++) t[i] = sh->slot[i];
+    for (int w = 1; w < G; w *= 2)
+      for (int i = 0; i < G; i += 2 * w) t[i] = t[i] + t[i + w];
+    pthread_barrier_wait(&sh->bar);
+    return t[0];
+  }
+  double from_lane(double x, int k) const {
+    sh->slot[l] = x;
+    pthread_barrier_wait(&sh->bar);
+    const double r = sh->slot[k];
+    pthread_barrier_wait(&sh->bar);
+    return r;
+  }
+  void stamp(int) const {}
+};
+template <int NL, int NB, int G>
+struct SwimmerLaneJob {
+  const SwimmerDev* P; LaneGroupShared<G>* sh; int lane;
+  const float *q_in, *v_in, *act; int t_in;
+  float q[NL + 2 + NB], v[NL + 2 + NB], o[2 * (NL + 2 + NB) + 4];
+  double inner, inf4[4]; int t_new, st;
+  static void* run(void* arg) {
+    SwimmerLaneJob& j = *(SwimmerLaneJob*)arg;
+    for (int k = 0; k < NL + 2 + NB; k++) { j.q[k] = j.q_in[k]; j.v[k] = j.v_in[k]; }
+    SwimmerLanesEmu<G> cx{j.lane, j.sh};
+    j.st = swimmer_maze_step<NL, NB, SwimmerLanesEmu<G>>(*j.P, j.q, j.v, j.act, j.t_in, j.o, &j.inner, j.inf4, &j.t_new, cx);
+    return nullptr;
+  }
+};
+template <int NL, int NB>
+static int swimmer_env_step_lanes_t(const SwimmerDev& P, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
+                                    float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
+  constexpr int G = NL <= 4 ? 4 : 8;  // as mzk_planar_step launches it
+  constexpr int NR = NL + 2, NV = NR + NB, NH = NL - 1;
+  const int nb3 = (NB && P.observe_blocks) ? 3 : 0, NO = 2 * NV + 1 + nb3;
+  LaneGroupShared<G> sh;
+  pthread_barrier_init(&sh.bar, nullptr, G);
+  for (int e = 0; e < n; e++) {
+    SwimmerLaneJob<NL, NB, G> job[G];
+    pthread_t th[G];
+    for (int l = 0; l < G; l++) {
+      job[l].P = &P; job[l].sh = &sh; job[l].lane = l; job[l].q_in = qpos + NV * e; job[l].v_in = qvel + NV * e; job[l].act = actions + NH * e; job[l].t_in = t[e];
+      pthread_create(&th[l], nullptr, SwimmerLaneJob<NL, NB, G>::run, &job[l]);
+    }
+    for (int l = 0; l < G; l++) pthread_join(th[l], nullptr);
+    // every lane of the group ends with the same state (the kernel stores lane 0's): part of what this emulation checks
+    for (int l = 1; l < G; l++)
+      for (int k = 0; k < NV; k++) if (memcmp(&job[l].q[k], &job[0].q[k], 4) || memcmp(&job[l].v[k], &job[0].v[k], 4)) { pthread_barrier_destroy(&sh.bar); return MZ_ERR_ARG; }
+    const SwimmerLaneJob<NL, NB, G>& j = job[0];
+    for (int k = 0; k < NV; k++) { qpos[NV * e + k] = j.q[k]; qvel[NV * e + k] = j.v[k]; }
+    float outer; int tm, gi;
+    task_eval_dev(P.task, j.o, &outer, &tm, &gi);
+    for (int k = 0; k < NO; k++) obs[NO * e + k] = j.o[k];
+    reward[e] = (float)(P.task.inner_scale * j.inner) + outer;
+    done[e] = (uint8_t)((tm ? 1 : 0) | (j.t_new >= P.task.max_steps ? 2 : 0));
+    if (goal_idx) goal_idx[e] = gi;
+    if (info) for (int k = 0; k < 4; k++) info[4 * e + k] = (float)j.inf4[k];
+    if (status) status[e] = j.st;
+    t[e] = j.t_new;
+  }
+  pthread_barrier_destroy(&sh.bar);
+  return MZ_OK;
+}
+extern "C" int emu_swimmer_env_step_lanes(const mz_model* m, int n, float* qpos, float* qvel, int32_t* t, const float* actions, float* obs,
+                                          float* reward, uint8_t* done, int32_t* goal_idx, float* info, int32_t* status) {
+  SwimmerDev P;
+  char err[128];
+  int rc = swimmer_dev_from_model(&P, m, err, sizeof(err));
+  if (rc != MZ_OK) return rc;
+  const int bd = P.nblock ? P.nbdof : 0;
+#define MZ_SW(NL, BD) swimmer_env_step_lanes_t<NL, BD>(P, n, qpos, qvel, t, actions, obs, reward, done, goal_idx, info, status)
+  if (P.nlink == 3) return bd == 3 ? MZ_SW(3, 3) : (bd == 2 ? MZ_SW(3, 2) : MZ_SW(3, 0));
+  if (P.nlink == 2) return bd == 3 ? MZ_SW(2, 3) : (bd == 2 ? MZ_SW(2, 2) : MZ_SW(2, 0));
+  if (P.nlink == 4) return MZ_SW(4, 0);
+  if (P.nlink == 5) return MZ_SW(5, 0);
+  return MZ_SW(6, 0);
+#undef MZ_SW
+}
+
 // ---------------------------------------------------------------- the bit-exact pieces, for CPU tests against the golden vectors
 // MazeEnv.get_top_down_view exactly as view_fill_kernel evaluates it (csrc/mz_view.h): float64 entries for one torso / block
 // placement, and the in-place fill of fp32 observation rows whose view slots hold the parked block positions

@@ -78,14 +78,15 @@ def point_env_step(cm, st, actions):
     return out
 
 
-def swimmer_env_step(cm, st, actions):
-    """st: dict of float32 qpos [n,nv], qvel [n,nv], int32 t [n] (updated in place); nv = 5 Swimmer, 4 Reacher."""
+def swimmer_env_step(cm, st, actions, lanes=False):
+    """st: dict of float32 qpos [n,nv], qvel [n,nv], int32 t [n] (updated in place); nv = 5 Swimmer, 4 Reacher.
+    lanes=True: the lane-group form of the step (the branch of swimmer_dyn.h the kernel runs), G host threads in lock step."""
     lib = load()
     n = st["qpos"].shape[0]
     a = np.ascontiguousarray(actions, np.float32)
     out = dict(obs=np.zeros((n, cm.c.obs_dim), np.float32), reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
                goal_idx=np.zeros(n, np.int32), info=np.zeros((n, 4), np.float32), status=np.zeros(n, np.int32))
-    rc = lib.emu_swimmer_env_step(C.byref(cm.c), n, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["t"]), _vp(a), _vp(out["obs"]),
+    rc = (lib.emu_swimmer_env_step_lanes if lanes else lib.emu_swimmer_env_step)(C.byref(cm.c), n, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["t"]), _vp(a), _vp(out["obs"]),
                                   _vp(out["reward"]), _vp(out["done"]), _vp(out["goal_idx"]), _vp(out["info"]), _vp(out["status"]))
     assert rc == 0, rc
     return out

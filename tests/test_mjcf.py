@@ -206,3 +206,41 @@ def test_user_chain_on_the_device(oracle):
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     assert np.all(env.status().cpu().numpy() == 0)
     env.close()
+
+
+# ------------------------------------------------------------------------------------------------ the chain kernel's lane-group branch on CPU
+@pytest.mark.parametrize("robot,nlink", [("swimmer", 3), ("reacher", 2), ("swimmer", 4), ("swimmer", 5)])
+def test_chain_lane_group_form_matches_one_lane_and_oracle(oracle, robot, nlink):
+    """swimmer_step_kernel runs the `C::nlanes > 1` branches of csrc/swimmer_dyn.h (lane b = link b: per-lane link constants in ONE
+    instruction stream, group sums, the slides' constant corner of M, closed-form limit rows for 2 / 3 links, the structured
+    Cholesky start + hinge-column refactorisation of the Newton iteration for longer chains).  tests/emu runs that branch on
+    G host threads in lock step (group sums in the order of the device's DPP butterfly): every lane must end with the same state,
+    and the step must agree with the one-lane form and with the float64 oracle — with joints at their limits."""
+    from tests import emu_lib
+
+    xml = None if nlink <= 3 else chain_swimmer_xml(nlink)
+    cm = model.compile_model(robot, T.DistRewardUMaze(4.0), 4.0, robot_xml=xml) if xml else model.compile_model(robot, T.DistRewardUMaze(4.0), 4.0)
+    m = cm.c
+    assert m.nv == nlink + 2
+    n = 24
+    st, _ = oracle.reset(cm, n, 5)
+    rng = np.random.default_rng(2)
+    lim = np.array([m.jnt_range[3 + k][1] for k in range(nlink - 1)])
+    at_limit = 0
+    hold = np.sign(rng.uniform(-1, 1, (n, m.nu)))  # sustained torques drive the inner hinges into their limits
+    for k in range(46):
+        act = (hold * rng.uniform(0.5, 1.5, (n, m.nu))).astype(np.float32)
+        if k % 15 == 0:
+            s64 = {kk: (v.astype(np.float32).astype(np.float64) if v.dtype == np.float64 else v.copy()) for kk, v in st.items()}
+            s_one, s_grp = emu_lib.f32_state(s64), emu_lib.f32_state(s64)
+            at_limit += int((np.abs(s64["qpos"][:, 3:]) > lim).any(1).sum())
+            ro = oracle.step(cm, s64, act.astype(np.float64))
+            r1 = emu_lib.swimmer_env_step(cm, s_one, act)
+            rg = emu_lib.swimmer_env_step(cm, s_grp, act, lanes=True)  # rc != 0 (asserted inside) if the lanes of a group disagree
+            assert np.all(rg["status"] == 0) and np.array_equal(rg["done"], r1["done"]) and np.array_equal(rg["done"], ro["done"])
+            assert np.abs(rg["obs"] - r1["obs"]).max() <= 2e-6 and np.abs(rg["reward"] - r1["reward"]).max() <= 1e-6
+            assert np.abs(rg["obs"] - ro["obs"]).max() < 2e-5 and np.abs(rg["reward"] - ro["reward"]).max() < 1e-5
+            assert np.abs(s_grp["qpos"] - s_one["qpos"]).max() <= 1e-6 and np.abs(s_grp["qvel"] - s_one["qvel"]).max() <= 2e-5
+        oracle.step(cm, st, act.astype(np.float64))
+        if k % 15 == 14: hold = np.sign(rng.uniform(-1, 1, (n, m.nu)))
+    assert at_limit > 0  # limit rows were active at a checkpoint

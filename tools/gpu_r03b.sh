@@ -27,6 +27,9 @@ for a in "--env Ant4Rooms-v0" "--env AntPush-v0 --envs 2048" "--env PointUMaze-v
   python bench.py --steps 300 --warmup 10 --no-cpu-baseline $a 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-62s %8.3f M env-steps/s   kernel %.4f ms   flagged envs %d' % (d['metric'][34:], d['value']/1e6, d['roofline']['kernel_ms'], d['config']['bad_envs']))"
 done > $out/other_configs.txt
 python tools/bench_generic.py 2>/dev/null > $out/generic_robots.txt
+# phase timers of the bare Point (with the per-wave spread) and of the chain kernels: experiment libraries built by tools/exp_build.sh PROF / SWPROF
+[ -f mujoco_maze_amd/csrc/exp_PROF.so ] && python tools/exp_point_prof.py PointUMaze-v0 > $out/point_phase_tail.txt 2>&1
+[ -f mujoco_maze_amd/csrc/exp_SWPROF.so ] && { python tools/exp_swimmer_prof.py SwimmerUMaze-v0; python tools/exp_swimmer_prof.py ReacherUMaze-v0; } > $out/chain_phase.txt 2>&1
 python tools/parity_stats.py 2>/dev/null > $out/parity.md
 python tools/soak.py 8000 2>/dev/null > $out/soak.txt
 mkdir -p $out/profiles_r03; cp -r profiles/r03/* $out/profiles_r03/ 2>/dev/null
