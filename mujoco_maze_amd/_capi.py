@@ -35,6 +35,11 @@ def load():
         raise MazeStepError(
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C mujoco_maze_amd/csrc). mujoco_maze_amd has no CPU fallback.")
+    # torch first: its wheel carries its own HIP runtime, and the device buffers this library works on are torch tensors — if
+    # libmazestep.so were loaded before torch, the process would hold the system's libamdhip64 as well and the second runtime to
+    # initialise sees no device (found on the GPU box: build() loading the library ahead of smoke()'s `import torch`)
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
     lib.mz_abi_version.restype = C.c_int

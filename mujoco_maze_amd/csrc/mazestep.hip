@@ -192,7 +192,7 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "waves_per_block")) {
     int w = (int)value;
     if (w != 1 && w != 2 && w != 4) return set_err(h, MZ_ERR_ARG, "waves_per_block must be 1, 2 or 4", hipSuccess);
-    h->waves_per_block = w;
+    h->waves_per_block = w; h->wpb_set = 1;
     return MZ_OK;
   }
   if (!strcmp(key, "time_kernels")) {

@@ -39,7 +39,7 @@ struct mz_handle {
   float* final_obs;     // caller's buffer for terminal observations under auto-reset (mz_bind_final_obs), or NULL
   float* record;        // caller's [n, obs_dim + 2] buffer for the packed record obs | reward | done (mz_bind_record), or NULL
   unsigned long long* prof;  // 16 phase-cycle accumulators (option "profile_phases")
-  int auto_reset, lanes, waves_per_block;
+  int auto_reset, lanes, waves_per_block, wpb_set;
   uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
   char err[256];
   int lanes_set;  // lanes_per_env chosen by the caller (else the per-robot default)

@@ -358,10 +358,11 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
   PointState S{h->state, h->pt_t, h->pt_ep};
   if (h->robot == MZ_ROBOT_SWIMMER) {
 #define MZ_SW_STEP(NL, NB)                                                                                                          \
-  hipLaunchKernelGGL((swimmer_step_kernel<NL, NB, (NL <= 4 ? 4 : 8)>), dim3((unsigned)(((size_t)h->n * (NL <= 4 ? 4 : 8) + 255) / 256)), dim3(256), 0, st, \
+  hipLaunchKernelGGL((swimmer_step_kernel<NL, NB, (NL <= 4 ? 4 : 8)>), dim3((unsigned)(((size_t)h->n * (NL <= 4 ? 4 : 8) + sw_bd - 1) / sw_bd)), dim3(sw_bd), 0, st, \
                      h->swimmer_dev, h->n, S, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed,    \
                      h->env0, h->final_obs, h->model.obs_dim)
     const int bd = h->swimmer.nblock ? h->swimmer.nbdof : 0;
+    const unsigned sw_bd = 64u * (unsigned)(h->wpb_set ? h->waves_per_block : 4);  // workgroup size (option "waves_per_block")
     if (h->swimmer.nlink == 3) { if (bd == 3) MZ_SW_STEP(3, 3); else if (bd == 2) MZ_SW_STEP(3, 2); else MZ_SW_STEP(3, 0); }
     else if (h->swimmer.nlink == 2) { if (bd == 3) MZ_SW_STEP(2, 3); else if (bd == 2) MZ_SW_STEP(2, 2); else MZ_SW_STEP(2, 0); }
     else if (h->swimmer.nlink == 4) MZ_SW_STEP(4, 0);  // longer chains (user MJCF): no movable blocks
