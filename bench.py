@@ -44,6 +44,7 @@ ENV_ID = "AntUMaze-v0"
 SETTLE_STEPS = 100             # untimed, before --warmup: the timed window is the settled regime whatever the caller's --warmup
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD's MI355X spec sheet: FP64 vector = half the FP32 vector rate (the guide lists FP32 only)
 N_SIMD = 256 * 4                 # 256 CUs x 4 SIMDs
 
 
@@ -86,6 +87,53 @@ def pmc_counters(env_id, n_envs):
     return vals
 
 
+def live_pmc_traffic(args):
+    """HBM traffic of the step kernel measured WITH this run: when `rocprofv3` is on PATH, the same
+    workload is stepped twice more in child processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
+    passes, counters only — no tracing domain — as MI355X_MICROARCH.md prescribes: the two do not fit one pass), 100 settle +
+    64 profiled launches each; returns ({"FETCH_SIZE": KB, "WRITE_SIZE": KB} per-launch averages over the launches after the
+    settle steps, note) or (None, why).  The children run with --no-live-pmc / --no-cpu-baseline and print nothing we use."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    vals, settle, steps = {}, 100, 64
+    tmp = tempfile.mkdtemp(prefix="mz_bench_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--env", args.env,
+                   "--envs", str(args.envs), "--settle", str(settle), "--warmup", "0", "--steps", str(steps), "--no-cpu-baseline", "--no-live-pmc"]
+            if args.lanes:
+                cmd += ["--lanes", str(args.lanes)]
+            for kv in args.opt:
+                cmd += ["--opt", kv]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+            rows = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "_step_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        rows.append((int(row.get("Dispatch_Id", len(rows))), float(row["Counter_Value"])))
+            rows.sort()
+            timed = [v for _, v in rows][settle:]
+            if not timed:
+                return None, f"rocprofv3 --pmc {counter}: no step-kernel rows in the counter file"
+            vals[counter] = sum(timed) / len(timed)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return vals, f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command ({settle} settle + {steps} profiled launches each), per-launch average in bytes"
+
+
 def pmc_traffic(vals):
     """HBM bytes per launch: FETCH_SIZE + WRITE_SIZE (rocprofv3 reports KB).  The guide's x2 correction applies to wide
     (16 B/lane) streaming reads only; these are 4-B-per-lane loads, so the raw sum is reported."""
@@ -94,7 +142,7 @@ def pmc_traffic(vals):
     return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def valu_roofline(vals, kernel_ms, env_steps_per_s, env_id):
+def valu_roofline(vals, kernel_ms, env_steps_per_s, env_id, f64=False):
     """The informative roofline for this latency / VALU-bound path: how busy the vector pipes are, how
     many of their lanes do work, and the measured floating-point work against the FP32 vector peak.
     SQ_* cycle counters tick once per 4 shader cycles and are summed over the SIMDs; SQ_THREAD_CYCLES_VALU counts active
@@ -117,9 +165,10 @@ def valu_roofline(vals, kernel_ms, env_steps_per_s, env_id):
         out["flops_per_env_step"] = fl["flops_per_env_step"]
         out["flops_source"] = os.path.relpath(files[-1], ROOT) + " (float64 oracle formulation, gcov-counted)"
         out["achieved"] = fl["flops_per_env_step"] * env_steps_per_s / 1e12
-        out["peak"] = FP32_VECTOR_PEAK_TFLOPS
+        out["peak"] = FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS
+        out["peak_dtype"] = "f64 vector" if f64 else "f32 vector"
         out["unit"] = "TFLOP/s"
-        out["frac"] = out["achieved"] / FP32_VECTOR_PEAK_TFLOPS
+        out["frac"] = out["achieved"] / out["peak"]
     return out if len(out) > 2 else None
 
 
@@ -161,6 +210,11 @@ def cpu_baseline(model, env_id, n, lo, hi, seconds_target=12.0):
             "sample": f"{env_id}, {n} envs x {steps} batch-steps ({dt:.1f} s) on {cores} cores + {n1} envs x {steps1} batch-steps on 1 core, "
                       "after 20 untimed settling steps; float64 CPU oracle (restatement, not mujoco-py) built -O3 -march=x86-64-v3 "
                       "(oracle/libmzo_fast.so; the strict-fp libmzo.so is the parity checker, not timed), OpenMP over envs"}
+
+
+def _capi_path():
+    from mujoco_maze_amd import _capi
+    return _capi.LIB_PATH
 
 
 def _free_port():
@@ -224,6 +278,7 @@ def main():
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup (1/2/4); 0 = library default")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL obs all-gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child passes for roofline.traffic (fall back to profiles/)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only, no GPU work (CPU test of --gpus N)")
     ap.add_argument("--opt", action="append", default=[], help="extra library option key=value (tuning experiments)")
     args = ap.parse_args()
@@ -343,6 +398,10 @@ def main():
         algo_bytes = per_env * n
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
         pmc = pmc_counters(env_id, n)
+        live, live_note = (None, "disabled (--no-live-pmc)") if (args.no_live_pmc or world > 1) else live_pmc_traffic(args)
+        traffic = pmc_traffic(live) if live else pmc_traffic(pmc)
+        traffic_source = live_note if live else (f"fallback ({live_note}): " + pmc.get("_file", "none committed for this workload") +
+                                                 ": FETCH_SIZE + WRITE_SIZE (KB) of the committed rocprofv3 --pmc passes of this command, bytes per launch")
         robot = env.model.c.robot
         kernel = {1: "ant_step_kernel", 0: "planar_step_kernel", 2: "swimmer_step_kernel"}[robot]
         out = {
@@ -353,17 +412,19 @@ def main():
             "config": {"workload": f"{env_id}, {n} envs/GPU, frame_skip {env.model.c.frame_skip} x RK4, random actions uniform in the action box, auto-reset; "
                                    f"{args.settle} untimed settle steps + {args.warmup} warm-up steps before the timed window",
                        "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
+                       "library": os.path.relpath(_capi_path(), ROOT),
                        "lanes_per_env": args.lanes or "library default", "waves_per_block": args.wpb or 1, "bad_envs": bad,
                        **({"rehearsal": "all ranks on one GPU over gloo (MZ_BENCH_SINGLE_GPU=1): not a scaling measurement"}
                           if os.environ.get("MZ_BENCH_SINGLE_GPU") == "1" else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(pmc),
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": kernel, "kernel_ms": kernel_ms, "kernel_ms_per_rank": kernel_ms_ranks, "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_per_env_step": per_env,
-                         "traffic_source": (pmc.get("_file", "none committed for this workload") + ": FETCH_SIZE + WRITE_SIZE (KB) of the committed rocprofv3 --pmc passes of this command, bytes per launch; not collected live"),
+                         "traffic_source": traffic_source,
+                         "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
                          "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},
         }
-        rv = valu_roofline(pmc, kernel_ms, n * args.steps / (kernel_ms * 1e-3 * args.steps) if kernel_ms > 0 else 0.0, env_id)
+        rv = valu_roofline(pmc, kernel_ms, n * args.steps / (kernel_ms * 1e-3 * args.steps) if kernel_ms > 0 else 0.0, env_id, f64=robot != 1)
         if rv is not None:
             out["roofline_valu"] = rv
         if no_gather is not None:

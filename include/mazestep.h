@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZ_ABI_VERSION 6
+#define MZ_ABI_VERSION 7
 
 #define MZ_MAX_BODY 24
 #define MZ_MAX_JNT 24
@@ -83,7 +83,7 @@ extern "C" {
 /* per-env status bits (mz_get_status) */
 #define MZ_STATUS_OK 0
 #define MZ_STATUS_BAD_STATE 1      /* NaN / |x| > 1e10 in qpos/qvel/qacc (MuJoCo mj_check*) */
-#define MZ_STATUS_CONTACT_OVERFLOW 2 /* more simultaneous contacts than the kernel's buffer */
+#define MZ_STATUS_CONTACT_OVERFLOW 2 /* more simultaneous contacts (or, generic robots, joint-limit rows) than the kernel's buffers */
 #define MZ_STATUS_SOLVER_MAXITER 4 /* constraint solver hit its iteration cap */
 
 /* error codes */
@@ -126,6 +126,12 @@ typedef struct mz_model {
   double body_quat[MZ_MAX_BODY][4];
   double body_ipos[MZ_MAX_BODY][3];
   double body_inertia[MZ_MAX_BODY][6]; /* xx yy zz xy xz yz about COM, body frame */
+  /* MuJoCo's own form of the same tensor: principal moments and the inertial frame's orientation in the body frame
+   * (mjModel.body_inertia / body_iquat; ximat = xmat * R(iquat)).  A body with ONE geom takes that geom's frame and moments
+   * (a capsule's fromto frame, axial moment third); several geoms: eigen-decomposition of the summed tensor, moments in
+   * decreasing order.  The inertia-box fluid model works in this frame. */
+  double body_iquat[MZ_MAX_BODY][4];
+  double body_pinertia[MZ_MAX_BODY][3];
   double body_mass[MZ_MAX_BODY];
   double body_invweight0[MZ_MAX_BODY][2];
 
@@ -265,6 +271,16 @@ int32_t mz_bind_final_obs(mz_handle* h, float* final_obs_dev);
  * reference steps one env per process: mujoco_maze/maze_env.py:448-481 returns the three values separately). */
 int32_t mz_bind_record(mz_handle* h, float* record_dev);
 
+/* Goal resampling (MazeEnv.reset calls MazeTask.sample_goals() and, when it returns True, moves the goal markers:
+ * mujoco_maze/maze_env.py:374-376; MazeTask.sample_goals: maze_task.py:66-67).  Replaces the goal table the task predicate of
+ * every later mz_step / mz_debug_task_eval evaluates: ngoal <= MZ_MAX_GOAL rows of HOST arrays — pos [ngoal][3] (z ignored where
+ * dim = 2), threshold [ngoal], reward_scale [ngoal], dim [ngoal] (2 or 3) — float64, the reference's own values
+ * (maze_task.py:26-47).  Work already queued on `stream` is finished first (the call synchronises on it), so a step launched
+ * before the call is judged on the old goals and every step after it on the new ones.  Reward kind, slots, PENALTY stay
+ * those of the model.  Returns MZ_OK or MZ_ERR_ARG. */
+int32_t mz_set_goals(mz_handle* h, int32_t ngoal, const double* pos, const double* threshold, const double* reward_scale,
+                     const int32_t* dim, void* stream);
+
 /* reset(): envs with mask_dev[i] != 0 (all when NULL) get t = 0 and a fresh state
  * from the reference's reset distribution (counter-based RNG keyed by seed and
  * env slot; streams differ from numpy's — distributional parity only).
@@ -283,7 +299,8 @@ int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warm
  *  obs_dev     [N, obs_dim]   the step's observation (under auto-reset: see mz_bind_final_obs)
  *  reward_dev  [N]            inner_reward_scaling * inner + task reward
  *  done_dev    [N] u8         bit0 = task termination, bit1 = TimeLimit truncation
- *  goal_idx_dev[N] i32        first matching goal index or -1   (nullable)
+ *  goal_idx_dev[N] i32        first matching goal (list order) or -1 (nullable): the goal whose reward_scale the reward is
+ *                             (maze_task.py:403-407); for zero / distance rewards the first goal that terminates
  *  info_dev    [N, 4]         position x, y, reward_forward, reward_ctrl (nullable) */
 int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                 int32_t* goal_idx_dev, float* info_dev, void* stream);

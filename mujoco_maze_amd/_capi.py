@@ -10,13 +10,17 @@ import os
 from mujoco_maze_amd.model import MzModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MZ_LIBMAZESTEP_EXPERIMENT") or os.path.join(_HERE, "csrc", "libmazestep.so")  # the override is for tools/ A/B timing only
+DEFAULT_LIB_PATH = os.path.join(_HERE, "csrc", "libmazestep.so")
+# A/B timing of experiment builds (tools/exp_*.sh) only: the override is announced on stderr when the library is loaded and
+# recorded in bench.py's JSON line (config.library), so a stale variable cannot swap the stepper silently
+LIB_PATH = os.environ.get("MZ_LIBMAZESTEP_EXPERIMENT") or DEFAULT_LIB_PATH
 
 # every entry point declared in include/mazestep.h
 SYMBOLS = [
     "mz_abi_version", "mz_model_sizeof", "mz_create", "mz_destroy", "mz_last_error", "mz_num_envs", "mz_obs_dim", "mz_nq",
     "mz_nv", "mz_nu", "mz_set_option", "mz_reset", "mz_set_state", "mz_get_state", "mz_step", "mz_get_status",
     "mz_debug_forward", "mz_last_kernel_ms", "mz_read_phase_cycles", "mz_bind_final_obs", "mz_debug_task_eval", "mz_debug_detect", "mz_read_wave_cycles", "mz_bind_record",
+    "mz_set_goals",
 ]
 
 _lib = None
@@ -40,6 +44,10 @@ def load():
     # initialise sees no device (found on the GPU box: build() loading the library ahead of smoke()'s `import torch`)
     import torch  # noqa: F401
 
+    if LIB_PATH != DEFAULT_LIB_PATH:
+        import sys
+
+        print(f"mujoco_maze_amd: MZ_LIBMAZESTEP_EXPERIMENT is set — loading {LIB_PATH} instead of {DEFAULT_LIB_PATH}", file=sys.stderr)
     lib = C.CDLL(LIB_PATH)
     vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
     lib.mz_abi_version.restype = C.c_int
@@ -70,6 +78,8 @@ def load():
     lib.mz_bind_final_obs.argtypes = [vp, vp]
     lib.mz_bind_record.restype = i32
     lib.mz_bind_record.argtypes = [vp, vp]
+    lib.mz_set_goals.restype = i32
+    lib.mz_set_goals.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.mz_debug_task_eval.restype = i32
     lib.mz_debug_task_eval.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.mz_debug_detect.restype = i32

@@ -1786,7 +1786,7 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
 MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int* term, int* goal_idx) {
 #pragma clang fp contract(off) reciprocal(off) reassociate(off)
   const double slot_a[3] = {(double)obs[0], (double)obs[1], (double)obs[2]}, slot_o[3] = {(double)obs[3], (double)obs[4], (double)obs[5]};
-  int tm = 0, first = -1;
+  int tm = 0, first = -1, first_t = -1;
   for (int g = 0; g < T.ngoal; g++) {
     double a = 0.0, b = 0.0;
     for (int k = 0; k < 3; k++)
@@ -1794,7 +1794,7 @@ MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int*
         double e = (T.term_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; a += e * e;
         double f = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; b += f * f;
       }
-    if (!tm && a <= T.thr_sq[g]) tm = 1;
+    if (!tm && a <= T.thr_sq[g]) { tm = 1; first_t = g; }
     if (first < 0 && b <= T.thr_sq[g]) first = g;
   }
   double r = 0.0;
@@ -1805,7 +1805,9 @@ MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int*
       if (k < T.goal_dim[0]) { double e = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[0][k]; a += e * e; }
     r = -sqrt(a) / T.task_scale;
   }
-  *reward = (float)r; *term = tm; *goal_idx = first;
+  // goal index: the goal that set the reward where the reward is a goal's (first match on the reward's slot, maze_task.py:403-407);
+  // for the other reward kinds (zero, distance) the first goal that ends the episode (termination's slot, maze_task.py:77-81,599,653)
+  *reward = (float)r; *term = tm; *goal_idx = T.reward_kind == MZ_REWARD_FIRST_MATCH ? first : first_t;
 }
 
 // coordinate c of movable block k's body origin (get_body_com, maze_env.py:364-368): spawn position + its slides

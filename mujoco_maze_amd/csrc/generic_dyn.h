@@ -26,7 +26,7 @@
 #define GN_NG 16
 #define GN_NC 16  // simultaneous contacts
 #define GN_NL 20  // joint-limit rows
-#define GN_STAGE 4  // contacts one geom can hold (floor: 2 capsule ends; a wall corner: 2 + 2)
+#define GN_STAGE 6  // contacts one geom can hold (a capsule lying in a wall corner on the floor: 2 floor ends + 2 + 2 wall contacts)
 
 struct GenPair { double margin, gap, mu, K, B, solimp[5]; int condim, pad; };
 
@@ -498,7 +498,8 @@ MZ_HD void gen_compact_contacts(const GenDev& K, GenScratch& s) {
     const double q = s.qpos[m.jnt_qposadr[j]];
     for (int side = -1; side <= 1; side += 2) {
       const double dist = side < 0 ? q - m.jnt_range[j][0] : m.jnt_range[j][1] - q;
-      if (!(dist < m.jnt_margin[j]) || nl >= GN_NL) continue;
+      if (!(dist < m.jnt_margin[j])) continue;
+      if (nl >= GN_NL) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; continue; }  // a dropped constraint row is never silent
       const int dof = m.jnt_dofadr[j];
       const double imp = gd_impedance(m.jnt_solimp[j], fabs(dist - m.jnt_margin[j]));
       const double R = fmax(1e-15, (1.0 - imp) * m.dof_invweight0[dof] / imp), sg = -(double)side;
@@ -634,8 +635,13 @@ MZ_HD void gen_fluid_item(const GenDev& K, GenScratch& s, int b) {
   for (int e = 0; e < 6; e++) s.ffl[b][e] = 0.0;
   const double mass = m.body_mass[b];
   if (b == 0 || mass < 1e-15 || !(m.density > 0.0 || m.viscosity > 0.0)) return;
-  const double* I6 = m.body_inertia[b];
-  const double I[3] = {I6[0], I6[1], I6[2]};
+  // principal moments and the inertial frame ximat = xmat * R(body_iquat) (MuJoCo evaluates the box model there; the
+  // diagonal of the body-frame tensor is not the same thing for a tilted link)
+  const double* I = m.body_pinertia[b];
+  double Ri[9], xim[9];
+  gd_quat2mat(Ri, m.body_iquat[b]);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) xim[3 * i + j] = s.xmat[b][3 * i] * Ri[j] + s.xmat[b][3 * i + 1] * Ri[3 + j] + s.xmat[b][3 * i + 2] * Ri[6 + j];
   const double bx[3] = {sqrt(fmax(1e-15, I[1] + I[2] - I[0]) / mass * 6.0), sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / mass * 6.0),
                         sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / mass * 6.0)};
   const double w[3] = {s.cvel[b][0], s.cvel[b][1], s.cvel[b][2]};
@@ -643,8 +649,8 @@ MZ_HD void gen_fluid_item(const GenDev& K, GenScratch& s, int b) {
   for (int k = 0; k < 3; k++) r[k] = s.xipos[b][k] - s.refpoint[k];
   gd_cross(wr, w, r);
   for (int k = 0; k < 3; k++) vc[k] = s.cvel[b][3 + k] + wr[k];
-  gd_mulmatT(lw, s.xmat[b], w);
-  gd_mulmatT(lv, s.xmat[b], vc);
+  gd_mulmatT(lw, xim, w);
+  gd_mulmatT(lv, xim, vc);
   double lf[3] = {0, 0, 0}, lt[3] = {0, 0, 0};
   const double pi = 3.14159265358979323846;
   if (m.viscosity > 0.0) {
@@ -661,8 +667,8 @@ MZ_HD void gen_fluid_item(const GenDev& K, GenScratch& s, int b) {
     lt[2] -= m.density * bx[2] * (p4(bx[0]) + p4(bx[1])) * fabs(lw[2]) * lw[2] / 64.0;
   }
   double f[3], t[3], rf[3];
-  gd_mulmat(f, s.xmat[b], lf);
-  gd_mulmat(t, s.xmat[b], lt);
+  gd_mulmat(f, xim, lf);
+  gd_mulmat(t, xim, lt);
   gd_cross(rf, r, f);
   for (int k = 0; k < 3; k++) { s.ffl[b][k] = t[k] + rf[k]; s.ffl[b][3 + k] = f[k]; }
 }

@@ -142,6 +142,9 @@ int mzk_generic_create(mz_handle* h, char* err, int errlen) {
   free(g);
   return rc;
 }
+hipError_t mzk_generic_set_task(mz_handle* h, const TaskDev* task) {
+  return hipMemcpy(reinterpret_cast<char*>(h->gen_dev) + offsetof(GenDev, task), task, sizeof(TaskDev), hipMemcpyHostToDevice);
+}
 void mzk_generic_destroy(mz_handle* h) { if (h->gen_dev) { (void)hipFree(h->gen_dev); h->gen_dev = nullptr; } }
 hipError_t mzk_generic_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   static int lds_set[32] = {};

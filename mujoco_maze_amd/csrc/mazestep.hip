@@ -167,6 +167,11 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "auto_reset")) { h->auto_reset = value != 0; return MZ_OK; }
   if (!strcmp(key, "seed")) { h->seed = (uint64_t)value; return MZ_OK; }
   if (!strcmp(key, "env_index_offset")) { h->env0 = (uint64_t)value; return MZ_OK; }
+  if (h->robot != MZ_ROBOT_ANT && (!strcmp(key, "solver_iterations") || !strcmp(key, "solver_tolerance") || !strcmp(key, "solver_rtol") ||
+                                   !strcmp(key, "ls_iterations") || !strcmp(key, "debug_frame_skip") || !strcmp(key, "waves_per_block")))
+    return set_err(h, MZ_ERR_UNSUPPORTED, "mz_set_option: this key tunes the Ant kernels only (the other robots' solvers have fixed settings)", hipSuccess);
+  if (h->robot == MZ_ROBOT_GENERIC && !strcmp(key, "lanes_per_env"))
+    return set_err(h, MZ_ERR_UNSUPPORTED, "mz_set_option: the generic-robot kernel runs one wavefront per env", hipSuccess);
   if (!strcmp(key, "solver_iterations")) { h->ant_dirty = 1; h->ant.max_iter = (int)value; return MZ_OK; }
   if (!strcmp(key, "solver_tolerance")) { h->ant_dirty = 1; h->ant.tol = (float)value; return MZ_OK; }
   if (!strcmp(key, "solver_rtol")) { h->ant_dirty = 1; h->ant.rtol = (float)value; return MZ_OK; }
@@ -216,6 +221,38 @@ int32_t mz_bind_final_obs(mz_handle* h, float* final_obs_dev) {
 int32_t mz_bind_record(mz_handle* h, float* record_dev) {
   if (!h) return MZ_ERR_ARG;
   h->record = record_dev;
+  return MZ_OK;
+}
+
+int32_t mz_set_goals(mz_handle* h, int32_t ngoal, const double* pos, const double* threshold, const double* reward_scale, const int32_t* dim,
+                     void* stream) {
+  if (!h) return MZ_ERR_ARG;
+  if (ngoal < 0 || ngoal > MZ_MAX_GOAL || (ngoal > 0 && (!pos || !threshold || !reward_scale || !dim)))
+    return set_err(h, MZ_ERR_ARG, "mz_set_goals: 0 <= ngoal <= MZ_MAX_GOAL rows of pos / threshold / reward_scale / dim", hipSuccess);
+  for (int g = 0; g < ngoal; g++)
+    if ((dim[g] != 2 && dim[g] != 3) || !(threshold[g] >= 0.0)) return set_err(h, MZ_ERR_ARG, "mz_set_goals: dim must be 2 or 3, threshold >= 0", hipSuccess);
+  DeviceScope scope(h->device);
+  mz_model* m = &h->model;
+  m->ngoal = ngoal;
+  for (int g = 0; g < ngoal; g++) {
+    for (int k = 0; k < 3; k++) m->goal_pos[g][k] = pos[3 * g + k];
+    m->goal_threshold[g] = threshold[g]; m->goal_reward_scale[g] = reward_scale[g]; m->goal_dim[g] = dim[g];
+  }
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));  // steps already queued keep the goals they were launched with
+  if (h->robot == MZ_ROBOT_ANT) {
+    task_dev_from_model(&h->ant.task, m);
+    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->ant_dev) + offsetof(AntDev, task), &h->ant.task, sizeof(TaskDev), hipMemcpyHostToDevice));
+  } else if (h->robot == MZ_ROBOT_POINT) {
+    task_dev_from_model(&h->point.task, m);
+    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->point_dev) + offsetof(PointDev, task), &h->point.task, sizeof(TaskDev), hipMemcpyHostToDevice));
+  } else if (h->robot == MZ_ROBOT_SWIMMER) {
+    task_dev_from_model(&h->swimmer.task, m);
+    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->swimmer_dev) + offsetof(SwimmerDev, task), &h->swimmer.task, sizeof(TaskDev), hipMemcpyHostToDevice));
+  } else {
+    TaskDev t;
+    task_dev_from_model(&t, m);
+    HIPCHK(h, mzk_generic_set_task(h, &t));
+  }
   return MZ_OK;
 }
 

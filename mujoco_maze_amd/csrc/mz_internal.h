@@ -77,4 +77,5 @@ hipError_t mzk_generic_step(mz_handle* h, hipStream_t st, const float* actions, 
 hipError_t mzk_generic_reset(mz_handle* h, hipStream_t st, const uint8_t* mask, uint64_t seed, float* obs);
 hipError_t mzk_generic_set_state(mz_handle* h, hipStream_t st, const float* qpos, const float* qvel, const float* warm, const int* t);
 hipError_t mzk_generic_get_state(mz_handle* h, hipStream_t st, float* qpos, float* qvel, float* warm, int* t);
+hipError_t mzk_generic_set_task(mz_handle* h, const TaskDev* task);  // replaces the task block of the device constants (mz_set_goals)
 hipError_t mzk_generic_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx);

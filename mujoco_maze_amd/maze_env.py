@@ -39,6 +39,58 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class WrappedRobot:
+    """`MazeEnv.wrapped_env` of the reference (maze_env.py:218): the robot object user code reaches into for
+    `get_xy()` / `set_xy(xy)` / `get_ori()` (agent_model.py:35-41, ant.py:98-111, point.py:83-92, swimmer.py:70-76).  The
+    simulators themselves live in the HIP kernels, so this object is a view on the device batch through
+    mz_get_state / mz_set_state; class-level knobs of the robot class (FILE, ORI_IND, RADIUS, ...) read through.
+
+    On a `VecMazeEnv` the methods are batched (device tensors [N, 2] / [N]); on the single-env `MazeEnv` they take and return
+    float64 numpy values like the reference."""
+
+    def __init__(self, vec: "VecMazeEnv", model_cls, single: bool = False) -> None:
+        self._vec, self._cls, self._single = vec, model_cls, single
+
+    def __getattr__(self, name):  # class attributes of the robot class (ORI_IND, RADIUS, MANUAL_COLLISION, ...)
+        return getattr(self._cls, name)
+
+    def get_xy(self):
+        """qpos[:2] (ant.py:110-111, point.py:83-84, swimmer.py:75-76): a fresh copy."""
+        xy = self._vec.get_state()[0][:, :2].clone()
+        return xy[0].double().cpu().numpy() if self._single else xy
+
+    def set_xy(self, xy) -> None:
+        """qpos[:2] = xy, everything else (qvel, qacc_warmstart, t) untouched: ant.py:105-108, point.py:86-89 call
+        `set_state(qpos, qvel)` with the current qvel; the warm start is not part of mujoco-py's state and survives."""
+        torch, vec = self._vec._torch, self._vec
+        qpos = vec.get_state()[0]
+        new = torch.as_tensor(np.asarray(xy, dtype=np.float32) if not torch.is_tensor(xy) else xy, device=vec.device).to(torch.float32)
+        if self._single:
+            new = new.reshape(1, 2)
+        if tuple(new.shape) != (vec.num_envs, 2):
+            raise ValueError(f"xy must have shape {(vec.num_envs, 2)}, got {tuple(new.shape)}")
+        qpos[:, :2] = new
+        vec.set_state(qpos=qpos)
+
+    def get_ori(self):
+        """Heading: the Point's qpos[ORI_IND] (point.py:91-92); the Ant's torso x axis rotated by its quaternion
+        qpos[ORI_IND:ORI_IND+4] and projected on the plane, arctan2(y, x) (ant.py:98-103, q_mult / q_inv :26-35)."""
+        ind = getattr(self._cls, "ORI_IND", None)
+        if ind is None:
+            raise AttributeError(f"{self._cls.__name__} has no ORI_IND: the reference defines get_ori for the Point and the Ant only")
+        qpos = self._vec.get_state()[0].double()
+        torch = self._vec._torch
+        if getattr(self._cls, "ROBOT", None) == "ant":
+            w, x, y, z = (qpos[:, ind + k] for k in range(4))
+            # rot * (0, 1, 0, 0) * conj(rot), components 1..2, written out (ant.py:26-35 multiply without normalising)
+            ox = w * w + x * x - y * y - z * z
+            oy = 2.0 * (x * y + w * z)
+            ori = torch.atan2(oy, ox)
+        else:
+            ori = qpos[:, ind].clone()
+        return float(ori[0].item()) if self._single else ori
+
+
 class VecMazeEnv:
     def __init__(self, model_cls: Type[AgentModel], maze_task: Type[MazeTask] = MazeTask, num_envs: int = 1,
                  maze_height: float = 0.5, maze_size_scaling: float = 4.0, inner_reward_scaling: float = 1.0,
@@ -66,6 +118,7 @@ class VecMazeEnv:
             manual_collision=getattr(model_cls, "MANUAL_COLLISION", False), radius=getattr(model_cls, "RADIUS", None),
             robot_xml=kwargs.pop("robot_xml", None), **gen_kw)
         self.wrapped_cls = model_cls
+        self.wrapped_env = WrappedRobot(self, model_cls)
         from mujoco_maze_amd.model import device_unsupported_reason
 
         why = device_unsupported_reason(self.model)
@@ -130,6 +183,10 @@ class VecMazeEnv:
         """Bind (or, with None, unbind) a float32 [N, obs_dim + 2] device tensor that every step fills with the packed record
         obs | reward | done — the send buffer of the sharded run's all-gather (mz_bind_record); the caller keeps it alive."""
         if record is not None:
+            if self._host_rewards:
+                raise ValueError("this task's reward()/termination() are Python overrides judged on the host after the kernel: the "
+                                 "kernel-written record would carry the device's built-in verdict.  Pack obs / reward / done after "
+                                 "step() instead (sharding.RecordGatherer.start(obs, reward, done))")
             if tuple(record.shape) != (self.num_envs, self.obs_dim + 2) or record.dtype != self._torch.float32 or not record.is_contiguous() \
                     or record.device != self.device:
                 raise ValueError(f"record must be a contiguous float32 tensor of shape {(self.num_envs, self.obs_dim + 2)} on {self.device}")
@@ -149,10 +206,37 @@ class VecMazeEnv:
             pass
 
     # -- API ---------------------------------------------------------------
+    def get_ori(self):
+        return self.wrapped_env.get_ori()  # maze_env.py:231-232
+
+    def set_goals(self, goals=None) -> None:
+        """Upload the task's goal list (default: `self._task.goals`) to the device: position, threshold, reward scale and
+        dimension of every MazeGoal replace the table the step kernel's predicate reads (mz_set_goals).  The counterpart of
+        the reference's `set_marker()` after `sample_goals()` (maze_env.py:374-376, 384-387)."""
+        goals = self._task.goals if goals is None else goals
+        n = len(goals)
+        if n > 8:
+            raise ValueError("too many goals (MZ_MAX_GOAL = 8)")
+        pos = np.zeros((max(n, 1), 3), np.float64)
+        for i, g in enumerate(goals):
+            pos[i, : g.dim] = np.asarray(g.pos, np.float64)[: g.dim]
+        thr = np.array([g.threshold for g in goals] or [0.0], np.float64)
+        rs = np.array([g.reward_scale for g in goals] or [0.0], np.float64)
+        dim = np.array([g.dim for g in goals] or [2], np.int32)
+        rc = self._lib.mz_set_goals(self._h, n, pos.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p),
+                                    rs.ctypes.data_as(C.c_void_p), dim.ctypes.data_as(C.c_void_p), self._stream())
+        _capi.check(self._lib, self._h, rc, "mz_set_goals")
+
     def reset(self, mask=None, seed: Optional[int] = None):
-        """Reset all (or the masked) envs; returns the observation tensor [N, obs_dim] on the GPU."""
+        """Reset all (or the masked) envs; returns the observation tensor [N, obs_dim] on the GPU.
+
+        A full reset (mask None) first asks the task for new goals — `MazeTask.sample_goals()`, maze_env.py:374-376 — and
+        re-uploads the goal table when it says they changed.  The batch shares ONE goal table (the reference has one task
+        object per env), so a masked reset of some envs leaves the goals of the others alone: it does not resample."""
         if seed is not None:
             self._seed = int(seed)
+        if mask is None and self._task.sample_goals():
+            self.set_goals()
         mk = None
         if mask is not None:
             mk = self._torch.as_tensor(mask, device=self.device).to(self._torch.uint8).contiguous()
@@ -326,6 +410,7 @@ class MazeEnv:
                               inner_reward_scaling=inner_reward_scaling, restitution_coef=restitution_coef,
                               task_kwargs=task_kwargs, **kwargs)
         self._task = self.vec._task
+        self.wrapped_env = WrappedRobot(self.vec, model_cls, single=True)
         self.t = 0
         self.action_space = self.vec.action_space
         self.observation_space = self.vec.observation_space
@@ -348,6 +433,9 @@ class MazeEnv:
     @property
     def _observe_balls(self) -> bool:
         return self._task.OBSERVE_BALLS
+
+    def get_ori(self) -> float:
+        return self.wrapped_env.get_ori()  # maze_env.py:231-232
 
     def reset(self, **kwargs):
         self.t = 0

@@ -105,9 +105,9 @@ static int goal_neighbor(const mz_model* m, int g, const double* slot) {
 void mzo_task_eval(const mz_model* m, const double* obs, double* reward, int* done, int* goal_idx) {
   const double* rslot = m->reward_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
   const double* tslot = m->term_slot == MZ_SLOT_OBJECT ? obs + 3 : obs;
-  int term = 0, first = -1;
+  int term = 0, first = -1, first_t = -1;
   for (int g = 0; g < m->ngoal; g++)
-    if (goal_neighbor(m, g, tslot)) { term = 1; break; }
+    if (goal_neighbor(m, g, tslot)) { term = 1; first_t = g; break; }
   for (int g = 0; g < m->ngoal; g++)
     if (goal_neighbor(m, g, rslot)) { first = g; break; }
   double r = 0.0;
@@ -121,7 +121,9 @@ void mzo_task_eval(const mz_model* m, const double* obs, double* reward, int* do
   }
   *reward = r;
   *done = term;
-  *goal_idx = first;
+  /* the goal that set the reward where the reward is a goal's; otherwise (zero / distance rewards) the first goal that
+     terminates, on the slot termination() looks at */
+  *goal_idx = m->reward_kind == MZ_REWARD_FIRST_MATCH ? first : first_t;
 }
 
 /* ---------------------------------------------------------------- top-down view (maze_env.py:262-349) */

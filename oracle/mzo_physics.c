@@ -360,10 +360,13 @@ void mzo_fluid_passive(const mz_model* m, mzo_data* d) {
   for (int b = 1; b < m->nbody; b++) {
     double mass = m->body_mass[b];
     if (mass < MINVAL) continue;
-    const double* I6 = m->body_inertia[b];
-    /* the robots here have principal body inertias aligned with the body frame
-       up to a rotation about z; use the diagonal (exact for the swimmer's capsules along x) */
-    double I[3] = {I6[0], I6[1], I6[2]};
+    /* principal moments in the inertial frame ximat = xmat * R(body_iquat), as MuJoCo (mjModel.body_inertia / body_iquat):
+       the diagonal of the body-frame tensor is something else for a tilted link */
+    const double* I = m->body_pinertia[b];
+    double Ri[9], xim[9];
+    quat_to_mat(Ri, m->body_iquat[b]);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) xim[3 * i + j] = d->xmat[b][3 * i] * Ri[j] + d->xmat[b][3 * i + 1] * Ri[3 + j] + d->xmat[b][3 * i + 2] * Ri[6 + j];
     double bx[3];
     bx[0] = sqrt(fmax(MINVAL, (I[1] + I[2] - I[0])) / mass * 6.0);
     bx[1] = sqrt(fmax(MINVAL, (I[0] + I[2] - I[1])) / mass * 6.0);
@@ -373,8 +376,8 @@ void mzo_fluid_passive(const mz_model* m, mzo_data* d) {
     sub3(r, d->xipos[b], c);
     cross3(wr, w, r);
     vc[0] = d->cvel[b][3] + wr[0]; vc[1] = d->cvel[b][4] + wr[1]; vc[2] = d->cvel[b][5] + wr[2];
-    mulmat3Tvec(lw, d->xmat[b], w);
-    mulmat3Tvec(lv, d->xmat[b], vc);
+    mulmat3Tvec(lw, xim, w);
+    mulmat3Tvec(lv, xim, vc);
     double lf[3] = {0, 0, 0}, lt[3] = {0, 0, 0};
     if (m->viscosity > 0.0) {
       double diam = (bx[0] + bx[1] + bx[2]) / 3.0;
@@ -391,8 +394,8 @@ void mzo_fluid_passive(const mz_model* m, mzo_data* d) {
       lt[2] -= m->density * bx[2] * (pow(bx[0], 4) + pow(bx[1], 4)) * fabs(lw[2]) * lw[2] / 64.0;
     }
     double f[3], t[3], fsp[6], rf[3];
-    mulmat3vec(f, d->xmat[b], lf);
-    mulmat3vec(t, d->xmat[b], lt);
+    mulmat3vec(f, xim, lf);
+    mulmat3vec(t, xim, lt);
     /* wrench at c: torque about c = t + r x f */
     cross3(rf, r, f);
     fsp[0] = t[0] + rf[0]; fsp[1] = t[1] + rf[1]; fsp[2] = t[2] + rf[2];

@@ -123,3 +123,87 @@ def test_host_judged_task_with_auto_reset(model_cls):
     want_r = np.array([task.reward(x) for x in last]) + inner
     assert np.allclose(rew.cpu().numpy(), want_r, atol=1e-5)
     env.close()
+
+
+class MovingGoalCross(InheritedRewardCross):
+    """A task that resamples its goal on every reset (MazeTask.sample_goals, maze_task.py:66-67; MazeEnv.reset acts on its
+    return value, maze_env.py:374-376): the goal alternates between the east arm and the north arm of the cross."""
+
+    def __init__(self, scale: float) -> None:
+        super().__init__(scale)
+        self._k = 0
+
+    def sample_goals(self) -> bool:
+        self._k += 1
+        east, north = np.array([2.0 * self.scale, 0.0]), np.array([2.0 * self.scale, -1.0 * self.scale])
+        self.goals = [MazeGoal(east if self._k % 2 else north, threshold=0.8)]
+        return True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_cls", [mm.PointEnv, mm.AntEnv, mm.SwimmerEnv])
+def test_resampled_goals_reach_the_device(model_cls):
+    """reset() asks the task for new goals and re-uploads the goal table (mz_set_goals): termination / reward of the kernel's
+    own predicate follow the NEW goal, threshold included."""
+    import torch
+
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+
+    n, scale = 32, 4.0
+    env = VecMazeEnv(model_cls, MovingGoalCross, maze_size_scaling=scale, num_envs=n, inner_reward_scaling=0.0)
+    assert not env._host_rewards  # the stock reward: judged inside the kernel
+    zero = torch.zeros((n, env.nu), device=env.device)
+    for episode in range(3):
+        env.reset(seed=episode)
+        goal = env._task.goals[0]
+        assert np.allclose(goal.pos, [8.0, 0.0] if episode % 2 == 0 else [8.0, -4.0])
+        other = np.array([8.0, -4.0] if episode % 2 == 0 else [8.0, 0.0])
+        qpos = env.get_state()[0]
+        qpos[: n // 4, 0], qpos[: n // 4, 1] = float(goal.pos[0]) - 0.7, float(goal.pos[1])   # inside 0.8, outside the default 0.6
+        qpos[n // 4: n // 2, 0], qpos[n // 4: n // 2, 1] = float(other[0]) - 0.1, float(other[1])  # at the goal of the OTHER episodes
+        env.set_state(qpos=qpos)
+        obs, rew, done, info = env.step(zero)
+        o = obs.double().cpu().numpy()
+        want = np.array([env._task.termination(x) for x in o])
+        got = (done.cpu().numpy() & 1).astype(bool)
+        assert np.array_equal(got, want), episode
+        assert want[: n // 4].all() and not want[n // 4:].any()
+        assert np.allclose(rew.cpu().numpy(), np.where(want, 1.0, env._task.PENALTY), atol=1e-7)
+        assert np.array_equal(info["goal_index"].cpu().numpy(), np.where(want, 0, -1))
+        # the parity-test entry evaluates the same table
+        r2, d2, g2 = env.debug_task_eval(obs)
+        assert np.array_equal(d2.cpu().numpy().astype(bool), want)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_set_goals_argument_checks_and_goal_free_tasks():
+    from mujoco_maze_amd import _capi
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+
+    env = VecMazeEnv(mm.PointEnv, InheritedRewardCross, maze_size_scaling=4.0, num_envs=8)
+    with pytest.raises(ValueError):
+        env.set_goals([MazeGoal(np.zeros(2))] * 9)
+    env.set_goals([])  # a task without goals never terminates (Corridor-v2: maze_task.py:483-503)
+    import torch
+    env.reset(seed=0)
+    obs, rew, done, info = env.step(torch.zeros((8, 2), device=env.device))
+    assert not done.cpu().numpy().any()
+    env.set_goals([MazeGoal(np.array([0.0, 0.0]), threshold=5.0), MazeGoal(np.array([0.0, 0.0, 0.0]), reward_scale=0.5)])
+    obs, rew, done, info = env.step(torch.zeros((8, 2), device=env.device))
+    assert (done.cpu().numpy() & 1).all() and (info["goal_index"].cpu().numpy() == 0).all()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_record_binding_is_refused_for_host_judged_tasks():
+    import torch
+
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+
+    env = VecMazeEnv(mm.PointEnv, GoalRewardCross, maze_size_scaling=4.0, num_envs=8)
+    assert env._host_rewards
+    with pytest.raises(ValueError, match="host"):
+        env.bind_record(torch.zeros((8, env.obs_dim + 2), device=env.device))
+    env.bind_record(None)
+    env.close()

@@ -54,3 +54,86 @@ def test_generic_kernel_logic_matches_the_oracle(oracle, name, xml, fs, reset, a
         oracle.step(cm, st, act.astype(np.float64), nthreads=4)
     if name == "biped":
         assert ncon_seen > 100  # floor and wall contacts really occur
+
+
+def test_inertial_frames_follow_mujocos_convention():
+    """the inertia-box fluid model works in the body's INERTIAL frame with its principal moments
+    (mjModel.body_inertia / body_iquat), not on the diagonal of the body-frame tensor.  A one-geom body inherits the geom's
+    frame (a tilted capsule: its fromto frame, axial moment last); a several-geom body is diagonalised, moments decreasing."""
+    cm = _compile(user_robots.BRANCHING_SWIMMER, T.DistRewardUMaze, 4.0, 4, "uniform_sym")
+    m = cm.c
+    for b in range(1, m.nbody):
+        I6, p, q = np.array(m.body_inertia[b]), np.array(m.body_pinertia[b]), np.array(m.body_iquat[b])
+        full = np.array([[I6[0], I6[3], I6[4]], [I6[3], I6[1], I6[5]], [I6[4], I6[5], I6[2]]])
+        Rm = model.quat_to_mat(q)
+        assert abs(np.linalg.norm(q) - 1.0) < 1e-12 and np.allclose(Rm @ np.diag(p) @ Rm.T, full, atol=1e-12 * np.abs(full).max())
+        assert abs(p[0] - p[1]) < 1e-12 * p[0] and p[2] < 0.2 * p[0]  # every link is ONE capsule: lateral, lateral, axial
+        assert np.allclose(Rm[:, 2] * np.sign(Rm[:, 2] @ Rm[:, 2]), Rm[:, 2])
+    # the tilted tails (fromto 0 0 0 -> -0.7 +-0.4 0): off-diagonal body-frame tensor, axis = local z of the inertial frame
+    for b, sy in ((3, -1.0), (4, 1.0)):
+        assert abs(m.body_inertia[b][3]) > 0.3 * m.body_inertia[b][0]
+        axis = model.quat_to_mat(np.array(m.body_iquat[b]))[:, 2]
+        assert np.allclose(axis, np.array([0.7, sy * 0.4, 0.0]) / np.hypot(0.7, 0.4), atol=1e-12)  # from - to, normalised
+    # several geoms on one body whose summed tensor is not diagonal: eigen-decomposition, decreasing moments, proper rotation
+    I = np.array([[2.0, 0.6, 0.0], [0.6, 1.0, 0.1], [0.0, 0.1, 3.0]])
+    q, p = model.principal_frame(I, [(None, None), (None, None)])
+    Rm = model.quat_to_mat(q)
+    assert p[0] >= p[1] >= p[2] and abs(np.linalg.det(Rm) - 1.0) < 1e-12 and np.allclose(Rm @ np.diag(p) @ Rm.T, I, atol=1e-12)
+    # the built-in robots' bodies keep a frame in which the old diagonal reading was exact (swimmer links lie on x)
+    sw = model.compile_model("swimmer", T.DistRewardUMaze(4.0), 4.0).c
+    for b in range(1, sw.nbody):
+        box_old = np.sort(np.array([sw.body_inertia[b][k] for k in range(3)]))
+        assert np.allclose(np.sort(np.array(sw.body_pinertia[b])), box_old, rtol=1e-12)
+
+
+def test_fluid_forces_of_a_tilted_link(oracle):
+    """The same physical link written two ways — a capsule tilted inside an unrotated body vs. the same capsule along the
+    body's x axis with the tilt put into the joint angle.  What MuJoCo's inertia-box model guarantees for the pair: the
+    viscous (linear, isotropic) part is identical, and so is the quadratic part for motion along the link's axis.  (With the
+    diagonal of the body-frame tensor the tilted form got the box of a much fatter body: both checks failed.)  The
+    quadratic drag of LATERAL motion is not compared: it is evaluated per axis of the inertial frame, a capsule's two
+    lateral axes are degenerate, and MuJoCo takes them from the geom's fromto frame — for a link tilted inside the plane they
+    are not (in-plane normal, z), an artefact this restatement keeps.  Checked on the oracle's forward dynamics; the
+    generic kernel shares the arithmetic (tests above / test_gpu_parity)."""
+    tmpl = """
+<mujoco model="one_link">
+  <compiler angle="degree" coordinate="local" inertiafromgeom="true"/>
+  <option integrator="RK4" timestep="0.01" density="{rho}" viscosity="{mu}" collision="predefined"/>
+  <default><geom conaffinity="1" condim="1" contype="1" density="1000"/><joint armature="0.1"/></default>
+  <worldbody>
+    <geom name="floor" type="plane" size="40 40 0.1" pos="0 0 -0.1" condim="3"/>
+    <body name="torso" pos="0 0 0">
+      <geom name="g" type="capsule" size="0.1" fromto="{ft}"/>
+      <joint name="slider1" type="slide" axis="1 0 0" pos="0 0 0"/>
+      <joint name="slider2" type="slide" axis="0 1 0" pos="0 0 0"/>
+      <joint name="rot" type="hinge" axis="0 0 1" pos="0 0 0"/>
+      <body name="tip" pos="{tip}">
+        <geom name="g2" type="capsule" size="0.05" fromto="0 0 0 {tipft}"/>
+        <joint name="rot2" type="hinge" axis="0 0 1" pos="0 0 0" limited="true" range="-100 100"/>
+      </body>
+    </body>
+  </worldbody>
+  <actuator><motor joint="rot2" gear="10" ctrllimited="true" ctrlrange="-1 1"/></actuator>
+</mujoco>"""
+    ang = np.deg2rad(35.0)
+    c, s = np.cos(ang), np.sin(ang)
+    forms = dict(straight=dict(ft="0 0 0 1 0 0", tip="1 0 0", tipft="0.5 0 0"),
+                 tilted=dict(ft=f"0 0 0 {c:.17g} {s:.17g} 0", tip=f"{c:.17g} {s:.17g} 0", tipft=f"{0.5 * c:.17g} {0.5 * s:.17g} 0"))
+    rng = np.random.default_rng(4)
+    # (1) viscosity only: any state
+    cs, ct = (_compile(tmpl.format(rho=0, mu=0.5, **forms[k]), T.DistRewardUMaze, 4.0, 4, "uniform_sym") for k in ("straight", "tilted"))
+    for _ in range(8):
+        q_t = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5)])
+        q_s = q_t + np.array([0.0, 0.0, ang, 0.0])  # the straight form carries the tilt in its root angle
+        v = rng.uniform(-2, 2, 4)
+        a_s, a_t = oracle.forward(cs, q_s, v)["qacc"][0], oracle.forward(ct, q_t, v)["qacc"][0]
+        assert np.allclose(a_s, a_t, rtol=1e-9, atol=1e-9), (a_s, a_t)
+    # (2) quadratic drag, both links moving along their common axis
+    cs, ct = (_compile(tmpl.format(rho=4000, mu=0, **forms[k]), T.DistRewardUMaze, 4.0, 4, "uniform_sym") for k in ("straight", "tilted"))
+    for _ in range(4):
+        th, sp = rng.uniform(-1, 1), rng.uniform(0.5, 2.0)
+        q_t = np.array([0.3, -0.2, th, 0.0])
+        q_s = q_t + np.array([0.0, 0.0, ang, 0.0])
+        v = np.array([sp * np.cos(th + ang), sp * np.sin(th + ang), 0.0, 0.0])
+        a_s, a_t = oracle.forward(cs, q_s, v)["qacc"][0], oracle.forward(ct, q_t, v)["qacc"][0]
+        assert np.allclose(a_s, a_t, rtol=1e-9, atol=1e-9) and np.abs(a_s[:2]).max() > 1e-3, (a_s, a_t)

@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 DET = np.load(os.path.join(G, "detect.npz"))
 REW = np.load(os.path.join(G, "reward.npz"))
+REW_F32 = np.load(os.path.join(G, "reward_f32.npz"))  # the reference's verdicts on float64(fp32(observations)): make_golden_r04.py
 REW_META = json.load(open(os.path.join(G, "reward_meta.json")))
 KAT = json.load(open(os.path.join(G, "line_kat.json")))
 
@@ -93,11 +94,13 @@ def _robots_for(cls, scale):
 
 @pytest.mark.parametrize("tag", sorted(REW_META))
 def test_all_golden_observations_through_the_hip_task_eval(torch, tag):
-    """All 400 golden observations of every task (50 tasks x the scales they are registered with = 30 000 rows), rounded to
-    fp32 — what the kernels observe — through the device predicate of EVERY robot family the task is registered for (the
-    Ant kernels are built with relaxed floating-point flags, the Point / Swimmer ones strictly).  Expected values: the
-    golden-pinned Python mirror on the same rounded observations, in float64.  Rows 390 / 391 sit exactly on the threshold
-    circle of the agent / object slot."""
+    """All 400 golden observations of every task (50 tasks x the scales they are registered with), rounded to fp32 — what
+    the kernels observe — through the device predicate of EVERY robot family the task is registered for (the Ant kernels are
+    built with relaxed floating-point flags, the Point / Swimmer ones strictly).  Expected values: what the REFERENCE's own
+    `task.reward()` / `task.termination()` / `MazeGoal.neighbor()` returned on float64(those fp32 observations) —
+    tests/golden/reward_f32.npz, written by make_golden_r04.py from the imported reference (maze_task.py:43-47,77-81,110-111,
+    403-407,592-604,646-658); this repository's Python mirror is not in the loop.  Rows 390 / 391 sit exactly on the
+    threshold circle of the agent / object slot."""
     from mujoco_maze_amd import model as M
     from mujoco_maze_amd.agent_model import ROBOT_CLASSES
 
@@ -105,12 +108,11 @@ def test_all_golden_observations_through_the_hip_task_eval(torch, tag):
     cls, scale = getattr(T, meta["task"]), meta["scale"]
     task = cls(scale)
     obs32 = REW[f"{tag}__obs"].astype(np.float32)
-    obs = obs32.astype(np.float64)
-    exp_r = np.array([task.reward(o) for o in obs]).astype(np.float32)
-    exp_t = np.array([bool(task.termination(o)) for o in obs])
+    ref_r64 = REW_F32[f"{tag}__reward"]
+    exp_r = ref_r64.astype(np.float32)
+    exp_t = REW_F32[f"{tag}__term"].astype(bool)
+    exp_g = REW_F32[f"{tag}__goal"]
     desc = T.device_reward_descriptor(task)
-    slot = obs[:, 3:6] if desc[1] == T.SLOT_OBJECT else obs[:, :3]
-    exp_g = np.array([next((i for i, g in enumerate(task.goals) if np.linalg.norm(s[: g.dim] - g.pos) <= g.threshold), -1) for s in slot])
     ran = 0
     for robot in _robots_for(cls, scale):
         from mujoco_maze_amd.maze_env import VecMazeEnv

@@ -80,7 +80,7 @@ def test_native_library_is_the_in_tree_one(torch):
     assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
     from mujoco_maze_amd.model import MZ_ABI_VERSION
 
-    assert lib.mz_abi_version() == MZ_ABI_VERSION == 6
+    assert lib.mz_abi_version() == MZ_ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("env_id", ["Ant4Rooms-v0", "AntPush-v0", "PointUMaze-v0", "SwimmerUMaze-v0", "PointSquareRoom-v0"])
@@ -1026,3 +1026,75 @@ def test_user_robot_of_another_topology_on_the_device(torch, oracle, which):
     o2, r, d, inf = single.step(single.action_space.sample(np.random.default_rng(0)))
     assert o.shape == (cm.c.obs_dim,) and o2.shape == o.shape and isinstance(r, float)
     single.close()
+
+
+@pytest.mark.parametrize("env_id", ["PointUMaze-v0", "AntUMaze-v0", "AntPush-v0", "SwimmerUMaze-v0"])
+def test_wrapped_env_get_xy_set_xy_get_ori(env_id):
+    """`env.wrapped_env.get_xy() / set_xy(xy) / get_ori()` (agent_model.py:35-41, ant.py:98-111, point.py:83-92, maze_env.py:218,232)
+    over mz_get_state / mz_set_state: set_xy moves qpos[:2] and nothing else; get_ori is the Point's angle / the heading of
+    the Ant's torso x axis."""
+    import torch
+
+    n = 16
+    env = mm.make(env_id, num_envs=n)
+    env.reset(seed=5)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        env.step(torch.as_tensor(rng.uniform(env.action_space.low, env.action_space.high, (n, env.nu)).astype(np.float32), device=env.device))
+    qpos0, qvel0, warm0, t0 = [x.clone() for x in env.get_state()]
+    w = env.wrapped_env
+    assert w.ORI_IND == env.wrapped_cls.ORI_IND and w.FILE == env.wrapped_cls.FILE  # class knobs read through
+    xy = w.get_xy()
+    assert torch.equal(xy, qpos0[:, :2]) and xy.data_ptr() != qpos0.data_ptr()
+    new = xy + torch.as_tensor(rng.uniform(-0.3, 0.3, (n, 2)).astype(np.float32), device=env.device)
+    w.set_xy(new)
+    qpos1, qvel1, warm1, t1 = env.get_state()
+    assert torch.equal(qpos1[:, :2], new) and torch.equal(qpos1[:, 2:], qpos0[:, 2:])
+    assert torch.equal(qvel1, qvel0) and torch.equal(warm1, warm0) and torch.equal(t1, t0)
+    assert torch.equal(w.get_xy(), new)
+    w.set_xy(new.cpu().numpy())  # numpy in, like the reference
+    assert torch.equal(w.get_xy(), new)
+    if env_id.startswith("Swimmer"):
+        with pytest.raises(AttributeError):
+            w.get_ori()
+    else:
+        ori = env.get_ori().cpu().numpy()
+        q = qpos1.double().cpu().numpy()
+        if env_id.startswith("Point"):
+            want = q[:, 2]
+        else:  # ant.py:26-35,98-103 written with explicit quaternion products
+            def qmul(a, b):
+                return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                                 a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3], a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+            want = []
+            for r in q[:, 3:7]:
+                o = qmul(qmul(r, [0, 1, 0, 0]), [r[0], -r[1], -r[2], -r[3]])[1:3]
+                want.append(np.arctan2(o[1], o[0]))
+            want = np.array(want)
+        assert np.allclose(ori, want, atol=1e-12)
+    env.close()
+
+
+def test_single_env_facade_wrapped_env():
+    env = mm.make("PointUMaze-v0")
+    env.reset(seed=0)
+    xy = env.wrapped_env.get_xy()
+    assert isinstance(xy, np.ndarray) and xy.shape == (2,) and xy.dtype == np.float64
+    env.wrapped_env.set_xy(np.array([1.5, -0.25]))
+    assert np.array_equal(env.wrapped_env.get_xy(), [1.5, -0.25])
+    assert isinstance(env.get_ori(), float)
+    obs, r, d, info = env.step(np.zeros(2))
+    assert abs(obs[0] - 1.5) < 0.2
+    env.close()
+
+
+def test_ant_only_options_are_refused_for_other_robots():
+    """solver / diagnostic keys that only the Ant kernels read must not be accepted silently elsewhere."""
+    from mujoco_maze_amd import _capi
+
+    env = mm.make("PointUMaze-v0", num_envs=4)
+    for key in ("solver_iterations", "solver_tolerance", "ls_iterations", "debug_frame_skip", "waves_per_block"):
+        with pytest.raises(_capi.MazeStepError, match="Ant"):
+            env.set_option(key, 1)
+    env.set_option("lanes_per_env", 32)
+    env.close()
