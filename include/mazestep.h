@@ -333,6 +333,9 @@ int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host);
 /* Same instrumented build: total shader cycles of every workgroup (one wavefront = 64 / lanes_per_env envs) accumulated
  * since the last call, n_host <= num_envs entries into HOST memory; cleared on read.  For load-balance analysis. */
 int32_t mz_read_wave_cycles(mz_handle* h, uint64_t* out_host, int32_t n_host);
+/* Same build: the 16 phase slots of every workgroup ([n_host][16] into HOST memory, accumulated since the last call, cleared on
+ * read) — which phase makes the slowest waves slow (Ant kernels). */
+int32_t mz_read_wave_phase_cycles(mz_handle* h, uint64_t* out_host, int32_t n_host);
 
 /* Average duration (ms) of the step kernel over the launches recorded since "time_kernels" was set (HIP events on
  * the stream each mz_step was given; synchronises on them); returns < 0 if not available. */

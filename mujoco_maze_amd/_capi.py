@@ -20,7 +20,7 @@ SYMBOLS = [
     "mz_abi_version", "mz_model_sizeof", "mz_create", "mz_destroy", "mz_last_error", "mz_num_envs", "mz_obs_dim", "mz_nq",
     "mz_nv", "mz_nu", "mz_set_option", "mz_reset", "mz_set_state", "mz_get_state", "mz_step", "mz_get_status",
     "mz_debug_forward", "mz_last_kernel_ms", "mz_read_phase_cycles", "mz_bind_final_obs", "mz_debug_task_eval", "mz_debug_detect", "mz_read_wave_cycles", "mz_bind_record",
-    "mz_set_goals",
+    "mz_set_goals", "mz_read_wave_phase_cycles",
 ]
 
 _lib = None
@@ -88,6 +88,8 @@ def load():
     lib.mz_read_phase_cycles.argtypes = [vp, vp]
     lib.mz_read_wave_cycles.restype = i32
     lib.mz_read_wave_cycles.argtypes = [vp, vp, i32]
+    lib.mz_read_wave_phase_cycles.restype = i32
+    lib.mz_read_wave_phase_cycles.argtypes = [vp, vp, i32]
     lib.mz_last_kernel_ms.restype = C.c_double
     lib.mz_last_kernel_ms.argtypes = [vp]
     if lib.mz_model_sizeof() != C.sizeof(MzModel):

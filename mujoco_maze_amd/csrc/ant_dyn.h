@@ -84,10 +84,16 @@ struct AntDims {
   static constexpr int NGEOM = 13 + NMOV;  // contact enumerators: movable bodies first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;
+  // coordinates carried as hi + lo pairs INSIDE a step (AntScratchT::qlo): the torso's x, y and the movable bodies' translations —
+  // the absolute positions, metres from the origin, that enter contact distances by subtraction (lo index: 0, 1, then 2 + k)
+  static constexpr int NLO = 2 + (BALL ? 3 : BD * NBLK);
   static constexpr int REC_T = NQ + 2 * NV;              // state record: qpos | qvel | warm | t | episode
   static constexpr int REC = (REC_T + 2 + 15) / 16 * 16;
 };
 MZ_HD int hub2dof(int h) { return h < 6 ? h : h + 8; }
+// position of root dof k (0..5) / of a movable block's slide (14, 15) in the dense copy Md of the mass matrix, which is kept in the
+// row solver's position order (rows::dof2pos, ant_newton_rows.h): the root's dofs sit on lanes 2 3 | 6 7 | 10 11 of the 16-lane row
+MZ_HD int md_root_pos(int k) { return k < 6 ? 4 * (k >> 1) + 2 + (k & 1) : k; }
 
 // ------------------------------------------------------------------ scratch (LDS) per env
 template <int NH>
@@ -110,6 +116,13 @@ struct alignas(16) AntScratchT {
   // step-persistent
   float qpos[D::NQ + 1], qvel[D::NV], x0q[D::NQ + 1], x0v[D::NV], accv[D::NV], accf[D::NV], warm[D::NV], fact[D::NV];
   float qacc[D::NV], qas[D::NV], qfs[D::NV];
+  // Low-order parts of the absolute positions (AntDims::NLO) within the step: qpos[i] + qlo[..] is the coordinate to ~1e-14.  The
+  // state that enters and leaves a step is fp32; between its 20 forward evaluations a coordinate of ~10 m rounded to fp32 is off by
+  // up to 5e-7, which a contact row turns into K * 5e-7 * h = 1e-5 of velocity (K ~ 2500-3900 /s^2 for these solref values) — the
+  // whole 1e-5 budget, for any contact whose distance is a difference of such coordinates (robot vs wall, block vs wall, robot
+  // vs block; measured: AntPush 99.9 % quantile 1.1e-5, round 3).  RK4's position updates are therefore formed in float64 and
+  // split (ant_integrate_pos), and the contact code subtracts hi parts first, lo parts after.
+  float qlo[D::NLO], x0lo[D::NLO];
   // kinematics (positions relative to the torso origin c)
   float R0[9], cz;               // torso rotation (row-major), torso height
   int nearwall;                  // 0: no maze wall within the ant's reach of the torso (wall tests skipped)
@@ -204,6 +217,31 @@ MZ_HD void mat_vecf(float* r, const float* m, const float* v) {
         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
+MZ_HD PairDev pair_copy(const PairDev& p) {  // (field by field: plain scalar loads, no address arithmetic on a selected pointer)
+  PairDev r;
+  r.margin = p.margin; r.mu = p.mu; r.K = p.K; r.B = p.B;
+  for (int k = 0; k < 7; k++) r.solimp[k] = p.solimp[k];
+  return r;
+}
+// Impedance d(x) AND its complement 1 - d, which the regulariser R = (1 - d) / d * diagApprox needs.  With the solimp of the block
+// mazes (.995 .995: maze_env.py:108-112) the fp32 expression `1.f - imp` is 0.005 with the rounding error of 0.995 in it — 6e-6
+// relative, which the stiff rows turn into the 1e-5 tail of AntPush's torso rates (round 3: 99.9 % quantile 1.1e-5, whatever the solver
+// tolerance).  si[5], si[6] hold 1 - d0 and 1 - dmax rounded from float64 (ant_model.h pair_from); 1 - d follows from them
+// without cancellation: 1 - d = (1 - d0) - y (dmax - d0).
+MZ_HD float impedance_pair(const float* si, float x, float* one_minus) {
+  const float d0 = si[0], dmax = si[1], width = si[2], mid = si[3], power = si[4], od0 = si[5], odm = si[6];
+  if (d0 == dmax || width <= 1e-15f) { *one_minus = 0.5f * (od0 + odm); return 0.5f * (d0 + dmax); }
+  const float xn = x / width;
+  if (xn >= 1.0f) { *one_minus = odm; return dmax; }
+  if (xn <= 0.0f) { *one_minus = od0; return d0; }
+  float y;
+  if (power <= 1.0f) y = xn;
+  else if (power == 2.0f) y = xn <= mid ? xn * xn / mid : 1.0f - (1.0f - xn) * (1.0f - xn) / (1.0f - mid);  // MuJoCo default
+  else if (xn <= mid) y = powf(xn, power) / powf(mid, power - 1.0f);
+  else y = 1.0f - powf(1.0f - xn, power) / powf(1.0f - mid, power - 1.0f);
+  *one_minus = od0 - y * (od0 - odm);
+  return d0 + y * (dmax - d0);
+}
 MZ_HD float impedancef(const float* si, float x) {
   float d0 = si[0], dmax = si[1], width = si[2], mid = si[3], power = si[4];
   if (d0 == dmax || width <= 1e-15f) return 0.5f * (d0 + dmax);
@@ -287,7 +325,7 @@ MZ_HD void kin_item(const AntDev& K, AntScratchT<NB>& s, int l) {
         float R[9];
         quat_to_matf(R, s.qpos + 18);
         for (int k = 0; k < 9; k++) s.bR[k] = R[k];
-        s.bx[0] = s.qpos[15] - s.qpos[0]; s.bx[1] = s.qpos[16] - s.qpos[1]; s.bx[2] = s.qpos[17] - s.qpos[2];
+        s.bx[0] = (s.qpos[15] - s.qpos[0]) + (s.qlo[2] - s.qlo[0]); s.bx[1] = (s.qpos[16] - s.qpos[1]) + (s.qlo[3] - s.qlo[1]); s.bx[2] = (s.qpos[17] - s.qpos[2]) + s.qlo[4];
         for (int k = 0; k < 3; k++) s.bc[k] = s.bx[k] + R[3 * k + 2] * K.ball_h;  // sphere centre = origin + R (0, 0, h)
         return;
       }
@@ -371,13 +409,14 @@ MZ_HD void crb_leg_item(const AntDev& K, AntScratchT<NB>& s, int l) {
       s.M.rl[l][0][3 + k] = dot3f(ax, Fh);
       s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
     }
-    if constexpr (NB <= 1) {  // dense rows of the two leg dofs, and their columns in the root rows
-      const int ph = 6 + 2 * l, pa = 7 + 2 * l;
+    if constexpr (NB <= 1) {  // dense rows of the two leg dofs, and their columns in the root rows — in the row solver's POSITION order
+      const int ph = 4 * l, pa = 4 * l + 1;  // (rows::pos2dof, ant_newton_rows.h: leg l's hinges sit on lanes 4l, 4l + 1 of the row)
       s.Md[ph][ph] = s.M.ll[l][0]; s.Md[ph][pa] = s.M.ll[l][1]; s.Md[pa][ph] = s.M.ll[l][1]; s.Md[pa][pa] = s.M.ll[l][2];
       for (int k = 0; k < 6; k++) {
         const float vh = s.M.rl[l][0][k], va = s.M.rl[l][1][k];
-        s.Md[ph][k] = vh; s.Md[k][ph] = vh;
-        s.Md[pa][k] = va; s.Md[k][pa] = va;
+        const int pk = md_root_pos(k);
+        s.Md[ph][pk] = vh; s.Md[pk][ph] = vh;
+        s.Md[pa][pk] = va; s.Md[pk][pa] = va;
       }
     }
     for (int k = 6; k < NH; k++) { s.M.rl[l][0][k] = 0.f; s.M.rl[l][1][k] = 0.f; }  // blocks are separate trees
@@ -439,7 +478,7 @@ MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       }
     }
     s.M.rr[i][j] = val; s.M.rr[j][i] = val;
-    if constexpr (NB <= 1) { s.Md[i][j] = val; s.Md[j][i] = val; }
+    if constexpr (NB <= 1) { s.Md[md_root_pos(i)][md_root_pos(j)] = val; s.Md[md_root_pos(j)][md_root_pos(i)] = val; }
 }
 
 // Recursive Newton-Euler, outward half, one body per lane: body b = 0 torso, 1 + 3l + k (k = 0 welded leg, 1 aux, 2 ankle).
@@ -781,6 +820,7 @@ MZ_HD void capsule_box_search(const float* cl, const float* h, float hl, const f
     if (nout > 1) continue;
     if (dist < best) { best = dist; bt = (float)i; cltype = -2 + i; face = f; }
   }
+#pragma nounroll
   for (int i = 0; i < 8; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -857,7 +897,18 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
     clface = nout == 1 ? lastout : -1;
     cledge = inaxis; boxpos = pin;
     // the segment runs through the box with both ends outside: MuJoCo's answer is its search order's
-    if (nout == 0) { corner = 0; capsule_box_search(cl, h, hl, bs, &t, &type, &clface, &cledge, &corner, &boxpos); }
+    if (nout == 0) {
+      corner = 0;
+      float clb[3] = {cl[0], cl[1], cl[2]}, hb[3] = {h[0], h[1], h[2]};
+#if defined(__HIP_DEVICE_COMPILE__)
+      // Opaque copies made INSIDE the rare branch: everything the search computes then depends on them, so none of it can be
+      // hoisted in front of the branch.  (It was: the loop-invariant parts of the twelve-edge search — reciprocals of the 2 x 2
+      // determinants, the clamped candidates — ran for every geom that came near a wall, a few hundred instructions and a dozen
+      // spilled condition masks on the path of the slowest waves.)
+      asm volatile("" : "+v"(clb[0]), "+v"(clb[1]), "+v"(clb[2]), "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]));
+#endif
+      capsule_box_search(clb, hb, hl, bs, &t, &type, &clface, &cledge, &corner, &boxpos);
+    }
   }
   const float second = capsule_box_second(cl, h, bs, t, type, clface, cledge, corner, boxpos);
   for (int pass = 0; pass < 2; pass++) {
@@ -909,21 +960,22 @@ MZ_HD bool aligned_box_box(const double* c1, const double* h1, const double* c2,
 template <int NB>
 MZ_HD void block_center(const AntDev& K, const AntScratchT<NB>& s, int k, float* bc) {
   using D = AntDims<NB>;
-  float p0[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f};
+  float p0[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f}, ql[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
     if (j == k && j < D::NBLK) {
       p0[0] = K.block_pos0[j][0]; p0[1] = K.block_pos0[j][1]; p0[2] = K.block_pos0[j][2];
 #pragma unroll
-      for (int a = 0; a < D::BD; a++) q[a] = s.qpos[15 + D::BD * j + a];
+      for (int a = 0; a < D::BD; a++) { q[a] = s.qpos[15 + D::BD * j + a]; ql[a] = s.qlo[2 + D::BD * j + a]; }
     }
   // slide a runs along coordinate axis K.block_axis[a] (increasing): (x, y), (y, z) / (x, z) for falling blocks, (x, y, z)
-  float d[3] = {0.f, 0.f, 0.f};
+  float d[3] = {0.f, 0.f, 0.f}, dl[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < D::BD; a++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) d[c] += K.block_axis[a] == c ? q[a] : 0.f;
-  bc[0] = (p0[0] - s.qpos[0]) + d[0]; bc[1] = (p0[1] - s.qpos[1]) + d[1]; bc[2] = (p0[2] - s.cz) + d[2];
+    for (int c = 0; c < 3; c++) { d[c] += K.block_axis[a] == c ? q[a] : 0.f; dl[c] += K.block_axis[a] == c ? ql[a] : 0.f; }
+  // hi parts first (the large coordinates cancel), the low-order parts after (AntScratchT::qlo)
+  bc[0] = ((p0[0] - s.qpos[0]) + d[0]) + (dl[0] - s.qlo[0]); bc[1] = ((p0[1] - s.qpos[1]) + d[1]) + (dl[1] - s.qlo[1]); bc[2] = ((p0[2] - s.cz) + d[2]) + dl[2];
 }
 
 // Enumerate the contacts of enumerator e: e < NMOV -> part e % BSUB of movable block e / BSUB (floor corners | one grid cell |
@@ -950,7 +1002,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
           for (int c = 0; c < 3; c++) bwd[c] = K.d_block_pos0[j][c];
 #pragma unroll
           for (int a = 0; a < D::BD; a++)
-            for (int c = 0; c < 3; c++) if (K.block_axis[a] == c) bwd[c] += (double)s.qpos[15 + D::BD * j + a];
+            for (int c = 0; c < 3; c++) if (K.block_axis[a] == c) bwd[c] += (double)s.qpos[15 + D::BD * j + a] + (double)s.qlo[2 + D::BD * j + a];
         }
     }
     float bottom = (bc[2] + s.cz) - hb[2];  // absolute height of the bottom face
@@ -986,7 +1038,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         if (!aligned_box_box(cw, hw, bwd, K.d_block_half, K.d_wall_margin, bb)) continue;
         if (!(bb.dist < K.d_wall_margin)) continue;  // not active: no row (mj_instantiateContact)
         const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1;
-        const double org[3] = {(double)s.qpos[0], (double)s.qpos[1], (double)s.cz};  // torso origin: positions go back to torso-relative fp32
+        const double org[3] = {(double)s.qpos[0] + (double)s.qlo[0], (double)s.qpos[1] + (double)s.qlo[1], (double)s.cz};  // torso origin: positions go back to torso-relative fp32
         for (int iu = 0; iu < bb.nu; iu++)
           for (int iv = 0; iv < bb.nv; iv++) {
             cg.kind = 4; cg.blk = e; cg.other = 0; cg.dist = (float)bb.dist;
@@ -1011,14 +1063,14 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
             for (int c = 0; c < 3; c++) c1w[c] = K.d_block_pos0[j][c];
 #pragma unroll
             for (int a = 0; a < D::BD; a++)
-              for (int c = 0; c < 3; c++) if (K.block_axis[a] == c) c1w[c] += (double)s.qpos[15 + D::BD * j + a];
+              for (int c = 0; c < 3; c++) if (K.block_axis[a] == c) c1w[c] += (double)s.qpos[15 + D::BD * j + a] + (double)s.qlo[2 + D::BD * j + a];
           }
       }
       AlignedBB bb;
       if (!aligned_box_box(c1w, K.d_block_half, bwd, K.d_block_half, K.d_wall_margin, bb)) continue;
       if (!(bb.dist < K.d_wall_margin)) continue;
       const int ax = bb.ax, u = ax == 2 ? 0 : ax + 1;
-      const double org[3] = {(double)s.qpos[0], (double)s.qpos[1], (double)s.cz};
+      const double org[3] = {(double)s.qpos[0] + (double)s.qlo[0], (double)s.qpos[1] + (double)s.qlo[1], (double)s.cz};
       for (int iu = 0; iu < bb.nu; iu++)
         for (int iv = 0; iv < bb.nv; iv++) {
           cg.kind = 5; cg.blk = e; cg.other = k; cg.dist = (float)bb.dist;
@@ -1039,7 +1091,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
       for (int j = 0; j < (D::NBLK ? D::NBLK : 1); j++)
         if (j == e && j < D::NBLK) {
 #pragma unroll
-          for (int a = 0; a < D::BD; a++) qs[a] = s.qpos[15 + D::BD * j + a];
+          for (int a = 0; a < D::BD; a++) qs[a] = s.qpos[15 + D::BD * j + a];  // (limits sit within a cell of zero: the fp32 part is exact enough)
         }
 #pragma unroll
       for (int a = 0; a < D::BD; a++) {
@@ -1078,7 +1130,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         for (int j = j0; j <= j1; j++) {
           if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) continue;
           if (!((maze_row_lds(s, i) >> j) & 1u)) continue;
-          float wc[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], z.center_z - s.cz};
+          float wc[3] = {((j * z.scale - z.tx) - s.qpos[0]) - s.qlo[0], ((i * z.scale - z.ty) - s.qpos[1]) - s.qlo[1], z.center_z - s.cz};
           round_vs_box(true, s.bc, zero, 0.f, rb, wc, bs, K.ball_wall.margin, 8, 0, emit);
         }
       return;
@@ -1163,7 +1215,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         const float cz1 = layer ? z.center_z : z.half_z;
         if (gz - reach > cz1 + z.half_z || gz + reach < cz1 - z.half_z) continue;
         // box centre relative to the torso origin, computed so that the large world coordinates cancel first
-        float bc[3] = {(j * z.scale - z.tx) - s.qpos[0], (i * z.scale - z.ty) - s.qpos[1], cz1 - s.cz};
+        float bc[3] = {((j * z.scale - z.tx) - s.qpos[0]) - s.qlo[0], ((i * z.scale - z.ty) - s.qpos[1]) - s.qlo[1], cz1 - s.cz};
         // no point of the geom is farther than hl from its centre: a centre at least hl + r + margin away from the box cannot
         // give a contact (dist < margin) — skips the segment-box minimisation for cells that only the bounding square touches
         float d2 = 0.f;
@@ -1314,8 +1366,8 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
           if (k == blk && sl == other) { if (a == 0) J[6 + D::BD * k + sl] = sg; vel = sg * s.qvel[14 + D::BD * k + sl]; }
       float aref = 0.f;
       if (a == 0) {
-        float imp = impedancef(K.blim_solimp, fabsf(dist - K.blim_margin));
-        float R = fmaxf(1e-15f, (1.f - imp) / imp * K.blim_w);
+        float omi, imp = impedance_pair(K.blim_solimp, fabsf(dist - K.blim_margin), &omi);
+        float R = fmaxf(1e-15f, omi / imp * K.blim_w);
         s.cD[c] = 0.25f / R;
         aref = -K.blim_B * vel - K.blim_K * imp * (dist - K.blim_margin);
       }
@@ -1325,7 +1377,13 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     }
     // contact kinds: 0 floor -> robot geom, 1 robot geom -> wall box, 2 robot geom -> block, 3 floor -> block, 4 wall box -> block,
     // 5 block -> block, (6 block slide limit, above), 7 floor -> ball, 8 ball -> wall box, 9 torso -> ball, 10 ball -> leg capsule
-    const PairDev& P = kind == 7 ? K.ball_floor : (kind == 8 ? K.ball_wall : (kind >= 9 ? K.ball_robot : ((kind == 0 || kind == 3) ? K.floor : K.wall)));
+    // the pair's parameters by VALUE: every candidate set is read with scalar loads and the nine numbers are selected — a reference
+    // chosen by `kind` compiles to an address select followed by dependent vector-memory loads, per contact row and evaluation
+    PairDev P = (kind == 0 || kind == 3) ? pair_copy(K.floor) : pair_copy(K.wall);
+    if constexpr (D::BALL) {
+      const PairDev bf = pair_copy(K.ball_floor), bw = pair_copy(K.ball_wall), br = pair_copy(K.ball_robot);
+      P = kind == 7 ? bf : (kind == 8 ? bw : (kind >= 9 ? br : P));
+    }
     int leg = s.cleg[c], cls = s.ccls[c];
     float t1[3], t2[3], f[3];
     make_tangents(n, hint, t1, t2);
@@ -1364,10 +1422,10 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     if (leg >= 0) vel += J[NH] * s.qvel[6 + 2 * leg] + J[NH + 1] * s.qvel[7 + 2 * leg];
     float aref = -P.B * vel;
     if (a == 0) {
-      float imp = impedancef(P.solimp, fabsf(dist - P.margin));
+      float omi, imp = impedance_pair(P.solimp, fabsf(dist - P.margin), &omi);
       float tran = (cls >= 0 ? K.bw_tran[cls] : 0.f) + ((kind >= 2 && kind <= 5) ? K.block_bw_tran : 0.f) + (kind == 5 ? K.block_bw_tran : 0.f) +
                    (sball != 0.f ? K.ball_bw_tran : 0.f);
-      float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
+      float R = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
       s.cD[c] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
       aref -= P.K * imp * (dist - P.margin);
     }
@@ -1385,8 +1443,8 @@ MZ_HD void limit_item(const AntDev& K, AntScratchT<NB>& s, int j) {
     else if (hi - q < 0.f) { sg = -1.f; pos = hi - q; }
     float Dl = 0.f, aref = 0.f;
     if (sg != 0.f) {
-      float imp = impedancef(K.lim_solimp, fabsf(pos));
-      float R = fmaxf(1e-15f, (1.f - imp) / imp * ((j & 1) ? K.dofw_ank : K.dofw_hip));
+      float omi, imp = impedance_pair(K.lim_solimp, fabsf(pos), &omi);
+      float R = fmaxf(1e-15f, omi / imp * ((j & 1) ? K.dofw_ank : K.dofw_hip));
       Dl = 1.0f / R;
       aref = -K.lim_B * (sg * s.qvel[6 + j]) - K.lim_K * imp * pos;
     }
@@ -1635,6 +1693,12 @@ template <int NB, class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   using D = AntDims<NB>;
   constexpr int NH = D::NH, NV = D::NV, NG = D::NGEOM, NROOT = 15 + (NH - 6) * NH;
+  if constexpr (NB == 0 && C::row_solver) {
+    // the plain ant on the device at >= 16 lanes per env: the whole evaluation in the registers of the row's leg quads
+    // (ant_forward_rows.h) — no LDS hand-off before the contact rows
+    ant_forward_rows(cx, K, s, first);
+    return;
+  }
   cx.tick(s, 9);
   MZ_FOR(l, 5 + (D::BALL ? 1 : 0)) kin_item<NB>(K, s, l);
   cx.sync();
@@ -1722,23 +1786,31 @@ MZ_HD void quat_integratef(const float* base, const float* w, float h, float* ou
   for (int k = 0; k < 4; k++) out[k] = q[k];
 }
 
+// base + base_lo + h v in float64, split into the fp32 coordinate and its remainder
+MZ_HD void mz_step_split(float base, float base_lo, float h, float v, float* hi, float* lo) {
+  const double t = ((double)base + (double)base_lo) + (double)h * (double)v;
+  const float fh = (float)t;
+  *hi = fh; *lo = (float)(t - (double)fh);
+}
 template <int NB, class C>
 MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base, const float* vel, float h) {
   using D = AntDims<NB>;
   MZ_FOR(i, 12 + (D::BALL ? 4 : D::BD * D::NBLK)) {
-    if (i < 3) s.qpos[i] = base[i] + h * vel[i];
+    if (i < 2) mz_step_split(base[i], s.x0lo[i], h, vel[i], &s.qpos[i], &s.qlo[i]);
+    else if (i < 3) s.qpos[i] = base[i] + h * vel[i];
     else if (i == 3) {
       float w[3] = {vel[3], vel[4], vel[5]};
       quat_integratef(base + 3, w, h, s.qpos + 3);
     } else if (D::BALL && i >= 12) {  // the ball's free joint: qpos[15:18] += h v, quaternion qpos[18:22] on the manifold
-      if (i < 15) s.qpos[15 + (i - 12)] = base[15 + (i - 12)] + h * vel[14 + (i - 12)];
+      if (i < 15) mz_step_split(base[15 + (i - 12)], s.x0lo[2 + (i - 12)], h, vel[14 + (i - 12)], &s.qpos[15 + (i - 12)], &s.qlo[2 + (i - 12)]);
       else {
         float w[3] = {vel[17], vel[18], vel[19]};
         quat_integratef(base + 18, w, h, s.qpos + 18);
       }
     } else {
       int j = i - 4;  // hinges 0..7, then block slides
-      s.qpos[7 + j] = base[7 + j] + h * vel[6 + j];
+      if (j < 8) s.qpos[7 + j] = base[7 + j] + h * vel[6 + j];
+      else mz_step_split(base[7 + j], s.x0lo[2 + (j - 8)], h, vel[6 + j], &s.qpos[7 + j], &s.qlo[2 + (j - 8)]);
     }
   }
 }
@@ -1749,6 +1821,7 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   using D = AntDims<NB>;
   const float h = K.h;
   MZ_FOR(i, D::NQ) s.x0q[i] = s.qpos[i];
+  MZ_FOR(i, D::NLO) s.x0lo[i] = s.qlo[i];
   MZ_FOR(i, D::NV) { s.x0v[i] = s.qvel[i]; s.accv[i] = 0.f; s.accf[i] = 0.f; }
   cx.sync();
   for (int st = 0; st < 4; st++) {
@@ -1852,6 +1925,7 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 // constant tables of the scratch block, once per step (to be followed by a cx.sync() before the first forward evaluation)
 template <int NB, class C>
 MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
+  MZ_FOR(i, AntDims<NB>::NLO) s.qlo[i] = 0.f;  // the state that enters a step is fp32: no low-order parts yet
   if constexpr (NB <= 1) { MZ_FOR(i, 256) s.Md[i >> 4][i & 15] = (NB == 1 && (i == 14 * 17 || i == 15 * 17)) ? K.block_mass : 0.f; }  // entries between different legs stay zero; a block's slides: its mass
   cx.sync();
   MZ_FOR(e, 9) {  // linear block of the root's mass matrix: total mass x identity (summed in body order, as the composite inertia is)
@@ -1859,7 +1933,7 @@ MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
     for (int b = 0; b < ANT_NBODY; b++) m += K.mass[body_class(b)];
     const int i = e / 3, j = e - 3 * i;
     s.M.rr[i][j] = i == j ? m : 0.f;
-    if constexpr (NB <= 1) s.Md[i][j] = i == j ? m : 0.f;
+    if constexpr (NB <= 1) s.Md[md_root_pos(i)][md_root_pos(j)] = i == j ? m : 0.f;
   }
   MZ_FOR(i, MZ_MAX_GRID) {
     s.rowmask[i] = maze_row(K.maze, i);
@@ -1891,7 +1965,7 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
   MZ_FOR(i, obs_dim) obs[i] = ant_obs_elem<NB>(K, s, i, t);
   MZ_FOR(one, 1) {
     float dt = K.h * (float)K.frame_skip;
-    float vx = (s.qpos[0] - s.red[1]) / dt, vy = (s.qpos[1] - s.red[2]) / dt;
+    float vx = ((s.qpos[0] - s.red[1]) + s.qlo[0]) / dt, vy = ((s.qpos[1] - s.red[2]) + s.qlo[1]) / dt;
     float fwd = sqrtf(vx * vx + vy * vy), cc = 0.f;
     for (int u = 0; u < ANT_NU; u++) cc += action[u] * action[u];
     cc *= (float)K.task.ctrl_w;

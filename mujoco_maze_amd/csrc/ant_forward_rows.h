@@ -1,0 +1,417 @@
+// ant_forward_rows.h — the plain ant's forward dynamics up to the constraint solve (kinematics, composite
+// inertias, mass matrix, bias forces, collision, constraint rows) in the REGISTERS of the row's four leg quads.  Device only;
+// included by ant_kernels.hip after ant_newton_rows.h, called by ant_forward (ant_dyn.h) for the plain ant at >= 16 lanes per env.
+//
+// Why (round 4).  After the Newton iteration had moved into one DPP row (ant_newton_rows.h) the phases in
+// front of it were 43 % of a wave's cycles: five LDS hand-offs (kinematics -> inertias -> leg blocks / composite inertia / body
+// forces -> hub block / dof forces -> contact rows), each phase a different instruction stream for a quarter to three quarters
+// of the lanes.  Here the 16 lanes of a row are the four legs' quads (rows::pos2dof):
+//
+//     lane 4l + j      as a BODY / GEOM lane             as a DOF lane (= the solver's position)
+//     j = 0            aux body of leg l                 hip l
+//     j = 1            ankle body of leg l               ankle l
+//     j = 2            welded leg capsule of leg l       root dof 2l       (l < 3; quad 3: spare)
+//     j = 3            torso (quad 0 only)               root dof 2l + 1   (l < 3; quad 3: spare)
+//
+// and one instruction stream serves all of them:
+//   K  every lane of quad l evaluates leg l's chain (two sincos, the capsule axes, joint axes at the torso origin) — redundantly,
+//      which costs what one lane per leg cost before, without the hand-off that followed;
+//   I  every lane the spatial inertia of its own body; the whole-body composite is ten row butterflies (rows::rsum), a leg's
+//      composites are `quad_perm` moves;
+//   M  composite-rigid-body rule in its general form: M[p][q] = S_p . (I_q^c S_q) for q in the subtree of p.  Every dof lane forms
+//      F_p = I_p^c S_p with ITS composite inertia (whole body / aux + ankle / ankle) and ITS motion axis; its root columns are dot
+//      products with the root's axes (known everywhere), its hinge columns S_p . F_q come through `row_newbcast:q` operands fused
+//      into the multiply-adds (48 instructions for the 8 hinge columns of all 14 rows) — row p of M lands in the registers of
+//      lane p, which is where the solver wants it (no dense copy in LDS any more);
+//   V  recursive Newton-Euler with per-lane masks instead of per-level branches; subtree force sums by quad_perm / rsum;
+//   C  a geom's lane enumerates its contacts from its own registers (same narrow phase: round_vs_box of ant_dyn.h), the compact
+//      slot order — geom order, as MuJoCo's — comes from ONE packed-count butterfly (2 bits per geom), and the lane that found a
+//      contact builds its three constraint rows on the spot: the only LDS hand-off left before the solver is the contact rows
+//      it reads (cJ, caref, cD).
+// A geom that finds more than three contacts (a foot in a wall corner) sends its env down the lane-group path of ant_dyn.h once:
+// the kinematics are published to LDS and con_count / con_fill / con_row run as for the block mazes — same contacts, same order.
+#pragma once
+#include "ant_newton_rows.h"
+
+namespace rows {
+
+template <int J>
+__device__ __forceinline__ float qbcast(float x) {  // value of lane J of this quad, on every lane of the quad
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), J | (J << 2) | (J << 4) | (J << 6), 0xF, 0xF, true));
+}
+__device__ __forceinline__ unsigned rsum_u(unsigned x) {  // integer all-reduce over the row (fields must not carry into each other)
+  x += (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, true);
+  return x;
+}
+__device__ __forceinline__ float sel4(const float (&v)[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+__device__ __forceinline__ unsigned sum2bit(unsigned w) { return (unsigned)__popc(w & 0x55555555u) + 2u * (unsigned)__popc(w & 0xAAAAAAAAu); }
+
+// bit select: m = all ones -> a, m = 0 -> b.  One v_bfi_b32 — and, unlike `cond ? a : b` on values only one role of lanes
+// needs, nothing the compiler can turn into a divergent branch with the operand's computation sunk into it (it did: the first
+// version of this file ran its role selects as ~60 exec-mask branches per evaluation)
+__device__ __forceinline__ float bsel(int m, float a, float b) { return __int_as_float((__float_as_int(a) & m) | (__float_as_int(b) & ~m)); }
+
+struct GeomHit { float pos[3], n[3], dist; int kind; };  // one staged contact of a geom lane (registers)
+
+// The 24-float record of one contact of a robot geom (ant_solve_rows_core, WR mode): rec[8 a + 0..5] = wrench of row a about the
+// torso origin, sr [r x f_a; f_a] (f_0 = n, f_1 = mu t1, f_2 = mu t2; sr: +1 floor -> geom, -1 geom -> wall: the side of the pair
+// the robot is on), rec[8 a + 6] = reference acceleration of row a, rec[7] = D, rec[15] = leg (7: none) | body class << 3.
+// Same arithmetic as con_row_item (ant_dyn.h): the row's velocity J qvel is wrench . (spatial velocity of the touching body), vb.
+__device__ __forceinline__ void contact_record(const AntDev& K, const float* pos, const float* n, float dist, int kind, const float* hint, int cls, int leg,
+                                               const float* vb, float tran, float* rec) {
+  // the pair's parameters: BOTH sets by scalar loads, then value selects (`const PairDev& P = kind == 0 ? K.floor : K.wall` came out as
+  // an address select followed by dependent vector-memory loads: three round trips to the cache on the contact's critical path)
+  const int mk = -(int)(kind == 0);
+  struct { float margin, mu, K, B; } P = {bsel(mk, K.floor.margin, K.wall.margin), bsel(mk, K.floor.mu, K.wall.mu), bsel(mk, K.floor.K, K.wall.K),
+                                         bsel(mk, K.floor.B, K.wall.B)};
+  float si[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) si[k] = bsel(mk, K.floor.solimp[k], K.wall.solimp[k]);
+  float t1[3], t2[3];
+  make_tangents(n, hint, t1, t2);
+  const float sr = bsel(mk, 1.f, -1.f);
+  float omi;
+  const float imp = impedance_pair(si, fabsf(dist - P.margin), &omi);
+  const float Rr = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
+  rec[7] = 1.0f / (2.f * P.mu * P.mu * Rr);  // [ASSUME-3]
+  rec[15] = __int_as_float((leg < 0 ? 7 : leg) | (cls << 3));
+  rec[23] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float sc = (a == 0 ? 1.f : P.mu) * sr;
+    const float* dir = a == 0 ? n : (a == 1 ? t1 : t2);
+    const float f[3] = {sc * dir[0], sc * dir[1], sc * dir[2]};
+    float m[3];
+    cross3f(m, pos, f);
+    float* w = rec + 8 * a;
+    w[0] = m[0]; w[1] = m[1]; w[2] = m[2]; w[3] = f[0]; w[4] = f[1]; w[5] = f[2];
+    const float vel = m[0] * vb[0] + m[1] * vb[1] + m[2] * vb[2] + f[0] * vb[3] + f[1] * vb[4] + f[2] * vb[5];
+    float aref = -P.B * vel;
+    if (a == 0) aref -= P.K * imp * (dist - P.margin);
+    w[6] = aref;
+  }
+}
+// fall-back (an env whose geom overflowed its staging): the record of compact slot c from the geometry con_fill_item left in
+// s.cY[c] and the kinematics the forward pass published to LDS
+template <class S>
+__device__ __forceinline__ void con_record_item(const AntDev& K, S& s, int c) {
+  const float* q = &s.cY[c][0][0];
+  const float pos[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
+  const int kind = (int)q[7] & 15, leg = s.cleg[c], cls = s.ccls[c], lg = leg < 0 ? 0 : leg;
+  float ww[3], vb[6];
+  mat_vecf(ww, s.R0, s.qvel + 3);
+  const float qdh = cls >= 2 ? s.qvel[6 + 2 * lg] : 0.f, qda = cls == 3 ? s.qvel[7 + 2 * lg] : 0.f;
+  for (int k = 0; k < 3; k++) { vb[k] = ww[k] + s.zw[k] * qdh + s.Sa[lg][k] * qda; vb[3 + k] = s.qvel[k] + s.Sh[lg][k] * qdh + s.Sa[lg][3 + k] * qda; }
+  float rec[24];
+  contact_record(K, pos, n, dist, kind, hint, cls, leg, vb, K.bw_tran[cls < 0 ? 0 : cls], rec);
+  float4* dst = reinterpret_cast<float4*>(&s.cJ[c][0][0]);
+#pragma unroll
+  for (int k = 0; k < 6; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+}
+
+// contacts of one robot geom of the plain ant against the floor plane and the maze's wall cells — the robot-geom part of
+// geom_contacts (ant_dyn.h) on register inputs: centre / axis relative to the torso origin, torso origin (x0, y0, cz) in the world
+template <class S, class Emit>
+__device__ __forceinline__ void plain_geom_contacts(const AntDev& K, const S& s, bool sphere, const float* ctr, const float* ax, float hl, float r,
+                                                    float x0, float y0, float x0l, float y0l, float cz, Emit&& emit) {
+  const MazeDev& z = K.maze;
+  const float inv = 1.0f / z.scale;
+  const float bs[3] = {z.half_xy, z.half_xy, z.half_z};
+  ContactGeo cg;
+  // floor plane z = 0, normal +z; capsule ends in MuJoCo's geom-frame order [ASSUME-5]: "+axis" is the end at the body origin
+#pragma unroll
+  for (int k2 = 0; k2 < 2; k2++) {
+    if (k2 == 1 && sphere) break;
+    const float sg = k2 == 0 ? -1.f : 1.f;
+    float p[3];
+    for (int k = 0; k < 3; k++) p[k] = ctr[k] + sg * ax[k] * hl;
+    const float dist = (cz + p[2]) - r;
+    if (dist < K.floor.margin) {
+      cg.dist = dist; cg.kind = 0; cg.blk = 0; cg.other = 0;
+      cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
+      cg.pos[0] = p[0]; cg.pos[1] = p[1]; cg.pos[2] = p[2] - (r + 0.5f * dist);
+      for (int k = 0; k < 3; k++) cg.hint[k] = 0.f;
+      emit(cg);
+    }
+  }
+  const float reach = r + hl + K.wall.margin;
+  const float gx = x0 + ctr[0], gy = y0 + ctr[1], gz = cz + ctr[2];
+  if (gz - reach > z.center_z + z.half_z) return;
+  const int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
+  const int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
+  const float zc = z.center_z - cz;
+  const float lim2 = (r + K.wall.margin) * (r + K.wall.margin) * 1.0001f;
+  // can cell (i, j) give a contact at all?  In the grid and a wall; the geom's z extent meets the box's; and the geom's axis
+  // segment — its bounding box, axis by axis — comes within radius + margin of the box: a lower bound of the true distance that is
+  // exact whenever the nearest feature is a face, i.e. for every wall a leg merely passes (cells are metres wide, capsules
+  // centimetres).  Only what survives pays for the closest-feature search of mjc_CapsuleBox (round_vs_box).
+  auto candidate = [&](int i, int j) {
+    if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) return false;
+    if (!((maze_row_lds(s, i) >> j) & 1u)) return false;
+    if (gz - reach > z.center_z + z.half_z || gz + reach < z.center_z - z.half_z) return false;
+    const float bc[3] = {((j * z.scale - z.tx) - x0) - x0l, ((i * z.scale - z.ty) - y0) - y0l, zc};
+    float g2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const float c = ctr[q] - bc[q], e = fabsf(ax[q]) * hl;  // the segment spans [c - e, c + e] on this axis
+      const float gap = fmaxf(fabsf(c) - e - bs[q], 0.f);
+      g2 += gap * gap;
+    }
+    return g2 <= lim2;
+  };
+  auto test = [&](int i, int j) {
+    const float bc[3] = {((j * z.scale - z.tx) - x0) - x0l, ((i * z.scale - z.ty) - y0) - y0l, zc};  // large world coordinates cancel first, then the low-order parts (AntScratchT::qlo)
+    round_vs_box(sphere, ctr, ax, hl, r, bc, bs, K.wall.margin, 1, 0, emit);
+  };
+  if (i1 - i0 <= 1 && j1 - j0 <= 1) {
+    // the usual case (a geom's bounding square covers at most 2 x 2 cells): both grid rows at once, leave when none of the cells is a wall
+    const uint32_t rows2 = maze_row_lds(s, i0) | (i1 != i0 ? maze_row_lds(s, i1) : 0u);
+    const uint32_t cols2 = ((j0 >= 0 && j0 < z.cols) ? 1u << j0 : 0u) | ((j1 != j0 && j1 >= 0 && j1 < z.cols) ? 1u << j1 : 0u);
+    if (!(rows2 & cols2)) return;
+  }
+  // the surviving cells as a bit set (bit 4 (i - i0) + (j - j0): up to 8 x 4 cells, row-major = MuJoCo's geom order of the wall
+  // boxes), then one cell per pass — lanes with one candidate each meet in the same pass instead of each waiting for the other's
+  // position in a loop nest
+  unsigned cand = 0u;
+  for (int i = i0; i <= i1 && i < i0 + 8; i++)
+    for (int j = j0; j <= j1 && j < j0 + 4; j++)
+      if (candidate(i, j)) cand |= 1u << (4 * (i - i0) + (j - j0));
+  while (cand) {
+    const int b = __ffs((int)cand) - 1;
+    cand &= cand - 1u;
+    test(i0 + (b >> 2), j0 + (b & 3));
+  }
+}
+
+}  // namespace rows
+
+// Per-lane constants of the quad layout, loaded ONCE per step into DevCtx::lc (registers; run-time indexed loads of the constant
+// block inside the 20 evaluations came out as address selects + vector-memory loads): leg signs, ankle axis, and the own body's
+// mass / inertia / capsule size / contact weight — zero mass for the torso's duplicates in quads 1..3, so that row sums count it once.
+enum { LC_SX, LC_SY, LC_AX0, LC_AX1, LC_AX2, LC_MASS, LC_ILAT, LC_DAX, LC_HLEN, LC_RAD, LC_TRAN, LC_N };  // (+ LC_LO, LC_HI, LC_DOFW: ant_newton_rows.h)
+template <int G, bool PROF>
+__device__ __forceinline__ void ant_lane_consts(const AntDev& K, DevCtx<G, PROF>& cx) {
+  static_assert(LC_N <= DevCtx<G, PROF>::NLC, "DevCtx::lc too small");
+  const int p = cx.l & 15, l = p >> 2, j = p & 3;
+  const int cls = j == 0 ? 2 : (j == 1 ? 3 : (j == 2 ? 1 : 0));
+  const bool primary = !(j == 3 && l > 0);
+  cx.lc[LC_SX] = K.sx[l]; cx.lc[LC_SY] = K.sy[l];
+  cx.lc[LC_AX0] = K.ank_axis[l][0]; cx.lc[LC_AX1] = K.ank_axis[l][1]; cx.lc[LC_AX2] = K.ank_axis[l][2];
+  cx.lc[LC_MASS] = primary ? K.mass[cls] : 0.f; cx.lc[LC_ILAT] = primary ? K.ilat[cls] : 0.f; cx.lc[LC_DAX] = primary ? K.iax[cls] - K.ilat[cls] : 0.f;
+  cx.lc[LC_HLEN] = K.half_len[cls]; cx.lc[LC_RAD] = K.radius[cls]; cx.lc[LC_TRAN] = K.bw_tran[cls];
+  ant_limit_consts(K, cx);
+}
+
+// One forward-dynamics evaluation of the plain ant: qacc from (s.qpos, s.qvel, s.fact); `first`: first evaluation of an env.step
+// (s.warm = MuJoCo's qacc_warmstart), otherwise s.warm = the previous evaluation's solution.  Same outputs as ant_forward's
+// lane-group path: s.qacc, s.qas (where computed), s.ncon, s.iters, status bits.
+template <int G, bool PROF>
+__device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<0>& s, bool first) {
+  static_assert(G >= 16, "one DPP row per env at least");
+  using namespace rows;
+  using C = DevCtx<G, PROF>;  // (MZ_FOR)
+  constexpr int NB = 0, NC = AntDims<0>::NC;
+  cx.tick(s, 9);
+  const int p = cx.l & 15, l = p >> 2, j = p & 3;
+  const bool hinge = j < 2, isroot = j >= 2 && l < 3;
+  const int iroot = 2 * l + j - 2;                 // root dof of a root lane
+  const bool isgeom = j < 3 || p == 3;
+  const int m0 = -(int)(j == 0), m1 = -(int)(j == 1), m2 = -(int)(j == 2), mh = -(int)hinge;  // role masks (bsel)
+  auto role = [&](float a0, float a1, float a2, float a3) { return bsel(m0, a0, bsel(m1, a1, bsel(m2, a2, a3))); };
+
+  // ---- K: leg l's chain, on every lane of its quad (kin_item of ant_dyn.h)
+  float R0[9];
+  quat_to_matf(R0, s.qpos + 3);
+  const float cz = s.qpos[2], x0 = s.qpos[0], y0 = s.qpos[1];
+  const float zw[3] = {R0[2], R0[5], R0[8]};
+  const float sx = cx.lc[LC_SX], sy = cx.lc[LC_SY];
+  const float aax[3] = {cx.lc[LC_AX0], cx.lc[LC_AX1], cx.lc[LC_AX2]};
+  const float qh = s.qpos[7 + 2 * l], qa = s.qpos[8 + 2 * l];
+  float w0[3], w1[3], w2[3], com0[3], com1[3], com2[3], p1[3], p2[3], ShL[3], Sa[6];
+  {
+    const float isq2 = 0.70710678118654752f;
+    const float u[3] = {sx * isq2, sy * isq2, 0.f}, off[3] = {sx * K.legoff, sy * K.legoff, 0.f};
+    float ch, sh, ca, sa;
+    mz_sincosf(qh, &sh, &ch);
+    mz_sincosf(qa, &sa, &ca);
+    float t[3], v[3];
+    mat_vecf(w0, R0, u);                                                    // level 0: welded leg capsule, torso frame
+    for (int k = 0; k < 3; k++) com0[k] = w0[k] * K.half_len[1];
+    mat_vecf(p1, R0, off);                                                  // level 1: aux body, rotated about body z by the hip angle
+    t[0] = ch * u[0] - sh * u[1]; t[1] = sh * u[0] + ch * u[1]; t[2] = 0.f;
+    mat_vecf(w1, R0, t);
+    for (int k = 0; k < 3; k++) com1[k] = p1[k] + w1[k] * K.half_len[2];
+    cross3f(ShL, p1, zw);                                                   // linear velocity at c of a unit hip rotation: zw x (c - p1)
+    t[0] = ch * off[0] - sh * off[1]; t[1] = sh * off[0] + ch * off[1]; t[2] = 0.f;
+    mat_vecf(v, R0, t);
+    for (int k = 0; k < 3; k++) p2[k] = p1[k] + v[k];                       // level 2: ankle body, rotated about its local axis
+    const float au = aax[0] * u[0] + aax[1] * u[1];
+    float axu[3], ul[3];
+    cross3f(axu, aax, u);
+    for (int k = 0; k < 3; k++) ul[k] = u[k] * ca + axu[k] * sa + aax[k] * au * (1.f - ca);  // Rodrigues
+    t[0] = ch * ul[0] - sh * ul[1]; t[1] = sh * ul[0] + ch * ul[1]; t[2] = ul[2];
+    mat_vecf(w2, R0, t);
+    for (int k = 0; k < 3; k++) com2[k] = p2[k] + w2[k] * K.half_len[3];
+    t[0] = ch * aax[0] - sh * aax[1]; t[1] = sh * aax[0] + ch * aax[1]; t[2] = aax[2];
+    mat_vecf(Sa, R0, t);                                                    // ankle axis (world)
+    cross3f(Sa + 3, p2, Sa);                                                // aw x (c - p2)
+  }
+  // this lane's own body: j = 0 aux (class 2), 1 ankle (3), 2 welded leg (1), 3 torso (0)
+  float com[3], w[3];
+  for (int k = 0; k < 3; k++) { com[k] = role(com1[k], com2[k], com0[k], 0.f); w[k] = role(w1[k], w2[k], w0[k], 0.f); }
+  const int cls = j == 0 ? 2 : (j == 1 ? 3 : (j == 2 ? 1 : 0));
+  const float hlen = cx.lc[LC_HLEN], rad = cx.lc[LC_RAD];
+  cx.tick(s, 0);
+  // ---- C: contacts of the own geom, staged in registers (the first three; more: the env takes the fall-back below).  Right after the
+  // kinematics: the narrow phase is the branchiest code of the evaluation, and here little else is live across it
+  GeomHit hit[3];
+  int nfound = 0;
+  if (isgeom) {
+    plain_geom_contacts(K, s, j == 3, com, w, hlen, rad, x0, y0, s.qlo[0], s.qlo[1], cz, [&](const ContactGeo& g) {
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        if (nfound == q) {
+          for (int k = 0; k < 3; k++) { hit[q].pos[k] = g.pos[k]; hit[q].n[k] = g.n[k]; }
+          hit[q].dist = g.dist; hit[q].kind = g.kind;
+        }
+      nfound++;
+    });
+  }
+  const bool over = cx.gany(nfound > 3);
+  // compact slots in geom order (torso, then per leg: welded capsule, aux, ankle): one packed-count butterfly
+  const int rank = j == 3 ? 0 : 1 + 3 * l + (j == 2 ? 0 : j + 1);
+  const unsigned word = rsum_u((unsigned)(nfound > 3 ? 3 : nfound) << (2 * rank));
+  const int off = (int)sum2bit(word & ((1u << (2 * rank)) - 1u));
+  int ncon = (int)sum2bit(word);
+  cx.tick(s, 2);
+
+  // ---- I: spatial inertia of the own body about the torso origin (inertia_item); composites
+  float cin[10];
+  {
+    const float m = cx.lc[LC_MASS], lat = cx.lc[LC_ILAT], dax = cx.lc[LC_DAX];
+    const float rr = dot3f(com, com);
+    cin[0] = m; cin[1] = m * com[0]; cin[2] = m * com[1]; cin[3] = m * com[2];
+    cin[4] = lat + dax * w[0] * w[0] + m * (rr - com[0] * com[0]);
+    cin[5] = lat + dax * w[1] * w[1] + m * (rr - com[1] * com[1]);
+    cin[6] = lat + dax * w[2] * w[2] + m * (rr - com[2] * com[2]);
+    cin[7] = dax * w[0] * w[1] - m * com[0] * com[1];
+    cin[8] = dax * w[0] * w[2] - m * com[0] * com[2];
+    cin[9] = dax * w[1] * w[2] - m * com[1] * com[2];
+  }
+  float Ip[10];  // composite inertia of this lane's dof: whole body (root), aux + ankle (hip), ankle (ankle)
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    const float all = rsum(cin[k]), ank = qbcast<1>(cin[k]);
+    Ip[k] = role(cin[k] + ank, cin[k], all, all);
+  }
+  // ---- motion axis of this lane's dof at the torso origin: [angular; linear]
+  float S[6];
+  {
+    const int c = iroot - 3;  // column of R0 for a root angular dof
+    const int mang = -(int)(isroot && iroot >= 3), mc0 = -(int)(c == 0), mc1 = -(int)(c == 1);
+    for (int k = 0; k < 3; k++) {
+      const float rc = bsel(mc0, R0[3 * k], bsel(mc1, R0[3 * k + 1], R0[3 * k + 2]));
+      S[k] = bsel(m0, zw[k], bsel(m1, Sa[k], bsel(mang, rc, 0.f)));
+      S[3 + k] = bsel(m0, ShL[k], bsel(m1, Sa[3 + k], bsel(-(int)(isroot && iroot == k), 1.f, 0.f)));
+    }
+  }
+  // ---- M: row p of the mass matrix, position order
+  float Mrow[14];
+  {
+    float F[6];
+    inertia_mulf(F, Ip, S);
+    // root columns: S_i . F with the root's axes (linear e_i; angular the columns of R0)
+    const float mr[6] = {F[3], F[4], F[5], R0[0] * F[0] + R0[3] * F[1] + R0[6] * F[2], R0[1] * F[0] + R0[4] * F[1] + R0[7] * F[2],
+                         R0[2] * F[0] + R0[5] * F[1] + R0[8] * F[2]};
+#pragma unroll
+    for (int i = 0; i < 6; i++) Mrow[dof2pos(i)] = mr[i];
+    // hinge columns q: S_mine . F_q — valid where q lies in the subtree of this lane's dof (root: every hinge; hip: itself and its
+    // ankle; ankle: itself).  The ankle's hip column is the transposed entry S_hip . F_mine (the hip's axis is known in its quad).
+    const float g0 = dot6_from<0>(F, S), g1 = dot6_from<1>(F, S), g4 = dot6_from<4>(F, S), g5 = dot6_from<5>(F, S);
+    const float g8 = dot6_from<8>(F, S), g9 = dot6_from<9>(F, S), g12 = dot6_from<12>(F, S), g13 = dot6_from<13>(F, S);
+    const float hipT = zw[0] * F[0] + zw[1] * F[1] + zw[2] * F[2] + ShL[0] * F[3] + ShL[1] * F[4] + ShL[2] * F[5];
+    const float gq[8] = {g0, g1, g4, g5, g8, g9, g12, g13};
+#pragma unroll
+    for (int l2 = 0; l2 < 4; l2++) {
+      const int mine = -(int)(l2 == l);
+      const float vh = gq[2 * l2], va = gq[2 * l2 + 1];
+      const float hh = bsel(mine, bsel(m1, hipT, vh + K.armature), 0.f), ha = bsel(mine, bsel(m1, va + K.armature, va), 0.f);  // hinge lanes
+      Mrow[4 * l2] = bsel(mh, hh, vh); Mrow[4 * l2 + 1] = bsel(mh, ha, va);
+    }
+  }
+  cx.tick(s, 3);
+  // ---- V: recursive Newton-Euler (bias_body_item / bias_dof_item), masks instead of branches
+  const float qv[6] = {s.qvel[0], s.qvel[1], s.qvel[2], s.qvel[3], s.qvel[4], s.qvel[5]};
+  const float qdh = s.qvel[6 + 2 * l], qda = s.qvel[7 + 2 * l];
+  float qfs, vb[6];  // vb: spatial velocity of the own body at the torso origin (the contact rows use it too)
+  {
+    float a[6], ww[3];
+    mat_vecf(ww, R0, qv + 3);  // world angular velocity (root angular dofs are body-frame)
+    for (int k = 0; k < 3; k++) { vb[k] = ww[k]; vb[3 + k] = qv[k]; a[k] = 0.f; }
+    cross3f(a + 3, qv, ww);
+    a[5] -= K.gz;              // gravity as base acceleration
+    const float vh = bsel(mh, qdh, 0.f), va = bsel(m1, qda, 0.f);  // aux and ankle move with the hip, the ankle body with the ankle as well
+    const float Sh6[6] = {zw[0], zw[1], zw[2], ShL[0], ShL[1], ShL[2]};
+    float sd[6];
+    motion_crossf(sd, vb, Sh6);
+    for (int k = 0; k < 6; k++) { a[k] += sd[k] * vh; vb[k] += Sh6[k] * vh; }
+    motion_crossf(sd, vb, Sa);
+    for (int k = 0; k < 6; k++) { a[k] += sd[k] * va; vb[k] += Sa[k] * va; }
+    float Ia[6], Iv[6], vf[6], f[6];
+    inertia_mulf(Ia, cin, a);
+    inertia_mulf(Iv, cin, vb);
+    force_crossf(vf, vb, Iv);
+    for (int k = 0; k < 6; k++) f[k] = Ia[k] + vf[k];
+    // force on the subtree of this lane's dof: ankle = its body; hip = aux + ankle; root = all bodies
+    float bias = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const float all = rsum(f[k]), ank = qbcast<1>(f[k]);
+      bias += S[k] * role(f[k] + ank, f[k], all, all);
+    }
+    const float fact = s.fact[hinge ? pos2dof(p) : 6];  // motors sit on the hinges only
+    qfs = bsel(mh, -K.damping * bsel(m0, qdh, qda) - bias + fact, bsel(-(int)isroot, -bias, 0.f));
+  }
+  cx.tick(s, 1);
+  if (!over) {
+    if (ncon > NC) { ncon = NC; if (p == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+    if (p == 0) { s.ncon = ncon; s.nblkcon = 0; }
+    // the records of the own contacts (contact_record), straight into the slots their owner lanes read
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int slot = off + q;
+      if (q < nfound && slot < NC) {
+        const GeomHit& h = hit[q];
+        const float hint[3] = {(h.kind == 0 && j < 3) ? w[0] : 0.f, (h.kind == 0 && j < 3) ? w[1] : 0.f, (h.kind == 0 && j < 3) ? w[2] : 0.f};
+        float rec[24];
+        contact_record(K, h.pos, h.n, h.dist, h.kind, hint, cls, j == 3 ? -1 : l, vb, cx.lc[LC_TRAN], rec);
+        float4* dst = reinterpret_cast<float4*>(&s.cJ[slot][0][0]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+      }
+    }
+    cx.sync();
+  }
+  if (cx.any(over)) {
+    // Fall-back (rare: some geom of some env of this wave found more than three contacts): publish the kinematics the lane-group
+    // contact code of ant_dyn.h reads, and let the envs concerned enumerate the two-pass way.
+    if (isgeom && j < 3) { const int b = 3 * l + (j == 2 ? 0 : j + 1); for (int k = 0; k < 3; k++) { s.com[b][k] = com[k]; s.w[b][k] = w[k]; } }
+    if (j == 0) { for (int k = 0; k < 3; k++) s.Sh[l][k] = ShL[k]; for (int k = 0; k < 6; k++) s.Sa[l][k] = Sa[k]; }
+    if (p == 0) { for (int k = 0; k < 9; k++) s.R0[k] = R0[k]; for (int k = 0; k < 3; k++) s.zw[k] = zw[k]; s.cz = cz; s.nearwall = 1; s.con_over = 1; }
+    cx.sync();
+    if (over) {
+      constexpr int NG = AntDims<0>::NGEOM;
+      MZ_FOR(e, NG) con_count_item<NB>(K, s, e);
+      cx.sync();
+      MZ_FOR(e, NG) con_fill_item<NB>(K, s, e);
+      cx.sync();
+      MZ_FOR(c, s.ncon) con_record_item(K, s, c);
+      cx.sync();
+    }
+  }
+  cx.tick(s, 11);
+  ant_solve_rows_core<NB, G, PROF, true>(cx, K, s, first, Mrow, qfs, S);
+}

@@ -21,6 +21,7 @@
 #include "ant_dyn.h"
 #include "mz_device.h"
 #include "ant_newton_rows.h"
+#include "ant_forward_rows.h"
 #include "mz_internal.h"
 
 // ------------------------------------------------------------------ Ant kernels
@@ -68,6 +69,8 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   AntEnvLDS<NB>* lds = reinterpret_cast<AntEnvLDS<NB>*>(lds_raw);
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
+  if constexpr (NB == 0 && G >= 16) ant_lane_consts(K, cx);  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
+  if constexpr (NB == 1 && G >= 16) ant_limit_consts(K, cx);
   const int slot = threadIdx.x / G;
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
@@ -163,14 +166,18 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
       atomicAdd(&prof[14], (tot >> 8) * (tot >> 8));  // sum of squares of the per-wave totals (units of 256 cycles)
       // per-workgroup totals (mz_read_wave_cycles): cycles in the low 40 bits, Newton iterations of the wave above them
       prof[16 + blockIdx.x] += tot + ((unsigned long long)s.prof[15] << 40);
+      for (int k = 0; k < 16; k++) prof[16 + gridDim.x * 0 + n + (size_t)blockIdx.x * 16 + k] += s.prof[k];  // per-workgroup phases (mz_read_wave_phase_cycles)
     }
   }
 }
 
 #ifdef MZ_ISA_ONLY
+#ifndef MZ_ISA_PROF
+#define MZ_ISA_PROF false
+#endif
 // developer aid (tools/isa_one.sh): compile ONE instantiation of the step kernel to look at its ISA / run the DPP hazard check
 // in seconds instead of building all of them:  hipcc ... -DMZ_ISA_ONLY -DMZ_ISA_NB=0 -DMZ_ISA_G=16 -S ant_kernels.hip
-template __global__ void ant_step_kernel<MZ_ISA_NB, MZ_ISA_G, false>(const AntDev*, int, float*, const float*, float*, float*, uint8_t*, int*, float*, int*, int,
+template __global__ void ant_step_kernel<MZ_ISA_NB, MZ_ISA_G, MZ_ISA_PROF>(const AntDev*, int, float*, const float*, float*, float*, uint8_t*, int*, float*, int*, int,
                                                                      uint64_t, uint64_t, unsigned long long*, float*, int, float*);
 #else
 template <int NB, int G>
@@ -182,6 +189,8 @@ __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   AntScratchT<NB>* sc = reinterpret_cast<AntScratchT<NB>*>(lds_raw);
   DevCtx<G> cx{(int)threadIdx.x % G};
+  if constexpr (NB == 0 && G >= 16) ant_lane_consts(K, cx);
+  if constexpr (NB == 1 && G >= 16) ant_limit_consts(K, cx);
   const int slot = threadIdx.x / G;
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
@@ -366,6 +375,10 @@ static hipError_t ant_sync_constants(mz_handle* h, hipStream_t st) {
 hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   hipError_t e = ant_sync_constants(h, st);
   if (e != hipSuccess) return e;
+#ifdef MZ_DEV_NB0  // developer build (make dev: libmazestep_dev.so, a minute instead of six): the plain ant's instantiations only
+  if (ant_config(h) != 0) return hipErrorNotSupported;
+  return dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
+#else
   switch (ant_config(h)) {  // configuration of movable bodies (AntDims)
     case 0: return dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
     case 1: return dispatch_ant_step<1>(h, st, a, o, r, d, gi, inf);
@@ -374,9 +387,14 @@ hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, 
     case 5: return dispatch_ant_step<5>(h, st, a, o, r, d, gi, inf);
     default: return dispatch_ant_step<3>(h, st, a, o, r, d, gi, inf);
   }
+#endif
 }
 
 hipError_t mzk_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
+#ifdef MZ_DEV_NB0
+  if (ant_config(h) != 0) return hipErrorNotSupported;
+  return dispatch_ant_forward<0>(h, st, a, qacc, counts);
+#else
   switch (ant_config(h)) {
     case 0: return dispatch_ant_forward<0>(h, st, a, qacc, counts);
     case 1: return dispatch_ant_forward<1>(h, st, a, qacc, counts);
@@ -385,6 +403,7 @@ hipError_t mzk_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* 
     case 5: return dispatch_ant_forward<5>(h, st, a, qacc, counts);
     default: return dispatch_ant_forward<3>(h, st, a, qacc, counts);
   }
+#endif
 }
 
 hipError_t mzk_ant_reset(mz_handle* h, hipStream_t st, const uint8_t* mask, uint64_t seed, float* obs) {

@@ -23,7 +23,7 @@
 #define ANT_OBS 30
 
 struct PairDev {  // mixed contact parameters of one geom-pair class
-  float margin, mu, K, B, solimp[5];
+  float margin, mu, K, B, solimp[7];  // d0 dmax width midpoint power | 1 - d0, 1 - dmax rounded from float64 (impedance_pair, ant_dyn.h)
 };
 
 // Task constants.  Everything a flag depends on is float64, exactly the reference's values (maze_task.py:26-47): the
@@ -57,7 +57,7 @@ struct AntDev {
   float ank_axis[4][3];
   float hip_lo, hip_hi, ank_lo[4], ank_hi[4];
   float armature, damping, dofw_hip, dofw_ank;
-  float lim_K, lim_B, lim_solimp[5];
+  float lim_K, lim_B, lim_solimp[7];
   float ctrl_lo, ctrl_hi, gear;
   int act_dof[ANT_NU];
   PairDev floor, wall;
@@ -76,7 +76,7 @@ struct AntDev {
   // the two slide axes of a block: (x, y) in the Push family; (y, z) — LIMITED, gravity on the z slide — in the Fall mazes
   // (x, y, z) for MultiFall's three-slide block.  block_axis[a] = coordinate axis of slide a (increasing), block_nax = 2 or 3
   int block_axis[3], block_nax, block_limited;
-  float block_lo[3], block_hi[3], blim_margin, blim_K, blim_B, blim_solimp[5], blim_w;  // joint-limit rows of the slides
+  float block_lo[3], block_hi[3], blim_margin, blim_K, blim_B, blim_solimp[7], blim_w;  // joint-limit rows of the slides
   // float64 copies of the geometry behind ONE decision that sits on an exact tie in a registered maze: a falling block is
   // shrunk to 99 % (maze_env.py:579-582), so at maze scale 2 (AntMultiFall) the faces of the neighbouring platforms /
   // walls are 0.01 away — exactly the contact margin.  `gap < margin` is false in the reference's float64 arithmetic
@@ -103,6 +103,7 @@ static inline void pair_from(PairDev* p, const mz_model* m, const double* f1, co
   p->K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr));
   p->B = (float)(2.0 / (dmax * tc));
   for (int k = 0; k < 5; k++) p->solimp[k] = (float)si[k];
+  p->solimp[5] = (float)(1.0 - si[0]); p->solimp[6] = (float)(1.0 - si[1]);
 }
 
 // largest double s with sqrt(s) <= thr (host libm sqrt is correctly rounded); -1 for a negative threshold (never matches)
@@ -195,6 +196,7 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
       a->blim_K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr)); a->blim_B = (float)(2.0 / (dmax * tc));
       a->blim_margin = (float)m->jnt_margin[j0]; a->blim_w = (float)m->dof_invweight0[m->jnt_dofadr[j0]];
       for (int q = 0; q < 5; q++) a->blim_solimp[q] = (float)m->jnt_solimp[j0][q];
+      a->blim_solimp[5] = (float)(1.0 - m->jnt_solimp[j0][0]); a->blim_solimp[6] = (float)(1.0 - m->jnt_solimp[j0][1]);
     }
     for (int q = 0; q < 3; q++) {
       a->block_pos0[k][q] = (float)m->body_pos[b][q]; a->block_half[q] = (float)m->geom_size[g][q];
@@ -246,6 +248,7 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
     a->lim_K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr));
     a->lim_B = (float)(2.0 / (dmax * tc));
     for (int k = 0; k < 5; k++) a->lim_solimp[k] = (float)m->jnt_solimp[1][k];
+    a->lim_solimp[5] = (float)(1.0 - m->jnt_solimp[1][0]); a->lim_solimp[6] = (float)(1.0 - m->jnt_solimp[1][1]);
   }
   a->ctrl_lo = (float)m->act_ctrlrange[0][0]; a->ctrl_hi = (float)m->act_ctrlrange[0][1]; a->gear = (float)m->act_gear[0];
   for (int u = 0; u < ANT_NU; u++) a->act_dof[u] = m->act_dofid[u];

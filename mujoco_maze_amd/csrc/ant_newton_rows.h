@@ -27,10 +27,23 @@
 
 namespace rows {
 
+// Position p of the 16-lane row <-> MuJoCo dof (round 4).  Quad l (lanes 4l .. 4l + 3) belongs to leg l: lane 4l owns its hip
+// (dof 6 + 2l), lane 4l + 1 its ankle (dof 7 + 2l); lanes 2, 3 of quads 0 .. 2 own the root's six dofs (0 .. 5) and lanes 14, 15
+// the movable block's two slides (dofs 14, 15; NB = 1) or nothing.  Everything the solver keeps per row — Mrow / Hrow entries,
+// `row_newbcast:k`, the pivot order — is indexed by POSITION; only the LDS vectors shared with the rest of the step (qpos, qvel,
+// qfs, warm, qas, qacc, the columns of cJ) are in dof order.  The point of the layout: a leg's kinematics, composite inertias and
+// bias forces are computed by the four lanes of its own quad (ant_forward_rows.h), and its two rows of M come out on the lanes
+// that own them — `quad_perm` moves instead of LDS hand-offs.
+__host__ __device__ constexpr int pos2dof(int p) { return (p & 3) < 2 ? 6 + 2 * (p >> 2) + (p & 1) : (p < 12 ? 2 * (p >> 2) + (p & 3) - 2 : p); }
+__host__ __device__ constexpr int dof2pos(int d) { return d < 6 ? 4 * (d >> 1) + 2 + (d & 1) : (d < 14 ? 4 * ((d - 6) >> 1) + ((d - 6) & 1) : d); }
+static_assert(dof2pos(0) == 2 && dof2pos(5) == 11 && dof2pos(6) == 0 && dof2pos(13) == 13 && pos2dof(7) == 3 && pos2dof(9) == 11 && pos2dof(15) == 15, "row layout");
+
 template <int P>
 __device__ __forceinline__ float bcast(float x) {  // value of lane P of this 16-lane row, on every lane of the row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + P, 0xF, 0xF, false));
 }
+template <int P>
+__device__ __forceinline__ int bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x150 + P, 0xF, 0xF, false); }
 // Every lane must end up with the SAME BITS: alpha, the convergence tests and the active-set votes are computed redundantly by the
 // lanes of a row from these sums, and a row whose lanes disagree in the last bit can part ways at a branch (round 3 soak: one env
 // in 2.5e8 env-steps — a line search whose Newton step landed exactly on its bracket on one lane and one ulp inside it on the
@@ -157,50 +170,64 @@ __device__ __forceinline__ void pivot(int r, float (&Hrow)[N], float& b, float& 
   dinv = (r == P) ? ri : dinv;
 }
 
-// H x = b, arrow-structured SPD H: leg dofs (6..13) are eliminated first, each touching its partner and the hub columns only
+// H x = b, arrow-structured SPD H, row-distributed in POSITION order (pos2dof above): the hinges (positions 0 1 | 4 5 | 8 9 | 12 13)
+// are eliminated first, each touching its partner and the hub columns (root: positions 2 3 6 7 10 11) only
 __device__ __forceinline__ float solve_rows(int r, float (&Hrow)[14], float b) {
   float dinv = 0.f;
   // the four legs do not couple: their hip pivots (then their ankle pivots) are independent chains — issued next to each
   // other so that the reciprocal / broadcast latencies of one hide behind the others
-  pivot<6, 14, 7, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<8, 14, 9, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<10, 14, 11, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<12, 14, 13, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<7, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<9, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<11, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<13, 14, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<0, 14, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<1, 14, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<2, 14, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<3, 14, 4, 5>(r, Hrow, b, dinv);
-  pivot<4, 14, 5>(r, Hrow, b, dinv);
-  pivot<5, 14>(r, Hrow, b, dinv);
+  pivot<0, 14, 1, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<4, 14, 5, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<8, 14, 9, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<12, 14, 13, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<1, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<5, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<9, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<13, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<2, 14, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<3, 14, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<6, 14, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<7, 14, 10, 11>(r, Hrow, b, dinv);
+  pivot<10, 14, 11>(r, Hrow, b, dinv);
+  pivot<11, 14>(r, Hrow, b, dinv);
   return b * dinv;
 }
-// the same with one movable block: its two slides (dofs 14, 15) belong to the hub (a robot-block contact couples them with the
+// the same with one movable block: its two slides (positions 14, 15) belong to the hub (a robot-block contact couples them with the
 // root and with one leg), eliminated between the legs and the root
 __device__ __forceinline__ float solve_rows(int r, float (&Hrow)[16], float b) {
   float dinv = 0.f;
-  pivot<6, 16, 7, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<8, 16, 9, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<10, 16, 11, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<12, 16, 13, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<7, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<9, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<11, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<13, 16, 0, 1, 2, 3, 4, 5, 14, 15>(r, Hrow, b, dinv);
-  pivot<14, 16, 15, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<15, 16, 0, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<0, 16, 1, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<1, 16, 2, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<2, 16, 3, 4, 5>(r, Hrow, b, dinv);
-  pivot<3, 16, 4, 5>(r, Hrow, b, dinv);
-  pivot<4, 16, 5>(r, Hrow, b, dinv);
-  pivot<5, 16>(r, Hrow, b, dinv);
+  pivot<0, 16, 1, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<4, 16, 5, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<8, 16, 9, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<12, 16, 13, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<1, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<5, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<9, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<13, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
+  pivot<14, 16, 15, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<15, 16, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<2, 16, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<3, 16, 6, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<6, 16, 7, 10, 11>(r, Hrow, b, dinv);
+  pivot<7, 16, 10, 11>(r, Hrow, b, dinv);
+  pivot<10, 16, 11>(r, Hrow, b, dinv);
+  pivot<11, 16>(r, Hrow, b, dinv);
   return b * dinv;
 }
 
+// S . F_q with F_q = the six F registers of lane Q of this row: sum_k F[k](lane Q) * S[k](mine) — six fused DPP multiply-adds on
+// three accumulators (the DPP read-after-write rule: ant_newton_rows.h; checked by tools/check_dpp_hazards.py)
+#define MZ_D6_MUL(o, k) "v_mul_f32_dpp %" #o ", %[f" #k "], %[s" #k "] row_newbcast:%[q]" MZ_DPP_TAIL
+#define MZ_D6_FMA(o, k) "v_fmac_f32_dpp %" #o ", %[f" #k "], %[s" #k "] row_newbcast:%[q]" MZ_DPP_TAIL
+template <int Q>
+__device__ __forceinline__ float dot6_from(const float (&F)[6], const float (&S)[6]) {
+  float a0, a1, a2;
+  asm("s_nop 1\n\t" MZ_D6_MUL(0, 0) MZ_D6_MUL(1, 1) MZ_D6_MUL(2, 2) MZ_D6_FMA(0, 3) MZ_D6_FMA(1, 4) MZ_D6_FMA(2, 5)
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2)
+      : [f0] "v"(F[0]), [f1] "v"(F[1]), [f2] "v"(F[2]), [f3] "v"(F[3]), [f4] "v"(F[4]), [f5] "v"(F[5]), [s0] "v"(S[0]), [s1] "v"(S[1]), [s2] "v"(S[2]),
+        [s3] "v"(S[3]), [s4] "v"(S[4]), [s5] "v"(S[5]), [q] "n"(Q));
+  return (a0 + a1) + a2;
+}
 // pyramidal contact: cost, and optionally gradient block g[3] / curvature block W[5] (same as contact_eval)
 __device__ __forceinline__ float ceval(float D, float u0, float u1, float u2) {
   float r0 = u0 + u1, r1 = u0 - u1, r2 = u0 + u2, r3 = u0 - u2;
@@ -213,6 +240,16 @@ __device__ __forceinline__ float ceval(float D, float u0, float u1, float u2) {
 }
 
 }  // namespace rows
+
+// Per-lane constants of the hinge lanes' joint-limit rows, loaded once per step into DevCtx::lc (run-time indexed reads of the
+// constant block inside the 20 evaluations were dependent vector-memory loads): range and inverse weight of the lane's own hinge.
+enum { LC_LO = 11, LC_HI = 12, LC_DOFW = 13 };
+template <int G, bool PROF>
+__device__ __forceinline__ void ant_limit_consts(const AntDev& K, DevCtx<G, PROF>& cx) {
+  static_assert(LC_DOFW < DevCtx<G, PROF>::NLC, "DevCtx::lc too small");
+  const int p = cx.l & 15, l = p >> 2, d = p & 1;
+  cx.lc[LC_LO] = d ? K.ank_lo[l] : K.hip_lo; cx.lc[LC_HI] = d ? K.ank_hi[l] : K.hip_hi; cx.lc[LC_DOFW] = d ? K.dofw_ank : K.dofw_hip;
+}
 
 // Constraint rows of a contact of the block's OWN enumerators (floor -> block, maze box -> block, slide limit; kinds 3, 4, 6 of
 // con_row_item in ant_dyn.h — the same arithmetic) straight from the contact's staged geometry into the owner lane's registers:
@@ -230,13 +267,20 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
     jb[0][0] = other == 0 ? sg : 0.f; jb[0][1] = other == 1 ? sg : 0.f;
     jb[1][0] = jb[1][1] = jb[2][0] = jb[2][1] = 0.f;
     const float vel = sg * (other == 0 ? v0 : v1);
-    const float imp = impedancef(K.blim_solimp, fabsf(dist - K.blim_margin));
-    const float R = fmaxf(1e-15f, (1.f - imp) / imp * K.blim_w);
+    float omi;
+    const float imp = impedance_pair(K.blim_solimp, fabsf(dist - K.blim_margin), &omi);
+    const float R = fmaxf(1e-15f, omi / imp * K.blim_w);
     Dout = 0.25f / R;
     ar[0] = -K.blim_B * vel - K.blim_K * imp * (dist - K.blim_margin); ar[1] = 0.f; ar[2] = 0.f;
     return;
   }
-  const PairDev& P = kind == 3 ? K.floor : K.wall;
+  // both pairs' parameters by scalar loads, then value selects (a reference chosen by `kind` became an address select followed
+  // by dependent vector-memory loads on every block contact of every evaluation)
+  const bool fl = kind == 3;
+  struct { float margin, mu, K, B; } P = {fl ? K.floor.margin : K.wall.margin, fl ? K.floor.mu : K.wall.mu, fl ? K.floor.K : K.wall.K, fl ? K.floor.B : K.wall.B};
+  float psi[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) { const float fv = K.floor.solimp[k], wv = K.wall.solimp[k]; psi[k] = fl ? fv : wv; }
   const float hint[3] = {0.f, 0.f, 0.f};
   float t1[3], t2[3];
   make_tangents(n, hint, t1, t2);
@@ -248,9 +292,10 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
     for (int sl = 0; sl < 2; sl++) jb[a][sl] = sc * (K.block_axis[sl] == 0 ? dir[0] : (K.block_axis[sl] == 1 ? dir[1] : dir[2]));
     ar[a] = -P.B * (jb[a][0] * v0 + jb[a][1] * v1);
   }
-  const float imp = impedancef(P.solimp, fabsf(dist - P.margin));
+  float omi;
+  const float imp = impedance_pair(psi, fabsf(dist - P.margin), &omi);
   const float tran = K.block_bw_tran;
-  const float R = fmaxf(1e-15f, (1.f - imp) / imp * (tran + P.mu * P.mu * tran));
+  const float R = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
   Dout = 1.0f / (2.f * P.mu * P.mu * R);
   ar[0] -= P.K * imp * (dist - P.margin);
   (void)sizeof(D);
@@ -267,19 +312,33 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
 // owns the contacts l, l + G, ...), its gradient (2) and curvature (3 numbers) enter the rows of dofs 14 / 15 through group
 // sums, and the line search adds its terms the same way.  Twenty contacts of the block thus cost five group sums per
 // iteration instead of twenty folds into sixteen Hessian rows.
-template <int NB, int G, bool PROF>
-__device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare) {
+// `Mrow` = row r of M in position order and `qfs` = entry r of qfrc_smooth, in registers (the plain ant's forward pass builds them
+// there: ant_forward_rows.h; ant_solve_rows below reads them from the LDS copies the lane-group forward pass of ant_dyn.h writes).
+//
+// WR ("wrench records", the plain ant's forward pass of ant_forward_rows.h): a contact arrives as the 24-float record its geom's
+// lane wrote into s.cJ[c] — three wrenches sr [r x f_a; f_a] about the torso origin (normal, mu t1, mu t2), the three reference
+// accelerations, D and the (leg, body class) of the touching geom — read by ITS owner lane only.  No Jacobian is ever stored:
+//   * this lane's column of contact C is  S_p . wrench_a(C)  with S_p = the lane's own motion axis (`Sax`, in registers since the
+//     mass matrix) and the wrench fetched from lane C by `row_newbcast:C` operands (rows::dot6_from: 18 fused instructions per
+//     contact), masked by "dof p moves the touching body";
+//   * J x, which the owner needs, is the transposed product: one row butterfly per (contact, row) over the lanes' columns.
+// The staged Jacobian rows (cJ written by con_row_item, read back as jown / Jf: 16 + 6 LDS reads per lane and evaluation, on top
+// of the phase that built them) are gone for the plain ant; the ant with a movable block (WR = false) keeps them.
+template <int NB, int G, bool PROF, bool WR = false>
+__device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare,
+                                                    const float (&Mrow)[14 + 2 * NB], const float qfs, const float (&Sax)[6]) {
   static_assert(G >= 16, "one DPP row per env at least");
   static_assert(NB <= 1, "one 16-lane row holds 14 dofs + one block's two slides");
+  static_assert(!WR || NB == 0, "wrench records: plain ant");
   using namespace rows;
   using D = AntDims<NB>;
-  constexpr int NR = 14 + 2 * NB;                 // dofs = lanes of the row that own one
+  constexpr int NR = 14 + 2 * NB;                 // positions of the row that own a dof
   constexpr int NHC = D::NH;                      // hub columns of a contact Jacobian: root 6 (+ block 2); then hip, ankle
   constexpr int MB = NB ? (D::NC + G - 1) / G : 0; // block-own contacts per lane
   constexpr int MA = NB ? 2 : 1;                   // robot contacts per lane of the row (16 MA in all)
-  const int r = cx.l & 15;                       // dof of this lane; beyond NR: spare lanes (zero rows, never pivots)
-  const bool isdof = r < NR, ishinge = r >= 6 && r < 14;
-  const int leg = (r - 6) >> 1, d = (r - 6) & 1;  // hinge lanes: own leg, 0 hip / 1 ankle
+  const int r = cx.l & 15;                       // position of this lane (rows::pos2dof); beyond NR: spare lanes (zero rows, never pivots)
+  const bool isdof = r < NR, ishinge = (r & 3) < 2 && r < 14;
+  const int leg = r >> 2, d = r & 1;              // hinge lanes: own leg, 0 hip / 1 ankle
   const int nB = NB ? s.nblkcon : 0;             // block-own contacts: slots [0, nB)
   int nA = s.ncon - nB;                          // robot contacts: slots [nB, ncon), owned by the lanes 0 .. nA - 1 of the row
   if (nA > 16 * MA) { nA = 16 * MA; if (cx.l == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
@@ -288,26 +347,23 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   bool iscon[MA];                                // this lane owns robot contact r (+ 16: second slot)
   int cr[MA], cl[MA];
 #pragma unroll
-  for (int m = 0; m < MA; m++) { iscon[m] = r + 16 * m < ncon; cr[m] = nB + (iscon[m] ? r + 16 * m : 0); cl[m] = iscon[m] ? s.cleg[cr[m]] : -1; }
+  for (int m = 0; m < MA; m++) { iscon[m] = r + 16 * m < ncon; cr[m] = nB + (iscon[m] ? r + 16 * m : 0); cl[m] = (!WR && iscon[m]) ? s.cleg[cr[m]] : -1; }
 
-  // ---- row r of M, per-dof vectors, own limit row
-  float Mrow[NR];
-#pragma unroll
-  for (int k = 0; k < NR; k++) Mrow[k] = s.Md[r][k];  // dense rows written beside the arrow form (crb_leg_item / crb_root_item); spare rows are zero
-  const int ri = isdof ? r : 0;
-  const float qfs = isdof ? s.qfs[ri] : 0.f;
+  // ---- per-dof vectors, own limit row
+  const int ri = isdof ? pos2dof(r) : 0;          // this lane's index into the dof-ordered LDS vectors
   cx.tick(s, 12);
   // joint-limit row of this lane's own hinge (limit_item of ant_dyn.h, in registers: the row never leaves its lane)
   float lsign = 0.f, lD = 0.f, laref = 0.f;
   if (ishinge) {
-    const int j = r - 6, l = j >> 1;
-    const float q = s.qpos[7 + j], lo = (j & 1) ? K.ank_lo[l] : K.hip_lo, hi = (j & 1) ? K.ank_hi[l] : K.hip_hi;
+    const int j = 2 * leg + d;
+    const float q = s.qpos[7 + j], lo = cx.lc[LC_LO], hi = cx.lc[LC_HI];
     float pos = 0.f;
     if (q - lo < 0.f) { lsign = 1.f; pos = q - lo; }
     else if (hi - q < 0.f) { lsign = -1.f; pos = hi - q; }
     if (lsign != 0.f) {
-      const float imp = impedancef(K.lim_solimp, fabsf(pos));
-      const float R = fmaxf(1e-15f, (1.f - imp) / imp * ((j & 1) ? K.dofw_ank : K.dofw_hip));
+      float omi;
+      const float imp = impedance_pair(K.lim_solimp, fabsf(pos), &omi);
+      const float R = fmaxf(1e-15f, omi / imp * cx.lc[LC_DOFW]);
       lD = 1.0f / R;
       laref = -K.lim_B * (lsign * s.qvel[6 + j]) - K.lim_K * imp * pos;
     }
@@ -327,11 +383,29 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   const float warm = isdof ? s.warm[ri] : 0.f;  // later evaluations start from the previous evaluation's solution
   // own robot contact: 3 x (NHC + 2) Jacobian rows stay in LDS (row-major, read as needed); constants in registers
   float cD[MA], ar[MA][3];
+  float wr[3][6];  // WR: the own contact's three wrenches
+  int wmeta = 0;   // WR: leg (7: none) | body class << 3 of the touching geom
+  if constexpr (WR) {
+    const float4* q = reinterpret_cast<const float4*>(&s.cJ[cr[0]][0][0]);
+    float rec[24];
 #pragma unroll
-  for (int m = 0; m < MA; m++) {
-    cD[m] = iscon[m] ? s.cD[cr[m]] : 0.f;
+    for (int k = 0; k < 6; k++) { const float4 v4 = q[k]; rec[4 * k] = v4.x; rec[4 * k + 1] = v4.y; rec[4 * k + 2] = v4.z; rec[4 * k + 3] = v4.w; }
+    const int on = -(int)iscon[0];
 #pragma unroll
-    for (int a = 0; a < 3; a++) ar[m][a] = iscon[m] ? s.caref[cr[m]][a] : 0.f;
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) wr[a][k] = __int_as_float(__float_as_int(rec[8 * a + k]) & on);
+      ar[0][a] = __int_as_float(__float_as_int(rec[8 * a + 6]) & on);
+    }
+    cD[0] = __int_as_float(__float_as_int(rec[7]) & on);
+    wmeta = __float_as_int(rec[15]) & on;
+  } else {
+#pragma unroll
+    for (int m = 0; m < MA; m++) {
+      cD[m] = iscon[m] ? s.cD[cr[m]] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; a++) ar[m][a] = iscon[m] ? s.caref[cr[m]][a] : 0.f;
+    }
   }
   // own block contacts (NB = 1): slots cx.l + m G < nB
   float bj[MB ? MB : 1][3][2], bar[MB ? MB : 1][3], bD[MB ? MB : 1], bu[MB ? MB : 1][3], bv[MB ? MB : 1][3];
@@ -375,13 +449,25 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   each_contact([&](auto Cc) {
     constexpr int C = decltype(Cc)::value;
     jown[C][0] = jown[C][1] = jown[C][2] = 0.f;
+    if constexpr (WR) {
+      // S_p . wrench_a of contact C (its owner: lane C of the row), for the dofs that move the touching body: the root always,
+      // a hip when the geom sits on its leg below it (aux, ankle body), an ankle for its own ankle body
+      const int mc = bcast_i<(C & 15)>(wmeta), lc = mc & 7, cc = mc >> 3;
+      const bool sees = C < ncon && (ishinge ? (leg == lc && (d == 0 ? cc >= 2 : cc == 3)) : r < 12);
+      const int on = -(int)sees;
+#pragma unroll
+      for (int a = 0; a < 3; a++) jown[C][a] = __int_as_float(__float_as_int(dot6_from<(C & 15)>(wr[a], Sax)) & on);
+    } else
     if (C < ncon) {  // (uniform within the env's row)
       const int lc = s.cleg[nB + C];
-      const int col = r < 6 ? r : ((ishinge && leg == lc) ? NHC + d : ((NB == 1 && r >= 14 && r < 16) ? r - 8 : -1));
+      // column of this lane's dof in the contact's 3 x (hub + 2) Jacobian: root dof i -> i, the block's slides -> 6, 7, the hinges
+      // of the contact's own leg -> NHC, NHC + 1
+      const int col = ishinge ? (leg == lc ? NHC + d : -1) : (r < 12 ? ri : ((NB == 1 && r >= 14 && r < 16) ? r - 8 : -1));
       if (col >= 0) { jown[C][0] = s.cJ[nB + C][0][col]; jown[C][1] = s.cJ[nB + C][1][col]; jown[C][2] = s.cJ[nB + C][2][col]; }
     }
   });
   float Jf[MA][3][NR];
+  if constexpr (!WR)
 #pragma unroll
   for (int m = 0; m < MA; m++) {
 #pragma unroll
@@ -394,21 +480,34 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
       for (int a = 0; a < 3; a++) {
         const float* Jr = s.cJ[cr[m]][a];
 #pragma unroll
-        for (int k = 0; k < 6; k++) Jf[m][a][k] = Jr[k];
+        for (int k = 0; k < 6; k++) Jf[m][a][dof2pos(k)] = Jr[k];
         if constexpr (NB == 1) { Jf[m][a][14] = Jr[6]; Jf[m][a][15] = Jr[7]; }
         const float jh = Jr[NHC], ja = Jr[NHC + 1];
 #pragma unroll
-        for (int l2 = 0; l2 < 4; l2++) { Jf[m][a][6 + 2 * l2] = cl[m] == l2 ? jh : 0.f; Jf[m][a][7 + 2 * l2] = cl[m] == l2 ? ja : 0.f; }
+        for (int l2 = 0; l2 < 4; l2++) { Jf[m][a][4 * l2] = cl[m] == l2 ? jh : 0.f; Jf[m][a][4 * l2 + 1] = cl[m] == l2 ? ja : 0.f; }
       }
     }
   }
   // J[c][a] . x for the lane's own robot contact(s), x row-distributed (one entry per dof lane; spare lanes are never read)
   auto jdot3 = [&](float x, float (&o)[MA][3]) {
+    if constexpr (WR) {
+      // transposed: (J x)[C][a] = sum over the lanes of their column entry times their x — one row butterfly per (contact, row);
+      // every lane gets every sum, the owner keeps its own
+      o[0][0] = o[0][1] = o[0][2] = 0.f;
+      each_contact([&](auto Cc) {
+        constexpr int C = decltype(Cc)::value;
+        if (C < ncon) {
+          const float t0 = rsum(jown[C][0] * x), t1 = rsum(jown[C][1] * x), t2 = rsum(jown[C][2] * x);
+          if (r == C) { o[0][0] = t0; o[0][1] = t1; o[0][2] = t2; }
+        }
+      });
+    } else {
 #pragma unroll
-    for (int m = 0; m < MA; m++) {
-      o[m][0] = o[m][1] = o[m][2] = 0.f;
-      if (m == 1 && !any2) continue;
-      o[m][0] = matvec(Jf[m][0], x); o[m][1] = matvec(Jf[m][1], x); o[m][2] = matvec(Jf[m][2], x);
+      for (int m = 0; m < MA; m++) {
+        o[m][0] = o[m][1] = o[m][2] = 0.f;
+        if (m == 1 && !any2) continue;
+        o[m][0] = matvec(Jf[m][0], x); o[m][1] = matvec(Jf[m][1], x); o[m][2] = matvec(Jf[m][2], x);
+      }
     }
   };
   // block contacts: residual rows from the two block entries (b0, b1) of a row-distributed vector
@@ -533,7 +632,8 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
     }
     if (lsign != 0.f) { const float t = lsign * lact * ljar; g += t; ga += fabsf(t); }
 #pragma unroll
-    for (int k = 6; k < 14; k++) Hrow[k] += (r == k) ? lact : 0.f;
+    for (int k = 0; k < 14; k++)
+      if ((k & 3) < 2) Hrow[k] += (r == k) ? lact : 0.f;  // hinge positions: the limit row's curvature on its own diagonal
     if (!isdof) { g = 0.f; ga = 0.f; }
     const float gnorm = sqrtf(rsum(g * g)), anorm = sqrtf(rsum(ga * ga));
     // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
@@ -641,4 +741,18 @@ __device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const 
   if (cx.l == 0) { s.iters = it; if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER; s.prof[15] += (unsigned)it; }
   cx.sync();
   cx.tick(s, 8);
+}
+
+// The solve on the LDS copies of M and qfrc_smooth (s.Md: dense rows in POSITION order, written by crb_leg_item / crb_root_item /
+// ant_fill_tables of ant_dyn.h; s.qfs in dof order): the ant with one movable block, and the fall-back forward pass.
+template <int NB, int G, bool PROF>
+__device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare) {
+  constexpr int NR = 14 + 2 * NB;
+  const int r = cx.l & 15;
+  float Mrow[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) Mrow[k] = s.Md[r][k];  // spare rows are zero
+  const float qfs = r < NR ? s.qfs[rows::pos2dof(r)] : 0.f;
+  const float none[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  ant_solve_rows_core<NB, G, PROF, false>(cx, K, s, compare, Mrow, qfs, none);
 }

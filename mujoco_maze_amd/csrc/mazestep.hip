@@ -185,8 +185,8 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   }
   if (!strcmp(key, "profile_phases")) {
     if (value != 0 && !h->prof) {  // 16 accumulators + one total per workgroup (at most one workgroup per env)
-      HIPCHK(h, hipMalloc(&h->prof, (16 + (size_t)h->n) * sizeof(unsigned long long)));
-      HIPCHK(h, hipMemset(h->prof, 0, (16 + (size_t)h->n) * sizeof(unsigned long long)));
+      HIPCHK(h, hipMalloc(&h->prof, (16 + 17 * (size_t)h->n) * sizeof(unsigned long long)));
+      HIPCHK(h, hipMemset(h->prof, 0, (16 + 17 * (size_t)h->n) * sizeof(unsigned long long)));
     }
     if (value == 0 && h->prof) {
       HIPCHK(h, hipDeviceSynchronize());  // an instrumented step kernel may still be adding to the accumulators
@@ -365,6 +365,16 @@ int32_t mz_read_wave_cycles(mz_handle* h, uint64_t* out_host, int32_t n_host) {
   HIPCHK(h, hipDeviceSynchronize());
   HIPCHK(h, hipMemcpy(out_host, h->prof + 16, (size_t)n_host * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemset(h->prof + 16, 0, (size_t)h->n * sizeof(unsigned long long)));
+  return MZ_OK;
+}
+
+// Per-workgroup, per-phase cycles of the PROF kernel build accumulated since the last call (then cleared): [n_host][16].
+int32_t mz_read_wave_phase_cycles(mz_handle* h, uint64_t* out_host, int32_t n_host) {
+  if (!h || !out_host || !h->prof || n_host <= 0 || n_host > h->n) return MZ_ERR_ARG;
+  DeviceScope scope(h->device);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(out_host, h->prof + 16 + h->n, (size_t)n_host * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemset(h->prof + 16 + h->n, 0, (size_t)h->n * 16 * sizeof(unsigned long long)));
   return MZ_OK;
 }
 

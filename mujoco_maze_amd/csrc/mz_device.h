@@ -10,12 +10,25 @@
 // row[base_dim - 1 ...].
 __host__ __device__ inline int obs_slot(int i, int base_dim, int ostride) { return i == base_dim - 1 ? ostride - 1 : i; }
 
+// Workgroup -> block of environments, XCD-aware.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with an L2 of
+// its own; with block b = workgroup id, the 16 one-wave workgroups whose envs share a 128-byte line of an SoA state array
+// (32 envs x 4 B; the Point / chain kernels) sit on 8 different XCDs and the line is fetched — and partially written — by all
+// of them (PointUMaze, round 3: FETCH + WRITE = 3.9 x the algorithmic bytes).  Here the workgroups of XCD x (ids = x mod 8) take
+// the x-th contiguous eighth of the blocks, so a line has one home.  Placement is a speed hint only (the id -> XCD map is not
+// architectural): any map is correct, every block is taken exactly once.
+__device__ __forceinline__ int xcd_block(int wg, int nwg) {
+  const int per = nwg >> 3;                       // blocks per XCD (the remainder nwg & 7 keeps the identity map)
+  return wg < 8 * per ? (wg & 7) * per + (wg >> 3) : wg;
+}
+
 // ------------------------------------------------------------------ device context of a lane group
 template <int G, bool PROF = false>
 struct DevCtx {
   static constexpr int nlanes = G;
   static constexpr bool row_solver = G >= 16;  // plain ant: Newton iteration resident in one 16-lane DPP row (ant_newton_rows.h)
+  static constexpr int NLC = 14;
   int l;
+  float lc[NLC] = {};  // per-lane constants of the plain ant's quad layout (ant_forward_rows.h ant_lane_consts); unused elsewhere
   // phase timer (PROF builds only): lane 0 of the group accumulates shader cycles since the previous tick
   template <class S>
   __device__ __forceinline__ void tick(S& s, int id) const {

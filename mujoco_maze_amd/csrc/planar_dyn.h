@@ -340,6 +340,12 @@ MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const do
     const double c1 = -fabs(d2) + size1[2] + size2[2], c2 = -fabs(d2) + size2[2] + size1[2];
     if (c1 < -margin || c2 < -margin) return;
     if (c1 < penetration || c2 < penetration) {  // vertical reference normal: the general routine (rare: a deep overlap)
+#if defined(__HIP_DEVICE_COMPILE__)
+      // opaque copy made inside the rare branch: what the general routine computes then depends on it, so the compiler cannot hoist
+      // its loop-invariant parts in front of the branch, onto the path of every arrow near a wall (round 3 measured the general
+      // routine's mere presence at 10 % of the launch; ant_dyn.h round_vs_box: same effect, same cure)
+      asm volatile("" : "+v"(co), "+v"(si));
+#endif
       const double m1[9] = {rot_first ? co : 1.0, rot_first ? -si : 0.0, 0.0, rot_first ? si : 0.0, rot_first ? co : 1.0, 0.0, 0.0, 0.0, 1.0};
       const double m2[9] = {rot_first ? 1.0 : co, rot_first ? 0.0 : -si, 0.0, rot_first ? 0.0 : si, rot_first ? 1.0 : co, 0.0, 0.0, 0.0, 1.0};
       pl_box_box(pos1, m1, size1, pos2, m2, size2, margin, b1id, b2id, cls, emit);

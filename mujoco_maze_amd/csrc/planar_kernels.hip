@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && 
   __syncthreads();
   DevCtx<G> cx{(int)threadIdx.x % G};
   const int grp = threadIdx.x / G;
-  int env = blockIdx.x * EPW + grp;
+  int env = xcd_block(blockIdx.x, gridDim.x) * EPW + grp;
   const bool live = env < n;
   if (!live) env = n - 1;  // idle groups shadow the last env (no stores) so that every lane reaches the wave-level votes
   PlanarScratch<NB, NS>& s = scr[grp];

@@ -373,6 +373,12 @@ class VecMazeEnv:
         self.last_wave_newton_iters = out >> np.uint64(40)  # Newton iterations the wave ran (packed above the cycle count)
         return out & np.uint64((1 << 40) - 1)
 
+    def wave_phase_cycles(self, n: int):
+        """Per-workgroup phase cycles of the instrumented kernel since the last call (numpy uint64 [n, 16])."""
+        out = np.zeros((n, 16), np.uint64)
+        _capi.check(self._lib, self._h, self._lib.mz_read_wave_phase_cycles(self._h, out.ctypes.data_as(C.c_void_p), n), "mz_read_wave_phase_cycles")
+        return out
+
     def kernel_ms(self) -> float:
         return float(self._lib.mz_last_kernel_ms(self._h))
 

@@ -29,39 +29,118 @@ def _f32(st):
     return out
 
 
-def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, atol=ATOL, max_outlier_frac=0.002, hard_atol=None):
+BRANCH_ATOL = 5e-5  # device vs the oracle's one-sided limit at a discontinuity of the step map (see _assert_step_parity)
+
+
+def _tie_mixture(dev, a, seen, branch_atol):
+    """An EXACT tie, re-decided at every RK4 stage: a Point teleported onto the diagonal of a block sees two faces at the same depth,
+    and so it does at each of the four stages of the step (the configuration stays symmetric) — which face wins a stage is decided
+    by the last bit of two equal numbers.  The oracle, perturbed at 1e-6, lands on one side for ALL stages (outcome A or B); the
+    device, like the unperturbed oracle, may pick per stage, and its step is then the RK4-weighted blend of the two: a point ON
+    THE SEGMENT between A and B.  That is what is demanded here: some perturbed outcome B (clearly distinct from A) with dev within
+    branch_atol + 2 % |B - A| of A + lambda (B - A), 0 <= lambda <= 1."""
+    for b in seen:
+        ab = b - a
+        nab = np.abs(ab).max()
+        if nab < 100 * branch_atol:
+            continue
+        lam = float(np.dot(dev - a, ab) / np.dot(ab, ab))
+        if -0.02 <= lam <= 1.02 and np.abs(dev - (a + lam * ab)).max() <= branch_atol + 0.02 * nab:
+            return True
+    return False
+
+
+def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, atol=ATOL, max_outlier_frac=0.002, hard_atol=None, dev_out=None,
+                        branch_atol=BRANCH_ATOL):
     """Per-DoF parity after one env.step: EVERY env is inside |dev - oracle| <= atol + 1e-5 |oracle| on qpos and qvel, or
-    the float64 oracle is itself discontinuous there.
+    sits on a discontinuity of the step map AND agrees with the float64 oracle's value on the device's side of it.
 
     MuJoCo's soft constraints switch on at `dist < margin` / `q < limit` with a velocity-dependent (damping) term, and the
     box rules pick faces by comparisons, so the step map has jumps: an env whose contact crosses such a threshold within
-    fp32 round-off legitimately lands on the other branch.  Such an env is accepted only if the oracle ITSELF is that
-    sensitive: re-running it from the same state perturbed at the scale of the device's round-off must move its own answer by
-    more than the tolerance.  Scales: 2e-7 (one fp32 ulp of the state), 1e-6 (what absolute coordinates of ~10 m carry in
-    fp32) and 5e-6 (the error the device's intermediate states carry INSIDE the step: a forward evaluation is good to
-    2e-4 in qacc — test_ant_forward_dynamics_and_contact_counts — i.e. 4e-6 in the velocity of the next RK4 stage).  Two
-    fp32 implementations of the step (the 8-lane generic solver and the 16-lane row solver of the same library) part ways
-    at this rate too: 183 of 819 200 env-steps, tools/dbg_outlier.py.
-    `max_outlier_frac` caps how many envs may need that excuse (<= 2x what was measured: profiles/r02/parity.md).
-    `hard_atol` (block mazes only): an outlier inside this looser bound is accepted as round-off of the ~50x stiffer rows
-    (solimp .995, 0.2 g block) without the sensitivity proof; beyond it the proof is required."""
+    fp32 round-off legitimately lands on the other branch.  For every env outside the tolerance (round 4: no env is
+    masked out any more):
+      1. the oracle is re-run from the same state perturbed at the scale of the device's round-off — 2e-7 (one fp32 ulp of the
+         state), 1e-6 (what absolute coordinates of ~10 m carry in fp32), 5e-6 (the error the device's intermediate states carry
+         INSIDE the step: a forward evaluation is good to 2e-4 in qacc, i.e. 4e-6 in the velocity of the next RK4 stage).  Some
+         perturbed run must land nearer to the device's answer than to the unperturbed oracle's: the oracle itself is
+         discontinuous there, and that run is on the device's branch;
+      2. bisection between the unperturbed start (oracle's branch) and that perturbed start (device's branch) walks up to the
+         discontinuity: the last state on the device's side differs from the given start by < 1e-8 — nothing at the resolution of
+         an fp32 state — and the oracle's step from THERE is what the device is compared with: qpos / qvel (and, with
+         `dev_out` = (obs, reward, done) of the device, observation, reward and flags) within `branch_atol`.  Several
+         discontinuities within round-off of each other (a block on four corners) are crossed one at a time, up to five;
+      3. the one case without a branch of the oracle to compare with is an exact tie that every RK4 stage decides anew
+         (_tie_mixture): the device must then lie on the segment between two outcomes of the oracle.
+    `max_outlier_frac` caps how many envs may take that route (<= 2x what was measured: profiles/r02/parity.md).
+    `hard_atol` (kept for the Fall mazes' first steps only, [ASSUME-14]): an outlier inside this looser bound is accepted as
+    round-off without the proof.  Returns the mask of the envs inside the plain tolerance."""
     ok = np.all(_close(dev_qpos, ref_state["qpos"], atol=atol), axis=1) & np.all(_close(dev_qvel, ref_state["qvel"], atol=atol), axis=1)
     bad = np.where(~ok)[0]
     assert len(bad) <= max(1, int(max_outlier_frac * len(ok))), (len(bad), len(ok), np.abs(dev_qvel - ref_state["qvel"]).max())
     rng = np.random.default_rng(123)
+
+    def run(p, e):
+        out = oracle.step(cm, p, act[e:e + 1].astype(np.float64))
+        return p, out
+
+    def dist_to(p, qpos, qvel):
+        return max(np.abs(p["qpos"][0] - qpos).max(), np.abs(p["qvel"][0] - qvel).max())
+
     for e in bad:
         if hard_atol is not None and np.all(_close(dev_qpos[e], ref_state["qpos"][e], atol=hard_atol)) and np.all(_close(dev_qvel[e], ref_state["qvel"][e], atol=hard_atol)):
             continue
-        spread = 0.0
-        for scale in (2e-7, 1e-6, 5e-6):
-            for _ in range(12):
-                p = {k: v[e:e + 1].copy() for k, v in start.items()}
-                p["qpos"] = p["qpos"] + rng.uniform(-scale, scale, p["qpos"].shape) * np.maximum(1.0, np.abs(p["qpos"]))
-                p["qvel"] = p["qvel"] + rng.uniform(-scale, scale, p["qvel"].shape) * np.maximum(1.0, np.abs(p["qvel"]))
-                oracle.step(cm, p, act[e:e + 1].astype(np.float64))
-                spread = max(spread, np.abs(p["qvel"] - ref_state["qvel"][e]).max())
-        assert spread > atol, f"env {e}: device differs from the oracle by {np.abs(dev_qvel[e] - ref_state['qvel'][e]).max():.2e} " \
-                              f"but the oracle is smooth there (spread {spread:.2e})"
+        err = max(np.abs(dev_qvel[e] - ref_state["qvel"][e]).max(), np.abs(dev_qpos[e] - ref_state["qpos"][e]).max())
+        base = {k: v[e:e + 1].copy() for k, v in start.items()}
+        # walk from the given start towards the device's side, one discontinuity at a time (a block resting on four corners, a foot
+        # in a wall corner: several activation thresholds within round-off of each other)
+        cur, cur_res, cur_out, mixed = base, (ref_state["qpos"][e], ref_state["qvel"][e]), None, False
+        for _round in range(5):
+            d_cur = max(np.abs(cur_res[0] - dev_qpos[e]).max(), np.abs(cur_res[1] - dev_qvel[e]).max())
+            if cur_out is not None and np.all(_close(dev_qpos[e], cur_res[0], atol=branch_atol)) and np.all(_close(dev_qvel[e], cur_res[1], atol=branch_atol)):
+                break
+            best, best_d, best_res = None, d_cur, None
+            seen = []
+            for scale in (2e-7, 1e-6, 5e-6):
+                for _ in range(12):
+                    p0 = {k: v.copy() for k, v in cur.items()}
+                    p0["qpos"] = p0["qpos"] + rng.uniform(-scale, scale, p0["qpos"].shape) * np.maximum(1.0, np.abs(p0["qpos"]))
+                    p0["qvel"] = p0["qvel"] + rng.uniform(-scale, scale, p0["qvel"].shape) * np.maximum(1.0, np.abs(p0["qvel"]))
+                    p, _ = run({k: v.copy() for k, v in p0.items()}, e)
+                    seen.append(np.concatenate([p["qpos"][0], p["qvel"][0]]))
+                    d_dev = dist_to(p, dev_qpos[e], dev_qvel[e])
+                    if d_dev < 0.5 * best_d or (best is None and d_dev < 0.9 * d_cur and d_dev < best_d):
+                        best, best_d, best_res = p0, d_dev, (p["qpos"][0].copy(), p["qvel"][0].copy())
+            if best is None and _tie_mixture(np.concatenate([dev_qpos[e], dev_qvel[e]]), np.concatenate(cur_res), seen, branch_atol):
+                mixed = True
+                break
+            assert best is not None, f"env {e}: device differs from the oracle by {err:.2e} ({d_cur:.2e} after {_round} discontinuities) and no perturbation of the " \
+                                     f"start state at round-off scale brings the oracle nearer: the oracle is smooth there"
+            # bisection: lo = a start whose outcome is cur's, hi = one whose outcome is the nearer one; keep the nearer side
+            lo, hi, hi_pack = cur, best, None
+            for _ in range(14):
+                mid = {k: (0.5 * (lo[k] + hi[k]) if k in ("qpos", "qvel", "warm") else hi[k].copy()) for k in hi}
+                p, out = run({k: v.copy() for k, v in mid.items()}, e)
+                if dist_to(p, best_res[0], best_res[1]) < dist_to(p, cur_res[0], cur_res[1]):
+                    hi, hi_pack = mid, (p, out)
+                else:
+                    lo = mid
+            if hi_pack is None:
+                hi_pack = run({k: v.copy() for k, v in hi.items()}, e)
+            cur, cur_out = hi, hi_pack[1]
+            cur_res = (hi_pack[0]["qpos"][0].copy(), hi_pack[0]["qvel"][0].copy())
+        moved = max(np.abs(cur["qpos"] - base["qpos"]).max(), np.abs(cur["qvel"] - base["qvel"]).max())
+        assert moved < 2e-5, (e, moved)
+        if mixed:
+            continue  # between two outcomes of the oracle (an exact tie re-decided at every RK4 stage): nothing further to compare with
+        assert np.all(_close(dev_qpos[e], cur_res[0], atol=branch_atol)) and np.all(_close(dev_qvel[e], cur_res[1], atol=branch_atol)), \
+            f"env {e}: {err:.2e} off the oracle; on the device's side of the discontinuities (start moved by {moved:.1e}) the oracle is still " \
+            f"{max(np.abs(cur_res[0] - dev_qpos[e]).max(), np.abs(cur_res[1] - dev_qvel[e]).max()):.2e} away"
+        if dev_out is not None:
+            d_obs, d_rew, d_done = dev_out
+            out = cur_out
+            assert np.all(_close(d_obs[e], out["obs"][0], atol=branch_atol)), f"env {e}: observation off the oracle's on the device's branch"
+            assert abs(float(d_rew[e]) - float(out["reward"][0])) <= branch_atol + 1e-4 * abs(float(out["reward"][0])), f"env {e}: reward off on the device's branch"
+            assert int(d_done[e]) == int(out["done"][0]), f"env {e}: done flag differs from the oracle's on the device's branch"
     return ok
 
 
@@ -140,7 +219,7 @@ def test_ant_single_step_parity(torch, oracle, env_id):
         obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
         qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
         ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)  # advances st in place
-        ok = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st)
+        ok = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
         assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok]))
         assert np.all(_close(rew.cpu().numpy()[ok], ref["reward"][ok], atol=1e-6))
         assert np.array_equal(done.cpu().numpy(), ref["done"])
@@ -227,7 +306,7 @@ def test_ant_wall_contacts_and_goal(torch, oracle):
     qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
     ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     # stiff, partly artificial wall penetrations: measured 1 env of 64 on an activation flip (oracle-sensitive), the rest inside 1e-5
-    good = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, max_outlier_frac=2 / 64)
+    good = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, max_outlier_frac=2 / 64, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
     assert np.all(_close(obs.cpu().numpy()[good], ref["obs"][good]))
     assert np.array_equal(done.cpu().numpy(), ref["done"]) and ref["done"][n // 2:].sum() > 5
     assert np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
@@ -273,12 +352,21 @@ def test_ant_corner_contacts_overflow_the_staging(torch, oracle):
     obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
     qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
     ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    status = env.status().cpu().numpy()
+    # An env with more simultaneous contacts than the kernel's 16 slots loses the surplus ones and SAYS so (MZ_STATUS_CONTACT_OVERFLOW,
+    # per env): it is not a parity case — the oracle keeps all of them — and it is not silent.  Every env that starts beyond the
+    # slots must carry the flag; parity is demanded of every env without it.
+    flagged = (status & 2) != 0
+    assert flagged[nc > 16].all() and flagged.sum() <= 12, (np.where(nc > 16)[0], np.where(flagged)[0])
+    keep = np.where(~flagged)[0]
+    sub = lambda d: {k: v[keep] for k, v in d.items()}
     # ants dropped INTO a wall corner (leg segments through the boxes): far more activation flips than any rollout state has — every
-    # outlier must still be proven on the oracle
-    good = _assert_step_parity(oracle, cm, start, act, qpos, qvel, st, max_outlier_frac=0.08)
-    assert np.all(_close(obs.cpu().numpy()[good], ref["obs"][good]))
+    # outlier must still be matched with the oracle's value on its side of the discontinuity
+    good = _assert_step_parity(oracle, cm, sub(start), act[keep], qpos[keep], qvel[keep], sub(st), max_outlier_frac=0.08,
+                               dev_out=(obs.cpu().numpy()[keep], rew.cpu().numpy()[keep], done.cpu().numpy()[keep]))
+    assert np.all(_close(obs.cpu().numpy()[keep][good], ref["obs"][keep][good]))
     assert np.array_equal(done.cpu().numpy(), ref["done"])
-    assert np.all((env.status().cpu().numpy() & 1) == 0)
+    assert np.all((status & 1) == 0)
     env.close()
 
 
@@ -301,10 +389,11 @@ def test_ant_push_movable_block(torch, oracle):
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             # Movable-block mazes switch every default geom to solimp .995 (maze_env.py:108-112): contact rows are ~50x stiffer
-            # than in AntUMaze and the block weighs 0.2 g, so the fp32 round-off of the Jacobians is amplified to 1.0-1.4e-5 on
-            # the torso's angular rates in <= 0.25 % of the envs (measured, profiles/r02/parity.md).  Bar: every env inside
-            # 1e-5 (+1e-5 rel) except <= 0.5 %, those inside 2e-5 — or on a discontinuity the float64 oracle shows itself.
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.005, hard_atol=2e-5)
+            # than in AntUMaze and the block weighs 0.2 g.  Round 4: the regulariser's (1 - d) is no longer formed in fp32 from
+            # d = 0.995 (impedance_pair, ant_dyn.h) and the absolute positions are carried as hi + lo pairs inside the step
+            # (AntScratchT::qlo): the 99.9 % quantile is 8e-6 (profiles/r04/parity.md) and the looser `hard_atol` bound of rounds
+            # 2-3 is gone — every env inside 1e-5 (+1e-5 rel), or matched with the oracle on its side of a discontinuity.
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.005, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
             assert np.median(per_env) < 2e-6
             assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=2e-5))
@@ -338,7 +427,7 @@ def test_ant_multi_block_mazes(torch, oracle, env_id, nblock):
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             # measured: <= 0.6 % of the envs outside 1e-5, each of them inside 2e-5 or on an oracle-visible discontinuity
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.006, hard_atol=2e-5)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.006, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
             worst.append(per_env[ok])
             assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=2e-5))
@@ -407,7 +496,7 @@ def test_point_with_movable_blocks(torch, oracle, env_id, nblock):
             assert np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
             # every env inside 2e-6 (the kernel computes in float64; what separates it from the oracle is the fp32 state it stores), or —
             # a robot teleported onto a block's diagonal sits on a tie between two faces — on a discontinuity the oracle shows itself
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-6, max_outlier_frac=0.004)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-6, max_outlier_frac=0.004, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1)[ok])
             assert np.array_equal(t, s64["t"])
             assert np.all((env.status().cpu().numpy() & ~8) == 0)
@@ -510,7 +599,7 @@ def test_point_fall_maze(torch, oracle):
             qpos, qvel, _, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-6, max_outlier_frac=0.004)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-6, max_outlier_frac=0.004, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             errs.append(np.abs(obs.cpu().numpy() - ref["obs"]).max(1)[ok])
             assert np.array_equal(t, s64["t"])
             assert np.all((env.status().cpu().numpy() & ~8) == 0)
@@ -555,7 +644,10 @@ def test_ant_fall_maze(torch, oracle, env_id):
             # at most 5 of 1024 — except k = 1, the step in which the block is being expelled from its platform, 4 m in 0.3 s against a
             # stiff limit row: 18 (Fall) / 32 (MultiFall) of 1024, none of them beyond 4.2e-5)
             cap = (0.064 if multi else 0.036) if k == 1 else 0.01
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=cap, hard_atol=4.5e-5 if k == 1 else 2e-5)
+            # The Fall family is held to 2e-5, not to the 1e-5 of the BASELINE configs, and says so here: a 1 g block on limited slides
+            # (limit rows with R from dof_invweight0 = 1 / m = 1000) next to rows at solimp .995 — measured 99.9 % quantile 1.4e-5
+            # (profiles/r04/parity.md).  No registered BASELINE config uses these mazes; [ASSUME-14] describes their first steps.
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-5, max_outlier_frac=cap, hard_atol=4.5e-5 if k == 1 else None, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             worst.append((np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)[ok])
             assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=4e-5))
             assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
@@ -841,7 +933,7 @@ def test_user_robot_xml_on_the_device(torch, oracle):
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
-            _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.01)
+            _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.01, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             assert np.array_equal(done.cpu().numpy(), ref["done"])
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     env.close()
@@ -899,7 +991,7 @@ def test_ant_small_billiard_free_joint_ball(torch, oracle):
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.01, hard_atol=1e-4)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.01, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok]))
             assert np.array_equal(done.cpu().numpy()[ok], ref["done"][ok])
             assert np.all(_close(rew.cpu().numpy()[ok], ref["reward"][ok], atol=1e-5))
@@ -1003,7 +1095,7 @@ def test_user_robot_of_another_topology_on_the_device(torch, oracle, which):
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, warm, t = [x.cpu().numpy() for x in env.get_state()]
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=1e-6, max_outlier_frac=0.0)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=1e-6, max_outlier_frac=0.0, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             assert ok.all()
             assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=1e-6)) and np.all(_close(rew.cpu().numpy(), ref["reward"], atol=1e-6))
             assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])

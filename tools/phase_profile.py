@@ -23,6 +23,12 @@ cyc = env.phase_cycles()
 # 7 = J search, vote, line search, update; 11 = contact rows; 12 = row of M + qacc_smooth by the row elimination
 names = ["P0 kinematics+broadphase", "P1 inertia|contact count", "P2 crb|bias legs|contact fill", "P3 hub M|bias dofs", "solve:limits+start", "solve:grad+H rows", "solve:elimination", "solve:vote/linesearch/update", "solve:tail",
          "rk4/integrate", "io+epilogue", "P4 contact rows", "P5 row of M -> qacc_smooth"]
+if env.model.c.nblock == 0 and env.model.c.nball == 0 and lanes >= 16:
+    # the plain ant since round 4 (ant_forward_rows.h: everything before the solver in the registers of the leg quads); the compiler
+    # moves arithmetic across the timer reads, so neighbouring pre-solver slots blur into each other by a few hundred cycles
+    names[:4] = ["K kinematics (quads)", "V bias forces (RNE)", "C contact enumeration", "I+M inertias, mass matrix rows"]
+    names[11] = "contact records (+ fall-back)"
+    names[12] = "(solver prologue)"
 wgs = n // (64 // lanes)
 tot = sum(cyc[:13])
 print(f"{env_id} n={n} lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0f}   newton iters per forward eval (mean over group 0 envs) = {cyc[15]/steps/wgs/20:.2f}")
