@@ -114,7 +114,9 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
     const int want = h->robot == MZ_ROBOT_SWIMMER ? 2 * kq + 1 + nb3 : 7 + nb3;
     h->base_obs = want;
     if (want + vdim != model->obs_dim || want > MZ_MAX_OBS) { delete h; return fail("mz_create: obs_dim mismatch"); }
-    e = hipMalloc(&h->state, (size_t)num_envs * 2 * kq * sizeof(float));
+    h->pt_rec = mzk_planar_record_width(h);
+    const size_t state_floats = (size_t)num_envs * (h->pt_rec ? h->pt_rec : 2 * kq);
+    e = hipMalloc(&h->state, state_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->pt_t, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->pt_ep, (size_t)num_envs * sizeof(uint32_t));
     if (h->robot == MZ_ROBOT_SWIMMER) {
@@ -124,7 +126,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
       if (e == hipSuccess) e = hipMalloc(&h->point_dev, sizeof(PointDev));
       if (e == hipSuccess) e = hipMemcpy(h->point_dev, &h->point, sizeof(PointDev), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * 2 * kq * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->state, 0, state_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->pt_t, 0, (size_t)num_envs * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->pt_ep, 0, (size_t)num_envs * sizeof(uint32_t));
   }

@@ -17,6 +17,9 @@ __host__ __device__ inline int obs_slot(int i, int base_dim, int ostride) { retu
 // the x-th contiguous eighth of the blocks, so a line has one home.  Placement is a speed hint only (the id -> XCD map is not
 // architectural): any map is correct, every block is taken exactly once.
 __device__ __forceinline__ int xcd_block(int wg, int nwg) {
+#ifdef MZ_EXP_NOXCD  // A/B experiment build (tools/exp_build.sh NOXCD): the identity map
+  return wg;
+#endif
   const int per = nwg >> 3;                       // blocks per XCD (the remainder nwg & 7 keeps the identity map)
   return wg < 8 * per ? (wg & 7) * per + (wg >> 3) : wg;
 }

@@ -33,6 +33,7 @@ struct mz_handle {
   float* state;         // ant: [n][REC]; point / swimmer: SoA [2 NV][n]
   int* pt_t;
   uint32_t* pt_ep;
+  int pt_rec;           // Point: floats per env-major state record (planar_kernels.hip PointState); 0: SoA
   int* status;
   ViewDev view;         // MazeTask.TOP_DOWN_VIEW: the maze bitmasks the view kernel reads (passed by value)
   int base_obs;         // observation width without the view; rows are model.obs_dim = base_obs (+ MZ_VIEW_DIM) floats apart
@@ -68,7 +69,8 @@ hipError_t mzk_point_detect(mz_handle* h, hipStream_t st, int n, const double* o
 // MazeEnv.get_top_down_view into the rows the step / reset kernel just wrote (no-op unless the task has TOP_DOWN_VIEW):
 // every row of obs, and the rows of final_obs of envs that finished (done != NULL: the step under auto-reset)
 hipError_t mzk_view_fill(mz_handle* h, hipStream_t st, float* obs, float* final_obs, const uint8_t* done);
-int mzk_planar_state_width(const mz_handle* h);  // coordinates per env of the SoA state (NV)
+int mzk_planar_state_width(const mz_handle* h);  // coordinates per env of the state (NV)
+int mzk_planar_record_width(const mz_handle* h); // Point: floats per env-major record; 0 for the chains (SoA)
 
 // ---- generic_kernels.hip (a user robot of any tree topology, csrc/generic_dyn.h)
 int mzk_generic_create(mz_handle* h, char* err, int errlen);  // builds + uploads the constant block; MZ_OK or MZ_ERR_*

@@ -23,8 +23,17 @@
 #include "mz_device.h"
 #include "mz_internal.h"
 
-// ------------------------------------------------------------------ Point kernels (SoA: q0 q1 q2 v0 v1 v2 | t | episode)
-struct PointState { float* qv; int* t; uint32_t* ep; };
+// ------------------------------------------------------------------ state in HBM
+// Chains (Swimmer / Reacher: 64 envs per workgroup): SoA qv[2 NV][n] + t[n] + episode[n] — a wave's loads of one coordinate are one line.
+// Point (`rec` > 0; round 4): env-major records qv[n][rec] = q[NV] | v[NV] | t | episode (| pad to a multiple of 4 floats).  A Point
+// workgroup is ONE wave = 2 envs (32 lanes each): in SoA it touched 8 bytes of eight different 128-byte lines per array pass, and
+// every such partial store left the L2 as a transaction of its own (PMC, round 4: WRITE_SIZE 1.9 MB per launch against 0.3 MB of
+// algorithmic writes, FETCH_SIZE 1.1 MB against 0.2); its two records are 64 contiguous bytes.
+struct PointState { float* qv; int* t; uint32_t* ep; int rec; };
+__device__ __forceinline__ float& st_q(const PointState& S, int n, int nv, int k, int env) { return S.rec ? S.qv[(size_t)env * S.rec + k] : S.qv[(size_t)k * n + env]; }
+__device__ __forceinline__ float& st_v(const PointState& S, int n, int nv, int k, int env) { return S.rec ? S.qv[(size_t)env * S.rec + nv + k] : S.qv[(size_t)(nv + k) * n + env]; }
+__device__ __forceinline__ int& st_t(const PointState& S, int nv, int env) { return S.rec ? reinterpret_cast<int*>(S.qv)[(size_t)env * S.rec + 2 * nv] : S.t[env]; }
+__device__ __forceinline__ uint32_t& st_ep(const PointState& S, int nv, int env) { return S.rec ? reinterpret_cast<uint32_t*>(S.qv)[(size_t)env * S.rec + 2 * nv + 1] : S.ep[env]; }
 
 // One MazeEnv.step of the Point (+ NB movable blocks or NS object balls): G lanes per env, PlanarScratch in LDS, SoA state in HBM
 // (q_0..q_{NV-1} | v_0..v_{NV-1}, each [n]).
@@ -50,9 +59,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && 
   const bool live = env < n;
   if (!live) env = n - 1;  // idle groups shadow the last env (no stores) so that every lane reaches the wave-level votes
   PlanarScratch<NB, NS>& s = scr[grp];
-  for (int k = cx.l; k < NV; k += G) { s.q[k] = (double)S.qv[(size_t)k * n + env]; s.v[k] = (double)S.qv[(size_t)(NV + k) * n + env]; }
+  for (int k = cx.l; k < NV; k += G) { s.q[k] = (double)st_q(S, n, NV, k, env); s.v[k] = (double)st_v(S, n, NV, k, env); }
   double a[2] = {(double)actions[(size_t)env * 2], (double)actions[(size_t)env * 2 + 1]};
-  const int t_new = S.t[env] + 1;
+  const int t_new = st_t(S, NV, env) + 1;
   cx.sync();
 #ifdef MZ_EXP_PROF
   if constexpr (NB == 0 && NS == 0) { if (cx.l == 0) { for (int k = 0; k < 12; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && 
       if (st) atomicOr(&status[env], st);
     }
   }
-  uint32_t ep = S.ep[env];
+  uint32_t ep = st_ep(S, NV, env);
   if (rst) {  // point.py:71-81: noise on the robot, blocks / ball back to their spawn state
     ep += 1;
     const uint64_t es = episode_seed(seed, ep);
@@ -109,10 +118,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && 
   }
   if (live) {
     for (int k = cx.l; k < NV; k += G) {
-      S.qv[(size_t)k * n + env] = (float)s.q[k];
-      S.qv[(size_t)(NV + k) * n + env] = (float)s.v[k];
+      st_q(S, n, NV, k, env) = (float)s.q[k];
+      st_v(S, n, NV, k, env) = (float)s.v[k];
     }
-    if (cx.l == 0) { S.t[env] = rst ? 0 : t_new; S.ep[env] = ep; }
+    if (cx.l == 0) { st_t(S, NV, env) = rst ? 0 : t_new; st_ep(S, NV, env) = ep; }
   }
 }
 
@@ -124,34 +133,34 @@ __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, cons
   if (env >= n) return;
   if (!mask || mask[env]) {
     for (int k = 0; k < NV; k++) {
-      S.qv[(size_t)k * n + env] = k < 3 ? reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k) : 0.f;
-      S.qv[(size_t)(NV + k) * n + env] = k < 3 ? reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k) : 0.f;
+      st_q(S, n, NV, k, env) = k < 3 ? reset_qpos((float)Pp->qpos0[k], seed, env0 + (uint64_t)env, k) : 0.f;
+      st_v(S, n, NV, k, env) = k < 3 ? reset_qvel(Pp->reset_kind, NV, seed, env0 + (uint64_t)env, k) : 0.f;
     }
-    S.t[env] = 0;
-    S.ep[env] = 0;
+    st_t(S, NV, env) = 0;
+    st_ep(S, NV, env) = 0;
   }
   if (obs) {
     const int nb3 = (Pp->observe_blocks ? 3 * NB : 0) + (Pp->observe_balls ? 3 * NS : 0);
     float* o = obs + (size_t)env * ostride;
-    for (int k = 0; k < 3; k++) { o[k] = S.qv[(size_t)k * n + env]; o[3 + nb3 + k] = S.qv[(size_t)(NV + k) * n + env]; }
+    for (int k = 0; k < 3; k++) { o[k] = st_q(S, n, NV, k, env); o[3 + nb3 + k] = st_v(S, n, NV, k, env); }
     if (NS > 0 && nb3) {
-      o[3] = (float)Pp->ball_pos0[0] + S.qv[(size_t)3 * n + env]; o[4] = (float)Pp->ball_pos0[1] + S.qv[(size_t)4 * n + env];
+      o[3] = (float)Pp->ball_pos0[0] + st_q(S, n, NV, 3, env); o[4] = (float)Pp->ball_pos0[1] + st_q(S, n, NV, 4, env);
       o[5] = (float)Pp->ball_pos0[2];
     }
     for (int b = 0; b < NB && nb3; b++) {
       float p3[3] = {(float)Pp->block_pos0[b][0], (float)Pp->block_pos0[b][1], (float)Pp->block_pos0[b][2]};
-      p3[Pp->block_axis[0]] += S.qv[(size_t)(3 + 2 * b) * n + env];
-      p3[Pp->block_axis[1]] += S.qv[(size_t)(4 + 2 * b) * n + env];
+      p3[Pp->block_axis[0]] += st_q(S, n, NV, 3 + 2 * b, env);
+      p3[Pp->block_axis[1]] += st_q(S, n, NV, 4 + 2 * b, env);
       o[3 + 3 * b] = p3[0]; o[4 + 3 * b] = p3[1]; o[5 + 3 * b] = p3[2];
     }
     if (ostride != NOBS)  // top-down view: block x, y parked for mzk_view_fill, time entry behind the view
       for (int b = 0; b < NB; b++) {
         float p3[3] = {(float)Pp->block_pos0[b][0], (float)Pp->block_pos0[b][1], (float)Pp->block_pos0[b][2]};
-        p3[Pp->block_axis[0]] += S.qv[(size_t)(3 + 2 * b) * n + env];
-        p3[Pp->block_axis[1]] += S.qv[(size_t)(4 + 2 * b) * n + env];
+        p3[Pp->block_axis[0]] += st_q(S, n, NV, 3 + 2 * b, env);
+        p3[Pp->block_axis[1]] += st_q(S, n, NV, 4 + 2 * b, env);
         o[NOBS - 1 + 2 * b] = p3[0]; o[NOBS + 2 * b] = p3[1];
       }
-    o[ostride - 1] = (float)S.t[env] * 0.001f;
+    o[ostride - 1] = (float)st_t(S, NV, env) * 0.001f;
   }
 }
 
@@ -160,21 +169,21 @@ __global__ void point_set_state_kernel(int n, PointState S, const float* qpos, c
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   for (int k = 0; k < KQ; k++) {
-    if (qpos) S.qv[(size_t)k * n + env] = qpos[(size_t)env * KQ + k];
-    if (qvel) S.qv[(size_t)(KQ + k) * n + env] = qvel[(size_t)env * KQ + k];
+    if (qpos) st_q(S, n, KQ, k, env) = qpos[(size_t)env * KQ + k];
+    if (qvel) st_v(S, n, KQ, k, env) = qvel[(size_t)env * KQ + k];
   }
-  if (t) S.t[env] = t[env];
+  if (t) st_t(S, KQ, env) = t[env];
 }
 template <int KQ>
 __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* qvel, float* warm, int* t) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= n) return;
   for (int k = 0; k < KQ; k++) {
-    if (qpos) qpos[(size_t)env * KQ + k] = S.qv[(size_t)k * n + env];
-    if (qvel) qvel[(size_t)env * KQ + k] = S.qv[(size_t)(KQ + k) * n + env];
+    if (qpos) qpos[(size_t)env * KQ + k] = st_q(S, n, KQ, k, env);
+    if (qvel) qvel[(size_t)env * KQ + k] = st_v(S, n, KQ, k, env);
     if (warm) warm[(size_t)env * KQ + k] = 0.f;
   }
-  if (t) t[env] = S.t[env];
+  if (t) t[env] = st_t(S, KQ, env);
 }
 
 // ------------------------------------------------------------------ Swimmer / Reacher kernels (NL links, one movable block with BD
@@ -349,13 +358,17 @@ __global__ void point_detect_kernel(const PointDev* __restrict__ Pp, int n, cons
 }
 
 // ------------------------------------------------------------------ entry points of this translation unit (mz_internal.h)
+// floats per env of the Point's env-major state record (q | v | t | episode, padded to 16 bytes); 0 = SoA (the chains)
+int mzk_planar_record_width(const mz_handle* h) {
+  return h->robot == MZ_ROBOT_POINT ? (2 * mzk_planar_state_width(h) + 2 + 3) / 4 * 4 : 0;
+}
 int mzk_planar_state_width(const mz_handle* h) {
   return h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + (h->swimmer.nblock ? h->swimmer.nbdof : 0) : 3 + 2 * h->point.nblock + 3 * h->point.nball;
 }
 
 hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                            int* goal_idx_dev, float* info_dev) {
-  PointState S{h->state, h->pt_t, h->pt_ep};
+  PointState S{h->state, h->pt_t, h->pt_ep, h->pt_rec};
   if (h->robot == MZ_ROBOT_SWIMMER) {
 #define MZ_SW_STEP(NL, NB)                                                                                                          \
   hipLaunchKernelGGL((swimmer_step_kernel<NL, NB, (NL <= 4 ? 4 : 8)>), dim3((unsigned)(((size_t)h->n * (NL <= 4 ? 4 : 8) + sw_bd - 1) / sw_bd)), dim3(sw_bd), 0, st, \
@@ -394,7 +407,7 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
 }
 
 hipError_t mzk_planar_reset(mz_handle* h, hipStream_t st, const uint8_t* mask_dev, uint64_t seed, float* obs_dev) {
-  PointState S{h->state, h->pt_t, h->pt_ep};
+  PointState S{h->state, h->pt_t, h->pt_ep, h->pt_rec};
   const int nb = (h->n + 255) / 256;
   if (h->robot == MZ_ROBOT_SWIMMER) {
 #define MZ_SW_RESET(NL, NB) hipLaunchKernelGGL((swimmer_reset_kernel<NL, NB>), dim3(nb), dim3(256), 0, st, h->swimmer_dev, h->n, S, mask_dev, seed, h->env0, obs_dev, h->model.obs_dim)
@@ -418,7 +431,7 @@ hipError_t mzk_planar_reset(mz_handle* h, hipStream_t st, const uint8_t* mask_de
 }
 
 hipError_t mzk_planar_set_state(mz_handle* h, hipStream_t st, const float* qpos_dev, const float* qvel_dev, const int* t_dev) {
-  PointState S{h->state, h->pt_t, h->pt_ep};
+  PointState S{h->state, h->pt_t, h->pt_ep, h->pt_rec};
   const dim3 grid((h->n + 255) / 256), blk(256);
   switch (mzk_planar_state_width(h)) {
     case 3: hipLaunchKernelGGL(point_set_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, t_dev); break;
@@ -433,7 +446,7 @@ hipError_t mzk_planar_set_state(mz_handle* h, hipStream_t st, const float* qpos_
 }
 
 hipError_t mzk_planar_get_state(mz_handle* h, hipStream_t st, float* qpos_dev, float* qvel_dev, float* warmstart_dev, int* t_dev) {
-  PointState S{h->state, h->pt_t, h->pt_ep};
+  PointState S{h->state, h->pt_t, h->pt_ep, h->pt_rec};
   const dim3 grid((h->n + 255) / 256), blk(256);
   switch (mzk_planar_state_width(h)) {
     case 3: hipLaunchKernelGGL(point_get_state_kernel<3>, grid, blk, 0, st, h->n, S, qpos_dev, qvel_dev, warmstart_dev, t_dev); break;
