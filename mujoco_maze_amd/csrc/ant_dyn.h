@@ -153,6 +153,7 @@ struct alignas(16) AntScratchT {
   uint32_t rowmask[MZ_MAX_GRID + 4];  // the maze's cell grid (bit j of word i: BLOCK), copied once per step: one LDS read per row lookup
   uint32_t platmask[MZ_MAX_GRID + 4]; // elevated mazes: bit j of word i: the cell carries a platform (every cell but the chasms)
   int status, iters;
+  int ncon_true;  // contacts as MuJoCo counts them (s.ncon counts merged entries of the block's enumerators once: con_enum_item MERGE)
   // optional phase timers (device builds with PROF): cycles per phase id, last timestamp
   unsigned long long prof_t0;
   unsigned int prof[16];
@@ -1240,12 +1241,29 @@ MZ_HD float* con_stage(AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 
 template <int NB>
 MZ_HD const float* con_stage(const AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
 
-template <int NB>
+// MERGE (the movable block's own enumerators in the quad forward pass, ant_forward_rows.h): the contact points of one face pair —
+// four floor corners, the up to four corners of a block / wall overlap rectangle — arrive one after the other with the same
+// kind, normal and distance, and the block has no rotational dof: their constraint rows are IDENTICAL.  They are staged as one
+// entry with a multiplicity (code + 2048 (mult - 1)), which block_rows_direct turns into mult times the row's weight D — the same
+// cost function term for term, a third of the block's rows.  s.cnt[e] = entries | emitted contacts << 8.
+template <int NB, bool MERGE = false>
 MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
   constexpr int MZ_STAGE = MZ_STAGE_OF(NB);
   static_assert(8 * MZ_STAGE * AntDims<NB>::NGEOM <= 3 * AntDims<NB>::NC * AntDims<NB>::NCOL, "staging lives in the cY block");
-  int n = 0;
+  int n = 0, emitted = 0;
+  float ld = 0.f, ln[3] = {0.f, 0.f, 0.f};
+  int lk = -1, lmult = 0;
   geom_contacts<NB>(K, s, e, [&](const ContactGeo& g) {
+    emitted++;
+    if constexpr (MERGE) {
+      if (n > 0 && g.kind == lk && g.kind != 6 && g.dist == ld && g.n[0] == ln[0] && g.n[1] == ln[1] && g.n[2] == ln[2] && lmult < 8) {
+        lmult++;
+        if (n <= MZ_STAGE) con_stage<NB>(s, MZ_STAGE * e + n - 1)[7] = (float)(g.kind + 16 * g.blk + 128 * g.other + 2048 * (lmult - 1));
+        return;
+      }
+      lk = g.kind; ld = g.dist; lmult = 1;
+      for (int k = 0; k < 3; k++) ln[k] = g.n[k];
+    }
     if (n < MZ_STAGE) {
       float* q = con_stage<NB>(s, MZ_STAGE * e + n);
       for (int k = 0; k < 3; k++) { q[k] = g.pos[k]; q[3 + k] = g.n[k]; }
@@ -1253,7 +1271,7 @@ MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
     }
     n++;
   });
-  s.cnt[e] = n;
+  s.cnt[e] = MERGE ? (n | (emitted << 8)) : n;
   if (n > MZ_STAGE) s.con_over = 1;
 }
 
@@ -1693,9 +1711,9 @@ template <int NB, class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   using D = AntDims<NB>;
   constexpr int NH = D::NH, NV = D::NV, NG = D::NGEOM, NROOT = 15 + (NH - 6) * NH;
-  if constexpr (NB == 0 && C::row_solver) {
-    // the plain ant on the device at >= 16 lanes per env: the whole evaluation in the registers of the row's leg quads
-    // (ant_forward_rows.h) — no LDS hand-off before the contact rows
+  if constexpr (NB <= 1 && C::row_solver) {
+    // the plain ant, and the ant with one two-slide block, on the device at >= 16 lanes per env: the whole evaluation in the registers
+    // of the row's leg quads (ant_forward_rows.h) — no LDS hand-off before the contact records
     ant_forward_rows(cx, K, s, first);
     return;
   }

@@ -57,11 +57,14 @@ __device__ __forceinline__ float bsel(int m, float a, float b) { return __int_as
 struct GeomHit { float pos[3], n[3], dist; int kind; };  // one staged contact of a geom lane (registers)
 
 // The 24-float record of one contact of a robot geom (ant_solve_rows_core, WR mode): rec[8 a + 0..5] = wrench of row a about the
-// torso origin, sr [r x f_a; f_a] (f_0 = n, f_1 = mu t1, f_2 = mu t2; sr: +1 floor -> geom, -1 geom -> wall: the side of the pair
-// the robot is on), rec[8 a + 6] = reference acceleration of row a, rec[7] = D, rec[15] = leg (7: none) | body class << 3.
-// Same arithmetic as con_row_item (ant_dyn.h): the row's velocity J qvel is wrench . (spatial velocity of the touching body), vb.
+// torso origin, sr [r x f_a; f_a] (f_0 = n, f_1 = mu t1, f_2 = mu t2; sr: +1 floor -> geom, -1 geom -> wall / geom -> movable block:
+// the side of the pair the robot is on), rec[8 a + 6] = reference acceleration of row a, rec[7] = D,
+// rec[15] = leg (7: none) | body class << 3 | 64 when the partner is the movable block (its slide lanes then see the reaction).
+// Same arithmetic as con_row_item (ant_dyn.h): the row's velocity J qvel is wrench . (spatial velocity of the touching body) —
+// minus, for the block, the force direction times the block's slide velocities.  kind: 0 floor, 1 wall / platform, 2 block.
+template <int NB>
 __device__ __forceinline__ void contact_record(const AntDev& K, const float* pos, const float* n, float dist, int kind, const float* hint, int cls, int leg,
-                                               const float* vb, float tran, float* rec) {
+                                               const float* vb, const float* vblk, float tran, float* rec) {
   // the pair's parameters: BOTH sets by scalar loads, then value selects (`const PairDev& P = kind == 0 ? K.floor : K.wall` came out as
   // an address select followed by dependent vector-memory loads: three round trips to the cache on the contact's critical path)
   const int mk = -(int)(kind == 0);
@@ -75,9 +78,10 @@ __device__ __forceinline__ void contact_record(const AntDev& K, const float* pos
   const float sr = bsel(mk, 1.f, -1.f);
   float omi;
   const float imp = impedance_pair(si, fabsf(dist - P.margin), &omi);
+  if (NB == 1 && kind == 2) tran += K.block_bw_tran;
   const float Rr = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
   rec[7] = 1.0f / (2.f * P.mu * P.mu * Rr);  // [ASSUME-3]
-  rec[15] = __int_as_float((leg < 0 ? 7 : leg) | (cls << 3));
+  rec[15] = __int_as_float((leg < 0 ? 7 : leg) | (cls << 3) | ((NB == 1 && kind == 2) ? 64 : 0));
   rec[23] = 0.f;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -88,7 +92,13 @@ __device__ __forceinline__ void contact_record(const AntDev& K, const float* pos
     cross3f(m, pos, f);
     float* w = rec + 8 * a;
     w[0] = m[0]; w[1] = m[1]; w[2] = m[2]; w[3] = f[0]; w[4] = f[1]; w[5] = f[2];
-    const float vel = m[0] * vb[0] + m[1] * vb[1] + m[2] * vb[2] + f[0] * vb[3] + f[1] * vb[4] + f[2] * vb[5];
+    float vel = m[0] * vb[0] + m[1] * vb[1] + m[2] * vb[2] + f[0] * vb[3] + f[1] * vb[4] + f[2] * vb[5];
+    if constexpr (NB == 1) {
+      if (kind == 2) {  // the block moves along its slides: its point velocity enters with the opposite sign
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) vel -= (K.block_axis[sl] == 0 ? f[0] : (K.block_axis[sl] == 1 ? f[1] : f[2])) * vblk[sl];
+      }
+    }
     float aref = -P.B * vel;
     if (a == 0) aref -= P.K * imp * (dist - P.margin);
     w[6] = aref;
@@ -96,7 +106,7 @@ __device__ __forceinline__ void contact_record(const AntDev& K, const float* pos
 }
 // fall-back (an env whose geom overflowed its staging): the record of compact slot c from the geometry con_fill_item left in
 // s.cY[c] and the kinematics the forward pass published to LDS
-template <class S>
+template <int NB, class S>
 __device__ __forceinline__ void con_record_item(const AntDev& K, S& s, int c) {
   const float* q = &s.cY[c][0][0];
   const float pos[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3] = {q[8], q[9], q[10]}, dist = q[6];
@@ -105,17 +115,19 @@ __device__ __forceinline__ void con_record_item(const AntDev& K, S& s, int c) {
   mat_vecf(ww, s.R0, s.qvel + 3);
   const float qdh = cls >= 2 ? s.qvel[6 + 2 * lg] : 0.f, qda = cls == 3 ? s.qvel[7 + 2 * lg] : 0.f;
   for (int k = 0; k < 3; k++) { vb[k] = ww[k] + s.zw[k] * qdh + s.Sa[lg][k] * qda; vb[3 + k] = s.qvel[k] + s.Sh[lg][k] * qdh + s.Sa[lg][3 + k] * qda; }
+  const float vblk[2] = {NB == 1 ? s.qvel[14] : 0.f, NB == 1 ? s.qvel[14 + (NB == 1 ? 1 : 0)] : 0.f};
   float rec[24];
-  contact_record(K, pos, n, dist, kind, hint, cls, leg, vb, K.bw_tran[cls < 0 ? 0 : cls], rec);
-  float4* dst = reinterpret_cast<float4*>(&s.cJ[c][0][0]);
+  contact_record<NB>(K, pos, n, dist, kind, hint, cls, leg, vb, vblk, K.bw_tran[cls < 0 ? 0 : cls], rec);
+  float4* dst = reinterpret_cast<float4*>(wr_record(s, c));
 #pragma unroll
   for (int k = 0; k < 6; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
 }
 
-// contacts of one robot geom of the plain ant against the floor plane and the maze's wall cells — the robot-geom part of
-// geom_contacts (ant_dyn.h) on register inputs: centre / axis relative to the torso origin, torso origin (x0, y0, cz) in the world
-template <class S, class Emit>
-__device__ __forceinline__ void plain_geom_contacts(const AntDev& K, const S& s, bool sphere, const float* ctr, const float* ax, float hl, float r,
+// contacts of one robot geom against the floor plane, the movable block (NB = 1) and the maze's cells (walls; in an elevated maze the
+// platform under a cell first) — the robot-geom part of geom_contacts (ant_dyn.h), same order, on register inputs: centre / axis
+// relative to the torso origin, torso origin (x0 + x0l, y0 + y0l, cz) in the world
+template <int NB, class S, class Emit>
+__device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s, bool sphere, const float* ctr, const float* ax, float hl, float r,
                                                     float x0, float y0, float x0l, float y0l, float cz, Emit&& emit) {
   const MazeDev& z = K.maze;
   const float inv = 1.0f / z.scale;
@@ -138,21 +150,36 @@ __device__ __forceinline__ void plain_geom_contacts(const AntDev& K, const S& s,
     }
   }
   const float reach = r + hl + K.wall.margin;
+  if constexpr (NB == 1) {
+    // the movable block: spawn position + its two slides, hi parts first, low-order parts after (block_center of ant_dyn.h)
+    float d[3] = {0.f, 0.f, 0.f}, dl[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) { d[c] += K.block_axis[sl] == c ? s.qpos[15 + sl] : 0.f; dl[c] += K.block_axis[sl] == c ? s.qlo[2 + sl] : 0.f; }
+    const float bc[3] = {((K.block_pos0[0][0] - x0) + d[0]) + (dl[0] - x0l), ((K.block_pos0[0][1] - y0) + d[1]) + (dl[1] - y0l), ((K.block_pos0[0][2] - cz) + d[2]) + dl[2]};
+    float d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) { const float dd = fmaxf(fabsf(ctr[q] - bc[q]) - K.block_half[q], 0.f); d2 += dd * dd; }
+    if (d2 < reach * reach) round_vs_box(sphere, ctr, ax, hl, r, bc, K.block_half, K.wall.margin, 2, 0, emit);
+  }
+  const bool elevated = NB > 0 && z.elevated;
   const float gx = x0 + ctr[0], gy = y0 + ctr[1], gz = cz + ctr[2];
   if (gz - reach > z.center_z + z.half_z) return;
   const int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
   const int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
-  const float zc = z.center_z - cz;
   const float lim2 = (r + K.wall.margin) * (r + K.wall.margin) * 1.0001f;
-  // can cell (i, j) give a contact at all?  In the grid and a wall; the geom's z extent meets the box's; and the geom's axis
-  // segment — its bounding box, axis by axis — comes within radius + margin of the box: a lower bound of the true distance that is
-  // exact whenever the nearest feature is a face, i.e. for every wall a leg merely passes (cells are metres wide, capsules
-  // centimetres).  Only what survives pays for the closest-feature search of mjc_CapsuleBox (round_vs_box).
-  auto candidate = [&](int i, int j) {
+  // can the box of cell (i, j) — layer 1: the wall, layer 0: the platform of an elevated maze — give a contact at all?  In the grid
+  // and present; the geom's z extent meets the box's; and the geom's axis segment — its bounding box, axis by axis — comes within
+  // radius + margin of the box: a lower bound of the true distance that is exact whenever the nearest feature is a face, i.e. for
+  // every wall a leg merely passes (cells are metres wide, capsules centimetres).  Only what survives pays for the
+  // closest-feature search of mjc_CapsuleBox (round_vs_box).
+  auto candidate = [&](int i, int j, int layer) {
     if (i < 0 || j < 0 || i >= z.rows || j >= z.cols) return false;
-    if (!((maze_row_lds(s, i) >> j) & 1u)) return false;
-    if (gz - reach > z.center_z + z.half_z || gz + reach < z.center_z - z.half_z) return false;
-    const float bc[3] = {((j * z.scale - z.tx) - x0) - x0l, ((i * z.scale - z.ty) - y0) - y0l, zc};
+    if (!(((layer ? maze_row_lds(s, i) : plat_row_lds(s, i)) >> j) & 1u)) return false;
+    const float cz1 = layer ? z.center_z : z.half_z;
+    if (gz - reach > cz1 + z.half_z || gz + reach < cz1 - z.half_z) return false;
+    const float bc[3] = {((j * z.scale - z.tx) - x0) - x0l, ((i * z.scale - z.ty) - y0) - y0l, cz1 - cz};
     float g2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
@@ -162,27 +189,33 @@ __device__ __forceinline__ void plain_geom_contacts(const AntDev& K, const S& s,
     }
     return g2 <= lim2;
   };
-  auto test = [&](int i, int j) {
-    const float bc[3] = {((j * z.scale - z.tx) - x0) - x0l, ((i * z.scale - z.ty) - y0) - y0l, zc};  // large world coordinates cancel first, then the low-order parts (AntScratchT::qlo)
+  auto test = [&](int i, int j, int layer) {
+    const float cz1 = layer ? z.center_z : z.half_z;
+    const float bc[3] = {((j * z.scale - z.tx) - x0) - x0l, ((i * z.scale - z.ty) - y0) - y0l, cz1 - cz};  // large world coordinates cancel first, then the low-order parts (AntScratchT::qlo)
     round_vs_box(sphere, ctr, ax, hl, r, bc, bs, K.wall.margin, 1, 0, emit);
   };
   if (i1 - i0 <= 1 && j1 - j0 <= 1) {
-    // the usual case (a geom's bounding square covers at most 2 x 2 cells): both grid rows at once, leave when none of the cells is a wall
-    const uint32_t rows2 = maze_row_lds(s, i0) | (i1 != i0 ? maze_row_lds(s, i1) : 0u);
+    // the usual case (a geom's bounding square covers at most 2 x 2 cells): both grid rows at once, leave when none of the cells holds a box
+    uint32_t rows2 = maze_row_lds(s, i0) | (i1 != i0 ? maze_row_lds(s, i1) : 0u);
+    if (elevated) rows2 |= plat_row_lds(s, i0) | (i1 != i0 ? plat_row_lds(s, i1) : 0u);
     const uint32_t cols2 = ((j0 >= 0 && j0 < z.cols) ? 1u << j0 : 0u) | ((j1 != j0 && j1 >= 0 && j1 < z.cols) ? 1u << j1 : 0u);
     if (!(rows2 & cols2)) return;
   }
-  // the surviving cells as a bit set (bit 4 (i - i0) + (j - j0): up to 8 x 4 cells, row-major = MuJoCo's geom order of the wall
-  // boxes), then one cell per pass — lanes with one candidate each meet in the same pass instead of each waiting for the other's
-  // position in a loop nest
-  unsigned cand = 0u;
+  // the surviving boxes as bit sets (bit 4 (i - i0) + (j - j0): up to 8 x 4 cells, row-major = MuJoCo's geom order of the maze's
+  // boxes; per cell the platform before the wall), then one cell per pass — lanes with one candidate each meet in the same pass
+  // instead of each waiting for the other's position in a loop nest
+  unsigned candw = 0u, candp = 0u;
   for (int i = i0; i <= i1 && i < i0 + 8; i++)
-    for (int j = j0; j <= j1 && j < j0 + 4; j++)
-      if (candidate(i, j)) cand |= 1u << (4 * (i - i0) + (j - j0));
-  while (cand) {
-    const int b = __ffs((int)cand) - 1;
-    cand &= cand - 1u;
-    test(i0 + (b >> 2), j0 + (b & 3));
+    for (int j = j0; j <= j1 && j < j0 + 4; j++) {
+      if (candidate(i, j, 1)) candw |= 1u << (4 * (i - i0) + (j - j0));
+      if (elevated && candidate(i, j, 0)) candp |= 1u << (4 * (i - i0) + (j - j0));
+    }
+  while (candw | candp) {
+    const int b = __ffs((int)(candw | candp)) - 1;
+    const unsigned bit = 1u << b;
+    if (candp & bit) test(i0 + (b >> 2), j0 + (b & 3), 0);
+    if (candw & bit) test(i0 + (b >> 2), j0 + (b & 3), 1);
+    candw &= ~bit; candp &= ~bit;
   }
 }
 
@@ -205,15 +238,23 @@ __device__ __forceinline__ void ant_lane_consts(const AntDev& K, DevCtx<G, PROF>
   ant_limit_consts(K, cx);
 }
 
-// One forward-dynamics evaluation of the plain ant: qacc from (s.qpos, s.qvel, s.fact); `first`: first evaluation of an env.step
-// (s.warm = MuJoCo's qacc_warmstart), otherwise s.warm = the previous evaluation's solution.  Same outputs as ant_forward's
-// lane-group path: s.qacc, s.qas (where computed), s.ncon, s.iters, status bits.
-template <int G, bool PROF>
-__device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<0>& s, bool first) {
+// One forward-dynamics evaluation of the plain ant (NB = 0) or of the ant with ONE movable block on two slides (NB = 1: AntPush,
+// AntFall, ...): qacc from (s.qpos, s.qvel, s.fact); `first`: first evaluation of an env.step (s.warm = MuJoCo's qacc_warmstart),
+// otherwise s.warm = the previous evaluation's solution.  Same outputs as ant_forward's lane-group path: s.qacc, s.qas (where
+// computed), s.ncon, s.iters, status bits.
+// NB = 1: the block's two slides are positions 14, 15 of the row (a diagonal block of M, gravity on a z slide).  Its OWN contacts
+// (floor corners, maze boxes, slide limits) are enumerated by the first eleven lanes of the group in a second pass — the
+// sub-enumerators of geom_contacts, staged as before — and take the first slots; their rows are built inside the solver by the
+// lanes that own them (block_rows_direct).  A robot geom touching the block is a record like any other, flagged so that the slide
+// lanes see its reaction.
+template <int NB, int G, bool PROF>
+__device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   static_assert(G >= 16, "one DPP row per env at least");
+  static_assert(NB <= 1, "row layout: 14 robot dofs + one block's two slides");
   using namespace rows;
   using C = DevCtx<G, PROF>;  // (MZ_FOR)
-  constexpr int NB = 0, NC = AntDims<0>::NC;
+  using D = AntDims<NB>;
+  constexpr int NC = D::NC, NR = 14 + 2 * NB;
   cx.tick(s, 9);
   const int p = cx.l & 15, l = p >> 2, j = p & 3;
   const bool hinge = j < 2, isroot = j >= 2 && l < 3;
@@ -265,12 +306,13 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
   const int cls = j == 0 ? 2 : (j == 1 ? 3 : (j == 2 ? 1 : 0));
   const float hlen = cx.lc[LC_HLEN], rad = cx.lc[LC_RAD];
   cx.tick(s, 0);
+  if constexpr (NB == 1) { if (p == 0) { s.cz = cz; s.con_over = 0; } }  // (the block's enumerators below read them)
   // ---- C: contacts of the own geom, staged in registers (the first three; more: the env takes the fall-back below).  Right after the
   // kinematics: the narrow phase is the branchiest code of the evaluation, and here little else is live across it
   GeomHit hit[3];
   int nfound = 0;
   if (isgeom) {
-    plain_geom_contacts(K, s, j == 3, com, w, hlen, rad, x0, y0, s.qlo[0], s.qlo[1], cz, [&](const ContactGeo& g) {
+    robot_geom_contacts<NB>(K, s, j == 3, com, w, hlen, rad, x0, y0, s.qlo[0], s.qlo[1], cz, [&](const ContactGeo& g) {
 #pragma unroll
       for (int q = 0; q < 3; q++)
         if (nfound == q) {
@@ -280,12 +322,31 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
       nfound++;
     });
   }
-  const bool over = cx.gany(nfound > 3);
+  // the movable block's own enumerators (floor corners | the 3 x 3 cells under it, platform and wall each | slide limits), one per
+  // lane of the group's first eleven, staged in the cY block as in the lane-group path; their contacts take the first slots
+  int nblk = 0, nrep = 0;  // nrep: contact points folded into merged entries (for the count MuJoCo would report)
+  bool bover = false;
+  if constexpr (NB == 1) {
+    cx.sync();
+    MZ_FOR(e, D::NMOV) con_enum_item<NB, true>(K, s, e);
+    cx.sync();
+    int mine = 0, before = 0;
+#pragma unroll
+    for (int e = 0; e < D::NMOV; e++) {
+      const int ce = s.cnt[e], c = ce & 255;  // merged entries | contacts emitted << 8
+      nblk += c; nrep += (ce >> 8) - c; before += e < cx.l ? c : 0; mine = e == cx.l ? c : mine;
+    }
+    bover = s.con_over != 0;
+    if (cx.l < D::NMOV && !bover)
+      for (int i = 0; i < mine; i++) { const int slot = before + i; if (slot < NC) { s.csrc[slot] = MZ_STAGE_OF(NB) * cx.l + i; s.cleg[slot] = -1; s.ccls[slot] = -1; } }
+    if (nblk > NC) nblk = NC;
+  }
+  const bool over = cx.gany(nfound > 3) || bover;
   // compact slots in geom order (torso, then per leg: welded capsule, aux, ankle): one packed-count butterfly
   const int rank = j == 3 ? 0 : 1 + 3 * l + (j == 2 ? 0 : j + 1);
   const unsigned word = rsum_u((unsigned)(nfound > 3 ? 3 : nfound) << (2 * rank));
-  const int off = (int)sum2bit(word & ((1u << (2 * rank)) - 1u));
-  int ncon = (int)sum2bit(word);
+  const int off = nblk + (int)sum2bit(word & ((1u << (2 * rank)) - 1u));
+  int ncon = nblk + (int)sum2bit(word);
   cx.tick(s, 2);
 
   // ---- I: spatial inertia of the own body about the torso origin (inertia_item); composites
@@ -318,8 +379,17 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
       S[3 + k] = bsel(m0, ShL[k], bsel(m1, Sa[3 + k], bsel(-(int)(isroot && iroot == k), 1.f, 0.f)));
     }
   }
+  float Sax[6];  // what the solver's contact columns use: S, and for the block's slide lanes MINUS their world axis (linear part)
+#pragma unroll
+  for (int k = 0; k < 6; k++) Sax[k] = S[k];
+  if constexpr (NB == 1) {
+    const int sl = p - 14;  // slide index of a block lane
+    const int ax = sl == 0 ? K.block_axis[0] : K.block_axis[1];
+#pragma unroll
+    for (int k = 0; k < 3; k++) Sax[3 + k] = p >= 14 ? (ax == k ? -1.f : 0.f) : S[3 + k];
+  }
   // ---- M: row p of the mass matrix, position order
-  float Mrow[14];
+  float Mrow[NR];
   {
     float F[6];
     inertia_mulf(F, Ip, S);
@@ -340,6 +410,9 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
       const float vh = gq[2 * l2], va = gq[2 * l2 + 1];
       const float hh = bsel(mine, bsel(m1, hipT, vh + K.armature), 0.f), ha = bsel(mine, bsel(m1, va + K.armature, va), 0.f);  // hinge lanes
       Mrow[4 * l2] = bsel(mh, hh, vh); Mrow[4 * l2 + 1] = bsel(mh, ha, va);
+    }
+    if constexpr (NB == 1) {  // the block: a separate tree — its mass on the diagonal of its two slides, no coupling with the robot
+      Mrow[14] = p == 14 ? K.block_mass : 0.f; Mrow[15] = p == 15 ? K.block_mass : 0.f;
     }
   }
   cx.tick(s, 3);
@@ -374,11 +447,17 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
     }
     const float fact = s.fact[hinge ? pos2dof(p) : 6];  // motors sit on the hinges only
     qfs = bsel(mh, -K.damping * bsel(m0, qdh, qda) - bias + fact, bsel(-(int)isroot, -bias, 0.f));
+    if constexpr (NB == 1) {  // block slides: undamped, unactuated; gravity acts on a z slide (falling blocks)
+      const int ax = p == 14 ? K.block_axis[0] : K.block_axis[1];
+      if (p >= 14) qfs = ax == 2 ? K.block_mass * K.gz : 0.f;
+    }
   }
   cx.tick(s, 1);
   if (!over) {
     if (ncon > NC) { ncon = NC; if (p == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
-    if (p == 0) { s.ncon = ncon; s.nblkcon = 0; }
+    if (p == 0) { s.ncon = ncon; s.nblkcon = nblk; s.ncon_true = ncon + nrep; }
+    float vblk[2] = {0.f, 0.f};
+    if constexpr (NB == 1) { vblk[0] = s.qvel[14]; vblk[1] = s.qvel[15]; }
     // the records of the own contacts (contact_record), straight into the slots their owner lanes read
 #pragma unroll
     for (int q = 0; q < 3; q++) {
@@ -387,8 +466,8 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
         const GeomHit& h = hit[q];
         const float hint[3] = {(h.kind == 0 && j < 3) ? w[0] : 0.f, (h.kind == 0 && j < 3) ? w[1] : 0.f, (h.kind == 0 && j < 3) ? w[2] : 0.f};
         float rec[24];
-        contact_record(K, h.pos, h.n, h.dist, h.kind, hint, cls, j == 3 ? -1 : l, vb, cx.lc[LC_TRAN], rec);
-        float4* dst = reinterpret_cast<float4*>(&s.cJ[slot][0][0]);
+        contact_record<NB>(K, h.pos, h.n, h.dist, h.kind, hint, cls, j == 3 ? -1 : l, vb, vblk, cx.lc[LC_TRAN], rec);
+        float4* dst = reinterpret_cast<float4*>(wr_record(s, slot));
 #pragma unroll
         for (int k = 0; k < 6; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
       }
@@ -403,15 +482,17 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
     if (p == 0) { for (int k = 0; k < 9; k++) s.R0[k] = R0[k]; for (int k = 0; k < 3; k++) s.zw[k] = zw[k]; s.cz = cz; s.nearwall = 1; s.con_over = 1; }
     cx.sync();
     if (over) {
-      constexpr int NG = AntDims<0>::NGEOM;
+      constexpr int NG = D::NGEOM;
       MZ_FOR(e, NG) con_count_item<NB>(K, s, e);
       cx.sync();
       MZ_FOR(e, NG) con_fill_item<NB>(K, s, e);
       cx.sync();
-      MZ_FOR(c, s.ncon) con_record_item(K, s, c);
+      const int nb0 = NB ? s.nblkcon : 0;  // (the block's own contacts keep their staged geometry: block_rows_direct reads it)
+      MZ_FOR(c, s.ncon - nb0) con_record_item<NB>(K, s, nb0 + c);
+      if (p == 0) s.ncon_true = s.ncon;  // (nothing is merged on this path)
       cx.sync();
     }
   }
   cx.tick(s, 11);
-  ant_solve_rows_core<NB, G, PROF, true>(cx, K, s, first, Mrow, qfs, S);
+  ant_solve_rows_core<NB, G, PROF, true>(cx, K, s, first, Mrow, qfs, Sax);
 }

@@ -69,8 +69,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   AntEnvLDS<NB>* lds = reinterpret_cast<AntEnvLDS<NB>*>(lds_raw);
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
-  if constexpr (NB == 0 && G >= 16) ant_lane_consts(K, cx);  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
-  if constexpr (NB == 1 && G >= 16) ant_limit_consts(K, cx);
+  if constexpr (NB <= 1 && G >= 16) ant_lane_consts(K, cx);  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
   const int slot = threadIdx.x / G;
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
@@ -189,8 +188,7 @@ __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   AntScratchT<NB>* sc = reinterpret_cast<AntScratchT<NB>*>(lds_raw);
   DevCtx<G> cx{(int)threadIdx.x % G};
-  if constexpr (NB == 0 && G >= 16) ant_lane_consts(K, cx);
-  if constexpr (NB == 1 && G >= 16) ant_limit_consts(K, cx);
+  if constexpr (NB <= 1 && G >= 16) ant_lane_consts(K, cx);
   const int slot = threadIdx.x / G;
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
@@ -207,7 +205,7 @@ __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const 
   ant_forward<NB>(cx, K, s, true);
   if (live) {
     for (int i = cx.l; i < D::NV; i += G) qacc[(size_t)env * D::NV + i] = s.qacc[i];
-    if (cx.l == 0 && counts) { counts[2 * env] = s.ncon; counts[2 * env + 1] = s.iters; }
+    if (cx.l == 0 && counts) { counts[2 * env] = (NB <= 1 && G >= 16) ? s.ncon_true : s.ncon; counts[2 * env + 1] = s.iters; }
   }
 }
 
@@ -375,9 +373,12 @@ static hipError_t ant_sync_constants(mz_handle* h, hipStream_t st) {
 hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   hipError_t e = ant_sync_constants(h, st);
   if (e != hipSuccess) return e;
-#ifdef MZ_DEV_NB0  // developer build (make dev: libmazestep_dev.so, a minute instead of six): the plain ant's instantiations only
+#if defined(MZ_DEV_NB0)  // developer build (make dev: libmazestep_dev.so, a minute instead of six): the plain ant's instantiations only
   if (ant_config(h) != 0) return hipErrorNotSupported;
   return dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
+#elif defined(MZ_DEV_NB01)  // (make dev1: plus the ant with one two-slide block)
+  if (ant_config(h) > 1) return hipErrorNotSupported;
+  return ant_config(h) ? dispatch_ant_step<1>(h, st, a, o, r, d, gi, inf) : dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
 #else
   switch (ant_config(h)) {  // configuration of movable bodies (AntDims)
     case 0: return dispatch_ant_step<0>(h, st, a, o, r, d, gi, inf);
@@ -391,9 +392,12 @@ hipError_t mzk_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, 
 }
 
 hipError_t mzk_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {
-#ifdef MZ_DEV_NB0
+#if defined(MZ_DEV_NB0)
   if (ant_config(h) != 0) return hipErrorNotSupported;
   return dispatch_ant_forward<0>(h, st, a, qacc, counts);
+#elif defined(MZ_DEV_NB01)
+  if (ant_config(h) > 1) return hipErrorNotSupported;
+  return ant_config(h) ? dispatch_ant_forward<1>(h, st, a, qacc, counts) : dispatch_ant_forward<0>(h, st, a, qacc, counts);
 #else
   switch (ant_config(h)) {
     case 0: return dispatch_ant_forward<0>(h, st, a, qacc, counts);

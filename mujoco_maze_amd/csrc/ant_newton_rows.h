@@ -241,6 +241,14 @@ __device__ __forceinline__ float ceval(float D, float u0, float u1, float u2) {
 
 }  // namespace rows
 
+// wrench record of contact slot c (WR mode of ant_solve_rows_core): 24 floats, packed one after the other in the cJ block (for the
+// plain ant, NCOL = 8, that IS cJ[c]; with a movable block cJ's slots are 30 floats wide and would leave every other record off a
+// 16-byte boundary)
+template <class S>
+__device__ __forceinline__ float* wr_record(S& s, int c) { return &s.cJ[0][0][0] + 24 * c; }
+template <class S>
+__device__ __forceinline__ const float* wr_record(const S& s, int c) { return &s.cJ[0][0][0] + 24 * c; }
+
 // Per-lane constants of the hinge lanes' joint-limit rows, loaded once per step into DevCtx::lc (run-time indexed reads of the
 // constant block inside the 20 evaluations were dependent vector-memory loads): range and inverse weight of the lane's own hinge.
 enum { LC_LO = 11, LC_HI = 12, LC_DOFW = 13 };
@@ -260,7 +268,9 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
   const int src = s.csrc[c];
   const float* q = src >= 0 ? con_stage<NB>(s, src) : &s.cY[c][0][0];
   const float n[3] = {q[3], q[4], q[5]}, dist = q[6];
-  const int code = (int)q[7], kind = code & 15, other = code >> 7;
+  // code = kind + 16 blk + 128 other + 2048 (multiplicity - 1): a merged entry stands for `mult` identical contact points (MERGE)
+  const int code = (int)q[7], kind = code & 15, other = (code >> 7) & 15;
+  const float mult = (float)((code >> 11) + 1);
   const float v0 = s.qvel[14], v1 = s.qvel[15];
   if (kind == 6) {  // slide limit: one frictionless row riding as a pyramid with vanishing tangents (cD = D / 4)
     const float sg = n[0] + n[1] + n[2];
@@ -296,7 +306,7 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
   const float imp = impedance_pair(psi, fabsf(dist - P.margin), &omi);
   const float tran = K.block_bw_tran;
   const float R = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
-  Dout = 1.0f / (2.f * P.mu * P.mu * R);
+  Dout = mult / (2.f * P.mu * P.mu * R);  // `mult` identical rows = one row with mult times the weight: same cost, gradient, curvature
   ar[0] -= P.K * imp * (dist - P.margin);
   (void)sizeof(D);
 }
@@ -329,19 +339,22 @@ __device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, c
                                                     const float (&Mrow)[14 + 2 * NB], const float qfs, const float (&Sax)[6]) {
   static_assert(G >= 16, "one DPP row per env at least");
   static_assert(NB <= 1, "one 16-lane row holds 14 dofs + one block's two slides");
-  static_assert(!WR || NB == 0, "wrench records: plain ant");
   using namespace rows;
   using D = AntDims<NB>;
   constexpr int NR = 14 + 2 * NB;                 // positions of the row that own a dof
   constexpr int NHC = D::NH;                      // hub columns of a contact Jacobian: root 6 (+ block 2); then hip, ankle
-  constexpr int MB = NB ? (D::NC + G - 1) / G : 0; // block-own contacts per lane
-  constexpr int MA = NB ? 2 : 1;                   // robot contacts per lane of the row (16 MA in all)
+  // block-own contacts per lane.  WR (the quad forward pass): the enumerators merge the identical rows of a face's contact points
+  // (con_enum_item MERGE: a block resting on the floor against two walls is 3 entries instead of 12), one per lane of the group
+  // holds them; more than G of them: flagged, the surplus dropped
+  constexpr int MB = NB ? (WR ? 1 : (D::NC + G - 1) / G) : 0;
+  constexpr int MA = NB ? 2 : 1;                   // robot contacts per lane of the row (16 MA in all; an ant on its back next to the block: > 16)
   const int r = cx.l & 15;                       // position of this lane (rows::pos2dof); beyond NR: spare lanes (zero rows, never pivots)
   const bool isdof = r < NR, ishinge = (r & 3) < 2 && r < 14;
   const int leg = r >> 2, d = r & 1;              // hinge lanes: own leg, 0 hip / 1 ankle
   const int nB = NB ? s.nblkcon : 0;             // block-own contacts: slots [0, nB)
   int nA = s.ncon - nB;                          // robot contacts: slots [nB, ncon), owned by the lanes 0 .. nA - 1 of the row
   if (nA > 16 * MA) { nA = 16 * MA; if (cx.l == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+  if (NB && MB * G < nB && cx.l == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW;  // block contacts without an owner lane (robot slots still start at nB)
   const int ncon = nA;
   const bool any2 = MA > 1 && cx.any(nA > 16);   // some env of the wave uses the second contact slot of its lanes (wave-uniform: the slot's code is skipped otherwise)
   bool iscon[MA];                                // this lane owns robot contact r (+ 16: second slot)
@@ -383,22 +396,35 @@ __device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, c
   const float warm = isdof ? s.warm[ri] : 0.f;  // later evaluations start from the previous evaluation's solution
   // own robot contact: 3 x (NHC + 2) Jacobian rows stay in LDS (row-major, read as needed); constants in registers
   float cD[MA], ar[MA][3];
-  float wr[3][6];  // WR: the own contact's three wrenches
-  int wmeta = 0;   // WR: leg (7: none) | body class << 3 of the touching geom
+  float wr[MA][3][6];  // WR: the own contacts' three wrenches each
+  int wmeta[MA];       // WR: leg (7: none) | body class << 3 | 64 if the touching geom's partner is the movable block
+#pragma unroll
+  for (int m = 0; m < MA; m++) wmeta[m] = 0;
   if constexpr (WR) {
-    const float4* q = reinterpret_cast<const float4*>(&s.cJ[cr[0]][0][0]);
-    float rec[24];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { const float4 v4 = q[k]; rec[4 * k] = v4.x; rec[4 * k + 1] = v4.y; rec[4 * k + 2] = v4.z; rec[4 * k + 3] = v4.w; }
-    const int on = -(int)iscon[0];
+    for (int m = 0; m < MA; m++) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
+      for (int a = 0; a < 3; a++) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) wr[a][k] = __int_as_float(__float_as_int(rec[8 * a + k]) & on);
-      ar[0][a] = __int_as_float(__float_as_int(rec[8 * a + 6]) & on);
+        for (int k = 0; k < 6; k++) wr[m][a][k] = 0.f;
+        ar[m][a] = 0.f;
+      }
+      cD[m] = 0.f;
+      if (m == 1 && !any2) continue;
+      const float4* q = reinterpret_cast<const float4*>(wr_record(s, cr[m]));
+      float rec[24];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { const float4 v4 = q[k]; rec[4 * k] = v4.x; rec[4 * k + 1] = v4.y; rec[4 * k + 2] = v4.z; rec[4 * k + 3] = v4.w; }
+      const int on = -(int)iscon[m];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) wr[m][a][k] = __int_as_float(__float_as_int(rec[8 * a + k]) & on);
+        ar[m][a] = __int_as_float(__float_as_int(rec[8 * a + 6]) & on);
+      }
+      cD[m] = __int_as_float(__float_as_int(rec[7]) & on);
+      wmeta[m] = __float_as_int(rec[15]) & on;
     }
-    cD[0] = __int_as_float(__float_as_int(rec[7]) & on);
-    wmeta = __float_as_int(rec[15]) & on;
   } else {
 #pragma unroll
     for (int m = 0; m < MA; m++) {
@@ -432,31 +458,53 @@ __device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, c
         f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
         if (cx.any(ncon > 8)) {
           f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
-          f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{});
+          if (cx.any(ncon > 12)) { f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{}); }
           if constexpr (MA > 1) {
-            if (any2) {  // second slot of the contact lanes: a robot lying against block and walls at once
+            if (any2) {  // second slot of the contact lanes: an ant on its back, a robot lying against block and walls at once —
+              // in groups of four as well: such an env decides how long its whole launch lasts (a launch waits for its slowest wave)
               f(std::integral_constant<int, 16>{}); f(std::integral_constant<int, 17>{}); f(std::integral_constant<int, 18>{}); f(std::integral_constant<int, 19>{});
-              f(std::integral_constant<int, 20>{}); f(std::integral_constant<int, 21>{}); f(std::integral_constant<int, 22>{}); f(std::integral_constant<int, 23>{});
-              f(std::integral_constant<int, 24>{}); f(std::integral_constant<int, 25>{}); f(std::integral_constant<int, 26>{}); f(std::integral_constant<int, 27>{});
-              f(std::integral_constant<int, 28>{}); f(std::integral_constant<int, 29>{}); f(std::integral_constant<int, 30>{}); f(std::integral_constant<int, 31>{});
+              if (cx.any(ncon > 20)) {
+                f(std::integral_constant<int, 20>{}); f(std::integral_constant<int, 21>{}); f(std::integral_constant<int, 22>{}); f(std::integral_constant<int, 23>{});
+                if (cx.any(ncon > 24)) {
+                  f(std::integral_constant<int, 24>{}); f(std::integral_constant<int, 25>{}); f(std::integral_constant<int, 26>{}); f(std::integral_constant<int, 27>{});
+                  f(std::integral_constant<int, 28>{}); f(std::integral_constant<int, 29>{}); f(std::integral_constant<int, 30>{}); f(std::integral_constant<int, 31>{});
+                }
+              }
             }
           }
         }
       }
     }
   };
-  float jown[16 * MA][3];
+  // WR: the columns of the SECOND slot's contacts (C >= 16: an ant on its back next to the block, rare, behind the wave-uniform
+  // `any2`) are not kept — 48 registers live through the whole solve for a path hardly any wave takes — but recomputed from the
+  // owner's wrenches where they are used (own_col below)
+  constexpr int NJ = WR ? 16 : 16 * MA;
+  float jown[NJ][3];
+  auto wr_col = [&](auto Cc, float (&o)[3]) {  // S_p . wrench_a of contact C, masked by "dof p moves the touching body"
+    constexpr int C = decltype(Cc)::value;
+    // S_p . wrench_a of contact C (its owner: lane C of the row), for the dofs that move the touching body: the root always, a hip
+    // when the geom sits on its leg below it (aux, ankle body), an ankle for its own ankle body.  (The movable block's two slide
+    // lanes carry MINUS their axis in Sax: a robot -> block contact pushes the block with the reaction of what the record holds
+    // for the robot.)
+    const int mc = bcast_i<(C & 15)>(wmeta[C / 16]), lc = mc & 7, cc = (mc >> 3) & 7;
+    const bool sees = C < ncon && (ishinge ? (leg == lc && (d == 0 ? cc >= 2 : cc == 3)) : (r < 12 || (NB == 1 && r >= 14 && (mc & 64) != 0)));
+    const int on = -(int)sees;
+#pragma unroll
+    for (int a = 0; a < 3; a++) o[a] = __int_as_float(__float_as_int(dot6_from<(C & 15)>(wr[C / 16][a], Sax)) & on);
+  };
+  auto own_col = [&](auto Cc, float (&o)[3]) {
+    constexpr int C = decltype(Cc)::value;
+    if constexpr (WR && C >= 16) wr_col(Cc, o);
+    else { o[0] = jown[C < NJ ? C : 0][0]; o[1] = jown[C < NJ ? C : 0][1]; o[2] = jown[C < NJ ? C : 0][2]; }
+  };
   each_contact([&](auto Cc) {
     constexpr int C = decltype(Cc)::value;
+    if constexpr (WR && C >= 16) return;
+    else {
     jown[C][0] = jown[C][1] = jown[C][2] = 0.f;
     if constexpr (WR) {
-      // S_p . wrench_a of contact C (its owner: lane C of the row), for the dofs that move the touching body: the root always,
-      // a hip when the geom sits on its leg below it (aux, ankle body), an ankle for its own ankle body
-      const int mc = bcast_i<(C & 15)>(wmeta), lc = mc & 7, cc = mc >> 3;
-      const bool sees = C < ncon && (ishinge ? (leg == lc && (d == 0 ? cc >= 2 : cc == 3)) : r < 12);
-      const int on = -(int)sees;
-#pragma unroll
-      for (int a = 0; a < 3; a++) jown[C][a] = __int_as_float(__float_as_int(dot6_from<(C & 15)>(wr[a], Sax)) & on);
+      wr_col(Cc, jown[C]);
     } else
     if (C < ncon) {  // (uniform within the env's row)
       const int lc = s.cleg[nB + C];
@@ -464,6 +512,7 @@ __device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, c
       // of the contact's own leg -> NHC, NHC + 1
       const int col = ishinge ? (leg == lc ? NHC + d : -1) : (r < 12 ? ri : ((NB == 1 && r >= 14 && r < 16) ? r - 8 : -1));
       if (col >= 0) { jown[C][0] = s.cJ[nB + C][0][col]; jown[C][1] = s.cJ[nB + C][1][col]; jown[C][2] = s.cJ[nB + C][2][col]; }
+    }
     }
   });
   float Jf[MA][3][NR];
@@ -493,12 +542,15 @@ __device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, c
     if constexpr (WR) {
       // transposed: (J x)[C][a] = sum over the lanes of their column entry times their x — one row butterfly per (contact, row);
       // every lane gets every sum, the owner keeps its own
-      o[0][0] = o[0][1] = o[0][2] = 0.f;
+#pragma unroll
+      for (int m = 0; m < MA; m++) o[m][0] = o[m][1] = o[m][2] = 0.f;
       each_contact([&](auto Cc) {
         constexpr int C = decltype(Cc)::value;
         if (C < ncon) {
-          const float t0 = rsum(jown[C][0] * x), t1 = rsum(jown[C][1] * x), t2 = rsum(jown[C][2] * x);
-          if (r == C) { o[0][0] = t0; o[0][1] = t1; o[0][2] = t2; }
+          float jc[3];
+          own_col(Cc, jc);
+          const float t0 = rsum(jc[0] * x), t1 = rsum(jc[1] * x), t2 = rsum(jc[2] * x);
+          if (r == (C & 15)) { o[C / 16][0] = t0; o[C / 16][1] = t1; o[C / 16][2] = t2; }
         }
       });
     } else {
@@ -621,9 +673,11 @@ __device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, c
       constexpr int C = decltype(Cc)::value;
       if (C < ncon) {  // (uniform within the env's row)
         float t, t0, t1, t2;
-        fold_t<(C & 15)>(mycg[C / 16], jown[C][0], jown[C][1], jown[C][2], t, t0, t1, t2);
+        float jc[3];
+        own_col(Cc, jc);
+        fold_t<(C & 15)>(mycg[C / 16], jc[0], jc[1], jc[2], t, t0, t1, t2);
         g += t; ga += fabsf(t);
-        fold_h(Hrow, jown[C][0], jown[C][1], jown[C][2], t0, t1, t2);
+        fold_h(Hrow, jc[0], jc[1], jc[2], t0, t1, t2);
       }
     });
     if constexpr (NB == 1) {
