@@ -33,6 +33,8 @@
 // iterations of an MZ_FOR are independent, and nothing but LDS scratch carries
 // values from one phase to the next (group-uniform scalars may live in registers).
 #pragma once
+#include <cstddef>
+
 #include "ant_model.h"
 
 #if defined(__HIPCC__)
@@ -113,9 +115,14 @@ struct ArrowFactor {
 template <int NB>
 struct alignas(16) AntScratchT {
   using D = AntDims<NB>;
+  // ================= part 1: what EVERY path uses — and all that the quad forward pass (ant_forward_rows.h: plain ant, one two-slide
+  // block, >= 16 lanes per env) ever touches.  Its kernels allocate only this prefix per env (slim_bytes(): 4.7 KB instead of 9.1 KB
+  // for the plain ant, so that 32 envs fit a CU's LDS and 8192 envs run in one round); the members of part 2 must not be
+  // reached from that path.
   // step-persistent
   float qpos[D::NQ + 1], qvel[D::NV], x0q[D::NQ + 1], x0v[D::NV], accv[D::NV], accf[D::NV], warm[D::NV], fact[D::NV];
-  float qacc[D::NV], qas[D::NV], qfs[D::NV];
+  float qacc[D::NV], qas[D::NV];
+  float grad[D::NV], Mx[D::NV];  // (the RK4 bookkeeping of ant_mj_step borrows them between evaluations)
   // Low-order parts of the absolute positions (AntDims::NLO) within the step: qpos[i] + qlo[..] is the coordinate to ~1e-14.  The
   // state that enters and leaves a step is fp32; between its 20 forward evaluations a coordinate of ~10 m rounded to fp32 is off by
   // up to 5e-7, which a contact row turns into K * 5e-7 * h = 1e-5 of velocity (K ~ 2500-3900 /s^2 for these solref values) — the
@@ -123,40 +130,44 @@ struct alignas(16) AntScratchT {
   // vs block; measured: AntPush 99.9 % quantile 1.1e-5, round 3).  RK4's position updates are therefore formed in float64 and
   // split (ant_integrate_pos), and the contact code subtracts hi parts first, lo parts after.
   float qlo[D::NLO], x0lo[D::NLO];
-  // kinematics (positions relative to the torso origin c)
+  float red[4];
+  // kinematics (positions relative to the torso origin c) — the quad path publishes them only for its fall-back
   float R0[9], cz;               // torso rotation (row-major), torso height
   int nearwall;                  // 0: no maze wall within the ant's reach of the torso (wall tests skipped)
-  float p1[4][3], p2[4][3];      // aux / ankle body origins
   float w[12][3], com[12][3];    // capsule axis and centre of body 1 + 3l + k
-  float bR[9], bx[3], bc[3];     // object ball (config 5): rotation (row-major), body origin and sphere centre relative to the torso origin
   float zw[3];                   // hip axis (world) = R0 * ez
   float Sh[4][3], Sa[4][6];      // hip: linear part (angular = zw); ankle: angular, linear
-  float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
-  float fbody[13][6], bias[D::NV], Iall[10];  // per-body inertial + velocity-product force (spatial, at c)
-  alignas(16) Arrow<D::NH> M, H;
-  // plain ant: M once more as dense rows (16 floats apart, zeros preset per step): lane r of the row solver reads its row with
-  // four wide loads instead of 22 scattered ones and a select chain
-  alignas(16) float Md[NB <= 1 ? 16 : 1][16];  // (one movable block: dofs 14, 15 = its slides — still one 16-lane row)
-  ArrowFactor<D::NH> F;
-  float grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
   // contacts
   int ncon, cnt[D::NGEOM], cbeg[5];  // contacts of leg l occupy slots [cbeg[l], cbeg[l+1]); hub-only contacts [0, cbeg[0])
   int nblkcon;                       // the first nblkcon slots hold the contacts of the movable bodies' own enumerators (no robot geom involved)
   int cleg[D::NC], ccls[D::NC];      // leg (-1 none) and robot body class (-1 none) of the contact
   int csrc[D::NC], con_over;         // single-pass enumeration (plain ant): staging entry of the contact (-1: geometry in cY[c]); a geom overflowed its staging
-  alignas(16) float cJ[D::NC][3][D::NCOL];  // [normal, mu*t1, mu*t2] x [hub, hip, ankle]
+  alignas(16) float cJ[D::NC][3][D::NCOL];  // [normal, mu*t1, mu*t2] x [hub, hip, ankle]; quad path: the contacts' 24-float wrench records
   alignas(16) float cY[D::NC][3][D::NCOL];  // W * J of the current Newton iterate (also stages contact geometry)
-  float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3];
-  // joint limits (8 hinges)
-  float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
-  float red[4];
   uint32_t rowmask[MZ_MAX_GRID + 4];  // the maze's cell grid (bit j of word i: BLOCK), copied once per step: one LDS read per row lookup
   uint32_t platmask[MZ_MAX_GRID + 4]; // elevated mazes: bit j of word i: the cell carries a platform (every cell but the chasms)
   int status, iters;
   int ncon_true;  // contacts as MuJoCo counts them (s.ncon counts merged entries of the block's enumerators once: con_enum_item MERGE)
+  // ================= part 2: the lane-group formulation only (8-lane groups, two and more blocks, the ball, the host emulation) and
+  // the instrumented builds
+  alignas(16) float legacy_begin[4];  // (marks the end of the prefix)
+  float qfs[D::NV];
+  float p1[4][3], p2[4][3];      // aux / ankle body origins
+  float bR[9], bx[3], bc[3];     // object ball (config 5): rotation (row-major), body origin and sphere centre relative to the torso origin
+  float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
+  float fbody[13][6], bias[D::NV], Iall[10];  // per-body inertial + velocity-product force (spatial, at c)
+  alignas(16) Arrow<D::NH> M, H;
+  // M once more as dense rows in the row solver's position order (ant_solve_rows: the row solver on the lane-group forward pass)
+  alignas(16) float Md[NB <= 1 ? 16 : 1][16];
+  ArrowFactor<D::NH> F;
+  float search[D::NV], Ms[D::NV];
+  float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3];
+  // joint limits (8 hinges)
+  float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   // optional phase timers (device builds with PROF): cycles per phase id, last timestamp
   unsigned long long prof_t0;
   unsigned int prof[16];
+  static constexpr size_t slim_bytes() { return offsetof(AntScratchT, legacy_begin); }
 };
 using AntScratch = AntScratchT<0>;
 
@@ -1837,6 +1848,10 @@ MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base,
 template <int NB, class C>
 MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame) {
   using D = AntDims<NB>;
+  if constexpr (NB <= 1 && C::row_solver) {  // the quad layout: RK4 bookkeeping in the dof lanes' registers (ant_forward_rows.h)
+    ant_mj_step_rows(cx, K, s, first_frame);
+    return;
+  }
   const float h = K.h;
   MZ_FOR(i, D::NQ) s.x0q[i] = s.qpos[i];
   MZ_FOR(i, D::NLO) s.x0lo[i] = s.qlo[i];
@@ -1944,6 +1959,8 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 template <int NB, class C>
 MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
   MZ_FOR(i, AntDims<NB>::NLO) s.qlo[i] = 0.f;  // the state that enters a step is fp32: no low-order parts yet
+  constexpr bool quad = NB <= 1 && C::row_solver;  // the quad forward pass keeps M in registers — and its kernels do not even allocate part 2 of the scratch block
+  if constexpr (!quad) {
   if constexpr (NB <= 1) { MZ_FOR(i, 256) s.Md[i >> 4][i & 15] = (NB == 1 && (i == 14 * 17 || i == 15 * 17)) ? K.block_mass : 0.f; }  // entries between different legs stay zero; a block's slides: its mass
   cx.sync();
   MZ_FOR(e, 9) {  // linear block of the root's mass matrix: total mass x identity (summed in body order, as the composite inertia is)
@@ -1952,6 +1969,7 @@ MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
     const int i = e / 3, j = e - 3 * i;
     s.M.rr[i][j] = i == j ? m : 0.f;
     if constexpr (NB <= 1) s.Md[md_root_pos(i)][md_root_pos(j)] = i == j ? m : 0.f;
+  }
   }
   MZ_FOR(i, MZ_MAX_GRID) {
     s.rowmask[i] = maze_row(K.maze, i);

@@ -248,7 +248,7 @@ __device__ __forceinline__ void ant_lane_consts(const AntDev& K, DevCtx<G, PROF>
 // lanes that own them (block_rows_direct).  A robot geom touching the block is a record like any other, flagged so that the slide
 // lanes see its reaction.
 template <int NB, int G, bool PROF>
-__device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
+__device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   static_assert(G >= 16, "one DPP row per env at least");
   static_assert(NB <= 1, "row layout: 14 robot dofs + one block's two slides");
   using namespace rows;
@@ -494,5 +494,59 @@ __device__ __forceinline__ void ant_forward_rows(const DevCtx<G, PROF>& cx, cons
     }
   }
   cx.tick(s, 11);
-  ant_solve_rows_core<NB, G, PROF, true>(cx, K, s, first, Mrow, qfs, Sax);
+  return ant_solve_rows_core<NB, G, PROF, true>(cx, K, s, first, Mrow, qfs, Sax);  // qacc of this lane's dof
+}
+
+// One mj_step with RK4 (ant_mj_step of ant_dyn.h) on the quad layout: every dof lane keeps its own velocity, the RK4
+// accumulators and the stage's acceleration in registers — the forward pass hands qacc back in the register of the lane that owns
+// it — and writes only what the next evaluation reads (qpos, qvel, the solver's warm start) to LDS: one hand-off per stage instead
+// of three.  The free joint's quaternion is advanced redundantly by every lane (the three body-frame rates come by row
+// broadcast) and stored by one.
+template <int NB, int G, bool PROF>
+__device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame) {
+  using namespace rows;
+  using C = DevCtx<G, PROF>;  // (MZ_FOR)
+  using D = AntDims<NB>;
+  constexpr int NR = 14 + 2 * NB;
+  const float h = K.h;
+  const int p = cx.l & 15;
+  const bool isdof = p < NR;
+  const int i = isdof ? pos2dof(p) : 0;              // this lane's dof
+  MZ_FOR(k, D::NQ) s.x0q[k] = s.qpos[k];
+  MZ_FOR(k, D::NLO) s.x0lo[k] = s.qlo[k];
+  const float x0v = isdof ? s.qvel[i] : 0.f;
+  float qvel = x0v, accv = 0.f, accf = 0.f;
+  cx.sync();
+  // position update of this lane's coordinate from the frame's start: qpos <- integrate(x0q, vel, h) (mj_integratePos)
+  auto integrate = [&](float vel) {
+    const float w0 = bcast<7>(vel), w1 = bcast<10>(vel), w2 = bcast<11>(vel);  // root angular dofs 3, 4, 5 sit on lanes 7, 10, 11
+    float quat[4];
+    const float w[3] = {w0, w1, w2};
+    quat_integratef(s.x0q + 3, w, h, quat);
+    if (p == 7) { s.qpos[3] = quat[0]; s.qpos[4] = quat[1]; s.qpos[5] = quat[2]; s.qpos[6] = quat[3]; }
+    if (isdof) {
+      if (i < 2) mz_step_split(s.x0q[i], s.x0lo[i], h, vel, &s.qpos[i], &s.qlo[i]);       // absolute x, y: hi + lo (AntScratchT::qlo)
+      else if (i == 2) s.qpos[2] = s.x0q[2] + h * vel;
+      else if (i >= 6 && i < 14) s.qpos[i + 1] = s.x0q[i + 1] + h * vel;                   // hinges: qpos index = dof + 1
+      else if (i >= 14) mz_step_split(s.x0q[i + 1], s.x0lo[2 + (i - 14)], h, vel, &s.qpos[i + 1], &s.qlo[2 + (i - 14)]);  // block slides
+    }
+  };
+  for (int st = 0; st < 4; st++) {
+    const float qacc = ant_forward_rows(cx, K, s, first_frame && st == 0);
+    const float bw = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+    const float aw = st == 2 ? 1.0f : 0.5f;  // Butcher A: diag(1/2, 1/2, 1)
+    accv += bw * qvel;
+    accf += bw * qacc;
+    // the next stage's constraint solve starts from this stage's solution (after the 4th stage: MuJoCo's qacc_warmstart)
+    if (isdof) s.warm[i] = qacc;
+    if (st < 3) {
+      integrate(aw * qvel);
+      qvel = x0v + h * aw * qacc;
+      if (isdof) s.qvel[i] = qvel;
+      cx.sync();
+    }
+  }
+  integrate(accv);
+  if (isdof) s.qvel[i] = x0v + h * accf;
+  cx.sync();
 }

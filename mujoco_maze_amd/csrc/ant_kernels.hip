@@ -50,6 +50,12 @@ struct AntIO {  // per-env staging of the step's inputs / outputs next to the sc
 };
 template <int NB>
 struct alignas(16) AntEnvLDS { AntScratchT<NB> s; AntIO io; };
+// LDS bytes of one env: scratch block + I/O staging.  The quad forward pass (plain ant / one two-slide block at >= 16 lanes per env, not
+// instrumented) touches only part 1 of the scratch block (AntScratchT::slim_bytes): 4.7 + 0.3 KB per plain-ant env, 32 envs per CU.
+template <int NB, int G, bool PROF>
+constexpr size_t ant_scratch_bytes() { return (NB <= 1 && G >= 16 && !PROF) ? (AntScratchT<NB>::slim_bytes() + 15) / 16 * 16 : sizeof(AntScratchT<NB>); }
+template <int NB, int G, bool PROF>
+constexpr size_t ant_env_lds_bytes() { return ant_scratch_bytes<NB, G, PROF>() + (sizeof(AntIO) + 15) / 16 * 16; }
 
 // Register budget per lane-group width: the batch is fixed (4096 envs/GPU), so the wave count is 64*N/G and
 // the kernel must fit  N*G/64 / 1024 SIMDs  waves per SIMD to be resident in one round.
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   using D = AntDims<NB>;
   const AntDev& K = *Kp;  // model constants: scalar loads from a device-resident block (L2 / scalar-cache hits)
-  AntEnvLDS<NB>* lds = reinterpret_cast<AntEnvLDS<NB>*>(lds_raw);
+  constexpr size_t SB = ant_scratch_bytes<NB, G, PROF>(), EB = ant_env_lds_bytes<NB, G, PROF>();  // scratch block | I/O staging, per env
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
   if constexpr (NB <= 1 && G >= 16) ant_lane_consts(K, cx);  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
@@ -74,11 +80,12 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   int env = blockIdx.x * EPB + slot;
   const bool live = env < n;
   if (!live) env = n - 1;  // surplus groups shadow the last env (no stores)
-  AntScratchT<NB>& s = lds[slot].s;
-  float* act_s = lds[slot].io.act;
-  float* obs_s = lds[slot].io.obs;
-  float* out_s = lds[slot].io.out;
-  int* iout_s = lds[slot].io.iout;
+  AntScratchT<NB>& s = *reinterpret_cast<AntScratchT<NB>*>(lds_raw + (size_t)slot * EB);
+  AntIO& io = *reinterpret_cast<AntIO*>(lds_raw + (size_t)slot * EB + SB);
+  float* act_s = io.act;
+  float* obs_s = io.obs;
+  float* out_s = io.out;
+  int* iout_s = io.iout;
   float* rec = state + (size_t)env * D::REC;
   ant_load<NB>(cx, s, rec);
   for (int i = cx.l; i < ANT_NU; i += G) act_s[i] = actions[(size_t)env * ANT_NU + i];
@@ -95,10 +102,11 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   int env2 = blockIdx.x * EPB + slot2;
   const bool live2 = env2 < n;
   if (!live2) env2 = n - 1;
-  AntScratchT<NB>& s2 = lds[slot2].s;
-  const float* obs2 = lds[slot2].io.obs;
-  const float* out2 = lds[slot2].io.out;
-  const int* iout2 = lds[slot2].io.iout;
+  AntScratchT<NB>& s2 = *reinterpret_cast<AntScratchT<NB>*>(lds_raw + (size_t)slot2 * EB);
+  const AntIO& io2 = *reinterpret_cast<const AntIO*>(lds_raw + (size_t)slot2 * EB + SB);
+  const float* obs2 = io2.obs;
+  const float* out2 = io2.out;
+  const int* iout2 = io2.iout;
   float* rec2 = state + (size_t)env2 * D::REC;
   const int obs_dim = ANT_OBS + ant_obs_extra<NB>(K);
   const uint8_t d = *(const uint8_t*)&iout2[0];
@@ -272,8 +280,9 @@ template <int NB, int G>
 static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   int wpb = h->waves_per_block;
   int epb = wpb * 64 / G;
-  size_t lds = (size_t)epb * sizeof(AntEnvLDS<NB>);
-  while (lds > 160 * 1024 && wpb > 1) { wpb /= 2; epb = wpb * 64 / G; lds = (size_t)epb * sizeof(AntEnvLDS<NB>); }
+  const size_t per_env = h->prof ? ant_env_lds_bytes<NB, G, true>() : ant_env_lds_bytes<NB, G, false>();
+  size_t lds = (size_t)epb * per_env;
+  while (lds > 160 * 1024 && wpb > 1) { wpb /= 2; epb = wpb * 64 / G; lds = (size_t)epb * per_env; }
   const dim3 grid((h->n + epb - 1) / epb), block(64 * wpb);
   // the dynamic-LDS attribute is per kernel function: set once per (instantiation, size), not on every step
   static size_t lds_set[2][32] = {};  // [instrumented build][device]

@@ -335,7 +335,7 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
 // The staged Jacobian rows (cJ written by con_row_item, read back as jown / Jf: 16 + 6 LDS reads per lane and evaluation, on top
 // of the phase that built them) are gone for the plain ant; the ant with a movable block (WR = false) keeps them.
 template <int NB, int G, bool PROF, bool WR = false>
-__device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare,
+__device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare,
                                                     const float (&Mrow)[14 + 2 * NB], const float qfs, const float (&Sax)[6]) {
   static_assert(G >= 16, "one DPP row per env at least");
   static_assert(NB <= 1, "one 16-lane row holds 14 dofs + one block's two slides");
@@ -792,9 +792,14 @@ __device__ __forceinline__ void ant_solve_rows_core(const DevCtx<G, PROF>& cx, c
     it++;
   }
   if (isdof) s.qacc[ri] = qacc;
-  if (cx.l == 0) { s.iters = it; if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER; s.prof[15] += (unsigned)it; }
+  if (cx.l == 0) {
+    s.iters = it;
+    if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER;
+    if constexpr (PROF) s.prof[15] += (unsigned)it;  // (part 2 of the scratch block: instrumented builds only)
+  }
   cx.sync();
   cx.tick(s, 8);
+  return qacc;  // this lane's entry (position order; 0 on lanes without a dof)
 }
 
 // The solve on the LDS copies of M and qfrc_smooth (s.Md: dense rows in POSITION order, written by crb_leg_item / crb_root_item /
