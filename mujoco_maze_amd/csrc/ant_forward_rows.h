@@ -322,6 +322,9 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx, con
       nfound++;
     });
   }
+#ifdef MZ_EXP_SUBTICK  // experiment build: the robot geoms' narrow phase is booked on slot 0, the block's enumerators on slot 3
+  cx.tick(s, 0);
+#endif
   // the movable block's own enumerators (floor corners | the 3 x 3 cells under it, platform and wall each | slide limits), one per
   // lane of the group's first eleven, staged in the cY block as in the lane-group path; their contacts take the first slots
   int nblk = 0, nrep = 0;  // nrep: contact points folded into merged entries (for the count MuJoCo would report)
@@ -341,6 +344,9 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx, con
       for (int i = 0; i < mine; i++) { const int slot = before + i; if (slot < NC) { s.csrc[slot] = MZ_STAGE_OF(NB) * cx.l + i; s.cleg[slot] = -1; s.ccls[slot] = -1; } }
     if (nblk > NC) nblk = NC;
   }
+#ifdef MZ_EXP_SUBTICK
+  cx.tick(s, 3);
+#endif
   const bool over = cx.gany(nfound > 3) || bover;
   // compact slots in geom order (torso, then per leg: welded capsule, aux, ankle): one packed-count butterfly
   const int rank = j == 3 ? 0 : 1 + 3 * l + (j == 2 ? 0 : j + 1);

@@ -77,7 +77,12 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
   if constexpr (NB <= 1 && G >= 16) ant_lane_consts(K, cx);  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
   const int slot = threadIdx.x / G;
-  int env = blockIdx.x * EPB + slot;
+  // XCD-aware block of envs (mz_device.h xcd_block; round 4): the workgroups of one XCD take a contiguous range of envs, so the
+  // cache lines two neighbouring workgroups share — obs rows are 120 B, records 192 B, reward / done a few bytes per workgroup —
+  // are merged in ONE L2 instead of being fetched for ownership and written back by several (PMC, AntPush at two envs per
+  // workgroup: FETCH + WRITE 1.61 x the algorithmic bytes with the identity map)
+  const int wg = xcd_block(blockIdx.x, gridDim.x);
+  int env = wg * EPB + slot;
   const bool live = env < n;
   if (!live) env = n - 1;  // surplus groups shadow the last env (no stores)
   AntScratchT<NB>& s = *reinterpret_cast<AntScratchT<NB>*>(lds_raw + (size_t)slot * EB);
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int slot2 = tid / G, l2 = tid % G;
-  int env2 = blockIdx.x * EPB + slot2;
+  int env2 = xcd_block(blockIdx.x, gridDim.x) * EPB + slot2;
   const bool live2 = env2 < n;
   if (!live2) env2 = n - 1;
   AntScratchT<NB>& s2 = *reinterpret_cast<AntScratchT<NB>*>(lds_raw + (size_t)slot2 * EB);
@@ -172,8 +177,8 @@ __global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G
       atomicMax(&prof[13], tot);                  // slowest wave of the accumulation window
       atomicAdd(&prof[14], (tot >> 8) * (tot >> 8));  // sum of squares of the per-wave totals (units of 256 cycles)
       // per-workgroup totals (mz_read_wave_cycles): cycles in the low 40 bits, Newton iterations of the wave above them
-      prof[16 + blockIdx.x] += tot + ((unsigned long long)s.prof[15] << 40);
-      for (int k = 0; k < 16; k++) prof[16 + gridDim.x * 0 + n + (size_t)blockIdx.x * 16 + k] += s.prof[k];  // per-workgroup phases (mz_read_wave_phase_cycles)
+      prof[16 + wg] += tot + ((unsigned long long)s.prof[15] << 40);  // (indexed by env block, not by workgroup id)
+      for (int k = 0; k < 16; k++) prof[16 + gridDim.x * 0 + n + (size_t)wg * 16 + k] += s.prof[k];  // per-workgroup phases (mz_read_wave_phase_cycles)
     }
   }
 }

@@ -34,8 +34,8 @@ namespace rows {
 // qfs, warm, qas, qacc, the columns of cJ) are in dof order.  The point of the layout: a leg's kinematics, composite inertias and
 // bias forces are computed by the four lanes of its own quad (ant_forward_rows.h), and its two rows of M come out on the lanes
 // that own them — `quad_perm` moves instead of LDS hand-offs.
-__host__ __device__ constexpr int pos2dof(int p) { return (p & 3) < 2 ? 6 + 2 * (p >> 2) + (p & 1) : (p < 12 ? 2 * (p >> 2) + (p & 3) - 2 : p); }
-__host__ __device__ constexpr int dof2pos(int d) { return d < 6 ? 4 * (d >> 1) + 2 + (d & 1) : (d < 14 ? 4 * ((d - 6) >> 1) + ((d - 6) & 1) : d); }
+__host__ __device__ __forceinline__ constexpr int pos2dof(int p) { return (p & 3) < 2 ? 6 + 2 * (p >> 2) + (p & 1) : (p < 12 ? 2 * (p >> 2) + (p & 3) - 2 : p); }
+__host__ __device__ __forceinline__ constexpr int dof2pos(int d) { return d < 6 ? 4 * (d >> 1) + 2 + (d & 1) : (d < 14 ? 4 * ((d - 6) >> 1) + ((d - 6) & 1) : d); }
 static_assert(dof2pos(0) == 2 && dof2pos(5) == 11 && dof2pos(6) == 0 && dof2pos(13) == 13 && pos2dof(7) == 3 && pos2dof(9) == 11 && pos2dof(15) == 15, "row layout");
 
 template <int P>
@@ -784,7 +784,10 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       }
     }
 #ifdef MZ_EXP_TRACE  // developer aid (tools/replay_trace.py): one line per Newton iteration of the first env of a wave
-    if (cx.l == 0) printf("TRACE it %d ncon %d gnorm %g anorm %g changed %d alpha %g sn %g qn %g exact %d done %d u %g %g %g v %g %g %g D %g\n", it, ncon, gnorm, anorm, (int)changed, alpha, sn, qn, (int)exact, (int)done, u[0][0], u[0][1], u[0][2], v[0][0], v[0][1], v[0][2], cD[0]);
+    {
+      const float g14 = NR > 14 ? bcast<14>(g) : 0.f, g15 = NR > 14 ? bcast<15>(g) : 0.f, s14 = NR > 14 ? bcast<14>(search) : 0.f, s15 = NR > 14 ? bcast<15>(search) : 0.f;
+      if (cx.l == 0) printf("TRACE it %d ncon %d nB %d gnorm %g anorm %g gblk %g %g sblk %g %g changed %d alpha %g sn %g qn %g exact %d done %d u %g %g %g v %g %g %g D %g\n", it, ncon, nB, gnorm, anorm, g14, g15, s14, s15, (int)changed, alpha, sn, qn, (int)exact, (int)done, u[0][0], u[0][1], u[0][2], v[0][0], v[0][1], v[0][2], cD[0]);
+    }
 #endif
     if (exact && K.trust_exact) done = true;
     if (changed && alpha * alpha * sn <= MZ_NEWTON_STALL * MZ_NEWTON_STALL * qn) done = true;  // stationary at fp32 resolution (ant_dyn.h ant_solve)

@@ -44,19 +44,23 @@ struct PlanarDims {
 #endif
 
 // Staging of the bare Point's single-pass contact enumeration (planar_forward): geometry of the contacts an enumerator found,
-// 1 entry for a sphere-wall cell enumerator, 8 for an arrow-wall cell one (mjc_BoxBox's maximum).
+// 1 entry for a sphere-wall cell enumerator, 8 for an arrow-wall cell one (mjc_BoxBox's maximum).  An enumerator takes its block of
+// entries when it finds its first contact (an LDS counter; round 4): the sphere and the arrow — a 0.2 cube — reach four cells each
+// at most, so 4 + 4 x 8 entries serve where a fixed block per enumerator took 81 (4.5 KB of the 13 KB an env held in LDS, which
+// kept the step kernel at six workgroups per CU where its registers allow eight).  Which block an enumerator gets depends on the
+// order the lanes arrive in; the contact ORDER does not: slots are dealt by enumerator index, as before.
 struct PlStageEntry { double dist, pos[3], n[3]; };
 template <int NB, int NS>
 struct PlStage {};
 template <>
 struct PlStage<0, 0> {
-  static constexpr int NSTAGE = 9 + 8 * 9;
+  static constexpr int NSTAGE = 40;
   PlStageEntry stage[NSTAGE];
-  int csrc[24];  // contact slot -> staging entry
+  int csrc[24];  // contact slot -> staging entry (| 256 for the arrow's contacts)
+  int nstage, sbase[18];  // entries taken so far; first entry of enumerator e
 #ifdef MZ_EXP_PROF
   unsigned long long prof[12], prof_t0;
 #endif
-  static MZP_HD int base(int e) { return e < 9 ? e : 9 + 8 * (e - 9); }
   static MZP_HD int cap(int e) { return e < 9 ? 1 : 8; }
 };
 
@@ -68,9 +72,11 @@ struct alignas(16) PlanarScratch : PlStage<NB, NS> {
   double qas[D::NV], qacc[D::NV], grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
   double wd[D::NV];           // constraint-induced acceleration (qacc - qacc_smooth) of the previous RK4 stage: warm start
   double M3[3][3];            // robot block of the mass matrix (blocks: block_mass on the diagonal)
-  double H[D::NV][D::NV];
-  double cJ[D::NC][3][D::NV], caref[D::NC][3], cD[D::NC], cu[D::NC][3], cg[D::NC][3], cW[D::NC][5], cjv[D::NC][3];
+  static constexpr bool BARE = NB == 0 && NS == 0;  // the bare Point keeps gradient / curvature blocks and the Hessian in registers (planar_forward)
+  double H[BARE ? 1 : D::NV][BARE ? 1 : D::NV];
+  double cJ[D::NC][3][D::NV], caref[D::NC][3], cD[D::NC], cu[D::NC][3], cg[BARE ? 1 : D::NC][3], cW[BARE ? 1 : D::NC][5], cjv[D::NC][3];
   double co, si;              // cos / sin of the heading of the current stage
+  double old_xy[2];           // robot xy in front of the step (the wall detector's start point): parked here, not carried in registers through the step
   int ncon, cnt[D::NE], cbeg[D::NE], status, robot_near;
 };
 
@@ -229,44 +235,10 @@ MZP_HD void pl_box_box(const double* pos1, const double* mat1, const double* siz
   const double P1 = sel3d(cf, a1), P2 = sel3d(cf, a2), P3 = sel3d(cf, a), U1 = sel3d(u, a1), U2 = sel3d(u, a2), U3 = sel3d(u, a);
   const double V1 = sel3d(v, a1), V2 = sel3d(v, a2), V3 = sel3d(v, a), S1 = sel3d(sA, a1), S2 = sel3d(sA, a2), S3 = sel3d(sA, a);
   const double tol = 1e-12 * (1.0 + S1 + S2), dtol = 1e-9 * (1.0 + S1 + S2);
-  double k1[8], k2[8], k3[8];  // candidates kept so far (constant indices only)
-  int nk = 0, nemit = 0;
   // Candidates can coincide only when an incident corner lies on a border line of the reference rectangle: structurally so
   // when the incident edges run parallel to the reference axes (aligned boxes), otherwise only by a coincidence at the 1e-9
   // level, which is ignored here — the comparison against the kept candidates runs for aligned rectangles only.
   const bool aligned = fabs(U1 * U2) + fabs(V1 * V2) <= 1e-9 * (U1 * U1 + U2 * U2 + V1 * V1 + V2 * V2);
-  auto consider = [&](double x1, double x2, double x3) {
-    if (aligned) {
-      bool dup = false;
-#pragma unroll
-      for (int e = 0; e < 8; e++)
-        if (e < nk && fabs(x1 - k1[e]) <= dtol && fabs(x2 - k2[e]) <= dtol && fabs(x3 - k3[e]) <= dtol) dup = true;
-      if (dup || nk >= 8) return;  // (a ninth distinct vertex cannot exist: two rectangles intersect in at most an octagon)
-#pragma unroll
-      for (int e = 0; e < 8; e++) if (e == nk) { k1[e] = x1; k2[e] = x2; k3[e] = x3; }
-      nk++;
-    }
-    const double dist = sg * x3 - S3;
-    if (dist > margin || nemit >= 8) return;
-    nemit++;
-    const double x3m = x3 - sg * 0.5 * dist;
-    double pl[3], nl[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { pl[k] = k == a1 ? x1 : (k == a2 ? x2 : x3m); nl[k] = k == a ? (fromB ? -sg : sg) : 0.0; }
-    PlContact c;
-    c.dist = dist;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      c.pos[k] = matA[3 * k] * pl[0] + matA[3 * k + 1] * pl[1] + matA[3 * k + 2] * pl[2] + posA[k];
-      c.n[k] = matA[3 * k] * nl[0] + matA[3 * k + 1] * nl[1] + matA[3 * k + 2] * nl[2];
-    }
-    c.b1 = b1id; c.b2 = b2id; c.cls = cls;
-    emit(c);
-  };
-  // The 24 candidates in the oracle's order — 4 incident corners inside the reference rectangle | 4 incident edges x 2 border
-  // directions x 2 sides | 4 reference corners inside the incident rectangle (on the incident plane) — as ONE rolled loop: this
-  // path is rare (a deep overlap, whose least-penetration axis is vertical), and 24 inlined copies of `consider` with the
-  // caller's emit in each cost every launch a third of its time in instruction fetch alone (measured).
   const double det = U1 * V2 - U2 * V1;
   // no area -> no contact [ASSUME-12]: only rectangles with parallel edges can intersect in a segment (a border line shared);
   // their intersection is the rectangle of the overlapping extents — measured directly (the oracle measures its candidates)
@@ -274,35 +246,76 @@ MZP_HD void pl_box_box(const double* pos1, const double* mat1, const double* siz
     const double e1 = fabs(U1) + fabs(V1), e2 = fabs(U2) + fabs(V2);
     if (fmin(S1, P1 + e1) - fmax(-S1, P1 - e1) <= MZ_BOX_MINOVERLAP || fmin(S2, P2 + e2) - fmax(-S2, P2 - e2) <= MZ_BOX_MINOVERLAP) return;
   }
-  {
-#pragma unroll 1
-    for (int c = 0; c < 24; c++) {
-      double x1 = 0.0, x2 = 0.0, x3 = 0.0;
-      bool valid = false;
-      if (c < 4) {
-        const double su = (c & 1) ? 1.0 : -1.0, sv = (c & 2) ? 1.0 : -1.0;
-        x1 = P1 + su * U1 + sv * V1; x2 = P2 + su * U2 + sv * V2; x3 = P3 + su * U3 + sv * V3;
-        valid = fabs(x1) <= S1 + tol && fabs(x2) <= S2 + tol;
-      } else if (c < 20) {
-        const int k = c - 4, e = k >> 2, w = (k >> 1) & 1;
-        const double side = (k & 1) ? 1.0 : -1.0, sgn = (e & 1) ? 1.0 : -1.0;
-        const double p1 = e < 2 ? P1 + sgn * V1 : P1 + sgn * U1, p2 = e < 2 ? P2 + sgn * V2 : P2 + sgn * U2, p3 = e < 2 ? P3 + sgn * V3 : P3 + sgn * U3;
-        const double q1 = e < 2 ? U1 : V1, q2 = e < 2 ? U2 : V2, q3 = e < 2 ? U3 : V3;
-        const double pc = w ? p2 : p1, qc = w ? q2 : q1, po = w ? p1 : p2, qo = w ? q1 : q2, Sc = w ? S2 : S1, So = w ? S1 : S2;
-        if (fabs(qc) >= 1e-15) {
-          const double t = (side * Sc - pc) / qc;
-          valid = t >= -1.0 && t <= 1.0 && fabs(po + t * qo) <= So + tol;
-          x1 = p1 + t * q1; x2 = p2 + t * q2; x3 = p3 + t * q3;
-        }
-      } else if (fabs(det) > 1e-15) {
-        const int k = c - 20;
-        const double x = ((k & 1) ? S1 : -S1) - P1, y = ((k & 2) ? S2 : -S2) - P2;
-        const double al = (x * V2 - y * V1) / det, be = (U1 * y - U2 * x) / det;
-        valid = fabs(al) <= 1.0 + 1e-12 && fabs(be) <= 1.0 + 1e-12;
-        x1 = P1 + al * U1 + be * V1; x2 = P2 + al * U2 + be * V2; x3 = P3 + al * U3 + be * V3;
+  // The 24 candidates in the oracle's order — 4 incident corners inside the reference rectangle | 4 incident edges x 2 border
+  // directions x 2 sides | 4 reference corners inside the incident rectangle (on the incident plane) — as ONE rolled loop: this
+  // path is rare (a deep overlap, whose least-penetration axis is vertical), and 24 inlined copies of the caller's emit cost every
+  // launch a third of its time in instruction fetch alone (measured).
+  auto cand = [&](int c, double& x1, double& x2, double& x3) -> bool {
+    bool valid = false;
+    x1 = 0.0; x2 = 0.0; x3 = 0.0;
+    if (c < 4) {
+      const double su = (c & 1) ? 1.0 : -1.0, sv = (c & 2) ? 1.0 : -1.0;
+      x1 = P1 + su * U1 + sv * V1; x2 = P2 + su * U2 + sv * V2; x3 = P3 + su * U3 + sv * V3;
+      valid = fabs(x1) <= S1 + tol && fabs(x2) <= S2 + tol;
+    } else if (c < 20) {
+      const int k = c - 4, e = k >> 2, w = (k >> 1) & 1;
+      const double side = (k & 1) ? 1.0 : -1.0, sgn = (e & 1) ? 1.0 : -1.0;
+      const double p1 = e < 2 ? P1 + sgn * V1 : P1 + sgn * U1, p2 = e < 2 ? P2 + sgn * V2 : P2 + sgn * U2, p3 = e < 2 ? P3 + sgn * V3 : P3 + sgn * U3;
+      const double q1 = e < 2 ? U1 : V1, q2 = e < 2 ? U2 : V2, q3 = e < 2 ? U3 : V3;
+      const double pc = w ? p2 : p1, qc = w ? q2 : q1, po = w ? p1 : p2, qo = w ? q1 : q2, Sc = w ? S2 : S1, So = w ? S1 : S2;
+      if (fabs(qc) >= 1e-15) {
+        const double t = (side * Sc - pc) / qc;
+        valid = t >= -1.0 && t <= 1.0 && fabs(po + t * qo) <= So + tol;
+        x1 = p1 + t * q1; x2 = p2 + t * q2; x3 = p3 + t * q3;
       }
-      if (valid) consider(x1, x2, x3);
+    } else if (fabs(det) > 1e-15) {
+      const int k = c - 20;
+      const double x = ((k & 1) ? S1 : -S1) - P1, y = ((k & 2) ? S2 : -S2) - P2;
+      const double al = (x * V2 - y * V1) / det, be = (U1 * y - U2 * x) / det;
+      valid = fabs(al) <= 1.0 + 1e-12 && fabs(be) <= 1.0 + 1e-12;
+      x1 = P1 + al * U1 + be * V1; x2 = P2 + al * U2 + be * V2; x3 = P3 + al * U3 + be * V3;
     }
+    return valid;
+  };
+  // The candidates kept so far are a BIT SET, not a table of coordinates (round 4): a kept candidate is recomputed from its index
+  // where a later one is compared against it.  The table was 24 doubles = 48 registers live through the routine — in a kernel that
+  // never runs it for most envs, they were what pushed the bare Point's step kernel into scratch spills (PMC: most of its HBM
+  // traffic); the recomputation is paid by aligned rectangles in deep overlap only.
+  unsigned kept = 0u;
+  int nk = 0, nemit = 0;
+#pragma unroll 1
+  for (int c = 0; c < 24; c++) {
+    double x1, x2, x3;
+    if (!cand(c, x1, x2, x3)) continue;
+    if (aligned) {
+      bool dup = false;
+#pragma unroll 1
+      for (int e = 0; e < c; e++) {
+        if (!((kept >> e) & 1u)) continue;
+        double y1, y2, y3;
+        cand(e, y1, y2, y3);
+        if (fabs(x1 - y1) <= dtol && fabs(x2 - y2) <= dtol && fabs(x3 - y3) <= dtol) dup = true;
+      }
+      if (dup || nk >= 8) continue;  // (a ninth distinct vertex cannot exist: two rectangles intersect in at most an octagon)
+      kept |= 1u << c;
+      nk++;
+    }
+    const double dist = sg * x3 - S3;
+    if (dist > margin || nemit >= 8) continue;
+    nemit++;
+    const double x3m = x3 - sg * 0.5 * dist;
+    double pl[3], nl[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pl[k] = k == a1 ? x1 : (k == a2 ? x2 : x3m); nl[k] = k == a ? (fromB ? -sg : sg) : 0.0; }
+    PlContact ct;
+    ct.dist = dist;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      ct.pos[k] = matA[3 * k] * pl[0] + matA[3 * k + 1] * pl[1] + matA[3 * k + 2] * pl[2] + posA[k];
+      ct.n[k] = matA[3 * k] * nl[0] + matA[3 * k + 1] * nl[1] + matA[3 * k + 2] * nl[2];
+    }
+    ct.b1 = b1id; ct.b2 = b2id; ct.cls = cls;
+    emit(ct);
   }
 }
 
@@ -341,7 +354,7 @@ MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const do
     if (c1 < -margin || c2 < -margin) return;
     if (c1 < penetration || c2 < penetration) {  // vertical reference normal: the general routine (rare: a deep overlap)
 #if defined(__HIP_DEVICE_COMPILE__)
-      // opaque copy made inside the rare branch: what the general routine computes then depends on it, so the compiler cannot hoist
+      // opaque copy made inside the branch: what the general routine computes then depends on it, so the compiler cannot hoist
       // its loop-invariant parts in front of the branch, onto the path of every arrow near a wall (round 3 measured the general
       // routine's mere presence at 10 % of the launch; ant_dyn.h round_vs_box: same effect, same cure)
       asm volatile("" : "+v"(co), "+v"(si));
@@ -663,6 +676,7 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     s.M3[1][0] = 0.0; s.M3[1][1] = P.mass; s.M3[1][2] = mc * co;
     s.M3[2][0] = -mc * si; s.M3[2][1] = mc * co; s.M3[2][2] = P.izz;
     s.robot_near = point_near_wall(P, s.q[0], s.q[1]) ? 1 : 0;
+    if constexpr (NB == 0 && NS == 0) s.nstage = 0;
   }
   cx.sync();
   MZ_FOR(i, NV) s.qacc[i] = s.qas[i];
@@ -681,19 +695,28 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     static_assert(NE == 18 && NC == 24, "staging layout of the bare Point");
     MZ_FOR(i, NE) {
       const int e = i < 9 ? i + 9 : i - 9;
-      int n = 0;
+      int n = 0, base = 0;
       if (maybe)
         planar_contacts<NB, NS>(P, s, e, [&](const PlContact& c) {
           if (c.dist < P.pair[c.cls].margin) {
-            if (n < PlStage<0, 0>::cap(e)) {
-              PlStageEntry& q = s.stage[PlStage<0, 0>::base(e) + n];
+            if (n == 0) {  // first contact of this enumerator: take its block of staging entries
+#if defined(__HIP_DEVICE_COMPILE__)
+              base = atomicAdd(&s.nstage, PlStage<0, 0>::cap(e));
+#else
+              base = s.nstage; s.nstage += PlStage<0, 0>::cap(e);
+#endif
+            }
+            if (n < PlStage<0, 0>::cap(e) && base + n < PlStage<0, 0>::NSTAGE) {
+              PlStageEntry& q = s.stage[base + n];
               q.dist = c.dist;
               for (int k = 0; k < 3; k++) { q.pos[k] = c.pos[k]; q.n[k] = c.n[k]; }
             }
             n++;
           }
         });
-      s.cnt[e] = n < PlStage<0, 0>::cap(e) ? n : PlStage<0, 0>::cap(e);
+      if (n > PlStage<0, 0>::cap(e)) n = PlStage<0, 0>::cap(e);
+      if (base + n > PlStage<0, 0>::NSTAGE) n = base < PlStage<0, 0>::NSTAGE ? PlStage<0, 0>::NSTAGE - base : 0;  // (flagged below)
+      s.cnt[e] = n; s.sbase[e] = base;
     }
     cx.sync();
     MZP_TICK(1);
@@ -702,10 +725,10 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       for (int g = 0; g < NE; g++) off += g < e ? s.cnt[g] : 0;
       s.cbeg[e] = off;
       const int n = s.cnt[e];
-      for (int k = 0; k < n; k++) if (off + k < NC) s.csrc[off + k] = PlStage<0, 0>::base(e) + k;
+      for (int k = 0; k < n; k++) if (off + k < NC) s.csrc[off + k] = (s.sbase[e] + k) | (e < 9 ? 0 : 256);
       if (e == NE - 1) {
         int tot = off + n;
-        if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
+        if (tot > NC || s.nstage > PlStage<0, 0>::NSTAGE) { tot = tot > NC ? NC : tot; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
         s.ncon = tot;
       }
     }
@@ -715,11 +738,11 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     if (!cx.any(ncon1 > 0)) return;
     MZ_FOR(slot, ncon1) {
       const int src = s.csrc[slot];
-      const PlStageEntry& q = s.stage[src];
+      const PlStageEntry& q = s.stage[src & 255];
       PlContact c;
       c.dist = q.dist;
       for (int k = 0; k < 3; k++) { c.pos[k] = q.pos[k]; c.n[k] = q.n[k]; }
-      const bool sphere = src < 9;  // sphere (geom1, robot) -> wall | wall (geom1) -> arrow (robot)
+      const bool sphere = src < 256;  // sphere (geom1, robot) -> wall | wall (geom1) -> arrow (robot)
       c.b1 = sphere ? 0 : -1; c.b2 = sphere ? -1 : 0; c.cls = 0;
       planar_fill_contact<NB, NS>(P, s, slot, c);
     }
@@ -1064,9 +1087,9 @@ template <int NB, int NS, class C>
 MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, const double* action) {
   constexpr int NV = PlanarDims<NB, NS>::NV;
   const double PI = 3.141592653589793;
-  double old_x = s.q[0], old_y = s.q[1];  // every lane reads the same values
   cx.sync();
   MZ_FOR(one, 1) {  // point.py:45-56
+    s.old_xy[0] = s.q[0]; s.old_xy[1] = s.q[1];
     double th = s.q[2] + action[1];
     if (th < -PI) th += PI * 2;
     else if (PI < th) th -= PI * 2;
@@ -1100,7 +1123,7 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
   // maze_env.py:454-464: manual wall bounce on the robot's xy
 #ifndef MZ_EXP_NODETECT
   if (P.nseg > 0) {
-    const double old_xy[2] = {old_x, old_y}, new_xy[2] = {s.q[0], s.q[1]};
+    const double old_xy[2] = {s.old_xy[0], s.old_xy[1]}, new_xy[2] = {s.q[0], s.q[1]};
     double fin[2];
     cx.sync();  // every lane has read the new position before the hand-off buffer (and later s.q) is written
     const int r = point_bounce_group<NB, NS>(cx, P, s, old_xy, new_xy, fin);

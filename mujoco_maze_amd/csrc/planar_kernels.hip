@@ -40,28 +40,15 @@ __device__ __forceinline__ uint32_t& st_ep(const PointState& S, int nv, int env)
 // The bare Point at 32 lanes per env runs two waves per SIMD (4096 envs = 2048 waves on 1024 SIMDs): its register budget is pinned
 // to 256 so that a few registers more do not silently halve the occupancy and send half the waves into a second round.
 template <int NB, int NS, int G>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && NS == 0 && G == 32) ? 2 : 1))) void planar_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
-                                                          const float* __restrict__ actions, float* __restrict__ obs,
-                                                          float* __restrict__ reward, uint8_t* __restrict__ done,
-                                                          int* __restrict__ goal_idx, float* __restrict__ info,
-                                                          int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
-                                                          float* __restrict__ final_obs, int ostride) {
+__device__ __forceinline__ void planar_step_body(const PointDev& P, PlanarScratch<NB, NS>& s, float* o, const DevCtx<G>& cx, int n, const PointState& S,
+                                                 int env, bool live, const float* __restrict__ actions, float* __restrict__ obs,
+                                                 float* __restrict__ reward, uint8_t* __restrict__ done, int* __restrict__ goal_idx,
+                                                 float* __restrict__ info, int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
+                                                 float* __restrict__ final_obs, int ostride) {
   using D = PlanarDims<NB, NS>;
-  constexpr int NV = D::NV, NOBS = D::NOBS, EPW = 64 / G;
-  __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
-  __shared__ PlanarScratch<NB, NS> scr[EPW];
-  __shared__ float obuf[EPW][MZ_MAX_OBS];
-  for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
-  __syncthreads();
-  DevCtx<G> cx{(int)threadIdx.x % G};
-  const int grp = threadIdx.x / G;
-  int env = xcd_block(blockIdx.x, gridDim.x) * EPW + grp;
-  const bool live = env < n;
-  if (!live) env = n - 1;  // idle groups shadow the last env (no stores) so that every lane reaches the wave-level votes
-  PlanarScratch<NB, NS>& s = scr[grp];
+  constexpr int NV = D::NV, NOBS = D::NOBS;
   for (int k = cx.l; k < NV; k += G) { s.q[k] = (double)st_q(S, n, NV, k, env); s.v[k] = (double)st_v(S, n, NV, k, env); }
   double a[2] = {(double)actions[(size_t)env * 2], (double)actions[(size_t)env * 2 + 1]};
-  const int t_new = st_t(S, NV, env) + 1;
   cx.sync();
 #ifdef MZ_EXP_PROF
   if constexpr (NB == 0 && NS == 0) { if (cx.l == 0) { for (int k = 0; k < 12; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
@@ -74,7 +61,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && 
              s.prof[3], s.prof[4], s.prof[5], s.prof[6], s.prof[7], s.prof[8]);
   }
 #endif
-  float* o = obuf[grp];
+  const int t_new = st_t(S, NV, env) + 1;  // (read here, behind the step: one register less carried through it)
   for (int i = cx.l; i < NOBS; i += G) o[i] = planar_obs_elem<NB, NS>(P, s, i, t_new);
   cx.sync();
   float outer; int tm, gi;
@@ -123,6 +110,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && 
     }
     if (cx.l == 0) { st_t(S, NV, env) = rst ? 0 : t_new; st_ep(S, NV, env) = ep; }
   }
+}
+
+template <int NB, int NS, int G>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 0 && NS == 0 && G == 32) ? 2 : 1))) void planar_step_kernel(const PointDev* __restrict__ Pp, int n, PointState S,
+                                                          const float* __restrict__ actions, float* __restrict__ obs,
+                                                          float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                          int* __restrict__ goal_idx, float* __restrict__ info,
+                                                          int* __restrict__ status, int auto_reset, uint64_t seed, uint64_t env0,
+                                                          float* __restrict__ final_obs, int ostride) {
+  constexpr int EPW = 64 / G;
+  __shared__ PointDev P;  // segment table + task shared by the block (L2-resident source)
+  __shared__ PlanarScratch<NB, NS> scr[EPW];
+  __shared__ float obuf[EPW][MZ_MAX_OBS];
+  for (int i = threadIdx.x; i < (int)(sizeof(PointDev) / 4); i += blockDim.x) ((uint32_t*)&P)[i] = ((const uint32_t*)Pp)[i];
+  __syncthreads();
+  DevCtx<G> cx{(int)threadIdx.x % G};
+  const int grp = threadIdx.x / G;
+  int env = xcd_block(blockIdx.x, gridDim.x) * EPW + grp;
+  const bool live = env < n;
+  if (!live) env = n - 1;  // idle groups shadow the last env (no stores) so that every lane reaches the wave-level votes
+  planar_step_body<NB, NS, G>(P, scr[grp], obuf[grp], cx, n, S, env, live, actions, obs, reward, done, goal_idx, info, status, auto_reset, seed, env0, final_obs,
+                              ostride);
 }
 
 template <int NB, int NS>
@@ -319,6 +328,10 @@ __global__ void view_fill_kernel(ViewDev V, int n, int ostride, int view_off, fl
   if (final_obs && done && done[env]) mzv_fill_row(V, final_obs + (size_t)env * ostride, view_off);
 }
 
+#ifdef MZ_ISA_POINT  // developer aid (tools/isa_point.sh): the bare Point's kernel only, for a look at its ISA / register budget
+template __global__ void planar_step_kernel<0, 0, 32>(const PointDev*, int, PointState, const float*, float*, float*, uint8_t*, int*, float*, int*, int, uint64_t,
+                                                        uint64_t, float*, int);
+#else
 hipError_t mzk_view_fill(mz_handle* h, hipStream_t st, float* obs, float* final_obs, const uint8_t* done) {
   if (!h->view.on) return hipSuccess;
   hipLaunchKernelGGL(view_fill_kernel, dim3((h->n + 63) / 64), dim3(64), 0, st, h->view, h->n, h->model.obs_dim, h->base_obs - 1, obs, final_obs, done);
@@ -471,3 +484,4 @@ hipError_t mzk_point_detect(mz_handle* h, hipStream_t st, int n, const double* o
   hipLaunchKernelGGL(point_detect_kernel, dim3((n + 63) / 64), dim3(64), 0, st, h->point_dev, n, old_xy, new_xy, hit, point, final_xy);
   return hipGetLastError();
 }
+#endif  // MZ_ISA_POINT

@@ -473,6 +473,50 @@ def test_point_step_parity_and_bounce(torch, oracle):
     env.close()
 
 
+def test_point_arrow_deep_inside_a_wall(torch, oracle):
+    """The bare Point's step kernel carries no general mjc_BoxBox routine (planar_kernels.hip, MODE 1): an env whose arrow sits so deep
+    inside a wall that the least-penetration axis is vertical leaves its step undone and is stepped by the kernel's second launch.
+    Here most envs are such a case (arrow centre well inside a wall box), next to ordinary ones: all of
+    them must agree with the oracle's mjc_BoxBox, whichever launch stepped them, and a second step must find the list empty again."""
+    n = 512
+    env = mm.make("PointUMaze-v0", num_envs=n)
+    cm = env.model
+    boxes = np.array(cm.world.wall_boxes())  # x, y, z, hx, hy, hz
+    rng = np.random.default_rng(31)
+    xmin, xmax, ymin, ymax = cm.world.xy_limits()
+
+    def inside(xy, shrink):
+        return ((np.abs(xy[:, None, 0] - boxes[None, :, 0]) < boxes[None, :, 3] - shrink) & (np.abs(xy[:, None, 1] - boxes[None, :, 1]) < boxes[None, :, 4] - shrink)).any(1)
+
+    qpos = np.zeros((0, 3))
+    for _ in range(200):
+        c = np.stack([rng.uniform(xmin, xmax, 4096), rng.uniform(ymin, ymax, 4096), rng.uniform(-3.1, 3.1, 4096)], 1)
+        arrow = c[:, :2] + 0.6 * np.stack([np.cos(c[:, 2]), np.sin(c[:, 2])], 1)  # point.xml: the arrow box sits 0.6 ahead of the centre
+        # the arrow (a 0.2 cube) overlaps the wall by 0.2 vertically: the vertical axis is the least-penetration one once its centre is
+        # more than 0.1 + 0.2 inside, horizontally, on every side
+        keep = inside(arrow, 0.35)
+        qpos = np.concatenate([qpos, c[keep]])
+        if len(qpos) >= n - 64:
+            break
+    assert len(qpos) >= n - 64
+    qpos = qpos[: n - 64]
+    free = np.stack([rng.uniform(xmin, xmax, 64), rng.uniform(ymin, ymax, 64), rng.uniform(-3.1, 3.1, 64)], 1)
+    st = _f32(dict(qpos=np.concatenate([qpos, free]), qvel=np.stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n), rng.uniform(-3, 3, n)], 1),
+                   warm=np.zeros((n, 3)), t=np.zeros(n, np.int32)))
+    g = oracle.forward(cm, st["qpos"], st["qvel"])
+    assert (g["counts"][: n - 64, 1] >= 4).mean() > 0.9, (g["counts"][: n - 64, 1] >= 4).mean()  # the face contacts of the oracle's general routine
+    act = np.zeros((n, 2), np.float32)  # no teleport: the step is MuJoCo's alone (a zero-length move: no manual bounce either)
+    for k in range(2):
+        env.set_state(st["qpos"], st["qvel"], None, st["t"])
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+        ref = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+        assert np.all(env.status().cpu().numpy() == 0) and np.all(ref["status"] == 0)
+        assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=1e-6, rtol=2e-7)), np.abs(obs.cpu().numpy() - ref["obs"]).max()
+        assert np.array_equal(done.cpu().numpy(), ref["done"])
+        st = _f32(st)  # (oracle.step advanced it in place) the second step: both sides from the same fp32 state again
+    env.close()
+
+
 @pytest.mark.parametrize("env_id,nblock", [("PointPush-v0", 1), ("PointPushMaze-v0", 3), ("PointBilliard-v0", 0), ("PointSmallBilliard-v1", 0)])
 def test_point_with_movable_blocks(torch, oracle, env_id, nblock):
     """Point + movable XY blocks (or the Billiard's object ball) on the lane-group planar kernel (32 / 64 lanes per env)."""

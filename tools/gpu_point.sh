@@ -1,8 +1,7 @@
-#!/bin/bash
-# GPU box helper: the Point kernels after a change — their GPU tests (golden detector moves included), bench lines, phase timers
+# Point developer loop: the Point GPU tests + bench (+ live PMC traffic)
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x -k "point or Point or golden or billiard or Billiard" 2>&1 | tail -3
-for e in PointUMaze-v0 Point4Rooms-v0 PointPush-v0 PointBilliard-v0 PointFall-v0; do
-  python bench.py --steps 300 --warmup 10 --no-cpu-baseline --env $e 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-62s %8.3f M env-steps/s   kernel %.4f ms   flagged envs %d' % (d['metric'][34:], d['value']/1e6, d['roofline']['kernel_ms'], d['config']['bad_envs']))"
-done
-[ -f mujoco_maze_amd/csrc/exp_PROF.so ] && python tools/exp_point_prof.py PointUMaze-v0
+mkdir -p gpurun_out/point
+timeout 500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -q -x --timeout 120 -k "point or Point or golden or detect" -p no:cacheprovider 2>&1 | tail -8 | tee gpurun_out/point/pytest.txt
+for a in "--env PointUMaze-v0" "--env Point4Rooms-v0" "--env PointUMaze-v0 --envs 8192"; do
+python bench.py --steps 300 --warmup 10 --no-cpu-baseline $a 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-50s %8.3f M env-steps/s   kernel %.4f ms   traffic x%.2f (%s)   flagged envs %d' % (d['metric'][34:], d['value']/1e6, r['kernel_ms'], r.get('traffic_over_algorithmic') or 0, r['traffic_source'][:4], d['config']['bad_envs']))"
+done | tee gpurun_out/point/bench.txt
