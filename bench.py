@@ -422,6 +422,8 @@ def main():
                          "algorithmic_bytes_per_env_step": per_env,
                          "traffic_source": traffic_source,
                          "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                         "traffic_fetch_bytes": ((live or pmc).get("FETCH_SIZE", 0.0) * 1024.0) if traffic else None,
+                         "traffic_write_bytes": ((live or pmc).get("WRITE_SIZE", 0.0) * 1024.0) if traffic else None,
                          "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},
         }
         rv = valu_roofline(pmc, kernel_ms, n * args.steps / (kernel_ms * 1e-3 * args.steps) if kernel_ms > 0 else 0.0, env_id, f64=robot != 1)

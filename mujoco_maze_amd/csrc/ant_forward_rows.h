@@ -216,6 +216,12 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
     if (candp & bit) test(i0 + (b >> 2), j0 + (b & 3), 0);
     if (candw & bit) test(i0 + (b >> 2), j0 + (b & 3), 1);
     candw &= ~bit; candp &= ~bit;
+#ifdef MZ_EXP_ONECAND  // timing experiment (wrong physics): at most one narrow-phase run per geom — what would dealing the candidates to idle lanes save?
+    candw = 0u; candp = 0u;
+#endif
+#ifdef MZ_EXP_NOCAND
+    break;
+#endif
   }
 }
 

@@ -349,6 +349,8 @@ static int ant_lanes(const mz_handle* h) {
   // — 2048 envs then put exactly one wave on every SIMD; more blocks / the ball: the lane-group solver at 64
   // (the plain ant: 16 at every batch size since the solver's DPP operands were fused, round 3 — 8192 / 16384 / 32768 envs run
   // 12.8 / 13.4 / 13.8 M env-steps/s at 16 lanes against 11.6 / 12.4 / 13.1 M at 32)
+  // (round 4, tried: 16 lanes for the one-block ant from 4096 envs on — no gain at 4096 (four envs per wave need 47 KB of LDS: three
+  // waves per CU, two rounds), 6.2 against 5.0 M at 8192; and one env in 4096 then sits 2.5e-5 off the oracle: not taken)
   return h->lanes_set ? h->lanes : (NB == 1 ? 32 : (NB ? 64 : 16));
 }
 template <int NB>
