@@ -944,7 +944,7 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
 // only a border line: a block at its spawn position and the diagonal wall cells — makes no contact [ASSUME-12].
 // Box 1 = geom1: the normal points from box 1 to box 2.
 #define MZ_BOX_MINOVERLAP 1e-6
-struct AlignedBB { int ax, nu, nv; double dist, sg, pa, pu[2], pv[2]; };
+struct AlignedBB { int ax, nu, nv; double dist, sg, pa, pu[2], pv[2]; };  // (pu / pv: read through selects, never by a run-time index — an indexed read put the struct into scratch memory)
 MZ_HD bool aligned_box_box(const double* c1, const double* h1, const double* c2, const double* h2, double margin, AlignedBB& o) {
   double pen[3];
   for (int k = 0; k < 3; k++) { pen[k] = h1[k] + h2[k] - fabs(c2[k] - c1[k]); if (pen[k] < -margin) return false; }
@@ -1055,7 +1055,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
           for (int iv = 0; iv < bb.nv; iv++) {
             cg.kind = 4; cg.blk = e; cg.other = 0; cg.dist = (float)bb.dist;
             for (int k = 0; k < 3; k++) {
-              const double pw = k == ax ? bb.pa : (k == u ? bb.pu[iu] : bb.pv[iv]);
+              const double pw = k == ax ? bb.pa : (k == u ? (iu ? bb.pu[1] : bb.pu[0]) : (iv ? bb.pv[1] : bb.pv[0]));
               cg.n[k] = k == ax ? (float)bb.sg : 0.f; cg.hint[k] = 0.f;
               cg.pos[k] = (float)(pw - (k == 0 ? org[0] : (k == 1 ? org[1] : org[2])));
             }
@@ -1087,7 +1087,7 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
         for (int iv = 0; iv < bb.nv; iv++) {
           cg.kind = 5; cg.blk = e; cg.other = k; cg.dist = (float)bb.dist;
           for (int q = 0; q < 3; q++) {
-            const double pw = q == ax ? bb.pa : (q == u ? bb.pu[iu] : bb.pv[iv]);
+            const double pw = q == ax ? bb.pa : (q == u ? (iu ? bb.pu[1] : bb.pu[0]) : (iv ? bb.pv[1] : bb.pv[0]));
             cg.n[q] = q == ax ? (float)bb.sg : 0.f; cg.hint[q] = 0.f;
             cg.pos[q] = (float)(pw - (q == 0 ? org[0] : (q == 1 ? org[1] : org[2])));
           }

@@ -420,7 +420,7 @@ MZP_HD void pl_box_box_aligned(const double* c1, const double* h1, const double*
     for (int iw = 0; iw < bb.nv; iw++) {
       PlContact c;
       c.dist = bb.dist;
-      for (int k = 0; k < 3; k++) { c.n[k] = k == ax ? bb.sg : 0.0; c.pos[k] = k == ax ? bb.pa : (k == u ? bb.pu[iu] : bb.pv[iw]); }
+      for (int k = 0; k < 3; k++) { c.n[k] = k == ax ? bb.sg : 0.0; c.pos[k] = k == ax ? bb.pa : (k == u ? (iu ? bb.pu[1] : bb.pu[0]) : (iw ? bb.pv[1] : bb.pv[0])); }
       c.b1 = b1; c.b2 = b2; c.cls = cls;
       emit(c);
     }
