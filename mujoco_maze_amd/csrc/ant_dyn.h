@@ -873,6 +873,9 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
   ContactGeo cg;
   cg.kind = kind; cg.blk = blk; cg.other = 0;
   cg.hint[0] = cg.hint[1] = cg.hint[2] = 0.f;
+#ifdef MZ_EXP_SPHEREONLY  // timing experiment (wrong physics): a capsule is tested as a sphere at its centre
+  sphere = true;
+#endif
   if (sphere) {
     if (sphere_aabb(cl, r, bs, margin, &dist, pos, n) && dist < margin) {
       cg.dist = dist;
@@ -909,7 +912,11 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
     clface = nout == 1 ? lastout : -1;
     cledge = inaxis; boxpos = pin;
     // the segment runs through the box with both ends outside: MuJoCo's answer is its search order's
+#ifdef MZ_EXP_NOSEARCH  // timing experiment (wrong physics): never run the twelve-edge search
+    if (false) {
+#else
     if (nout == 0) {
+#endif
       corner = 0;
       float clb[3] = {cl[0], cl[1], cl[2]}, hb[3] = {h[0], h[1], h[2]};
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -922,7 +929,11 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
       capsule_box_search(clb, hb, hl, bs, &t, &type, &clface, &cledge, &corner, &boxpos);
     }
   }
+#ifdef MZ_EXP_NOSECOND  // timing experiment (wrong physics): no second support point
+  const float second = 0.f;
+#else
   const float second = capsule_box_second(cl, h, bs, t, type, clface, cledge, corner, boxpos);
+#endif
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1 && !(fabsf(second) > 1e-12f)) break;
     const float tt = t + (pass ? second : 0.f);

@@ -210,6 +210,9 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
       if (candidate(i, j, 1)) candw |= 1u << (4 * (i - i0) + (j - j0));
       if (elevated && candidate(i, j, 0)) candp |= 1u << (4 * (i - i0) + (j - j0));
     }
+#ifdef MZ_EXP_NOWALL  // timing experiment (wrong physics): no wall narrow phase at all
+  candw = 0u; candp = 0u;
+#endif
   while (candw | candp) {
     const int b = __ffs((int)(candw | candp)) - 1;
     const unsigned bit = 1u << b;
@@ -218,9 +221,6 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
     candw &= ~bit; candp &= ~bit;
 #ifdef MZ_EXP_ONECAND  // timing experiment (wrong physics): at most one narrow-phase run per geom — what would dealing the candidates to idle lanes save?
     candw = 0u; candp = 0u;
-#endif
-#ifdef MZ_EXP_NOCAND
-    break;
 #endif
   }
 }

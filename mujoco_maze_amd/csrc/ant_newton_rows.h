@@ -455,7 +455,11 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
     if (cx.any(ncon > 0)) {
       f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
       if (cx.any(ncon > 4)) {
-        f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
+        // (slots 4 .. 7 in pairs: the waves a launch waits for are those whose ants lean on a wall — five or six contacts — and two
+        // skipped slots are 160 instructions per Newton iteration; measured 0.2971 -> 0.2949 ms.  The same guard between slots 1 and 2
+        // gains nothing: the waves with at most two contacts per env are not the ones the launch waits for)
+        f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{});
+        if (cx.any(ncon > 6)) { f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{}); }
         if (cx.any(ncon > 8)) {
           f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
           if (cx.any(ncon > 12)) { f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{}); }
