@@ -1234,3 +1234,40 @@ def test_ant_only_options_are_refused_for_other_robots():
             env.set_option(key, 1)
     env.set_option("lanes_per_env", 32)
     env.close()
+
+
+@pytest.mark.parametrize("env_id,n,lanes", [("AntUMaze-v0", 256, 16), ("AntPush-v0", 128, 32)])
+def test_instrumented_kernel_steps_like_the_product_kernel(torch, env_id, n, lanes):
+    """The phase timers behind profiles/ come from separate instantiations of the Ant step kernel (option `profile_phases`): they must
+    step like the un-instrumented kernel, and their counters must add up — per-wave totals = sum of the per-wave phases,
+    totals over the waves = the global accumulators, a Newton iteration count per wave that a step can have."""
+    rng = np.random.default_rng(12)
+    acts = [torch.as_tensor(rng.uniform(-30, 30, (n, 8)).astype(np.float32), device="cuda") for _ in range(6)]
+    outs = []
+    for prof in (0, 1):
+        env = mm.make(env_id, num_envs=n, force_vec=True)
+        env.reset(seed=4)
+        for a in acts[:3]:
+            env.step(a)
+        if prof:
+            env.set_option("profile_phases", 1)
+            env.step(acts[3])  # (the first instrumented launch zeroes nothing yet: read and drop)
+            env.phase_cycles(); env.wave_cycles(n * lanes // 64); env.wave_phase_cycles(n * lanes // 64)
+        else:
+            env.step(acts[3])
+        res = [env.step(a) for a in acts[4:]]
+        outs.append([torch.cat([o, r[:, None], d[:, None].float()], 1).cpu().numpy() for o, r, d, _ in res])
+        if prof:
+            nw = n * lanes // 64
+            glob = np.array(env.phase_cycles(), dtype=np.float64)
+            tot = env.wave_cycles(nw).astype(np.float64)
+            iters = env.last_wave_newton_iters.astype(np.int64)
+            ph = env.wave_phase_cycles(nw).astype(np.float64)
+            assert np.all(tot > 1e5) and np.all(tot < 1e8)                     # two env.steps of 20 evaluations each, per wave
+            assert np.allclose(ph[:, :13].sum(1), tot)                         # per wave: phases add up to its total
+            assert np.allclose(ph[:, :13].sum(0), glob[:13])                   # over the waves: the global accumulators
+            assert np.all(iters >= 2 * 20) and np.all(iters <= 2 * 20 * 50)     # >= one Newton iteration per evaluation, <= the cap
+            assert glob[15] == ph[:, 15].sum()
+        env.close()
+    for a, b in zip(*outs):  # (two instantiations: the compiler contracts their arithmetic differently — the same step to round-off, not to the bit)
+        assert np.allclose(a[:, :-1], b[:, :-1], atol=1e-4, rtol=1e-5) and np.array_equal(a[:, -1], b[:, -1])
