@@ -338,6 +338,17 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
 //   * J x, which the owner needs, is the transposed product: one row butterfly per (contact, row) over the lanes' columns.
 // The staged Jacobian rows (cJ written by con_row_item, read back as jown / Jf: 16 + 6 LDS reads per lane and evaluation, on top
 // of the phase that built them) are gone for the plain ant; the ant with a movable block (WR = false) keeps them.
+// Per-lane conditions of the Newton loop that only skip work whose result is zero anyway (a lane that owns no contact holds D = 0,
+// u = v = 0; a dof without an active limit row holds lsign = lD = 0; a row without contact C holds zero columns): as `if`s they are
+// exec-mask regions — two scalar instructions, a branch and the exec hazards, per region — around a handful of vector instructions
+// that the wave executes anyway as long as ONE of its lanes needs them.  With one wave per SIMD nobody fills those bubbles: the
+// conditions are gone (the arithmetic adds its zeros), round 4: 0.2941 -> 0.2813 ms.  MZ_IF_OWNER marks the places (-DMZ_EXP_BRANCHY
+// brings the `if`s back for an A / B run).
+#ifdef MZ_EXP_BRANCHY
+#define MZ_IF_OWNER(c) if (c)
+#else
+#define MZ_IF_OWNER(c) if (true)
+#endif
 template <int NB, int G, bool PROF, bool WR = false>
 __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare,
                                                     const float (&Mrow)[14 + 2 * NB], const float qfs, const float (&Sax)[6]) {
@@ -554,7 +565,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       for (int m = 0; m < MA; m++) o[m][0] = o[m][1] = o[m][2] = 0.f;
       each_contact([&](auto Cc) {
         constexpr int C = decltype(Cc)::value;
-        if (C < ncon) {
+        {  // (no per-row guard `C < ncon`: a row without contact C holds zero columns and adds zeros; one exec-mask region less per slot)
           float jc[3];
           own_col(Cc, jc);
           const float t0 = rsum(jc[0] * x), t1 = rsum(jc[1] * x), t2 = rsum(jc[2] * x);
@@ -641,7 +652,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
 #pragma unroll
       for (int k = 0; k < 8; k++) mycg[m][k] = 0.f;
       if (m == 1 && !any2) continue;
-      if (iscon[m]) {
+      MZ_IF_OWNER(iscon[m]) {
         const float u0 = u[m][0], u1 = u[m][1], u2 = u[m][2], Dm = cD[m];
         const float r0 = u0 + u1, r1 = u0 - u1, r2 = u0 + u2, r3 = u0 - u2;
         const float a0 = r0 < 0.f ? 1.f : 0.f, a1 = r1 < 0.f ? 1.f : 0.f, a2 = r2 < 0.f ? 1.f : 0.f, a3 = r3 < 0.f ? 1.f : 0.f;
@@ -679,7 +690,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
     float g = Mx, ga = fabsf(Mx);
     each_contact([&](auto Cc) {
       constexpr int C = decltype(Cc)::value;
-      if (C < ncon) {  // (uniform within the env's row)
+      {  // (no per-row guard `C < ncon`, as in jdot3)
         float t, t0, t1, t2;
         float jc[3];
         own_col(Cc, jc);
@@ -689,10 +700,18 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       }
     });
     if constexpr (NB == 1) {
+#ifdef MZ_EXP_BLKSEL  // the two slide lanes' terms by selects (no exec-mask region per lane)
+      {
+        const bool l14 = r == 14, l15 = r == 15;
+        g += l14 ? bg0 : (l15 ? bg1 : 0.f); ga += l14 ? bga0 : (l15 ? bga1 : 0.f);
+        Hrow[14] += l14 ? bh00 : (l15 ? bh01 : 0.f); Hrow[15] += l14 ? bh01 : (l15 ? bh11 : 0.f);
+      }
+#else
       if (r == 14) { g += bg0; ga += bga0; Hrow[14] += bh00; Hrow[15] += bh01; }
       if (r == 15) { g += bg1; ga += bga1; Hrow[14] += bh01; Hrow[15] += bh11; }
+#endif
     }
-    if (lsign != 0.f) { const float t = lsign * lact * ljar; g += t; ga += fabsf(t); }
+    MZ_IF_OWNER(lsign != 0.f) { const float t = lsign * lact * ljar; g += t; ga += fabsf(t); }
 #pragma unroll
     for (int k = 0; k < 14; k++)
       if ((k & 3) < 2) Hrow[k] += (r == k) ? lact : 0.f;  // hinge positions: the limit row's curvature on its own diagonal
@@ -711,12 +730,12 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
     bool changed = false;
 #pragma unroll
     for (int m = 0; m < MA; m++)
-      if ((m == 0 || any2) && iscon[m]) {
+      if (m == 0 || any2) MZ_IF_OWNER(iscon[m]) {
         const float u0 = u[m][0], u1 = u[m][1], u2 = u[m][2], w0 = u0 + v[m][0], w1 = u1 + v[m][1], w2 = u2 + v[m][2];
         changed = changed || ((u0 + u1 < 0.f) != (w0 + w1 < 0.f)) || ((u0 - u1 < 0.f) != (w0 - w1 < 0.f)) || ((u0 + u2 < 0.f) != (w0 + w2 < 0.f)) ||
                   ((u0 - u2 < 0.f) != (w0 - w2 < 0.f));
       }
-    if (lsign != 0.f) changed = changed || ((ljar < 0.f) != (ljar + ljv < 0.f));
+    MZ_IF_OWNER(lsign != 0.f) changed = changed || ((ljar < 0.f) != (ljar + ljv < 0.f));
     if constexpr (NB == 1) {
       bdot(bcast<14>(search), bcast<15>(search), bv);
 #pragma unroll
@@ -738,7 +757,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
         float d1 = 0.f, d2 = 0.f;
 #pragma unroll
         for (int m = 0; m < MA; m++)
-          if ((m == 0 || any2) && iscon[m]) {
+          if (m == 0 || any2) MZ_IF_OWNER(iscon[m]) {
             const float v0 = v[m][0], v1 = v[m][1], v2 = v[m][2], Dm = cD[m];
             const float x0 = u[m][0] + alpha * v0, x1 = u[m][1] + alpha * v1, x2 = u[m][2] + alpha * v2;
             float rr, vv;
@@ -747,7 +766,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
             rr = x0 + x2; vv = v0 + v2; if (rr < 0.f) { d1 += Dm * rr * vv; d2 += Dm * vv * vv; }
             rr = x0 - x2; vv = v0 - v2; if (rr < 0.f) { d1 += Dm * rr * vv; d2 += Dm * vv * vv; }
           }
-        if (lsign != 0.f) { const float rr = ljar + alpha * ljv; if (rr < 0.f) { d1 += lD * rr * ljv; d2 += lD * ljv * ljv; } }
+        MZ_IF_OWNER(lsign != 0.f) { const float rr = ljar + alpha * ljv; if (rr < 0.f) { d1 += lD * rr * ljv; d2 += lD * ljv * ljv; } }
         d1 = rsum(d1) + p1 + alpha * p2;
         d2 = rsum(d2) + p2;
         if constexpr (NB == 1) {
@@ -782,7 +801,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
         Mx += alpha * Ms;
 #pragma unroll
         for (int m = 0; m < MA; m++) { u[m][0] += alpha * v[m][0]; u[m][1] += alpha * v[m][1]; u[m][2] += alpha * v[m][2]; }
-        if (lsign != 0.f) { ljar += alpha * ljv; lact = ljar < 0.f ? lD : 0.f; }
+        MZ_IF_OWNER(lsign != 0.f) { ljar += alpha * ljv; lact = ljar < 0.f ? lD : 0.f; }
         if constexpr (NB == 1) {
 #pragma unroll
           for (int m = 0; m < MB; m++)
