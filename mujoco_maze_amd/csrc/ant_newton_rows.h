@@ -700,16 +700,8 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       }
     });
     if constexpr (NB == 1) {
-#ifdef MZ_EXP_BLKSEL  // the two slide lanes' terms by selects (no exec-mask region per lane)
-      {
-        const bool l14 = r == 14, l15 = r == 15;
-        g += l14 ? bg0 : (l15 ? bg1 : 0.f); ga += l14 ? bga0 : (l15 ? bga1 : 0.f);
-        Hrow[14] += l14 ? bh00 : (l15 ? bh01 : 0.f); Hrow[15] += l14 ? bh01 : (l15 ? bh11 : 0.f);
-      }
-#else
       if (r == 14) { g += bg0; ga += bga0; Hrow[14] += bh00; Hrow[15] += bh01; }
       if (r == 15) { g += bg1; ga += bga1; Hrow[14] += bh01; Hrow[15] += bh11; }
-#endif
     }
     MZ_IF_OWNER(lsign != 0.f) { const float t = lsign * lact * ljar; g += t; ga += fabsf(t); }
 #pragma unroll
