@@ -56,6 +56,7 @@ struct HostCtx {
   MZ_HD void sync() const {}
   MZ_HD float gsum(float x) const { return x; }
   MZ_HD double gsum(double x) const { return x; }
+  MZ_HD double rowsum(double x) const { return x; }
   MZ_HD bool any(bool p) const { return p; }
   MZ_HD bool gany(bool p) const { return p; }
   template <class S> MZ_HD void tick(S&, int) const {}

@@ -124,6 +124,16 @@ struct DevCtx {
     }
     return x;
   }
+  // sum over the 16-lane DPP row of the lane (the whole group when it is narrower): four DPP steps, no cross-row traffic.  The rows
+  // of a wider group reduce independently (point_bare.h: every row of a group holds the same contacts and gets the same bits).
+  __device__ __forceinline__ double rowsum(double x) const {
+#pragma clang fp contract(off)
+    if constexpr (G >= 2) x += dpp_movd<0xB1, 0xF, true>(x);
+    if constexpr (G >= 4) x += dpp_movd<0x4E, 0xF, true>(x);
+    if constexpr (G >= 8) x += dpp_movd<0x141, 0xF, true>(x);
+    if constexpr (G >= 16) x += dpp_movd<0x140, 0xF, true>(x);
+    return x;
+  }
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
   // any() restricted to this lane group: one ballot, no shuffles
   __device__ __forceinline__ bool gany(bool p) const {

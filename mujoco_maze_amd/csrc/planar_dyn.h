@@ -35,49 +35,30 @@ struct PlanarDims {
   static constexpr int NOBS = 7 + 3 * NB + 3 * NS;
 };
 
-// developer aid (tools/exp_point.sh): -DMZ_EXP_PROF builds an experiment library whose bare-Point kernel times its phases with
-// s_memtime (lane 0 of a group; planar_kernels.hip prints one workgroup's totals) — compiled out otherwise
+// developer aid (tools/exp_point.sh): -DMZ_EXP_PROF builds an experiment library whose bare-Point kernel (point_bare.h) times its phases
+// with s_memtime (lane 0 of a group; planar_kernels.hip prints one workgroup's totals) — compiled out otherwise
 #if defined(MZ_EXP_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define MZP_TICK(id) do { if constexpr (NB == 0 && NS == 0) { if (cx.lane0() == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); s.prof[id] += now_ - s.prof_t0; s.prof_t0 = now_; } } } while (0)
+#define MZB_TICK(id) do { if (cx.lane0() == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); s.prof[id] += now_ - s.prof_t0; s.prof_t0 = now_; } } while (0)
 #else
-#define MZP_TICK(id) do { } while (0)
+#define MZB_TICK(id) do { } while (0)
 #endif
 
-// Staging of the bare Point's single-pass contact enumeration (planar_forward): geometry of the contacts an enumerator found,
-// 1 entry for a sphere-wall cell enumerator, 8 for an arrow-wall cell one (mjc_BoxBox's maximum).  An enumerator takes its block of
-// entries when it finds its first contact (an LDS counter; round 4): the sphere and the arrow — a 0.2 cube — reach four cells each
-// at most, so 4 + 4 x 8 entries serve where a fixed block per enumerator took 81 (4.5 KB of the 13 KB an env held in LDS, which
-// kept the step kernel at six workgroups per CU where its registers allow eight).  Which block an enumerator gets depends on the
-// order the lanes arrive in; the contact ORDER does not: slots are dealt by enumerator index, as before.
-struct PlStageEntry { double dist, pos[3], n[3]; };
 template <int NB, int NS>
-struct PlStage {};
-template <>
-struct PlStage<0, 0> {
-  static constexpr int NSTAGE = 40;
-  PlStageEntry stage[NSTAGE];
-  int csrc[24];  // contact slot -> staging entry (| 256 for the arrow's contacts)
-  int nstage, sbase[18];  // entries taken so far; first entry of enumerator e
-#ifdef MZ_EXP_PROF
-  unsigned long long prof[12], prof_t0;
-#endif
-  static MZP_HD int cap(int e) { return e < 9 ? 1 : 8; }
-};
-
-template <int NB, int NS>
-struct alignas(16) PlanarScratch : PlStage<NB, NS> {
+struct alignas(16) PlanarScratch {  // (the bare Point, <0, 0>: point_bare.h)
   using D = PlanarDims<NB, NS>;
   double q[D::NV], v[D::NV];  // state of the current RK4 stage
   double x0[D::NV], v0[D::NV], accv[D::NV], accf[D::NV];
   double qas[D::NV], qacc[D::NV], grad[D::NV], search[D::NV], Mx[D::NV], Ms[D::NV];
   double wd[D::NV];           // constraint-induced acceleration (qacc - qacc_smooth) of the previous RK4 stage: warm start
   double M3[3][3];            // robot block of the mass matrix (blocks: block_mass on the diagonal)
-  static constexpr bool BARE = NB == 0 && NS == 0;  // the bare Point keeps gradient / curvature blocks and the Hessian in registers (planar_forward)
-  double H[BARE ? 1 : D::NV][BARE ? 1 : D::NV];
-  double cJ[D::NC][3][D::NV], caref[D::NC][3], cD[D::NC], cu[D::NC][3], cg[BARE ? 1 : D::NC][3], cW[BARE ? 1 : D::NC][5], cjv[D::NC][3];
+  double H[D::NV][D::NV];
+  double cJ[D::NC][3][D::NV], caref[D::NC][3], cD[D::NC], cu[D::NC][3], cg[D::NC][3], cW[D::NC][5], cjv[D::NC][3];
   double co, si;              // cos / sin of the heading of the current stage
   double old_xy[2];           // robot xy in front of the step (the wall detector's start point): parked here, not carried in registers through the step
   int ncon, cnt[D::NE], cbeg[D::NE], status, robot_near;
+  // the wall detector's hand-off buffer: the contact arrays cJ ... cjv (one declaration, contiguous), free between the RK4 step and the next env.step
+  MZP_HD double* detect_buf() { return &cJ[0][0][0]; }
+  static constexpr int detect_buf_doubles = (int)((sizeof(cJ) + sizeof(caref) + sizeof(cD) + sizeof(cu) + sizeof(cg) + sizeof(cW) + sizeof(cjv)) / sizeof(double));
 };
 
 // ---- small helpers
@@ -325,9 +306,11 @@ MZP_HD void pl_box_box(const double* pos1, const double* mat1, const double* siz
 // are dropped (they change no value), which leaves a 2-D separating-axis test, the z overlap, and pl_box_box's fast path in
 // scalars — about a quarter of the general routine's instructions.  A vertical least-penetration axis (deep overlap) hands
 // over to the general routine.
-template <class Emit>
-MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const double* pos2, const double* size2, double co, double si, bool rot_first,
-                               double margin, int b1id, int b2id, int cls, Emit&& emit) {
+// BARE (point_bare.h): the two contacts of an overlap's bottom and top edge at one (x, y) are emitted once, with their number —
+// emit(contact, mult) — and the deep overlap is reported — deep(dist, sign of the z offset) — instead of clipped here.
+template <bool BARE, class Emit, class Deep>
+MZP_HD void pl_box_box_upright_t(const double* pos1, const double* size1, const double* pos2, const double* size2, double co, double si, bool rot_first,
+                                 double margin, int b1id, int b2id, int cls, Emit&& emit, Deep&& deep) {
   const double d0 = pos2[0] - pos1[0], d1 = pos2[1] - pos1[1], d2 = pos2[2] - pos1[2];
   // rot[i][j] = axis i of box 1 . axis j of box 2 (upper-left 2 x 2; rot[2][2] = 1, the rest 0)
   const double r00 = co, r11 = co, r01 = rot_first ? si : -si, r10 = rot_first ? -si : si;
@@ -352,7 +335,8 @@ MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const do
   {
     const double c1 = -fabs(d2) + size1[2] + size2[2], c2 = -fabs(d2) + size2[2] + size1[2];
     if (c1 < -margin || c2 < -margin) return;
-    if (c1 < penetration || c2 < penetration) {  // vertical reference normal: the general routine (rare: a deep overlap)
+    if (c1 < penetration || c2 < penetration) {  // vertical reference normal: the general routine (a deep overlap)
+      if constexpr (BARE) { deep(-c1, d2 < 0.0 ? -1.0 : 1.0); return; } else {
 #if defined(__HIP_DEVICE_COMPILE__)
       // opaque copy made inside the branch: what the general routine computes then depends on it, so the compiler cannot hoist
       // its loop-invariant parts in front of the branch, onto the path of every arrow near a wall (round 3 measured the general
@@ -363,6 +347,7 @@ MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const do
       const double m2[9] = {rot_first ? 1.0 : co, rot_first ? 0.0 : -si, 0.0, rot_first ? 0.0 : si, rot_first ? 1.0 : co, 0.0, 0.0, 0.0, 1.0};
       pl_box_box(pos1, m1, size1, pos2, m2, size2, margin, b1id, b2id, cls, emit);
       return;
+      }
     }
   }
   if (code < 0) return;
@@ -398,15 +383,20 @@ MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const do
     const double x3m = x3 - sg * 0.5 * dist;
     const double pl0 = a == 0 ? x3m : hh, pl1 = a == 0 ? hh : x3m;
     const double wx = rotA ? co * pl0 - si * pl1 : pl0, wy = rotA ? si * pl0 + co * pl1 : pl1;
-    for (int iz = 0; iz < nz; iz++) {
+    for (int iz = 0; iz < (BARE ? 1 : nz); iz++) {
       PlContact c;
       c.dist = dist;
       c.pos[0] = wx + posA[0]; c.pos[1] = wy + posA[1]; c.pos[2] = (iz ? zhi : zlo) + posA[2];
       c.n[0] = nx; c.n[1] = ny; c.n[2] = 0.0;
       c.b1 = b1id; c.b2 = b2id; c.cls = cls;
-      emit(c);
+      if constexpr (BARE) emit(c, nz); else emit(c);
     }
   }
+}
+template <class Emit>
+MZP_HD void pl_box_box_upright(const double* pos1, const double* size1, const double* pos2, const double* size2, double co, double si, bool rot_first,
+                               double margin, int b1id, int b2id, int cls, Emit&& emit) {
+  pl_box_box_upright_t<false>(pos1, size1, pos2, size2, co, si, rot_first, margin, b1id, b2id, cls, emit, [](double, double) {});
 }
 
 // axis-aligned box (geom1: centre c1, half h1) vs axis-aligned box (geom2: centre c2, half h2): aligned_box_box (ant_dyn.h)
@@ -655,7 +645,10 @@ MZP_HD void pl_contact_eval(double D, const double* u, double* g, double* W) {
   W[0] = D * (a0 + a1 + a2 + a3); W[1] = D * (a0 - a1); W[2] = D * (a2 - a3); W[3] = D * (a0 + a1); W[4] = D * (a2 + a3);
 }
 
+#include "point_bare.h"  // PlanarScratch<0, 0>, point_env_step_bare: the bare Point's register-resident step
+
 // ------------------------------------------------------------------ one forward-dynamics evaluation: s.q, s.v -> s.qacc
+// (Point with movable blocks or an object ball; the bare Point: point_bare.h)
 template <int NB, int NS, class C>
 MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, bool warm) {
   using D = PlanarDims<NB, NS>;
@@ -676,78 +669,14 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     s.M3[1][0] = 0.0; s.M3[1][1] = P.mass; s.M3[1][2] = mc * co;
     s.M3[2][0] = -mc * si; s.M3[2][1] = mc * co; s.M3[2][2] = P.izz;
     s.robot_near = point_near_wall(P, s.q[0], s.q[1]) ? 1 : 0;
-    if constexpr (NB == 0 && NS == 0) s.nstage = 0;
   }
   cx.sync();
   MZ_FOR(i, NV) s.qacc[i] = s.qas[i];
-  MZP_TICK(0);
   bool maybe = NB + NS > 0 || s.robot_near != 0;  // group-uniform
 #ifdef MZ_EXP_NOCOLLISION
   maybe = false;
 #endif
   if (!cx.any(maybe)) { cx.sync(); return; }
-  if constexpr (NB == 0 && NS == 0) {
-    // ---- the bare Point: ONE enumeration.  The narrow phase runs once per evaluation and parks what it finds in the staging
-    // block (the two-pass scheme ran mjc_BoxBox twice and built up to eight constraint rows serially on the enumerator's lane);
-    // one lane turns the counts into slots, then every contact's rows are built on a lane of its own.  Contact order = slot
-    // order = enumerator order, as before.  Items are dealt so that the nine arrow enumerators share the first round of a
-    // 16-lane group and the second round holds two sphere enumerators only (lanes that run different code serialise).
-    static_assert(NE == 18 && NC == 24, "staging layout of the bare Point");
-    MZ_FOR(i, NE) {
-      const int e = i < 9 ? i + 9 : i - 9;
-      int n = 0, base = 0;
-      if (maybe)
-        planar_contacts<NB, NS>(P, s, e, [&](const PlContact& c) {
-          if (c.dist < P.pair[c.cls].margin) {
-            if (n == 0) {  // first contact of this enumerator: take its block of staging entries
-#if defined(__HIP_DEVICE_COMPILE__)
-              base = atomicAdd(&s.nstage, PlStage<0, 0>::cap(e));
-#else
-              base = s.nstage; s.nstage += PlStage<0, 0>::cap(e);
-#endif
-            }
-            if (n < PlStage<0, 0>::cap(e) && base + n < PlStage<0, 0>::NSTAGE) {
-              PlStageEntry& q = s.stage[base + n];
-              q.dist = c.dist;
-              for (int k = 0; k < 3; k++) { q.pos[k] = c.pos[k]; q.n[k] = c.n[k]; }
-            }
-            n++;
-          }
-        });
-      if (n > PlStage<0, 0>::cap(e)) n = PlStage<0, 0>::cap(e);
-      if (base + n > PlStage<0, 0>::NSTAGE) n = base < PlStage<0, 0>::NSTAGE ? PlStage<0, 0>::NSTAGE - base : 0;  // (flagged below)
-      s.cnt[e] = n; s.sbase[e] = base;
-    }
-    cx.sync();
-    MZP_TICK(1);
-    MZ_FOR(e, NE) {  // every enumerator finds its own first slot (18 independent loads, no serial walk) and maps its contacts
-      int off = 0;
-      for (int g = 0; g < NE; g++) off += g < e ? s.cnt[g] : 0;
-      s.cbeg[e] = off;
-      const int n = s.cnt[e];
-      for (int k = 0; k < n; k++) if (off + k < NC) s.csrc[off + k] = (s.sbase[e] + k) | (e < 9 ? 0 : 256);
-      if (e == NE - 1) {
-        int tot = off + n;
-        if (tot > NC || s.nstage > PlStage<0, 0>::NSTAGE) { tot = tot > NC ? NC : tot; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
-        s.ncon = tot;
-      }
-    }
-    cx.sync();
-    MZP_TICK(2);
-    const int ncon1 = s.ncon;
-    if (!cx.any(ncon1 > 0)) return;
-    MZ_FOR(slot, ncon1) {
-      const int src = s.csrc[slot];
-      const PlStageEntry& q = s.stage[src & 255];
-      PlContact c;
-      c.dist = q.dist;
-      for (int k = 0; k < 3; k++) { c.pos[k] = q.pos[k]; c.n[k] = q.n[k]; }
-      const bool sphere = src < 256;  // sphere (geom1, robot) -> wall | wall (geom1) -> arrow (robot)
-      c.b1 = sphere ? 0 : -1; c.b2 = sphere ? -1 : 0; c.cls = 0;
-      planar_fill_contact<NB, NS>(P, s, slot, c);
-    }
-    MZP_TICK(3);
-  } else {
   // ---- collision: count, prefix, fill
   MZ_FOR(e, NE) {
     int n = 0;
@@ -799,119 +728,9 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
       planar_fill_contact<NB, NS>(P, s, slot, c);
     }
   }
-  }
   const int ncon = s.ncon;
   if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = s.qas[i] + s.wd[i]; }  // envs without contacts keep qacc = qacc_smooth
   cx.sync();
-  if constexpr (NB == 0 && NS == 0) {
-    // The bare Point: 3 dofs.  Everything per dof (qacc, M qacc - qfrc, gradient, the 3 x 3 Hessian, its Cholesky, the search
-    // direction) is carried redundantly in the registers of every lane; the contacts are spread over the lanes and enter
-    // through group sums (DPP) — the same Newton iteration, unit-step vote and exact line search as below, without the LDS
-    // hand-offs that a per-dof distribution of a 3-dof problem consists of.
-    double a[3] = {s.qacc[0], s.qacc[1], s.qacc[2]};
-    const double qs[3] = {s.qas[0], s.qas[1], s.qas[2]};
-    double M[3][3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = s.M3[i][j];
-    bool done = ncon == 0;
-#ifdef MZ_EXP_NONEWTON
-    done = true;
-#endif
-    int it = 0;
-    while (cx.any(!done) && it < 50) {
-      double Mx[3], pg[3] = {0.0, 0.0, 0.0}, pH[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // H entries 00 01 02 11 12 22
-      for (int i = 0; i < 3; i++) { double t = 0.0; for (int j = 0; j < 3; j++) t += M[i][j] * (a[j] - qs[j]); Mx[i] = t; }
-      MZ_FOR(c, ncon) {
-        double J[3][3], u[3], g3[3], W[5];
-        for (int r = 0; r < 3; r++) {
-          double t = -s.caref[c][r];
-          for (int i = 0; i < 3; i++) { J[r][i] = s.cJ[c][r][i]; t += J[r][i] * a[i]; }
-          u[r] = t; s.cu[c][r] = t;
-        }
-        pl_contact_eval(s.cD[c], u, g3, W);
-        int e = 0;
-        for (int i = 0; i < 3; i++) {
-          pg[i] += J[0][i] * g3[0] + J[1][i] * g3[1] + J[2][i] * g3[2];
-          for (int j = i; j < 3; j++, e++)
-            pH[e] += W[0] * J[0][i] * J[0][j] + W[1] * (J[0][i] * J[1][j] + J[1][i] * J[0][j]) + W[2] * (J[0][i] * J[2][j] + J[2][i] * J[0][j]) +
-                     W[3] * J[1][i] * J[1][j] + W[4] * J[2][i] * J[2][j];
-        }
-      }
-      double g[3], H[3][3];
-      for (int i = 0; i < 3; i++) g[i] = Mx[i] + cx.gsum(pg[i]);
-      {
-        int e = 0;
-        for (int i = 0; i < 3; i++) for (int j = i; j < 3; j++, e++) { const double h = M[i][j] + cx.gsum(pH[e]); H[i][j] = h; H[j][i] = h; }
-      }
-      const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-      if (!done && P.inv_scale * gn < 1e-10) done = true;
-      if (!cx.any(!done)) break;
-      if (it == 49 && !done) { MZ_FOR(one, 1) s.status |= MZ_STATUS_SOLVER_MAXITER; }
-      double L[3][3], y[3], sr[3], inv[3];  // Cholesky with one reciprocal square root per column, no division
-      for (int j = 0; j < 3; j++) {
-        double d = H[j][j];
-        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-#if defined(__HIP_DEVICE_COMPILE__)
-        inv[j] = rsqrt(fmax(d, 1e-300));
-#else
-        inv[j] = 1.0 / sqrt(fmax(d, 1e-300));
-#endif
-        for (int i = j + 1; i < 3; i++) {
-          double t = H[i][j];
-          for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-          L[i][j] = t * inv[j];
-        }
-      }
-      for (int i = 0; i < 3; i++) { double t = -g[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t * inv[i]; }
-      for (int i = 2; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 3; k++) t -= L[k][i] * y[k]; y[i] = t * inv[i]; }
-      for (int i = 0; i < 3; i++) sr[i] = y[i];
-      double p1 = 0.0, p2 = 0.0;
-      for (int i = 0; i < 3; i++) {
-        double t = 0.0;
-        for (int j = 0; j < 3; j++) t += M[i][j] * sr[j];
-        p1 += sr[i] * Mx[i]; p2 += sr[i] * t;
-      }
-      bool changed = false;
-      MZ_FOR(c, ncon) {
-        double v[3];
-        for (int r = 0; r < 3; r++) { v[r] = s.cJ[c][r][0] * sr[0] + s.cJ[c][r][1] * sr[1] + s.cJ[c][r][2] * sr[2]; s.cjv[c][r] = v[r]; }
-        const double u0 = s.cu[c][0], u1 = s.cu[c][1], u2 = s.cu[c][2], w0 = u0 + v[0], w1 = u1 + v[1], w2 = u2 + v[2];
-        changed = changed || ((u0 + u1 < 0) != (w0 + w1 < 0)) || ((u0 - u1 < 0) != (w0 - w1 < 0)) || ((u0 + u2 < 0) != (w0 + w2 < 0)) ||
-                  ((u0 - u2 < 0) != (w0 - w2 < 0));
-      }
-      changed = cx.gany(changed);
-      double lo = 0.0, hi = -1.0, alpha = 1.0, prev_d2 = -1.0;
-      for (int ls = 0; ls < 30 && changed; ls++) {
-        double d1 = 0.0, d2 = 0.0;
-        MZ_FOR(c, ncon) {
-          const double Dc = s.cD[c], v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
-          const double u0 = s.cu[c][0] + alpha * v0, u1 = s.cu[c][1] + alpha * v1, u2 = s.cu[c][2] + alpha * v2;
-          double r, w;
-          r = u0 + u1; w = v0 + v1; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
-          r = u0 - u1; w = v0 - v1; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
-          r = u0 + u2; w = v0 + v2; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
-          r = u0 - u2; w = v0 - v2; if (r < 0) { d1 += Dc * r * w; d2 += Dc * w * w; }
-        }
-        d1 = cx.gsum(d1) + p1 + alpha * p2;
-        d2 = cx.gsum(d2) + p2;
-        if (d2 == prev_d2) break;
-        prev_d2 = d2;
-        if (d1 < 0) lo = alpha; else hi = alpha;
-        double next = alpha - d1 / d2;
-        if (hi >= 0 && !(next > lo && next < hi)) next = 0.5 * (lo + hi);
-        if (!(next > 0)) next = hi >= 0 ? 0.5 * (lo + hi) : 0.0;
-        if (fabs(next - alpha) <= 1e-15 * fabs(next)) { alpha = next; break; }
-        alpha = next;
-      }
-      if (!done) { for (int i = 0; i < 3; i++) a[i] += alpha * sr[i]; }
-      if (!changed) done = true;
-      it++;
-    }
-    cx.sync();
-    if (ncon > 0) { MZ_FOR(i, NV) s.qacc[i] = i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
-    cx.sync();
-    MZP_TICK(4);
-    return;
-  }
   // ---- Newton on the primal problem (dense), exact line search
   bool done = ncon == 0;
   int it = 0;
@@ -1035,15 +854,13 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
 template <int NB, int NS, class C>
 MZP_HD int point_detect_group(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, const double* o, const double* n, double* pt, double* rf) {
 #pragma clang fp contract(off) reciprocal(off) reassociate(off)
-  // hand-off buffer: the contact arrays cJ ... cjv (one declaration, contiguous), free between the RK4 step and the next env.step
-  static_assert(sizeof(s.cJ) + sizeof(s.caref) + sizeof(s.cD) + sizeof(s.cu) + sizeof(s.cg) + sizeof(s.cW) + sizeof(s.cjv) >= sizeof(double) * 8 * C::nlanes,
-                "the detector's hand-off buffer lives in the contact arrays");
+  static_assert(PlanarScratch<NB, NS>::detect_buf_doubles >= 8 * C::nlanes, "the detector's hand-off buffer lives in arrays that are free between steps");
   const double mvx = n[0] - o[0], mvy = n[1] - o[1];
   if (mz_hypot(mvx, mvy) <= 1e-8) return 0;
   PtCand c;
   c.found = 0; c.degenerate = 0; c.k = 0; c.dist = 0.0; c.pt[0] = c.pt[1] = c.rf[0] = c.rf[1] = 0.0;
   point_detect_range(P, o, n, mvx, mvy, cx.lane0(), C::nlanes, c);
-  double* buf = &s.cJ[0][0][0];
+  double* buf = s.detect_buf();
   {
     double* q = buf + 8 * cx.lane0();
     q[0] = (double)(c.found + 2 * c.degenerate); q[1] = c.dist; q[2] = (double)c.k; q[3] = c.pt[0]; q[4] = c.pt[1]; q[5] = c.rf[0]; q[6] = c.rf[1];
@@ -1085,6 +902,7 @@ MZP_HD int point_bounce_group(const C& cx, const PointDev& P, PlanarScratch<NB, 
 // ------------------------------------------------------------------ One MazeEnv.step.  s.q / s.v hold the state in and out.
 template <int NB, int NS, class C>
 MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS>& s, const double* action) {
+  if constexpr (NB == 0 && NS == 0) { point_env_step_bare(cx, P, s, action); return; } else {
   constexpr int NV = PlanarDims<NB, NS>::NV;
   const double PI = 3.141592653589793;
   cx.sync();
@@ -1100,14 +918,12 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
   }
   MZ_FOR(i, NV) s.v[i] = fmin(fmax(s.v[i], -P.vel_limit), P.vel_limit);  // the clip covers the whole qvel (point.py:54-55)
   cx.sync();
-  MZP_TICK(5);
   for (int f = 0; f < P.frame_skip; f++) {  // mj_step, RK4 (point.xml:3)
     const double h = P.h;
     MZ_FOR(i, NV) { s.x0[i] = s.q[i]; s.v0[i] = s.v[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; }
     cx.sync();
     for (int st = 0; st < 4; st++) {
       planar_forward<NB, NS>(cx, P, s, st > 0);
-      MZP_TICK(8);
       double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
       MZ_FOR(i, NV) {
         s.accv[i] += bw * s.v[i]; s.accf[i] += bw * s.qacc[i];
@@ -1118,7 +934,6 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
     }
     MZ_FOR(i, NV) { s.q[i] = s.x0[i] + h * s.accv[i]; s.v[i] = s.v0[i] + h * s.accf[i]; }
     cx.sync();
-    MZP_TICK(6);
   }
   // maze_env.py:454-464: manual wall bounce on the robot's xy
 #ifndef MZ_EXP_NODETECT
@@ -1132,9 +947,9 @@ MZP_HD void planar_env_step(const C& cx, const PointDev& P, PlanarScratch<NB, NS
       s.q[0] = fin[0]; s.q[1] = fin[1];
     }
     cx.sync();
-    MZP_TICK(7);
   }
 #endif
+  }
 }
 
 // coordinate c of movable block b's body origin (get_body_com, maze_env.py:364-368): spawn position + its two slides
