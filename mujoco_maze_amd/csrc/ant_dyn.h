@@ -59,6 +59,7 @@ struct HostCtx {
   MZ_HD double rowsum(double x) const { return x; }
   MZ_HD bool any(bool p) const { return p; }
   MZ_HD bool gany(bool p) const { return p; }
+  MZ_HD unsigned long long gballot(bool p) const { return p ? 1ULL : 0ULL; }
   template <class S> MZ_HD void tick(S&, int) const {}
 };
 

@@ -135,6 +135,12 @@ struct DevCtx {
     return x;
   }
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+  // ballot restricted to this lane group, bit k = lane k of the group
+  __device__ __forceinline__ unsigned long long gballot(bool p) const {
+    const unsigned long long b = __ballot(p);
+    if constexpr (G >= 64) return b;
+    else return (b >> (__lane_id() - (unsigned)l)) & ((1ULL << (G & 63)) - 1ULL);
+  }
   // any() restricted to this lane group: one ballot, no shuffles
   __device__ __forceinline__ bool gany(bool p) const {
     unsigned long long b = __ballot(p);

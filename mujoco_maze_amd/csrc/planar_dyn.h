@@ -860,15 +860,20 @@ MZP_HD int point_detect_group(const C& cx, const PointDev& P, PlanarScratch<NB, 
   PtCand c;
   c.found = 0; c.degenerate = 0; c.k = 0; c.dist = 0.0; c.pt[0] = c.pt[1] = c.rf[0] = c.rf[1] = 0.0;
   point_detect_range(P, o, n, mvx, mvy, cx.lane0(), C::nlanes, c);
+  // which lanes hold a candidate: none (the usual case: no wall between the two positions) ends the detection here, without the
+  // hand-off; otherwise only those lanes' entries are read
+  unsigned long long holders = cx.gballot(c.found != 0 || c.degenerate != 0);
+  if (holders == 0ULL) return 0;
   double* buf = s.detect_buf();
-  {
+  if (c.found || c.degenerate) {
     double* q = buf + 8 * cx.lane0();
     q[0] = (double)(c.found + 2 * c.degenerate); q[1] = c.dist; q[2] = (double)c.k; q[3] = c.pt[0]; q[4] = c.pt[1]; q[5] = c.rf[0]; q[6] = c.rf[1];
   }
   cx.sync();
   int found = 0, degenerate = 0, bestk = 0;
   double best = 0.0;
-  for (int j = 0; j < C::nlanes; j++) {
+  for (; holders != 0ULL; holders &= holders - 1ULL) {
+    const int j = __builtin_ctzll(holders);
     const double* q = buf + 8 * j;
     const int fl = (int)q[0], k = (int)q[2];
     if (fl & 2) degenerate = 1;

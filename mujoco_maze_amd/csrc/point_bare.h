@@ -22,6 +22,8 @@
 // The one-lane host context (tests/emu) runs this source on the CPU against the oracle.
 #pragma once
 
+#define MZ_PB_SLACK 0.25  // how far a stage state may drift from the step's start before the once-per-step broad phase is re-done
+
 // sin and cos of x.  |x| < 1e5 (the heading: wrapped to [-pi, pi] once per step, point.py:47-51): k = nearest multiple of
 // pi/2, r = x - k pi/2 by fdlibm's three-term Cody-Waite split (exact first product for |k| < 2^20), then fdlibm's
 // __kernel_sin / __kernel_cos minimax polynomials on [-pi/4, pi/4]: below 1 ulp.  Anything else goes to libm.
@@ -156,7 +158,7 @@ MZP_HD void pb_fill(const PointDev& P, const PlBareEntry& e, const double* q, co
 // lane holds it); qacc / qas: in — the previous stage's (warm start), out — this stage's.
 template <class C>
 MZP_HD void point_forward_bare(const C& cx, const PointDev& P, PlanarScratch<0, 0>& s, const double* q, const double* v, double* qacc, double* qas,
-                               bool warm) {
+                               bool warm, bool maybe) {
   using S = PlanarScratch<0, 0>;
   constexpr int G = C::nlanes, SW = G < 16 ? G : 16, K = S::CAP / SW, KC = (24 + G - 1) / G;
   const int lane = cx.lane0();
@@ -166,7 +168,10 @@ MZP_HD void point_forward_bare(const C& cx, const PointDev& P, PlanarScratch<0, 
   const double w2 = v[2] * v[2], mc = P.mass * P.com_x, mcs = mc * si, mcc = mc * co;
   qas[0] = P.com_x * w2 * co; qas[1] = P.com_x * w2 * si; qas[2] = 0.0;
   qacc[0] = qas[0]; qacc[1] = qas[1]; qacc[2] = qas[2];
-  bool near = point_near_wall(P, q[0], q[1]);
+  // broad phase: `maybe` (once per step, point_env_step_bare: a wall within reach + 1.5 MZ_PB_SLACK of the step's start) or a stage
+  // state that has moved by more than the slack sends the env to the exact per-stage test; everybody else is done
+  bool near = maybe || fabs(q[0] - s.x0[0]) > MZ_PB_SLACK || fabs(q[1] - s.x0[1]) > MZ_PB_SLACK;
+  if (cx.any(near)) near = near && point_near_wall3(P, q[0], q[1], P.reach);
 #ifdef MZ_EXP_NOCOLLISION
   near = false;
 #endif
@@ -453,9 +458,12 @@ MZP_HD void point_env_step_bare(const C& cx, const PointDev& P, PlanarScratch<0,
   for (int f = 0; f < P.frame_skip; f++) {  // mj_step, RK4 (point.xml:3)
     const double h = P.h;
     MZ_FOR(one, 1) { for (int i = 0; i < 3; i++) { s.x0[i] = q[i]; s.v0[i] = v[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; } }
+    cx.sync();
+    // (a drift of up to the slack in x AND in y is sqrt(2) slacks: the pre-test's radius grows by 1.5)
+    const bool maybe = !(P.reach + 1.5 * MZ_PB_SLACK < (double)P.maze.scale) || point_near_wall3(P, q[0], q[1], P.reach + 1.5 * MZ_PB_SLACK);
     double qacc[3] = {0.0, 0.0, 0.0}, qas[3] = {0.0, 0.0, 0.0};
     for (int st = 0; st < 4; st++) {
-      point_forward_bare(cx, P, s, q, v, qacc, qas, st > 0);
+      point_forward_bare(cx, P, s, q, v, qacc, qas, st > 0, maybe);
       MZB_TICK(8);
       const double bw = (st == 0 || st == 3) ? 1.0 / 6 : 1.0 / 3, aw = st == 2 ? 1.0 : 0.5;
       MZ_FOR(one, 1) { for (int i = 0; i < 3; i++) { s.accv[i] += bw * v[i]; s.accf[i] += bw * qacc[i]; } }

@@ -299,6 +299,33 @@ MZP_HD bool point_near_wall(const PointDev& P, double x, double y) {
 }
 
 
+// The same predicate for a robot whose reach is smaller than a maze cell, straight-line: only the 3 x 3 cells around the cell under
+// (x, y) can be that close (point_dev_from_model: reach < scale), and a cell's distance is (dx[dj]^2 + dy[di]^2)^(1/2) with three
+// values each — no loops over a lane-dependent cell range.  `reach` may be enlarged by the caller (a conservative pre-test).
+MZP_HD bool point_near_wall3(const PointDev& P, double x, double y, double reach) {
+  const MazeDev& z = P.maze;
+  const double s = z.scale, inv = 1.0 / s;
+  const int jc = (int)floor((x + z.tx) * inv + 0.5), ic = (int)floor((y + z.ty) * inv + 0.5);
+  double dx2[3], dy2[3];
+  unsigned bits[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int j = jc + d - 1, i = ic + d - 1;
+    const double ex = fmax(fabs(x - (j * s - z.tx)) - z.half_xy, 0.0), ey = fmax(fabs(y - (i * s - z.ty)) - z.half_xy, 0.0);
+    dx2[d] = ex * ex; dy2[d] = ey * ey;
+    const unsigned row = (i >= 0 && i < z.rows && i < MZ_MAX_GRID) ? z.rowmask[i] : 0u;  // (bits of columns >= cols are never set)
+    const int sh = jc + 1;  // column c sits at bit c + 2 of row << 2, so the columns jc - 1, jc, jc + 1 are the bits sh, sh + 1, sh + 2
+    bits[d] = (sh >= 0 && sh < 16) ? (((row << 2) >> sh) & 7u) : 0u;
+  }
+  const double r2 = reach * reach;
+  bool near = false;
+#pragma unroll
+  for (int di = 0; di < 3; di++)
+#pragma unroll
+    for (int dj = 0; dj < 3; dj++) near = near || (((bits[di] >> dj) & 1u) && dx2[dj] + dy2[di] < r2);
+  return near;
+}
+
 MZP_HD double pt_impedance(const double* si, double x) {
   double d0 = si[0], dmax = si[1], width = si[2], mid = si[3], power = si[4];
   if (d0 == dmax || width <= 1e-15) return 0.5 * (d0 + dmax);
