@@ -46,6 +46,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD's MI355X spec sheet: FP64 vector = half the FP32 vector rate (the guide lists FP32 only)
 N_SIMD = 256 * 4                 # 256 CUs x 4 SIMDs
+PMC_PASS_TIMEOUT_S = 120         # each of the two live rocprofv3 --pmc child passes (about 20 s each on a fresh box)
+SUSTAINED_STEPS = 1000           # the untimed-by-the-metric leg behind the timed window: the settled kernel over a long rollout
+# tools/fetch_calib.hip under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on 1 GiB (past the 256 MiB Infinity Cache), profiles/r05/fetch_calibration.txt
+FETCH_CALIBRATION = "see profiles/r05/fetch_calibration.txt"
 
 
 def algo_bytes_per_env_step(m):
@@ -108,30 +112,30 @@ def live_pmc_traffic(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--env", args.env,
-                   "--envs", str(args.envs), "--settle", str(settle), "--warmup", "0", "--steps", str(steps), "--no-cpu-baseline", "--no-live-pmc"]
+                   "--envs", str(args.envs), "--settle", str(settle), "--warmup", "0", "--steps", str(steps), "--no-cpu-baseline", "--no-live-pmc", "--sustained", "0"]
             if args.lanes:
                 cmd += ["--lanes", str(args.lanes)]
             for kv in args.opt:
                 cmd += ["--opt", kv]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=PMC_PASS_TIMEOUT_S)
             except subprocess.TimeoutExpired:
                 return None, f"rocprofv3 --pmc {counter} pass timed out"
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
-            rows = []
+            per_dispatch = {}  # one value per launch: rows of one Dispatch_Id (per XCD / dimension, should rocprofv3 emit several) are summed
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if "_step_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        rows.append((int(row.get("Dispatch_Id", len(rows))), float(row["Counter_Value"])))
-            rows.sort()
-            timed = [v for _, v in rows][settle:]
+                        d = int(row["Dispatch_Id"]) if row.get("Dispatch_Id") not in (None, "") else len(per_dispatch)
+                        per_dispatch[d] = per_dispatch.get(d, 0.0) + float(row["Counter_Value"])
+            timed = [per_dispatch[d] for d in sorted(per_dispatch)][settle:]
             if not timed:
                 return None, f"rocprofv3 --pmc {counter}: no step-kernel rows in the counter file"
             vals[counter] = sum(timed) / len(timed)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return vals, f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command ({settle} settle + {steps} profiled launches each), per-launch average in bytes"
+    return vals, f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command ({settle} settle + {steps} profiled launches each), per-launch average; rocprofv3 reports KB, x 1024 here; calibration of the counters for this kernel's 4-byte-per-lane accesses: " + FETCH_CALIBRATION
 
 
 def pmc_traffic(vals):
@@ -278,6 +282,7 @@ def main():
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup (1/2/4); 0 = library default")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL obs all-gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained", type=int, default=SUSTAINED_STEPS, help="steps of the extra, separately reported leg behind the timed window (0 = off)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child passes for roofline.traffic (fall back to profiles/)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only, no GPU work (CPU test of --gpus N)")
     ap.add_argument("--opt", action="append", default=[], help="extra library option key=value (tuning experiments)")
@@ -381,6 +386,14 @@ def main():
     status = env.status()
     bad = int(((status & 3) != 0).sum().item())
     kernel_ms_ranks, no_gather = [kernel_ms], None
+    # the sustained number: the driver's short window sits a few hundred launches into the rollout; the same
+    # loop once more over SUSTAINED_STEPS launches, NOT part of `value` / `ms_per_step`
+    sustained = None
+    if world == 1 and args.sustained > 0:
+        env.set_option("time_kernels", args.sustained)
+        dt_s = timed(args.sustained)
+        sustained = {"value": n * args.sustained / dt_s, "kernel_ms": env.kernel_ms(), "ms_per_step": dt_s / args.sustained * 1e3, "steps": args.sustained,
+                     "note": "same loop, run after the timed window; not part of value"}
     if world > 1:
         km = torch.zeros(world, dtype=torch.float64, device=dev)
         km[rank] = kernel_ms
@@ -429,6 +442,8 @@ def main():
         rv = valu_roofline(pmc, kernel_ms, n * args.steps / (kernel_ms * 1e-3 * args.steps) if kernel_ms > 0 else 0.0, env_id, f64=robot != 1)
         if rv is not None:
             out["roofline_valu"] = rv
+        if sustained is not None:
+            out["sustained"] = sustained
         if no_gather is not None:
             out["without_allgather"] = no_gather  # same ranks, same steps, collective off (with / without)
         if world == 1 and not args.no_cpu_baseline:

@@ -249,10 +249,13 @@ int32_t mz_nu(const mz_handle* h);
 
 /* Tunables: "auto_reset" (0/1), "seed", "env_index_offset" (global slot of local env 0 in a
  * sharded run: keys the reset RNG), "solver_iterations", "solver_tolerance", "solver_rtol",
- * "ls_iterations" (Ant solver), "lanes_per_env" (8/16/32/64 lanes of a wavefront per environment; defaults: Ant 32,
- * Ant with movable blocks 64, Point 16 / 32 / 64 by block count), "waves_per_block" (1/2/4, Ant), "profile_phases" (0/1:
- * instrumented Ant kernel, see mz_read_phase_cycles), "time_kernels" (n > 0: ring of n HIP event pairs around the step
- * kernel, see mz_last_kernel_ms). Returns MZ_OK or MZ_ERR_ARG. */
+ * "ls_iterations" (Ant solver), "lanes_per_env" (8/16/32/64 lanes of a wavefront per environment; defaults: plain Ant 16,
+ * Ant with one movable block 32, with more blocks / a three-slide block / the ball 64; Point 32, with two or three blocks 64;
+ * Swimmer / Reacher 4, fixed), "waves_per_block" (1/2/4, Ant), "waves_per_simd" (plain Ant at 16 lanes: 1 = the one-wave
+ * kernel, 2 = the kernel held to 256 registers so that two waves share a SIMD, 0 = default: by the wave count of the
+ * launch — more waves than SIMDs takes the second), "profile_phases" (0/1: instrumented Ant kernel, see
+ * mz_read_phase_cycles), "time_kernels" (n > 0: ring of n HIP event pairs around the step kernel, see
+ * mz_last_kernel_ms). Returns MZ_OK, MZ_ERR_ARG, or MZ_ERR_UNSUPPORTED for an Ant-only key on another robot. */
 int32_t mz_set_option(mz_handle* h, const char* key, double value);
 
 /* Auto-reset observation convention.  With option "auto_reset" = 1 an env whose step ended its episode (done != 0) is

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB_PATH = os.path.join(_HERE, "csrc", "libmazestep.so")
 # A/B timing of experiment builds (tools/exp_*.sh) only: the override is announced on stderr when the library is loaded and
 # recorded in bench.py's JSON line (config.library), so a stale variable cannot swap the stepper silently
-LIB_PATH = os.environ.get("MZ_LIBMAZESTEP_EXPERIMENT") or DEFAULT_LIB_PATH
+# — and it is honoured only together with MZ_DEBUG=1 (a developer's shell), never on its own
+LIB_PATH = (os.environ.get("MZ_LIBMAZESTEP_EXPERIMENT") if os.environ.get("MZ_DEBUG") == "1" else None) or DEFAULT_LIB_PATH
 
 # every entry point declared in include/mazestep.h
 SYMBOLS = [

@@ -61,9 +61,17 @@ constexpr size_t ant_env_lds_bytes() { return ant_scratch_bytes<NB, G, PROF>() +
 // the kernel must fit  N*G/64 / 1024 SIMDs  waves per SIMD to be resident in one round.
 template <int G>
 constexpr int ant_waves_per_simd() { return G >= 64 ? 4 : (G == 32 ? 2 : 1); }
+// WPS = 2: the second instantiation of the 16-lane plain ant (round 5), held to 256 registers IN ALL so that two of its waves share a
+// SIMD.  The one-wave kernel uses 256 + 38 accumulation registers: beyond 4096 envs (more waves than the 1024 SIMDs) its launch ran in
+// rounds — 0.282 ms at 4096 envs, 0.522 ms at 8192.  Forced into 256 registers the compiler spills 36 of them, all per-step lane
+// constants re-read once per forward evaluation (no scratch access inside a Newton iteration): 4 % slower with one wave per SIMD
+// (13.7 against 14.2 M env-steps/s at 4096 envs), but two co-resident waves fill each other's issue gaps — 21.0 against 15.5 M at 8192
+// envs, 23.4 against 16.4 M at 16384.  launch_ant_step picks by the wave count of the launch (option "waves_per_simd" overrides).
+template <int NB, int G, int WPS>
+constexpr int ant_occupancy() { return WPS ? WPS : (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G>()); }
 
-template <int NB, int G, bool PROF>
-__global__ __launch_bounds__(256, (NB ? (G >= 64 ? 2 : 1) : ant_waves_per_simd<G>())) void ant_step_kernel(const AntDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
+template <int NB, int G, bool PROF, int WPS = 0>
+__global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_kernel(const AntDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
                                                        float* __restrict__ obs, float* __restrict__ reward,
                                                        uint8_t* __restrict__ done, int* __restrict__ goal_idx,
                                                        float* __restrict__ info, int* __restrict__ status, int auto_reset,
@@ -281,6 +289,21 @@ __global__ void ant_get_state_kernel(AntLayout L, int n, const float* state, flo
   else if (i == L.rec_t) { if (t) t[env] = ((const int*)rec)[L.rec_t]; }
 }
 
+// the two-waves-per-SIMD instantiation (WPS = 2) exists for the 16-lane plain ant; taken when the launch has more waves than the
+// device has SIMDs (4 per compute unit), or as option "waves_per_simd" says (1 / 2; 0 = by the wave count)
+template <int NB, int G>
+static bool ant_two_waves(const mz_handle* h, int waves) {
+  if (!(NB == 0 && G == 16)) return false;
+  if (h->waves_per_simd) return h->waves_per_simd == 2;
+  static int simds[32] = {};
+  const int dv = h->device & 31;
+  if (!simds[dv]) {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cu <= 0) cu = 256;
+    simds[dv] = 4 * cu;
+  }
+  return waves > simds[dv];
+}
 template <int NB, int G>
 static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   int wpb = h->waves_per_block;
@@ -302,6 +325,17 @@ static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, 
     }
     hipLaunchKernelGGL((ant_step_kernel<NB, G, true>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
                        h->auto_reset, h->seed, h->env0, h->prof, h->final_obs, h->lay.ostride, rec);
+  } else if (ant_two_waves<NB, G>(h, (int)grid.x * wpb)) {
+    if constexpr (NB == 0 && G == 16) {
+      static size_t lds_set2[32] = {};
+      if (lds_set2[dv] != lds) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set2[dv] = lds;
+      }
+      hipLaunchKernelGGL((ant_step_kernel<NB, G, false, 2>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
+                         h->auto_reset, h->seed, h->env0, (unsigned long long*)nullptr, h->final_obs, h->lay.ostride, rec);
+    }
   } else {
     if (lds_set[0][dv] != lds) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -141,6 +141,14 @@ __device__ __forceinline__ void fold_t(const float (&cg)[8], float j0, float j1,
       : [c0] "v"(cg[0]), [c1] "v"(cg[1]), [c2] "v"(cg[2]), [c3] "v"(cg[3]), [c4] "v"(cg[4]), [c5] "v"(cg[5]), [c6] "v"(cg[6]), [c7] "v"(cg[7]),
         [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [p] "n"(P));
 }
+// gradient part alone (the refinement step of ant_solve_rows_core): t = g . j with g = three registers of the owner lane P
+template <int P>
+__device__ __forceinline__ float fold_g(float g0, float g1, float g2, float j0, float j1, float j2) {
+  float t;
+  asm("s_nop 1\n\t" MZ_FA_MUL(0, c0, j0) MZ_FA_FMA(0, c1, j1) MZ_FA_FMA(0, c2, j2)
+      : "=&v"(t) : [c0] "v"(g0), [c1] "v"(g1), [c2] "v"(g2), [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [p] "n"(P));
+  return t;
+}
 #define MZ_FH(k, j, t) "v_fmac_f32_dpp %" #k ", %[" #j "], %[" #t "] row_newbcast:" #k MZ_DPP_TAIL
 #define MZ_FH14(j, t) MZ_FH(0, j, t) MZ_FH(1, j, t) MZ_FH(2, j, t) MZ_FH(3, j, t) MZ_FH(4, j, t) MZ_FH(5, j, t) MZ_FH(6, j, t) MZ_FH(7, j, t) \
                       MZ_FH(8, j, t) MZ_FH(9, j, t) MZ_FH(10, j, t) MZ_FH(11, j, t) MZ_FH(12, j, t) MZ_FH(13, j, t)
@@ -162,7 +170,7 @@ __device__ __forceinline__ void fold_h(float (&H)[16], float j0, float j1, float
 // one Gauss-Jordan pivot P on the row-distributed system (Hrow | b): every other row gets rid of column P.
 // COLS... = the columns that can still be non-zero in the pivot row (compile-time list: the arrow structure).
 template <int P, int N, int... COLS>
-__device__ __forceinline__ void pivot(int r, float (&Hrow)[N], float& b, float& dinv) {
+__device__ __forceinline__ void pivot(int r, float (&Hrow)[N], float& b, float& dinv, float (&mlt)[N]) {
   // `r == P` is compared HERE, next to its two selects (one v_cmp into VCC): left to itself the compiler hoists the 14-16 lane masks of
   // a solve out of every loop, runs out of scalar registers, spills them to VGPR lanes and restores each with two v_readlane per
   // pivot (round 4: 387 -> 315 v_readlane in the kernel, 48 -> 42 accumulation registers, 0.2949 -> 0.2937 ms)
@@ -172,50 +180,77 @@ __device__ __forceinline__ void pivot(int r, float (&Hrow)[N], float& b, float& 
   const float nli = (r == P) ? 0.f : -(Hrow[P] * ri);
   elim<P>(nli, b, Hrow[COLS]...);
   dinv = (r == P) ? ri : dinv;
+  mlt[P] = nli;  // this row's multiplier of pivot P: kept for a second right-hand side (resolve_rows); dead code where nobody asks
 }
 
 // H x = b, arrow-structured SPD H, row-distributed in POSITION order (pos2dof above): the hinges (positions 0 1 | 4 5 | 8 9 | 12 13)
 // are eliminated first, each touching its partner and the hub columns (root: positions 2 3 6 7 10 11) only
-__device__ __forceinline__ float solve_rows(int r, float (&Hrow)[14], float b) {
-  float dinv = 0.f;
+__device__ __forceinline__ float solve_rows(int r, float (&Hrow)[14], float b, float (&mlt)[14], float& dinv) {
+  dinv = 0.f;
   // the four legs do not couple: their hip pivots (then their ankle pivots) are independent chains — issued next to each
   // other so that the reciprocal / broadcast latencies of one hide behind the others
-  pivot<0, 14, 1, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<4, 14, 5, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<8, 14, 9, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<12, 14, 13, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<1, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<5, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<9, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<13, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<2, 14, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<3, 14, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<6, 14, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<7, 14, 10, 11>(r, Hrow, b, dinv);
-  pivot<10, 14, 11>(r, Hrow, b, dinv);
-  pivot<11, 14>(r, Hrow, b, dinv);
+  pivot<0, 14, 1, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<4, 14, 5, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<8, 14, 9, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<12, 14, 13, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<1, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<5, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<9, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<13, 14, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<2, 14, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<3, 14, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<6, 14, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<7, 14, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<10, 14, 11>(r, Hrow, b, dinv, mlt);
+  pivot<11, 14>(r, Hrow, b, dinv, mlt);
   return b * dinv;
+}
+__device__ __forceinline__ float solve_rows(int r, float (&Hrow)[14], float b) {
+  float mlt[14], dinv;
+  return solve_rows(r, Hrow, b, mlt, dinv);
 }
 // the same with one movable block: its two slides (positions 14, 15) belong to the hub (a robot-block contact couples them with the
 // root and with one leg), eliminated between the legs and the root
+__device__ __forceinline__ float solve_rows(int r, float (&Hrow)[16], float b, float (&mlt)[16], float& dinv) {
+  dinv = 0.f;
+  pivot<0, 16, 1, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<4, 16, 5, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<8, 16, 9, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<12, 16, 13, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<1, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<5, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<9, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<13, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv, mlt);
+  pivot<14, 16, 15, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<15, 16, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<2, 16, 3, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<3, 16, 6, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<6, 16, 7, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<7, 16, 10, 11>(r, Hrow, b, dinv, mlt);
+  pivot<10, 16, 11>(r, Hrow, b, dinv, mlt);
+  pivot<11, 16>(r, Hrow, b, dinv, mlt);
+  return b * dinv;
+}
+
 __device__ __forceinline__ float solve_rows(int r, float (&Hrow)[16], float b) {
-  float dinv = 0.f;
-  pivot<0, 16, 1, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<4, 16, 5, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<8, 16, 9, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<12, 16, 13, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<1, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<5, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<9, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<13, 16, 2, 3, 6, 7, 10, 11, 14, 15>(r, Hrow, b, dinv);
-  pivot<14, 16, 15, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<15, 16, 2, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<2, 16, 3, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<3, 16, 6, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<6, 16, 7, 10, 11>(r, Hrow, b, dinv);
-  pivot<7, 16, 10, 11>(r, Hrow, b, dinv);
-  pivot<10, 16, 11>(r, Hrow, b, dinv);
-  pivot<11, 16>(r, Hrow, b, dinv);
+  float mlt[16], dinv;
+  return solve_rows(r, Hrow, b, mlt, dinv);
+}
+// A second right-hand side through the SAME elimination (iterative refinement of the Newton step, ant_solve_rows_core): the pivots
+// of solve_rows in their order, each one instruction on the right-hand side alone — b_r += mlt_P(r) * b[lane P] — then the diagonal.
+template <int P>
+__device__ __forceinline__ void repivot(float m, float& b) { elim<P>(m, b); }
+__device__ __forceinline__ float resolve_rows(const float (&mlt)[16], float dinv, float b) {
+  repivot<0>(mlt[0], b); repivot<4>(mlt[4], b); repivot<8>(mlt[8], b); repivot<12>(mlt[12], b);
+  repivot<1>(mlt[1], b); repivot<5>(mlt[5], b); repivot<9>(mlt[9], b); repivot<13>(mlt[13], b);
+  repivot<14>(mlt[14], b); repivot<15>(mlt[15], b);
+  repivot<2>(mlt[2], b); repivot<3>(mlt[3], b); repivot<6>(mlt[6], b); repivot<7>(mlt[7], b); repivot<10>(mlt[10], b); repivot<11>(mlt[11], b);
+  return b * dinv;
+}
+__device__ __forceinline__ float resolve_rows(const float (&mlt)[14], float dinv, float b) {
+  repivot<0>(mlt[0], b); repivot<4>(mlt[4], b); repivot<8>(mlt[8], b); repivot<12>(mlt[12], b);
+  repivot<1>(mlt[1], b); repivot<5>(mlt[5], b); repivot<9>(mlt[9], b); repivot<13>(mlt[13], b);
+  repivot<2>(mlt[2], b); repivot<3>(mlt[3], b); repivot<6>(mlt[6], b); repivot<7>(mlt[7], b); repivot<10>(mlt[10], b); repivot<11>(mlt[11], b);
   return b * dinv;
 }
 
@@ -363,6 +398,11 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
   // holds them; more than G of them: flagged, the surplus dropped
   constexpr int MB = NB ? (WR ? 1 : (D::NC + G - 1) / G) : 0;
   constexpr int MA = NB ? 2 : 1;                   // robot contacts per lane of the row (16 MA in all; an ant on its back next to the block: > 16)
+#ifdef MZ_EXP_NOREFINE
+  constexpr bool REFINE = false;
+#else
+  constexpr bool REFINE = NB == 1;                 // iterative refinement of an accepted unit step (below): the stiff (solimp .995) mazes
+#endif
   const int r = cx.l & 15;                       // position of this lane (rows::pos2dof); beyond NR: spare lanes (zero rows, never pivots)
   const bool isdof = r < NR, ishinge = (r & 3) < 2 && r < 14;
   const int leg = r >> 2, d = r & 1;              // hinge lanes: own leg, 0 hip / 1 ankle
@@ -714,7 +754,8 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
     if (!cx.any(!done)) { cx.tick(s, 5); break; }
     cx.tick(s, 5);
     // ---- Newton direction: H search = -grad
-    const float search = solve_rows(r, Hrow, -g);
+    float mlt[NR], dinv;
+    const float search = solve_rows(r, Hrow, -g, mlt, dinv);
     cx.tick(s, 6);
     // ---- J search on the contact lanes, limit rows on their own dofs; vote on the active set
     jdot3(search, v);
@@ -800,6 +841,58 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
 #pragma unroll
             for (int a = 0; a < 3; a++) bu[m][a] += alpha * bv[m][a];
         }
+      }
+    }
+    // ---- one step of iterative refinement behind an ACCEPTED unit step (round 5; mazes with a movable block).  The unit step is
+    // taken as exact when the active set does not change — true of the arithmetic, not of an fp32 elimination: with every geom at
+    // solimp .995 (maze_env.py:108-112) H = M + J^T D J has a condition number of 1e3 .. 1e4, and the step's error is relative to
+    // the WHOLE step — hinge accelerations of thousands of rad/s^2 — so the torso's angular entries (tens of rad/s^2) came out 3e-4
+    // off, 4e-6 in their velocity per evaluation: the whole of AntPush's error tail (tools/exp_forward_err.py; the float64 oracle,
+    // fed inputs perturbed at fp32 round-off, moves by 1e-5 at most).  The residual gradient at qacc + search (same active set, the
+    // affine quantities follow the step) goes through the SAME elimination — its multipliers were kept (resolve_rows) — and the
+    // correction is added: ~120 instructions, no second Hessian.
+    if constexpr (REFINE) {
+      if (cx.any(exact && !done)) {
+        const float Ms2 = changed ? Ms : matvec(Mrow, search);
+        float g2 = Mx + Ms2;
+        float cg2[MA][3];
+#pragma unroll
+        for (int m = 0; m < MA; m++) {
+          cg2[m][0] = cg2[m][1] = cg2[m][2] = 0.f;
+          if (m == 1 && !any2) continue;
+          const float u0 = u[m][0] + v[m][0], u1 = u[m][1] + v[m][1], u2 = u[m][2] + v[m][2], Dm = cD[m];
+          const float r0 = u0 + u1, r1 = u0 - u1, r2 = u0 + u2, r3 = u0 - u2;
+          const float a0 = r0 < 0.f ? r0 : 0.f, a1 = r1 < 0.f ? r1 : 0.f, a2 = r2 < 0.f ? r2 : 0.f, a3 = r3 < 0.f ? r3 : 0.f;
+          cg2[m][0] = Dm * (a0 + a1 + a2 + a3); cg2[m][1] = Dm * (a0 - a1); cg2[m][2] = Dm * (a2 - a3);
+        }
+        each_contact([&](auto Cc) {
+          constexpr int C = decltype(Cc)::value;
+          float jc[3];
+          own_col(Cc, jc);
+          g2 += fold_g<(C & 15)>(cg2[C / 16][0], cg2[C / 16][1], cg2[C / 16][2], jc[0], jc[1], jc[2]);
+        });
+        {
+          const float lj2 = ljar + ljv;
+          g2 += lsign * (lj2 < 0.f ? lD : 0.f) * lj2;
+        }
+        if constexpr (NB == 1) {
+          float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+          for (int m = 0; m < MB; m++) {
+            const float x0 = bu[m][0] + bv[m][0], x1 = bu[m][1] + bv[m][1], x2 = bu[m][2] + bv[m][2], Dm = bD[m];
+            const float r0 = x0 + x1, r1 = x0 - x1, r2 = x0 + x2, r3 = x0 - x2;
+            const float a0 = r0 < 0.f ? r0 : 0.f, a1 = r1 < 0.f ? r1 : 0.f, a2 = r2 < 0.f ? r2 : 0.f, a3 = r3 < 0.f ? r3 : 0.f;
+            const float g0 = Dm * (a0 + a1 + a2 + a3), g1 = Dm * (a0 - a1), gg2 = Dm * (a2 - a3);
+            c0 += bj[m][0][0] * g0 + bj[m][1][0] * g1 + bj[m][2][0] * gg2;
+            c1 += bj[m][0][1] * g0 + bj[m][1][1] * g1 + bj[m][2][1] * gg2;
+          }
+          c0 = cx.gsum(c0); c1 = cx.gsum(c1);
+          if (r == 14) g2 += c0;
+          if (r == 15) g2 += c1;
+        }
+        if (!isdof) g2 = 0.f;
+        const float corr = resolve_rows(mlt, dinv, -g2);
+        if (exact && !done) qacc += corr;
       }
     }
 #ifdef MZ_EXP_TRACE  // developer aid (tools/replay_trace.py): one line per Newton iteration of the first env of a wave

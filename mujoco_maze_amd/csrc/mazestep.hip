@@ -170,7 +170,7 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "seed")) { h->seed = (uint64_t)value; return MZ_OK; }
   if (!strcmp(key, "env_index_offset")) { h->env0 = (uint64_t)value; return MZ_OK; }
   if (h->robot != MZ_ROBOT_ANT && (!strcmp(key, "solver_iterations") || !strcmp(key, "solver_tolerance") || !strcmp(key, "solver_rtol") ||
-                                   !strcmp(key, "ls_iterations") || !strcmp(key, "debug_frame_skip") || !strcmp(key, "waves_per_block")))
+                                   !strcmp(key, "ls_iterations") || !strcmp(key, "debug_frame_skip") || !strcmp(key, "waves_per_block") || !strcmp(key, "waves_per_simd")))
     return set_err(h, MZ_ERR_UNSUPPORTED, "mz_set_option: this key tunes the Ant kernels only (the other robots' solvers have fixed settings)", hipSuccess);
   if (h->robot == MZ_ROBOT_GENERIC && !strcmp(key, "lanes_per_env"))
     return set_err(h, MZ_ERR_UNSUPPORTED, "mz_set_option: the generic-robot kernel runs one wavefront per env", hipSuccess);
@@ -200,6 +200,12 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
     int w = (int)value;
     if (w != 1 && w != 2 && w != 4) return set_err(h, MZ_ERR_ARG, "waves_per_block must be 1, 2 or 4", hipSuccess);
     h->waves_per_block = w; h->wpb_set = 1;
+    return MZ_OK;
+  }
+  if (!strcmp(key, "waves_per_simd")) {
+    int w = (int)value;
+    if (w < 0 || w > 2) return set_err(h, MZ_ERR_ARG, "waves_per_simd must be 0 (by the launch's wave count), 1 or 2", hipSuccess);
+    h->waves_per_simd = w;
     return MZ_OK;
   }
   if (!strcmp(key, "time_kernels")) {

@@ -41,6 +41,7 @@ struct mz_handle {
   float* record;        // caller's [n, obs_dim + 2] buffer for the packed record obs | reward | done (mz_bind_record), or NULL
   unsigned long long* prof;  // 16 phase-cycle accumulators (option "profile_phases")
   int auto_reset, lanes, waves_per_block, wpb_set;
+  int waves_per_simd;  // option "waves_per_simd": 0 = chosen by the launch's wave count, 1 / 2 = the plain ant's one- / two-wave kernel (ant_kernels.hip)
   uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
   char err[256];
   int lanes_set;  // lanes_per_env chosen by the caller (else the per-robot default)

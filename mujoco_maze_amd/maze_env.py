@@ -52,6 +52,10 @@ class WrappedRobot:
         self._vec, self._cls, self._single = vec, model_cls, single
 
     def __getattr__(self, name):  # class attributes of the robot class (ORI_IND, RADIUS, MANUAL_COLLISION, ...)
+        # (only reached for names the instance does not have: private names and a half-built instance — copy / pickle probe
+        # __setstate__ & co. before __init__ has run — must not recurse through the missing `_cls`)
+        if name.startswith("_") or "_cls" not in self.__dict__:
+            raise AttributeError(name)
         return getattr(self._cls, name)
 
     def get_xy(self):
@@ -86,8 +90,16 @@ class WrappedRobot:
             ox = w * w + x * x - y * y - z * z
             oy = 2.0 * (x * y + w * z)
             ori = torch.atan2(oy, ox)
-        else:
+        elif getattr(self._cls, "ROBOT", None) == "point":
             ori = qpos[:, ind].clone()
+        else:
+            # a user robot: qpos[ORI_IND] is a yaw angle only if its class says so (a free-joint robot's entry there is a
+            # quaternion component) — it supplies the rule as a static `ori_from_qpos(qpos [N, nq]) -> [N]`
+            fn = getattr(self._cls, "ori_from_qpos", None)
+            if fn is None:
+                raise AttributeError(f"{self._cls.__name__}: get_ori is defined for the Point (qpos[ORI_IND]) and the Ant (torso quaternion); "
+                                     "a user robot provides `ori_from_qpos(qpos)`")
+            ori = fn(qpos)
         return float(ori[0].item()) if self._single else ori
 
 
@@ -148,6 +160,8 @@ class VecMazeEnv:
         self._final_obs = None
         self._host_mask = None
         self._record = None
+        self._resampled_goals = False
+        self._warned_goal_resampling = False
         self.set_auto_reset(auto_reset)
         lo = np.array([m.act_ctrlrange[a][0] for a in range(m.nu)], dtype=np.float32)
         hi = np.array([m.act_ctrlrange[a][1] for a in range(m.nu)], dtype=np.float32)
@@ -226,6 +240,31 @@ class VecMazeEnv:
         rc = self._lib.mz_set_goals(self._h, n, pos.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p),
                                     rs.ctypes.data_as(C.c_void_p), dim.ctypes.data_as(C.c_void_p), self._stream())
         _capi.check(self._lib, self._h, rc, "mz_set_goals")
+        # the host copy of the model follows (tools that judge with `env.model` must see the new goals; model.py fills the same fields)
+        m = self.model.c
+        m.ngoal = n
+        for i in range(n):
+            for k in range(3):
+                m.goal_pos[i][k] = float(pos[i, k])
+            m.goal_threshold[i], m.goal_reward_scale[i], m.goal_dim[i] = float(thr[i]), float(rs[i]), int(dim[i])
+
+    def _sync_goals_across_ranks(self) -> None:
+        """Sharded runs (sharding.py): every rank called sample_goals() on its own unsynchronised RNG — rank 0's goals win, so that
+        the batch really has ONE goal table (positions only: thresholds / reward scales are class constants of the task)."""
+        try:
+            import torch.distributed as dist
+        except Exception:
+            return
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        torch = self._torch
+        buf = torch.zeros((8, 3), dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        for i, g in enumerate(self._task.goals[:8]):
+            buf[i, : g.dim] = torch.as_tensor(np.asarray(g.pos, np.float64)[: g.dim])
+        dist.broadcast(buf, src=0)
+        host = buf.cpu().numpy()
+        for i, g in enumerate(self._task.goals[:8]):
+            g.pos = host[i, : g.dim].copy()
 
     def reset(self, mask=None, seed: Optional[int] = None):
         """Reset all (or the masked) envs; returns the observation tensor [N, obs_dim] on the GPU.
@@ -236,7 +275,16 @@ class VecMazeEnv:
         if seed is not None:
             self._seed = int(seed)
         if mask is None and self._task.sample_goals():
+            self._resampled_goals = True
+            self._sync_goals_across_ranks()
             self.set_goals()
+            if self._auto_reset and not self._warned_goal_resampling:
+                import warnings
+
+                self._warned_goal_resampling = True
+                warnings.warn(f"{type(self._task).__name__}.sample_goals() returned True and auto_reset is on: the reference resamples goals "
+                              "at EVERY episode reset (maze_env.py:374-376), the device auto-reset (and a masked reset) keeps the batch's "
+                              "one goal table — goals change at full reset() calls only")
         mk = None
         if mask is not None:
             mk = self._torch.as_tensor(mask, device=self.device).to(self._torch.uint8).contiguous()
@@ -443,10 +491,13 @@ class MazeEnv:
     def get_ori(self) -> float:
         return self.wrapped_env.get_ori()  # maze_env.py:231-232
 
-    def reset(self, **kwargs):
+    def reset(self, *, return_info: bool = True, **kwargs):
+        """`(obs, info)` like the reference's MazeEnv.reset (maze_env.py:371-382).  `return_info=False` hands back the bare
+        observation — the old-gym convention the reference's own tests are written against (`env.reset().shape`,
+        tests/test_envs.py:13,27), for callers that have not moved to the tuple."""
         self.t = 0
-        obs = self.vec.reset(seed=kwargs.get("seed"))
-        return obs[0].double().cpu().numpy(), {}
+        obs = self.vec.reset(seed=kwargs.get("seed"))[0].double().cpu().numpy()
+        return (obs, {}) if return_info else obs
 
     def step(self, action):
         self.t += 1

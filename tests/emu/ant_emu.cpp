@@ -164,6 +164,10 @@ extern "C" int emu_point_env_step(const mz_model* m, int n, float* qpos, float* 
   return rc;
 }
 
+extern "C" void emu_pt_sincos(int n, const double* x, double* s, double* c) {
+  for (int i = 0; i < n; i++) pt_sincos(x[i], s + i, c + i);
+}
+
 // ---------------------------------------------------------------- Swimmer: the per-lane step function of swimmer_step_kernel
 #include "../../mujoco_maze_amd/csrc/swimmer_dyn.h"
 

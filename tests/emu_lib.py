@@ -78,6 +78,14 @@ def point_env_step(cm, st, actions):
     return out
 
 
+def pt_sincos(x):
+    lib = load()
+    x = np.ascontiguousarray(x, np.float64)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib.emu_pt_sincos(len(x), _vp(x), _vp(s), _vp(c))
+    return s, c
+
+
 def swimmer_env_step(cm, st, actions, lanes=False):
     """st: dict of float32 qpos [n,nv], qvel [n,nv], int32 t [n] (updated in place); nv = 5 Swimmer, 4 Reacher.
     lanes=True: the lane-group form of the step (the branch of swimmer_dyn.h the kernel runs), G host threads in lock step."""

@@ -12,7 +12,8 @@ from mujoco_maze_amd.model import MzModel
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "libmzo.so")
+# MZO_LIB=libmzo_ubsan.so (oracle/Makefile `make ubsan`) runs the CPU suite against the sanitizer build of the same sources
+LIB = os.path.join(ORACLE_DIR, os.environ.get("MZO_LIB", "libmzo.so"))
 
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")

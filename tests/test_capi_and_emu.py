@@ -303,6 +303,53 @@ def test_point_step_logic_with_mujoco_wall_contacts(oracle):
     assert gave_up.sum() > 20  # the give-up branch of the manual bounce is exercised
 
 
+def test_point_deep_overlap_aligned_and_rotated(oracle):
+    """csrc/point_bare.h, the deep overlap of the arrow with wall cells (least-penetration axis vertical): the per-lane rectangle
+    clipping (pb_cand) for rotated headings and its serial duplicate filter for a heading of exactly 0 (edges parallel to the cell's:
+    candidates coincide) — against the oracle's literal mjc_BoxBox, incl. arrows that straddle two or more cells."""
+    from tests import emu_lib
+
+    cm = model.compile_model("point", T.DistRewardUMaze(4.0), 4.0)
+    boxes = np.array(cm.world.wall_boxes())
+    rng = np.random.default_rng(5)
+    xmin, xmax, ymin, ymax = cm.world.xy_limits()
+    rows = []
+    for theta0 in (0.0, None):
+        got = np.zeros((0, 3))
+        while len(got) < 256:
+            th = np.zeros(4096) if theta0 is not None else rng.uniform(-3.1, 3.1, 4096)
+            c = np.stack([rng.uniform(xmin - 1, xmax + 1, 4096), rng.uniform(ymin - 1, ymax + 1, 4096), th], 1)
+            arrow = c[:, :2] + 0.6 * np.stack([np.cos(th), np.sin(th)], 1)
+            near = ((np.abs(arrow[:, None, 0] - boxes[None, :, 0]) < boxes[None, :, 3] + 0.05) & (np.abs(arrow[:, None, 1] - boxes[None, :, 1]) < boxes[None, :, 4] + 0.05)).any(1)
+            got = np.concatenate([got, c[near]])
+        rows.append(got[:256])
+    qpos = np.concatenate(rows)
+    n = len(qpos)
+    st = _f32(dict(qpos=qpos, qvel=np.stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n), rng.uniform(-3, 3, n)], 1), warm=np.zeros((n, 3)),
+                   t=np.zeros(n, np.int32)))
+    assert np.all(st["qpos"][:256, 2] == 0.0)
+    g = oracle.forward(cm, st["qpos"], st["qvel"])
+    assert (g["counts"][:, 1] >= 4).mean() > 0.5
+    act = np.zeros((n, 2), np.float32)
+    s32 = dict(qpos=st["qpos"].astype(np.float32), qvel=st["qvel"].astype(np.float32), t=st["t"].copy())
+    ro = oracle.step(cm, st, act.astype(np.float64), nthreads=8)
+    re_ = emu_lib.point_env_step(cm, s32, act)
+    assert np.all(ro["status"] == 0) and np.all(re_["status"] == 0)
+    assert np.all(np.abs(re_["obs"] - ro["obs"]) <= 1e-6 + 2e-7 * np.abs(ro["obs"])), np.abs(re_["obs"] - ro["obs"]).max()
+
+
+def test_point_sincos_kernel():
+    """pt_sincos (point_bare.h: Cody-Waite reduction + fdlibm kernels) against libm over the range the heading can take, the
+    quadrant boundaries included; beyond 1e5 it IS libm."""
+    from tests import emu_lib
+
+    rng = np.random.default_rng(0)
+    k = np.arange(-40, 41) * (np.pi / 2)
+    x = np.concatenate([rng.uniform(-4, 4, 20000), rng.uniform(-1e4, 1e4, 20000), k, np.nextafter(k, 1e9), np.nextafter(k, -1e9), k + 1e-9, [0.0, 1e-300, 3e5, -7e8]])
+    s, c = emu_lib.pt_sincos(x)
+    assert np.max(np.abs(s - np.sin(x))) < 2.5e-16 and np.max(np.abs(c - np.cos(x))) < 2.5e-16
+
+
 @pytest.mark.parametrize("name,nblock", [("Push", 1), ("MultiPush", 2), ("PushMaze", 3), ("BlockMaze", 1)])
 def test_point_with_movable_blocks(oracle, name, nblock):
     """Point + movable XY blocks (PointPush & co., maze_task.py:179-330): the lane-group planar code (csrc/planar_dyn.h:

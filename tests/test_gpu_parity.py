@@ -50,8 +50,16 @@ def _tie_mixture(dev, a, seen, branch_atol):
     return False
 
 
+def _log_branch(kind, cm, err, one_sided):
+    """MZ_PARITY_LOG=<file>: one line per env that took the discontinuity route (tools: what BRANCH_ATOL really needs)."""
+    path = os.environ.get("MZ_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{kind} robot {cm.c.robot} nblock {cm.c.nblock} elevated {cm.c.elevated} err {err:.3e} one_sided {one_sided:.3e} test {os.environ.get('PYTEST_CURRENT_TEST', '')}\n")
+
+
 def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, atol=ATOL, max_outlier_frac=0.002, hard_atol=None, dev_out=None,
-                        branch_atol=BRANCH_ATOL):
+                        branch_atol=BRANCH_ATOL, ref_done=None):
     """Per-DoF parity after one env.step: EVERY env is inside |dev - oracle| <= atol + 1e-5 |oracle| on qpos and qvel, or
     sits on a discontinuity of the step map AND agrees with the float64 oracle's value on the device's side of it.
 
@@ -76,6 +84,7 @@ def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, a
     round-off without the proof.  Returns the mask of the envs inside the plain tolerance."""
     ok = np.all(_close(dev_qpos, ref_state["qpos"], atol=atol), axis=1) & np.all(_close(dev_qvel, ref_state["qvel"], atol=atol), axis=1)
     bad = np.where(~ok)[0]
+    n_mixed = 0
     assert len(bad) <= max(1, int(max_outlier_frac * len(ok))), (len(bad), len(ok), np.abs(dev_qvel - ref_state["qvel"]).max())
     rng = np.random.default_rng(123)
 
@@ -88,6 +97,7 @@ def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, a
 
     for e in bad:
         if hard_atol is not None and np.all(_close(dev_qpos[e], ref_state["qpos"][e], atol=hard_atol)) and np.all(_close(dev_qvel[e], ref_state["qvel"][e], atol=hard_atol)):
+            _log_branch("hard_atol", cm, max(np.abs(dev_qvel[e] - ref_state["qvel"][e]).max(), np.abs(dev_qpos[e] - ref_state["qpos"][e]).max()), 0.0)
             continue
         err = max(np.abs(dev_qvel[e] - ref_state["qvel"][e]).max(), np.abs(dev_qpos[e] - ref_state["qpos"][e]).max())
         base = {k: v[e:e + 1].copy() for k, v in start.items()}
@@ -131,7 +141,15 @@ def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, a
         moved = max(np.abs(cur["qpos"] - base["qpos"]).max(), np.abs(cur["qvel"] - base["qvel"]).max())
         assert moved < 2e-5, (e, moved)
         if mixed:
-            continue  # between two outcomes of the oracle (an exact tie re-decided at every RK4 stage): nothing further to compare with
+            # between two outcomes of the oracle (an exact tie re-decided at every RK4 stage): no single branch to compare with.
+            # Rare by construction — counted, capped, and the flags must still be the oracle's
+            n_mixed += 1
+            assert n_mixed <= max(1, int(0.002 * len(ok))), f"{n_mixed} envs excused as tie mixtures"
+            if dev_out is not None and ref_done is not None:
+                assert int(dev_out[2][e]) == int(ref_done[e]), f"env {e}: done flag of a tie-mixture env differs from the oracle's"
+            _log_branch("mixture", cm, err, 0.0)
+            continue
+        _log_branch("branch", cm, err, max(np.abs(cur_res[0] - dev_qpos[e]).max(), np.abs(cur_res[1] - dev_qvel[e]).max()))
         assert np.all(_close(dev_qpos[e], cur_res[0], atol=branch_atol)) and np.all(_close(dev_qvel[e], cur_res[1], atol=branch_atol)), \
             f"env {e}: {err:.2e} off the oracle; on the device's side of the discontinuities (start moved by {moved:.1e}) the oracle is still " \
             f"{max(np.abs(cur_res[0] - dev_qpos[e]).max(), np.abs(cur_res[1] - dev_qvel[e]).max()):.2e} away"
@@ -274,6 +292,50 @@ def test_ant_lane_group_widths_agree(torch, oracle):
         assert np.all(_close(outs[g], outs[16], atol=4e-6)), g
 
 
+def test_ant_two_waves_per_simd_kernel(torch, oracle):
+    """The plain ant's second instantiation (ant_kernels.hip: WPS = 2, held to 256 registers so that two waves share a SIMD; taken
+    beyond 4096 envs, or by option "waves_per_simd") against the oracle and against the one-wave kernel — same source, same
+    arithmetic: the same bits — over a rollout with wall contacts and auto-resets; and a batch large enough to select it by itself."""
+    n = 512
+    outs = {}
+    for wps in (1, 2):
+        env = mm.make("AntUMaze-v0", num_envs=n, auto_reset=True)
+        env.set_option("waves_per_simd", wps)
+        cm = env.model
+        st = _rollout_states(oracle, cm, n, 31, {30})[30]
+        act = np.random.default_rng(7).uniform(-30, 30, (n, 8)).astype(np.float32)
+        ref_state = {k: v.copy() for k, v in st.items()}
+        oracle.step(cm, ref_state, act.astype(np.float64), nthreads=8)
+        env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+        qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+        _assert_step_parity(oracle, cm, st, act, qpos, qvel, ref_state, max_outlier_frac=0.004)
+        g = torch.Generator(device=env.device).manual_seed(3)
+        for _ in range(60):
+            obs, rew, done, info = env.step(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30)
+        outs[wps] = (obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done.cpu().numpy().copy())
+        assert np.all((env.status().cpu().numpy() & 7) == 0)
+        env.close()
+    for a, b in zip(outs[1], outs[2]):
+        assert np.array_equal(a, b)
+    with pytest.raises(Exception):
+        env = mm.make("AntUMaze-v0", num_envs=4)
+        env.set_option("waves_per_simd", 3)
+    n = 4096 + 64  # more waves than the device has SIMDs: the two-wave kernel by default
+    env = mm.make("AntUMaze-v0", num_envs=n)
+    cm = env.model
+    st, _ = oracle.reset(cm, n, 4)
+    s64 = _f32(st)
+    act = np.random.default_rng(8).uniform(-30, 30, (n, 8)).astype(np.float32)
+    env.set_state(s64["qpos"], s64["qvel"], s64["warm"], s64["t"])
+    env.step(torch.as_tensor(act, device=env.device))
+    qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+    start = _f32(st)
+    oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
+    _assert_step_parity(oracle, cm, start, act, qpos, qvel, s64, max_outlier_frac=0.002)
+    env.close()
+
+
 def _place_ant(st, xy, yaw=0.0):
     st["qpos"][:, 0], st["qpos"][:, 1] = xy[0], xy[1]
     st["qpos"][:, 3] = np.cos(yaw / 2) * np.ones(len(st["qpos"]))
@@ -396,7 +458,7 @@ def test_ant_push_movable_block(torch, oracle):
             ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.005, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
             assert np.median(per_env) < 2e-6
-            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=2e-5))
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok]))
             assert np.all(_close(rew.cpu().numpy()[ok], ref["reward"][ok], atol=1e-6))
             assert np.array_equal(done.cpu().numpy(), ref["done"])
             assert np.array_equal(obs.cpu().numpy()[:, 5], np.full(n, 2.0, np.float32))  # block z in the obs slot
@@ -430,7 +492,7 @@ def test_ant_multi_block_mazes(torch, oracle, env_id, nblock):
             ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.006, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
             per_env = (np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)
             worst.append(per_env[ok])
-            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=2e-5))
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok]))
             assert np.array_equal(done.cpu().numpy(), ref["done"])
             assert np.all((env.status().cpu().numpy() & 7) == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
@@ -474,10 +536,10 @@ def test_point_step_parity_and_bounce(torch, oracle):
 
 
 def test_point_arrow_deep_inside_a_wall(torch, oracle):
-    """The bare Point's step kernel carries no general mjc_BoxBox routine (planar_kernels.hip, MODE 1): an env whose arrow sits so deep
-    inside a wall that the least-penetration axis is vertical leaves its step undone and is stepped by the kernel's second launch.
-    Here most envs are such a case (arrow centre well inside a wall box), next to ordinary ones: all of
-    them must agree with the oracle's mjc_BoxBox, whichever launch stepped them, and a second step must find the list empty again."""
+    """The deep overlap of the bare Point's arrow with a wall cell — least-penetration axis vertical: mjc_BoxBox's general face case,
+    the intersection polygon of two rectangles — is clipped with one candidate per lane (csrc/point_bare.h: pb_cand, the deep jobs of
+    point_forward_bare).  Here most envs are such a case (arrow centre well inside a wall box, several cells at once for some), next
+    to ordinary ones: all of them must agree with the oracle's literal mjc_BoxBox restatement, for two steps in a row."""
     n = 512
     env = mm.make("PointUMaze-v0", num_envs=n)
     cm = env.model
@@ -579,6 +641,8 @@ def test_swimmer_step_parity(torch, oracle, robot, nq):
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     env.close()
     single = mm.make(f"{robot}SquareRoom-v1")
+    bare = single.reset(return_info=False)  # the old-gym convention of the reference's own tests (tests/test_envs.py:13: env.reset().shape)
+    assert isinstance(bare, np.ndarray) and bare.shape == (2 * nq + 1,)
     s0, _ = single.reset()
     s, r, d, inf = single.step(single.action_space.sample(np.random.default_rng(1)))
     assert s0.shape == (2 * nq + 1,) and s.shape == (2 * nq + 1,)  # reference tests/test_envs.py:77-78 (swimmer: 11)
@@ -688,12 +752,13 @@ def test_ant_fall_maze(torch, oracle, env_id):
             # at most 5 of 1024 — except k = 1, the step in which the block is being expelled from its platform, 4 m in 0.3 s against a
             # stiff limit row: 18 (Fall) / 32 (MultiFall) of 1024, none of them beyond 4.2e-5)
             cap = (0.064 if multi else 0.036) if k == 1 else 0.01
-            # The Fall family is held to 2e-5, not to the 1e-5 of the BASELINE configs, and says so here: a 1 g block on limited slides
-            # (limit rows with R from dof_invweight0 = 1 / m = 1000) next to rows at solimp .995 — measured 99.9 % quantile 1.4e-5
-            # (profiles/r04/parity.md).  No registered BASELINE config uses these mazes; [ASSUME-14] describes their first steps.
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, atol=2e-5, max_outlier_frac=cap, hard_atol=4.5e-5 if k == 1 else None, dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()))
+            # Bulk tolerance 1e-5 like everywhere else; the share of envs that may sit between 1e-5 and 2e-5 without the discontinuity
+            # proof (`hard_atol`: a 1 g block on limited slides — limit rows with R from dof_invweight0 = 1 / m = 1000 — next to rows at
+            # solimp .995) is capped by `cap` together with the proven ones; k = 1, the step that expels the block: up to 4.5e-5.
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=cap, hard_atol=4.5e-5 if k == 1 else 2e-5,
+                                     dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()), ref_done=ref["done"])
             worst.append((np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)[ok])
-            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok], atol=4e-5))
+            assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok]))
             assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info["goal_index"].cpu().numpy(), ref["goal_idx"])
             assert np.all((env.status().cpu().numpy() & 7) == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
@@ -942,7 +1007,7 @@ def test_ragged_batch_sizes_and_argument_errors(torch, oracle, env_id):
         obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
         ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=2)
         assert obs.shape == (n, env.obs_dim) and rew.shape == (n,) and done.shape == (n,)
-        assert np.all(_close(obs.cpu().numpy(), ref["obs"], atol=2e-5))
+        assert np.all(_close(obs.cpu().numpy(), ref["obs"]))
         assert np.array_equal(done.cpu().numpy(), ref["done"])
         assert np.all(env.status().cpu().numpy() == 0)
         with pytest.raises(ValueError):

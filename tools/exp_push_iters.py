@@ -38,7 +38,7 @@ if os.environ.get("MZ_PART") != "2":
     print("corr(iters[t], iters[t+1]) per env: %.3f" % np.corrcoef(h[:-1].ravel(), h[1:].ravel())[0, 1])
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(root, "gpurun_out/push_iter_cases.npy"), np.array(cases, dtype=object), allow_pickle=True)
-    sub = subprocess.run([sys.executable, __file__, env_id], env=dict(os.environ, MZ_PART="2", MZ_LIBMAZESTEP_EXPERIMENT=os.path.join(root, "mujoco_maze_amd/csrc/libmazestep_dev.so")),
+    sub = subprocess.run([sys.executable, __file__, env_id], env=dict(os.environ, MZ_PART="2", MZ_DEBUG="1", MZ_LIBMAZESTEP_EXPERIMENT=os.path.join(root, "mujoco_maze_amd/csrc/libmazestep_dev.so")),
                          capture_output=True, text=True, cwd=root)
     print(sub.stdout[-60000:])
     print(sub.stderr[-2000:])

@@ -3,7 +3,7 @@
 cycles per env.step and phase over the printed workgroups of the last 200 steps."""
 import os, re, subprocess, sys, collections
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-env = dict(os.environ, MZ_LIBMAZESTEP_EXPERIMENT=os.path.join(root, "mujoco_maze_amd/csrc/exp_SWPROF.so"))
+env = dict(os.environ, MZ_DEBUG="1", MZ_LIBMAZESTEP_EXPERIMENT=os.path.join(root, "mujoco_maze_amd/csrc/exp_SWPROF.so"))
 code = """
 import torch, mujoco_maze_amd as mm
 n=4096

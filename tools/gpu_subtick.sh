@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export MZ_LIBMAZESTEP_EXPERIMENT=$GRAFT_REPO_ROOT/mujoco_maze_amd/csrc/libmazestep_dev.so
+export MZ_DEBUG=1 MZ_LIBMAZESTEP_EXPERIMENT=$GRAFT_REPO_ROOT/mujoco_maze_amd/csrc/libmazestep_dev.so
 mkdir -p gpurun_out/subtick
 python tools/phase_profile.py 32 AntPush-v0 2048 2>/dev/null | tee gpurun_out/subtick/push32.txt
 python tools/phase_profile.py 16 AntPush-v0 2048 2>/dev/null | tee gpurun_out/subtick/push16.txt

@@ -9,7 +9,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_${envid}_${nenv}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # the default bench command (100 settle + 100 warm-up + 1000 timed steps), minus the CPU leg
-CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --env $envid --envs $nenv ${BENCH_ARGS:-}"
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-live-pmc --sustained 0 --env $envid --envs $nenv ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $CMD > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $CMD > $out/bench_write.log 2>&1

@@ -14,7 +14,7 @@ for c in cases:
     torch.cuda.synchronize()
     print('status', int(env.status()[0]))
 """ % (sys.argv[1] if len(sys.argv) > 1 else "AntUMaze-v0")
-env = dict(os.environ, MZ_LIBMAZESTEP_EXPERIMENT=os.path.join(root, "mujoco_maze_amd/csrc/exp_TRACE.so"))
+env = dict(os.environ, MZ_DEBUG="1", MZ_LIBMAZESTEP_EXPERIMENT=os.path.join(root, "mujoco_maze_amd/csrc/exp_TRACE.so"))
 out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True)
 lines = [l for l in out.stdout.splitlines() if l.startswith(("TRACE", "status"))]
 print("\n".join(lines))
