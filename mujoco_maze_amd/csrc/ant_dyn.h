@@ -1556,6 +1556,15 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
   cx.tick(s, 4);
   bool done = !has;
   int it = 0;
+  // An accepted unit step is exact in exact arithmetic only.  In the mazes with movable bodies every geom sits at solimp .995
+  // (maze_env.py:108-112): H = M + J^T D J then has a condition number of 1e3 .. 1e4 and an fp32 factorisation leaves the step 1e-4 of
+  // its size off — hinge accelerations of thousands of rad/s^2 next to torso entries of tens (round 5: the whole error tail of the
+  // Push / Fall families; ant_newton_rows.h carries the one-block ant's cheap form of the cure).  Here: the first accepted unit step
+  // of a solve is followed by ONE more iteration from the stepped point — the affine residuals follow the step as after a line
+  // search, the gradient is re-evaluated, and unless it already sits at the round-off floor a second Newton step (the refinement)
+  // is taken, whose acceptance ends the solve.
+  constexpr bool REFINE = NB >= 2;
+  bool refined = false;
   while (cx.any(!done) && it < K.max_iter) {
     // (a) one dot product per lane: rows of M (qacc - qas) = M qacc - qfrc_smooth | contact residuals u[c][a] | limit residuals.
     // Only the first iteration computes them from qacc; afterwards they follow the step: every one of them is affine in
@@ -1649,6 +1658,8 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     changed = cx.gany(changed);
     float alpha = 1.f, sn = 1.f, qn = 0.f;
     bool exact = !changed;
+    const bool follow = changed || (REFINE && !refined);  // the affine residuals are needed again after this step
+    if (follow && !changed) { MZ_FOR(i, NV) s.Ms[i] = arrow_row_mul<NH>(s.M, s.search, i); }
     if (changed) {
       float p1 = 0.f, p2 = 0.f;
       MZ_FOR(i, NV) { float ms = arrow_row_mul<NH>(s.M, s.search, i); s.Ms[i] = ms; p1 += s.search[i] * s.Mx[i]; p2 += s.search[i] * ms; }
@@ -1692,7 +1703,7 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     // not computed and its residuals are not used again)
     if (alpha != 0.f) {  // group-uniform; a finished env touches nothing (0 * stale values could still poison qacc)
       MZ_FOR(i, NV) s.qacc[i] += alpha * s.search[i];
-      if (changed) {
+      if (follow) {
         MZ_FOR(i, NV) s.Mx[i] += alpha * s.Ms[i];
         MZ_FOR_AT(e, 3 * s.ncon, NV) { int c = e / 3, a = e - 3 * c; s.cu[c][a] += alpha * s.cjv[c][a]; }
         MZ_FOR_AT(j, 8, NV + 3 * s.ncon) {
@@ -1703,7 +1714,8 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     cx.sync();
     // The full Newton step stayed inside one active set: the cost is exactly quadratic there, so the new
     // point is its minimiser — no verification pass needed.
-    if (exact && K.trust_exact) done = true;
+    if (exact && K.trust_exact && (!REFINE || refined)) done = true;
+    if (exact) refined = true;
     // stationary at fp32 resolution: a line-searched step that moves qacc by less than MZ_NEWTON_STALL of its norm.  Active-set
     // flips of rows whose residual is zero within round-off otherwise keep the iteration alive until the cap (soak, round 3:
     // such envs jittered by 3e-7 |qacc| per iteration for 50 iterations, 1e-7 from the oracle's answer all along).
