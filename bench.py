@@ -49,7 +49,7 @@ N_SIMD = 256 * 4                 # 256 CUs x 4 SIMDs
 PMC_PASS_TIMEOUT_S = 120         # each of the two live rocprofv3 --pmc child passes (about 20 s each on a fresh box)
 SUSTAINED_STEPS = 1000           # the untimed-by-the-metric leg behind the timed window: the settled kernel over a long rollout
 # tools/fetch_calib.hip under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on 1 GiB (past the 256 MiB Infinity Cache), profiles/r05/fetch_calibration.txt
-FETCH_CALIBRATION = "see profiles/r05/fetch_calibration.txt"
+FETCH_CALIBRATION = "FETCH_SIZE = 0.50 x bytes for 4 / 8 / 16-byte-per-lane and 192-byte-record data streams, 1.0 x per XCD for instruction fetch; WRITE_SIZE = 1.00 x (profiles/r05/fetch_calibration.txt)"
 
 
 def algo_bytes_per_env_step(m):
@@ -138,12 +138,16 @@ def live_pmc_traffic(args):
     return vals, f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command ({settle} settle + {steps} profiled launches each), per-launch average; rocprofv3 reports KB, x 1024 here; calibration of the counters for this kernel's 4-byte-per-lane accesses: " + FETCH_CALIBRATION
 
 
-def pmc_traffic(vals):
-    """HBM bytes per launch: FETCH_SIZE + WRITE_SIZE (rocprofv3 reports KB).  The guide's x2 correction applies to wide
-    (16 B/lane) streaming reads only; these are 4-B-per-lane loads, so the raw sum is reported."""
+def pmc_traffic(vals, corrected=True):
+    """HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (rocprofv3 reports KB).  Calibrated on this hardware with streams of known
+    size (tools/fetch_calib.hip, profiles/r05/fetch_calibration.txt): FETCH_SIZE reports HALF the bytes of a data stream at every
+    access width the step kernels use — 4, 8 and 16 bytes per lane, and the Ant's 192-byte record pattern — i.e. MI355X_MICROARCH.md's
+    gfx950 correction (x 2) applies to them too; WRITE_SIZE is exact; INSTRUCTION fetch is counted in full (128 KiB of straight-line
+    code: 8.07 x its size per launch — once per XCD).  `corrected`: 2 x FETCH + WRITE, the guide's correction — an upper bound, because
+    the code's share of FETCH (0.4-0.6 MB per launch of these kernels) is doubled with the data; raw: FETCH + WRITE, the lower bound."""
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
-    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return ((2.0 if corrected else 1.0) * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def valu_roofline(vals, kernel_ms, env_steps_per_s, env_id, f64=False):
@@ -435,6 +439,9 @@ def main():
                          "algorithmic_bytes_per_env_step": per_env,
                          "traffic_source": traffic_source,
                          "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                         "traffic_lower": pmc_traffic(live or pmc, corrected=False) if traffic else None,
+                         "traffic_note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts data reads at half their bytes — calibrated for this "
+                                         "kernel's access widths, tools/fetch_calib.hip — but instruction fetch in full: an upper bound); traffic_lower = FETCH_SIZE + WRITE_SIZE",
                          "traffic_fetch_bytes": ((live or pmc).get("FETCH_SIZE", 0.0) * 1024.0) if traffic else None,
                          "traffic_write_bytes": ((live or pmc).get("WRITE_SIZE", 0.0) * 1024.0) if traffic else None,
                          "note": "latency/VALU-bound path (SURVEY 8d): ~0.5 KB of HBM traffic per 20 forward-dynamics evaluations; HBM fraction reported because north_star asks for it"},

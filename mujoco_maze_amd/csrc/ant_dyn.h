@@ -95,10 +95,6 @@ struct AntDims {
   static constexpr int REC = (REC_T + 2 + 15) / 16 * 16;
 };
 MZ_HD int hub2dof(int h) { return h < 6 ? h : h + 8; }
-// position of root dof k (0..5) / of a movable block's slide (14, 15) in the dense copy Md of the mass matrix, which is kept in the
-// row solver's position order (rows::dof2pos, ant_newton_rows.h): the root's dofs sit on lanes 2 3 | 6 7 | 10 11 of the 16-lane row
-MZ_HD int md_root_pos(int k) { return k < 6 ? 4 * (k >> 1) + 2 + (k & 1) : k; }
-
 // ------------------------------------------------------------------ scratch (LDS) per env
 template <int NH>
 struct Arrow {        // symmetric matrix with the ant's sparsity
@@ -150,6 +146,9 @@ struct alignas(16) AntScratchT {
   uint32_t platmask[MZ_MAX_GRID + 4]; // elevated mazes: bit j of word i: the cell carries a platform (every cell but the chasms)
   int status, iters;
   int ncon_true;  // contacts as MuJoCo counts them (s.ncon counts merged entries of the block's enumerators once: con_enum_item MERGE)
+  // quad forward pass, NB = 1: the block's own enumerators are re-run only when the block has moved (ant_forward_rows.h).  bkey[0..3] =
+  // bits of its slides (hi, lo) at the enumeration whose results sit in the staging block and in cnt[0 .. NMOV); bkey[4] != 0: valid
+  int bkey[5];
   // ================= part 2: the lane-group formulation only (8-lane groups, two and more blocks, the ball, the host emulation) and
   // the instrumented builds
   alignas(16) float legacy_begin[4];  // (marks the end of the prefix)
@@ -159,8 +158,6 @@ struct alignas(16) AntScratchT {
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
   float fbody[13][6], bias[D::NV], Iall[10];  // per-body inertial + velocity-product force (spatial, at c)
   alignas(16) Arrow<D::NH> M, H;
-  // M once more as dense rows in the row solver's position order (ant_solve_rows: the row solver on the lane-group forward pass)
-  alignas(16) float Md[NB <= 1 ? 16 : 1][16];
   ArrowFactor<D::NH> F;
   float search[D::NV], Ms[D::NV];
   float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3];
@@ -423,16 +420,6 @@ MZ_HD void crb_leg_item(const AntDev& K, AntScratchT<NB>& s, int l) {
       s.M.rl[l][0][3 + k] = dot3f(ax, Fh);
       s.M.rl[l][1][3 + k] = dot3f(ax, Fa);
     }
-    if constexpr (NB <= 1) {  // dense rows of the two leg dofs, and their columns in the root rows — in the row solver's POSITION order
-      const int ph = 4 * l, pa = 4 * l + 1;  // (rows::pos2dof, ant_newton_rows.h: leg l's hinges sit on lanes 4l, 4l + 1 of the row)
-      s.Md[ph][ph] = s.M.ll[l][0]; s.Md[ph][pa] = s.M.ll[l][1]; s.Md[pa][ph] = s.M.ll[l][1]; s.Md[pa][pa] = s.M.ll[l][2];
-      for (int k = 0; k < 6; k++) {
-        const float vh = s.M.rl[l][0][k], va = s.M.rl[l][1][k];
-        const int pk = md_root_pos(k);
-        s.Md[ph][pk] = vh; s.Md[pk][ph] = vh;
-        s.Md[pa][pk] = va; s.Md[pk][pa] = va;
-      }
-    }
     for (int k = 6; k < NH; k++) { s.M.rl[l][0][k] = 0.f; s.M.rl[l][1][k] = 0.f; }  // blocks are separate trees
 }
 
@@ -492,7 +479,6 @@ MZ_HD void crb_root_item(const AntDev& K, AntScratchT<NB>& s, int e) {
       }
     }
     s.M.rr[i][j] = val; s.M.rr[j][i] = val;
-    if constexpr (NB <= 1) { s.Md[md_root_pos(i)][md_root_pos(j)] = val; s.Md[md_root_pos(j)][md_root_pos(i)] = val; }
 }
 
 // Recursive Newton-Euler, outward half, one body per lane: body b = 0 torso, 1 + 3l + k (k = 0 welded leg, 1 aux, 2 ankle).
@@ -1740,9 +1726,9 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
 //   P3  hub mass-matrix entries (21 + ..) | bias / smooth force per dof (NV)
 //   P4  2x2 leg inverses of M (4) | contact Jacobian rows (3 ncon) | joint-limit rows (8)
 //   P5  Schur entries + reduced rhs    P6  hub Cholesky (1 lane)    P7  back-substitution -> qacc_smooth
-// The plain ant on the device differs: contacts are enumerated once (P1 con_enum_item stages them, P2 con_map_item assigns the
-// slots), there is no torso-level wall broad phase, and P4 onwards is the row solver of ant_newton_rows.h (which reads M from
-// the dense copy Md and solves for qacc_smooth only where it is needed).
+// On the device at >= 16 lanes per env contacts are enumerated once (P1 con_enum_item stages them, P2 con_map_item assigns the
+// slots).  The plain ant and the ant with one two-slide block do not come here at all at those widths: their whole evaluation is
+// ant_forward_rows (ant_forward_rows.h) + the row solver of ant_newton_rows.h.
 template <int NB, class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   using D = AntDims<NB>;
@@ -1760,7 +1746,6 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   // single-pass contact enumeration (con_enum_item) on the device: the narrow phase runs ONCE per evaluation, so count and
   // geometry cannot disagree; only an env whose enumerator overflows its staging re-enumerates (con_fill_item)
   constexpr bool one_pass = C::row_solver;
-  constexpr bool rows = NB <= 1 && C::row_solver;  // the DPP-row Newton solver (ant_newton_rows.h)
   MZ_FOR_AT(b, ANT_NBODY, 0) inertia_item<NB>(K, s, b);
   if constexpr (one_pass) { MZ_FOR_AT(e, NG, ANT_NBODY) con_enum_item<NB>(K, s, e); }
   else { MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e); }
@@ -1781,22 +1766,11 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   cx.tick(s, 2);
   MZ_FOR_AT(e, NROOT, 0) crb_root_item<NB>(K, s, e);
   MZ_FOR_AT(i, NV, NROOT) bias_dof_item<NB>(K, s, i);
-  if (!first && !rows) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7 (lane-group solver: shifted start)
+  if (!first) { MZ_FOR(i, NV) s.warm[i] -= s.qas[i]; }  // previous qacc_smooth: still intact until P7 (shifted start)
   cx.sync();
   cx.tick(s, 3);
-  if constexpr (rows) {
-    // plain ant (and the ant with ONE movable block: 16 dofs, still one DPP row) on the device: constraint rows, then the register-resident solver of ant_newton_rows.h, which also
-    // computes qacc_smooth = M^-1 qfrc_smooth with its row elimination (no Schur / Cholesky phases) and builds the joint-limit
-    // rows on their own dof lanes — same mathematics
-    // (one movable block: the rows of the block's own contacts — the first nblkcon slots — are built inside the solver, by the
-    // lanes that own them: ant_newton_rows.h block_rows_direct)
-    const int nb0 = NB == 1 ? s.nblkcon : 0;
-    MZ_FOR_AT(item, 3 * (s.ncon - nb0), 0) con_row_item<NB>(K, s, 3 * nb0 + item);
-    cx.sync();
-    cx.tick(s, 11);
-    ant_solve_rows(cx, K, s, first);
-  } else {
-    // everything else (movable blocks, 8-lane groups, the host emulation): the lane-group formulation
+  {
+    // the lane-group formulation (two and more movable bodies, 8-lane groups, the host emulation)
     MZ_FOR_AT(l, 4, 0) factor_leg_item<NH>(s.M, s.F, l);
     MZ_FOR_AT(item, 3 * s.ncon, 4) con_row_item<NB>(K, s, item);
     MZ_FOR_AT(j, 8, 4 + 3 * s.ncon) limit_item<NB>(K, s, j);
@@ -1984,16 +1958,15 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 template <int NB, class C>
 MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
   MZ_FOR(i, AntDims<NB>::NLO) s.qlo[i] = 0.f;  // the state that enters a step is fp32: no low-order parts yet
+  MZ_FOR(one, 1) s.bkey[4] = 0;                  // (LDS does not survive the launch: nothing is staged yet)
   constexpr bool quad = NB <= 1 && C::row_solver;  // the quad forward pass keeps M in registers — and its kernels do not even allocate part 2 of the scratch block
   if constexpr (!quad) {
-  if constexpr (NB <= 1) { MZ_FOR(i, 256) s.Md[i >> 4][i & 15] = (NB == 1 && (i == 14 * 17 || i == 15 * 17)) ? K.block_mass : 0.f; }  // entries between different legs stay zero; a block's slides: its mass
   cx.sync();
   MZ_FOR(e, 9) {  // linear block of the root's mass matrix: total mass x identity (summed in body order, as the composite inertia is)
     float m = 0.f;
     for (int b = 0; b < ANT_NBODY; b++) m += K.mass[body_class(b)];
     const int i = e / 3, j = e - 3 * i;
     s.M.rr[i][j] = i == j ? m : 0.f;
-    if constexpr (NB <= 1) s.Md[md_root_pos(i)][md_root_pos(j)] = i == j ? m : 0.f;
   }
   }
   MZ_FOR(i, MZ_MAX_GRID) {

@@ -337,8 +337,26 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx, con
   bool bover = false;
   if constexpr (NB == 1) {
     cx.sync();
-    MZ_FOR(e, D::NMOV) con_enum_item<NB, true>(K, s, e);
-    cx.sync();
+    // Round 5: enumerate only when the block has MOVED since the enumeration whose results are still staged.  A block nobody touches
+    // is at rest to the bit (no force along its slides: zero acceleration, zero velocity), which is most envs at most times — and its
+    // eleven float64 enumerators were 14 % of a wave (24 % of the slow ones: profiles/r04/tail_phases_AntPush-v0_2048.txt), re-run
+    // for each of the step's 20 evaluations.  What they stage — kind, normal, distance, multiplicity of each entry; block_rows_direct
+    // reads nothing else — is a function of the block's position and the maze alone; the rows' velocity terms are rebuilt from the
+    // staged geometry at every evaluation as before.  An env that took the lane-group fall-back (its staging was overwritten) or whose
+    // enumeration overflowed re-enumerates.
+#ifndef MZ_EXP_NOBLOCKCACHE
+    const int k0 = __float_as_int(s.qpos[15]), k1 = __float_as_int(s.qpos[16]), k2 = __float_as_int(s.qlo[2]), k3 = __float_as_int(s.qlo[3]);
+    const bool staged = s.bkey[4] != 0 && s.bkey[0] == k0 && s.bkey[1] == k1 && s.bkey[2] == k2 && s.bkey[3] == k3;
+#else
+    const int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    const bool staged = false;
+#endif
+    if (cx.any(!staged)) {
+      cx.sync();  // (every lane has read the key)
+      if (!staged) { MZ_FOR(e, D::NMOV) con_enum_item<NB, true>(K, s, e); }
+      cx.sync();
+      if (!staged && cx.l == 0) { s.bkey[0] = k0; s.bkey[1] = k1; s.bkey[2] = k2; s.bkey[3] = k3; s.bkey[4] = s.con_over == 0; }
+    }
     int mine = 0, before = 0;
 #pragma unroll
     for (int e = 0; e < D::NMOV; e++) {
@@ -491,7 +509,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx, con
     // contact code of ant_dyn.h reads, and let the envs concerned enumerate the two-pass way.
     if (isgeom && j < 3) { const int b = 3 * l + (j == 2 ? 0 : j + 1); for (int k = 0; k < 3; k++) { s.com[b][k] = com[k]; s.w[b][k] = w[k]; } }
     if (j == 0) { for (int k = 0; k < 3; k++) s.Sh[l][k] = ShL[k]; for (int k = 0; k < 6; k++) s.Sa[l][k] = Sa[k]; }
-    if (p == 0) { for (int k = 0; k < 9; k++) s.R0[k] = R0[k]; for (int k = 0; k < 3; k++) s.zw[k] = zw[k]; s.cz = cz; s.nearwall = 1; s.con_over = 1; }
+    if (p == 0) { for (int k = 0; k < 9; k++) s.R0[k] = R0[k]; for (int k = 0; k < 3; k++) s.zw[k] = zw[k]; s.cz = cz; s.nearwall = 1; s.con_over = 1; s.bkey[4] = 0; }
     cx.sync();
     if (over) {
       constexpr int NG = D::NGEOM;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
   constexpr size_t SB = ant_scratch_bytes<NB, G, PROF>(), EB = ant_env_lds_bytes<NB, G, PROF>();  // scratch block | I/O staging, per env
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
+  cx.mfma = WPS == 2;  // two waves per SIMD: the Hessian fold goes to the matrix cores (ant_newton_rows.h)
   if constexpr (NB <= 1 && G >= 16) ant_lane_consts(K, cx);  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
   const int slot = threadIdx.x / G;
   // XCD-aware block of envs (mz_device.h xcd_block; round 4): the workgroups of one XCD take a contiguous range of envs, so the

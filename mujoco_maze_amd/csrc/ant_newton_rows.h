@@ -144,10 +144,10 @@ __device__ __forceinline__ void fold_t(const float (&cg)[8], float j0, float j1,
 // gradient part alone (the refinement step of ant_solve_rows_core): t = g . j with g = three registers of the owner lane P
 template <int P>
 __device__ __forceinline__ float fold_g(float g0, float g1, float g2, float j0, float j1, float j2) {
-  float t;
-  asm("s_nop 1\n\t" MZ_FA_MUL(0, c0, j0) MZ_FA_FMA(0, c1, j1) MZ_FA_FMA(0, c2, j2)
-      : "=&v"(t) : [c0] "v"(g0), [c1] "v"(g1), [c2] "v"(g2), [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [p] "n"(P));
-  return t;
+  float a0, a1, a2;  // three independent products (a dependent fmac_dpp chain would read its accumulator inside the DPP hazard window)
+  asm("s_nop 1\n\t" MZ_FA_MUL(0, c0, j0) MZ_FA_MUL(1, c1, j1) MZ_FA_MUL(2, c2, j2)
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2) : [c0] "v"(g0), [c1] "v"(g1), [c2] "v"(g2), [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [p] "n"(P));
+  return (a0 + a1) + a2;
 }
 #define MZ_FH(k, j, t) "v_fmac_f32_dpp %" #k ", %[" #j "], %[" #t "] row_newbcast:" #k MZ_DPP_TAIL
 #define MZ_FH14(j, t) MZ_FH(0, j, t) MZ_FH(1, j, t) MZ_FH(2, j, t) MZ_FH(3, j, t) MZ_FH(4, j, t) MZ_FH(5, j, t) MZ_FH(6, j, t) MZ_FH(7, j, t) \
@@ -165,6 +165,53 @@ __device__ __forceinline__ void fold_h(float (&H)[16], float j0, float j1, float
       : "+v"(H[0]), "+v"(H[1]), "+v"(H[2]), "+v"(H[3]), "+v"(H[4]), "+v"(H[5]), "+v"(H[6]), "+v"(H[7]), "+v"(H[8]), "+v"(H[9]), "+v"(H[10]),
         "+v"(H[11]), "+v"(H[12]), "+v"(H[13]), "+v"(H[14]), "+v"(H[15])
       : MZ_FH_IN);
+}
+
+// ---- the Hessian update on the matrix cores (round 5).  `v_mfma_f32_16x16x1_4b_f32` is FOUR independent 16 x 16 rank-1 updates,
+// D_b += A_b (x) B_b, block b = lanes 16 b .. 16 b + 15 of the wave — exactly the solver's layout: the wave's four 16-lane rows (four
+// envs at 16 lanes per env; mirrored rows of one env at 32 / 64), lane 16 b + i = position i.  With A = (W j)_a and B = j_a of a contact
+// slot (what fold_t leaves in every lane) one instruction is  H_b[i][k] += t_a[i] j_a[k]  for all four rows at once: three per slot
+// where fold_h spends 3 x 16 fused DPP multiply-adds — on another pipe, next to which the vector ALU goes on with the next slot's
+// fold_t.  The accumulator comes back in the MFMA's own layout — register 4 b + v of lane 16 g + j = D_b[4 g + v][j] (probed:
+// tools/mfma_fold_bench.hip) — i.e., H_b being symmetric once a slot's three rows are in, lane 16 g + j holds H_b[j][4 g .. 4 g + 3]:
+// a 4 x 4 transpose of register groups across the wave's four rows (8 v_permlane32_swap + 8 v_permlane16_swap) puts row j of block
+// b on lane 16 b + j, where the elimination wants it.  Measured in isolation (profiles/r05/mfma_fold_bench.txt, one wave per SIMD,
+// fold_t included): 0.97 / 0.81 / 0.75 / 0.73 of the DPP fold's cycles at 2 / 4 / 6 / 8 slots.
+// Hazard: fold_t is inline asm — the compiler's hazard recognizer does not see its VALU writes in front of the MFMA that reads them
+// (the benchmark's first version read stale operands, erratically); `mfma_operands_ready` puts the wait states there by hand.
+typedef float v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void mfma_operands_ready(float& t0, float& t1, float& t2) { asm("s_nop 3" : "+v"(t0), "+v"(t1), "+v"(t2)); }
+__device__ __forceinline__ void fold_h_mfma(v16f& acc, float j0, float j1, float j2, float t0, float t1, float t2) {
+  mfma_operands_ready(t0, t1, t2);
+  acc = __builtin_amdgcn_mfma_f32_16x16x1f32(t0, j0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x1f32(t1, j1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x1f32(t2, j2, acc, 0, 0, 0);
+}
+// accumulator (MFMA layout) -> this lane's row: out[4 g + v] = H_b[row of this lane][4 g + v]
+__device__ __forceinline__ void mfma_rows(const v16f& acc, float (&out)[16]) {
+  float G[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; b++)
+#pragma unroll
+    for (int v = 0; v < 4; v++) G[b][v] = acc[4 * b + v];
+#pragma unroll
+  for (int v = 0; v < 4; v++) {  // halves of the wave: register groups (0, 2) and (1, 3) change places between lanes 0-31 and 32-63
+    auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_int(G[0][v]), __float_as_int(G[2][v]), false, false);
+    G[0][v] = __int_as_float(r0[0]); G[2][v] = __int_as_float(r0[1]);
+    auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_int(G[1][v]), __float_as_int(G[3][v]), false, false);
+    G[1][v] = __int_as_float(r1[0]); G[3][v] = __int_as_float(r1[1]);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; v++) {  // 16-lane rows inside each half: groups (0, 1) and (2, 3)
+    auto r0 = __builtin_amdgcn_permlane16_swap(__float_as_int(G[0][v]), __float_as_int(G[1][v]), false, false);
+    G[0][v] = __int_as_float(r0[0]); G[1][v] = __int_as_float(r0[1]);
+    auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_int(G[2][v]), __float_as_int(G[3][v]), false, false);
+    G[2][v] = __int_as_float(r1[0]); G[3][v] = __int_as_float(r1[1]);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int v = 0; v < 4; v++) out[4 * g + v] = G[g][v];
 }
 
 // one Gauss-Jordan pivot P on the row-distributed system (Hrow | b): every other row gets rid of column P.
@@ -350,7 +397,7 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
   (void)sizeof(D);
 }
 
-// The solve.  In: s.Md (dense rows of M), s.qfs, s.warm (first evaluation of a step: MuJoCo's qacc_warmstart; later: the previous
+// The solve.  In: `Mrow` / `qfs` (below), s.warm (first evaluation of a step: MuJoCo's qacc_warmstart; later: the previous
 // evaluation's solution), contacts (s.cJ, s.caref, s.cD, s.cleg, s.ncon, s.nblkcon); the joint-limit rows of the robot's hinges
 // are built here from s.qpos / s.qvel.  Out: s.qas = M^-1 qfs (where needed), s.qacc, s.iters, status bits.  Requires G >= 16.
 //
@@ -362,7 +409,8 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
 // sums, and the line search adds its terms the same way.  Twenty contacts of the block thus cost five group sums per
 // iteration instead of twenty folds into sixteen Hessian rows.
 // `Mrow` = row r of M in position order and `qfs` = entry r of qfrc_smooth, in registers (the plain ant's forward pass builds them
-// there: ant_forward_rows.h; ant_solve_rows below reads them from the LDS copies the lane-group forward pass of ant_dyn.h writes).
+// there: ant_forward_rows.h — the only caller since round 5; the wrapper that fed this solver from LDS copies written by the
+// lane-group forward pass, and the WR = false paths it took, are history).
 //
 // WR ("wrench records", the plain ant's forward pass of ant_forward_rows.h): a contact arrives as the 24-float record its geom's
 // lane wrote into s.cJ[c] — three wrenches sr [r x f_a; f_a] about the torso origin (normal, mu t1, mu t2), the three reference
@@ -396,6 +444,13 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
   // block-own contacts per lane.  WR (the quad forward pass): the enumerators merge the identical rows of a face's contact points
   // (con_enum_item MERGE: a block resting on the floor against two walls is 3 entries instead of 12), one per lane of the group
   // holds them; more than G of them: flagged, the surplus dropped
+  // Round 5 (WR): the block's entries live on the 16 lanes of a ROW — lane l of every row of the group owns entry l, every row holds
+  // the same ones and arrives at the same bits — so their sums are 4-step row butterflies like everything else in the solver (the
+  // 32-lane group sums cost a cross-row step, two v_readlane and a select each: seven per iteration plus two per line-search step), and
+  // the line search's two block sums ride inside the robot contacts' (one butterfly for both).  Sixteen merged entries are ample: the
+  // floor is one (four corners, one row set), a wall or platform face one each, a slide limit one — eight at the very most; more
+  // flags CONTACT_OVERFLOW.  (A second entry per lane, tried: 55 more accumulation registers and spills — slower than the group sums.)
+  constexpr int BW = WR ? 16 : G;                 // lanes the block's entries are dealt over
   constexpr int MB = NB ? (WR ? 1 : (D::NC + G - 1) / G) : 0;
   constexpr int MA = NB ? 2 : 1;                   // robot contacts per lane of the row (16 MA in all; an ant on its back next to the block: > 16)
 #ifdef MZ_EXP_NOREFINE
@@ -409,7 +464,8 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
   const int nB = NB ? s.nblkcon : 0;             // block-own contacts: slots [0, nB)
   int nA = s.ncon - nB;                          // robot contacts: slots [nB, ncon), owned by the lanes 0 .. nA - 1 of the row
   if (nA > 16 * MA) { nA = 16 * MA; if (cx.l == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
-  if (NB && MB * G < nB && cx.l == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW;  // block contacts without an owner lane (robot slots still start at nB)
+  if (NB && MB * BW < nB && cx.l == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW;  // block contacts without an owner lane (robot slots still start at nB)
+  auto bsum = [&](float x) { if constexpr (WR) return rsum(x); else return cx.gsum(x); };
   const int ncon = nA;
   const bool any2 = MA > 1 && cx.any(nA > 16);   // some env of the wave uses the second contact slot of its lanes (wave-uniform: the slot's code is skipped otherwise)
   bool iscon[MA];                                // this lane owns robot contact r (+ 16: second slot)
@@ -493,7 +549,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
   if constexpr (NB == 1) {
 #pragma unroll
     for (int m = 0; m < MB; m++) {
-      const int c = cx.l + m * G;
+      const int c = (WR ? (cx.l & 15) : cx.l) + m * BW;
       const bool on = c < nB;
       bD[m] = 0.f;
 #pragma unroll
@@ -658,7 +714,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
         cwb += ceval(bD[m], bw[m][0] - bar[m][0], bw[m][1] - bar[m][1], bw[m][2] - bar[m][2]);
         csb += ceval(bD[m], bs[m][0] - bar[m][0], bs[m][1] - bar[m][1], bs[m][2] - bar[m][2]);
       }
-      cw += cx.gsum(cwb); cs += cx.gsum(csb);
+      cw += bsum(cwb); cs += bsum(csb);
     }
     qacc = cw < cs ? warm : qas;
   }
@@ -720,14 +776,37 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
           else bh11 += t0 * j0 + t1 * j1 + t2 * j2;
         }
       }
-      bg0 = cx.gsum(bg0); bg1 = cx.gsum(bg1); bga0 = cx.gsum(bga0); bga1 = cx.gsum(bga1);
-      bh00 = cx.gsum(bh00); bh01 = cx.gsum(bh01); bh11 = cx.gsum(bh11);
+      bg0 = bsum(bg0); bg1 = bsum(bg1); bga0 = bsum(bga0); bga1 = bsum(bga1);
+      bh00 = bsum(bh00); bh01 = bsum(bh01); bh11 = bsum(bh11);
     }
     // ---- row r of H = M + sum_c Jc^T Wc Jc + limit curvature; gradient entry r
     float Hrow[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
     float g = Mx, ga = fabsf(Mx);
+    // Where the matrix cores take the fold (cx.mfma: the two-waves-per-SIMD instantiation, ant_kernels.hip): measured on the whole
+    // kernel (A / B libraries, AntUMaze-v0), the MFMA fold is 1.4 % SLOWER with one wave per SIMD (4096 envs: 0.2804 -> 0.2846 ms — the
+    // dependent MFMA chain, its drain and the accumulator's way back through 16 more accumulation registers cost what the 42-instruction
+    // DPP fold of the usual four slots costs) and 2 % FASTER with two (8192 envs: 0.3839 -> 0.3765 ms — the second wave's vector
+    // instructions fill the matrix pipe's latency).  The constant folds after inlining: each instantiation carries one of the two.
+    if (cx.mfma) {
+     if (cx.any(ncon > 0)) {  // (wave-uniform) the contacts' J^T W J through the matrix cores (fold_h_mfma above)
+      v16f hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      each_contact([&](auto Cc) {
+        constexpr int C = decltype(Cc)::value;
+        float t, t0, t1, t2;
+        float jc[3];
+        own_col(Cc, jc);
+        fold_t<(C & 15)>(mycg[C / 16], jc[0], jc[1], jc[2], t, t0, t1, t2);
+        g += t; ga += fabsf(t);
+        fold_h_mfma(hacc, jc[0], jc[1], jc[2], t0, t1, t2);
+      });
+      float hc[16];
+      mfma_rows(hacc, hc);
+#pragma unroll
+      for (int k = 0; k < NR; k++) Hrow[k] += hc[k];
+     }
+    } else
     each_contact([&](auto Cc) {
       constexpr int C = decltype(Cc)::value;
       {  // (no per-row guard `C < ncon`, as in jdot3)
@@ -800,8 +879,10 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
             rr = x0 - x2; vv = v0 - v2; if (rr < 0.f) { d1 += Dm * rr * vv; d2 += Dm * vv * vv; }
           }
         MZ_IF_OWNER(lsign != 0.f) { const float rr = ljar + alpha * ljv; if (rr < 0.f) { d1 += lD * rr * ljv; d2 += lD * ljv * ljv; } }
-        d1 = rsum(d1) + p1 + alpha * p2;
-        d2 = rsum(d2) + p2;
+        if constexpr (NB != 1 || !WR) {
+          d1 = rsum(d1) + p1 + alpha * p2;
+          d2 = rsum(d2) + p2;
+        }
         if constexpr (NB == 1) {
           float e1 = 0.f, e2 = 0.f;
 #pragma unroll
@@ -814,7 +895,8 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
             rr = x0 + x2; vv = y0 + y2; if (rr < 0.f) { e1 += Dm * rr * vv; e2 += Dm * vv * vv; }
             rr = x0 - x2; vv = y0 - y2; if (rr < 0.f) { e1 += Dm * rr * vv; e2 += Dm * vv * vv; }
           }
-          d1 += cx.gsum(e1); d2 += cx.gsum(e2);
+          if constexpr (WR) { d1 = rsum(d1 + e1) + p1 + alpha * p2; d2 = rsum(d2 + e2) + p2; }
+          else { d1 += cx.gsum(e1); d2 += cx.gsum(e2); }
         }
         if (d2 == prev_d2) break;  // same slope as at the previous iterate: same linear piece, alpha is its root
         prev_d2 = d2;
@@ -886,7 +968,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
             c0 += bj[m][0][0] * g0 + bj[m][1][0] * g1 + bj[m][2][0] * gg2;
             c1 += bj[m][0][1] * g0 + bj[m][1][1] * g1 + bj[m][2][1] * gg2;
           }
-          c0 = cx.gsum(c0); c1 = cx.gsum(c1);
+          c0 = bsum(c0); c1 = bsum(c1);
           if (r == 14) g2 += c0;
           if (r == 15) g2 += c1;
         }
@@ -915,18 +997,4 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
   cx.sync();
   cx.tick(s, 8);
   return qacc;  // this lane's entry (position order; 0 on lanes without a dof)
-}
-
-// The solve on the LDS copies of M and qfrc_smooth (s.Md: dense rows in POSITION order, written by crb_leg_item / crb_root_item /
-// ant_fill_tables of ant_dyn.h; s.qfs in dof order): the ant with one movable block, and the fall-back forward pass.
-template <int NB, int G, bool PROF>
-__device__ __forceinline__ void ant_solve_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare) {
-  constexpr int NR = 14 + 2 * NB;
-  const int r = cx.l & 15;
-  float Mrow[NR];
-#pragma unroll
-  for (int k = 0; k < NR; k++) Mrow[k] = s.Md[r][k];  // spare rows are zero
-  const float qfs = r < NR ? s.qfs[rows::pos2dof(r)] : 0.f;
-  const float none[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  ant_solve_rows_core<NB, G, PROF, false>(cx, K, s, compare, Mrow, qfs, none);
 }

@@ -32,6 +32,7 @@ struct DevCtx {
   static constexpr int NLC = 14;
   int l;
   float lc[NLC] = {};  // per-lane constants of the plain ant's quad layout (ant_forward_rows.h ant_lane_consts); unused elsewhere
+  bool mfma = false;   // the row solver's Hessian fold on the matrix cores (ant_newton_rows.h fold_h_mfma): set by the kernel, a compile-time constant after inlining
   // phase timer (PROF builds only): lane 0 of the group accumulates shader cycles since the previous tick
   template <class S>
   __device__ __forceinline__ void tick(S& s, int id) const {

@@ -35,7 +35,7 @@ struct PlanarDims {
   static constexpr int NOBS = 7 + 3 * NB + 3 * NS;
 };
 
-// developer aid (tools/exp_point.sh): -DMZ_EXP_PROF builds an experiment library whose bare-Point kernel (point_bare.h) times its phases
+// developer aid (tools/exp_build.sh PROF, tools/exp_point_prof.py): -DMZ_EXP_PROF builds an experiment library whose bare-Point kernel (point_bare.h) times its phases
 // with s_memtime (lane 0 of a group; planar_kernels.hip prints one workgroup's totals) — compiled out otherwise
 #if defined(MZ_EXP_PROF) && defined(__HIP_DEVICE_COMPILE__)
 #define MZB_TICK(id) do { if (cx.lane0() == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); s.prof[id] += now_ - s.prof_t0; s.prof_t0 = now_; } } while (0)

@@ -29,7 +29,11 @@ def _f32(st):
     return out
 
 
-BRANCH_ATOL = 5e-5  # device vs the oracle's one-sided limit at a discontinuity of the step map (see _assert_step_parity)
+# device vs the oracle's one-sided limit at a discontinuity of the step map (see _assert_step_parity): the same 1e-5 as everywhere
+# else.  (Round 4 needed 5e-5 here; it was not the discontinuities — MZ_PARITY_LOG showed "branch" envs 1.4e-5 .. 3.7e-5 off on BOTH
+# sides: stiff-maze envs whose accepted Newton unit step carried the fp32 elimination's error.  With the refinement step of round 5
+# every env that takes this route is a real branch flip, 1e-2 .. 1e-1 off the other branch and <= 1.3e-6 off its own.)
+BRANCH_ATOL = 1e-5
 
 
 def _tie_mixture(dev, a, seen, branch_atol):
@@ -58,7 +62,7 @@ def _log_branch(kind, cm, err, one_sided):
             f.write(f"{kind} robot {cm.c.robot} nblock {cm.c.nblock} elevated {cm.c.elevated} err {err:.3e} one_sided {one_sided:.3e} test {os.environ.get('PYTEST_CURRENT_TEST', '')}\n")
 
 
-def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, atol=ATOL, max_outlier_frac=0.002, hard_atol=None, dev_out=None,
+def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, atol=ATOL, max_outlier_frac=0.002, dev_out=None,
                         branch_atol=BRANCH_ATOL, ref_done=None):
     """Per-DoF parity after one env.step: EVERY env is inside |dev - oracle| <= atol + 1e-5 |oracle| on qpos and qvel, or
     sits on a discontinuity of the step map AND agrees with the float64 oracle's value on the device's side of it.
@@ -80,8 +84,8 @@ def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, a
       3. the one case without a branch of the oracle to compare with is an exact tie that every RK4 stage decides anew
          (_tie_mixture): the device must then lie on the segment between two outcomes of the oracle.
     `max_outlier_frac` caps how many envs may take that route (<= 2x what was measured: profiles/r02/parity.md).
-    `hard_atol` (kept for the Fall mazes' first steps only, [ASSUME-14]): an outlier inside this looser bound is accepted as
-    round-off without the proof.  Returns the mask of the envs inside the plain tolerance."""
+    There is no looser bound without the proof (the `hard_atol` of rounds 2-4 is gone).  Returns the mask of the envs inside the
+    plain tolerance."""
     ok = np.all(_close(dev_qpos, ref_state["qpos"], atol=atol), axis=1) & np.all(_close(dev_qvel, ref_state["qvel"], atol=atol), axis=1)
     bad = np.where(~ok)[0]
     n_mixed = 0
@@ -96,9 +100,6 @@ def _assert_step_parity(oracle, cm, start, act, dev_qpos, dev_qvel, ref_state, a
         return max(np.abs(p["qpos"][0] - qpos).max(), np.abs(p["qvel"][0] - qvel).max())
 
     for e in bad:
-        if hard_atol is not None and np.all(_close(dev_qpos[e], ref_state["qpos"][e], atol=hard_atol)) and np.all(_close(dev_qvel[e], ref_state["qvel"][e], atol=hard_atol)):
-            _log_branch("hard_atol", cm, max(np.abs(dev_qvel[e] - ref_state["qvel"][e]).max(), np.abs(dev_qpos[e] - ref_state["qpos"][e]).max()), 0.0)
-            continue
         err = max(np.abs(dev_qvel[e] - ref_state["qvel"][e]).max(), np.abs(dev_qpos[e] - ref_state["qpos"][e]).max())
         base = {k: v[e:e + 1].copy() for k, v in start.items()}
         # walk from the given start towards the device's side, one discontinuity at a time (a block resting on four corners, a foot
@@ -293,9 +294,10 @@ def test_ant_lane_group_widths_agree(torch, oracle):
 
 
 def test_ant_two_waves_per_simd_kernel(torch, oracle):
-    """The plain ant's second instantiation (ant_kernels.hip: WPS = 2, held to 256 registers so that two waves share a SIMD; taken
-    beyond 4096 envs, or by option "waves_per_simd") against the oracle and against the one-wave kernel — same source, same
-    arithmetic: the same bits — over a rollout with wall contacts and auto-resets; and a batch large enough to select it by itself."""
+    """The plain ant's second instantiation (ant_kernels.hip: WPS = 2, held to 256 registers so that two waves share a SIMD, its Hessian
+    fold on the matrix cores: v_mfma_f32_16x16x1_4b_f32; taken beyond 4096 envs, or by option "waves_per_simd") against the oracle and
+    against the one-wave kernel — the same step to round-off (the MFMA accumulates in another order) — then a rollout with wall
+    contacts and auto-resets without a flag; and a batch large enough to select it by itself."""
     n = 512
     outs = {}
     for wps in (1, 2):
@@ -309,15 +311,15 @@ def test_ant_two_waves_per_simd_kernel(torch, oracle):
         env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
         obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
         qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
-        _assert_step_parity(oracle, cm, st, act, qpos, qvel, ref_state, max_outlier_frac=0.004)
+        ok = _assert_step_parity(oracle, cm, st, act, qpos, qvel, ref_state, max_outlier_frac=0.004)
+        outs[wps] = (obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done.cpu().numpy().copy(), ok)
         g = torch.Generator(device=env.device).manual_seed(3)
         for _ in range(60):
-            obs, rew, done, info = env.step(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30)
-        outs[wps] = (obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done.cpu().numpy().copy())
+            env.step(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30)
         assert np.all((env.status().cpu().numpy() & 7) == 0)
         env.close()
-    for a, b in zip(outs[1], outs[2]):
-        assert np.array_equal(a, b)
+    both = outs[1][3] & outs[2][3]  # (envs on a discontinuity of the step map may land on either side)
+    assert np.all(_close(outs[1][0][both], outs[2][0][both], atol=3e-6)) and np.array_equal(outs[1][2][both], outs[2][2][both])
     with pytest.raises(Exception):
         env = mm.make("AntUMaze-v0", num_envs=4)
         env.set_option("waves_per_simd", 3)
@@ -748,14 +750,10 @@ def test_ant_fall_maze(torch, oracle, env_id):
             ref = oracle.step(cm, s64, act.astype(np.float64), nthreads=8)
             # at maze scale 2 the ant straddles the seams between platform boxes and walls all the time (as in the scale-2
             # multi-block mazes): more envs sit on a contact-activation discontinuity, each of them proven on the oracle
-            # caps = 2 x the measured share of envs beyond 1e-5 per checkpoint (profiles/r03/fall_outliers.txt, tools/fall_outliers.py:
-            # at most 5 of 1024 — except k = 1, the step in which the block is being expelled from its platform, 4 m in 0.3 s against a
-            # stiff limit row: 18 (Fall) / 32 (MultiFall) of 1024, none of them beyond 4.2e-5)
-            cap = (0.064 if multi else 0.036) if k == 1 else 0.01
-            # Bulk tolerance 1e-5 like everywhere else; the share of envs that may sit between 1e-5 and 2e-5 without the discontinuity
-            # proof (`hard_atol`: a 1 g block on limited slides — limit rows with R from dof_invweight0 = 1 / m = 1000 — next to rows at
-            # solimp .995) is capped by `cap` together with the proven ones; k = 1, the step that expels the block: up to 4.5e-5.
-            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=cap, hard_atol=4.5e-5 if k == 1 else 2e-5,
+            # cap: envs on a contact-activation discontinuity, each proven on the oracle (measured: at most 5 of 1024 per checkpoint)
+            # 1e-5 like everywhere else, the step that expels the block (k = 1) included; no looser bound without the discontinuity proof
+            # (rounds 3-4 held this family to 2e-5 .. 4.5e-5: the same unrefined Newton steps as AntPush's tail, see BRANCH_ATOL)
+            ok = _assert_step_parity(oracle, cm, _f32(st), act, qpos, qvel, s64, max_outlier_frac=0.01,
                                      dev_out=(obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()), ref_done=ref["done"])
             worst.append((np.abs(qvel - s64["qvel"]) / (1.0 + np.abs(s64["qvel"]))).max(1)[ok])
             assert np.all(_close(obs.cpu().numpy()[ok], ref["obs"][ok]))

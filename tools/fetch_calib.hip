@@ -42,6 +42,15 @@ __global__ void record_kernel(const float* __restrict__ src, size_t nrec, float*
   if (acc == 1.2345f) sink[0] = acc;
 }
 
+// instruction fetch: 128 KiB of straight-line code (32768 four-byte VALU instructions), run by 8 / 64 / 1024 one-wave workgroups — what
+// does FETCH_SIZE count per launch for CODE (the step kernels' fixed fetch term: every XCD's L2 fetches the code it executes)?
+template <int TAG>
+__global__ void code_kernel(unsigned* sink) {
+  unsigned x = threadIdx.x;
+  asm volatile(".rept 32768\n\tv_add_u32_e32 %0, 1, %0\n\t.endr" : "+v"(x));
+  if (x == 0xdeadbeefu) sink[0] = x + TAG;
+}
+
 int main() {
   const size_t bytes = (size_t)1 << 30;
   void *buf, *sink;
@@ -59,6 +68,12 @@ int main() {
     hipLaunchKernelGGL(write_kernel<uint4>, grid, blk, 0, 0, (uint4*)buf, bytes / 16, 7u);
   }
   hipDeviceSynchronize();
+  for (int rep = 0; rep < 3; rep++) {  // distinct instantiations = distinct code addresses: every launch fetches code nobody has cached
+    if (rep == 0) { hipLaunchKernelGGL(code_kernel<0>, dim3(8), dim3(64), 0, 0, (unsigned*)sink); hipLaunchKernelGGL(code_kernel<1>, dim3(64), dim3(64), 0, 0, (unsigned*)sink); hipLaunchKernelGGL(code_kernel<2>, dim3(1024), dim3(64), 0, 0, (unsigned*)sink); }
+    if (rep == 1) { hipLaunchKernelGGL(code_kernel<0>, dim3(8), dim3(64), 0, 0, (unsigned*)sink); hipLaunchKernelGGL(code_kernel<1>, dim3(64), dim3(64), 0, 0, (unsigned*)sink); hipLaunchKernelGGL(code_kernel<2>, dim3(1024), dim3(64), 0, 0, (unsigned*)sink); }
+    if (rep == 2) { hipMemset(buf, 2, bytes); hipLaunchKernelGGL(code_kernel<2>, dim3(1024), dim3(64), 0, 0, (unsigned*)sink); }  // after 1 GiB of other traffic
+    hipDeviceSynchronize();
+  }
   printf("fetch_calib: %zu bytes per kernel, 3 repetitions\n", bytes);
   return 0;
 }

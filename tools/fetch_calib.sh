@@ -15,6 +15,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = acc[r["Kernel_Name"].split("(")[0]]
                 d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     for k, d in sorted(acc.items()):
+        if "code_kernel" in k:  # per launch, in dispatch order: counter bytes / 128 KiB of code
+            if c == "FETCH_SIZE":
+                print(f"  {c:10s} {k:45s} per launch, counter bytes / 131072 code bytes: " + " ".join(f"{v * 1024.0 / 131072:.2f}" for _, v in sorted(d.items(), key=lambda kv: int(kv[0]))))
+            continue
         v = sum(d.values()) / len(d) * 1024.0
         nb = known if "record" not in k else known // 192 * 192
         print(f"  {c:10s} {k:45s} {v / nb:6.3f}")

@@ -6,7 +6,7 @@ import torch
 import mujoco_maze_amd as mm
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
-for env_id, n in (("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 2048), ("AntPushMaze-v0", 1024), ("PointUMaze-v0", 4096),
+for env_id, n in (("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 2048), ("AntMultiPush-v0", 1024), ("AntPushMaze-v0", 1024), ("PointUMaze-v0", 4096),
                   ("PointPush-v0", 4096), ("PointBilliard-v0", 4096), ("SwimmerUMaze-v0", 4096), ("ReacherUMaze-v0", 4096),
                   ("AntFall-v0", 2048), ("AntMultiFall-v0", 1024), ("PointFall-v0", 4096), ("AntSmallBilliard-v0", 2048)):
     if ONLY and env_id not in ONLY: continue
@@ -17,7 +17,7 @@ for env_id, n in (("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 
     g = torch.Generator(device=env.device).manual_seed(seed - 3)
     lo = torch.as_tensor(env.action_space.low, device=env.device); hi = torch.as_tensor(env.action_space.high, device=env.device)
     acts = [lo + (hi - lo) * torch.rand((n, env.nu), device=env.device, generator=g) for _ in range(64)]
-    k = steps if not (env_id.startswith("AntPushMaze") or "Fall" in env_id) else steps // 4
+    k = steps if not (env_id.startswith("AntPushMaze") or env_id.startswith("AntMultiPush") or "Fall" in env_id) else steps // 4
     bits = torch.zeros(n, dtype=torch.int32, device=env.device); nonfinite = 0; dones = 0
     t0 = time.perf_counter()
     for i in range(k):
