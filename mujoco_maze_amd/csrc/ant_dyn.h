@@ -1285,23 +1285,28 @@ MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
   if (n > MZ_STAGE) s.con_over = 1;
 }
 
-template <int NB>
+// MERGED: the movable bodies' enumerators (e < NMOV) ran con_enum_item<NB, true> — cnt = merged entries | contacts emitted << 8
+template <int NB, bool MERGED = false>
 MZ_HD void con_map_item(const AntDev& K, AntScratchT<NB>& s, int e) {
   using D = AntDims<NB>;
   constexpr int NC = D::NC, NG = D::NGEOM, MZ_STAGE = MZ_STAGE_OF(NB);
+  auto cnt_of = [&](int g) { return (MERGED && g < D::NMOV) ? (s.cnt[g] & 255) : s.cnt[g]; };
   int off = 0;
-  for (int g = 0; g < e; g++) off += s.cnt[g];
+  for (int g = 0; g < e; g++) off += cnt_of(g);
   if (e == NG - 1) {
-    int tot = off + s.cnt[e];
+    int tot = off + cnt_of(e);
+    int nrep = 0;  // contact points folded into merged entries: what MuJoCo would count on top
+    if constexpr (MERGED) { for (int g = 0; g < D::NMOV; g++) nrep += (s.cnt[g] >> 8) - (s.cnt[g] & 255); }
     if (tot > NC) { tot = NC; s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
     s.ncon = tot;
+    s.ncon_true = tot + nrep;
     s.cbeg[4] = tot;
   }
   const int b = e - D::NMOV;
   if (b == 0) s.nblkcon = off < NC ? off : NC;  // the torso's enumerator follows those of the movable bodies
   if (b > 0 && (b - 1) % 3 == 0) s.cbeg[(b - 1) / 3] = off < NC ? off : NC;
   if (s.con_over) return;  // the env re-enumerates with con_fill_item
-  const int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, n = s.cnt[e];
+  const int cls = b >= 0 ? body_class(b) : -1, leg = b > 0 ? (b - 1) / 3 : -1, n = cnt_of(e);
   for (int i = 0; i < n; i++) {
     const int slot = off + i;
     if (slot < NC) { s.csrc[slot] = MZ_STAGE * e + i; s.cleg[slot] = leg; s.ccls[slot] = cls; }
@@ -1373,7 +1378,10 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
     const int src = s.csrc[c];
     const float* q = src >= 0 ? con_stage<NB>(s, src) : &s.cY[c][0][0];
     float r[3] = {q[0], q[1], q[2]}, n[3] = {q[3], q[4], q[5]}, hint[3], dist = q[6];
-    int code = (int)q[7], kind = code & 15, blk = (code >> 4) & 7, other = code >> 7;
+    // code = kind + 16 blk + 128 other + 2048 (multiplicity - 1): a merged entry of a movable block's own enumerators stands for
+    // `mult` contact points with identical rows (con_enum_item MERGE) — mult times the weight, the same cost function term for term
+    int code = (int)q[7], kind = code & 15, blk = (code >> 4) & 7, other = (code >> 7) & 15;
+    const float mult = (float)((code >> 11) + 1);
     if (src >= 0) {  // staged contact: the hint of a capsule-floor contact is the capsule's axis (geom_contacts), nothing else has one
       const int b = src / MZ_STAGE_OF(NB) - D::NMOV;
       for (int k = 0; k < 3; k++) hint[k] = (kind == 0 && b > 0) ? s.w[b > 0 ? b - 1 : 0][k] : 0.f;
@@ -1454,7 +1462,7 @@ MZ_HD void con_row_item(const AntDev& K, AntScratchT<NB>& s, int item) {
       float tran = (cls >= 0 ? K.bw_tran[cls] : 0.f) + ((kind >= 2 && kind <= 5) ? K.block_bw_tran : 0.f) + (kind == 5 ? K.block_bw_tran : 0.f) +
                    (sball != 0.f ? K.ball_bw_tran : 0.f);
       float R = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
-      s.cD[c] = 1.0f / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
+      s.cD[c] = mult / (2.f * P.mu * P.mu * R);  // [ASSUME-3]
       aref -= P.K * imp * (dist - P.margin);
     }
     for (int k = 0; k < D::NCOL; k++) s.cJ[c][a][k] = J[k];
@@ -1747,19 +1755,28 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   // geometry cannot disagree; only an env whose enumerator overflows its staging re-enumerates (con_fill_item)
   constexpr bool one_pass = C::row_solver;
   MZ_FOR_AT(b, ANT_NBODY, 0) inertia_item<NB>(K, s, b);
-  if constexpr (one_pass) { MZ_FOR_AT(e, NG, ANT_NBODY) con_enum_item<NB>(K, s, e); }
-  else { MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e); }
+  // Round 5: the movable blocks' own enumerators merge the contact points of one face pair into one entry with a multiplicity, as the
+  // one-block ant's quad path does (con_enum_item MERGE): blocks only translate, the points' rows are identical.  Two blocks in a
+  // corner are 7 entries instead of 28 — fewer rows for the solver, and the 40 / 72 slots stop overflowing under an ant lying across
+  // blocks and walls (AntMultiPush soak, round 4: 2 flagged envs per bench sweep; round 5 before this: 8 of 1024 in 2000 steps).
+  constexpr bool merged = one_pass && D::NBLK > 0;
+  if constexpr (one_pass) {
+    MZ_FOR_AT(e, NG, ANT_NBODY) { if (merged && e < D::NMOV) con_enum_item<NB, true>(K, s, e); else con_enum_item<NB, false>(K, s, e); }
+  } else { MZ_FOR_AT(e, NG, ANT_NBODY) con_count_item<NB>(K, s, e); }
   cx.sync();
   cx.tick(s, 1);
   MZ_FOR_AT(l, 4, 0) crb_leg_item<NB>(K, s, l);
   MZ_FOR_AT(k, 10, 4) iall_item<NB>(K, s, k);
   MZ_FOR_AT(b, ANT_NBODY, 14) bias_body_item<NB>(K, s, b);
-  if constexpr (one_pass) { MZ_FOR_AT(e, NG, 14 + ANT_NBODY) con_map_item<NB>(K, s, e); }
+  if constexpr (one_pass) { MZ_FOR_AT(e, NG, 14 + ANT_NBODY) con_map_item<NB, merged>(K, s, e); }
   else { MZ_FOR_AT(e, NG, 14 + ANT_NBODY) con_fill_item<NB>(K, s, e); }
   cx.sync();
   if constexpr (one_pass) {
-    if (s.con_over) {  // some geom found more contacts than its staging holds: this env fills the two-pass way
+    if (s.con_over) {  // some geom found more contacts than its staging holds: this env counts and fills the two-pass way (unmerged)
+      if constexpr (merged) { MZ_FOR(e, NG) con_count_item<NB>(K, s, e); cx.sync(); }
       MZ_FOR(e, NG) con_fill_item<NB>(K, s, e);
+      cx.sync();
+      MZ_FOR(one, 1) s.ncon_true = s.ncon;
       cx.sync();
     }
   }

@@ -254,10 +254,25 @@ __device__ __forceinline__ void ant_lane_consts(const AntDev& K, DevCtx<G, PROF>
 // lanes that own them (block_rows_direct).  A robot geom touching the block is a record like any other, flagged so that the slide
 // lanes see its reaction.
 template <int NB, int G, bool PROF>
-__device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
+__device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step, const AntDev& K, AntScratchT<NB>& s, bool first) {
   static_assert(G >= 16, "one DPP row per env at least");
   static_assert(NB <= 1, "row layout: 14 robot dofs + one block's two slides");
   using namespace rows;
+  // The two-waves-per-SIMD instantiation (cx.mfma; 256 registers in all) re-reads its per-lane constants from the constant block at
+  // every evaluation instead of carrying them through the step: carried, they were what the compiler spilled — 36 registers to
+  // scratch, stored by every wave and re-read per evaluation (PMC, 8192 envs: WRITE_SIZE 14.5 MB per launch against 2.8 MB of
+  // algorithmic writes).  The opaque lane index keeps the loads inside the evaluation (they are loop-invariant otherwise).
+  DevCtx<G, PROF> cx = cx_step;
+#ifdef MZ_EXP_LCRELOAD  // A / B build: the one-wave kernel as well
+  if (true) {
+#else
+  if (cx_step.mfma) {
+#endif
+    int ll = cx_step.l;
+    asm volatile("" : "+v"(ll));
+    cx.l = ll;
+    ant_lane_consts(K, cx);
+  }
   using C = DevCtx<G, PROF>;  // (MZ_FOR)
   using D = AntDims<NB>;
   constexpr int NC = D::NC, NR = 14 + 2 * NB;

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
   DevCtx<G, PROF> cx{(int)threadIdx.x % G};
   cx.mfma = WPS == 2;  // two waves per SIMD: the Hessian fold goes to the matrix cores (ant_newton_rows.h)
-  if constexpr (NB <= 1 && G >= 16) ant_lane_consts(K, cx);  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
+#ifndef MZ_EXP_LCRELOAD
+  if constexpr (NB <= 1 && G >= 16 && WPS != 2) ant_lane_consts(K, cx);  // (WPS = 2: per evaluation, ant_forward_rows)
+#endif  // per-lane constants of the quad layout (ant_forward_rows.h), once per step
   const int slot = threadIdx.x / G;
   // XCD-aware block of envs (mz_device.h xcd_block; round 4): the workgroups of one XCD take a contiguous range of envs, so the
   // cache lines two neighbouring workgroups share — obs rows are 120 B, records 192 B, reward / done a few bytes per workgroup —
@@ -198,7 +200,10 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
 #endif
 // developer aid (tools/isa_one.sh): compile ONE instantiation of the step kernel to look at its ISA / run the DPP hazard check
 // in seconds instead of building all of them:  hipcc ... -DMZ_ISA_ONLY -DMZ_ISA_NB=0 -DMZ_ISA_G=16 -S ant_kernels.hip
-template __global__ void ant_step_kernel<MZ_ISA_NB, MZ_ISA_G, MZ_ISA_PROF>(const AntDev*, int, float*, const float*, float*, float*, uint8_t*, int*, float*, int*, int,
+#ifndef MZ_ISA_WPS
+#define MZ_ISA_WPS 0
+#endif
+template __global__ void ant_step_kernel<MZ_ISA_NB, MZ_ISA_G, MZ_ISA_PROF, MZ_ISA_WPS>(const AntDev*, int, float*, const float*, float*, float*, uint8_t*, int*, float*, int*, int,
                                                                      uint64_t, uint64_t, unsigned long long*, float*, int, float*);
 #else
 template <int NB, int G>
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(64) void ant_forward_kernel(AntDev K, int n, const 
   ant_forward<NB>(cx, K, s, true);
   if (live) {
     for (int i = cx.l; i < D::NV; i += G) qacc[(size_t)env * D::NV + i] = s.qacc[i];
-    if (cx.l == 0 && counts) { counts[2 * env] = (NB <= 1 && G >= 16) ? s.ncon_true : s.ncon; counts[2 * env + 1] = s.iters; }
+    if (cx.l == 0 && counts) { counts[2 * env] = (G >= 16 && (NB <= 1 || AntDims<NB>::NBLK > 0)) ? s.ncon_true : s.ncon; /* paths that merge a block's contact points report MuJoCo's count */ counts[2 * env + 1] = s.iters; }
   }
 }
 

@@ -15,6 +15,7 @@ if [[ $part == *a* ]]; then
     set -- $w
     tools/profile.sh $tag $1 $2 > $out/profile_$1_$2.log 2>&1
     python tools/pmc_summary.py $tag $1 $2 > $out/pmc_summary_$1_$2.log 2>&1
+    rm -rf gpurun_out/prof_${tag}_$1_$2  # the raw rocprofv3 output (tens of MiB per workload): only what pmc_summary.py kept travels back
     [ "$w" != "AntUMaze-v0 4096" ] && python bench.py --no-cpu-baseline --env $1 --envs $2 > $out/bench_line_$1_$2.json 2>/dev/null
   done
   cp -r profiles/$tag $out/profiles_$tag
