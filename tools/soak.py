@@ -6,7 +6,8 @@ import torch
 import mujoco_maze_amd as mm
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
-for env_id, n in (("AntUMaze-v0", 4096), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 2048), ("AntMultiPush-v0", 1024), ("AntPushMaze-v0", 1024), ("PointUMaze-v0", 4096),
+# (AntUMaze at 8192 envs: the two-waves-per-SIMD kernel)
+for env_id, n in (("AntUMaze-v0", 4096), ("AntUMaze-v0", 8192), ("Ant4Rooms-v0", 4096), ("AntPush-v0", 2048), ("AntMultiPush-v0", 1024), ("AntPushMaze-v0", 1024), ("PointUMaze-v0", 4096),
                   ("PointPush-v0", 4096), ("PointBilliard-v0", 4096), ("SwimmerUMaze-v0", 4096), ("ReacherUMaze-v0", 4096),
                   ("AntFall-v0", 2048), ("AntMultiFall-v0", 1024), ("PointFall-v0", 4096), ("AntSmallBilliard-v0", 2048)):
     if ONLY and env_id not in ONLY: continue
