@@ -49,61 +49,8 @@ __device__ __forceinline__ unsigned rsum_u(unsigned x) {  // integer all-reduce 
 __device__ __forceinline__ float sel4(const float (&v)[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ unsigned sum2bit(unsigned w) { return (unsigned)__popc(w & 0x55555555u) + 2u * (unsigned)__popc(w & 0xAAAAAAAAu); }
 
-// bit select: m = all ones -> a, m = 0 -> b.  One v_bfi_b32 — and, unlike `cond ? a : b` on values only one role of lanes
-// needs, nothing the compiler can turn into a divergent branch with the operand's computation sunk into it (it did: the first
-// version of this file ran its role selects as ~60 exec-mask branches per evaluation)
-__device__ __forceinline__ float bsel(int m, float a, float b) { return __int_as_float((__float_as_int(a) & m) | (__float_as_int(b) & ~m)); }
-
 struct GeomHit { float pos[3], n[3], dist; int kind; };  // one staged contact of a geom lane (registers)
 
-// The 24-float record of one contact of a robot geom (ant_solve_rows_core, WR mode): rec[8 a + 0..5] = wrench of row a about the
-// torso origin, sr [r x f_a; f_a] (f_0 = n, f_1 = mu t1, f_2 = mu t2; sr: +1 floor -> geom, -1 geom -> wall / geom -> movable block:
-// the side of the pair the robot is on), rec[8 a + 6] = reference acceleration of row a, rec[7] = D,
-// rec[15] = leg (7: none) | body class << 3 | 64 when the partner is the movable block (its slide lanes then see the reaction).
-// Same arithmetic as con_row_item (ant_dyn.h): the row's velocity J qvel is wrench . (spatial velocity of the touching body) —
-// minus, for the block, the force direction times the block's slide velocities.  kind: 0 floor, 1 wall / platform, 2 block.
-template <int NB>
-__device__ __forceinline__ void contact_record(const AntDev& K, const float* pos, const float* n, float dist, int kind, const float* hint, int cls, int leg,
-                                               const float* vb, const float* vblk, float tran, float* rec) {
-  // the pair's parameters: BOTH sets by scalar loads, then value selects (`const PairDev& P = kind == 0 ? K.floor : K.wall` came out as
-  // an address select followed by dependent vector-memory loads: three round trips to the cache on the contact's critical path)
-  const int mk = -(int)(kind == 0);
-  struct { float margin, mu, K, B; } P = {bsel(mk, K.floor.margin, K.wall.margin), bsel(mk, K.floor.mu, K.wall.mu), bsel(mk, K.floor.K, K.wall.K),
-                                         bsel(mk, K.floor.B, K.wall.B)};
-  float si[7];
-#pragma unroll
-  for (int k = 0; k < 7; k++) si[k] = bsel(mk, K.floor.solimp[k], K.wall.solimp[k]);
-  float t1[3], t2[3];
-  make_tangents(n, hint, t1, t2);
-  const float sr = bsel(mk, 1.f, -1.f);
-  float omi;
-  const float imp = impedance_pair(si, fabsf(dist - P.margin), &omi);
-  if (NB == 1 && kind == 2) tran += K.block_bw_tran;
-  const float Rr = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
-  rec[7] = 1.0f / (2.f * P.mu * P.mu * Rr);  // [ASSUME-3]
-  rec[15] = __int_as_float((leg < 0 ? 7 : leg) | (cls << 3) | ((NB == 1 && kind == 2) ? 64 : 0));
-  rec[23] = 0.f;
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    const float sc = (a == 0 ? 1.f : P.mu) * sr;
-    const float* dir = a == 0 ? n : (a == 1 ? t1 : t2);
-    const float f[3] = {sc * dir[0], sc * dir[1], sc * dir[2]};
-    float m[3];
-    cross3f(m, pos, f);
-    float* w = rec + 8 * a;
-    w[0] = m[0]; w[1] = m[1]; w[2] = m[2]; w[3] = f[0]; w[4] = f[1]; w[5] = f[2];
-    float vel = m[0] * vb[0] + m[1] * vb[1] + m[2] * vb[2] + f[0] * vb[3] + f[1] * vb[4] + f[2] * vb[5];
-    if constexpr (NB == 1) {
-      if (kind == 2) {  // the block moves along its slides: its point velocity enters with the opposite sign
-#pragma unroll
-        for (int sl = 0; sl < 2; sl++) vel -= (K.block_axis[sl] == 0 ? f[0] : (K.block_axis[sl] == 1 ? f[1] : f[2])) * vblk[sl];
-      }
-    }
-    float aref = -P.B * vel;
-    if (a == 0) aref -= P.K * imp * (dist - P.margin);
-    w[6] = aref;
-  }
-}
 // fall-back (an env whose geom overflowed its staging): the record of compact slot c from the geometry con_fill_item left in
 // s.cY[c] and the kinematics the forward pass published to LDS
 template <int NB, class S>
@@ -116,11 +63,8 @@ __device__ __forceinline__ void con_record_item(const AntDev& K, S& s, int c) {
   const float qdh = cls >= 2 ? s.qvel[6 + 2 * lg] : 0.f, qda = cls == 3 ? s.qvel[7 + 2 * lg] : 0.f;
   for (int k = 0; k < 3; k++) { vb[k] = ww[k] + s.zw[k] * qdh + s.Sa[lg][k] * qda; vb[3 + k] = s.qvel[k] + s.Sh[lg][k] * qdh + s.Sa[lg][3 + k] * qda; }
   const float vblk[2] = {NB == 1 ? s.qvel[14] : 0.f, NB == 1 ? s.qvel[14 + (NB == 1 ? 1 : 0)] : 0.f};
-  float rec[24];
-  contact_record<NB>(K, pos, n, dist, kind, hint, cls, leg, vb, vblk, K.bw_tran[cls < 0 ? 0 : cls], rec);
-  float4* dst = reinterpret_cast<float4*>(wr_record(s, c));
-#pragma unroll
-  for (int k = 0; k < 6; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+  contact_raw_store(wr_record(s, c), pos, n, dist, kind, hint, cls, leg, vb, K.bw_tran[cls < 0 ? 0 : cls]);
+  (void)vblk;
 }
 
 // contacts of one robot geom against the floor plane, the movable block (NB = 1) and the maze's cells (walls; in an elevated maze the
@@ -501,20 +445,18 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
   if (!over) {
     if (ncon > NC) { ncon = NC; if (p == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
     if (p == 0) { s.ncon = ncon; s.nblkcon = nblk; s.ncon_true = ncon + nrep; }
-    float vblk[2] = {0.f, 0.f};
-    if constexpr (NB == 1) { vblk[0] = s.qvel[14]; vblk[1] = s.qvel[15]; }
-    // the records of the own contacts (contact_record), straight into the slots their owner lanes read
+    // Round 5: the geom's lane only STAGES its contacts (position, normal, distance, kind, tangent hint, body class / leg, the body's
+    // spatial velocity, the body's contact weight: 18 numbers); the three wrenches, the reference accelerations and D are built by the
+    // lane that OWNS the slot in the solver (contact_record in ant_solve_rows_core), one contact per lane in one pass — a geom with two
+    // or three contacts (a capsule lying on the floor, a foot in a wall corner: the envs a launch waits for) built them one after
+    // the other here (`C records` 72 k against 33 k cycles in the slowest wave of a step, profiles/r05/tail_phases.txt).
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int slot = off + q;
       if (q < nfound && slot < NC) {
         const GeomHit& h = hit[q];
         const float hint[3] = {(h.kind == 0 && j < 3) ? w[0] : 0.f, (h.kind == 0 && j < 3) ? w[1] : 0.f, (h.kind == 0 && j < 3) ? w[2] : 0.f};
-        float rec[24];
-        contact_record<NB>(K, h.pos, h.n, h.dist, h.kind, hint, cls, j == 3 ? -1 : l, vb, vblk, cx.lc[LC_TRAN], rec);
-        float4* dst = reinterpret_cast<float4*>(wr_record(s, slot));
-#pragma unroll
-        for (int k = 0; k < 6; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+        contact_raw_store(wr_record(s, slot), h.pos, h.n, h.dist, h.kind, hint, cls, j == 3 ? -1 : l, vb, cx.lc[LC_TRAN]);
       }
     }
     cx.sync();

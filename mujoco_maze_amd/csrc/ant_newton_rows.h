@@ -325,6 +325,72 @@ __device__ __forceinline__ float ceval(float D, float u0, float u1, float u2) {
   return 0.5f * D * c;
 }
 
+// bit select: m = all ones -> a, m = 0 -> b.  One v_bfi_b32 — and, unlike `cond ? a : b` on values only one role of lanes
+// needs, nothing the compiler can turn into a divergent branch with the operand's computation sunk into it (it did: the first
+// version of this file ran its role selects as ~60 exec-mask branches per evaluation)
+__device__ __forceinline__ float bsel(int m, float a, float b) { return __int_as_float((__float_as_int(a) & m) | (__float_as_int(b) & ~m)); }
+
+// The 24-float record of one contact of a robot geom (ant_solve_rows_core, WR mode): rec[8 a + 0..5] = wrench of row a about the
+// torso origin, sr [r x f_a; f_a] (f_0 = n, f_1 = mu t1, f_2 = mu t2; sr: +1 floor -> geom, -1 geom -> wall / geom -> movable block:
+// the side of the pair the robot is on), rec[8 a + 6] = reference acceleration of row a, rec[7] = D,
+// rec[15] = leg (7: none) | body class << 3 | 64 when the partner is the movable block (its slide lanes then see the reaction).
+// Same arithmetic as con_row_item (ant_dyn.h): the row's velocity J qvel is wrench . (spatial velocity of the touching body) —
+// minus, for the block, the force direction times the block's slide velocities.  kind: 0 floor, 1 wall / platform, 2 block.
+template <int NB>
+__device__ __forceinline__ void contact_record(const AntDev& K, const float* pos, const float* n, float dist, int kind, const float* hint, int cls, int leg,
+                                               const float* vb, const float* vblk, float tran, float* rec) {
+  // the pair's parameters: BOTH sets by scalar loads, then value selects (`const PairDev& P = kind == 0 ? K.floor : K.wall` came out as
+  // an address select followed by dependent vector-memory loads: three round trips to the cache on the contact's critical path)
+  const int mk = -(int)(kind == 0);
+  struct { float margin, mu, K, B; } P = {bsel(mk, K.floor.margin, K.wall.margin), bsel(mk, K.floor.mu, K.wall.mu), bsel(mk, K.floor.K, K.wall.K),
+                                         bsel(mk, K.floor.B, K.wall.B)};
+  float si[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) si[k] = bsel(mk, K.floor.solimp[k], K.wall.solimp[k]);
+  float t1[3], t2[3];
+  make_tangents(n, hint, t1, t2);
+  const float sr = bsel(mk, 1.f, -1.f);
+  float omi;
+  const float imp = impedance_pair(si, fabsf(dist - P.margin), &omi);
+  if (NB == 1 && kind == 2) tran += K.block_bw_tran;
+  const float Rr = fmaxf(1e-15f, omi / imp * (tran + P.mu * P.mu * tran));
+  rec[7] = 1.0f / (2.f * P.mu * P.mu * Rr);  // [ASSUME-3]
+  rec[15] = __int_as_float((leg < 0 ? 7 : leg) | (cls << 3) | ((NB == 1 && kind == 2) ? 64 : 0));
+  rec[23] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float sc = (a == 0 ? 1.f : P.mu) * sr;
+    const float* dir = a == 0 ? n : (a == 1 ? t1 : t2);
+    const float f[3] = {sc * dir[0], sc * dir[1], sc * dir[2]};
+    float m[3];
+    cross3f(m, pos, f);
+    float* w = rec + 8 * a;
+    w[0] = m[0]; w[1] = m[1]; w[2] = m[2]; w[3] = f[0]; w[4] = f[1]; w[5] = f[2];
+    float vel = m[0] * vb[0] + m[1] * vb[1] + m[2] * vb[2] + f[0] * vb[3] + f[1] * vb[4] + f[2] * vb[5];
+    if constexpr (NB == 1) {
+      if (kind == 2) {  // the block moves along its slides: its point velocity enters with the opposite sign
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) vel -= (K.block_axis[sl] == 0 ? f[0] : (K.block_axis[sl] == 1 ? f[1] : f[2])) * vblk[sl];
+      }
+    }
+    float aref = -P.B * vel;
+    if (a == 0) aref -= P.K * imp * (dist - P.margin);
+    w[6] = aref;
+  }
+}
+
+// A staged robot contact (round 5): what the geom's lane knows, for the slot's owner lane to turn into the contact's rows.
+//   q[0..2] position (torso-relative), q[3..5] normal, q[6] distance, q[7] kind | (cls + 1) << 4 | (leg + 1) << 8 as an int,
+//   q[8..10] tangent hint, q[11..16] spatial velocity of the touching body at the torso origin, q[17] the body's contact weight
+__device__ __forceinline__ void contact_raw_store(float* q, const float* pos, const float* n, float dist, int kind, const float* hint, int cls, int leg,
+                                                  const float* vb, float tran) {
+  float4* dst = reinterpret_cast<float4*>(q);
+  dst[0] = make_float4(pos[0], pos[1], pos[2], n[0]);
+  dst[1] = make_float4(n[1], n[2], dist, __int_as_float(kind | ((cls + 1) << 4) | ((leg + 1) << 8)));
+  dst[2] = make_float4(hint[0], hint[1], hint[2], vb[0]);
+  dst[3] = make_float4(vb[1], vb[2], vb[3], vb[4]);
+  dst[4] = make_float4(vb[5], tran, 0.f, 0.f);
+}
 }  // namespace rows
 
 // wrench record of contact slot c (WR mode of ant_solve_rows_core): 24 floats, packed one after the other in the cJ block (for the
@@ -522,10 +588,15 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       }
       cD[m] = 0.f;
       if (m == 1 && !any2) continue;
+      // the slot's staged contact (contact_raw_store) -> its 24-float record, here on the lane that owns it
       const float4* q = reinterpret_cast<const float4*>(wr_record(s, cr[m]));
-      float rec[24];
+      float raw[20];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { const float4 v4 = q[k]; rec[4 * k] = v4.x; rec[4 * k + 1] = v4.y; rec[4 * k + 2] = v4.z; rec[4 * k + 3] = v4.w; }
+      for (int k = 0; k < 5; k++) { const float4 v4 = q[k]; raw[4 * k] = v4.x; raw[4 * k + 1] = v4.y; raw[4 * k + 2] = v4.z; raw[4 * k + 3] = v4.w; }
+      const int rmeta = __float_as_int(raw[7]);
+      const float vblk[2] = {NB == 1 ? s.qvel[14] : 0.f, NB == 1 ? s.qvel[14 + (NB == 1 ? 1 : 0)] : 0.f};
+      float rec[24];
+      contact_record<NB>(K, raw, raw + 3, raw[6], rmeta & 15, raw + 8, ((rmeta >> 4) & 15) - 1, ((rmeta >> 8) & 15) - 1, raw + 11, vblk, raw[17], rec);
       const int on = -(int)iscon[m];
 #pragma unroll
       for (int a = 0; a < 3; a++) {
