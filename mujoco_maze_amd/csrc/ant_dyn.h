@@ -853,6 +853,9 @@ MZ_HD void capsule_box_search(const float* cl, const float* h, float hl, const f
 // sphere / capsule (centre ctr, axis ax = the capsule's from -> to direction, half length hl, radius r; torso-relative) against an
 // axis-aligned box (centre bc torso-relative, half sizes bs): up to two sphere-box contacts (mjc_CapsuleBox), normal from the
 // robot geom to the box
+#if defined(MZ_EXP_STAMPS) && defined(__HIPCC__)
+__device__ unsigned mz_exp_general_runs;  // (experiment build) capsule-box tests that did not qualify for the face case
+#endif
 template <class Emit>
 MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl, float r, const float* bc, const float* bs,
                         float margin, int kind, int blk, Emit&& emit) {
@@ -880,6 +883,53 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
     em[k] = cl[k] - h[k]; ep[k] = cl[k] + h[k];
     in_m = in_m && fabsf(em[k]) <= bs[k]; in_p = in_p && fabsf(ep[k]) <= bs[k];
   }
+#ifndef MZ_EXP_NOFACEPATH
+  // The FACE case, written out (round 5): both ends of the axis segment beyond the same face of the box and inside its other two
+  // slabs — a leg against a wall, which is nearly every wall test an ant ever causes (maze cells are metres wide, capsules
+  // centimetres; a concave corner is two boxes, one face each).  Then everything the general code below works out is known: the closest
+  // point of the segment is the end nearer to the face (the first end on a tie), the feature is that face, the second support point is
+  // the other end (it stays over the face: frac = 1), and each of the two sphere tests sees a centre outside along that one axis —
+  // depth = |coordinate| - half size - radius, normal = minus the axis.  Same contacts, same order; ~60 instructions instead of
+  // ~1000.  Why it matters: per-wave start / end stamps of the product kernel (tools/exp_launch_stamps.py) put ONE wall test at 1.9 us
+  // of its wave — 4 650 cycles — and the slowest wave of a launch at 24 of them per step: 46 of the 61 us it runs longer than the
+  // mean wave.  (Round 4 tried a fast path for the closest-point search alone and lost 1 %: the rest of the test still ran.)
+  {
+    int nin = 0, kf = 0;
+    bool beyond = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const bool ink = fabsf(em[k]) <= bs[k] && fabsf(ep[k]) <= bs[k];
+      const bool outk = (em[k] > bs[k] && ep[k] > bs[k]) || (em[k] < -bs[k] && ep[k] < -bs[k]);
+      nin += ink ? 1 : 0;
+      if (outk) { kf = k; beyond = true; }
+    }
+    if (nin == 2 && beyond) {
+      const float emk = sel3f(em, kf), epk = sel3f(ep, kf), bsk = sel3f(bs, kf);
+      const bool p_first = fabsf(epk) < fabsf(emk);  // the closest end comes first: end -1 (em) unless end +1 is strictly nearer
+      const float sgn = emk > 0.f ? 1.f : -1.f, d0 = fabsf(p_first ? epk : emk) - bsk;
+      if (d0 * d0 > (r + margin) * (r + margin)) return;  // (the general code's reject on the closest point)
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        const bool usep = (pass == 0) == p_first;
+        const float pk = usep ? epk : emk, dd = (fabsf(pk) - bsk) - r;
+        if (dd < margin) {
+          cg.dist = dd;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const float nk = k == kf ? -sgn : 0.f;
+            cg.n[k] = nk;
+            cg.pos[k] = (usep ? ep[k] : em[k]) + nk * (r + 0.5f * dd) + bc[k];
+          }
+          emit(cg);
+        }
+      }
+      return;
+    }
+  }
+#endif
+#if defined(MZ_EXP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  atomicAdd(&mz_exp_general_runs, 1u);
+#endif
   float t, boxpos = 0.f;
   int type = 0, clface = -1, cledge = 0, corner = 0;
   if (in_m || in_p) t = in_m ? -1.f : 1.f;  // an end inside the box (end -1 first): the face case without a face

@@ -149,6 +149,43 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
   // boxes; per cell the platform before the wall), then one cell per pass — lanes with one candidate each meet in the same pass
   // instead of each waiting for the other's position in a loop nest
   unsigned candw = 0u, candp = 0u;
+  if (i1 - i0 <= 1 && j1 - j0 <= 1) {
+    // the usual 2 x 2 block in a straight line (round 5): the same test as `candidate` — a cell's gap is (x gap of its column)^2 +
+    // (y gap of its row)^2 + (z gap of its layer)^2, six numbers for eight boxes — without the two nested loops over lane-dependent
+    // cell ranges (every geom of an ant near a wall ran them, four to eight `candidate` calls each, whether or not it touched anything)
+    const float ex = fabsf(ax[0]) * hl, ey = fabsf(ax[1]) * hl, ez = fabsf(ax[2]) * hl;
+    float xg2[2], yg2[2];
+    bool jin[2], iin[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int j = q ? j1 : j0, i = q ? i1 : i0;
+      const float bx = ((j * z.scale - z.tx) - x0) - x0l, by = ((i * z.scale - z.ty) - y0) - y0l;
+      const float gx_ = fmaxf(fabsf(ctr[0] - bx) - ex - bs[0], 0.f), gy_ = fmaxf(fabsf(ctr[1] - by) - ey - bs[1], 0.f);
+      xg2[q] = gx_ * gx_; yg2[q] = gy_ * gy_;
+      jin[q] = j >= 0 && j < z.cols && (q == 0 || j1 != j0);
+      iin[q] = i >= 0 && i < z.rows && (q == 0 || i1 != i0);
+    }
+#pragma unroll
+    for (int layer = 1; layer >= 0; layer--) {
+      if (layer == 0 && !elevated) break;
+      const float cz1 = layer ? z.center_z : z.half_z;
+      const bool zok = !(gz - reach > cz1 + z.half_z || gz + reach < cz1 - z.half_z);
+      const float gz_ = fmaxf(fabsf(ctr[2] - (cz1 - cz)) - ez - bs[2], 0.f), zg2 = gz_ * gz_;
+      unsigned m = 0u;
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++) {
+        const int i = qi ? i1 : i0;
+        const uint32_t row = layer ? maze_row_lds(s, i) : plat_row_lds(s, i);
+#pragma unroll
+        for (int qj = 0; qj < 2; qj++) {
+          const int j = qj ? j1 : j0;
+          const bool present = iin[qi] && jin[qj] && ((row >> (j & 31)) & 1u);
+          if (present && zok && xg2[qj] + yg2[qi] + zg2 <= lim2) m |= 1u << (4 * qi + qj);
+        }
+      }
+      if (layer) candw = m; else candp = m;
+    }
+  } else
   for (int i = i0; i <= i1 && i < i0 + 8; i++)
     for (int j = j0; j <= j1 && j < j0 + 4; j++) {
       if (candidate(i, j, 1)) candw |= 1u << (4 * (i - i0) + (j - j0));
@@ -158,6 +195,9 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
   candw = 0u; candp = 0u;
 #endif
   while (candw | candp) {
+#ifdef MZ_EXP_STAMPS  // (NB = 0 only: bkey is free there) narrow-phase runs of this env over the step
+    atomicAdd(const_cast<int*>(&s.bkey[0]), 1);
+#endif
     const int b = __ffs((int)(candw | candp)) - 1;
     const unsigned bit = 1u << b;
     if (candp & bit) test(i0 + (b >> 2), j0 + (b & 3), 0);
@@ -461,6 +501,9 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
     }
     cx.sync();
   }
+#ifdef MZ_EXP_STAMPS
+  if (over && p == 0) s.bkey[1] += 1;
+#endif
   if (cx.any(over)) {
     // Fall-back (rare: some geom of some env of this wave found more than three contacts): publish the kinematics the lane-group
     // contact code of ant_dyn.h reads, and let the envs concerned enumerate the two-pass way.

@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
                                                        float* __restrict__ final_obs, int ostride, float* __restrict__ record) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   using D = AntDims<NB>;
+#ifdef MZ_EXP_STAMPS  // experiment build (tools/exp_launch_stamps.py): when does each wave of the PRODUCT kernel start and end?
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const AntDev& K = *Kp;  // model constants: scalar loads from a device-resident block (L2 / scalar-cache hits)
   constexpr size_t SB = ant_scratch_bytes<NB, G, PROF>(), EB = ant_env_lds_bytes<NB, G, PROF>();  // scratch block | I/O staging, per env
   const int EPB = blockDim.x / G;  // envs per workgroup (blockDim.x = 64 * waves per workgroup)
@@ -107,6 +110,9 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
   for (int i = cx.l; i < ANT_NU; i += G) act_s[i] = actions[(size_t)env * ANT_NU + i];
   if (cx.l == 0) { iout_s[2] = ((const int*)rec)[D::REC_T]; iout_s[3] = ((const int*)rec)[D::REC_T + 1]; }  // t, episode: parked in LDS for the step
   if constexpr (PROF) { if (cx.l == 0) { for (int k = 0; k < 16; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
+#ifdef MZ_EXP_STAMPS
+  if (cx.l == 0) { s.red[2] = 0.f; s.red[3] = 0.f; s.bkey[0] = 0; s.bkey[1] = 0; }
+#endif
   cx.sync();
   ant_env_step<NB>(cx, K, s, act_s, obs_s, &out_s[0], (uint8_t*)&iout_s[0], &iout_s[1], &out_s[1], &iout_s[2]);
   cx.sync();
@@ -192,6 +198,28 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
       for (int k = 0; k < 16; k++) prof[16 + gridDim.x * 0 + n + (size_t)wg * 16 + k] += s.prof[k];  // per-workgroup phases (mz_read_wave_phase_cycles)
     }
   }
+#ifdef MZ_EXP_STAMPS
+  if constexpr (!PROF) {
+    if (prof && threadIdx.x == 0) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* w = prof + 16 + n + (size_t)blockIdx.x * 16;
+      w[0] = stamp0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = hwid; w[3] = xcc;
+      float mx = 0.f;
+      int npass = 0, nover = 0, pmax = 0;
+      for (int q = 0; q < 64 / G; q++) {
+        const AntScratchT<NB>& sq = *reinterpret_cast<const AntScratchT<NB>*>(lds_raw + (size_t)q * EB);
+        mx = fmaxf(mx, sq.red[3]);
+        npass += sq.bkey[0]; nover += sq.bkey[1]; pmax = sq.bkey[0] > pmax ? sq.bkey[0] : pmax;
+      }
+      w[9] = (unsigned long long)mz_exp_general_runs;  // (device-wide running total)
+      w[6] = (unsigned long long)npass; w[7] = (unsigned long long)nover; w[8] = (unsigned long long)pmax;
+      w[4] = (unsigned long long)s.red[2]; w[5] = (unsigned long long)mx;  // lock-step Newton iterations of the wave; most contact-evaluations among its envs
+    }
+  }
+#endif
 }
 
 #ifdef MZ_ISA_ONLY
@@ -323,6 +351,19 @@ static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, 
   const int dv = h->device & 31;
   float* rec = h->view.on ? nullptr : h->record;  // with a top-down view the record is packed after mzk_view_fill (mazestep.hip)
   hipError_t e;
+#ifdef MZ_EXP_STAMPS
+  if (h->prof && !(NB == 0 && G == 16)) return hipErrorNotSupported;
+  if (h->prof) {  // the non-instrumented kernel, stamping into the profile buffer
+    if (lds_set[0][dv] != lds) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      lds_set[0][dv] = lds;
+    }
+    hipLaunchKernelGGL((ant_step_kernel<NB, G, false>), grid, block, lds, st, h->ant_dev, h->n, h->state, a, o, r, d, gi, inf, h->status,
+                       h->auto_reset, h->seed, h->env0, h->prof, h->final_obs, h->lay.ostride, rec);
+    return hipSuccess;
+  }
+#endif
   if (h->prof) {
     if (lds_set[1][dv] != lds) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ant_step_kernel<NB, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
