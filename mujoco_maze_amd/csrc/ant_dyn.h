@@ -1714,7 +1714,8 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
         sn = cx.gsum(sp); qn = cx.gsum(qp);
       }
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
-      for (int ls = 0; ls < K.ls_iter; ls++) {
+      const int ls_max = it < K.ls_fast_iters ? K.ls_fast : K.ls_iter;  // (the rule of ant_newton_rows.h: unit steps first, the exact search behind them)
+      for (int ls = 0; ls < ls_max; ls++) {
         float d1 = 0.f, d2 = 0.f;
         MZ_FOR(c, s.ncon) {
           float Dc = s.cD[c];

@@ -936,7 +936,16 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       const float p1 = rsum(search * Mx), p2 = rsum(search * Ms);
       sn = rsum(isdof ? search * search : 0.f); qn = rsum(isdof ? qacc * qacc : 0.f);
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
-      for (int ls = 0; ls < K.ls_iter; ls++) {
+      // Round 5: the first K.ls_fast_iters (3) iterations of an evaluation take the UNIT step when the active set changes (K.ls_fast = 0
+      // evaluations of phi'), later ones search the line exactly as before.  What the line search buys is global convergence, not
+      // accuracy: the solve ends with a unit step inside the final active set (or on the gradient test) whichever way it got there, so
+      // the answer is the same to fp32 round-off (profiles/r05/ls_parity.txt: identical error quantiles against the float64 oracle), and
+      // Newton with an exact search converges from ANY point — the unit steps only move where it starts.  Unit steps alone do cycle
+      // (AntPush with 50 fast iterations: 2024 of 2048 envs hit the iteration cap within 500 steps; profiles/r05/ls_iters.txt), three
+      // of them do not cost an iteration (lock-step iterations per step 55 -> 55) and save the search's matvec + ~3 evaluations, two
+      // reductions each: AntUMaze-v0 0.2754 -> 0.2555 ms per step, AntPush-v0 0.5009 -> 0.4551.  `it` is wave-uniform: no divergence.
+      const int ls_max = it < K.ls_fast_iters ? K.ls_fast : K.ls_iter;
+      for (int ls = 0; ls < ls_max; ls++) {
         float d1 = 0.f, d2 = 0.f;
 #pragma unroll
         for (int m = 0; m < MA; m++)

@@ -170,7 +170,7 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "seed")) { h->seed = (uint64_t)value; return MZ_OK; }
   if (!strcmp(key, "env_index_offset")) { h->env0 = (uint64_t)value; return MZ_OK; }
   if (h->robot != MZ_ROBOT_ANT && (!strcmp(key, "solver_iterations") || !strcmp(key, "solver_tolerance") || !strcmp(key, "solver_rtol") ||
-                                   !strcmp(key, "ls_iterations") || !strcmp(key, "debug_frame_skip") || !strcmp(key, "waves_per_block") || !strcmp(key, "waves_per_simd")))
+                                   !strcmp(key, "ls_iterations") || !strcmp(key, "ls_fast_iterations") || !strcmp(key, "ls_fast") || !strcmp(key, "debug_frame_skip") || !strcmp(key, "waves_per_block") || !strcmp(key, "waves_per_simd")))
     return set_err(h, MZ_ERR_UNSUPPORTED, "mz_set_option: this key tunes the Ant kernels only (the other robots' solvers have fixed settings)", hipSuccess);
   if (h->robot == MZ_ROBOT_GENERIC && !strcmp(key, "lanes_per_env"))
     return set_err(h, MZ_ERR_UNSUPPORTED, "mz_set_option: the generic-robot kernel runs one wavefront per env", hipSuccess);
@@ -178,6 +178,8 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "solver_tolerance")) { h->ant_dirty = 1; h->ant.tol = (float)value; return MZ_OK; }
   if (!strcmp(key, "solver_rtol")) { h->ant_dirty = 1; h->ant.rtol = (float)value; return MZ_OK; }
   if (!strcmp(key, "ls_iterations")) { h->ant_dirty = 1; h->ant.ls_iter = (int)value; return MZ_OK; }
+  if (!strcmp(key, "ls_fast_iterations")) { h->ant_dirty = 1; h->ant.ls_fast_iters = (int)value; return MZ_OK; }
+  if (!strcmp(key, "ls_fast")) { h->ant_dirty = 1; h->ant.ls_fast = (int)value; return MZ_OK; }
   if (!strcmp(key, "debug_frame_skip")) { h->ant_dirty = 1; h->ant.frame_skip = (int)value; return MZ_OK; }  // diagnostics: mj_steps per env.step (Ant)
   if (!strcmp(key, "lanes_per_env")) {
     int g = (int)value;

@@ -35,8 +35,13 @@ def oracle_sensitive(cm, start, act, ref_qvel, e, rng, atol=1e-5):
 LONG = len(sys.argv) > 1 and sys.argv[1] == "long"
 if LONG:
     CONFIGS = [(e, 4 * n, tuple(range(0, (301 if max(c) >= 100 else 101), 10))) for e, n, c in CONFIGS]
+# experiments: MZ_PS_CONFIGS="AntUMaze-v0,AntPush-v0" keeps those configs, MZ_PS_OPTS="ls_iterations=0,max_iterations=60" sets handle options
+if os.environ.get("MZ_PS_CONFIGS"):
+    CONFIGS = [c for c in CONFIGS if c[0] in os.environ["MZ_PS_CONFIGS"].split(",")]
+OPTS = [kv.split("=") for kv in os.environ.get("MZ_PS_OPTS", "").split(",") if kv]
 for env_id, n, checks in CONFIGS:
     env = mm.make(env_id.split("@")[0], num_envs=n, force_vec=True, **({"maze_size_scaling": float(env_id.split("@")[1])} if "@" in env_id else {}))
+    for k_, v_ in OPTS: env.set_option(k_, float(v_))
     cm = env.model
     prng = np.random.default_rng(5)
     nsens, nout = 0, 0
