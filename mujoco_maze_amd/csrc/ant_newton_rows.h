@@ -1073,6 +1073,9 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
     s.iters = it;
     if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER;
     if constexpr (PROF) s.prof[15] += (unsigned)it;  // (part 2 of the scratch block: instrumented builds only)
+#ifdef MZ_EXP_STAMPS  // (tools/exp_launch_stamps.py) lock-step iterations of the wave | contact-evaluations of this env, over the step
+    s.red[2] += (float)it; s.red[3] += (float)ncon;
+#endif
   }
   cx.sync();
   cx.tick(s, 8);

@@ -13,6 +13,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ref = None
 # (fast iterations k, evaluations in them): the first k Newton iterations of an evaluation search the line with at most that many evaluations
 SETTINGS = [(0, 0), (1, 0), (2, 0), (3, 0), (50, 0), (1, 1), (2, 1), (3, 1), (50, 1)]
+if os.environ.get("MZ_LS_SETTINGS"):  # "3:0,4:0,6:0"
+    SETTINGS = [tuple(int(x) for x in kv.split(":")) for kv in os.environ["MZ_LS_SETTINGS"].split(",")]
 for kf, ls in SETTINGS:
     env = mm.make(env_id, num_envs=n, auto_reset=True, force_vec=True)
     env.set_option("ls_fast_iterations", kf); env.set_option("ls_fast", ls)
