@@ -293,6 +293,38 @@ def test_ant_lane_group_widths_agree(torch, oracle):
         assert np.all(_close(outs[g], outs[16], atol=4e-6)), g
 
 
+@pytest.mark.parametrize("env_id,n", [("AntUMaze-v0", 256), ("AntPush-v0", 128), ("AntMultiPush-v0", 64)])
+def test_ant_unit_steps_then_exact_search_changes_nothing(torch, env_id, n):
+    """Option "ls_fast_iterations" (default 3: the first three Newton iterations of a solve take the unit step, the exact line search
+    of MuJoCo's Newton solver — engine_solver.c mj_solNewton / PrimalSearch — only behind them): a converged solve does not depend on
+    the way there.  The same states stepped with the search in every iteration (0) and with the default agree to fp32 round-off, and
+    no env runs into the iteration cap; row solver (plain ant, one block) and lane-group solver (two blocks)."""
+    envs = []
+    for fast in (0, 3):
+        env = mm.make(env_id, num_envs=n)
+        env.set_option("ls_fast_iterations", fast)
+        env.reset(seed=5)
+        envs.append(env)
+    g = torch.Generator(device=envs[0].device).manual_seed(3)
+    acts = [(torch.rand((n, envs[0].nu), device=envs[0].device, generator=g) * 2 - 1) * 30 for _ in range(18)]
+    for a in acts[:12]:
+        envs[0].step(a)
+    worst, sizes = 0.0, []
+    for a in acts[12:]:  # single steps from IDENTICAL states (a rollout would compare two chaotic trajectories, not two solvers)
+        st = [x.cpu().numpy() for x in envs[0].get_state()]
+        envs[1].set_state(*st)
+        envs[0].step(a); envs[1].step(a)
+        for x, y in zip(envs[0].get_state()[:2], envs[1].get_state()[:2]):
+            d = ((x - y).abs() / (1 + x.abs())).max(1).values
+            # (an env on a discontinuity of the step map may land on either side under ANY change of round-off: at most a few)
+            sizes.append(int((d > 1e-5).sum().item()))
+            worst = max(worst, float(d[d <= 1e-5].max().item()) if bool((d <= 1e-5).any()) else 0.0)
+    assert sum(sizes) <= max(2, int(0.004 * n * 6)), sizes
+    assert int((envs[1].status() & 4).sum().item()) == 0  # MZ_STATUS_SOLVER_MAXITER
+    for env in envs:
+        env.close()
+
+
 def test_ant_two_waves_per_simd_kernel(torch, oracle):
     """The plain ant's second instantiation (ant_kernels.hip: WPS = 2, held to 256 registers so that two waves share a SIMD, its Hessian
     fold on the matrix cores: v_mfma_f32_16x16x1_4b_f32; taken beyond 4096 envs, or by option "waves_per_simd") against the oracle and
