@@ -33,6 +33,12 @@
 #pragma once
 #include "ant_newton_rows.h"
 
+// experiment build -DMZ_EXP_SUBTICK2: the forward pass's timers all book on slot 3, slots 0 .. 2 time the solver's set-up (ant_newton_rows.h)
+#ifdef MZ_EXP_SUBTICK2
+#define MZ_FT(k) 3
+#else
+#define MZ_FT(k) (k)
+#endif
 namespace rows {
 
 template <int J>
@@ -71,10 +77,11 @@ __device__ __forceinline__ void con_record_item(const AntDev& K, S& s, int c) {
 // platform under a cell first) — the robot-geom part of geom_contacts (ant_dyn.h), same order, on register inputs: centre / axis
 // relative to the torso origin, torso origin (x0 + x0l, y0 + y0l, cz) in the world
 template <int NB, class S, class Emit>
-__device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s, bool sphere, const float* ctr, const float* ax, float hl, float r,
+__device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const AntU& z, const S& s, bool sphere, const float* ctr, const float* ax, float hl, float r,
                                                     float x0, float y0, float x0l, float y0l, float cz, Emit&& emit) {
-  const MazeDev& z = K.maze;
-  const float inv = 1.0f / z.scale;
+  // (z: the maze's geometry and the two margins — register-held constants of the step in the one-wave kernel, ant_newton_rows.h ant_u)
+  const float floor_margin = z.floor_margin, wall_margin = z.wall_margin;
+  const float inv = z.inv_scale_xy;
   const float bs[3] = {z.half_xy, z.half_xy, z.half_z};
   ContactGeo cg;
   // floor plane z = 0, normal +z; capsule ends in MuJoCo's geom-frame order [ASSUME-5]: "+axis" is the end at the body origin
@@ -85,7 +92,7 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
     float p[3];
     for (int k = 0; k < 3; k++) p[k] = ctr[k] + sg * ax[k] * hl;
     const float dist = (cz + p[2]) - r;
-    if (dist < K.floor.margin) {
+    if (dist < floor_margin) {
       cg.dist = dist; cg.kind = 0; cg.blk = 0; cg.other = 0;
       cg.n[0] = 0.f; cg.n[1] = 0.f; cg.n[2] = 1.f;
       cg.pos[0] = p[0]; cg.pos[1] = p[1]; cg.pos[2] = p[2] - (r + 0.5f * dist);
@@ -93,7 +100,7 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
       emit(cg);
     }
   }
-  const float reach = r + hl + K.wall.margin;
+  const float reach = r + hl + wall_margin;
   if constexpr (NB == 1) {
     // the movable block: spawn position + its two slides, hi parts first, low-order parts after (block_center of ant_dyn.h)
     float d[3] = {0.f, 0.f, 0.f}, dl[3] = {0.f, 0.f, 0.f};
@@ -105,14 +112,14 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
     float d2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 3; q++) { const float dd = fmaxf(fabsf(ctr[q] - bc[q]) - K.block_half[q], 0.f); d2 += dd * dd; }
-    if (d2 < reach * reach) round_vs_box(sphere, ctr, ax, hl, r, bc, K.block_half, K.wall.margin, 2, 0, emit);
+    if (d2 < reach * reach) round_vs_box(sphere, ctr, ax, hl, r, bc, K.block_half, wall_margin, 2, 0, emit);
   }
   const bool elevated = NB > 0 && z.elevated;
   const float gx = x0 + ctr[0], gy = y0 + ctr[1], gz = cz + ctr[2];
   if (gz - reach > z.center_z + z.half_z) return;
   const int j0 = (int)floorf((gx - reach + z.tx) * inv + 0.5f), j1 = (int)floorf((gx + reach + z.tx) * inv + 0.5f);
   const int i0 = (int)floorf((gy - reach + z.ty) * inv + 0.5f), i1 = (int)floorf((gy + reach + z.ty) * inv + 0.5f);
-  const float lim2 = (r + K.wall.margin) * (r + K.wall.margin) * 1.0001f;
+  const float lim2 = (r + wall_margin) * (r + wall_margin) * 1.0001f;
   // can the box of cell (i, j) — layer 1: the wall, layer 0: the platform of an elevated maze — give a contact at all?  In the grid
   // and present; the geom's z extent meets the box's; and the geom's axis segment — its bounding box, axis by axis — comes within
   // radius + margin of the box: a lower bound of the true distance that is exact whenever the nearest feature is a face, i.e. for
@@ -136,7 +143,7 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const S& s,
   auto test = [&](int i, int j, int layer) {
     const float cz1 = layer ? z.center_z : z.half_z;
     const float bc[3] = {((j * z.scale - z.tx) - x0) - x0l, ((i * z.scale - z.ty) - y0) - y0l, cz1 - cz};  // large world coordinates cancel first, then the low-order parts (AntScratchT::qlo)
-    round_vs_box(sphere, ctr, ax, hl, r, bc, bs, K.wall.margin, 1, 0, emit);
+    round_vs_box(sphere, ctr, ax, hl, r, bc, bs, wall_margin, 1, 0, emit);
   };
   if (i1 - i0 <= 1 && j1 - j0 <= 1) {
     // the usual case (a geom's bounding square covers at most 2 x 2 cells): both grid rows at once, leave when none of the cells holds a box
@@ -310,14 +317,14 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
   for (int k = 0; k < 3; k++) { com[k] = role(com1[k], com2[k], com0[k], 0.f); w[k] = role(w1[k], w2[k], w0[k], 0.f); }
   const int cls = j == 0 ? 2 : (j == 1 ? 3 : (j == 2 ? 1 : 0));
   const float hlen = cx.lc[LC_HLEN], rad = cx.lc[LC_RAD];
-  cx.tick(s, 0);
+  cx.tick(s, MZ_FT(0));
   if constexpr (NB == 1) { if (p == 0) { s.cz = cz; s.con_over = 0; } }  // (the block's enumerators below read them)
   // ---- C: contacts of the own geom, staged in registers (the first three; more: the env takes the fall-back below).  Right after the
   // kinematics: the narrow phase is the branchiest code of the evaluation, and here little else is live across it
   GeomHit hit[3];
   int nfound = 0;
   if (isgeom) {
-    robot_geom_contacts<NB>(K, s, j == 3, com, w, hlen, rad, x0, y0, s.qlo[0], s.qlo[1], cz, [&](const ContactGeo& g) {
+    robot_geom_contacts<NB>(K, ant_u(cx, K), s, j == 3, com, w, hlen, rad, x0, y0, s.qlo[0], s.qlo[1], cz, [&](const ContactGeo& g) {
 #pragma unroll
       for (int q = 0; q < 3; q++)
         if (nfound == q) {
@@ -328,7 +335,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
     });
   }
 #ifdef MZ_EXP_SUBTICK  // experiment build: the robot geoms' narrow phase is booked on slot 0, the block's enumerators on slot 3
-  cx.tick(s, 0);
+  cx.tick(s, MZ_FT(0));
 #endif
   // the movable block's own enumerators (floor corners | the 3 x 3 cells under it, platform and wall each | slide limits), one per
   // lane of the group's first eleven, staged in the cY block as in the lane-group path; their contacts take the first slots
@@ -376,7 +383,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
   const unsigned word = rsum_u((unsigned)(nfound > 3 ? 3 : nfound) << (2 * rank));
   const int off = nblk + (int)sum2bit(word & ((1u << (2 * rank)) - 1u));
   int ncon = nblk + (int)sum2bit(word);
-  cx.tick(s, 2);
+  cx.tick(s, MZ_FT(2));
 
   // ---- I: spatial inertia of the own body about the torso origin (inertia_item); composites
   float cin[10];
@@ -437,7 +444,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
     for (int l2 = 0; l2 < 4; l2++) {
       const int mine = -(int)(l2 == l);
       const float vh = gq[2 * l2], va = gq[2 * l2 + 1];
-      const float hh = bsel(mine, bsel(m1, hipT, vh + K.armature), 0.f), ha = bsel(mine, bsel(m1, va + K.armature, va), 0.f);  // hinge lanes
+      const float hh = bsel(mine, bsel(m1, hipT, vh + ant_u(cx, K).armature), 0.f), ha = bsel(mine, bsel(m1, va + ant_u(cx, K).armature, va), 0.f);  // hinge lanes
       Mrow[4 * l2] = bsel(mh, hh, vh); Mrow[4 * l2 + 1] = bsel(mh, ha, va);
     }
     if constexpr (NB == 1) {  // the block: a separate tree — its mass on the diagonal of its two slides, no coupling with the robot
@@ -454,7 +461,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
     mat_vecf(ww, R0, qv + 3);  // world angular velocity (root angular dofs are body-frame)
     for (int k = 0; k < 3; k++) { vb[k] = ww[k]; vb[3 + k] = qv[k]; a[k] = 0.f; }
     cross3f(a + 3, qv, ww);
-    a[5] -= K.gz;              // gravity as base acceleration
+    a[5] -= ant_u(cx, K).gz;   // gravity as base acceleration
     const float vh = bsel(mh, qdh, 0.f), va = bsel(m1, qda, 0.f);  // aux and ankle move with the hip, the ankle body with the ankle as well
     const float Sh6[6] = {zw[0], zw[1], zw[2], ShL[0], ShL[1], ShL[2]};
     float sd[6];
@@ -475,13 +482,13 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
       bias += S[k] * role(f[k] + ank, f[k], all, all);
     }
     const float fact = s.fact[hinge ? pos2dof(p) : 6];  // motors sit on the hinges only
-    qfs = bsel(mh, -K.damping * bsel(m0, qdh, qda) - bias + fact, bsel(-(int)isroot, -bias, 0.f));
+    qfs = bsel(mh, -ant_u(cx, K).damping * bsel(m0, qdh, qda) - bias + fact, bsel(-(int)isroot, -bias, 0.f));
     if constexpr (NB == 1) {  // block slides: undamped, unactuated; gravity acts on a z slide (falling blocks)
       const int ax = p == 14 ? K.block_axis[0] : K.block_axis[1];
       if (p >= 14) qfs = ax == 2 ? K.block_mass * K.gz : 0.f;
     }
   }
-  cx.tick(s, 1);
+  cx.tick(s, MZ_FT(1));
   if (!over) {
     if (ncon > NC) { ncon = NC; if (p == 0) s.status |= MZ_STATUS_CONTACT_OVERFLOW; }
     if (p == 0) { s.ncon = ncon; s.nblkcon = nblk; s.ncon_true = ncon + nrep; }

@@ -264,7 +264,7 @@ static inline int ant_dev_from_model(AntDev* a, const mz_model* m, char* err, in
   for (int k = 0; k < ANT_NQ + 7 * nball; k++) a->qpos0[k] = (float)m->qpos0[k];
   a->reset_kind = m->reset_qvel_kind;
   a->max_iter = 50;  // (the plain ant ran with 10 until round 3: one env in 2.5e8 env-steps of the 60 000-step soak needed an eleventh iteration)
-  a->ls_iter = 12; a->ls_fast_iters = 3; a->ls_fast = 0; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
+  a->ls_iter = 12; a->ls_fast_iters = 5; a->ls_fast = 0; a->trust_exact = 1; a->tol = 1e-6f; a->rtol = 1e-6f;
   a->inv_scale = (float)(1.0 / (m->meaninertia * m->nv));
   return MZ_OK;
 }

@@ -404,11 +404,52 @@ __device__ __forceinline__ const float* wr_record(const S& s, int c) { return &s
 // Per-lane constants of the hinge lanes' joint-limit rows, loaded once per step into DevCtx::lc (run-time indexed reads of the
 // constant block inside the 20 evaluations were dependent vector-memory loads): range and inverse weight of the lane's own hinge.
 enum { LC_LO = 11, LC_HI = 12, LC_DOFW = 13 };
+// UNIFORM constants of the model that every forward evaluation reads — margins, the maze grid's geometry, armature / damping /
+// gravity, the solver's settings — held in vector registers next to the per-lane ones (round 5).  Left in the constant block they
+// were scalar loads INSIDE the evaluation (the step's 100-odd spilled scalar registers leave the compiler no room to keep them):
+// ten wait groups per evaluation, each the scalar cache's latency in front of the instruction that needs the value, with one wave
+// per SIMD and nothing else to issue.  The empty asm makes a value opaque: it cannot be rematerialised by loading it again.
+// Measured (A / B, AntUMaze-v0 4096 envs): 0.2516 -> 0.2483..0.2499 ms.  NOT in the two-waves-per-SIMD instantiation (cx.mfma), whose
+// 256 registers have no room for 18 more: it reads the constant block where it needs a value, as before (`ant_u` below hands out one
+// or the other; held there as well, 8192 envs lose 1 %).
+enum { LU_FLOORM = 14, LU_WALLM, LU_SCALE, LU_INVS, LU_TX, LU_TY, LU_HXY, LU_HZ, LU_CZ, LU_GRID, LU_ARM, LU_DAMP, LU_GZ, LU_TOL, LU_RTOL, LU_ISC,
+       LU_ITERS, LU_LS, LU_N };
+struct AntU {
+  float floor_margin, wall_margin, scale, inv_scale_xy, tx, ty, half_xy, half_z, center_z;
+  int rows, cols;
+  bool elevated;
+  float armature, damping, gz, tol, rtol, inv_scale;
+  int max_iter, ls_iter, ls_fast_iters, ls_fast, trust_exact;  // (scalar registers: wave-uniform loop bounds)
+};
+template <int G, bool PROF>
+__device__ __forceinline__ AntU ant_u(const DevCtx<G, PROF>& cx, const AntDev& K) {
+  const MazeDev& z = K.maze;
+  if (cx.mfma)
+    return {K.floor.margin, K.wall.margin, z.scale, 1.0f / z.scale, z.tx, z.ty, z.half_xy, z.half_z, z.center_z, z.rows, z.cols, z.elevated != 0,
+            K.armature, K.damping, K.gz, K.tol, K.rtol, K.inv_scale, K.max_iter, K.ls_iter, K.ls_fast_iters, K.ls_fast, K.trust_exact};
+  const int g = __float_as_int(cx.lc[LU_GRID]);
+  const int a = __builtin_amdgcn_readfirstlane(__float_as_int(cx.lc[LU_ITERS])), b = __builtin_amdgcn_readfirstlane(__float_as_int(cx.lc[LU_LS]));
+  return {cx.lc[LU_FLOORM], cx.lc[LU_WALLM], cx.lc[LU_SCALE], cx.lc[LU_INVS], cx.lc[LU_TX], cx.lc[LU_TY], cx.lc[LU_HXY], cx.lc[LU_HZ], cx.lc[LU_CZ],
+          g & 255, (g >> 8) & 255, ((g >> 16) & 1) != 0, cx.lc[LU_ARM], cx.lc[LU_DAMP], cx.lc[LU_GZ], cx.lc[LU_TOL], cx.lc[LU_RTOL], cx.lc[LU_ISC],
+          a, b & 1023, (b >> 10) & 1023, (b >> 20) & 1023, (b >> 30) & 1};
+}
+__device__ __forceinline__ float lu_hold(float x) { asm("" : "+v"(x)); return x; }
 template <int G, bool PROF>
 __device__ __forceinline__ void ant_limit_consts(const AntDev& K, DevCtx<G, PROF>& cx) {
-  static_assert(LC_DOFW < DevCtx<G, PROF>::NLC, "DevCtx::lc too small");
+  static_assert(LU_N <= DevCtx<G, PROF>::NLC, "DevCtx::lc too small");
   const int p = cx.l & 15, l = p >> 2, d = p & 1;
   cx.lc[LC_LO] = d ? K.ank_lo[l] : K.hip_lo; cx.lc[LC_HI] = d ? K.ank_hi[l] : K.hip_hi; cx.lc[LC_DOFW] = d ? K.dofw_ank : K.dofw_hip;
+  if (cx.mfma) return;
+  const MazeDev& z = K.maze;
+  cx.lc[LU_FLOORM] = lu_hold(K.floor.margin); cx.lc[LU_WALLM] = lu_hold(K.wall.margin);
+  cx.lc[LU_SCALE] = lu_hold(z.scale); cx.lc[LU_INVS] = lu_hold(1.0f / z.scale); cx.lc[LU_TX] = lu_hold(z.tx); cx.lc[LU_TY] = lu_hold(z.ty);
+  cx.lc[LU_HXY] = lu_hold(z.half_xy); cx.lc[LU_HZ] = lu_hold(z.half_z); cx.lc[LU_CZ] = lu_hold(z.center_z);
+  cx.lc[LU_GRID] = lu_hold(__int_as_float(z.rows | (z.cols << 8) | ((z.elevated ? 1 : 0) << 16)));
+  cx.lc[LU_ARM] = lu_hold(K.armature); cx.lc[LU_DAMP] = lu_hold(K.damping); cx.lc[LU_GZ] = lu_hold(K.gz);
+  cx.lc[LU_TOL] = lu_hold(K.tol); cx.lc[LU_RTOL] = lu_hold(K.rtol); cx.lc[LU_ISC] = lu_hold(K.inv_scale);
+  auto c10 = [](int v) { return v < 0 ? 0 : (v > 1023 ? 1023 : v); };
+  cx.lc[LU_ITERS] = lu_hold(__int_as_float(K.max_iter < 0 ? 0 : K.max_iter));
+  cx.lc[LU_LS] = lu_hold(__int_as_float(c10(K.ls_iter) | (c10(K.ls_fast_iters) << 10) | (c10(K.ls_fast) << 20) | ((K.trust_exact ? 1 : 0) << 30)));
 }
 
 // Constraint rows of a contact of the block's OWN enumerators (floor -> block, maze box -> block, slide limit; kinds 3, 4, 6 of
@@ -561,7 +602,9 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
   const bool has = s.ncon > 0 || cx.gany(lsign != 0.f);
   // qacc_smooth = M^-1 qfrc_smooth by the same row elimination — only where it is used: on the first evaluation of a step
   // (MuJoCo's warm-start rule compares against it) and for an env without any constraint (then it is the answer).  The
-  // Newton iteration itself works on M qacc - qfrc_smooth and never needs it.
+  // Newton iteration itself works on M qacc - qfrc_smooth and never needs it.  (Round 5, tried: an unconstrained env through the
+  // Newton loop instead — H = M there, the first unit step lands on the answer — so that one airborne ant does not buy its wave a
+  // second elimination: nothing in the settled rollout of the bench, and the different register allocation cost 1 %.  Not taken.)
   float qas = 0.f;
   if (compare || cx.any(!has)) {
     float Hq[NR];
@@ -571,6 +614,9 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
     if (isdof) s.qas[ri] = qas;
   }
   const float warm = isdof ? s.warm[ri] : 0.f;  // later evaluations start from the previous evaluation's solution
+#ifdef MZ_EXP_SUBTICK2
+  cx.tick(s, 0);  // limit row, qacc_smooth where needed
+#endif
   // own robot contact: 3 x (NHC + 2) Jacobian rows stay in LDS (row-major, read as needed); constants in registers
   float cD[MA], ar[MA][3];
   float wr[MA][3][6];  // WR: the own contacts' three wrenches each
@@ -615,6 +661,9 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       for (int a = 0; a < 3; a++) ar[m][a] = iscon[m] ? s.caref[cr[m]][a] : 0.f;
     }
   }
+#ifdef MZ_EXP_SUBTICK2
+  cx.tick(s, 1);  // the slots' records
+#endif
   // own block contacts (NB = 1): slots cx.l + m G < nB
   float bj[MB ? MB : 1][3][2], bar[MB ? MB : 1][3], bD[MB ? MB : 1], bu[MB ? MB : 1][3], bv[MB ? MB : 1][3];
   if constexpr (NB == 1) {
@@ -756,6 +805,9 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       for (int a = 0; a < 3; a++) o[m][a] = bj[m][a][0] * b0 + bj[m][a][1] * b1;
   };
 
+#ifdef MZ_EXP_SUBTICK2
+  cx.tick(s, 2);  // block rows, own columns / rows of the contacts
+#endif
   // ---- initial guess
   float qacc = warm;
   if (compare) {  // MuJoCo's rule on the first evaluation of a step: the better of warm start and qacc_smooth, by cost
@@ -810,7 +862,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
         for (int a = 0; a < 3; a++) bu[m][a] -= bar[m][a];
     }
   }
-  while (cx.any(!done) && it < K.max_iter) {
+  while (cx.any(!done) && it < ant_u(cx, K).max_iter) {
     // ---- contact lanes: gradient block g3 and curvature block W of their contact, in registers; every lane of the row reads
     // them with `row_newbcast:c` (fold_contact<c>): no LDS publish, no hand-off wait
     float mycg[MA][8];
@@ -900,7 +952,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
     if (!isdof) { g = 0.f; ga = 0.f; }
     const float gnorm = sqrtf(rsum(g * g)), anorm = sqrtf(rsum(ga * ga));
     // converged: MuJoCo's scaled-gradient test, or the gradient is at the fp32 cancellation floor
-    if (!done && (K.inv_scale * gnorm < K.tol || gnorm <= K.rtol * anorm)) done = true;
+    if (!done && (ant_u(cx, K).inv_scale * gnorm < ant_u(cx, K).tol || gnorm <= ant_u(cx, K).rtol * anorm)) done = true;
     if (!cx.any(!done)) { cx.tick(s, 5); break; }
     cx.tick(s, 5);
     // ---- Newton direction: H search = -grad
@@ -936,15 +988,15 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       const float p1 = rsum(search * Mx), p2 = rsum(search * Ms);
       sn = rsum(isdof ? search * search : 0.f); qn = rsum(isdof ? qacc * qacc : 0.f);
       float lo = 0.f, hi = -1.f, prev_d2 = -1.f;  // phi'(0) < 0 (descent direction); hi < 0: no upper bracket yet
-      // Round 5: the first K.ls_fast_iters (3) iterations of an evaluation take the UNIT step when the active set changes (K.ls_fast = 0
+      // Round 5: the first K.ls_fast_iters (5) iterations of an evaluation take the UNIT step when the active set changes (K.ls_fast = 0
       // evaluations of phi'), later ones search the line exactly as before.  What the line search buys is global convergence, not
       // accuracy: the solve ends with a unit step inside the final active set (or on the gradient test) whichever way it got there, so
       // the answer is the same to fp32 round-off (profiles/r05/ls_parity.txt: identical error quantiles against the float64 oracle), and
       // Newton with an exact search converges from ANY point — the unit steps only move where it starts.  Unit steps alone do cycle
-      // (AntPush with 50 fast iterations: 2024 of 2048 envs hit the iteration cap within 500 steps; profiles/r05/ls_iters.txt), three
-      // of them do not cost an iteration (lock-step iterations per step 55 -> 55) and save the search's matvec + ~3 evaluations, two
+      // (AntPush with 50 fast iterations: 2024 of 2048 envs hit the iteration cap within 500 steps; profiles/r05/ls_iters.txt), a
+      // few of them (3 .. 8 measure alike on the plain ant, 5 is best on the one-block mazes: ls_k.txt) do not cost an iteration (lock-step iterations per step 55 -> 55) and save the search's matvec + ~3 evaluations, two
       // reductions each: AntUMaze-v0 0.2754 -> 0.2555 ms per step, AntPush-v0 0.5009 -> 0.4551.  `it` is wave-uniform: no divergence.
-      const int ls_max = it < K.ls_fast_iters ? K.ls_fast : K.ls_iter;
+      const int ls_max = it < ant_u(cx, K).ls_fast_iters ? ant_u(cx, K).ls_fast : ant_u(cx, K).ls_iter;
       for (int ls = 0; ls < ls_max; ls++) {
         float d1 = 0.f, d2 = 0.f;
 #pragma unroll
@@ -1063,7 +1115,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
       if (cx.l == 0) printf("TRACE it %d ncon %d nB %d gnorm %g anorm %g gblk %g %g sblk %g %g changed %d alpha %g sn %g qn %g exact %d done %d u %g %g %g v %g %g %g D %g\n", it, ncon, nB, gnorm, anorm, g14, g15, s14, s15, (int)changed, alpha, sn, qn, (int)exact, (int)done, u[0][0], u[0][1], u[0][2], v[0][0], v[0][1], v[0][2], cD[0]);
     }
 #endif
-    if (exact && K.trust_exact) done = true;
+    if (exact && ant_u(cx, K).trust_exact) done = true;
     if (changed && alpha * alpha * sn <= MZ_NEWTON_STALL * MZ_NEWTON_STALL * qn) done = true;  // stationary at fp32 resolution (ant_dyn.h ant_solve)
     cx.tick(s, 7);
     it++;
@@ -1071,7 +1123,7 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
   if (isdof) s.qacc[ri] = qacc;
   if (cx.l == 0) {
     s.iters = it;
-    if (it >= K.max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER;
+    if (it >= ant_u(cx, K).max_iter && !done) s.status |= MZ_STATUS_SOLVER_MAXITER;
     if constexpr (PROF) s.prof[15] += (unsigned)it;  // (part 2 of the scratch block: instrumented builds only)
 #ifdef MZ_EXP_STAMPS  // (tools/exp_launch_stamps.py) lock-step iterations of the wave | contact-evaluations of this env, over the step
     s.red[2] += (float)it; s.red[3] += (float)ncon;

@@ -29,7 +29,7 @@ template <int G, bool PROF = false>
 struct DevCtx {
   static constexpr int nlanes = G;
   static constexpr bool row_solver = G >= 16;  // plain ant: Newton iteration resident in one 16-lane DPP row (ant_newton_rows.h)
-  static constexpr int NLC = 14;
+  static constexpr int NLC = 32;
   int l;
   float lc[NLC] = {};  // per-lane constants of the plain ant's quad layout (ant_forward_rows.h ant_lane_consts); unused elsewhere
   bool mfma = false;   // the row solver's Hessian fold on the matrix cores (ant_newton_rows.h fold_h_mfma): set by the kernel, a compile-time constant after inlining

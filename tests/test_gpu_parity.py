@@ -295,12 +295,12 @@ def test_ant_lane_group_widths_agree(torch, oracle):
 
 @pytest.mark.parametrize("env_id,n", [("AntUMaze-v0", 256), ("AntPush-v0", 128), ("AntMultiPush-v0", 64)])
 def test_ant_unit_steps_then_exact_search_changes_nothing(torch, env_id, n):
-    """Option "ls_fast_iterations" (default 3: the first three Newton iterations of a solve take the unit step, the exact line search
+    """Option "ls_fast_iterations" (default 5: the first five Newton iterations of a solve take the unit step, the exact line search
     of MuJoCo's Newton solver — engine_solver.c mj_solNewton / PrimalSearch — only behind them): a converged solve does not depend on
     the way there.  The same states stepped with the search in every iteration (0) and with the default agree to fp32 round-off, and
     no env runs into the iteration cap; row solver (plain ant, one block) and lane-group solver (two blocks)."""
     envs = []
-    for fast in (0, 3):
+    for fast in (0, 5):
         env = mm.make(env_id, num_envs=n)
         env.set_option("ls_fast_iterations", fast)
         env.reset(seed=5)
