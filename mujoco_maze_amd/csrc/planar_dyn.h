@@ -20,6 +20,11 @@
 #pragma once
 #include "ant_dyn.h"    // MZ_FOR, HostCtx, maze_row
 #include "point_dyn.h"  // PointDev, point_detect, pt_impedance
+// Newton iterations of a solve that take the unit step before the exact line search takes over (round 5; measured on PointUMaze /
+// PointPush, tools/gpu_point.sh)
+#ifndef MZ_PL_UNIT_STEPS
+#define MZ_PL_UNIT_STEPS 5
+#endif
 
 template <int NB, int NS>
 struct PlanarDims {
@@ -816,8 +821,8 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     changed = cx.gany(changed);
     double lo = 0.0, hi = -1.0, alpha = 1.0, prev_d2 = -1.0;
     double p1 = 0.0, p2 = 0.0;
-    if (changed) { p1 = cx.gsum(p1p); p2 = cx.gsum(p2p); }
-    for (int ls = 0; ls < 30 && changed; ls++) {
+    if (changed && it >= MZ_PL_UNIT_STEPS) { p1 = cx.gsum(p1p); p2 = cx.gsum(p2p); }
+    for (int ls = 0; ls < 30 && changed && it >= MZ_PL_UNIT_STEPS; ls++) {  // (unit steps first: point_bare.h / ant_newton_rows.h)
       double d1 = 0.0, d2 = 0.0;
       MZ_FOR(c, ncon) {
         double Dc = s.cD[c], v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];
