@@ -531,7 +531,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
     }
   }
   cx.tick(s, 11);
-  return ant_solve_rows_core<NB, G, PROF, true>(cx, K, s, first, Mrow, qfs, Sax);  // qacc of this lane's dof
+  return ant_solve_rows_core<NB, G, PROF, true>(cx, K, s, first, Mrow, qfs, Sax, bsel(m0, qh, qa), bsel(m0, qdh, qda));  // qacc of this lane's dof
 }
 
 // One mj_step with RK4 (ant_mj_step of ant_dyn.h) on the quad layout: every dof lane keeps its own velocity, the RK4
