@@ -84,7 +84,11 @@ struct AntDims {
   static constexpr int NQ = 15 + (BALL ? 7 : BD * NBLK);
   static constexpr int NCOL = NH + 2;      // contact Jacobian columns: hub, hip, ankle
   // contact slots: a block resting in a corridor holds 4 floor corners + 4 per adjacent wall/block face
-  static constexpr int NC = NB == 0 ? 16 : (NB == 1 ? 40 : NB == 5 ? 28 : ((NB == 2 || NB == 4) ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each); NB = 4: a three-slide block between platforms, walls and the floor filled 28 in long rollouts
+  static constexpr int NC = NB == 0 ? 16 : (NB == 1 ? 32 : NB == 5 ? 28 : ((NB == 2 || NB == 4) ? 40 : 72));  // NB = 2: 40 keeps 8 one-env workgroups per CU (20 KB each); NB = 4: a three-slide block between platforms, walls and the floor filled 28 in long rollouts
+  // NB = 1: 32 since round 5 (40 before) — the block's own contacts are merged entries now (a block on the floor against two walls: 3,
+  // not 12), and 32 slots make an env's LDS block 9.9 KB: FOUR 16-lane waves (16 envs) fit a CU's 160 KB, so that batches beyond
+  // 2048 envs run the one-block ant at 16 lanes per env in one round (ant_kernels.hip ant_lanes; AntPush 4096 envs 5.4 -> 8.6 M
+  // env-steps/s).  Soak at 32 slots: 2 x (61 M + 15 M) env-steps of AntPush / AntFall, no CONTACT_OVERFLOW (tools/exp_push_nc.sh).
   static constexpr int NGEOM = 13 + NMOV;  // contact enumerators: movable bodies first, then the 13 robot geoms
   static constexpr int NHESS = NH * NH + 8 * NH + 12;
   static constexpr int NTRI = NH * (NH + 1) / 2;

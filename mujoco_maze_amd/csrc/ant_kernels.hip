@@ -325,10 +325,7 @@ __global__ void ant_get_state_kernel(AntLayout L, int n, const float* state, flo
 
 // the two-waves-per-SIMD instantiation (WPS = 2) exists for the 16-lane plain ant; taken when the launch has more waves than the
 // device has SIMDs (4 per compute unit), or as option "waves_per_simd" says (1 / 2; 0 = by the wave count)
-template <int NB, int G>
-static bool ant_two_waves(const mz_handle* h, int waves) {
-  if (!(NB == 0 && G == 16)) return false;
-  if (h->waves_per_simd) return h->waves_per_simd == 2;
+static int device_simds(const mz_handle* h) {  // 4 per compute unit
   static int simds[32] = {};
   const int dv = h->device & 31;
   if (!simds[dv]) {
@@ -336,7 +333,13 @@ static bool ant_two_waves(const mz_handle* h, int waves) {
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cu <= 0) cu = 256;
     simds[dv] = 4 * cu;
   }
-  return waves > simds[dv];
+  return simds[dv];
+}
+template <int NB, int G>
+static bool ant_two_waves(const mz_handle* h, int waves) {
+  if (!(NB == 0 && G == 16)) return false;
+  if (h->waves_per_simd) return h->waves_per_simd == 2;
+  return waves > device_simds(h);
 }
 template <int NB, int G>
 static hipError_t launch_ant_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
@@ -432,7 +435,13 @@ static int ant_lanes(const mz_handle* h) {
   // 12.8 / 13.4 / 13.8 M env-steps/s at 16 lanes against 11.6 / 12.4 / 13.1 M at 32)
   // (round 4, tried: 16 lanes for the one-block ant from 4096 envs on — no gain at 4096 (four envs per wave need 47 KB of LDS: three
   // waves per CU, two rounds), 6.2 against 5.0 M at 8192; and one env in 4096 then sits 2.5e-5 off the oracle: not taken)
-  return h->lanes_set ? h->lanes : (NB == 1 ? 32 : (NB ? 64 : 16));
+  // Round 5: 16 lanes for the one-block ant as soon as 32 lanes would mean more waves than SIMDs (beyond 2048 envs on a 256-CU
+  // device): with 32 contact slots four 16-lane waves fit a CU's LDS (AntDims::NC), and the iterative refinement of the accepted
+  // Newton step (ant_newton_rows.h) closed the parity gap noted above.  AntPush 4096 / 8192 envs: 5.4 / 5.8 -> 8.6 / 9.4 M
+  // env-steps/s, AntFall 4.5 / 4.8 -> 7.3 / 8.0 M (profiles/r05/push_nc.txt); 2048 envs (BASELINE config 5) stay at 32 lanes.
+  if (h->lanes_set) return h->lanes;
+  if (NB == 1) return h->n / 2 > device_simds(h) ? 16 : 32;
+  return NB ? 64 : 16;
 }
 template <int NB>
 static hipError_t dispatch_ant_forward(mz_handle* h, hipStream_t st, const float* a, float* qacc, int* counts) {

@@ -325,6 +325,38 @@ def test_ant_unit_steps_then_exact_search_changes_nothing(torch, env_id, n):
         env.close()
 
 
+@pytest.mark.parametrize("env_id", ["AntPush-v0", "AntFall-v0"])
+def test_one_block_ant_beyond_2048_envs_takes_16_lanes(torch, oracle, env_id):
+    """A batch of the one-block ant with more waves at 32 lanes per env than the device has SIMDs runs at 16 lanes (ant_kernels.hip
+    ant_lanes; four such waves fit a CU's LDS with the 32 contact slots of AntDims<1>): the default of a 2048 + 64-env handle against
+    the oracle on rollout states, and the same states through an explicit 16- and 32-lane handle — the default must be bit for bit the
+    16-lane one (the instantiation it selects), and that within round-off of the 32-lane one."""
+    n = 2048 + 64
+    outs = {}
+    for lanes in (0, 16, 32):
+        env = mm.make(env_id, num_envs=n, auto_reset=True)
+        if lanes:
+            env.set_option("lanes_per_env", lanes)
+        cm = env.model
+        st = _rollout_states(oracle, cm, n, 21, {20})[20]
+        act = np.random.default_rng(9).uniform(-30, 30, (n, 8)).astype(np.float32)
+        ref_state = {k: v.copy() for k, v in st.items()}
+        oracle.step(cm, ref_state, act.astype(np.float64), nthreads=8)
+        env.set_state(st["qpos"], st["qvel"], st["warm"], st["t"])
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
+        qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
+        ok = _assert_step_parity(oracle, cm, st, act, qpos, qvel, ref_state, max_outlier_frac=0.006)
+        outs[lanes] = (qpos.copy(), qvel.copy(), done.cpu().numpy().copy(), ok)
+        g = torch.Generator(device=env.device).manual_seed(3)
+        for _ in range(40):
+            env.step(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30)
+        assert np.all((env.status().cpu().numpy() & 7) == 0)
+        env.close()
+    assert np.array_equal(outs[0][0], outs[16][0]) and np.array_equal(outs[0][1], outs[16][1])
+    both = outs[16][3] & outs[32][3]
+    assert np.all(_close(outs[16][1][both], outs[32][1][both], atol=1e-5)) and np.array_equal(outs[16][2][both], outs[32][2][both])
+
+
 def test_ant_two_waves_per_simd_kernel(torch, oracle):
     """The plain ant's second instantiation (ant_kernels.hip: WPS = 2, held to 256 registers so that two waves share a SIMD, its Hessian
     fold on the matrix cores: v_mfma_f32_16x16x1_4b_f32; taken beyond 4096 envs, or by option "waves_per_simd") against the oracle and
