@@ -264,6 +264,15 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
     cx.l = ll;
     ant_lane_consts(K, cx);
   }
+  else if constexpr (NB == 0) {
+    // (round 5) the plain ant's one-wave kernel: the lane index opaque per evaluation, so that the lane predicates (role masks, `r == P`
+    // ...) are compared again inside each evaluation instead of being carried through the step in scalar-register pairs the kernel does
+    // not have — v_readlane 371 -> 130, v_writelane 196 -> 85 in the kernel, 0.2455 -> 0.2443 ms.  (The one-block kernel at 32 lanes
+    // loses 1.7 % with it: not there.)
+    int ll = cx_step.l;
+    asm volatile("" : "+v"(ll));
+    cx.l = ll;
+  }
   using C = DevCtx<G, PROF>;  // (MZ_FOR)
   using D = AntDims<NB>;
   constexpr int NC = D::NC, NR = 14 + 2 * NB;
