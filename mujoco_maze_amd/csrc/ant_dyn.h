@@ -880,11 +880,11 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
     return;
   }
   // MuJoCo's half axis: the geom z axis of a fromto capsule points from `to` to `from`, i.e. along -ax
-  const float h[3] = {-ax[0] * hl, -ax[1] * hl, -ax[2] * hl};
+  const float hh[3] = {-ax[0] * hl, -ax[1] * hl, -ax[2] * hl};
   float em[3], ep[3];
   bool in_m = true, in_p = true;
   for (int k = 0; k < 3; k++) {
-    em[k] = cl[k] - h[k]; ep[k] = cl[k] + h[k];
+    em[k] = cl[k] - hh[k]; ep[k] = cl[k] + hh[k];
     in_m = in_m && fabsf(em[k]) <= bs[k]; in_p = in_p && fabsf(ep[k]) <= bs[k];
   }
 #ifndef MZ_EXP_NOFACEPATH
@@ -933,6 +933,19 @@ MZ_HD void round_vs_box(bool sphere, const float* ctr, const float* ax, float hl
 #endif
 #if defined(MZ_EXP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
   atomicAdd(&mz_exp_general_runs, 1u);
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MZ_EXP_NOLAUNDER)
+  // Keep the general case's arithmetic BEHIND its branch (round 5): the wall loop of the forward pass calls this once per candidate
+  // cell, and everything below that does not depend on the cell — reciprocals of the axis, its products, two dozen comparison masks —
+  // was hoisted in front of that loop by the compiler, i.e. executed by every geom that reached the loop at all, 98.6 % of which
+  // leave through the face case above (ISA: ~300 instructions between the candidate scan and the loop's first pass; cycle stamps
+  // around the region: 3 500 per narrow-phase run).  Values that pass through an empty asm are defined here, not before the loop.
+  float h_[3] = {hh[0], hh[1], hh[2]};
+#pragma unroll
+  for (int k = 0; k < 3; k++) asm volatile("" : "+v"(cl[k]), "+v"(em[k]), "+v"(ep[k]), "+v"(h_[k]));
+  const float* const h = h_;
+#else
+  const float* const h = hh;
 #endif
   float t, boxpos = 0.f;
   int type = 0, clface = -1, cledge = 0, corner = 0;

@@ -152,6 +152,9 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const AntU&
     const uint32_t cols2 = ((j0 >= 0 && j0 < z.cols) ? 1u << j0 : 0u) | ((j1 != j0 && j1 >= 0 && j1 < z.cols) ? 1u << j1 : 0u);
     if (!(rows2 & cols2)) return;
   }
+#ifdef MZ_EXP_STAMPS  // cycles the wave spends between here and the end of the narrow phase (booked by the first active lane, on its env)
+  const unsigned long long exp_t0 = __builtin_amdgcn_s_memtime();
+#endif
   // the surviving boxes as bit sets (bit 4 (i - i0) + (j - j0): up to 8 x 4 cells, row-major = MuJoCo's geom order of the maze's
   // boxes; per cell the platform before the wall), then one cell per pass — lanes with one candidate each meet in the same pass
   // instead of each waiting for the other's position in a loop nest
@@ -214,6 +217,12 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const AntU&
     candw = 0u; candp = 0u;
 #endif
   }
+#ifdef MZ_EXP_STAMPS
+  {
+    const unsigned long long act = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(const_cast<int*>(&s.bkey[2]), (int)(__builtin_amdgcn_s_memtime() - exp_t0));
+  }
+#endif
 }
 
 }  // namespace rows

@@ -17,6 +17,7 @@ nw = (n + 3) // 4
 rows = []
 feats = []
 gen_total, run_total = [], []
+cyc_rows = []
 for i in range(200):
     env.step(pool[i % 32])
     w = env.wave_phase_cycles(nw).astype(np.int64)
@@ -24,6 +25,7 @@ for i in range(200):
     its, ncs = w[:, 4].astype(float), w[:, 5].astype(float)
     dur = (en - st).astype(float)
     gen_total.append(int(w[:, 9].max())); run_total.append(int(w[:, 6].sum()))
+    cyc_rows.append(np.stack([w[:, 10].astype(float), w[:, 6].astype(float)], 1))
     feats.append(np.stack([dur, its, ncs, w[:, 6].astype(float), w[:, 7].astype(float), w[:, 8].astype(float)], 1))
     t0 = st.min()
     last = int(np.argmax(en))
@@ -54,3 +56,9 @@ for lo, hi in ((0, 45), (45, 60), (60, 80), (80, 120), (120, 1000)):
     m = (ncs >= lo) & (ncs < hi)
     if m.sum(): print(f"     waves whose busiest env has {lo:3d}-{hi:3d} contact-evaluations per step: {100 * m.mean():5.1f} %  duration mean {dur[m].mean():.1f} us  iterations {its[m].mean():.1f}")
 print(f"  capsule / sphere tests against wall boxes over the 200 launches: {sum(run_total)}, of which capsule tests outside the face case: {gen_total[-1] - gen_total[0] + 0} (device-wide counter, first to last launch)")
+
+cr = np.concatenate(cyc_rows)
+m = cr[:, 1] > 0
+if m.any():
+    print(f"  shader cycles between the cell early-out and the end of the narrow phase (waves with runs): {cr[m, 0].sum() / cr[m, 1].sum():.0f} per run "
+          f"(= {cr[m, 0].sum() / cr[m, 1].sum() / 2400:.2f} us at 2.4 GHz); waves without a run but past the early-out: mean {cr[~m, 0].mean():.0f} cycles per step")
