@@ -529,7 +529,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
 #ifdef MZ_EXP_STAMPS
   if (over && p == 0) s.bkey[1] += 1;
 #endif
-  if (cx.any(over)) {
+  if (cx.any(over)) {  // (compiled out as a timing experiment, round 5: no faster — nothing of this block is paid by the waves that skip it)
     // Fall-back (rare: some geom of some env of this wave found more than three contacts): publish the kinematics the lane-group
     // contact code of ant_dyn.h reads, and let the envs concerned enumerate the two-pass way.
     if (isgeom && j < 3) { const int b = 3 * l + (j == 2 ? 0 : j + 1); for (int k = 0; k < 3; k++) { s.com[b][k] = com[k]; s.w[b][k] = w[k]; } }
