@@ -185,7 +185,7 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const AntU&
 #pragma unroll
       for (int qi = 0; qi < 2; qi++) {
         const int i = qi ? i1 : i0;
-        const uint32_t row = layer ? maze_row_lds(s, i) : plat_row_lds(s, i);
+        const uint32_t row = layer ? maze_row_lds(s, i) : plat_row_lds(s, i);  // (kept from the early-out's reads, tried: neutral)
 #pragma unroll
         for (int qj = 0; qj < 2; qj++) {
           const int j = qj ? j1 : j0;
@@ -203,6 +203,12 @@ __device__ __forceinline__ void robot_geom_contacts(const AntDev& K, const AntU&
     }
 #ifdef MZ_EXP_NOWALL  // timing experiment (wrong physics): no wall narrow phase at all
   candw = 0u; candp = 0u;
+#endif
+#ifdef MZ_EXP_STAMPS  // cycles of the candidate scan alone (same booking as below)
+  {
+    const unsigned long long act = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(const_cast<int*>(&s.bkey[3]), (int)(__builtin_amdgcn_s_memtime() - exp_t0));
+  }
 #endif
   while (candw | candp) {
 #ifdef MZ_EXP_STAMPS  // (NB = 0 only: bkey is free there) narrow-phase runs of this env over the step

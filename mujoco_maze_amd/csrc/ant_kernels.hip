@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
   if (cx.l == 0) { iout_s[2] = ((const int*)rec)[D::REC_T]; iout_s[3] = ((const int*)rec)[D::REC_T + 1]; }  // t, episode: parked in LDS for the step
   if constexpr (PROF) { if (cx.l == 0) { for (int k = 0; k < 16; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
 #ifdef MZ_EXP_STAMPS
-  if (cx.l == 0) { s.red[2] = 0.f; s.red[3] = 0.f; s.bkey[0] = 0; s.bkey[1] = 0; s.bkey[2] = 0; }
+  if (cx.l == 0) { s.red[2] = 0.f; s.red[3] = 0.f; s.bkey[0] = 0; s.bkey[1] = 0; s.bkey[2] = 0; s.bkey[3] = 0; }
 #endif
   cx.sync();
   ant_env_step<NB>(cx, K, s, act_s, obs_s, &out_s[0], (uint8_t*)&iout_s[0], &iout_s[1], &out_s[1], &iout_s[2]);
@@ -208,13 +208,14 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
       unsigned long long* w = prof + 16 + n + (size_t)blockIdx.x * 16;
       w[0] = stamp0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = hwid; w[3] = xcc;
       float mx = 0.f;
-      int npass = 0, nover = 0, pmax = 0, ncyc = 0;
+      int npass = 0, nover = 0, pmax = 0, ncyc = 0, nscan = 0;
       for (int q = 0; q < 64 / G; q++) {
         const AntScratchT<NB>& sq = *reinterpret_cast<const AntScratchT<NB>*>(lds_raw + (size_t)q * EB);
         mx = fmaxf(mx, sq.red[3]);
-        npass += sq.bkey[0]; nover += sq.bkey[1]; pmax = sq.bkey[0] > pmax ? sq.bkey[0] : pmax; ncyc += sq.bkey[2];
+        npass += sq.bkey[0]; nover += sq.bkey[1]; pmax = sq.bkey[0] > pmax ? sq.bkey[0] : pmax; ncyc += sq.bkey[2]; nscan += sq.bkey[3];
       }
       w[9] = (unsigned long long)mz_exp_general_runs;  // (device-wide running total)
+      w[11] = (unsigned long long)nscan;  // ... of which the candidate scan
       w[10] = (unsigned long long)ncyc;  // shader cycles between the cell early-out and the end of the narrow phase, summed over the step
       w[6] = (unsigned long long)npass; w[7] = (unsigned long long)nover; w[8] = (unsigned long long)pmax;
       w[4] = (unsigned long long)s.red[2]; w[5] = (unsigned long long)mx;  // lock-step Newton iterations of the wave; most contact-evaluations among its envs

@@ -25,7 +25,7 @@ for i in range(200):
     its, ncs = w[:, 4].astype(float), w[:, 5].astype(float)
     dur = (en - st).astype(float)
     gen_total.append(int(w[:, 9].max())); run_total.append(int(w[:, 6].sum()))
-    cyc_rows.append(np.stack([w[:, 10].astype(float), w[:, 6].astype(float)], 1))
+    cyc_rows.append(np.stack([w[:, 10].astype(float), w[:, 6].astype(float), w[:, 11].astype(float)], 1))
     feats.append(np.stack([dur, its, ncs, w[:, 6].astype(float), w[:, 7].astype(float), w[:, 8].astype(float)], 1))
     t0 = st.min()
     last = int(np.argmax(en))
@@ -61,4 +61,4 @@ cr = np.concatenate(cyc_rows)
 m = cr[:, 1] > 0
 if m.any():
     print(f"  shader cycles between the cell early-out and the end of the narrow phase (waves with runs): {cr[m, 0].sum() / cr[m, 1].sum():.0f} per run "
-          f"(= {cr[m, 0].sum() / cr[m, 1].sum() / 2400:.2f} us at 2.4 GHz); waves without a run but past the early-out: mean {cr[~m, 0].mean():.0f} cycles per step")
+          f"(= {cr[m, 0].sum() / cr[m, 1].sum() / 2400:.2f} us at 2.4 GHz); waves without a run but past the early-out: mean {cr[~m, 0].mean():.0f} cycles per step; of the region, the candidate scan: {100 * cr[m, 2].sum() / cr[m, 0].sum():.0f} % in waves with runs")
