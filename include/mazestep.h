@@ -251,7 +251,7 @@ int32_t mz_nu(const mz_handle* h);
  * sharded run: keys the reset RNG), "solver_iterations", "solver_tolerance", "solver_rtol",
  * "ls_iterations" (Ant solver: evaluations of the exact line search), "ls_fast_iterations" / "ls_fast" (the first n Newton
  * iterations of a solve search the line with at most that many evaluations; defaults 5 / 0: unit steps), "lanes_per_env" (8/16/32/64 lanes of a wavefront per environment; defaults: plain Ant 16,
- * Ant with one movable block 32 — 16 for batches beyond 2048 envs, where 32 would mean more waves than the device has SIMDs —, with more blocks / a three-slide block / the ball 64; Point 32, with two or three blocks 64;
+ * Ant with one movable block 32 — 16 for batches beyond 2048 envs, where 32 would mean more waves than the device has SIMDs —, with more blocks / a three-slide block / the ball 64; Point 16 while that leaves every wave a SIMD of its own (up to 4096 envs), else 32; with one block or the ball 32, with two or three blocks 64;
  * Swimmer / Reacher 4, fixed), "waves_per_block" (1/2/4, Ant), "waves_per_simd" (plain Ant at 16 lanes: 1 = the one-wave
  * kernel, 2 = the kernel held to 256 registers so that two waves share a SIMD, 0 = default: by the wave count of the
  * launch — more waves than SIMDs takes the second), "profile_phases" (0/1: instrumented Ant kernel, see

@@ -406,11 +406,28 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
                      obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev, h->status, h->auto_reset, h->seed, h->env0, h->final_obs, h->model.obs_dim)
   if (h->point.nball) MZ_PLANAR_LAUNCH(0, 1, 32);
   else switch (h->point.nblock) {
-    case 0:
-      if (h->lanes_set && h->lanes == 8) MZ_PLANAR_LAUNCH(0, 0, 8);
-      else if (h->lanes_set && h->lanes == 16) MZ_PLANAR_LAUNCH(0, 0, 16);
+    case 0: {
+      // Round 5: 16 lanes per env by default while that still gives every wave a SIMD of its own (up to 4096 envs on a 256-CU device).
+      // Round 3 measured the opposite (34.8 against 31.6 M at 32 lanes: two envs per wave and a second wave to fill the gaps); with
+      // the step in registers (point_bare.h) and the unit-step solver the waves are short and even enough that four envs per wave on
+      // a SIMD of their own win: PointUMaze 4096 envs 74.3 -> 79.6 M env-steps/s, Point4Rooms 79.6 -> 82.6 M; beyond (8192 envs:
+      // 108.0 at 32 lanes against 106.3) it stays at 32 (profiles/r05/point_knobs.txt).
+      int lanes = h->lanes_set ? h->lanes : 0;
+      if (!lanes) {
+        static int simds[32] = {};
+        const int dv = h->device & 31;
+        if (!simds[dv]) {
+          int cu = 0;
+          if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cu <= 0) cu = 256;
+          simds[dv] = 4 * cu;
+        }
+        lanes = (h->n + 3) / 4 <= simds[dv] ? 16 : 32;
+      }
+      if (lanes == 8) MZ_PLANAR_LAUNCH(0, 0, 8);
+      else if (lanes == 16) MZ_PLANAR_LAUNCH(0, 0, 16);
       else MZ_PLANAR_LAUNCH(0, 0, 32);
       break;
+    }
     case 1: MZ_PLANAR_LAUNCH(1, 0, 32); break;
     case 2: MZ_PLANAR_LAUNCH(2, 0, 64); break;
     default: MZ_PLANAR_LAUNCH(3, 0, 64); break;
