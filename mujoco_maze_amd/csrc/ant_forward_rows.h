@@ -573,23 +573,29 @@ __device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, cons
   const int p = cx.l & 15;
   const bool isdof = p < NR;
   const int i = isdof ? pos2dof(p) : 0;              // this lane's dof
-  MZ_FOR(k, D::NQ) s.x0q[k] = s.qpos[k];
-  MZ_FOR(k, D::NLO) s.x0lo[k] = s.qlo[k];
+  // (round 5) the frame's start state stays in registers — every dof lane its own coordinate and that coordinate's low part, every
+  // lane the quaternion — instead of the x0q / x0lo copies in LDS: 17 loads + 17 stores + a hand-off per frame and two waits per RK4
+  // stage less (A / B: 0.2403 -> 0.2365 ms)
+  // (the two-waves-per-SIMD instantiation pays ~1 % for the six live registers — 8192 envs 24.3 -> 24.0 M; keeping its LDS copies behind
+  // `cx.mfma` left the one-wave kernel 2 % slower than this plain form, A / B in one call: 0.2421 against 0.2367 ms)
+  const int qi_ = !isdof ? 0 : (i < 3 ? i : (i >= 6 ? i + 1 : 0)), li_ = !isdof ? 0 : (i < 2 ? i : (i >= 14 ? 2 + (i - 14) : 0));
+  const float x0c = s.qpos[qi_], x0l = s.qlo[li_ < D::NLO ? li_ : 0];
+  const float q0[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
   const float x0v = isdof ? s.qvel[i] : 0.f;
   float qvel = x0v, accv = 0.f, accf = 0.f;
   cx.sync();
-  // position update of this lane's coordinate from the frame's start: qpos <- integrate(x0q, vel, h) (mj_integratePos)
+  // position update of this lane's coordinate from the frame's start: qpos <- integrate(x0, vel, h) (mj_integratePos)
   auto integrate = [&](float vel) {
     const float w0 = bcast<7>(vel), w1 = bcast<10>(vel), w2 = bcast<11>(vel);  // root angular dofs 3, 4, 5 sit on lanes 7, 10, 11
     float quat[4];
     const float w[3] = {w0, w1, w2};
-    quat_integratef(s.x0q + 3, w, h, quat);
+    quat_integratef(q0, w, h, quat);
     if (p == 7) { s.qpos[3] = quat[0]; s.qpos[4] = quat[1]; s.qpos[5] = quat[2]; s.qpos[6] = quat[3]; }
     if (isdof) {
-      if (i < 2) mz_step_split(s.x0q[i], s.x0lo[i], h, vel, &s.qpos[i], &s.qlo[i]);       // absolute x, y: hi + lo (AntScratchT::qlo)
-      else if (i == 2) s.qpos[2] = s.x0q[2] + h * vel;
-      else if (i >= 6 && i < 14) s.qpos[i + 1] = s.x0q[i + 1] + h * vel;                   // hinges: qpos index = dof + 1
-      else if (i >= 14) mz_step_split(s.x0q[i + 1], s.x0lo[2 + (i - 14)], h, vel, &s.qpos[i + 1], &s.qlo[2 + (i - 14)]);  // block slides
+      if (i < 2) mz_step_split(x0c, x0l, h, vel, &s.qpos[i], &s.qlo[i]);                        // absolute x, y: hi + lo (AntScratchT::qlo)
+      else if (i == 2) s.qpos[2] = x0c + h * vel;
+      else if (i >= 6 && i < 14) s.qpos[i + 1] = x0c + h * vel;                                 // hinges: qpos index = dof + 1
+      else if (i >= 14) mz_step_split(x0c, x0l, h, vel, &s.qpos[i + 1], &s.qlo[2 + (i - 14)]);  // block slides
     }
   };
   for (int st = 0; st < 4; st++) {
