@@ -1928,12 +1928,17 @@ MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base,
   }
 }
 
+// (the quad layout's step, ant_forward_rows.h: device builds only — declared here so that the host emulation, which never takes that
+// branch, can parse the call with its explicit template arguments)
+template <int NB, bool XREG, class C>
+MZ_HD void ant_mj_step_rows(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame);
 // one mj_step with RK4.  State in s.qpos / s.qvel / s.warm, actuator forces in s.fact.
 template <int NB, class C>
 MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame) {
   using D = AntDims<NB>;
   if constexpr (NB <= 1 && C::row_solver) {  // the quad layout: RK4 bookkeeping in the dof lanes' registers (ant_forward_rows.h)
-    ant_mj_step_rows(cx, K, s, first_frame);
+    if (cx.mfma) ant_mj_step_rows<NB, false>(cx, K, s, first_frame);  // (a constant after inlining: one of the two survives)
+    else ant_mj_step_rows<NB, true>(cx, K, s, first_frame);
     return;
   }
   const float h = K.h;

@@ -563,7 +563,7 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
 // it — and writes only what the next evaluation reads (qpos, qvel, the solver's warm start) to LDS: one hand-off per stage instead
 // of three.  The free joint's quaternion is advanced redundantly by every lane (the three body-frame rates come by row
 // broadcast) and stored by one.
-template <int NB, int G, bool PROF>
+template <int NB, bool XREG, int G, bool PROF>
 __device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame) {
   using namespace rows;
   using C = DevCtx<G, PROF>;  // (MZ_FOR)
@@ -576,11 +576,18 @@ __device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, cons
   // (round 5) the frame's start state stays in registers — every dof lane its own coordinate and that coordinate's low part, every
   // lane the quaternion — instead of the x0q / x0lo copies in LDS: 17 loads + 17 stores + a hand-off per frame and two waits per RK4
   // stage less (A / B: 0.2403 -> 0.2365 ms)
-  // (the two-waves-per-SIMD instantiation pays ~1 % for the six live registers — 8192 envs 24.3 -> 24.0 M; keeping its LDS copies behind
-  // `cx.mfma` left the one-wave kernel 2 % slower than this plain form, A / B in one call: 0.2421 against 0.2367 ms)
+  // XREG = false: the two-waves-per-SIMD instantiation keeps the LDS copies (six more live registers sent its 256-register budget to
+  // scratch: 8192 envs, WRITE + FETCH 5.3 -> 11.8 MB per launch).  A compile-time switch: the same choice behind the run-time constant
+  // `cx.mfma` left the one-wave kernel 2 % slower than the plain register form (A / B in one call: 0.2421 against 0.2367 ms).
   const int qi_ = !isdof ? 0 : (i < 3 ? i : (i >= 6 ? i + 1 : 0)), li_ = !isdof ? 0 : (i < 2 ? i : (i >= 14 ? 2 + (i - 14) : 0));
-  const float x0c = s.qpos[qi_], x0l = s.qlo[li_ < D::NLO ? li_ : 0];
-  const float q0[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
+  float x0c = 0.f, x0l = 0.f, q0[4] = {1.f, 0.f, 0.f, 0.f};
+  if constexpr (XREG) {
+    x0c = s.qpos[qi_]; x0l = s.qlo[li_ < D::NLO ? li_ : 0];
+    q0[0] = s.qpos[3]; q0[1] = s.qpos[4]; q0[2] = s.qpos[5]; q0[3] = s.qpos[6];
+  } else {
+    MZ_FOR(k, D::NQ) s.x0q[k] = s.qpos[k];
+    MZ_FOR(k, D::NLO) s.x0lo[k] = s.qlo[k];
+  }
   const float x0v = isdof ? s.qvel[i] : 0.f;
   float qvel = x0v, accv = 0.f, accf = 0.f;
   cx.sync();
@@ -589,13 +596,24 @@ __device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, cons
     const float w0 = bcast<7>(vel), w1 = bcast<10>(vel), w2 = bcast<11>(vel);  // root angular dofs 3, 4, 5 sit on lanes 7, 10, 11
     float quat[4];
     const float w[3] = {w0, w1, w2};
-    quat_integratef(q0, w, h, quat);
-    if (p == 7) { s.qpos[3] = quat[0]; s.qpos[4] = quat[1]; s.qpos[5] = quat[2]; s.qpos[6] = quat[3]; }
-    if (isdof) {
-      if (i < 2) mz_step_split(x0c, x0l, h, vel, &s.qpos[i], &s.qlo[i]);                        // absolute x, y: hi + lo (AntScratchT::qlo)
-      else if (i == 2) s.qpos[2] = x0c + h * vel;
-      else if (i >= 6 && i < 14) s.qpos[i + 1] = x0c + h * vel;                                 // hinges: qpos index = dof + 1
-      else if (i >= 14) mz_step_split(x0c, x0l, h, vel, &s.qpos[i + 1], &s.qlo[2 + (i - 14)]);  // block slides
+    if constexpr (XREG) {
+      quat_integratef(q0, w, h, quat);
+      if (p == 7) { s.qpos[3] = quat[0]; s.qpos[4] = quat[1]; s.qpos[5] = quat[2]; s.qpos[6] = quat[3]; }
+      if (isdof) {
+        if (i < 2) mz_step_split(x0c, x0l, h, vel, &s.qpos[i], &s.qlo[i]);                        // absolute x, y: hi + lo (AntScratchT::qlo)
+        else if (i == 2) s.qpos[2] = x0c + h * vel;
+        else if (i >= 6 && i < 14) s.qpos[i + 1] = x0c + h * vel;                                 // hinges: qpos index = dof + 1
+        else if (i >= 14) mz_step_split(x0c, x0l, h, vel, &s.qpos[i + 1], &s.qlo[2 + (i - 14)]);  // block slides
+      }
+    } else {
+      quat_integratef(s.x0q + 3, w, h, quat);
+      if (p == 7) { s.qpos[3] = quat[0]; s.qpos[4] = quat[1]; s.qpos[5] = quat[2]; s.qpos[6] = quat[3]; }
+      if (isdof) {
+        if (i < 2) mz_step_split(s.x0q[i], s.x0lo[i], h, vel, &s.qpos[i], &s.qlo[i]);
+        else if (i == 2) s.qpos[2] = s.x0q[2] + h * vel;
+        else if (i >= 6 && i < 14) s.qpos[i + 1] = s.x0q[i + 1] + h * vel;
+        else if (i >= 14) mz_step_split(s.x0q[i + 1], s.x0lo[2 + (i - 14)], h, vel, &s.qpos[i + 1], &s.qlo[2 + (i - 14)]);
+      }
     }
   };
   for (int st = 0; st < 4; st++) {
