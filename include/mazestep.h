@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZ_ABI_VERSION 7
+#define MZ_ABI_VERSION 8
 
 #define MZ_MAX_BODY 24
 #define MZ_MAX_JNT 24
@@ -110,7 +110,9 @@ typedef struct mz_model {
   int32_t max_episode_steps;    /* gym TimeLimit (mujoco_maze/__init__.py:31) */
   int32_t obs_dim;
   int32_t reset_qvel_kind; /* 0 normal*0.1, 1 U[0,1)*0.1, 2 U(-.1,.1) */
-  int32_t pad0;
+  int32_t engine; /* 0: the robot family's specialised kernels where they can step this model, the general engine (csrc/generic_dyn.h:
+                   * walks the compiled tree; any joints / geoms / movable bodies this struct can describe) where they cannot — SPIN
+                   * plates, user robots, more than three blocks; 1: the general engine whatever the robot (ABI 8) */
   double timestep;
   double gravity[3];
   double density, viscosity;
@@ -183,7 +185,10 @@ typedef struct mz_model {
   uint8_t grid[MZ_MAX_GRID][MZ_MAX_GRID];
   double maze_scale, torso_x, torso_y;
   double wall_half_xy, wall_half_z, wall_center_z; /* box half sizes / centre height */
-  int32_t wall_contype, wall_conaffinity, wall_condim, pad1;
+  int32_t wall_contype, wall_conaffinity, wall_condim;
+  int32_t step_kind; /* the robot's own step (AgentModel.step): 0 = the robot family's; 1 = motors (ant.py:61-73, swimmer.py:37-48: clamped
+                      * motors, forward reward, control cost); 2 = the Point's (point.py:44-61: heading / position moved by the action,
+                      * velocity clip, no control).  Read by the general engine; a user robot picks one (ABI 8) */
   double wall_friction[3];
   double wall_solref[2];
   double wall_solimp[5];

@@ -13,10 +13,14 @@ from typing import Optional
 
 class AgentModel:
     """Subclass it for a robot of your own (reference README.md:127): `ROBOT = "generic"`, `FILE` = path (or text) of its MJCF —
-    free / slide / hinge joints, sphere / capsule geoms without self-collision, motors — plus `FRAME_SKIP` and, optionally,
-    `RESET_QVEL` ("normal" | "uniform01" | "uniform_sym": the reset noise of ant.py / point.py / swimmer.py).  Such a robot is
-    stepped on the device by the generic tree kernel (csrc/generic_dyn.h) with the ant's step shape: clamped motors, forward
-    reward |dxy| / dt, control cost; observation qpos | qvel | t / 1000."""
+    free / ball / slide / hinge joints, sphere / capsule / box geoms (no capsule-capsule pairs: keep the robot's own geoms at
+    conaffinity 0 as the reference assets do), motors — plus `FRAME_SKIP` and, optionally, `RESET_QVEL` ("normal" | "uniform01" |
+    "uniform_sym": the reset noise of ant.py / point.py / swimmer.py) and `STEP`: "motors" (default; the ant's step shape,
+    ant.py:61-73: clamped motors, forward reward |dxy| / dt, control cost) or "point" (point.py:44-61: the action turns and moves
+    the robot, velocities are clipped to `VELOCITY_LIMITS`, no inner reward; with `MANUAL_COLLISION = True` and `RADIUS` the maze's
+    wall bounce of maze_env.py:451-464 follows).  Such a robot is stepped on the device by the general engine
+    (csrc/generic_dyn.h) in any maze — movable blocks, object balls, platforms and SPIN plates included; observation
+    qpos[:3] | observed balls / blocks | qpos[3:] | qvel | t / 1000."""
 
     FILE: str
     ROBOT: str  # key into robots.ROBOTS, or "generic"
@@ -25,6 +29,7 @@ class AgentModel:
     RADIUS: Optional[float] = None
     OBJBALL_TYPE: Optional[str] = None
     FRAME_SKIP: int = 1
+    STEP: str = "motors"
 
 
 class PointEnv(AgentModel):

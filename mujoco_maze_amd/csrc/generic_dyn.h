@@ -1,44 +1,67 @@
-// generic_dyn.h — MazeEnv.step for a robot of ANY tree topology (a user's AgentModel; reference plugin
-// surface mujoco_maze/agent_model.py:12-41, README.md:127 "you can define your own robot"), as lane-group SPMD code in float64.
+// generic_dyn.h — the GENERAL ENGINE: MazeEnv.step for any compiled `mz_model`, as lane-group SPMD code in float64.
 //
-// The specialised kernels (ant_dyn.h, planar_dyn.h, swimmer_dyn.h) hard-wire the reference's four robots.  A robot whose MJCF
-// compiles to another shape — a two-legged ant, a branching swimmer, a hopper — steps here instead of being refused: the
-// kernel walks the kinematic tree of the compiled `mz_model` itself (bodies, joints, dofs, geoms, motors; at most GN_NB bodies,
-// GN_NV dofs).  Slower than the specialised paths by design — tree walks are serial, the mass matrix and the Newton system are
-// dense — but the same physics: what the reference gets from `do_simulation(action, frame_skip)` (ant.py:61-63,
-// swimmer.py:37-39), i.e. frame_skip x mj_step with RK4:
-//   kinematics -> spatial inertias, composite rigid bodies, dense M -> collision (floor plane and maze boxes against the robot's
-//   spheres / capsules; mjc_CapsuleBox as restated in DESIGN.md section 5) -> joint-limit and pyramidal contact rows ->
+// The specialised kernels (ant_dyn.h, planar_dyn.h, swimmer_dyn.h) hard-wire the reference's four robots in the mazes its
+// registry builds.  Everything else the reference's plugin surface admits steps here instead of being refused:
+//   * a user's AgentModel of any tree topology (mujoco_maze/agent_model.py:12-41, README.md:127 "you can define your own robot"):
+//     free / ball / slide / hinge joints, sphere / capsule / box geoms, motors — in any maze, movable bodies included;
+//   * SPIN plates (maze_env.py:119-120,575,649-660, maze_env_utils.py:33,74-75, maze_task.py:67 PUT_SPIN_NEAR_AGENT): a thin box on two
+//     slides and a BALL joint next to the robot — a box of general orientation against floor, walls, blocks and the robot;
+//   * any built-in robot in any maze when the caller asks for it (mz_model.engine = 1): a second, independent device
+//     implementation the specialised kernels are compared with (tests/test_gpu_general_engine.py).
+// The kernel walks the kinematic tree of the compiled model itself (bodies, joints, dofs, geoms, motors; the maze's wall /
+// platform boxes come from the cell grid).  Slower than the specialised paths by design — tree walks are serial, the mass matrix
+// and the Newton system are dense, one wavefront steps one env — but the same physics: what the reference gets from
+// `do_simulation(action, frame_skip)` (ant.py:61-63, swimmer.py:37-39) or from the Point's teleport step (point.py:44-61),
+// i.e. frame_skip x mj_step with RK4:
+//   kinematics -> spatial inertias, composite rigid bodies, dense M -> collision: every geom pair the contype / conaffinity and
+//   parent-child filters admit, and every moving geom against the maze boxes under its bounding square (plane-sphere / -capsule /
+//   -box, sphere-sphere / -capsule / -box, capsule-box = mjc_CapsuleBox, box-box = mjc_BoxBox with its edge-edge case, all as restated
+//   in oracle/mzo_physics.c and DESIGN.md section 5) -> joint-limit and pyramidal contact rows between TWO moving bodies ->
 //   recursive Newton-Euler bias, joint damping, MuJoCo's inertia-box fluid forces, clamped motors -> qacc_smooth (dense
-//   Cholesky) -> primal Newton with exact line search -> RK4 with manifold quaternion update.
-// One env per lane group; its working set (GenScratch, ~32 KB) lives in LDS for the whole step.  Serial tree walks run on the
-// group's first lane, everything indexed by body / dof / geom / constraint row is an MZ_FOR over the lanes.
-//
-// Scope: robot geoms are spheres and capsules, no robot self-collision (contype / conaffinity must exclude it, as in every
-// reference asset), mazes without movable blocks / balls / platforms — gen_dev_from_model refuses the rest by name.
+//   Cholesky) -> primal Newton with exact line search -> RK4 with manifold quaternion update (free and ball joints).
+// Then MazeEnv.step's own part (maze_env.py:448-481): the Point's manual wall bounce (the bit-exact detector of point_dyn.h),
+// the observation with the object balls' / movable blocks' body positions (maze_env.py:351-369), reward and termination.
+// One env per lane group; its working set (GenScratch) lives in LDS for the whole step.  Serial tree walks run on the group's
+// first lane, everything indexed by body / dof / geom / collision item / constraint row is an MZ_FOR over the lanes.
 #pragma once
-#include "ant_dyn.h"  // MZ_FOR, MZ_HD, HostCtx, TaskDev / MazeDev, task_eval_dev
+#include "ant_dyn.h"    // MZ_FOR, MZ_HD, HostCtx, TaskDev / MazeDev, task_eval_dev
+#include "point_dyn.h"  // point_bounce: CollisionDetector.detect + the bounce rule, operation by operation (Point step shape)
 
-#define GN_NB 16  // bodies, world included
-#define GN_NJ 20
-#define GN_NV 20
-#define GN_NQ 24
-#define GN_NG 16
-#define GN_NC 16  // simultaneous contacts
-#define GN_NL 20  // joint-limit rows
-#define GN_STAGE 6  // contacts one geom can hold (a capsule lying in a wall corner on the floor: 2 floor ends + 2 + 2 wall contacts)
+#define GN_NB MZ_MAX_BODY  // bodies, world included
+#define GN_NJ MZ_MAX_JNT
+#define GN_NV MZ_MAX_DOF
+#define GN_NQ MZ_MAX_Q
+#define GN_NG MZ_MAX_GEOM
+#define GN_NI 192   // collision items: geom pairs + one "maze boxes" item per moving geom
+#define GN_POOL 96  // contacts found by the narrow phase in one evaluation (active or within the margin)
+#define GN_NC 64    // simultaneous ACTIVE contacts (rows of the solver)
+#define GN_NL 24    // joint-limit rows
+#define GN_KEY 64   // pool key = item * GN_KEY + emission index inside the item
 
-struct GenPair { double margin, gap, mu, K, B, solimp[5]; int condim, pad; };
+// collision item kinds (geom1 -> geom2 in MuJoCo's order: by type, then by id; the maze boxes are world geoms with ids below
+// every robot geom's)
+enum { GK_PLANE_SPHERE = 0, GK_PLANE_CAPSULE, GK_PLANE_BOX, GK_SPHERE_SPHERE, GK_SPHERE_CAPSULE, GK_SPHERE_BOX, GK_CAPSULE_BOX, GK_BOX_BOX,
+       GK_SPHERE_WALL, GK_CAPSULE_WALL, GK_WALL_BOX };
+// step shapes (mz_model.step_kind; 0 = the robot family's)
+#define GN_STEP_MOTORS 1  // ant.py:61-73 / swimmer.py:37-48: clamped motors, frame_skip x mj_step, forward reward, control cost
+#define GN_STEP_POINT 2   // point.py:44-61: heading += a[1] (wrapped), teleport a[0] along it, velocity clip, no control, no inner reward
+
+struct GenPair { double margin, gap, mu, K, B, solimp[5], tran; int condim, pad; };
+struct GenItem { int kind, g1, g2, b1, b2, pad; GenPair P; };  // g = -1: the maze boxes (world body)
 
 struct GenDev {
   mz_model m;   // the compiled model as it is (float64): read with uniform (scalar) loads
   TaskDev task;
   MazeDev maze;
-  GenPair pf[GN_NG], pw[GN_NG];  // robot geom g against the floor / against a maze box
+  int nitem, step_kind;
+  GenItem item[GN_NI];
   double lim_K[GN_NJ], lim_B[GN_NJ];
   int max_iter, ls_iter;
   double tol, inv_scale;
   int dof_parent[GN_NV];
+  // the Point's manual wall bounce (maze_env.py:451-464): point_bounce reads these three names
+  int nseg, obs_extra;
+  double seg[MZ_MAX_SEG][4], restitution;
 };
 
 static inline int gen_fail(char* err, int n, const char* msg) {
@@ -47,7 +70,7 @@ static inline int gen_fail(char* err, int n, const char* msg) {
 }
 
 static inline void gen_pair(GenPair* p, const mz_model* m, const double* f1, const double* sr1, const double* si1, double mg1, double gp1, int cd1,
-                            const double* f2, const double* sr2, const double* si2, double mg2, double gp2, int cd2) {
+                            const double* f2, const double* sr2, const double* si2, double mg2, double gp2, int cd2, double tran) {
   double sr[2], si[5];
   for (int k = 0; k < 2; k++) sr[k] = 0.5 * (sr1[k] + sr2[k]);
   for (int k = 0; k < 5; k++) si[k] = 0.5 * (si1[k] + si2[k]);
@@ -56,40 +79,82 @@ static inline void gen_pair(GenPair* p, const mz_model* m, const double* f1, con
   p->K = 1.0 / fmax(1e-15, dmax * dmax * tc * tc * dr * dr);
   p->B = 2.0 / fmax(1e-15, dmax * tc);
   for (int k = 0; k < 5; k++) p->solimp[k] = si[k];
-  p->condim = cd1 > cd2 ? cd1 : cd2; p->pad = 0;
+  p->condim = cd1 > cd2 ? cd1 : cd2; p->pad = 0; p->tran = tran;
+}
+
+// does the model need this engine (no specialised kernel steps it)?  mazestep.hip asks before it dispatches.
+static inline int gen_model_needs_general_engine(const mz_model* m) {
+  if (m->robot == MZ_ROBOT_GENERIC || m->engine == 1) return 1;
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MZ_JNT_BALL) return 1;  // SPIN plates
+  if (m->nblock > 3) return 1;
+  for (int k = 0; k < m->nblock; k++)  // a three-slide block (MultiFall's XYZ block) has a specialised kernel for the one-block ant only
+    if (m->body_jntnum[m->block_bodyid[k]] != 2 && !(m->robot == MZ_ROBOT_ANT && m->nblock == 1)) return 1;
+  for (int a = 1; a < m->nblock; a++)  // blocks of several sizes in one maze (half blocks next to full ones)
+    for (int k = 0; k < 3; k++) if (m->geom_size[m->block_geomid[a]][k] != m->geom_size[m->block_geomid[0]][k]) return 1;
+  return 0;
 }
 
 static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, int errlen) {
   memset(g, 0, sizeof(*g));
-  if (m->nbody > GN_NB || m->njnt > GN_NJ || m->nv > GN_NV || m->nq > GN_NQ || m->ngeom > GN_NG)
-    return gen_fail(err, errlen, "generic robot kernel: at most 15 bodies, 20 joints / dofs, 24 coordinates, 16 geoms");
-  if (m->nblock || m->nball || m->elevated || m->top_down_view || m->manual_collision)
-    return gen_fail(err, errlen, "generic robot kernel: mazes with movable blocks, object balls, platforms, a top-down view or the manual wall bounce "
-                                 "are on the device for the built-in robots only");
-  if (m->geom_type[0] != MZ_GEOM_PLANE) return gen_fail(err, errlen, "generic robot kernel: geom 0 must be the floor plane");
-  for (int a = 1; a < m->ngeom; a++) {
-    if (m->geom_type[a] != MZ_GEOM_SPHERE && m->geom_type[a] != MZ_GEOM_CAPSULE)
-      return gen_fail(err, errlen, "generic robot kernel: robot geoms must be spheres or capsules");
-    for (int b = a + 1; b < m->ngeom && !m->collision_predefined; b++) {  // (collision="predefined": no dynamic pairs at all, swimmer.xml:3)
-      const int ba = m->geom_bodyid[a], bb = m->geom_bodyid[b];
-      if (ba == bb || m->body_parent[ba] == bb || m->body_parent[bb] == ba) continue;
-      if ((m->geom_contype[a] & m->geom_conaffinity[b]) || (m->geom_contype[b] & m->geom_conaffinity[a]))
-        return gen_fail(err, errlen, "generic robot kernel: robot self-collision is not implemented (give the robot's geoms conaffinity 0, as the reference assets do)");
-    }
-  }
-  for (int j = 0; j < m->njnt; j++)
-    if (m->jnt_type[j] == MZ_JNT_BALL) return gen_fail(err, errlen, "generic robot kernel: ball joints are not implemented");
+  if (m->nbody > GN_NB || m->njnt > GN_NJ || m->nv > GN_NV || m->nq > GN_NQ || m->ngeom > GN_NG || m->nbody < 2)
+    return gen_fail(err, errlen, "general engine: at most 23 bodies, 24 joints / dofs, 28 coordinates, 24 geoms");
+  if (m->geom_type[0] != MZ_GEOM_PLANE || m->geom_bodyid[0] != 0) return gen_fail(err, errlen, "general engine: geom 0 must be the floor plane on the world body");
   for (int b = 1; b < m->nbody; b++)
-    if (m->body_parent[b] >= b) return gen_fail(err, errlen, "generic robot kernel: bodies must be listed parents first");
+    if (m->body_parent[b] >= b) return gen_fail(err, errlen, "general engine: bodies must be listed parents first");
+  for (int j = 0; j < m->njnt; j++) {
+    if (m->jnt_type[j] == MZ_JNT_BALL && m->jnt_limited[j]) return gen_fail(err, errlen, "general engine: limited ball joints are not implemented");
+    if (m->jnt_type[j] == MZ_JNT_FREE && m->body_jntnum[m->jnt_bodyid[j]] != 1) return gen_fail(err, errlen, "general engine: a free joint must be its body's only joint");
+  }
+  g->step_kind = m->step_kind ? m->step_kind : (m->robot == MZ_ROBOT_POINT ? GN_STEP_POINT : GN_STEP_MOTORS);
+  if (g->step_kind == GN_STEP_POINT && (m->nq < 3 || m->jnt_type[0] != MZ_JNT_SLIDE || m->jnt_type[1] != MZ_JNT_SLIDE || m->jnt_type[2] != MZ_JNT_HINGE || m->nu < 2))
+    return gen_fail(err, errlen, "general engine: the Point's step shape needs a slide-x, slide-y, hinge-z root and two action entries (point.py:44-61)");
+  if (m->manual_collision && m->nseg <= 0) return gen_fail(err, errlen, "general engine: MANUAL_COLLISION without wall segments");
   g->m = *m;
   task_dev_from_model(&g->task, m);
   maze_dev_from_model(&g->maze, m);
-  for (int a = 1; a < m->ngeom; a++) {
-    gen_pair(&g->pf[a], m, m->geom_friction[0], m->geom_solref[0], m->geom_solimp[0], m->geom_margin[0], m->geom_gap[0], m->geom_condim[0],
-             m->geom_friction[a], m->geom_solref[a], m->geom_solimp[a], m->geom_margin[a], m->geom_gap[a], m->geom_condim[a]);
-    gen_pair(&g->pw[a], m, m->geom_friction[a], m->geom_solref[a], m->geom_solimp[a], m->geom_margin[a], m->geom_gap[a], m->geom_condim[a],
-             m->wall_friction, m->wall_solref, m->wall_solimp, m->wall_margin, m->wall_gap, m->wall_condim);
+  // ---- collision items, in the order the oracle walks them (mzo_physics.c collision()): the explicit geom pairs g1 < g2, then
+  // every moving geom against the maze boxes
+  int n = 0;
+  for (int a = 0; a < m->ngeom && !m->collision_predefined; a++)  // (collision="predefined": no dynamic pairs at all, swimmer.xml:3)
+    for (int b = a + 1; b < m->ngeom; b++) {
+      const int ba = m->geom_bodyid[a], bb = m->geom_bodyid[b];
+      if (ba == bb) continue;
+      if (!((m->geom_contype[a] & m->geom_conaffinity[b]) || (m->geom_contype[b] & m->geom_conaffinity[a]))) continue;
+      if (ba != 0 && bb != 0 && (m->body_parent[ba] == bb || m->body_parent[bb] == ba)) continue;  // parent-child filter (not against the world)
+      int g1 = a, g2 = b;
+      if (m->geom_type[g1] > m->geom_type[g2]) { g1 = b; g2 = a; }  // MuJoCo orders a pair by geom type
+      const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+      int kind = -1;
+      if (t1 == MZ_GEOM_PLANE) kind = t2 == MZ_GEOM_SPHERE ? GK_PLANE_SPHERE : t2 == MZ_GEOM_CAPSULE ? GK_PLANE_CAPSULE : t2 == MZ_GEOM_BOX ? GK_PLANE_BOX : -1;
+      else if (t1 == MZ_GEOM_SPHERE) kind = t2 == MZ_GEOM_SPHERE ? GK_SPHERE_SPHERE : t2 == MZ_GEOM_CAPSULE ? GK_SPHERE_CAPSULE : t2 == MZ_GEOM_BOX ? GK_SPHERE_BOX : -1;
+      else if (t1 == MZ_GEOM_CAPSULE) kind = t2 == MZ_GEOM_BOX ? GK_CAPSULE_BOX : -1;
+      else if (t1 == MZ_GEOM_BOX) kind = t2 == MZ_GEOM_BOX ? GK_BOX_BOX : -1;
+      if (kind < 0) return gen_fail(err, errlen, "general engine: a geom pair that can collide has no narrow phase here (capsule-capsule: give the robot's own "
+                                                 "geoms conaffinity 0, as the reference assets do; geom types: plane, sphere, capsule, box)");
+      if (n >= GN_NI) return gen_fail(err, errlen, "general engine: too many geom pairs");
+      GenItem& it = g->item[n++];
+      it.kind = kind; it.g1 = g1; it.g2 = g2; it.b1 = m->geom_bodyid[g1]; it.b2 = m->geom_bodyid[g2]; it.pad = 0;
+      gen_pair(&it.P, m, m->geom_friction[g1], m->geom_solref[g1], m->geom_solimp[g1], m->geom_margin[g1], m->geom_gap[g1], m->geom_condim[g1],
+               m->geom_friction[g2], m->geom_solref[g2], m->geom_solimp[g2], m->geom_margin[g2], m->geom_gap[g2], m->geom_condim[g2],
+               m->body_invweight0[it.b1][0] + m->body_invweight0[it.b2][0]);
+      if (it.P.condim != 1 && it.P.condim != 3) return gen_fail(err, errlen, "general engine: condim must be 1 or 3");
+    }
+  for (int a = 1; a < m->ngeom && !m->collision_predefined; a++) {
+    if (m->geom_bodyid[a] == 0) continue;
+    if (!((m->geom_contype[a] & m->wall_conaffinity) || (m->wall_contype & m->geom_conaffinity[a]))) continue;
+    const int t = m->geom_type[a];
+    if (t != MZ_GEOM_SPHERE && t != MZ_GEOM_CAPSULE && t != MZ_GEOM_BOX) return gen_fail(err, errlen, "general engine: geom types are plane, sphere, capsule, box");
+    if (n >= GN_NI) return gen_fail(err, errlen, "general engine: too many geom pairs");
+    GenItem& it = g->item[n++];
+    const bool box = t == MZ_GEOM_BOX;  // a maze box is geom1 against another box (same type, lower id), geom2 against spheres / capsules
+    it.kind = t == MZ_GEOM_SPHERE ? GK_SPHERE_WALL : t == MZ_GEOM_CAPSULE ? GK_CAPSULE_WALL : GK_WALL_BOX;
+    it.g1 = box ? -1 : a; it.g2 = box ? a : -1; it.b1 = box ? 0 : m->geom_bodyid[a]; it.b2 = box ? m->geom_bodyid[a] : 0; it.pad = 0;
+    gen_pair(&it.P, m, m->geom_friction[a], m->geom_solref[a], m->geom_solimp[a], m->geom_margin[a], m->geom_gap[a], m->geom_condim[a],
+             m->wall_friction, m->wall_solref, m->wall_solimp, m->wall_margin, m->wall_gap, m->wall_condim,
+             m->body_invweight0[m->geom_bodyid[a]][0] + m->body_invweight0[0][0]);
+    if (it.P.condim != 1 && it.P.condim != 3) return gen_fail(err, errlen, "general engine: condim must be 1 or 3");
   }
+  g->nitem = n;
   for (int j = 0; j < m->njnt; j++) {
     const double tc = fmax(m->jnt_solref[j][0], 2.0 * m->timestep), dr = m->jnt_solref[j][1], dmax = m->jnt_solimp[j][1];
     g->lim_K[j] = 1.0 / fmax(1e-15, dmax * dmax * tc * tc * dr * dr);
@@ -106,6 +171,13 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
   }
   g->max_iter = 100; g->ls_iter = 50; g->tol = 1e-10;
   g->inv_scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
+  g->nseg = m->manual_collision ? m->nseg : 0;
+  for (int k = 0; k < m->nseg && k < MZ_MAX_SEG; k++) for (int c = 0; c < 4; c++) g->seg[k][c] = m->seg[k][c];
+  g->restitution = m->restitution;
+  g->obs_extra = 3 * ((m->observe_balls ? m->nball : 0) + (m->observe_blocks ? m->nblock : 0));
+  if (m->nq_robot < 3 || m->obs_dim != m->nq_robot + m->nv_robot + 1 + g->obs_extra + (m->top_down_view ? MZ_VIEW_DIM : 0))
+    return gen_fail(err, errlen, "general engine: obs_dim must be nq_robot + nv_robot + 1 + 3 per observed ball / block (+ the top-down view)");
+  if (m->nq_robot + m->nv_robot + 1 + g->obs_extra > MZ_MAX_OBS) return gen_fail(err, errlen, "general engine: observation wider than MZ_MAX_OBS");
   return MZ_OK;
 }
 
@@ -118,18 +190,26 @@ struct alignas(16) GenScratch {
   double gpos[GN_NG][3], gmat[GN_NG][9];
   double S[GN_NV][6], refpoint[3];
   double M[GN_NV][GN_NV], H[GN_NV][GN_NV];
-  // contacts: staged per geom, then compacted
-  int scnt[GN_NG];
-  double sdist[GN_NG][GN_STAGE], spos[GN_NG][GN_STAGE][3], snrm[GN_NG][GN_STAGE][3], shint[GN_NG][GN_STAGE][3];
-  int skind[GN_NG][GN_STAGE];  // 0: floor (geom1) -> robot geom; 1: robot geom (geom1) -> maze box
-  int ncon, nlim, status, iters;
-  int cgeom[GN_NC], ckind[GN_NC];
+  // contacts: found by the items into a pool (arrival order), then the active ones compacted in the oracle's order
+  int npool, ncon, nlim, status, iters, pad;
+  int pkey[GN_POOL];
+  double pdist[GN_POOL], ppos[GN_POOL][3], pnrm[GN_POOL][3], phint[GN_POOL][3];
+  int citem[GN_NC];
   double cdist[GN_NC], cpos[GN_NC][3], cnrm[GN_NC][3], chint[GN_NC][3];
   double cJ[GN_NC][3][GN_NV], caref[GN_NC][3], cD[GN_NC], cu[GN_NC][3], cjv[GN_NC][3];
   int ldof[GN_NL];
   double lsign[GN_NL], lD[GN_NL], laref[GN_NL], ljar[GN_NL], ljv[GN_NL];
   double grad[GN_NV], search[GN_NV], Mx[GN_NV], Ms[GN_NV], red[8];
 };
+
+// slot of the contact pool (LDS counter; a wavefront's arrival order is whatever it is — the compaction sorts by key)
+MZ_HD int gen_take(int* counter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicAdd(counter, 1);
+#else
+  return (*counter)++;
+#endif
+}
 
 // ------------------------------------------------------------------ small float64 helpers
 MZ_HD double gd_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -223,12 +303,18 @@ MZ_HD void gen_kinematics(const GenDev& K, GenScratch& s) {
         gd_mulmat(axis, mat, m.jnt_axis[j]);
         gd_mulmat(anchor, mat, m.jnt_pos[j]);
         for (int k = 0; k < 3; k++) anchor[k] += pos[k];
-        const double q = s.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]];
         if (m.jnt_type[j] == MZ_JNT_SLIDE) {
+          const double q = s.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]];
           for (int k = 0; k < 3; k++) pos[k] += axis[k] * q;
-        } else {  // hinge: rotate about the joint axis through the anchor
-          const double sh = sin(0.5 * q), ql[4] = {cos(0.5 * q), m.jnt_axis[j][0] * sh, m.jnt_axis[j][1] * sh, m.jnt_axis[j][2] * sh};
-          double qn[4], v[3];
+        } else {  // hinge: rotate about the joint axis through the anchor; ball: the coordinates ARE the relative quaternion
+          double ql[4], qn[4], v[3];
+          if (m.jnt_type[j] == MZ_JNT_BALL) {
+            for (int k = 0; k < 4; k++) ql[k] = s.qpos[m.jnt_qposadr[j] + k];
+            gd_quat_norm(ql);
+          } else {
+            const double q = s.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]], sh = sin(0.5 * q);
+            ql[0] = cos(0.5 * q); ql[1] = m.jnt_axis[j][0] * sh; ql[2] = m.jnt_axis[j][1] * sh; ql[3] = m.jnt_axis[j][2] * sh;
+          }
           gd_quat_mul(qn, quat, ql);
           for (int k = 0; k < 4; k++) quat[k] = qn[k];
           gd_quat2mat(mat, quat);
@@ -264,13 +350,18 @@ MZ_HD void gen_axis_item(const GenDev& K, GenScratch& s, int j) {
   const int b = m.jnt_bodyid[j], d0 = m.jnt_dofadr[j];
   const double* c = s.refpoint;
   double off[3];
-  if (m.jnt_type[j] == MZ_JNT_FREE) {
+  if (m.jnt_type[j] == MZ_JNT_FREE || m.jnt_type[j] == MZ_JNT_BALL) {
+    // the rotational dofs are the angular velocity in the child frame: rotations about the body's own axes through the anchor
+    const int r0 = m.jnt_type[j] == MZ_JNT_FREE ? d0 + 3 : d0;
+    const double* anchor = m.jnt_type[j] == MZ_JNT_FREE ? s.xpos[b] : s.xanchor[j];
     for (int k = 0; k < 3; k++) {
-      for (int e = 0; e < 6; e++) s.S[d0 + k][e] = 0.0;
-      s.S[d0 + k][3 + k] = 1.0;
+      if (m.jnt_type[j] == MZ_JNT_FREE) {
+        for (int e = 0; e < 6; e++) s.S[d0 + k][e] = 0.0;
+        s.S[d0 + k][3 + k] = 1.0;
+      }
       const double ax[3] = {s.xmat[b][k], s.xmat[b][3 + k], s.xmat[b][6 + k]};
-      for (int e = 0; e < 3; e++) { off[e] = c[e] - s.xpos[b][e]; s.S[d0 + 3 + k][e] = ax[e]; }
-      gd_cross(s.S[d0 + 3 + k] + 3, ax, off);
+      for (int e = 0; e < 3; e++) { off[e] = c[e] - anchor[e]; s.S[r0 + k][e] = ax[e]; }
+      gd_cross(s.S[r0 + k] + 3, ax, off);
     }
   } else if (m.jnt_type[j] == MZ_JNT_SLIDE) {
     for (int e = 0; e < 3; e++) { s.S[d0][e] = 0.0; s.S[d0][3 + e] = s.xaxis[j][e]; }
@@ -307,7 +398,7 @@ MZ_HD void gen_mass_item(const GenDev& K, GenScratch& s, int i) {
   for (int j = K.dof_parent[i]; j >= 0; j = K.dof_parent[j]) s.M[i][j] = gd_dot6(s.S[j], F);
 }
 
-// ------------------------------------------------------------------ collision
+// ------------------------------------------------------------------ narrow phase
 // sphere (centre c in box coordinates) vs axis-aligned box; normal from the sphere to the box (mjraw_SphereBox)
 MZ_HD bool gen_sphere_box(const double* c, double r, const double* bs, double margin, double* dist, double* pos, double* nrm) {
   double q[3], dd;
@@ -413,85 +504,333 @@ MZ_HD void gen_capsule_box_features(const double* pos, const double* halfaxis, d
   *second = (secondpos > -3.0 && fabs(secondpos) > 1e-12) ? secondpos : 0.0;
 }
 
-// contacts of robot geom g into its staging entry: the floor plane (geom1 = floor), then the maze boxes under its bounding
-// square in row-major cell order (geom1 = the robot geom) — the oracle's pair order
-MZ_HD void gen_collide_item(const GenDev& K, GenScratch& s, int g) {
+// The routines below hand every contact they find to `emit(dist, pos, normal, hint)` — world frame, normal from geom1 to geom2,
+// hint = the tangent the contact frame should start from (the capsule's axis for capsule-plane) or nullptr.
+
+// sphere (geom1: centre cs, radius r) vs a box of any orientation (geom2): into the box frame, mjraw_SphereBox, back
+template <class E>
+MZ_HD void gen_sphere_vs_box(const double* cs, double r, const double* bpos, const double* bmat, const double* bsize, double margin, E& emit) {
+  double rel[3] = {cs[0] - bpos[0], cs[1] - bpos[1], cs[2] - bpos[2]}, c[3], dist, pl[3], nl[3], pw[3], nw[3];
+  gd_mulmatT(c, bmat, rel);
+  if (!gen_sphere_box(c, r, bsize, margin, &dist, pl, nl)) return;
+  gd_mulmat(pw, bmat, pl); gd_mulmat(nw, bmat, nl);
+  for (int k = 0; k < 3; k++) pw[k] += bpos[k];
+  emit(dist, pw, nw, nullptr);
+}
+
+// capsule (geom1: centre cpos, unit axis caxis, radius r, half length hl) vs a box of any orientation (geom2): mjc_CapsuleBox —
+// the feature search in the box frame, then at most two sphere-box contacts on the axis segment
+template <class E>
+MZ_HD void gen_capsule_vs_box(const double* cpos, const double* caxis, double r, double hl, const double* bpos, const double* bmat, const double* bsize,
+                              double margin, E& emit) {
+  double rel[3] = {cpos[0] - bpos[0], cpos[1] - bpos[1], cpos[2] - bpos[2]}, cl[3], al[3];
+  gd_mulmatT(cl, bmat, rel); gd_mulmatT(al, bmat, caxis);
+  const double h[3] = {al[0] * hl, al[1] * hl, al[2] * hl};
+  bool found; double t = 0.0, second = 0.0;
+  gen_capsule_box_features(cl, h, hl, bsize, margin, r, &found, &t, &second);
+  if (!found) return;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1 && second == 0.0) break;
+    const double tt = t + (pass ? second : 0.0), c[3] = {cl[0] + tt * h[0], cl[1] + tt * h[1], cl[2] + tt * h[2]};
+    double dist, pl[3], nl[3], pw[3], nw[3];
+    if (!gen_sphere_box(c, r, bsize, margin, &dist, pl, nl)) continue;
+    gd_mulmat(pw, bmat, pl); gd_mulmat(nw, bmat, nl);
+    for (int k = 0; k < 3; k++) pw[k] += bpos[k];
+    emit(dist, pw, nw, nullptr);
+  }
+}
+
+// box (geom1) vs box (geom2), both of any orientation: mjc_BoxBox as restated in oracle/mzo_physics.c box_box — the 15-axis
+// search in MuJoCo's order (face axes of box 1 and 2 by index, strict improvement; the nine edge-edge axes win only when clearly
+// smaller), the face case (vertices of the incident rectangle clipped by the reference rectangle, each with its own depth, at
+// most 8, [ASSUME-12]: an intersection without area makes no contact) and the edge-edge case (one contact midway between the
+// closest points of the two edges: a tilted SPIN plate on a wall's edge, a leg-less robot box across a block's edge)
+template <class E>
+MZ_HD void gen_box_vs_box(const double* pos1, const double* mat1, const double* size1, const double* pos2, const double* mat2, const double* size2,
+                          double margin, E& emit) {
+  double rot[9], rotabs[9], pos21[3], pos12[3], tmp[3], plen1[3], plen2[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {  // rot[i][j] = axis i of box 1 . axis j of box 2
+      rot[3 * i + j] = mat1[i] * mat2[j] + mat1[3 + i] * mat2[3 + j] + mat1[6 + i] * mat2[6 + j];
+      rotabs[3 * i + j] = fabs(rot[3 * i + j]);
+    }
+  for (int k = 0; k < 3; k++) tmp[k] = pos2[k] - pos1[k];
+  gd_mulmatT(pos21, mat1, tmp);
+  for (int k = 0; k < 3; k++) tmp[k] = pos1[k] - pos2[k];
+  gd_mulmatT(pos12, mat2, tmp);
+  for (int i = 0; i < 3; i++) {
+    plen2[i] = rotabs[3 * i] * size2[0] + rotabs[3 * i + 1] * size2[1] + rotabs[3 * i + 2] * size2[2];
+    plen1[i] = rotabs[i] * size1[0] + rotabs[3 + i] * size1[1] + rotabs[6 + i] * size1[2];
+  }
+  double penetration = margin;
+  for (int i = 0; i < 3; i++) penetration += 3.0 * (size1[i] + size2[i]);
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    const double c1 = -fabs(pos21[i]) + size1[i] + plen2[i], c2 = -fabs(pos12[i]) + size2[i] + plen1[i];
+    if (c1 < -margin || c2 < -margin) return;
+    if (c1 < penetration) { penetration = c1; code = i + 3 * (pos21[i] < 0); }
+    if (c2 < penetration) { penetration = c2; code = 6 + i + 3 * (pos12[i] < 0); }
+  }
+  double en[3] = {0, 0, 0};  // edge-edge axis (frame of box 1, pointing from box 1 to box 2)
+  int ei = -1, ej = -1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double ei3[3] = {i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0}, aj[3] = {rot[j], rot[3 + j], rot[6 + j]};
+      double cr[3];
+      gd_cross(cr, ei3, aj);
+      const double len = sqrt(gd_dot3(cr, cr));
+      if (len < 1e-10) continue;
+      for (int k = 0; k < 3; k++) cr[k] /= len;
+      double r1 = 0, r2 = 0;
+      for (int k = 0; k < 3; k++) {
+        r1 += size1[k] * fabs(cr[k]);
+        r2 += size2[k] * fabs(cr[0] * rot[k] + cr[1] * rot[3 + k] + cr[2] * rot[6 + k]);
+      }
+      const double sep = gd_dot3(pos21, cr), c3 = r1 + r2 - fabs(sep);
+      if (c3 < -margin) return;
+      if (c3 < penetration - 1e-10 * (fabs(penetration) + r1 + r2)) {
+        penetration = c3; code = 12 + 3 * i + j; ei = i; ej = j;
+        for (int k = 0; k < 3; k++) en[k] = sep >= 0 ? cr[k] : -cr[k];
+      }
+    }
+  if (code < 0) return;
+  if (code >= 12) {
+    double p1[3], p2[3], d1[3] = {ei == 0 ? 1.0 : 0.0, ei == 1 ? 1.0 : 0.0, ei == 2 ? 1.0 : 0.0}, d2[3] = {rot[ej], rot[3 + ej], rot[6 + ej]};
+    for (int k = 0; k < 3; k++) p1[k] = k == ei ? 0.0 : (en[k] >= 0 ? size1[k] : -size1[k]);
+    for (int k = 0; k < 3; k++) p2[k] = pos21[k];
+    for (int k = 0; k < 3; k++) {
+      if (k == ej) continue;
+      const double ak[3] = {rot[k], rot[3 + k], rot[6 + k]}, sg = gd_dot3(ak, en) >= 0 ? -size2[k] : size2[k];
+      for (int e = 0; e < 3; e++) p2[e] += ak[e] * sg;
+    }
+    const double w[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const double b = gd_dot3(d1, d2), dd = gd_dot3(d1, w), e = gd_dot3(d2, w), den = 1.0 - b * b;
+    const double sc = den > 1e-12 ? (b * e - dd) / den : 0.0, tc = den > 1e-12 ? (e - b * dd) / den : 0.0;
+    double mid[3], nw[3], pw[3];
+    for (int k = 0; k < 3; k++) mid[k] = 0.5 * ((p1[k] + sc * d1[k]) + (p2[k] + tc * d2[k]));
+    gd_mulmat(nw, mat1, en); gd_mulmat(pw, mat1, mid);
+    for (int k = 0; k < 3; k++) pw[k] += pos1[k];
+    emit(-penetration, pw, nw, nullptr);
+    return;
+  }
+  // face case, worked in the frame of the reference box A
+  const int fromB = code >= 6, a = code % 3;
+  const double* posA = fromB ? pos2 : pos1; const double* matA = fromB ? mat2 : mat1;
+  const double* sA = fromB ? size2 : size1; const double* sB = fromB ? size1 : size2;
+  const double* pBA = fromB ? pos12 : pos21;
+  double R[9];  // R[k][j] = axis k of A . axis j of B
+  for (int k = 0; k < 3; k++) for (int j = 0; j < 3; j++) R[3 * k + j] = fromB ? rot[3 * j + k] : rot[3 * k + j];
+  const double sg = pBA[a] < 0 ? -1.0 : 1.0;  // the reference normal sg * e_a points from A to B
+  int b = 0;
+  for (int j = 1; j < 3; j++) if (fabs(R[3 * a + j]) > fabs(R[3 * a + b])) b = j;
+  const double sb = R[3 * a + b] * sg > 0 ? -1.0 : 1.0;  // incident face: the one of B whose outward normal opposes the reference normal
+  const int b1 = (b + 1) % 3, b2 = (b + 2) % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+  double cf[3], u[3], v[3];
+  for (int k = 0; k < 3; k++) {
+    cf[k] = pBA[k] + sb * sB[b] * R[3 * k + b];
+    u[k] = sB[b1] * R[3 * k + b1];
+    v[k] = sB[b2] * R[3 * k + b2];
+  }
+  double cand[24][3];
+  int nc = 0;
+  const double tol = 1e-12 * (1.0 + sA[a1] + sA[a2]);
+  for (int c = 0; c < 4; c++) {  // incident corners inside the reference rectangle
+    const double su = (c & 1) ? 1.0 : -1.0, sv = (c & 2) ? 1.0 : -1.0;
+    double p[3];
+    for (int k = 0; k < 3; k++) p[k] = cf[k] + su * u[k] + sv * v[k];
+    if (fabs(p[a1]) <= sA[a1] + tol && fabs(p[a2]) <= sA[a2] + tol) { for (int k = 0; k < 3; k++) cand[nc][k] = p[k]; nc++; }
+  }
+  for (int e = 0; e < 4; e++) {  // incident edges against the border lines of the reference rectangle
+    double p[3], q[3];  // edge = p + t q, t in [-1, 1]
+    for (int k = 0; k < 3; k++) {
+      if (e < 2) { p[k] = cf[k] + (e ? v[k] : -v[k]); q[k] = u[k]; }
+      else { p[k] = cf[k] + (e == 3 ? u[k] : -u[k]); q[k] = v[k]; }
+    }
+    for (int w = 0; w < 2; w++) {
+      const int c = w ? a2 : a1, o = w ? a1 : a2;
+      if (fabs(q[c]) < 1e-15) continue;
+      for (int side = -1; side <= 1; side += 2) {
+        const double t = (side * sA[c] - p[c]) / q[c];
+        if (t < -1.0 || t > 1.0) continue;
+        if (fabs(p[o] + t * q[o]) > sA[o] + tol) continue;
+        for (int k = 0; k < 3; k++) cand[nc][k] = p[k] + t * q[k];
+        nc++;
+      }
+    }
+  }
+  {  // reference corners inside the incident rectangle, on the incident plane
+    const double det = u[a1] * v[a2] - u[a2] * v[a1];
+    if (fabs(det) > 1e-15)
+      for (int c = 0; c < 4; c++) {
+        const double x = ((c & 1) ? sA[a1] : -sA[a1]) - cf[a1], y = ((c & 2) ? sA[a2] : -sA[a2]) - cf[a2];
+        const double al = (x * v[a2] - y * v[a1]) / det, be = (u[a1] * y - u[a2] * x) / det;
+        if (fabs(al) <= 1.0 + 1e-12 && fabs(be) <= 1.0 + 1e-12) {
+          for (int k = 0; k < 3; k++) cand[nc][k] = cf[k] + al * u[k] + be * v[k];
+          nc++;
+        }
+      }
+  }
+  {
+    double lo1 = 1e300, hi1 = -1e300, lo2 = 1e300, hi2 = -1e300;
+    for (int c = 0; c < nc; c++) {
+      lo1 = fmin(lo1, cand[c][a1]); hi1 = fmax(hi1, cand[c][a1]);
+      lo2 = fmin(lo2, cand[c][a2]); hi2 = fmax(hi2, cand[c][a2]);
+    }
+    if (nc == 0 || hi1 - lo1 <= 1e-6 || hi2 - lo2 <= 1e-6) return;  // MZO_BOX_MINOVERLAP [ASSUME-12]
+  }
+  int emitted = 0;
+  const double dtol = 1e-9 * (1.0 + sA[a1] + sA[a2]);  // candidates closer than this (max norm) are one vertex
+  for (int c = 0; c < nc && emitted < 8; c++) {
+    bool dup = false;
+    for (int e = 0; e < c && !dup; e++)
+      if (fabs(cand[c][0] - cand[e][0]) <= dtol && fabs(cand[c][1] - cand[e][1]) <= dtol && fabs(cand[c][2] - cand[e][2]) <= dtol) dup = true;
+    if (dup) continue;
+    const double dist = sg * cand[c][a] - sA[a];
+    if (dist > margin) continue;
+    double pl[3] = {cand[c][0], cand[c][1], cand[c][2]}, pw[3], nl[3] = {0, 0, 0}, nw[3];
+    pl[a] -= sg * 0.5 * dist;
+    nl[a] = fromB ? -sg : sg;  // reported from geom1 to geom2
+    gd_mulmat(pw, matA, pl); gd_mulmat(nw, matA, nl);
+    for (int k = 0; k < 3; k++) pw[k] += posA[k];
+    emit(dist, pw, nw, nullptr);
+    emitted++;
+  }
+}
+
+// ------------------------------------------------------------------ collision: one item per lane
+// contacts of collision item `it` into the pool.  The oracle's order (item order, then the order inside a routine) is the pool
+// key; the compaction below sorts by it.
+MZ_HD void gen_collide_item(const GenDev& K, GenScratch& s, int it) {
   const mz_model& m = K.m;
+  const GenItem& I = K.item[it];
+  const double margin = I.P.margin;
   int n = 0;
-  auto put = [&](int kind, double dist, const double* pos, const double* nrm, const double* hint) {
-    if (n < GN_STAGE) {
-      s.sdist[g][n] = dist; s.skind[g][n] = kind;
-      for (int k = 0; k < 3; k++) { s.spos[g][n][k] = pos[k]; s.snrm[g][n][k] = nrm[k]; s.shint[g][n][k] = hint ? hint[k] : 0.0; }
+  auto emit = [&](double dist, const double* pos, const double* nrm, const double* hint) {
+    const int slot = gen_take(&s.npool);
+    if (slot < GN_POOL) {
+      s.pkey[slot] = it * GN_KEY + (n < GN_KEY ? n : GN_KEY - 1); s.pdist[slot] = dist;
+      for (int k = 0; k < 3; k++) { s.ppos[slot][k] = pos[k]; s.pnrm[slot][k] = nrm[k]; s.phint[slot][k] = hint ? hint[k] : 0.0; }
     }
     n++;
   };
-  if (m.collision_predefined || m.geom_bodyid[g] == 0) { s.scnt[g] = 0; return; }
-  const double* gp = s.gpos[g];
-  const double* gm = s.gmat[g];
-  const double r = m.geom_size[g][0], hl = m.geom_type[g] == MZ_GEOM_CAPSULE ? m.geom_size[g][1] : 0.0;
-  const double axis[3] = {gm[2], gm[5], gm[8]};
-  if ((m.geom_contype[0] & m.geom_conaffinity[g]) || (m.geom_contype[g] & m.geom_conaffinity[0])) {  // floor plane (geom 0)
-    const double* pm = s.gmat[0];
+  static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (I.kind <= GK_PLANE_BOX) {  // the floor plane (geom1) against a sphere / capsule ends / box corners
+    const int g = I.g2;
+    const double* pm = s.gmat[I.g1];
     const double nz[3] = {pm[2], pm[5], pm[8]};
-    const int nend = m.geom_type[g] == MZ_GEOM_CAPSULE ? 2 : 1;
-    for (int e = 0; e < nend; e++) {
+    const double* gp = s.gpos[g];
+    const double* gm = s.gmat[g];
+    if (I.kind == GK_PLANE_BOX) {
+      // mjc_PlaneBox: the corners in index order (bit 0 x, bit 1 y, bit 2 z); a corner is skipped when it lies beyond the margin or
+      // on the far side of the box centre (its offset along the plane normal is positive); at most 4
+      const double* sz = m.geom_size[g];
+      const double rel[3] = {gp[0] - s.gpos[I.g1][0], gp[1] - s.gpos[I.g1][1], gp[2] - s.gpos[I.g1][2]}, cdist = gd_dot3(rel, nz);
+      int cnt = 0;
+      for (int ci = 0; ci < 8 && cnt < 4; ci++) {
+        const double loc[3] = {(ci & 1 ? 1 : -1) * sz[0], (ci & 2 ? 1 : -1) * sz[1], (ci & 4 ? 1 : -1) * sz[2]};
+        double w[3], pos[3];
+        gd_mulmat(w, gm, loc);
+        const double ldist = gd_dot3(nz, w);
+        if (cdist + ldist > margin || ldist > 0) continue;
+        const double dist = cdist + ldist;
+        for (int k = 0; k < 3; k++) pos[k] = gp[k] + w[k] - nz[k] * (0.5 * dist);
+        emit(dist, pos, nz, nullptr);
+        cnt++;
+      }
+      return;
+    }
+    const double r = m.geom_size[g][0], hl = I.kind == GK_PLANE_CAPSULE ? m.geom_size[g][1] : 0.0;
+    const double axis[3] = {gm[2], gm[5], gm[8]};
+    const int nend = I.kind == GK_PLANE_CAPSULE ? 2 : 1;
+    for (int e = 0; e < nend; e++) {  // [ASSUME-5] end +axis first, then -axis; tangent hint = the capsule's axis
       const double sg = nend == 1 ? 0.0 : (e == 0 ? 1.0 : -1.0);
       double c[3], rel[3], pos[3];
-      for (int k = 0; k < 3; k++) { c[k] = gp[k] + sg * axis[k] * hl; rel[k] = c[k] - s.gpos[0][k]; }
+      for (int k = 0; k < 3; k++) { c[k] = gp[k] + sg * axis[k] * hl; rel[k] = c[k] - s.gpos[I.g1][k]; }
       const double dist = gd_dot3(rel, nz) - r;
-      if (dist > K.pf[g].margin) continue;
+      if (dist > margin) continue;
       for (int k = 0; k < 3; k++) pos[k] = c[k] - nz[k] * (r + 0.5 * dist);
-      put(0, dist, pos, nz, nend == 2 ? axis : nullptr);
+      emit(dist, pos, nz, nend == 2 ? axis : nullptr);
     }
+    return;
   }
-  if ((m.geom_contype[g] & m.wall_conaffinity) || (m.wall_contype & m.geom_conaffinity[g])) {
-    const double sc = m.maze_scale, reach = m.geom_rbound[g] + K.pw[g].margin, margin = K.pw[g].margin;
-    if (!(gp[2] - reach > m.wall_center_z + m.wall_half_z) && !(gp[2] + reach < m.wall_center_z - m.wall_half_z)) {
-      const int j0 = (int)floor((gp[0] - reach + m.torso_x) / sc + 0.5), j1 = (int)floor((gp[0] + reach + m.torso_x) / sc + 0.5);
-      const int i0 = (int)floor((gp[1] - reach + m.torso_y) / sc + 0.5), i1 = (int)floor((gp[1] + reach + m.torso_y) / sc + 0.5);
-      const double bs[3] = {m.wall_half_xy, m.wall_half_xy, m.wall_half_z};
-      for (int i = i0; i <= i1; i++)
-        for (int j = j0; j <= j1; j++) {
-          if (i < 0 || j < 0 || i >= m.grid_rows || j >= m.grid_cols || m.grid[i][j] != MZ_CELL_BLOCK) continue;
-          const double bpos[3] = {j * sc - m.torso_x, i * sc - m.torso_y, m.wall_center_z};
-          const double cl[3] = {gp[0] - bpos[0], gp[1] - bpos[1], gp[2] - bpos[2]};
-          double dist, pos[3], nrm[3];
-          if (m.geom_type[g] == MZ_GEOM_SPHERE) {
-            if (gen_sphere_box(cl, r, bs, margin, &dist, pos, nrm)) { for (int k = 0; k < 3; k++) pos[k] += bpos[k]; put(1, dist, pos, nrm, nullptr); }
-            continue;
-          }
-          const double h[3] = {axis[0] * hl, axis[1] * hl, axis[2] * hl};
-          bool found; double t = 0.0, second = 0.0;
-          gen_capsule_box_features(cl, h, hl, bs, margin, r, &found, &t, &second);
-          if (!found) continue;
-          for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1 && second == 0.0) break;
-            const double tt = t + (pass ? second : 0.0), c[3] = {cl[0] + tt * h[0], cl[1] + tt * h[1], cl[2] + tt * h[2]};
-            if (gen_sphere_box(c, r, bs, margin, &dist, pos, nrm)) { for (int k = 0; k < 3; k++) pos[k] += bpos[k]; put(1, dist, pos, nrm, nullptr); }
-          }
-        }
+  if (I.kind == GK_SPHERE_SPHERE || I.kind == GK_SPHERE_CAPSULE) {
+    // sphere-sphere; sphere-capsule = the point of the capsule's axis segment nearest to the sphere centre, then sphere-sphere
+    // (mjc_SphereCapsule); normal from geom1 to geom2
+    const double* c1 = s.gpos[I.g1];
+    double c2[3] = {s.gpos[I.g2][0], s.gpos[I.g2][1], s.gpos[I.g2][2]};
+    if (I.kind == GK_SPHERE_CAPSULE) {
+      const double* cm = s.gmat[I.g2];
+      const double axis[3] = {cm[2], cm[5], cm[8]}, vec[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]}, hl = m.geom_size[I.g2][1];
+      const double x = fmin(fmax(gd_dot3(axis, vec), -hl), hl);
+      for (int k = 0; k < 3; k++) c2[k] += axis[k] * x;
     }
+    const double dv[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]}, cd = sqrt(gd_dot3(dv, dv)), r1 = m.geom_size[I.g1][0], r2 = m.geom_size[I.g2][0];
+    const double dist = cd - r1 - r2;
+    if (dist > margin) return;
+    double nrm[3] = {1.0, 0.0, 0.0}, pos[3];
+    if (!(cd < 1e-15)) for (int k = 0; k < 3; k++) nrm[k] = dv[k] / cd;
+    for (int k = 0; k < 3; k++) pos[k] = c1[k] + nrm[k] * (r1 + 0.5 * dist);
+    emit(dist, pos, nrm, nullptr);
+    return;
   }
-  s.scnt[g] = n;
+  if (I.kind == GK_SPHERE_BOX) { gen_sphere_vs_box(s.gpos[I.g1], m.geom_size[I.g1][0], s.gpos[I.g2], s.gmat[I.g2], m.geom_size[I.g2], margin, emit); return; }
+  if (I.kind == GK_CAPSULE_BOX) {
+    const double* cm = s.gmat[I.g1];
+    const double axis[3] = {cm[2], cm[5], cm[8]};
+    gen_capsule_vs_box(s.gpos[I.g1], axis, m.geom_size[I.g1][0], m.geom_size[I.g1][1], s.gpos[I.g2], s.gmat[I.g2], m.geom_size[I.g2], margin, emit);
+    return;
+  }
+  if (I.kind == GK_BOX_BOX) { gen_box_vs_box(s.gpos[I.g1], s.gmat[I.g1], m.geom_size[I.g1], s.gpos[I.g2], s.gmat[I.g2], m.geom_size[I.g2], margin, emit); return; }
+  // the maze boxes under the geom's bounding square, row-major; per cell, in the order the reference emits the geoms
+  // (maze_env.py:124-152): the platform of an elevated maze (every cell but the chasms; z from 0 to height_offset), then the wall
+  const int g = I.kind == GK_WALL_BOX ? I.g2 : I.g1;
+  const double* gp = s.gpos[g];
+  const double sc = m.maze_scale, reach = m.geom_rbound[g] + margin;
+  if (gp[2] - reach > m.wall_center_z + m.wall_half_z) return;
+  if (!m.elevated && gp[2] + reach < m.wall_center_z - m.wall_half_z) return;
+  const int j0 = (int)floor((gp[0] - reach + m.torso_x) / sc + 0.5), j1 = (int)floor((gp[0] + reach + m.torso_x) / sc + 0.5);
+  const int i0 = (int)floor((gp[1] - reach + m.torso_y) / sc + 0.5), i1 = (int)floor((gp[1] + reach + m.torso_y) / sc + 0.5);
+  const double bs[3] = {m.wall_half_xy, m.wall_half_xy, m.wall_half_z};
+  for (int i = i0; i <= i1; i++)
+    for (int j = j0; j <= j1; j++) {
+      if (i < 0 || j < 0 || i >= m.grid_rows || j >= m.grid_cols) continue;
+      for (int layer = 0; layer < 2; layer++) {
+        if (layer == 0 && !(m.elevated && m.grid[i][j] != MZ_CELL_CHASM)) continue;
+        if (layer == 1 && m.grid[i][j] != MZ_CELL_BLOCK) continue;
+        const double bpos[3] = {j * sc - m.torso_x, i * sc - m.torso_y, layer == 0 ? m.wall_half_z : m.wall_center_z};
+        if (gp[2] - reach > bpos[2] + m.wall_half_z || gp[2] + reach < bpos[2] - m.wall_half_z) continue;
+        if (I.kind == GK_SPHERE_WALL) gen_sphere_vs_box(gp, m.geom_size[g][0], bpos, ident, bs, margin, emit);
+        else if (I.kind == GK_CAPSULE_WALL) {
+          const double* cm = s.gmat[g];
+          const double axis[3] = {cm[2], cm[5], cm[8]};
+          gen_capsule_vs_box(gp, axis, m.geom_size[g][0], m.geom_size[g][1], bpos, ident, bs, margin, emit);
+        } else gen_box_vs_box(bpos, ident, bs, gp, s.gmat[g], m.geom_size[g], margin, emit);
+      }
+    }
 }
 
-// staging -> compact list (serial: prefix sums), then one item per (contact, row): frame, Jacobian, reference acceleration
-MZ_HD void gen_compact_contacts(const GenDev& K, GenScratch& s) {
-  const mz_model& m = K.m;
-  int c = 0;
-  for (int g = 1; g < m.ngeom; g++) {
-    if (s.scnt[g] > GN_STAGE) s.status |= MZ_STATUS_CONTACT_OVERFLOW;
-    for (int k = 0; k < s.scnt[g] && k < GN_STAGE; k++) {
-      const GenPair& P = s.skind[g][k] == 0 ? K.pf[g] : K.pw[g];
-      if (!(s.sdist[g][k] < P.margin - P.gap)) continue;  // not active: no row
-      if (c >= GN_NC) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; continue; }
-      s.cgeom[c] = g; s.ckind[c] = s.skind[g][k]; s.cdist[c] = s.sdist[g][k];
-      for (int e = 0; e < 3; e++) { s.cpos[c][e] = s.spos[g][k][e]; s.cnrm[c][e] = s.snrm[g][k][e]; s.chint[c][e] = s.shint[g][k][e]; }
-      c++;
-    }
+// pool -> the ACTIVE contacts (dist < margin - gap), in key order: entry e's slot = the number of active entries with a smaller key
+MZ_HD void gen_compact_item(const GenDev& K, GenScratch& s, int e, int np) {
+  const GenPair& P = K.item[s.pkey[e] / GN_KEY].P;
+  if (!(s.pdist[e] < P.margin - P.gap)) return;
+  int rank = 0;
+  for (int o = 0; o < np; o++) {
+    const GenPair& Q = K.item[s.pkey[o] / GN_KEY].P;
+    if (s.pdist[o] < Q.margin - Q.gap && (s.pkey[o] < s.pkey[e] || (s.pkey[o] == s.pkey[e] && o < e))) rank++;
   }
+  if (rank >= GN_NC) return;  // (counted by gen_limits_serial)
+  s.citem[rank] = s.pkey[e] / GN_KEY; s.cdist[rank] = s.pdist[e];
+  for (int k = 0; k < 3; k++) { s.cpos[rank][k] = s.ppos[e][k]; s.cnrm[rank][k] = s.pnrm[e][k]; s.chint[rank][k] = s.phint[e][k]; }
+}
+
+// contact count and the joint-limit rows (hinge / slide), serial
+MZ_HD void gen_limits_serial(const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  int np = s.npool, c = 0;
+  if (np > GN_POOL) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; np = GN_POOL; }
+  for (int e = 0; e < np; e++) { const GenPair& P = K.item[s.pkey[e] / GN_KEY].P; if (s.pdist[e] < P.margin - P.gap) c++; }
+  if (c > GN_NC) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; c = GN_NC; }
   s.ncon = c;
-  // joint limits (hinge / slide)
   int nl = 0;
   for (int j = 0; j < m.njnt; j++) {
     if (!m.jnt_limited[j] || (m.jnt_type[j] != MZ_JNT_HINGE && m.jnt_type[j] != MZ_JNT_SLIDE)) continue;
@@ -511,10 +850,12 @@ MZ_HD void gen_compact_contacts(const GenDev& K, GenScratch& s) {
   s.nlim = nl;
 }
 
+// one item per (contact, frame axis): the contact frame, the Jacobian row J(body2) - J(body1), the reference acceleration
 MZ_HD void gen_contact_row_item(const GenDev& K, GenScratch& s, int item) {
   const mz_model& m = K.m;
-  const int c = item / 3, a = item - 3 * c, g = s.cgeom[c], kind = s.ckind[c];
-  const GenPair& P = kind == 0 ? K.pf[g] : K.pw[g];
+  const int c = item / 3, a = item - 3 * c;
+  const GenItem& I = K.item[s.citem[c]];
+  const GenPair& P = I.P;
   // frame (mju_makeFrame): the normal, a tangent from the hint (capsule axis for capsule-plane) or the default rule
   double n[3] = {s.cnrm[c][0], s.cnrm[c][1], s.cnrm[c][2]}, y[3] = {s.chint[c][0], s.chint[c][1], s.chint[c][2]}, t1[3], t2[3];
   {
@@ -535,28 +876,27 @@ MZ_HD void gen_contact_row_item(const GenDev& K, GenScratch& s, int item) {
   }
   const double* dir = a == 0 ? n : (a == 1 ? t1 : t2);
   const double sc = a == 0 ? 1.0 : P.mu;
-  // the contact force acts on geom2: the robot for a floor contact (+), the maze box for a wall contact (robot = geom1: -)
-  const double sgn = kind == 0 ? 1.0 : -1.0;
   double off[3], J[GN_NV];
   for (int k = 0; k < 3; k++) off[k] = s.cpos[c][k] - s.refpoint[k];
   for (int i = 0; i < m.nv; i++) J[i] = 0.0;
-  for (int b = m.geom_bodyid[g]; b > 0; b = m.body_parent[b])
-    for (int i = m.body_dofadr[b]; i >= 0 && i < m.body_dofadr[b] + m.body_dofnum[b]; i++) {
-      double wx[3];
-      gd_cross(wx, s.S[i], off);
-      J[i] = sgn * sc * ((s.S[i][3] + wx[0]) * dir[0] + (s.S[i][4] + wx[1]) * dir[1] + (s.S[i][5] + wx[2]) * dir[2]);
-    }
+  for (int side = 0; side < 2; side++) {  // the contact force acts on geom2's body (+) and reacts on geom1's (-)
+    const double sgn = side ? 1.0 : -1.0;
+    for (int b = side ? I.b2 : I.b1; b > 0; b = m.body_parent[b])
+      for (int i = m.body_dofadr[b]; i >= 0 && i < m.body_dofadr[b] + m.body_dofnum[b]; i++) {
+        double wx[3];
+        gd_cross(wx, s.S[i], off);
+        J[i] += sgn * sc * ((s.S[i][3] + wx[0]) * dir[0] + (s.S[i][4] + wx[1]) * dir[1] + (s.S[i][5] + wx[2]) * dir[2]);
+      }
+  }
   double vel = 0.0;
   for (int i = 0; i < m.nv; i++) { s.cJ[c][a][i] = J[i]; vel += J[i] * s.qvel[i]; }
   double aref = -P.B * vel;
   if (a == 0) {
     const double imp = gd_impedance(P.solimp, fabs(s.cdist[c] - (P.margin - P.gap)));
-    const int b = m.geom_bodyid[g];
-    const double tran = m.body_invweight0[b][0] + m.body_invweight0[0][0];
     if (P.condim == 1) {
-      s.cD[c] = -1.0 / fmax(1e-15, (1.0 - imp) * tran / imp);  // (negative: a single frictionless row, see gen_contact_eval)
+      s.cD[c] = -1.0 / fmax(1e-15, (1.0 - imp) * P.tran / imp);  // (negative: a single frictionless row, see gen_contact_eval)
     } else {
-      const double R = fmax(1e-15, (1.0 - imp) * (tran + P.mu * P.mu * tran) / imp);
+      const double R = fmax(1e-15, (1.0 - imp) * (P.tran + P.mu * P.mu * P.tran) / imp);
       s.cD[c] = 1.0 / (2.0 * P.mu * P.mu * R);
     }
     aref -= P.K * imp * (s.cdist[c] - (P.margin - P.gap));
@@ -605,13 +945,19 @@ MZ_HD void gen_rne_serial(const GenDev& K, GenScratch& s) {
     for (int e = 0; e < 6; e++) { v[e] = s.cvel[p][e]; a[e] = s.cacc[p][e]; }
     for (int j = j0; j < j0 + m.body_jntnum[b]; j++) {
       const int d0 = m.jnt_dofadr[j];
-      if (m.jnt_type[j] == MZ_JNT_FREE) {
-        for (int k = 0; k < 3; k++)
-          for (int e = 0; e < 6; e++) v[e] += s.S[d0 + k][e] * s.qvel[d0 + k];
+      if (m.jnt_type[j] == MZ_JNT_FREE || m.jnt_type[j] == MZ_JNT_BALL) {
+        // mj_comVel: the free joint's translations first (world-fixed axes: no derivative); then all three rotation-axis
+        // derivatives from the velocity in front of them, then the rotations' own velocity
+        int r0 = d0;
+        if (m.jnt_type[j] == MZ_JNT_FREE) {
+          for (int k = 0; k < 3; k++)
+            for (int e = 0; e < 6; e++) v[e] += s.S[d0 + k][e] * s.qvel[d0 + k];
+          r0 = d0 + 3;
+        }
         double sd[3][6];
-        for (int k = 0; k < 3; k++) gd_motion_cross(sd[k], v, s.S[d0 + 3 + k]);
+        for (int k = 0; k < 3; k++) gd_motion_cross(sd[k], v, s.S[r0 + k]);
         for (int k = 0; k < 3; k++)
-          for (int e = 0; e < 6; e++) { a[e] += sd[k][e] * s.qvel[d0 + 3 + k]; v[e] += s.S[d0 + 3 + k][e] * s.qvel[d0 + 3 + k]; }
+          for (int e = 0; e < 6; e++) { a[e] += sd[k][e] * s.qvel[r0 + k]; v[e] += s.S[r0 + k][e] * s.qvel[r0 + k]; }
       } else {
         double sd[6];
         gd_motion_cross(sd, v, s.S[d0]);
@@ -811,13 +1157,13 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
 template <class C>
 MZ_HD void gen_forward(const C& cx, const GenDev& K, GenScratch& s) {
   const mz_model& m = K.m;
-  MZ_FOR(one, 1) gen_kinematics(K, s);
+  MZ_FOR(one, 1) { gen_kinematics(K, s); s.npool = 0; }
   cx.sync();
   MZ_FOR(g, m.ngeom) gen_geom_item(K, s, g);
   MZ_FOR(j, m.njnt) gen_axis_item(K, s, j);
   MZ_FOR(b, m.nbody) if (b > 0) gen_inertia_item(K, s, b);
   cx.sync();
-  MZ_FOR(g, m.ngeom) gen_collide_item(K, s, g);
+  MZ_FOR(it, K.nitem) gen_collide_item(K, s, it);
   MZ_FOR(one, 1) {
     for (int b = m.nbody - 1; b >= 1; b--) { const int p = m.body_parent[b]; if (p > 0) for (int k = 0; k < 10; k++) s.crb[p][k] += s.crb[b][k]; }
     gen_rne_serial(K, s);
@@ -825,7 +1171,8 @@ MZ_HD void gen_forward(const C& cx, const GenDev& K, GenScratch& s) {
   cx.sync();
   MZ_FOR(i, m.nv) gen_mass_item(K, s, i);
   MZ_FOR(b, m.nbody) gen_fluid_item(K, s, b);
-  MZ_FOR(one, 1) gen_compact_contacts(K, s);
+  { const int np = s.npool < GN_POOL ? s.npool : GN_POOL; MZ_FOR(e, np) gen_compact_item(K, s, e, np); }
+  MZ_FOR(one, 1) gen_limits_serial(K, s);
   cx.sync();
   MZ_FOR(i, m.nv) gen_force_item(K, s, i);
   MZ_FOR(e, m.nv * m.nv) { const int i = e / m.nv, j = e - m.nv * i; if (i < j) s.M[i][j] = s.M[j][i]; }  // gen_mass_item wrote the lower triangle
@@ -843,10 +1190,14 @@ MZ_HD void gen_integrate_pos(const GenDev& K, GenScratch& s, const double* base,
   const mz_model& m = K.m;
   for (int j = 0; j < m.njnt; j++) {
     const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-    if (m.jnt_type[j] == MZ_JNT_FREE) {
-      for (int k = 0; k < 3; k++) s.qpos[qa + k] = base[qa + k] + h * vel[da + k];
-      const double w[3] = {vel[da + 3], vel[da + 4], vel[da + 5]}, n = sqrt(gd_dot3(w, w));
-      double q[4] = {base[qa + 3], base[qa + 4], base[qa + 5], base[qa + 6]};
+    if (m.jnt_type[j] == MZ_JNT_FREE || m.jnt_type[j] == MZ_JNT_BALL) {  // mj_integratePos: q <- q * exp(h w / 2), w in the child frame
+      int qq = qa, dw = da;
+      if (m.jnt_type[j] == MZ_JNT_FREE) {
+        for (int k = 0; k < 3; k++) s.qpos[qa + k] = base[qa + k] + h * vel[da + k];
+        qq = qa + 3; dw = da + 3;
+      }
+      const double w[3] = {vel[dw], vel[dw + 1], vel[dw + 2]}, n = sqrt(gd_dot3(w, w));
+      double q[4] = {base[qq], base[qq + 1], base[qq + 2], base[qq + 3]};
       if (n > 1e-15) {
         const double sh = sin(0.5 * h * n) / n, qr[4] = {cos(0.5 * h * n), w[0] * sh, w[1] * sh, w[2] * sh};
         double qn[4];
@@ -854,7 +1205,7 @@ MZ_HD void gen_integrate_pos(const GenDev& K, GenScratch& s, const double* base,
         for (int k = 0; k < 4; k++) q[k] = qn[k];
       }
       gd_quat_norm(q);
-      for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = q[k];
+      for (int k = 0; k < 4; k++) s.qpos[qq + k] = q[k];
     } else {
       s.qpos[qa] = base[qa] + h * vel[da];
     }
@@ -889,16 +1240,56 @@ MZ_HD void gen_mj_step(const C& cx, const GenDev& K, GenScratch& s) {
   cx.sync();
 }
 
-// observation element i (maze_env.py:351-369): qpos[:3] | qpos[3:nq_robot] | qvel[:nv_robot] | t / 1000
-MZ_HD float gen_obs_elem(const GenDev& K, const GenScratch& s, int i, int t) {
+// ------------------------------------------------------------------ observation (maze_env.py:351-369)
+// get_body_com of a movable body = its frame origin: the spawn position plus its slide coordinates along their axes; a free-joint
+// body's origin is its qpos (mzo_env.c body_origin).  Movable bodies hang off the world, so no kinematics pass is needed.
+template <class Q>
+MZ_HD double gen_body_origin(const mz_model& m, const Q* qpos, int body, int c) {
+  const int j0 = m.body_jntadr[body], jn = m.body_jntnum[body];
+  if (jn == 1 && m.jnt_type[j0] == MZ_JNT_FREE) return (double)qpos[m.jnt_qposadr[j0] + c];
+  double p = m.body_pos[body][c];
+  for (int j = j0; j < j0 + jn; j++)
+    if (m.jnt_type[j] == MZ_JNT_SLIDE) p += m.jnt_axis[j][c] * ((double)qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]]);
+  return p;
+}
+// element i of the observation WITHOUT the view: robot qpos[:3] | object balls' xpos | movable blocks' xpos (3 each, if observed) |
+// robot qpos[3:nq_robot] | robot qvel[:nv_robot] | t / 1000
+template <class Q>
+MZ_HD float gen_obs_elem(const GenDev& K, const Q* qpos, const Q* qvel, int i, int t) {
   const mz_model& m = K.m;
-  if (i < m.nq_robot) return (float)s.qpos[i];
-  if (i < m.nq_robot + m.nv_robot) return (float)s.qvel[i - m.nq_robot];
+  if (i < 3) return (float)qpos[i];
+  if (i < 3 + K.obs_extra) {
+    const int k = (i - 3) / 3, c = (i - 3) - 3 * k, nb = m.observe_balls ? m.nball : 0;
+    return (float)gen_body_origin(m, qpos, k < nb ? m.ball_bodyid[k] : m.block_bodyid[k - nb], c);
+  }
+  const int q = i - K.obs_extra;
+  if (q < m.nq_robot) return (float)qpos[q];
+  if (q < m.nq_robot + m.nv_robot) return (float)qvel[q - m.nq_robot];
   return (float)t * 0.001f;
 }
+// the row as the API hands it out: `base` = its width without the view; with a top-down view (row width base + MZ_VIEW_DIM) the
+// time entry moves behind the view and the movable blocks' x, y are parked in the view's first entries for mzk_view_fill
+template <class Q>
+MZ_HD void gen_store_obs(const GenDev& K, const Q* qpos, const Q* qvel, int t, float* row, int i) {
+  const mz_model& m = K.m;
+  const int base = m.nq_robot + m.nv_robot + 1 + K.obs_extra;
+  if (i < base - 1) { row[i] = gen_obs_elem(K, qpos, qvel, i, t); return; }
+  if (i == base - 1) {
+    row[m.top_down_view ? base - 1 + MZ_VIEW_DIM : base - 1] = (float)t * 0.001f;
+    if (m.top_down_view)
+      for (int b = 0; b < m.nblock && b < 4; b++) {
+        row[base - 1 + 2 * b] = (float)gen_body_origin(m, qpos, m.block_bodyid[b], 0);
+        row[base + 2 * b] = (float)gen_body_origin(m, qpos, m.block_bodyid[b], 1);
+      }
+  }
+}
 
-// MazeEnv.step for a generic robot: the ant's / swimmer's step shape (ant.py:61-73, swimmer.py:37-48) — clamped motors,
-// frame_skip x mj_step, forward reward |dxy| / dt, control cost on the raw action
+// ------------------------------------------------------------------ MazeEnv.step (maze_env.py:448-481)
+// The robot's own step in one of two shapes — motors (ant.py:61-73, swimmer.py:37-48: clamped motors, frame_skip x mj_step, forward
+// reward |dxy| / dt, control cost on the raw action) or the Point's (point.py:44-61: heading and position moved by the action,
+// velocities clipped, frame_skip x mj_step without control, no inner reward) — then the manual wall bounce where the robot asks
+// for it (maze_env.py:451-464), the observation, the task's reward and termination.
+// obs: a row of obs_dim floats (view entries left open, see gen_store_obs).
 template <class C>
 MZ_HD void gen_env_step(const C& cx, const GenDev& K, GenScratch& s, const float* action, float* obs, float* reward, uint8_t* done, int* goal_idx,
                         float* info, int* t_io) {
@@ -906,27 +1297,53 @@ MZ_HD void gen_env_step(const C& cx, const GenDev& K, GenScratch& s, const float
   MZ_FOR(i, m.nv) s.fact[i] = 0.0;
   MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
   cx.sync();
-  MZ_FOR(one, 1)
-    for (int u = 0; u < m.nu; u++) {
-      double c = (double)action[u];
-      if (m.act_ctrllimited[u]) c = fmin(fmax(c, m.act_ctrlrange[u][0]), m.act_ctrlrange[u][1]);
-      s.fact[m.act_dofid[u]] += m.act_gear[u] * c;
+  if (K.step_kind == GN_STEP_POINT) {
+    MZ_FOR(one, 1) {  // point.py:45-56
+      const double pi = 3.14159265358979323846;
+      double th = s.qpos[2] + (double)action[1];
+      if (th < -pi) th += pi * 2; else if (pi < th) th -= pi * 2;
+      s.qpos[2] = th;
+      s.qpos[0] += cos(th) * (double)action[0];
+      s.qpos[1] += sin(th) * (double)action[0];
     }
+    MZ_FOR(i, m.nv) s.qvel[i] = fmin(fmax(s.qvel[i], -m.velocity_limit), m.velocity_limit);
+  } else {
+    MZ_FOR(one, 1)
+      for (int u = 0; u < m.nu; u++) {
+        double c = (double)action[u];
+        if (m.act_ctrllimited[u]) c = fmin(fmax(c, m.act_ctrlrange[u][0]), m.act_ctrlrange[u][1]);
+        s.fact[m.act_dofid[u]] += m.act_gear[u] * c;
+      }
+  }
   cx.sync();
   for (int f = 0; f < m.frame_skip; f++) gen_mj_step(cx, K, s);
-  const int t = *t_io + 1, obs_dim = m.obs_dim;
-  MZ_FOR(i, obs_dim) obs[i] = gen_obs_elem(K, s, i, t);
+  if (K.nseg > 0) {  // CollisionDetector.detect + bounce / give-up on the robot's xy (maze_env.py:451-464)
+    MZ_FOR(one, 1) {
+      const double old_xy[2] = {s.red[1], s.red[2]}, new_xy[2] = {s.qpos[0], s.qpos[1]};
+      double fin[2];
+      const int r = point_bounce(K, old_xy, new_xy, fin, (double*)nullptr);
+      if (r < 0) s.status |= MZ_STATUS_COLLINEAR;
+      s.qpos[0] = fin[0]; s.qpos[1] = fin[1];
+    }
+    cx.sync();
+  }
+  const int t = *t_io + 1, base = m.nq_robot + m.nv_robot + 1 + K.obs_extra;
+  MZ_FOR(i, base) gen_store_obs(K, s.qpos, s.qvel, t, obs, i);
   cx.sync();
   MZ_FOR(one, 1) {
-    const double dt = m.timestep * m.frame_skip, vx = (s.qpos[0] - s.red[1]) / dt, vy = (s.qpos[1] - s.red[2]) / dt, fwd = sqrt(vx * vx + vy * vy);
-    double cc = 0.0;
-    for (int u = 0; u < m.nu; u++) cc += (double)action[u] * (double)action[u];
-    cc *= K.task.ctrl_w;
+    double fwd = 0.0, cc = 0.0, inner = 0.0;
+    if (K.step_kind != GN_STEP_POINT) {
+      const double dt = m.timestep * m.frame_skip, vx = (s.qpos[0] - s.red[1]) / dt, vy = (s.qpos[1] - s.red[2]) / dt;
+      fwd = sqrt(vx * vx + vy * vy);
+      for (int u = 0; u < m.nu; u++) cc += (double)action[u] * (double)action[u];
+      cc *= K.task.ctrl_w;
+      inner = K.task.fwd_w * fwd - cc;
+    }
     float o6[6];
-    for (int k = 0; k < 6; k++) o6[k] = k < obs_dim ? obs[k] : 0.f;
+    for (int k = 0; k < 6; k++) o6[k] = k < base - 1 ? obs[k] : 0.f;
     float outer; int tm, gi;
     task_eval_dev(K.task, o6, &outer, &tm, &gi);
-    *reward = (float)(K.task.inner_scale * (K.task.fwd_w * fwd - cc) + (double)outer);
+    *reward = (float)(K.task.inner_scale * inner + (double)outer);
     *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
     if (goal_idx) *goal_idx = gi;
     if (info) { info[0] = (float)s.qpos[0]; info[1] = (float)s.qpos[1]; info[2] = (float)fwd; info[3] = (float)-cc; }

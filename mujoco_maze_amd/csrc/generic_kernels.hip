@@ -1,14 +1,17 @@
-// generic_kernels.hip — HIP kernels (gfx950 / CDNA4) of the generic-robot path (csrc/generic_dyn.h): a user's AgentModel whose
-// MJCF compiles to a kinematic tree none of the specialised kernels is written for.
+// generic_kernels.hip — HIP kernels (gfx950 / CDNA4) of the GENERAL ENGINE (csrc/generic_dyn.h): any compiled mz_model none of the
+// specialised kernels steps — a user's AgentModel of any tree topology, mazes with SPIN plates (a box on a ball joint), more than
+// three movable blocks — and any model at all when the caller asks for it (mz_model.engine = 1: the cross-check of the
+// specialised kernels).
 //
 //   generic_step_kernel   one MazeEnv.step per env: ONE WAVEFRONT (64 lanes) per environment, the env's working set
-//                         (GenScratch, 32 KB, float64) in LDS for the frame_skip x 4 forward evaluations of the step; the
-//                         compiled mz_model itself is the constant block (global memory, uniform loads).
+//                         (GenScratch, ~100 KB, float64) in LDS for the frame_skip x 4 forward evaluations of the step — a
+//                         gfx950 workgroup may hold up to 160 KB; the compiled mz_model itself is the constant block (global
+//                         memory, uniform loads).
 //   reset / state copy kernels.
 //
 // HBM layout: state[N][REC] fp32 record = qpos[nq] | qvel[nv] | qacc_warmstart[nv] | t | episode (REC = nq + 2 nv + 2).
 // Built with the strict floating-point flags of csrc/Makefile (no fast-math): the path computes in float64 and is compared
-// with the float64 oracle at 1e-6.
+// with the float64 oracle at 1e-6; the Point's manual wall bounce (point_dyn.h) is bit-exact under these flags.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,7 +21,7 @@
 #include "mz_device.h"
 #include "mz_internal.h"
 
-struct GenIO { float act[MZ_MAX_ACT], obs[MZ_MAX_OBS], out[8]; int iout[4]; };
+struct GenIO { float act[MZ_MAX_ACT], obs[MZ_MAX_OBS + MZ_VIEW_DIM], out[8]; int iout[4]; };
 struct alignas(16) GenEnvLDS { GenScratch s; GenIO io; };
 
 __global__ __launch_bounds__(64) void generic_step_kernel(const GenDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
@@ -66,7 +69,9 @@ __global__ __launch_bounds__(64) void generic_step_kernel(const GenDev* __restri
     cx.sync();
     if (cx.l == 0 && m.njnt > 0 && m.jnt_type[0] == MZ_JNT_FREE) gd_quat_norm(s.qpos + m.jnt_qposadr[0] + 3);  // [ASSUME-8]
     cx.sync();
-    for (int i = cx.l; i < obs_dim; i += 64) { const float v = gen_obs_elem(K, s, i, 0); obs[(size_t)env * obs_dim + i] = v; if (rrow) rrow[i] = v; }
+    for (int i = cx.l; i < obs_dim - (m.top_down_view ? MZ_VIEW_DIM : 0); i += 64) gen_store_obs(K, s.qpos, s.qvel, 0, L.io.obs, i);
+    cx.sync();
+    for (int i = cx.l; i < obs_dim; i += 64) { const float v = L.io.obs[i]; obs[(size_t)env * obs_dim + i] = v; if (rrow) rrow[i] = v; }
   }
   cx.sync();
   for (int i = cx.l; i < rec_t; i += 64) rec[i] = (float)(i < nq ? s.qpos[i] : (i < nq + nv ? s.qvel[i - nq] : s.warm[i - nq - nv]));
@@ -92,9 +97,7 @@ __global__ void generic_reset_kernel(const GenDev* __restrict__ Kp, int n, float
   }
   if (obs) {
     float* o = obs + (size_t)env * m.obs_dim;
-    for (int i = 0; i < m.nq_robot; i++) o[i] = rec[i];
-    for (int i = 0; i < m.nv_robot; i++) o[m.nq_robot + i] = rec[nq + i];
-    o[m.obs_dim - 1] = (float)((int*)rec)[rec_t] * 0.001f;
+    for (int i = 0; i < m.obs_dim - (m.top_down_view ? MZ_VIEW_DIM : 0); i++) gen_store_obs(*Kp, rec, rec + nq, ((int*)rec)[rec_t], o, i);
   }
 }
 
@@ -130,14 +133,14 @@ __global__ void generic_task_eval_kernel(const GenDev* __restrict__ Kp, int n, i
 }
 
 // ------------------------------------------------------------------ entry points of this translation unit (mz_internal.h)
+int mzk_generic_needed(const mz_model* m) { return gen_model_needs_general_engine(m); }
 int mzk_generic_create(mz_handle* h, char* err, int errlen) {
   GenDev* g = (GenDev*)malloc(sizeof(GenDev));
   if (!g) return MZ_ERR_HIP;
   int rc = gen_dev_from_model(g, &h->model, err, errlen);
-  if (rc == MZ_OK && h->model.obs_dim != h->model.nq_robot + h->model.nv_robot + 1) rc = gen_fail(err, errlen, "generic robot kernel: obs_dim must be nq_robot + nv_robot + 1");
   if (rc == MZ_OK) {
     if (hipMalloc(&h->gen_dev, sizeof(GenDev)) != hipSuccess || hipMemcpy(h->gen_dev, g, sizeof(GenDev), hipMemcpyHostToDevice) != hipSuccess)
-      rc = gen_fail(err, errlen, "generic robot kernel: device allocation failed") == MZ_ERR_UNSUPPORTED ? MZ_ERR_HIP : MZ_ERR_HIP;
+      rc = gen_fail(err, errlen, "general engine: device allocation failed") == MZ_ERR_UNSUPPORTED ? MZ_ERR_HIP : MZ_ERR_HIP;
   }
   free(g);
   return rc;

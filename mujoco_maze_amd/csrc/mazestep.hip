@@ -73,12 +73,15 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   if (!h) return fail("mz_create: out of memory");
   memset(h, 0, sizeof(*h));
   h->model = *model; h->n = num_envs; h->device = device; h->robot = model->robot; h->lanes = 32; h->waves_per_block = 1; h->seed = 0x5EEDULL;
+  // the general engine (generic_dyn.h) steps what no specialised kernel does — user robots, SPIN plates, more than three blocks —
+  // and whatever the caller asks it to (mz_model.engine = 1); h->robot is the dispatch key, h->model.robot stays the family
+  if (mzk_generic_needed(model)) h->robot = MZ_ROBOT_GENERIC;
   char msg[200] = {0};
   int rc = MZ_OK;
-  if (model->robot == MZ_ROBOT_ANT) rc = ant_dev_from_model(&h->ant, model, msg, sizeof(msg));
+  if (h->robot == MZ_ROBOT_GENERIC) rc = MZ_OK;  // checked by mzk_generic_create below (it needs the device)
+  else if (model->robot == MZ_ROBOT_ANT) rc = ant_dev_from_model(&h->ant, model, msg, sizeof(msg));
   else if (model->robot == MZ_ROBOT_POINT) rc = point_dev_from_model(&h->point, model, msg, sizeof(msg));
   else if (model->robot == MZ_ROBOT_SWIMMER) rc = swimmer_dev_from_model(&h->swimmer, model, msg, sizeof(msg));
-  else if (model->robot == MZ_ROBOT_GENERIC) rc = MZ_OK;  // checked by mzk_generic_create below (it needs the device)
   else { rc = MZ_ERR_UNSUPPORTED; snprintf(msg, sizeof(msg), "mz_create: robot kind %d has no device kernel yet", model->robot); }
   if (rc != MZ_OK) { delete h; return fail(msg); }
   hipError_t e = hipSuccess;
@@ -88,7 +91,7 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   if (h->robot == MZ_ROBOT_GENERIC) {
     rc = mzk_generic_create(h, msg, sizeof(msg));
     if (rc != MZ_OK) { mz_destroy(h); return fail(msg); }
-    h->base_obs = model->obs_dim;
+    h->base_obs = model->obs_dim - vdim;
     const size_t rec = (size_t)model->nq + 2 * model->nv + 2;
     e = hipMalloc(&h->state, (size_t)num_envs * rec * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)num_envs * rec * sizeof(float));

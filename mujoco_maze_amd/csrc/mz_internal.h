@@ -74,6 +74,7 @@ int mzk_planar_state_width(const mz_handle* h);  // coordinates per env of the s
 int mzk_planar_record_width(const mz_handle* h); // Point: floats per env-major record; 0 for the chains (SoA)
 
 // ---- generic_kernels.hip (a user robot of any tree topology, csrc/generic_dyn.h)
+int mzk_generic_needed(const mz_model* m);  // no specialised kernel steps this model, or the caller asked for the general engine (mz_model.engine)
 int mzk_generic_create(mz_handle* h, char* err, int errlen);  // builds + uploads the constant block; MZ_OK or MZ_ERR_*
 void mzk_generic_destroy(mz_handle* h);
 hipError_t mzk_generic_step(mz_handle* h, hipStream_t st, const float* actions, float* obs, float* reward, uint8_t* done, int* goal_idx, float* info);

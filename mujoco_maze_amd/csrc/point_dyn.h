@@ -214,9 +214,11 @@ MZP_HD double cross2d(double ax, double ay, double bx, double by) {
 // one among equals (`dist < best`, strict).  point_detect_range is that loop body over the segments k0, k0 + kstep, ...: the whole
 // table for the serial form (point_detect: the golden-vector kernel mz_debug_detect, the host emulation), one residue class per
 // lane for the step kernel's lane groups (planar_dyn.h point_detect_group, which then takes the minimum by (dist, k) — the same
-// winner).  The arithmetic of a segment is the same function either way.
+// winner).  The arithmetic of a segment is the same function either way.  PD: anything with nseg / seg / restitution (PointDev;
+// the general engine's GenDev, generic_dyn.h).
 struct PtCand { int found, degenerate, k; double dist, pt[2], rf[2]; };
-MZP_HD void point_detect_range(const PointDev& P, const double* o, const double* n, double mvx, double mvy, int k0, int kstep, PtCand& c) {
+template <class PD>
+MZP_HD void point_detect_range(const PD& P, const double* o, const double* n, double mvx, double mvy, int k0, int kstep, PtCand& c) {
 #pragma clang fp contract(off) reciprocal(off) reassociate(off)
   for (int k = k0; k < P.nseg; k += kstep) {
     const double* s = P.seg[k];
@@ -244,7 +246,8 @@ MZP_HD void point_detect_range(const PointDev& P, const double* o, const double*
 }
 
 // 1 hit, 0 none, -1 collinear (the reference raises ZeroDivisionError)
-MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, double* pt, double* rf) {
+template <class PD>
+MZP_HD int point_detect(const PD& P, const double* o, const double* n, double* pt, double* rf) {
 #pragma clang fp contract(off) reciprocal(off) reassociate(off)
   double mvx = n[0] - o[0], mvy = n[1] - o[1];
   if (mz_hypot(mvx, mvy) <= 1e-8) return 0;
@@ -258,7 +261,8 @@ MZP_HD int point_detect(const PointDev& P, const double* o, const double* n, dou
 
 // Wall bounce of MazeEnv.step (maze_env.py:457-464): 0 no hit, 1 bounced to `fin`, 2 gave up (fin = old position),
 // -1 where the reference would have raised (collinear move; fin = new position)
-MZP_HD int point_bounce(const PointDev& P, const double* old_xy, const double* new_xy, double* fin, double* hit_pt) {
+template <class PD>
+MZP_HD int point_bounce(const PD& P, const double* old_xy, const double* new_xy, double* fin, double* hit_pt) {
 #pragma clang fp contract(off) reciprocal(off) reassociate(off)
   double pt[2] = {0.0, 0.0}, rf[2] = {0.0, 0.0};
   fin[0] = new_xy[0]; fin[1] = new_xy[1];

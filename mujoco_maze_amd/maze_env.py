@@ -120,9 +120,15 @@ class VecMazeEnv:
                                       "topology, stepped from its MJCF: AgentModel.FILE)")
         if robot == "generic":  # the user's own robot (agent_model.py:12-41, README.md:127): its MJCF, frame_skip, reset distribution
             kwargs.setdefault("robot_xml", getattr(model_cls, "FILE", None))
-            gen_kw = dict(frame_skip=int(getattr(model_cls, "FRAME_SKIP", 1)), reset_qvel=getattr(model_cls, "RESET_QVEL", "normal"))
+            # round 6: STEP = "motors" (ant.py:61-73, the default) or "point" (point.py:44-61: the action moves heading and position,
+            # velocities clipped to VELOCITY_LIMITS); MANUAL_COLLISION / RADIUS as for the built-in Point
+            gen_kw = dict(frame_skip=int(getattr(model_cls, "FRAME_SKIP", 1)), reset_qvel=getattr(model_cls, "RESET_QVEL", "normal"),
+                          step=getattr(model_cls, "STEP", "motors"), velocity_limit=getattr(model_cls, "VELOCITY_LIMITS", None))
         else:
             gen_kw = {}
+        # engine="general": step this env on the general engine (csrc/generic_dyn.h) whatever the robot — the second, independent
+        # device implementation the specialised kernels are cross-checked with; "auto" (default): only where they cannot step it
+        gen_kw["engine"] = kwargs.pop("engine", "auto")
         self.model: CompiledModel = compile_model(
             robot, self._task, maze_size_scaling, inner_reward_scaling=inner_reward_scaling,
             restitution_coef=restitution_coef, maze_height=maze_height, max_episode_steps=max_episode_steps,

@@ -9,7 +9,7 @@ built-in robot — other masses, sizes, gears, limits, contact parameters — lo
 
 Supported elements: `<compiler angle coordinate inertiafromgeom>`, `<option timestep integrator density viscosity
 collision>`, one top-level `<default>` with `<geom>`, `<joint>`, `<motor>`; `<worldbody>` with one plane geom (the
-floor) and one robot body tree of `<body>`, `<joint type=free|slide|hinge>`, `<freejoint>`,
+floor) and one robot body tree of `<body>`, `<joint type=free|ball|slide|hinge>`, `<freejoint>`,
 `<geom type=sphere|capsule|box>`; `<actuator><motor>`.  Lights, cameras, sites, assets and materials are skipped.
 The device kernels are written for the topologies of the four built-in robots (`csrc/*_dyn.h` check it when the
 model is created), so an XML may change parameters, not structure.
@@ -22,7 +22,7 @@ from mujoco_maze_amd import robots as R
 
 _GEOM_TYPE = {"plane": R.PLANE, "sphere": R.SPHERE, "capsule": R.CAPSULE, "box": R.BOX}
 _GEOM_NAME = {v: k for k, v in _GEOM_TYPE.items()}
-_JOINT_TYPE = {"free": R.FREE, "slide": R.SLIDE, "hinge": R.HINGE}
+_JOINT_TYPE = {"free": R.FREE, "ball": R.BALL, "slide": R.SLIDE, "hinge": R.HINGE}
 _JOINT_NAME = {v: k for k, v in _JOINT_TYPE.items()}
 
 
@@ -82,7 +82,9 @@ def spec_to_mjcf(spec: R.RobotSpec) -> str:
             ET.SubElement(e, "geom", **_geom_attrs(g, dg))
         for j in b.joints:
             a = {"name": j.name, "type": _JOINT_NAME[j.type]}
-            if j.type != R.FREE:
+            if j.type == R.BALL:
+                a.update(pos=_fmt(j.pos), limited="false")
+            elif j.type != R.FREE:
                 a.update(axis=_fmt(j.axis), pos=_fmt(j.pos), limited="true" if j.limited else "false", range=_fmt(j.range))
             for f in _JOINT_FIELDS:
                 v = getattr(j, f)
@@ -142,7 +144,7 @@ def _apply_joint(base: R.JointSpec, e: ET.Element, name: str, radians: bool) -> 
     kw = {}
     jt = "free" if e.tag == "freejoint" else a.get("type", "hinge")  # MuJoCo's default joint type is hinge
     if jt not in _JOINT_TYPE:
-        raise ValueError(f"joint {name!r}: type {jt!r} is not supported (free, slide, hinge)")
+        raise ValueError(f"joint {name!r}: type {jt!r} is not supported (free, ball, slide, hinge)")
     kw["type"] = _JOINT_TYPE[jt]
     if "axis" in a:
         kw["axis"] = _floats(a["axis"])
@@ -169,8 +171,8 @@ def _apply_joint(base: R.JointSpec, e: ET.Element, name: str, radians: bool) -> 
 def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1, reset_qvel: str = "normal") -> R.RobotSpec:
     """Parse an MJCF file (path) or text into a RobotSpec.  `like` is the built-in spec of the robot family: it supplies
     what MJCF does not carry (frame_skip, reset distribution, robot coordinate counts — `ant.py`, `point.py`, ...).
-    `like = None`: a robot of the user's own (any tree of free / slide / hinge joints with sphere / capsule geoms and motors);
-    it is stepped by the generic device kernel (csrc/generic_dyn.h), frame_skip / reset distribution as given."""
+    `like = None`: a robot of the user's own (any tree of free / ball / slide / hinge joints with sphere / capsule / box geoms and
+    motors); it is stepped by the general engine (csrc/generic_dyn.h), frame_skip / reset distribution as given."""
     text = source if "<" in source else open(source).read()  # XML text or a file path
     root = ET.fromstring(text)
     if root.tag != "mujoco":
@@ -235,8 +237,8 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
         a.update(mtr.attrib)
         gear = _floats(a.get("gear", "1"))[0]
         acts.append(R.ActuatorSpec(a["joint"], gear, _floats(a.get("ctrlrange", "0 0")), a.get("ctrllimited", "false") == "true"))
-    nq = sum(7 if j.type == R.FREE else 1 for b in bodies for j in b.joints)
-    nv = sum(6 if j.type == R.FREE else 1 for b in bodies for j in b.joints)
+    nq = sum({R.FREE: 7, R.BALL: 4}.get(j.type, 1) for b in bodies for j in b.joints)
+    nv = sum({R.FREE: 6, R.BALL: 3}.get(j.type, 1) for b in bodies for j in b.joints)
     # The swimmer family's kernels are written for planar chains of 2..6 links (csrc/swimmer_dyn.h is generic in the link count;
     # Swimmer = 3, Reacher = 2): a user's chain may be longer or shorter than the built-in asset's.  Every other family keeps
     # its structure (parameters may change, topology not).

@@ -25,7 +25,7 @@ from mujoco_maze_amd import robots as R
 from mujoco_maze_amd.maze_env_utils import CollisionDetector, MazeCell
 from mujoco_maze_amd.maze_task import MazeTask, device_reward_descriptor
 
-MZ_ABI_VERSION = 7
+MZ_ABI_VERSION = 8
 MAX_BODY, MAX_JNT, MAX_DOF, MAX_Q, MAX_GEOM, MAX_ACT = 24, 24, 24, 28, 24, 8
 MAX_GRID, MAX_SEG, MAX_GOAL, MAX_OBS = 12, 96, 8, 48
 VIEW_DIM = 75  # MZ_VIEW_DIM: the 5 x 5 x 3 top-down view (maze_env.py:95)
@@ -41,7 +41,7 @@ class MzModel(C.Structure):
         ("nbody", i32), ("njnt", i32), ("nq", i32), ("nv", i32), ("ngeom", i32), ("nu", i32),
         ("nq_robot", i32), ("nv_robot", i32),
         ("frame_skip", i32), ("integrator_rk4", i32), ("collision_predefined", i32), ("manual_collision", i32),
-        ("max_episode_steps", i32), ("obs_dim", i32), ("reset_qvel_kind", i32), ("pad0", i32),
+        ("max_episode_steps", i32), ("obs_dim", i32), ("reset_qvel_kind", i32), ("engine", i32),
         ("timestep", f64), ("gravity", f64 * 3), ("density", f64), ("viscosity", f64), ("meaninertia", f64),
         ("body_parent", i32 * MAX_BODY), ("body_jntadr", i32 * MAX_BODY), ("body_jntnum", i32 * MAX_BODY),
         ("body_dofadr", i32 * MAX_BODY), ("body_dofnum", i32 * MAX_BODY),
@@ -65,7 +65,7 @@ class MzModel(C.Structure):
         ("grid_rows", i32), ("grid_cols", i32), ("grid", (u8 * MAX_GRID) * MAX_GRID),
         ("maze_scale", f64), ("torso_x", f64), ("torso_y", f64),
         ("wall_half_xy", f64), ("wall_half_z", f64), ("wall_center_z", f64),
-        ("wall_contype", i32), ("wall_conaffinity", i32), ("wall_condim", i32), ("pad1", i32),
+        ("wall_contype", i32), ("wall_conaffinity", i32), ("wall_condim", i32), ("step_kind", i32),
         ("wall_friction", f64 * 3), ("wall_solref", f64 * 2), ("wall_solimp", f64 * 5),
         ("wall_margin", f64), ("wall_gap", f64),
         ("nseg", i32), ("pad2", i32), ("seg", (f64 * 4) * MAX_SEG), ("restitution", f64), ("velocity_limit", f64),
@@ -219,11 +219,14 @@ def geom_rbound(gtype, size):
 class MazeWorld:
     """Cell grid -> world description (reference maze_env.py:57-68, 116-152)."""
 
-    def __init__(self, structure: List[List[MazeCell]], scale: float, maze_height: float = 0.5):
+    def __init__(self, structure: List[List[MazeCell]], scale: float, maze_height: float = 0.5, put_spin_near_agent: bool = False):
         self.structure = structure
         self.scale = float(scale)
+        self.put_spin_near_agent = bool(put_spin_near_agent)  # MazeTask.PUT_SPIN_NEAR_AGENT (maze_task.py:67, maze_env.py:51,119-120)
         self.rows, self.cols = len(structure), len(structure[0])
         self.elevated = any(c is MazeCell.CHASM for row in structure for c in row)
+        # maze_env.py:61: `self.blocks` looks at the structure as the task wrote it — a plate that PUT_SPIN_NEAR_AGENT drops
+        # onto the robot's cell does NOT switch the default geoms to solimp .995
         self.has_blocks = any(c.can_move() for row in structure for c in row)
         self.has_balls = any(c.is_object_ball() for row in structure for c in row)
         robots = [(j * scale, i * scale) for i in range(self.rows) for j in range(self.cols) if structure[i][j].is_robot()]
@@ -234,9 +237,14 @@ class MazeWorld:
         self.half_z = maze_height / 2.0 * scale
         self.height_offset = maze_height * scale if self.elevated else 0.0
 
+    def cell_as_built(self, i, j):
+        """The cell the world generator acts on (maze_env.py:116-120): a ROBOT cell becomes a SPIN plate under PUT_SPIN_NEAR_AGENT."""
+        c = self.structure[i][j]
+        return MazeCell.SPIN if (self.put_spin_near_agent and c.is_robot()) else c
+
     def movable_cells(self):
         """[(i, j, cell)] of movable-block cells in row-major order (maze_env.py:153-166)."""
-        return [(i, j, self.structure[i][j]) for i in range(self.rows) for j in range(self.cols) if self.structure[i][j].can_move()]
+        return [(i, j, self.cell_as_built(i, j)) for i in range(self.rows) for j in range(self.cols) if self.cell_as_built(i, j).can_move()]
 
     def ball_cells(self):
         """[(i, j)] of object-ball cells in row-major order (maze_env.py:167-191)."""
@@ -265,19 +273,25 @@ class MazeWorld:
 
 
 # ---------------------------------------------------------------- what the device kernels can step
-DEVICE_ELEVATED_ROBOTS = {"swimmer", "reacher", "point", "ant"}  # robots whose kernels handle elevated mazes (Fall / MultiFall): filled as kernels gain support
+def needs_general_engine(cm) -> bool:
+    """Mirror of csrc/generic_dyn.h gen_model_needs_general_engine: True when no specialised kernel steps this model (a user robot,
+    a SPIN plate's ball joint, more than three movable blocks, blocks of several sizes, a three-slide block anywhere but the
+    one-block ant) or the caller asked for the general engine."""
+    m = cm.c
+    if m.robot == ROBOT_ID["generic"] or m.engine == 1 or m.nblock > 3:
+        return True
+    if any(m.jnt_type[j] == R.BALL for j in range(m.njnt)):
+        return True
+    if any(m.body_jntnum[m.block_bodyid[k]] != 2 for k in range(m.nblock)) and not (m.robot == ROBOT_ID["ant"] and m.nblock == 1):
+        return True
+    sizes = {tuple(m.geom_size[m.block_geomid[k]]) for k in range(m.nblock)}
+    return len(sizes) > 1
 
 
 def device_unsupported_reason(cm) -> Optional[str]:
-    """None when the HIP kernels can step this compiled model, else why not.  `compile_model` itself accepts every maze
-    the host mirror and the CPU oracle understand (so that exporters and oracle tests work); the device path is narrower."""
-    m = cm.c
-    robot = {v: k for k, v in ROBOT_ID.items()}[m.robot] if m.robot in ROBOT_ID.values() else "?"
-    if any(m.body_jntnum[m.block_bodyid[k]] != 2 for k in range(m.nblock)) and not (cm.spec.name == "ant" and m.nblock == 1):
-        return ("movable blocks with three slides are on the device path for the ant with a single block only (MultiFall)")
-    if m.elevated and cm.spec.name not in DEVICE_ELEVATED_ROBOTS:
-        return (f"elevated mazes (Fall / MultiFall) are not on the device path for the {cm.spec.name} yet: platforms under the robot and "
-                "z-sliding blocks need kernel support (DESIGN.md section 8)")
+    """None when the HIP kernels can step this compiled model, else why not.  Since round 6 the general engine
+    (csrc/generic_dyn.h) steps whatever the specialised kernels do not, so every model `compile_model` accepts has a device path;
+    the library itself still refuses what exceeds its buffers (mz_create returns the reason)."""
     return None
 
 
@@ -308,8 +322,16 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
                   restitution_coef: float = 0.8, maze_height: float = 0.5, max_episode_steps: int = 1000,
                   forward_reward_weight: float = 1.0, ctrl_cost_weight: float = 1e-4,
                   manual_collision: Optional[bool] = None, radius: Optional[float] = None,
-                  robot_xml: Optional[str] = None, frame_skip: Optional[int] = None, reset_qvel: Optional[str] = None) -> CompiledModel:
-    """`robot_xml`: path or text of an MJCF variant of the built-in robot (see `mjcf.py`); default: the built-in asset data."""
+                  robot_xml: Optional[str] = None, frame_skip: Optional[int] = None, reset_qvel: Optional[str] = None,
+                  engine: str = "auto", step: Optional[str] = None, velocity_limit: Optional[float] = None) -> CompiledModel:
+    """`robot_xml`: path or text of an MJCF variant of the built-in robot (see `mjcf.py`); default: the built-in asset data.
+    `engine`: "auto" — the robot family's specialised kernels where they can step the model, the general engine
+    (csrc/generic_dyn.h) where they cannot (SPIN plates, user robots, more than three blocks); "general" — the general engine
+    whatever the robot.  `step` (user robots): "motors" (ant.py:61-73) or "point" (point.py:44-61)."""
+    if engine not in ("auto", "general"):
+        raise ValueError("engine must be \"auto\" or \"general\"")
+    if step not in (None, "motors", "point"):
+        raise ValueError("step must be \"motors\" or \"point\"")
     if robot == "generic":
         # a user's AgentModel (agent_model.py:12-41): nothing built in — the MJCF is the robot; frame_skip and the reset
         # distribution come from the AgentModel class (kwargs below)
@@ -325,11 +347,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
 
             spec = mjcf.spec_from_mjcf(robot_xml, spec)
     structure = task.create_maze()
-    world = MazeWorld(structure, scale, maze_height)
+    world = MazeWorld(structure, scale, maze_height, put_spin_near_agent=bool(getattr(task, "PUT_SPIN_NEAR_AGENT", False)))
     balls = world.ball_cells()
-    if (balls or world.movable_cells() or world.elevated) and robot == "generic":
-        raise NotImplementedError("generic robots run in mazes without movable blocks, object balls or platforms (the device kernel of a user "
-                                  "robot collides it with the floor and the maze walls only)")
     if balls and robot not in ("point", "ant"):
         raise ValueError(f"OBJBALL_TYPE is not registered for the {robot}")  # maze_env.py:189-191: only PointEnv and AntEnv define one
     if len(balls) > 1:
@@ -337,12 +356,11 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     blocks = world.movable_cells()
     if balls and blocks:
         raise NotImplementedError("object balls together with movable blocks")
-    if any(cell.can_spin() for _, _, cell in blocks):
-        raise NotImplementedError("SPIN blocks (ball joint) are not supported (no registered task uses them)")
-    if len({cell.is_half_block() for _, _, cell in blocks}) > 1:
-        raise NotImplementedError("mazes that mix half blocks with full-size blocks (the device keeps one block size per maze)")
-    if len(blocks) > 3:
-        raise NotImplementedError("more than 3 movable blocks")
+    spins = any(cell.can_spin() for _, _, cell in blocks)
+    if len({cell.is_half_block() for _, _, cell in blocks if not cell.can_spin()}) > 1 and not (spins or robot == "generic"):
+        raise NotImplementedError("mazes that mix half blocks with full-size blocks (the specialised kernels keep one block size per maze)")
+    if len(blocks) > (4 if (spins or robot == "generic") else 3):
+        raise NotImplementedError("more than 3 movable blocks (4 on the general-engine path)")
     if world.rows > MAX_GRID or world.cols > MAX_GRID:
         raise ValueError("maze grid larger than MZ_MAX_GRID")
 
@@ -357,6 +375,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     m.density, m.viscosity = spec.density, spec.viscosity
     m.max_episode_steps = max_episode_steps
     m.reset_qvel_kind = RESET_KIND[spec.reset_qvel]
+    m.engine = 1 if engine == "general" else 0
+    m.step_kind = {None: 0, "motors": 1, "point": 2}[step]
     m.nq_robot, m.nv_robot = spec.nq_robot, spec.nv_robot
 
     # movable blocks change the default geom class (maze_env.py:108-112) and add bodies (maze_env.py:563-660)
@@ -364,7 +384,7 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     import dataclasses
 
     spec = copy.deepcopy(spec)
-    if blocks:
+    if world.has_blocks:
         stiff = (0.995, 0.995, 0.01, 0.5, 2.0)
         for gs in [spec.floor, spec.wall_geom_defaults] + [g for b in spec.bodies for g in b.geoms]:
             if not gs.explicit_solimp:
@@ -381,9 +401,15 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         # a block spawns INSIDE the platform box of its own cell (DESIGN.md section 8 describes what follows from that).
         bx, by = world.cell_center(bi_, bj_)
         falling = cell.can_move_z()
-        # shrink (maze_env.py:575-586): falling blocks 0.99, XY_HALF_BLOCK 0.5, else 1
-        half = world.scale * 0.5 * (0.99 if falling else 0.5 if cell.is_half_block() else 1.0)
-        geom = dataclasses.replace(spec.wall_geom_defaults, name=f"block_{bi_}_{bj_}", type=R.BOX, size=(half, half, world.half_z),
+        bh = world.half_z
+        # shrink (maze_env.py:575-586): SPIN plates 0.1 (a tenth of the height as well, moved a quarter cell along x), falling
+        # blocks 0.99, XY_HALF_BLOCK 0.5, else 1
+        if cell.can_spin():
+            bh, bx, shrink = bh * 0.1, bx + world.scale * 0.25, 0.1
+        else:
+            shrink = 0.99 if falling else 0.5 if cell.is_half_block() else 1.0
+        half = world.scale * 0.5 * shrink
+        geom = dataclasses.replace(spec.wall_geom_defaults, name=f"block_{bi_}_{bj_}", type=R.BOX, size=(half, half, bh),
                                    pos=(0.0, 0.0, 0.0), fromto=None, mass=0.001 if falling else 0.0002, contype=1, conaffinity=1)
         joints = []
         if cell.can_move_x():
@@ -395,7 +421,9 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         if cell.can_move_z():
             joints.append(R.JointSpec(f"movable_z_{bi_}_{bj_}", R.SLIDE, axis=(0.0, 0.0, 1.0), margin=0.01, limited=True,
                                       range=(-world.height_offset, 0.0)))
-        body = R.BodySpec(f"movable_{bi_}_{bj_}", -1, (bx, by, world.half_z), joints=joints, geoms=[geom])
+        if cell.can_spin():  # maze_env.py:649-660: a ball joint behind the two slides (the plate tilts and spins freely)
+            joints.append(R.JointSpec(f"spinable_{bi_}_{bj_}", R.BALL, axis=(0.0, 0.0, 1.0)))
+        body = R.BodySpec(f"movable_{bi_}_{bj_}", -1, (bx, by, bh), joints=joints, geoms=[geom])
         block_body_index.append(1 + len(spec.bodies))
         spec.bodies.append(body)
 
@@ -471,6 +499,11 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
             if j.type == R.FREE:
                 qpos0 += [b.pos[0], b.pos[1], b.pos[2], 1.0, 0.0, 0.0, 0.0]
                 dq, dv = 7, 6
+            elif j.type == R.BALL:
+                if j.limited:
+                    raise NotImplementedError(f"joint {j.name!r}: limited ball joints are not implemented")
+                qpos0 += [1.0, 0.0, 0.0, 0.0]
+                dq, dv = 4, 3
             else:
                 qpos0 += [0.0]
                 dq, dv = 1, 1
@@ -557,6 +590,11 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
                         axis = Rw[:, k]
                         J[b, 3:, d0 + 3 + k] = axis
                         J[b, :3, d0 + 3 + k] = np.cross(axis, xipos[b] - xpos[anc])
+                elif jt == R.BALL:
+                    for k in range(3):
+                        axis = Rw[:, k]
+                        J[b, 3:, d0 + k] = axis
+                        J[b, :3, d0 + k] = np.cross(axis, xipos[b] - anchor)
                 elif jt == R.SLIDE:
                     J[b, :3, d0] = Rw @ np.array(m.jnt_axis[jid][:])
                 elif jt == R.HINGE:
@@ -577,6 +615,8 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         if m.jnt_type[jid] == R.FREE:
             dinv[d0:d0 + 3] = dinv[d0:d0 + 3].mean()
             dinv[d0 + 3:d0 + 6] = dinv[d0 + 3:d0 + 6].mean()
+        elif m.jnt_type[jid] == R.BALL:
+            dinv[d0:d0 + 3] = dinv[d0:d0 + 3].mean()
     for d in range(nv):
         m.dof_invweight0[d] = dinv[d]
     for b in range(1, nbody):
@@ -606,9 +646,9 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     manual = (rcls.MANUAL_COLLISION if rcls is not None else False) if manual_collision is None else manual_collision
     m.manual_collision = int(bool(manual))
     m.restitution = restitution_coef
-    m.velocity_limit = getattr(rcls, "VELOCITY_LIMITS", 0.0)
+    m.velocity_limit = getattr(rcls, "VELOCITY_LIMITS", 0.0) if velocity_limit is None else float(velocity_limit)
     if manual:
-        rad = rcls.RADIUS if radius is None else radius
+        rad = (rcls.RADIUS if rcls is not None else None) if radius is None else radius
         if rad is None:
             raise ValueError("Manual collision needs radius of the model")
         det = CollisionDetector(structure, scale, world.torso_x, world.torso_y, rad)

@@ -241,7 +241,7 @@ void mzo_env_step(const mz_model* m, mzo_env_state* s, const double* action, dou
   s->t += 1; /* maze_env.py:449 */
   double old_xy[2] = {d.qpos[0], d.qpos[1]};
   double inner = 0.0, fwd = 0.0, ctrl_cost = 0.0;
-  if (m->robot == MZ_ROBOT_POINT) {
+  if (m->step_kind ? m->step_kind == 2 : m->robot == MZ_ROBOT_POINT) { /* mz_model.step_kind: 0 = the robot family's, 1 motors, 2 the Point's */
     /* point.py:45-59 */
     double th = d.qpos[2] + action[1];
     if (th < -M_PI) th += M_PI * 2;

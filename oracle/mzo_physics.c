@@ -111,6 +111,17 @@ static void kinematics(const mz_model* m, mzo_data* d) {
         double q = d->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
         if (m->jnt_type[j] == MZ_JNT_SLIDE) {
           addscl3(pos, axis, q);
+        } else if (m->jnt_type[j] == MZ_JNT_BALL) {
+          /* ball (mj_kinematics): the joint's coordinates ARE the relative quaternion (normalised in place, as for the free
+           * joint [ASSUME-8]); the body turns about the anchor */
+          double ql[4], qn[4], v[3];
+          memcpy(ql, d->qpos + m->jnt_qposadr[j], sizeof(ql));
+          quat_normalize(ql);
+          quat_mul(qn, quat, ql);
+          memcpy(quat, qn, sizeof(quat));
+          quat_to_mat(mat, quat);
+          mulmat3vec(v, mat, m->jnt_pos[j]);
+          sub3(pos, anchor, v);
         } else { /* hinge: rotate about the joint axis through the anchor */
           double ql[4], qn[4], v[3];
           axis_angle_quat(ql, m->jnt_axis[j], q);
@@ -203,6 +214,15 @@ static void com_and_crb(const mz_model* m, mzo_data* d) {
         sub3(off, c, d->xpos[b]);
         cpy3(d->S[d0 + 3 + k], ax);
         cross3(d->S[d0 + 3 + k] + 3, ax, off);
+      }
+    } else if (m->jnt_type[j] == MZ_JNT_BALL) {
+      /* three rotations about the body's own axes (the body frame AFTER all of its joints) through the anchor: the dofs are the
+       * angular velocity in the child frame, as the free joint's rotational half */
+      sub3(off, c, d->xanchor[j]);
+      for (int k = 0; k < 3; k++) {
+        double ax[3] = {d->xmat[b][k], d->xmat[b][3 + k], d->xmat[b][6 + k]};
+        cpy3(d->S[d0 + k], ax);
+        cross3(d->S[d0 + k] + 3, ax, off);
       }
     } else if (m->jnt_type[j] == MZ_JNT_SLIDE) {
       memset(d->S[d0], 0, 3 * sizeof(double));
@@ -307,6 +327,15 @@ static void velocity_and_forces(const mz_model* m, mzo_data* d, const double* ct
           for (int e = 0; e < 6; e++) {
             a[e] += sd[k][e] * d->qvel[d0 + 3 + k];
             v[e] += d->S[d0 + 3 + k][e] * d->qvel[d0 + 3 + k];
+          }
+      } else if (m->jnt_type[j] == MZ_JNT_BALL) {
+        /* mj_comVel: all three axis derivatives from the velocity in front of the joint, then the joint's velocity */
+        double sd[3][6];
+        for (int k = 0; k < 3; k++) motion_cross(sd[k], v, d->S[d0 + k]);
+        for (int k = 0; k < 3; k++)
+          for (int e = 0; e < 6; e++) {
+            a[e] += sd[k][e] * d->qvel[d0 + k];
+            v[e] += d->S[d0 + k][e] * d->qvel[d0 + k];
           }
       } else {
         double sd[6];
@@ -1226,6 +1255,16 @@ static void integrate_pos(const mz_model* m, double* qpos, const double* vel, do
         memcpy(qpos + qa + 3, qn, sizeof(qn));
       }
       quat_normalize(qpos + qa + 3);
+    } else if (m->jnt_type[j] == MZ_JNT_BALL) { /* mj_integratePos: q <- q * exp(h w / 2), w in the child frame */
+      double w[3] = {vel[da], vel[da + 1], vel[da + 2]};
+      double n = norm3(w);
+      if (n > MINVAL) {
+        double ax[3] = {w[0] / n, w[1] / n, w[2] / n}, qr[4], qn[4];
+        axis_angle_quat(qr, ax, h * n);
+        quat_mul(qn, qpos + qa, qr);
+        memcpy(qpos + qa, qn, sizeof(qn));
+      }
+      quat_normalize(qpos + qa);
     } else {
       qpos[qa] += h * vel[da];
     }

@@ -369,11 +369,85 @@ extern "C" int emu_generic_env_step(const mz_model* m, int n, float* qpos, float
     uint8_t d = 0;
     float r = 0.f, inf[4];
     gen_env_step(cx, *K, *s, actions + (size_t)e * m->nu, obs + (size_t)e * m->obs_dim, &r, &d, &gi, inf, &tt);
+    if (m->top_down_view) {  // what mzk_view_fill does on the device: the view from the row's own robot position and the parked block x, y
+      ViewDev V;
+      view_dev_from_model(m, &V);
+      mzv_fill_row(V, obs + (size_t)e * m->obs_dim, m->obs_dim - 1 - MZ_VIEW_DIM);
+    }
     for (int i = 0; i < m->nq; i++) qpos[(size_t)e * m->nq + i] = (float)s->qpos[i];
     for (int i = 0; i < m->nv; i++) { qvel[(size_t)e * m->nv + i] = (float)s->qvel[i]; warm[(size_t)e * m->nv + i] = (float)s->warm[i]; }
     t[e] = tt; reward[e] = r; done[e] = d; goal_idx[e] = gi; status[e] = s->status;
     if (info) for (int k = 0; k < 4; k++) info[(size_t)e * 4 + k] = inf[k];
   }
+  free(s); free(K);
+  return MZ_OK;
+}
+
+// narrow-phase routines of the general engine on hand-made poses (tests/test_general_engine.py compares them with the oracle's
+// mzo_probe_pair on random poses): kind 0 capsule (size = radius, half length) vs box, 1 box vs box, 2 sphere vs box.
+// out: per contact 7 doubles dist | pos | normal (geom1 -> geom2); returns the contact count
+extern "C" int emu_probe_pair(int kind, const double* pos1, const double* mat1, const double* size1, const double* pos2, const double* mat2,
+                              const double* size2, double margin, int max_con, double* out) {
+  int n = 0;
+  auto emit = [&](double dist, const double* pos, const double* nrm, const double*) {
+    if (n < max_con) { out[7 * n] = dist; for (int k = 0; k < 3; k++) { out[7 * n + 1 + k] = pos[k]; out[7 * n + 4 + k] = nrm[k]; } }
+    n++;
+  };
+  if (kind == 0) {
+    const double axis[3] = {mat1[2], mat1[5], mat1[8]};
+    gen_capsule_vs_box(pos1, axis, size1[0], size1[1], pos2, mat2, size2, margin, emit);
+  } else if (kind == 1) gen_box_vs_box(pos1, mat1, size1, pos2, mat2, size2, margin, emit);
+  else gen_sphere_vs_box(pos1, size1[0], pos2, mat2, size2, margin, emit);
+  return n;
+}
+
+// one forward-dynamics evaluation of the general engine (float64 state in): qacc [nv], counts = ncon, nlim, Newton iterations, status;
+// con (nullable) = per active contact 8 doubles item | dist | pos | normal
+extern "C" int emu_generic_forward(const mz_model* m, const double* qpos, const double* qvel, const double* warm, const double* ctrl, double* qacc,
+                                   int32_t* counts, double* con, int max_con, char* err, int errlen) {
+  GenDev* K = (GenDev*)calloc(1, sizeof(GenDev));
+  int rc = gen_dev_from_model(K, m, err, errlen);
+  if (rc != MZ_OK) { free(K); return rc; }
+  HostCtx cx;
+  GenScratch* s = (GenScratch*)calloc(1, sizeof(GenScratch));
+  for (int i = 0; i < m->nq; i++) s->qpos[i] = qpos[i];
+  for (int i = 0; i < m->nv; i++) { s->qvel[i] = qvel[i]; s->warm[i] = warm ? warm[i] : 0.0; s->fact[i] = 0.0; }
+  for (int u = 0; u < m->nu && ctrl; u++) {
+    double c = ctrl[u];
+    if (m->act_ctrllimited[u]) c = fmin(fmax(c, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
+    s->fact[m->act_dofid[u]] += m->act_gear[u] * c;
+  }
+  gen_forward(cx, *K, *s);
+  for (int i = 0; i < m->nv; i++) qacc[i] = s->qacc[i];
+  counts[0] = s->ncon; counts[1] = s->nlim; counts[2] = s->iters; counts[3] = s->status;
+  for (int c = 0; c < s->ncon && c < max_con && con; c++) {
+    con[8 * c] = s->citem[c]; con[8 * c + 1] = s->cdist[c];
+    for (int k = 0; k < 3; k++) { con[8 * c + 2 + k] = s->cpos[c][k]; con[8 * c + 5 + k] = s->cnrm[c][k]; }
+  }
+  free(s); free(K);
+  return MZ_OK;
+}
+
+// raw mj_step x nsteps of the general engine on a float64 state (no maze logic, no fp32 rounding), for stage-level comparisons
+// with the oracle's mzo_raw_steps
+extern "C" int emu_generic_raw_steps(const mz_model* m, double* qpos, double* qvel, double* warm, const double* ctrl, int nsteps, int32_t* status,
+                                     char* err, int errlen) {
+  GenDev* K = (GenDev*)calloc(1, sizeof(GenDev));
+  int rc = gen_dev_from_model(K, m, err, errlen);
+  if (rc != MZ_OK) { free(K); return rc; }
+  HostCtx cx;
+  GenScratch* s = (GenScratch*)calloc(1, sizeof(GenScratch));
+  for (int i = 0; i < m->nq; i++) s->qpos[i] = qpos[i];
+  for (int i = 0; i < m->nv; i++) { s->qvel[i] = qvel[i]; s->warm[i] = warm ? warm[i] : 0.0; s->fact[i] = 0.0; }
+  for (int u = 0; u < m->nu && ctrl; u++) {
+    double c = ctrl[u];
+    if (m->act_ctrllimited[u]) c = fmin(fmax(c, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
+    s->fact[m->act_dofid[u]] += m->act_gear[u] * c;
+  }
+  for (int k = 0; k < nsteps; k++) gen_mj_step(cx, *K, *s);
+  for (int i = 0; i < m->nq; i++) qpos[i] = s->qpos[i];
+  for (int i = 0; i < m->nv; i++) { qvel[i] = s->qvel[i]; if (warm) warm[i] = s->warm[i]; }
+  if (status) *status = s->status;
   free(s); free(K);
   return MZ_OK;
 }

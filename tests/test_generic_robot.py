@@ -21,8 +21,9 @@ def test_generic_models_compile():
     cm = _compile(user_robots.BRANCHING_SWIMMER, T.DistRewardUMaze, 4.0, 4, "uniform_sym")
     m = cm.c
     assert (m.nbody, m.nq, m.nv, m.nu) == (5, 6, 6, 3) and m.body_parent[3] == 2 and m.body_parent[4] == 2 and m.collision_predefined == 1
-    with pytest.raises(NotImplementedError):  # movable blocks: built-in robots only
-        _compile(user_robots.BIPED_ANT, T.DistRewardPush, 4.0, 5, "normal")
+    # round 6: a user robot in a maze with a movable block compiles (and steps on the general engine, test below)
+    m = _compile(user_robots.BIPED_ANT, T.DistRewardPush, 4.0, 5, "normal").c
+    assert m.nblock == 1 and m.nbody == 8 and m.nv == 13 and m.obs_dim == 12 + 11 + 1 + 3 and m.geom_type[m.block_geomid[0]] == 6
 
 
 @pytest.mark.parametrize("name,xml,fs,reset,amp", [("biped", user_robots.BIPED_ANT, 5, "normal", 20.0), ("yswimmer", user_robots.BRANCHING_SWIMMER, 4, "uniform_sym", 1.0)],

@@ -178,7 +178,7 @@ def test_native_library_is_the_in_tree_one(torch):
     assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mm.__file__), "csrc", "libmazestep.so"))
     from mujoco_maze_amd.model import MZ_ABI_VERSION
 
-    assert lib.mz_abi_version() == MZ_ABI_VERSION == 7
+    assert lib.mz_abi_version() == MZ_ABI_VERSION == 8
 
 
 @pytest.mark.parametrize("env_id", ["Ant4Rooms-v0", "AntPush-v0", "PointUMaze-v0", "SwimmerUMaze-v0", "PointSquareRoom-v0"])
