@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD's MI355X spec sheet: FP64 vector = half the FP32 vector rate (the guide lists FP32 only)
 N_SIMD = 256 * 4                 # 256 CUs x 4 SIMDs
-PMC_PASS_TIMEOUT_S = 120         # each of the two live rocprofv3 --pmc child passes (about 20 s each on a fresh box)
+PMC_PASS_TIMEOUT_S = 240         # each of the two live rocprofv3 --pmc child passes (about 20 s each on a fresh box)
 SUSTAINED_STEPS = 1000           # the untimed-by-the-metric leg behind the timed window: the settled kernel over a long rollout
 # tools/fetch_calib.hip under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on 1 GiB (past the 256 MiB Infinity Cache), profiles/r05/fetch_calibration.txt
 FETCH_CALIBRATION = "FETCH_SIZE = 0.50 x bytes for 4 / 8 / 16-byte-per-lane and 192-byte-record data streams, 1.0 x per XCD for instruction fetch; WRITE_SIZE = 1.00 x (profiles/r05/fetch_calibration.txt)"
@@ -431,6 +431,7 @@ def main():
                        "envs_per_gpu": n, "obs_allgather": bool(world > 1 and not args.no_gather),
                        "library": os.path.relpath(_capi_path(), ROOT),
                        "lanes_per_env": args.lanes or "library default", "waves_per_block": args.wpb or 1, "bad_envs": bad,
+                       "launch": env.launch_info(),  # the instantiation this batch size / device selected (mz_get_info)
                        **({"rehearsal": "all ranks on one GPU over gloo (MZ_BENCH_SINGLE_GPU=1): not a scaling measurement"}
                           if os.environ.get("MZ_BENCH_SINGLE_GPU") == "1" else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -440,6 +441,8 @@ def main():
                          "traffic_source": traffic_source,
                          "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
                          "traffic_lower": pmc_traffic(live or pmc, corrected=False) if traffic else None,
+                         "traffic_definition": "v2 (since round 5): 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction; the lines of rounds 1-4 carried "
+                                               "v1 = FETCH_SIZE + WRITE_SIZE, which is this line's traffic_lower — compare like with like",
                          "traffic_note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts data reads at half their bytes — calibrated for this "
                                          "kernel's access widths, tools/fetch_calib.hip — but instruction fetch in full: an upper bound); traffic_lower = FETCH_SIZE + WRITE_SIZE",
                          "traffic_fetch_bytes": ((live or pmc).get("FETCH_SIZE", 0.0) * 1024.0) if traffic else None,

@@ -255,7 +255,9 @@ int32_t mz_nu(const mz_handle* h);
 /* Tunables: "auto_reset" (0/1), "seed", "env_index_offset" (global slot of local env 0 in a
  * sharded run: keys the reset RNG), "solver_iterations", "solver_tolerance", "solver_rtol",
  * "ls_iterations" (Ant solver: evaluations of the exact line search), "ls_fast_iterations" / "ls_fast" (the first n Newton
- * iterations of a solve search the line with at most that many evaluations; defaults 5 / 0: unit steps), "lanes_per_env" (8/16/32/64 lanes of a wavefront per environment; defaults: plain Ant 16,
+ * iterations of a solve search the line with at most that many evaluations; defaults 5 / 0: unit steps; "ls_fast_iterations" also
+ * sets the Point's float64 solvers; 0 = MuJoCo's search in every iteration, monotone on any maze at ~7 % of the Ant kernel's time:
+ * what the host mirror sets for custom tasks, whose stiffness nobody has soaked — the registered mazes are), "lanes_per_env" (8/16/32/64 lanes of a wavefront per environment; defaults: plain Ant 16,
  * Ant with one movable block 32 — 16 for batches beyond 2048 envs, where 32 would mean more waves than the device has SIMDs —, with more blocks / a three-slide block / the ball 64; Point 16 while that leaves every wave a SIMD of its own (up to 4096 envs), else 32; with one block or the ball 32, with two or three blocks 64;
  * Swimmer / Reacher 4, fixed), "waves_per_block" (1/2/4, Ant), "waves_per_simd" (plain Ant at 16 lanes: 1 = the one-wave
  * kernel, 2 = the kernel held to 256 registers so that two waves share a SIMD, 0 = default: by the wave count of the
@@ -263,6 +265,14 @@ int32_t mz_nu(const mz_handle* h);
  * mz_read_phase_cycles), "time_kernels" (n > 0: ring of n HIP event pairs around the step kernel, see
  * mz_last_kernel_ms). Returns MZ_OK, MZ_ERR_ARG, or MZ_ERR_UNSUPPORTED for an Ant-only key on another robot. */
 int32_t mz_set_option(mz_handle* h, const char* key, double value);
+
+/* What the next mz_step launches (ABI 8).  The kernel instantiation a handle steps with is chosen from the robot, its maze's
+ * movable bodies, the BATCH SIZE and the device's compute-unit count (lanes per env, one or two waves per SIMD: see
+ * "lanes_per_env" / "waves_per_simd" above), and the instantiations agree to fp32 round-off, not bit for bit: the same seed and
+ * states give round-off-different trajectories at different num_envs, on shards of unequal size or on devices with another
+ * CU count.  Keys: "engine" (0 = the robot family's specialised kernel, 1 = the general engine of mz_model.engine),
+ * "lanes_per_env", "waves_per_simd", "device_simds" (4 x compute units), "ls_fast_iterations".  Returns MZ_OK or MZ_ERR_ARG. */
+int32_t mz_get_info(const mz_handle* h, const char* key, double* value);
 
 /* Auto-reset observation convention.  With option "auto_reset" = 1 an env whose step ended its episode (done != 0) is
  * re-seeded inside the same kernel; mz_step then returns, for that env, the reward / done / goal index of the terminal step
@@ -335,9 +345,11 @@ int32_t mz_debug_detect(mz_handle* h, int32_t n_rows, const double* old_xy_dev, 
                         double* point_dev, double* final_xy_dev, void* stream);
 
 /* Kernel-internal phase timers (option "profile_phases" = 1 selects the instrumented kernel build):
- * 16 accumulators since the last read — slots 0..12 shader cycles per phase (ids: tools/phase_profile.py), 13 the slowest
- * wave's total, 14 the sum of squared per-wave totals (units of 256 cycles), 15 Newton iterations — taken from the first env
- * group of every workgroup; out16_host is HOST memory. */
+ * 16 accumulators over the window since the last mz_read_wave_phase_cycles (which clears the slots this call sums; this call clears
+ * nothing) — slots 0..12 shader cycles per phase (ids: tools/phase_profile.py), 13 the most loaded workgroup's total over the window,
+ * 14 the sum of squared per-workgroup window totals (units of 256 cycles), 15 Newton iterations — taken from the first env group of
+ * every workgroup and reduced on the host from the per-workgroup slots (the kernels issue no same-address atomics: they disturbed
+ * the waves still running); out16_host is HOST memory. */
 int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host);
 /* Same instrumented build: total shader cycles of every workgroup (one wavefront = 64 / lanes_per_env envs) accumulated
  * since the last call, n_host <= num_envs entries into HOST memory; cleared on read.  For load-balance analysis. */

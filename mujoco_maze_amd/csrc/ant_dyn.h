@@ -165,6 +165,10 @@ struct alignas(16) AntScratchT {
   ArrowFactor<D::NH> F;
   float search[D::NV], Ms[D::NV];
   float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3];
+  // bit k: hub column k of the contact's Jacobian is non-zero in some row (con_mask_item).  A movable block's OWN contacts — floor
+  // corners, maze boxes, slide limits: most of the contacts of a block maze — touch that block's two or three columns only; the
+  // solver's gradient / W J / Hessian / J x loops skip the structural zeros by this mask (round 6)
+  uint32_t cmask[D::NC];
   // joint limits (8 hinges)
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   // optional phase timers (device builds with PROF): cycles per phase id, last timestamp
@@ -1329,16 +1333,17 @@ MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
   static_assert(8 * MZ_STAGE * AntDims<NB>::NGEOM <= 3 * AntDims<NB>::NC * AntDims<NB>::NCOL, "staging lives in the cY block");
   int n = 0, emitted = 0;
   float ld = 0.f, ln[3] = {0.f, 0.f, 0.f};
-  int lk = -1, lmult = 0;
+  int lk = -1, lmult = 0, lblk = -1, lother = -1;
   geom_contacts<NB>(K, s, e, [&](const ContactGeo& g) {
     emitted++;
     if constexpr (MERGE) {
-      if (n > 0 && g.kind == lk && g.kind != 6 && g.dist == ld && g.n[0] == ln[0] && g.n[1] == ln[1] && g.n[2] == ln[2] && lmult < 8) {
+      // (same block AND same partner body: two partner blocks touching one face at the same depth have different reaction rows)
+      if (n > 0 && g.kind == lk && g.kind != 6 && g.blk == lblk && g.other == lother && g.dist == ld && g.n[0] == ln[0] && g.n[1] == ln[1] && g.n[2] == ln[2] && lmult < 8) {
         lmult++;
         if (n <= MZ_STAGE) con_stage<NB>(s, MZ_STAGE * e + n - 1)[7] = (float)(g.kind + 16 * g.blk + 128 * g.other + 2048 * (lmult - 1));
         return;
       }
-      lk = g.kind; ld = g.dist; lmult = 1;
+      lk = g.kind; ld = g.dist; lmult = 1; lblk = g.blk; lother = g.other;
       for (int k = 0; k < 3; k++) ln[k] = g.n[k];
     }
     if (n < MZ_STAGE) {
@@ -1564,12 +1569,25 @@ MZ_HD float contact_eval(float D, const float* u, float* g, float* W) {
   if (W) { W[0] = D * (a0 + a1 + a2 + a3); W[1] = D * (a0 - a1); W[2] = D * (a2 - a3); W[3] = D * (a0 + a1); W[4] = D * (a2 + a3); }
   return 0.5f * D * (a0 * r0 * r0 + a1 * r1 * r1 + a2 * r2 * r2 + a3 * r3 * r3);
 }
+// hub columns of contact c's Jacobian that hold a non-zero in some row (AntScratchT::cmask)
+template <int NB>
+MZ_HD void con_mask_item(AntScratchT<NB>& s, int c) {
+  constexpr int NH = AntDims<NB>::NH;
+  uint32_t m = 0u;
+  for (int k = 0; k < NH; k++)
+    if (s.cJ[c][0][k] != 0.f || s.cJ[c][1][k] != 0.f || s.cJ[c][2][k] != 0.f) m |= 1u << k;
+  s.cmask[c] = m;
+}
 template <int NB>
 MZ_HD float contact_Jdot(const AntScratchT<NB>& s, int c, int a, const float* x) {
   constexpr int NH = AntDims<NB>::NH;
   const float* J = s.cJ[c][a];
   float v = 0.f;
-  for (int k = 0; k < NH; k++) v += J[k] * x[hub2dof(k)];
+  if constexpr (NH > 6) {  // mazes with movable bodies: only the hub columns the contact touches (cmask)
+    for (uint32_t m = s.cmask[c]; m; m &= m - 1) { const int k = __builtin_ctz(m); v += J[k] * x[hub2dof(k)]; }
+  } else {
+    for (int k = 0; k < NH; k++) v += J[k] * x[hub2dof(k)];
+  }
   int leg = s.cleg[c];
   if (leg >= 0) v += J[NH] * x[6 + 2 * leg] + J[NH + 1] * x[7 + 2 * leg];
   return v;
@@ -1649,7 +1667,9 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
       float g = s.Mx[i], ga = fabsf(g);
       int c0 = 0, c1 = s.ncon, col = i < 6 ? i : i - 8;
       if (i >= 6 && i < 14) { int l = (i - 6) >> 1; c0 = s.cbeg[l]; c1 = s.cbeg[l + 1]; col = NH + ((i - 6) & 1); }
+      const bool hubcol = NH > 6 && !(i >= 6 && i < 14);
       for (int c = c0; c < c1; c++) {
+        if (hubcol && !((s.cmask[c] >> col) & 1u)) continue;  // a structural zero of the contact's Jacobian
         float g3[3];
         contact_eval(s.cD[c], s.cu[c], g3, nullptr);
         float t = s.cJ[c][0][col] * g3[0] + s.cJ[c][1][col] * g3[1] + s.cJ[c][2][col] * g3[2];
@@ -1662,6 +1682,7 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     }
     MZ_FOR_AT(e, NCOL * s.ncon, NV) {
       int c = e / NCOL, k = e - NCOL * c;
+      if (NH > 6 && k < NH && !((s.cmask[c] >> k) & 1u)) continue;  // never read: the Hessian loops skip the same entries
       float W[5];
       contact_eval(s.cD[c], s.cu[c], nullptr, W);
       float n_ = s.cJ[c][0][k], p_ = s.cJ[c][1][k], q_ = s.cJ[c][2][k];
@@ -1691,8 +1712,18 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
         dst = &s.H.ll[l][t]; acc = s.M.ll[l][t];
         if (t != 1) acc += s.lact[2 * l + (t == 2 ? 1 : 0)];
       }
-      for (int c = c0; c < c1; c++)
-        acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
+      if constexpr (NH > 6) {
+        // hub columns of this entry (leg columns NH, NH + 1 are dense within their leg's contact range): a contact contributes only
+        // where both are set — a block's own contacts to that block's 2 x 2 / 3 x 3 corner and to nothing else
+        const uint32_t need = (ci < NH ? 1u << ci : 0u) | (cj < NH ? 1u << cj : 0u);
+        for (int c = c0; c < c1; c++) {
+          if ((s.cmask[c] & need) != need) continue;
+          acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
+        }
+      } else {
+        for (int c = c0; c < c1; c++)
+          acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
+      }
       *dst = acc;
     }
     cx.sync();
@@ -1862,6 +1893,7 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
     cx.sync();
     cx.tick(s, 11);
     MZ_FOR(e, NH * (NH + 1) / 2 + NH) factor_schur_item<NH>(s.M, s.F, s.qfs, e);
+    if constexpr (NH > 6) { MZ_FOR_AT(c, s.ncon, (NH * (NH + 1) / 2 + NH) % C::nlanes) con_mask_item<NB>(s, c); }  // (rows complete since the fence above)
     cx.sync();
     MZ_FOR(one, 1) factor_serial_item<NH>(s.F);
     cx.sync();

@@ -628,10 +628,22 @@ __device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, cons
       integrate(aw * qvel);
       qvel = x0v + h * aw * qacc;
       if (isdof) s.qvel[i] = qvel;
+#ifdef MZ_EXP_RK4TICK  // (tools/tail_phases.py: what the "rk4" timer slot of the slowest waves is made of)
+      cx.tick(s, 13);
+#endif
       cx.sync();
+#ifdef MZ_EXP_RK4TICK
+      cx.tick(s, 14);
+#endif
     }
   }
   integrate(accv);
   if (isdof) s.qvel[i] = x0v + h * accf;
+#ifdef MZ_EXP_RK4TICK
+  cx.tick(s, 13);
+#endif
   cx.sync();
+#ifdef MZ_EXP_RK4TICK
+  cx.tick(s, 14);
+#endif
 }

@@ -862,6 +862,16 @@ __device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, 
         for (int a = 0; a < 3; a++) bu[m][a] -= bar[m][a];
     }
   }
+  // Unit steps and robustness (round 6).  The first ls_fast_iters iterations of a solve take the unit step across an
+  // active-set change without a line search; such a step may raise the cost, and unit steps alone can cycle.  Two guards were built
+  // and measured (A / B libraries, profiles/r06/unit_guard_ab.txt, AntUMaze-v0 4096 envs): an overshoot test on the next gradient
+  // (phi'(1) > 0 ends the solve's unit steps: 0.2366 -> 0.2577 ms, it fires often) and ADVICE's rule — take the unit step only if
+  // cost(qacc + search) <= cost(qacc), else search the line in that iteration (0.2570 ms: ~100 vector instructions per iteration
+  // with one wave per SIMD; as a run-time switch it still cost 1.2 % when off).  Either way a guarded unit step costs what the
+  // exact search it replaces costs (ls_fast_iters = 0: 0.2555 ms), so there is no guard: the registered mazes — soaked for 1e8
+  // env-steps without one solve at the iteration cap, error quantiles against the float64 oracle identical to the search in every
+  // iteration — take unit steps, and a CUSTOM task, maze or robot variant, whose stiffness nobody has soaked, runs with
+  // ls_fast_iterations = 0 by default (maze_env.py): MuJoCo's line search in every iteration, monotone on any maze.
   while (cx.any(!done) && it < ant_u(cx, K).max_iter) {
     // ---- contact lanes: gradient block g3 and curvature block W of their contact, in registers; every lane of the row reads
     // them with `row_newbcast:c` (fold_contact<c>): no LDS publish, no hand-off wait

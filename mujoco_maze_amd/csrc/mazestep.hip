@@ -73,6 +73,11 @@ mz_handle* mz_create(const mz_model* model, int32_t num_envs, int32_t device, ch
   if (!h) return fail("mz_create: out of memory");
   memset(h, 0, sizeof(*h));
   h->model = *model; h->n = num_envs; h->device = device; h->robot = model->robot; h->lanes = 32; h->waves_per_block = 1; h->seed = 0x5EEDULL;
+  {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cu <= 0) cu = 256;
+    h->simds = 4 * cu;
+  }
   // the general engine (generic_dyn.h) steps what no specialised kernel does — user robots, SPIN plates, more than three blocks —
   // and whatever the caller asks it to (mz_model.engine = 1); h->robot is the dispatch key, h->model.robot stays the family
   if (mzk_generic_needed(model)) h->robot = MZ_ROBOT_GENERIC;
@@ -172,6 +177,13 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   if (!strcmp(key, "auto_reset")) { h->auto_reset = value != 0; return MZ_OK; }
   if (!strcmp(key, "seed")) { h->seed = (uint64_t)value; return MZ_OK; }
   if (!strcmp(key, "env_index_offset")) { h->env0 = (uint64_t)value; return MZ_OK; }
+  if (h->robot == MZ_ROBOT_POINT && !strcmp(key, "ls_fast_iterations")) {  // the Point's float64 solvers: unit steps before the exact search (0 = search in every iteration)
+    if (value < 0 || value > 50) return set_err(h, MZ_ERR_ARG, "ls_fast_iterations must be 0 .. 50", hipSuccess);
+    h->point.unit_steps = (int)value;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(h->point_dev, &h->point, sizeof(PointDev), hipMemcpyHostToDevice));
+    return MZ_OK;
+  }
   if (h->robot != MZ_ROBOT_ANT && (!strcmp(key, "solver_iterations") || !strcmp(key, "solver_tolerance") || !strcmp(key, "solver_rtol") ||
                                    !strcmp(key, "ls_iterations") || !strcmp(key, "ls_fast_iterations") || !strcmp(key, "ls_fast") || !strcmp(key, "debug_frame_skip") || !strcmp(key, "waves_per_block") || !strcmp(key, "waves_per_simd")))
     return set_err(h, MZ_ERR_UNSUPPORTED, "mz_set_option: this key tunes the Ant kernels only (the other robots' solvers have fixed settings)", hipSuccess);
@@ -223,6 +235,26 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
     return MZ_OK;
   }
   return set_err(h, MZ_ERR_ARG, "unknown option", hipSuccess);
+}
+
+// What the next mz_step will launch — the kernel instantiation depends on the robot, the batch size and the device's compute-unit
+// count (include/mazestep.h), so a caller that compares runs across batch sizes or devices can record it.
+int32_t mz_get_info(const mz_handle* h, const char* key, double* value) {
+  if (!h || !key || !value) return MZ_ERR_ARG;
+  if (!strcmp(key, "engine")) { *value = h->robot == MZ_ROBOT_GENERIC ? 1.0 : 0.0; return MZ_OK; }
+  if (!strcmp(key, "device_simds")) { *value = (double)h->simds; return MZ_OK; }
+  if (!strcmp(key, "ls_fast_iterations")) {  // Newton iterations of a solve that take unit steps (-1: this handle's kernels have no such phase)
+    *value = h->robot == MZ_ROBOT_ANT ? (double)h->ant.ls_fast_iters : (h->robot == MZ_ROBOT_POINT ? (double)h->point.unit_steps : -1.0);
+    return MZ_OK;
+  }
+  if (!strcmp(key, "lanes_per_env") || !strcmp(key, "waves_per_simd")) {
+    int lanes = 64, wps = 1;
+    if (h->robot == MZ_ROBOT_ANT) mzk_ant_shape(h, &lanes, &wps);
+    else if (h->robot != MZ_ROBOT_GENERIC) lanes = mzk_planar_lanes(h);
+    *value = (double)(key[0] == 'l' ? lanes : wps);
+    return MZ_OK;
+  }
+  return MZ_ERR_ARG;
 }
 
 int32_t mz_bind_final_obs(mz_handle* h, float* final_obs_dev) {
@@ -365,8 +397,25 @@ int32_t mz_read_phase_cycles(mz_handle* h, uint64_t* out16_host) {
   if (!h || !out16_host || !h->prof) return MZ_ERR_ARG;
   DeviceScope scope(h->device);
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemcpy(out16_host, h->prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemset(h->prof, 0, 16 * sizeof(unsigned long long)));
+  // the step kernels write per-workgroup slots only (no same-address atomics: they disturbed what they measured, ant_kernels.hip);
+  // the 16 launch-wide accumulators are reduced here from the per-workgroup phase slots — accumulated since the last
+  // mz_read_wave_phase_cycles, which hands those slots out and clears them; this call clears nothing
+  const size_t nw = (size_t)h->n;
+  unsigned long long* buf = (unsigned long long*)malloc(17 * nw * sizeof(unsigned long long));
+  if (!buf) return set_err(h, MZ_ERR_HIP, "mz_read_phase_cycles: out of memory", hipSuccess);
+  hipError_t e = hipMemcpy(buf, h->prof + 16, 17 * nw * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { free(buf); return set_err(h, MZ_ERR_HIP, "mz_read_phase_cycles", e); }
+  for (int k = 0; k < 16; k++) out16_host[k] = 0;
+  for (size_t w = 0; w < nw; w++) {
+    const unsigned long long* ph = buf + nw + 16 * w;
+    unsigned long long tot = 0;
+    for (int k = 0; k < 13; k++) tot += ph[k];
+    if (!tot) continue;  // (slots of workgroups that do not exist at this lane width stay empty)
+    for (int k = 0; k < 16; k++) if (k != 13 && k != 14) out16_host[k] += ph[k];
+    if (tot > out16_host[13]) out16_host[13] = tot;   // slowest workgroup of the window (per-workgroup sums over the window's steps)
+    out16_host[14] += (tot >> 8) * (tot >> 8);         // sum of squares of the per-workgroup totals (units of 256 cycles)
+  }
+  free(buf);
   return MZ_OK;
 }
 

@@ -45,6 +45,7 @@ struct mz_handle {
   uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
   char err[256];
   int lanes_set;  // lanes_per_env chosen by the caller (else the per-robot default)
+  int simds;      // 4 x the device's compute units, read once in mz_create: the batch-size rules of the launch shapes compare wave counts with it
   // kernel timing ring (option "time_kernels")
   int ntime, itime;
   hipEvent_t* ev;  // 2 * ntime
@@ -58,6 +59,10 @@ hipError_t mzk_ant_reset(mz_handle* h, hipStream_t st, const uint8_t* mask, uint
 hipError_t mzk_ant_set_state(mz_handle* h, hipStream_t st, const float* qpos, const float* qvel, const float* warm, const int* t);
 hipError_t mzk_ant_get_state(mz_handle* h, hipStream_t st, float* qpos, float* qvel, float* warm, int* t);
 hipError_t mzk_ant_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx);
+
+// launch shape the next mz_step takes (mz_get_info): lanes per env, and for the plain ant at 16 lanes which instantiation (1 / 2 waves per SIMD)
+void mzk_ant_shape(const mz_handle* h, int* lanes, int* waves_per_simd);
+int mzk_planar_lanes(const mz_handle* h);
 
 // ---- planar_kernels.hip (Point, Swimmer, Reacher)
 hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions, float* obs, float* reward, uint8_t* done, int* goal_idx, float* info);

@@ -821,8 +821,9 @@ MZP_HD void planar_forward(const C& cx, const PointDev& P, PlanarScratch<NB, NS>
     changed = cx.gany(changed);
     double lo = 0.0, hi = -1.0, alpha = 1.0, prev_d2 = -1.0;
     double p1 = 0.0, p2 = 0.0;
-    if (changed && it >= MZ_PL_UNIT_STEPS) { p1 = cx.gsum(p1p); p2 = cx.gsum(p2p); }
-    for (int ls = 0; ls < 30 && changed && it >= MZ_PL_UNIT_STEPS; ls++) {  // (unit steps first: point_bare.h / ant_newton_rows.h)
+    const bool fast_now = it < P.unit_steps;  // (option "ls_fast_iterations"; default MZ_PL_UNIT_STEPS; custom tasks: 0, maze_env.py)
+    if (changed && !fast_now) { p1 = cx.gsum(p1p); p2 = cx.gsum(p2p); }
+    for (int ls = 0; ls < 30 && changed && !fast_now; ls++) {  // (unit steps first: point_bare.h / ant_newton_rows.h)
       double d1 = 0.0, d2 = 0.0;
       MZ_FOR(c, ncon) {
         double Dc = s.cD[c], v0 = s.cjv[c][0], v1 = s.cjv[c][1], v2 = s.cjv[c][2];

@@ -379,6 +379,16 @@ int mzk_planar_state_width(const mz_handle* h) {
   return h->robot == MZ_ROBOT_SWIMMER ? h->swimmer.nlink + 2 + (h->swimmer.nblock ? h->swimmer.nbdof : 0) : 3 + 2 * h->point.nblock + 3 * h->point.nball;
 }
 
+// lanes per env of the next step launch (one rule for the launch and for mz_get_info)
+int mzk_planar_lanes(const mz_handle* h) {
+  if (h->robot == MZ_ROBOT_SWIMMER) return h->swimmer.nlink <= 4 ? 4 : 8;
+  if (h->point.nball || h->point.nblock == 1) return 32;
+  if (h->point.nblock >= 2) return 64;
+  // the bare Point: 16 lanes per env while that still gives every wave a SIMD of its own (up to 4096 envs on a 256-CU device), else 32
+  const int lanes = h->lanes_set ? h->lanes : ((h->n + 3) / 4 <= h->simds ? 16 : 32);
+  return (lanes == 8 || lanes == 16) ? lanes : 32;
+}
+
 hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                            int* goal_idx_dev, float* info_dev) {
   PointState S{h->state, h->pt_t, h->pt_ep, h->pt_rec};
@@ -412,17 +422,7 @@ hipError_t mzk_planar_step(mz_handle* h, hipStream_t st, const float* actions_de
       // the step in registers (point_bare.h) and the unit-step solver the waves are short and even enough that four envs per wave on
       // a SIMD of their own win: PointUMaze 4096 envs 74.3 -> 79.6 M env-steps/s, Point4Rooms 79.6 -> 82.6 M; beyond (8192 envs:
       // 108.0 at 32 lanes against 106.3) it stays at 32 (profiles/r05/point_knobs.txt).
-      int lanes = h->lanes_set ? h->lanes : 0;
-      if (!lanes) {
-        static int simds[32] = {};
-        const int dv = h->device & 31;
-        if (!simds[dv]) {
-          int cu = 0;
-          if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cu <= 0) cu = 256;
-          simds[dv] = 4 * cu;
-        }
-        lanes = (h->n + 3) / 4 <= simds[dv] ? 16 : 32;
-      }
+      const int lanes = mzk_planar_lanes(h);
       if (lanes == 8) MZ_PLANAR_LAUNCH(0, 0, 8);
       else if (lanes == 16) MZ_PLANAR_LAUNCH(0, 0, 16);
       else MZ_PLANAR_LAUNCH(0, 0, 32);

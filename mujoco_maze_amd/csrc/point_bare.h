@@ -403,7 +403,8 @@ MZP_HD void point_forward_bare(const C& cx, const PointDev& P, PlanarScratch<0, 
     // (round 5, as in the Ant's solvers — ant_newton_rows.h: the first MZ_PL_UNIT_STEPS iterations of a solve take the unit step when
     // the active set changes, the exact search comes behind them: it buys global convergence, not accuracy, and Newton with an exact
     // search converges from wherever the unit steps leave it)
-    for (int ls = 0; ls < 30 && changed && it >= MZ_PL_UNIT_STEPS; ls++) {
+    const bool fast_now = it < P.unit_steps;  // (option "ls_fast_iterations"; default MZ_PL_UNIT_STEPS; custom tasks: 0, maze_env.py)
+    for (int ls = 0; ls < 30 && changed && !fast_now; ls++) {
       double e1 = 0.0, e2 = 0.0;
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {

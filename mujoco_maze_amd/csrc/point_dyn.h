@@ -54,6 +54,7 @@ struct PointDev {
   TaskDev task;
   double qpos0[3];
   int reset_kind;
+  int unit_steps;  // Newton iterations of a solve that take the unit step before the exact line search takes over (option "ls_fast_iterations"; planar_dyn.h MZ_PL_UNIT_STEPS)
 };
 
 static inline void pt_mix_pair(PtPair* p, double h, double m1, double m2, const double* f1, const double* f2, const double* sr1,
@@ -166,6 +167,7 @@ static inline int point_dev_from_model(PointDev* p, const mz_model* m, char* err
   task_dev_from_model(&p->task, m);
   for (int k = 0; k < 3; k++) p->qpos0[k] = m->qpos0[k];
   p->reset_kind = m->reset_qvel_kind;
+  p->unit_steps = 5;  // planar_dyn.h MZ_PL_UNIT_STEPS: the measured optimum (profiles/r05/point_unit_steps_ab.txt); option "ls_fast_iterations"
   return MZ_OK;
 }
 

@@ -103,6 +103,17 @@ class WrappedRobot:
         return float(ori[0].item()) if self._single else ori
 
 
+def _is_registered(model_cls, task_cls, scale) -> bool:
+    """Is (robot class, task class, maze scale) one of the 145 registered combinations (mujoco_maze/__init__.py:22-78)?"""
+    import mujoco_maze_amd as mm
+
+    for spec in mm.REGISTRY.values():
+        kw = spec.kwargs
+        if kw["model_cls"] is model_cls and kw["maze_task"] is task_cls and float(kw["maze_size_scaling"]) == float(scale):
+            return True
+    return False
+
+
 class VecMazeEnv:
     def __init__(self, model_cls: Type[AgentModel], maze_task: Type[MazeTask] = MazeTask, num_envs: int = 1,
                  maze_height: float = 0.5, maze_size_scaling: float = 4.0, inner_reward_scaling: float = 1.0,
@@ -129,6 +140,7 @@ class VecMazeEnv:
         # engine="general": step this env on the general engine (csrc/generic_dyn.h) whatever the robot — the second, independent
         # device implementation the specialised kernels are cross-checked with; "auto" (default): only where they cannot step it
         gen_kw["engine"] = kwargs.pop("engine", "auto")
+        has_xml = kwargs.get("robot_xml") is not None
         self.model: CompiledModel = compile_model(
             robot, self._task, maze_size_scaling, inner_reward_scaling=inner_reward_scaling,
             restitution_coef=restitution_coef, maze_height=maze_height, max_episode_steps=max_episode_steps,
@@ -155,6 +167,17 @@ class VecMazeEnv:
             raise _capi.MazeStepError(f"mz_create failed: {err.value.decode()}")
         m = self.model.c
         self.nq, self.nv, self.nu, self.obs_dim = m.nq, m.nv, m.nu, m.obs_dim
+        # The Ant's and the Point's Newton solvers take unit steps in the first iterations of a solve (ant_newton_rows.h).  The registered
+        # mazes are soaked with them (1e8 env-steps, no solve at the iteration cap); a CUSTOM task, maze or robot variant is not, so
+        # there every iteration searches the line exactly (ls_fast_iterations = 0: MuJoCo's monotone iteration on any maze, ~7 % of the
+        # Ant kernel's time; a guarded unit step was measured and costs the same: profiles/r06/unit_guard_ab.txt).
+        # set_option("ls_fast_iterations", 5) brings the unit steps back.  The general engine and the chain kernels search the line in
+        # every iteration / solve in closed form.
+        from mujoco_maze_amd.model import needs_general_engine
+
+        self.custom_task = not _is_registered(model_cls, maze_task, maze_size_scaling) or has_xml
+        if self.custom_task and robot in ("ant", "point") and not needs_general_engine(self.model):
+            _capi.check(self._lib, self._h, self._lib.mz_set_option(self._h, b"ls_fast_iterations", 0.0), "mz_set_option(ls_fast_iterations)")
         n, dev = self.num_envs, self.device
         self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=dev)
         self._reward = torch.empty(n, dtype=torch.float32, device=dev)
@@ -185,6 +208,17 @@ class VecMazeEnv:
         if key == "auto_reset":
             return self.set_auto_reset(value != 0)
         _capi.check(self._lib, self._h, self._lib.mz_set_option(self._h, key.encode(), float(value)), f"mz_set_option({key})")
+
+    def launch_info(self) -> dict:
+        """What the next step launches (mz_get_info): the engine (0 = the robot family's specialised kernel, 1 = the general engine),
+        lanes per env, waves per SIMD, the device's SIMD count.  The instantiation depends on the batch size and the device; its
+        results agree across instantiations to fp32 round-off, not bit for bit (include/mazestep.h)."""
+        out = {}
+        for key in ("engine", "lanes_per_env", "waves_per_simd", "device_simds", "ls_fast_iterations"):
+            v = C.c_double(0.0)
+            _capi.check(self._lib, self._h, self._lib.mz_get_info(self._h, key.encode(), C.byref(v)), f"mz_get_info({key})")
+            out[key] = int(v.value)
+        return out
 
     def set_auto_reset(self, on: bool) -> None:
         """Auto-reset follows the vector-env convention: an env whose step ended its episode returns the reward / done of
@@ -257,17 +291,21 @@ class VecMazeEnv:
     def _sync_goals_across_ranks(self) -> None:
         """Sharded runs (sharding.py): every rank called sample_goals() on its own unsynchronised RNG — rank 0's goals win, so that
         the batch really has ONE goal table (positions only: thresholds / reward scales are class constants of the task)."""
-        try:
-            import torch.distributed as dist
-        except Exception:
+        # Only where the caller SAID the env is one shard of a node-wide batch (sharding.ShardedVecMazeEnv sets goal_sync_group):
+        # a collective hidden behind dist.is_initialized() would deadlock a trainer whose ranks reset at different times (ADVICE r05)
+        group = getattr(self, "goal_sync_group", None)
+        if group is None:
             return
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        import torch.distributed as dist
+
+        grp = None if group == "world" else group
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(grp) > 1):
             return
         torch = self._torch
-        buf = torch.zeros((8, 3), dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        buf = torch.zeros((8, 3), dtype=torch.float64, device=self.device if dist.get_backend(grp) == "nccl" else "cpu")
         for i, g in enumerate(self._task.goals[:8]):
             buf[i, : g.dim] = torch.as_tensor(np.asarray(g.pos, np.float64)[: g.dim])
-        dist.broadcast(buf, src=0)
+        dist.broadcast(buf, src=dist.get_global_rank(grp, 0) if grp is not None else 0, group=grp)
         host = buf.cpu().numpy()
         for i, g in enumerate(self._task.goals[:8]):
             g.pos = host[i, : g.dim].copy()

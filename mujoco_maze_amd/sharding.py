@@ -115,6 +115,9 @@ class ShardedVecMazeEnv:
         self.env = mm.make(env_id, num_envs=envs_per_rank, device=device, force_vec=True, **kwargs)
         self.lo, self.hi = shard_range(self.rank, self.world, envs_per_rank)
         self.env.set_option("env_index_offset", float(self.lo))
+        # a task that resamples its goals on reset (MazeTask.sample_goals): rank 0's goals are broadcast over THIS group, and the
+        # ranks must therefore call reset() together (maze_env.py _sync_goals_across_ranks)
+        self.env.goal_sync_group = group if group is not None else "world"
         self.gatherer: Optional[RecordGatherer] = RecordGatherer(envs_per_rank, self.env.obs_dim, self.env.device, group, always_collective) if gather else None
         # the step kernel writes the packed record straight into the gatherer's send buffer — unless the task is judged by
         # Python overrides on the host, whose reward / done only exist after the kernel

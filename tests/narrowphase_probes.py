@@ -76,7 +76,24 @@ def probes():
     out.append(("small box on a big one (a block on its platform): four bottom corners, normal from geom1 up", "box_box",
                 ([0, 0, 0], I3, [2.0, 2.0, 1.0]), ([0.5, -0.25, 1.495], I3, CUBE), 0.01,
                 [[-0.005, x, y, 0.9975, 0, 0, 1] for x in (0.0, 1.0) for y in (-0.75, 0.25)]))
+    # ---- boxes of GENERAL orientation (round 6: SPIN plates, user robots' box geoms)
+    Rz = rotz(np.radians(30.0))
+    out.append(("sphere beside a face of a box turned 30 degrees about z: the face's normal, turned with the box", "sphere_box",
+                (Rz @ np.array([1.3, 0.2, 0.4]), I3, [0.25, 0, 0]), ([0, 0, 0], Rz, [1.0, 1.0, 1.0]), 0.1,
+                [[0.05, *(Rz @ np.array([1.025, 0.2, 0.4])), *(Rz @ np.array([-1.0, 0.0, 0.0]))]]))
+    # edge-edge: cube A turned 45 degrees about y (its top edge runs along y, 0.5 sqrt2 above its centre), cube B turned 45 degrees
+    # about x (its lowest edge runs along x, 0.5 sqrt2 below its centre) 0.01 lower than touching: the edges cross at right angles
+    # above the origin; every face axis penetrates by 0.36, the axis edge x edge = z by 0.01 — one contact midway between the edges
+    h = 0.5 * np.sqrt(2.0)
+    out.append(("two cubes crossing edge on edge (mjc_BoxBox's edge-edge case): one contact midway, normal along edge x edge", "box_box",
+                ([0, 0, 0], roty(np.pi / 4), CUBE), ([0, 0, 2 * h - 0.01], rotx(np.pi / 4), CUBE), 0.0,
+                [[-0.01, 0, 0, h - 0.005, 0, 0, 1]]))
     return out
+
+
+def rotx(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
 
 
 def _z_to(v):

@@ -521,3 +521,24 @@ def test_swimmer_step_logic(oracle, robot, nq):
             assert np.array_equal(re_["done"], ro["done"]) and np.all(re_["status"] == 0)
         oracle.step(cm, st, act.astype(np.float64), nthreads=8)
     assert hit_limit > 50 * nu
+
+
+def test_experiment_switches_cannot_reach_the_product_library(tmp_path):
+    """the kernel sources carry MZ_EXP_* timing-experiment switches, several of them wrong physics by design.
+    A translation unit that sees one without -DMZ_EXPERIMENTS does not compile (csrc/ant_model.h, which every unit includes), and
+    the Makefile's product target refuses flags that carry either."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "mujoco_maze_amd", "csrc")
+    src = tmp_path / "probe.cpp"
+    src.write_text('#include <cstring>\n#include <cmath>\n#include <cstdint>\n#include "ant_model.h"\nint main() { return 0; }\n')
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-I", csrc, str(src)]
+    assert subprocess.run(base, capture_output=True).returncode == 0
+    for sw in ("MZ_EXP_NOWALL", "MZ_EXP_NONEWTON", "MZ_EXP_STAMPS"):
+        bad = subprocess.run(base + [f"-D{sw}"], capture_output=True, text=True)
+        assert bad.returncode != 0 and "MZ_EXPERIMENTS" in bad.stderr, sw
+        assert subprocess.run(base + [f"-D{sw}", "-DMZ_EXPERIMENTS"], capture_output=True).returncode == 0, sw
+    for var in ("EXTRA=-DMZ_EXP_NOWALL", "CXXFLAGS=-DMZ_EXPERIMENTS", "FAST=-freciprocal-math -DMZ_EXP_NOSEARCH"):
+        out = subprocess.run(["make", "-C", csrc, "-n", "libmazestep.so", var], capture_output=True, text=True)
+        assert out.returncode != 0 and "experiment switches" in out.stderr, var
+    assert subprocess.run(["make", "-C", csrc, "-n", "libmazestep.so"], capture_output=True).returncode == 0

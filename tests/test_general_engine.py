@@ -244,3 +244,52 @@ def test_user_robot_with_a_box_geom_in_a_block_maze(oracle):
     st["qpos"][:, 1] = bx[1] + rng.uniform(-1.0, 1.0, n)
     acts = [rng.uniform(-20, 20, (n, m.nu)) for _ in range(9)]
     assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 3, 8)) > 20
+
+
+def test_plane_box_with_tilted_corners(oracle):
+    """mjc_PlaneBox for a box of general orientation, through the model path: the SPIN plate of SpinUMaze/ant (half sizes 0.4, 0.4,
+    0.2, centre 0.2 above the floor) tilted by 0.1 rad about y.  By hand: a corner (sx 0.4, sy 0.4, sz 0.2) sits at height
+    0.2 - sx 0.4 sin(0.1) + sz 0.2 cos(0.1); the two bottom corners on the +x side are 0.0389 deep, the two on the -x side 0.0409
+    above the floor (beyond the 0.01 margin), top corners never count."""
+    cm = model.compile_model("ant", SpinUMaze(8.0), 8.0)
+    m = cm.c
+    q = np.array(m.qpos0[: m.nq])
+    q[2] = 30.0  # the ant far above
+    qb = m.jnt_qposadr[m.body_jntadr[m.block_bodyid[0]] + 2]
+    th = 0.1
+    q[qb:qb + 4] = [np.cos(th / 2), 0.0, np.sin(th / 2), 0.0]
+    c = oracle.contacts(cm, q)
+    g = m.block_geomid[0]
+    floor = c[(c[:, 7] == 0) & (c[:, 8] == g)]
+    depth = 0.2 - 0.4 * np.sin(th) - 0.2 * np.cos(th)
+    assert len(floor) == 2 and np.allclose(floor[:, 0], depth, atol=1e-12) and depth < -0.038
+    cx = 2.0 + 0.4 * np.cos(th) - 0.2 * np.sin(th)  # the plate's centre is at x = 2 (a quarter cell from the robot, maze_env.py:577)
+    want = sorted((cx, y, 0.5 * depth) for y in (-0.4, 0.4))  # a contact sits midway between the corner and the plane
+    assert np.allclose(sorted(map(tuple, floor[:, 1:4])), want, atol=1e-12) and np.allclose(floor[:, 4:7], [0, 0, 1])
+
+
+def test_general_engine_narrow_phase_equals_the_oracles_on_random_poses(oracle):
+    """csrc/generic_dyn.h gen_sphere_vs_box / gen_capsule_vs_box / gen_box_vs_box (host build, tests/emu) against the oracle's
+    routines on 6000 random poses of boxes of general orientation — same contact count, same order, 1e-12."""
+    import ctypes as C
+    from tests import emu_lib
+
+    lib = emu_lib.load()
+    lib.emu_probe_pair.restype = C.c_int
+    lib.emu_probe_pair.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_double, C.c_int, C.c_void_p]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rng = np.random.default_rng(0)
+    kinds = ["capsule_box", "box_box", "sphere_box"]
+    seen = [0, 0, 0]
+    for it in range(6000):
+        kind = it % 3
+        q1, q2 = rng.normal(size=4), rng.normal(size=4)
+        m1 = np.ascontiguousarray(model.quat_to_mat(q1 / np.linalg.norm(q1)))
+        m2 = np.eye(3) if it % 5 == 0 else np.ascontiguousarray(model.quat_to_mat(q2 / np.linalg.norm(q2)))
+        p1, p2, s1, s2 = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3), rng.uniform(0.1, 0.6, 3), rng.uniform(0.1, 0.8, 3)
+        want = np.asarray(oracle.probe_pair(kinds[kind], p1, m1, s1, p2, m2, s2, 0.01)).reshape(-1, 7)
+        out = np.zeros((16, 7))
+        n = lib.emu_probe_pair(kind, vp(p1), vp(m1), vp(s1), vp(p2), vp(m2), vp(s2), 0.01, 16, vp(out))
+        assert n == len(want) and (n == 0 or np.abs(out[:n] - want).max() < 1e-12), (it, kinds[kind], n, len(want))
+        seen[kind] += n
+    assert min(seen) > 300

@@ -65,3 +65,76 @@ def test_record_allgather_over_rccl_single_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT, port=port)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "RCCL_PATH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+TWO_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from mujoco_maze_amd import sharding
+import mujoco_maze_amd as mm
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+single = os.environ.get("MZ_TEST_SINGLE_GPU") == "1"          # rehearsal on a one-GPU box: both ranks on cuda:0, gloo (RCCL wants a device per rank)
+torch.cuda.set_device(0 if single else rank)
+dev = torch.device("cuda", 0 if single else rank)
+if single:
+    dist.init_process_group(backend="gloo")
+else:
+    dist.init_process_group(backend="nccl", device_id=dev)
+n_local = 512
+env = sharding.ShardedVecMazeEnv("Ant4Rooms-v0", n_local, device=dev, gather=True, auto_reset=True)   # envs PER RANK
+assert (env.lo, env.hi) == (rank * n_local, (rank + 1) * n_local) and env._device_record
+env.reset(seed=3)
+whole = mm.make("Ant4Rooms-v0", num_envs=n_local * world, auto_reset=True, device=dev, force_vec=True) if rank == 0 else None
+if whole is not None:
+    whole.reset(seed=3)
+g = torch.Generator(device="cpu").manual_seed(0)
+for k in range(30):
+    act = (torch.rand((n_local * world, 8), generator=g) * 60 - 30)   # one table, indexed by GLOBAL slot (same generator on every rank)
+    obs, rew, done, info = env.step(act[env.lo:env.hi].to(dev))
+    got = env.gathered()                                       # [n_local * world, obs_dim + 2] on every rank, over RCCL / xGMI
+    mine = torch.cat([obs, rew[:, None], done.float()[:, None]], dim=1)
+    assert torch.equal(got[env.lo:env.hi], mine), k
+    if whole is not None:                                      # sharded == unsharded (same kernel instantiation: 512 and 1024 envs)
+        o, r, d, _ = whole.step(act.to(dev))
+        assert torch.equal(got, torch.cat([o, r[:, None], d.float()[:, None]], dim=1)), k
+dist.barrier()
+env.close()
+dist.destroy_process_group()
+if rank == 0:
+    print("TWO_RANKS_NCCL_OK")
+"""
+
+
+def test_two_ranks_nccl():
+    """the first time TWO GPUs are visible this runs instead of skipping — two processes, one per GPU, backend "nccl"
+    (RCCL over xGMI): rank-local records arrive in every rank's gathered tensor, and the sharded run equals the unsharded one bit for
+    bit; then `bench.py --gpus 2` itself (real nccl, gather on / off pair in its JSON line).  One-GPU boxes skip (the same code path
+    under gloo: tests/test_sharding_gloo.py, tests/test_gpu_two_ranks.py)."""
+    import json
+    import socket
+
+    import torch
+
+    two = torch.cuda.device_count() >= 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if not two:
+        env["MZ_TEST_SINGLE_GPU"] = "1"  # rehearse the very script on the one GPU (gloo), so that its first real run is not its first run
+    script = os.path.join(ROOT, "gpurun_out", "_two_ranks_nccl.py")
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    with open(script, "w") as f:
+        f.write(TWO_RANK_SCRIPT % dict(root=ROOT))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port), script]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "TWO_RANKS_NCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    if not two:
+        pytest.skip("the nccl leg needs two visible GPUs (the two-rank script itself was rehearsed on this GPU over gloo: passed)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--no-live-pmc",
+                          "--sustained", "0"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"

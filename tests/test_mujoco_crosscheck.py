@@ -97,10 +97,12 @@ def test_forward_dynamics_stage_by_stage(env_id, oracle):
             np.testing.assert_allclose(ref["qacc"][0], data.qacc, rtol=1e-6, atol=1e-7, err_msg="qacc of mj_forward [ASSUME-2/3/4 rows, 11 solver]")
 
 
-def _probe_geom_xml(name, kind_is_capsule, g):
+def _probe_geom_xml(name, kind_is_capsule, g, sphere=False):
     pos, mat, size = g
     q = np.zeros(4)
     mujoco.mju_mat2Quat(q, np.asarray(mat, float).ravel())
+    if sphere:
+        return f'<geom name="{name}" type="sphere" size="{size[0]}" pos="{pos[0]} {pos[1]} {pos[2]}"/>'
     if kind_is_capsule:
         return f'<geom name="{name}" type="capsule" size="{size[0]} {size[1]}" pos="{pos[0]} {pos[1]} {pos[2]}" quat="{q[0]} {q[1]} {q[2]} {q[3]}"/>'
     return f'<geom name="{name}" type="box" size="{size[0]} {size[1]} {size[2]}" pos="{pos[0]} {pos[1]} {pos[2]}" quat="{q[0]} {q[1]} {q[2]} {q[3]}"/>'
@@ -115,7 +117,7 @@ def test_narrowphase_probes_against_mujoco():
     verdict = {}
     for name, kind, g1, g2, margin, want in NP.probes():
         xml = f"""<mujoco><option gravity="0 0 0"/><default><geom margin="{margin}" contype="1" conaffinity="1"/></default><worldbody>
-          <body name="a">{_probe_geom_xml("g1", kind == "capsule_box", g1)}<freejoint/></body>
+          <body name="a">{_probe_geom_xml("g1", kind == "capsule_box", g1, sphere=kind == "sphere_box")}<freejoint/></body>
           {_probe_geom_xml("g2", False, g2)}</worldbody></mujoco>"""
         model = mujoco.MjModel.from_xml_string(xml)
         data = mujoco.MjData(model)

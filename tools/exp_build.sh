@@ -5,5 +5,5 @@
 #   tools/exp_build.sh SWPROF
 name=${1:?name}
 cd "$(dirname "$0")/../mujoco_maze_amd/csrc" && make libmazestep.so > /dev/null && \
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -fno-math-errno -freciprocal-math -DMZ_EXP_$name -c -o /tmp/planar_$name.o planar_kernels.hip && \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -fno-math-errno -freciprocal-math -DMZ_EXPERIMENTS -DMZ_EXP_$name -c -o /tmp/planar_$name.o planar_kernels.hip && \
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o exp_$name.so mazestep.o ant_kernels.o /tmp/planar_$name.o generic_kernels.o && ls -la exp_$name.so

@@ -15,7 +15,8 @@ g = torch.Generator(device=env.device).manual_seed(0)
 acts = [(torch.rand((n, 8), device=env.device, generator=g) * 60 - 30) for _ in range(16)]
 for i in range(100): env.step(acts[i % 16])
 env.set_option("profile_phases", 1)
-env.step(acts[0]); env.phase_cycles()
+wgs0 = n // (64 // lanes)
+env.step(acts[0]); env.wave_cycles(wgs0); env.wave_phase_cycles(wgs0)  # (these two reads clear the per-workgroup slots phase_cycles sums)
 steps = 50
 for i in range(steps): env.step(acts[i % 16])
 cyc = env.phase_cycles()
@@ -35,7 +36,10 @@ print(f"{env_id} n={n} lanes={lanes}  total cycles/step/wave = {tot/steps/wgs:.0
 for k, nm in enumerate(names):
     print(f"  {nm:36s} {cyc[k]/steps/wgs:10.0f} cycles/step  {100*cyc[k]/tot:5.1f} %")
 import math
+# since round 6 slots 13 / 14 are reduced on the host from per-workgroup sums over the WINDOW (no same-address atomics in the kernel): the
+# most loaded workgroup's window total and the sum of squares of the window totals — per-STEP spreads: tools/tail_phases.py
 mean = tot / steps / wgs
-sq = cyc[14] * 65536.0 / (steps * wgs)
+sq = cyc[14] * 65536.0 / wgs / (steps * steps)
 std = math.sqrt(max(0.0, sq - mean * mean))
-print(f"  per-wave total: mean {mean:.0f}  std {std:.0f}  max {cyc[13]:.0f}  (max/mean {cyc[13]/mean:.2f}; a launch lasts as long as its slowest wave)")
+print(f"  per-wave total per step, averaged over the {steps}-step window: mean {mean:.0f}  std across waves {std:.0f}  most loaded wave {cyc[13]/steps:.0f}  "
+      f"(x {cyc[13]/steps/mean:.2f}); the per-step slowest wave — what a launch waits for: tools/tail_phases.py")

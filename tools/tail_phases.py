@@ -19,7 +19,7 @@ for i in range(150): env.step(acts[i % 16])
 env.set_option("profile_phases", 1)
 env.step(acts[0]); env.phase_cycles(); env.wave_cycles(NW); env.wave_phase_cycles(NW)
 names = ["K kinematics", "V bias", "C enum", "I+M", "solve:setup", "solve:grad+H", "solve:elim", "solve:vote/ls/update", "solve:tail", "rk4", "io", "C records", "(prologue)"]
-allp, slow, nears, saved = [], [], [], []
+allp, slow, nears, saved, subs = [], [], [], [], []
 boxes = np.array(env.model.world.wall_boxes())  # x, y, z, hx, hy, hz
 def near_wall(xy, reach):
     dx = np.maximum(np.abs(xy[:, None, 0] - boxes[None, :, 0]) - boxes[None, :, 3], 0.0)
@@ -30,7 +30,9 @@ for k in range(12):
     xy = st0[0][:, :2]
     nears.append(np.stack([near_wall(xy, 1.2).reshape(NW, -1).sum(1), near_wall(xy, 0.7).reshape(NW, -1).sum(1)], 1))
     env.step(acts[(k + 1) % 16])
-    ph = env.wave_phase_cycles(NW).astype(np.float64)[:, :13]
+    raw = env.wave_phase_cycles(NW).astype(np.float64)
+    ph = raw[:, :13]
+    subs.append(raw[:, 13:15])  # sub-timers of experiment builds (-DMZ_EXP_RK4TICK: rk4 arithmetic + stores | the hand-off behind them); 0 otherwise
     it = env.wave_cycles(NW); its = env.last_wave_newton_iters.astype(np.float64)
     env.phase_cycles()
     tot = ph.sum(1)
@@ -46,6 +48,11 @@ print(f"{'phase':24s} {'all waves':>10s} {'slowest 1%':>11s} {'slowest/step':>13
 for i, nm in enumerate(names):
     print(f"{nm:24s} {A[:, i].mean():10.0f} {top[:, i].mean():11.0f} {S[:, i].mean():13.0f}")
 print(f"{'Newton iterations':24s} {A[:, 13].mean():10.1f} {top[:, 13].mean():11.1f} {S[:, 13].mean():13.1f}")
+X = np.concatenate(subs)
+if X.any():  # experiment build: slots 13 / 14 split the "rk4" slot (they are NOT part of the totals above)
+    sel = tot >= np.quantile(tot, 0.99)
+    for i, nm in enumerate(("sub 13: rk4 arithmetic+stores", "sub 14: hand-off behind it")):
+        print(f"{nm:30s} {X[:, i].mean():10.0f} {X[sel, i].mean():11.0f}")
 N = np.concatenate(nears)
 for col, nm in ((0, "torso within 1.2 of a wall"), (1, "torso within 0.7 of a wall")):
     print(f"envs of the wave with the {nm}:")
