@@ -300,6 +300,13 @@ int32_t mz_bind_record(mz_handle* h, float* record_dev);
 int32_t mz_set_goals(mz_handle* h, int32_t ngoal, const double* pos, const double* threshold, const double* reward_scale,
                      const int32_t* dim, void* stream);
 
+/* Per-env goal positions (ABI 8).  The reference gives every env its own task object and resamples its goals at EVERY episode reset
+ * (maze_env.py:374-376); a batch that shares one goal table can only do so at a full reset.  goal_pos_dev: DEVICE pointer,
+ * [num_envs][MZ_MAX_GOAL][3] float64, caller-owned and caller-updated between steps (the host mirror rewrites the rows of the envs
+ * whose episode just ended); NULL unbinds.  Thresholds, reward scales, dims and the goal count stay those of the shared table
+ * (mz_set_goals / the model).  Synchronises on `stream` first.  Returns MZ_OK, MZ_ERR_ARG or MZ_ERR_HIP. */
+int32_t mz_bind_env_goals(mz_handle* h, const double* goal_pos_dev, void* stream);
+
 /* reset(): envs with mask_dev[i] != 0 (all when NULL) get t = 0 and a fresh state
  * from the reference's reset distribution (counter-based RNG keyed by seed and
  * env slot; streams differ from numpy's — distributional parity only).
@@ -335,6 +342,7 @@ int32_t mz_debug_forward(mz_handle* h, const float* actions_dev, float* qacc_dev
  * mz_debug_task_eval: MazeTask.reward / termination / first matching goal (maze_task.py:43-47,77-81,110-111,403-407) on
  *   n_rows observation rows [n_rows, obs_dim] fp32 — the very task_eval_dev instance the handle's step kernel runs:
  *   reward_dev[n_rows] = task reward only (no inner reward), done_dev[n_rows] u8 = termination, goal_idx_dev (nullable).
+ *   With per-env goals bound (mz_bind_env_goals) row r < num_envs is judged with env r's goals, later rows with the shared table.
  * mz_debug_detect: CollisionDetector.detect + the bounce / give-up rule of MazeEnv.step (maze_env_utils.py:96-123,186-206;
  *   maze_env.py:457-464) on n_rows float64 moves old_xy -> new_xy ([n_rows, 2] each): hit_dev[n_rows] = 0 no wall hit,
  *   1 bounced, 2 gave up (position restored), -1 collinear move (the reference raises ZeroDivisionError);

@@ -21,7 +21,7 @@ SYMBOLS = [
     "mz_abi_version", "mz_model_sizeof", "mz_create", "mz_destroy", "mz_last_error", "mz_num_envs", "mz_obs_dim", "mz_nq",
     "mz_nv", "mz_nu", "mz_set_option", "mz_reset", "mz_set_state", "mz_get_state", "mz_step", "mz_get_status",
     "mz_debug_forward", "mz_last_kernel_ms", "mz_read_phase_cycles", "mz_bind_final_obs", "mz_debug_task_eval", "mz_debug_detect", "mz_read_wave_cycles", "mz_bind_record",
-    "mz_set_goals", "mz_read_wave_phase_cycles", "mz_get_info",
+    "mz_set_goals", "mz_read_wave_phase_cycles", "mz_get_info", "mz_bind_env_goals",
 ]
 
 _lib = None
@@ -63,6 +63,8 @@ def load():
         getattr(lib, name).argtypes = [vp]
     lib.mz_set_option.restype = i32
     lib.mz_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    lib.mz_bind_env_goals.restype = i32
+    lib.mz_bind_env_goals.argtypes = [vp, vp, vp]
     lib.mz_get_info.restype = i32
     lib.mz_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     lib.mz_reset.restype = i32

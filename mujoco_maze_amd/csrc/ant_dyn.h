@@ -114,13 +114,18 @@ struct ArrowFactor {
   float rhs[NH];      // reduced right-hand side / hub solution
 };
 
+// The per-env scratch block comes in two types.  AntScratchCoreT: what EVERY path uses — and all that the quad forward pass
+// (ant_forward_rows.h: plain ant, one two-slide block, >= 16 lanes per env) ever touches.  Its product kernels allocate only this
+// type per env (4.7 KB instead of 9.1 KB for the plain ant, so that 32 envs fit a CU's LDS and 8192 envs run in one round) and hand
+// the quad functions an AntScratchCoreT& — the members the lane-group formulation adds (AntScratchT below, derived) are out of
+// their reach by type, not by convention (round 6).
+template <bool BALL>
+struct AntBallKinT { float bR[9], bx[3], bc[3]; };  // object ball (config 5): rotation (row-major), body origin and sphere centre relative to the torso origin
+template <>
+struct AntBallKinT<false> {};                       // (no bytes in the other configurations: an empty base)
 template <int NB>
-struct alignas(16) AntScratchT {
+struct alignas(16) AntScratchCoreT : AntBallKinT<AntDims<NB>::BALL> {
   using D = AntDims<NB>;
-  // ================= part 1: what EVERY path uses — and all that the quad forward pass (ant_forward_rows.h: plain ant, one two-slide
-  // block, >= 16 lanes per env) ever touches.  Its kernels allocate only this prefix per env (slim_bytes(): 4.7 KB instead of 9.1 KB
-  // for the plain ant, so that 32 envs fit a CU's LDS and 8192 envs run in one round); the members of part 2 must not be
-  // reached from that path.
   // step-persistent
   float qpos[D::NQ + 1], qvel[D::NV], x0q[D::NQ + 1], x0v[D::NV], accv[D::NV], accf[D::NV], warm[D::NV], fact[D::NV];
   float qacc[D::NV], qas[D::NV];
@@ -153,28 +158,25 @@ struct alignas(16) AntScratchT {
   // quad forward pass, NB = 1: the block's own enumerators are re-run only when the block has moved (ant_forward_rows.h).  bkey[0..3] =
   // bits of its slides (hi, lo) at the enumeration whose results sit in the staging block and in cnt[0 .. NMOV); bkey[4] != 0: valid
   int bkey[5];
-  // ================= part 2: the lane-group formulation only (8-lane groups, two and more blocks, the ball, the host emulation) and
-  // the instrumented builds
-  alignas(16) float legacy_begin[4];  // (marks the end of the prefix)
-  float qfs[D::NV];
+};
+// The lane-group formulation (8-lane groups, two and more blocks, the ball, the host emulation) and the instrumented builds add:
+template <int NB>
+struct alignas(16) AntScratchT : AntScratchCoreT<NB> {
+  using D = AntDims<NB>;
+  alignas(16) float qfs[D::NV];
   float p1[4][3], p2[4][3];      // aux / ankle body origins
-  float bR[9], bx[3], bc[3];     // object ball (config 5): rotation (row-major), body origin and sphere centre relative to the torso origin
   float cin[13][10];             // spatial inertias at c: m, h(3), Ibar(xx yy zz xy xz yz)
   float fbody[13][6], bias[D::NV], Iall[10];  // per-body inertial + velocity-product force (spatial, at c)
   alignas(16) Arrow<D::NH> M, H;
   ArrowFactor<D::NH> F;
   float search[D::NV], Ms[D::NV];
   float caref[D::NC][3], cD[D::NC], cu[D::NC][3], cjv[D::NC][3];
-  // bit k: hub column k of the contact's Jacobian is non-zero in some row (con_mask_item).  A movable block's OWN contacts — floor
-  // corners, maze boxes, slide limits: most of the contacts of a block maze — touch that block's two or three columns only; the
-  // solver's gradient / W J / Hessian / J x loops skip the structural zeros by this mask (round 6)
-  uint32_t cmask[D::NC];
   // joint limits (8 hinges)
   float lsign[8], lD[8], laref[8], ljar[8], ljv[8], lact[8];
   // optional phase timers (device builds with PROF): cycles per phase id, last timestamp
   unsigned long long prof_t0;
   unsigned int prof[16];
-  static constexpr size_t slim_bytes() { return offsetof(AntScratchT, legacy_begin); }
+  static constexpr size_t slim_bytes() { return sizeof(AntScratchCoreT<NB>); }
 };
 using AntScratch = AntScratchT<0>;
 
@@ -1040,7 +1042,7 @@ MZ_HD bool aligned_box_box(const double* c1, const double* h1, const double* c2,
 
 // torso-relative centre of movable block k
 template <int NB>
-MZ_HD void block_center(const AntDev& K, const AntScratchT<NB>& s, int k, float* bc) {
+MZ_HD void block_center(const AntDev& K, const AntScratchCoreT<NB>& s, int k, float* bc) {
   using D = AntDims<NB>;
   float p0[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f}, ql[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1064,7 +1066,7 @@ MZ_HD void block_center(const AntDev& K, const AntScratchT<NB>& s, int k, float*
 // other blocks and slide limits) or the object ball; else robot geom (= body) b = e - NMOV (floor, walls, blocks / ball).  `emit` is called once per contact, in a fixed
 // order, identical in the count and fill passes.
 template <int NB, class Emit>
-MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&& emit) {
+MZ_HD void geom_contacts(const AntDev& K, const AntScratchCoreT<NB>& s, int e, Emit&& emit) {
   const MazeDev& z = K.maze;
   float inv = 1.0f / z.scale;
   float bs[3] = {z.half_xy, z.half_xy, z.half_z};
@@ -1318,9 +1320,9 @@ MZ_HD void geom_contacts(const AntDev& K, const AntScratchT<NB>& s, int e, Emit&
 #define MZ_NEWTON_STALL 2e-6f  // relative step below which a line-searched Newton step counts as no step (fp32: 6e-8 per operation)
 #define MZ_STAGE_OF(NB) ((NB) == 0 ? 3 : 4)  // a block's cell enumerator finds up to 2 x 2 contacts
 template <int NB>
-MZ_HD float* con_stage(AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
+MZ_HD float* con_stage(AntScratchCoreT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
 template <int NB>
-MZ_HD const float* con_stage(const AntScratchT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
+MZ_HD const float* con_stage(const AntScratchCoreT<NB>& s, int entry) { return &s.cY[0][0][0] + 8 * entry; }
 
 // MERGE (the movable block's own enumerators in the quad forward pass, ant_forward_rows.h): the contact points of one face pair —
 // four floor corners, the up to four corners of a block / wall overlap rectangle — arrive one after the other with the same
@@ -1328,7 +1330,7 @@ MZ_HD const float* con_stage(const AntScratchT<NB>& s, int entry) { return &s.cY
 // entry with a multiplicity (code + 2048 (mult - 1)), which block_rows_direct turns into mult times the row's weight D — the same
 // cost function term for term, a third of the block's rows.  s.cnt[e] = entries | emitted contacts << 8.
 template <int NB, bool MERGE = false>
-MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+MZ_HD void con_enum_item(const AntDev& K, AntScratchCoreT<NB>& s, int e) {
   constexpr int MZ_STAGE = MZ_STAGE_OF(NB);
   static_assert(8 * MZ_STAGE * AntDims<NB>::NGEOM <= 3 * AntDims<NB>::NC * AntDims<NB>::NCOL, "staging lives in the cY block");
   int n = 0, emitted = 0;
@@ -1359,7 +1361,7 @@ MZ_HD void con_enum_item(const AntDev& K, AntScratchT<NB>& s, int e) {
 
 // MERGED: the movable bodies' enumerators (e < NMOV) ran con_enum_item<NB, true> — cnt = merged entries | contacts emitted << 8
 template <int NB, bool MERGED = false>
-MZ_HD void con_map_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+MZ_HD void con_map_item(const AntDev& K, AntScratchCoreT<NB>& s, int e) {
   using D = AntDims<NB>;
   constexpr int NC = D::NC, NG = D::NGEOM, MZ_STAGE = MZ_STAGE_OF(NB);
   auto cnt_of = [&](int g) { return (MERGED && g < D::NMOV) ? (s.cnt[g] & 255) : s.cnt[g]; };
@@ -1387,7 +1389,7 @@ MZ_HD void con_map_item(const AntDev& K, AntScratchT<NB>& s, int e) {
 
 // per-item bodies of the collision / constraint-row phases
 template <int NB>
-MZ_HD void con_count_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+MZ_HD void con_count_item(const AntDev& K, AntScratchCoreT<NB>& s, int e) {
 
     int n = 0;
     geom_contacts<NB>(K, s, e, [&](const ContactGeo&) { n++; });
@@ -1395,7 +1397,7 @@ MZ_HD void con_count_item(const AntDev& K, AntScratchT<NB>& s, int e) {
 }
 
 template <int NB>
-MZ_HD void con_fill_item(const AntDev& K, AntScratchT<NB>& s, int e) {
+MZ_HD void con_fill_item(const AntDev& K, AntScratchCoreT<NB>& s, int e) {
   using D = AntDims<NB>;
   constexpr int NC = D::NC, NG = D::NGEOM;
 
@@ -1569,25 +1571,12 @@ MZ_HD float contact_eval(float D, const float* u, float* g, float* W) {
   if (W) { W[0] = D * (a0 + a1 + a2 + a3); W[1] = D * (a0 - a1); W[2] = D * (a2 - a3); W[3] = D * (a0 + a1); W[4] = D * (a2 + a3); }
   return 0.5f * D * (a0 * r0 * r0 + a1 * r1 * r1 + a2 * r2 * r2 + a3 * r3 * r3);
 }
-// hub columns of contact c's Jacobian that hold a non-zero in some row (AntScratchT::cmask)
-template <int NB>
-MZ_HD void con_mask_item(AntScratchT<NB>& s, int c) {
-  constexpr int NH = AntDims<NB>::NH;
-  uint32_t m = 0u;
-  for (int k = 0; k < NH; k++)
-    if (s.cJ[c][0][k] != 0.f || s.cJ[c][1][k] != 0.f || s.cJ[c][2][k] != 0.f) m |= 1u << k;
-  s.cmask[c] = m;
-}
 template <int NB>
 MZ_HD float contact_Jdot(const AntScratchT<NB>& s, int c, int a, const float* x) {
   constexpr int NH = AntDims<NB>::NH;
   const float* J = s.cJ[c][a];
   float v = 0.f;
-  if constexpr (NH > 6) {  // mazes with movable bodies: only the hub columns the contact touches (cmask)
-    for (uint32_t m = s.cmask[c]; m; m &= m - 1) { const int k = __builtin_ctz(m); v += J[k] * x[hub2dof(k)]; }
-  } else {
-    for (int k = 0; k < NH; k++) v += J[k] * x[hub2dof(k)];
-  }
+  for (int k = 0; k < NH; k++) v += J[k] * x[hub2dof(k)];
   int leg = s.cleg[c];
   if (leg >= 0) v += J[NH] * x[6 + 2 * leg] + J[NH + 1] * x[7 + 2 * leg];
   return v;
@@ -1667,9 +1656,7 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
       float g = s.Mx[i], ga = fabsf(g);
       int c0 = 0, c1 = s.ncon, col = i < 6 ? i : i - 8;
       if (i >= 6 && i < 14) { int l = (i - 6) >> 1; c0 = s.cbeg[l]; c1 = s.cbeg[l + 1]; col = NH + ((i - 6) & 1); }
-      const bool hubcol = NH > 6 && !(i >= 6 && i < 14);
       for (int c = c0; c < c1; c++) {
-        if (hubcol && !((s.cmask[c] >> col) & 1u)) continue;  // a structural zero of the contact's Jacobian
         float g3[3];
         contact_eval(s.cD[c], s.cu[c], g3, nullptr);
         float t = s.cJ[c][0][col] * g3[0] + s.cJ[c][1][col] * g3[1] + s.cJ[c][2][col] * g3[2];
@@ -1682,7 +1669,6 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
     }
     MZ_FOR_AT(e, NCOL * s.ncon, NV) {
       int c = e / NCOL, k = e - NCOL * c;
-      if (NH > 6 && k < NH && !((s.cmask[c] >> k) & 1u)) continue;  // never read: the Hessian loops skip the same entries
       float W[5];
       contact_eval(s.cD[c], s.cu[c], nullptr, W);
       float n_ = s.cJ[c][0][k], p_ = s.cJ[c][1][k], q_ = s.cJ[c][2][k];
@@ -1712,18 +1698,8 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
         dst = &s.H.ll[l][t]; acc = s.M.ll[l][t];
         if (t != 1) acc += s.lact[2 * l + (t == 2 ? 1 : 0)];
       }
-      if constexpr (NH > 6) {
-        // hub columns of this entry (leg columns NH, NH + 1 are dense within their leg's contact range): a contact contributes only
-        // where both are set — a block's own contacts to that block's 2 x 2 / 3 x 3 corner and to nothing else
-        const uint32_t need = (ci < NH ? 1u << ci : 0u) | (cj < NH ? 1u << cj : 0u);
-        for (int c = c0; c < c1; c++) {
-          if ((s.cmask[c] & need) != need) continue;
-          acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
-        }
-      } else {
-        for (int c = c0; c < c1; c++)
-          acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
-      }
+      for (int c = c0; c < c1; c++)
+        acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
       *dst = acc;
     }
     cx.sync();
@@ -1836,6 +1812,9 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
 // On the device at >= 16 lanes per env contacts are enumerated once (P1 con_enum_item stages them, P2 con_map_item assigns the
 // slots).  The plain ant and the ant with one two-slide block do not come here at all at those widths: their whole evaluation is
 // ant_forward_rows (ant_forward_rows.h) + the row solver of ant_newton_rows.h.
+// (the quad layout's evaluation, ant_forward_rows.h: device builds only — declared for the host emulation's parser, as ant_mj_step_rows below)
+template <int NB, class C, class S>
+MZ_HD float ant_forward_rows(const C& cx, const AntDev& K, S& s, bool first);
 template <int NB, class C>
 MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first) {
   using D = AntDims<NB>;
@@ -1843,7 +1822,7 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   if constexpr (NB <= 1 && C::row_solver) {
     // the plain ant, and the ant with one two-slide block, on the device at >= 16 lanes per env: the whole evaluation in the registers
     // of the row's leg quads (ant_forward_rows.h) — no LDS hand-off before the contact records
-    ant_forward_rows(cx, K, s, first);
+    ant_forward_rows<NB>(cx, K, s, first);
     return;
   }
   cx.tick(s, 9);
@@ -1893,7 +1872,6 @@ MZ_HD void ant_forward(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
     cx.sync();
     cx.tick(s, 11);
     MZ_FOR(e, NH * (NH + 1) / 2 + NH) factor_schur_item<NH>(s.M, s.F, s.qfs, e);
-    if constexpr (NH > 6) { MZ_FOR_AT(c, s.ncon, (NH * (NH + 1) / 2 + NH) % C::nlanes) con_mask_item<NB>(s, c); }  // (rows complete since the fence above)
     cx.sync();
     MZ_FOR(one, 1) factor_serial_item<NH>(s.F);
     cx.sync();
@@ -1938,7 +1916,7 @@ MZ_HD void mz_step_split(float base, float base_lo, float h, float v, float* hi,
   *hi = fh; *lo = (float)(t - (double)fh);
 }
 template <int NB, class C>
-MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base, const float* vel, float h) {
+MZ_HD void ant_integrate_pos(const C& cx, AntScratchCoreT<NB>& s, const float* base, const float* vel, float h) {
   using D = AntDims<NB>;
   MZ_FOR(i, 12 + (D::BALL ? 4 : D::BD * D::NBLK)) {
     if (i < 2) mz_step_split(base[i], s.x0lo[i], h, vel[i], &s.qpos[i], &s.qlo[i]);
@@ -1962,17 +1940,18 @@ MZ_HD void ant_integrate_pos(const C& cx, AntScratchT<NB>& s, const float* base,
 
 // (the quad layout's step, ant_forward_rows.h: device builds only — declared here so that the host emulation, which never takes that
 // branch, can parse the call with its explicit template arguments)
-template <int NB, bool XREG, class C>
-MZ_HD void ant_mj_step_rows(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame);
+template <int NB, bool XREG, class C, class S>
+MZ_HD void ant_mj_step_rows(const C& cx, const AntDev& K, S& s, bool first_frame);
 // one mj_step with RK4.  State in s.qpos / s.qvel / s.warm, actuator forces in s.fact.
-template <int NB, class C>
-MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame) {
+// S: AntScratchT<NB>, or AntScratchCoreT<NB> where the caller allocated no more (the quad layout's product kernels)
+template <int NB, class C, class S>
+MZ_HD void ant_mj_step(const C& cx, const AntDev& K, S& s, bool first_frame) {
   using D = AntDims<NB>;
   if constexpr (NB <= 1 && C::row_solver) {  // the quad layout: RK4 bookkeeping in the dof lanes' registers (ant_forward_rows.h)
     if (cx.mfma) ant_mj_step_rows<NB, false>(cx, K, s, first_frame);  // (a constant after inlining: one of the two survives)
     else ant_mj_step_rows<NB, true>(cx, K, s, first_frame);
     return;
-  }
+  } else {
   const float h = K.h;
   MZ_FOR(i, D::NQ) s.x0q[i] = s.qpos[i];
   MZ_FOR(i, D::NLO) s.x0lo[i] = s.qlo[i];
@@ -2003,6 +1982,7 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
   ant_integrate_pos<NB>(cx, s, s.x0q, s.accv, h);
   MZ_FOR(i, D::NV) s.qvel[i] = s.x0v[i] + h * s.accf[i];
   cx.sync();
+  }
 }
 
 // ------------------------------------------------------------------ MazeTask reward / termination on the fp32 observation
@@ -2010,16 +1990,21 @@ MZ_HD void ant_mj_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool fi
 // float64 predicate (maze_task.py:43-44 `np.linalg.norm(obs[:dim] - pos) <= threshold`, :77-81 any goal, :403-407 first
 // match) evaluated on float64(obs): differences and squares in fp64, summed in index order without contraction, compared
 // with the squared-threshold bound of TaskDev (bit-exact whatever the build flags of the translation unit).
-MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int* term, int* goal_idx) {
+// `env`: the env slot whose row of TaskDev::env_goals holds its own goal positions (per-episode resampling); -1 or no table bound:
+// the batch's shared goal table.
+MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int* term, int* goal_idx, int env = -1) {
 #pragma clang fp contract(off) reciprocal(off) reassociate(off)
+  // (two loads, not one pointer select: the shared table stays a scalar load of the constant block)
+  const double* eg = (T.env_goals && env >= 0) ? T.env_goals + (size_t)env * (3 * MZ_MAX_GOAL) : nullptr;
   const double slot_a[3] = {(double)obs[0], (double)obs[1], (double)obs[2]}, slot_o[3] = {(double)obs[3], (double)obs[4], (double)obs[5]};
   int tm = 0, first = -1, first_t = -1;
   for (int g = 0; g < T.ngoal; g++) {
     double a = 0.0, b = 0.0;
     for (int k = 0; k < 3; k++)
       if (k < T.goal_dim[g]) {
-        double e = (T.term_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; a += e * e;
-        double f = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[g][k]; b += f * f;
+        const double gk = eg ? eg[3 * g + k] : T.goal_pos[g][k];
+        double e = (T.term_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - gk; a += e * e;
+        double f = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - gk; b += f * f;
       }
     if (!tm && a <= T.thr_sq[g]) { tm = 1; first_t = g; }
     if (first < 0 && b <= T.thr_sq[g]) first = g;
@@ -2029,7 +2014,7 @@ MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int*
   else if (T.reward_kind == MZ_REWARD_NEG_DIST && T.ngoal > 0) {
     double a = 0.0;
     for (int k = 0; k < 3; k++)
-      if (k < T.goal_dim[0]) { double e = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - T.goal_pos[0][k]; a += e * e; }
+      if (k < T.goal_dim[0]) { double e = (T.reward_slot == MZ_SLOT_OBJECT ? slot_o[k] : slot_a[k]) - (eg ? eg[k] : T.goal_pos[0][k]); a += e * e; }
     r = -sqrt(a) / T.task_scale;
   }
   // goal index: the goal that set the reward where the reward is a goal's (first match on the reward's slot, maze_task.py:403-407);
@@ -2039,7 +2024,7 @@ MZ_HD void task_eval_dev(const TaskDev& T, const float* obs, float* reward, int*
 
 // coordinate c of movable block k's body origin (get_body_com, maze_env.py:364-368): spawn position + its slides
 template <int NB>
-MZ_HD float ant_block_coord(const AntDev& K, const AntScratchT<NB>& s, int k, int c) {
+MZ_HD float ant_block_coord(const AntDev& K, const AntScratchCoreT<NB>& s, int k, int c) {
   using D = AntDims<NB>;
   float v = 0.f;
 #pragma unroll
@@ -2061,7 +2046,7 @@ MZ_HD int ant_obs_extra(const AntDev& K) {
 
 // observation element i (maze_env.py:351-369): qpos[:3] | ball xpos / block xpos (3 each, if observed) | qpos[3:15] | qvel[:14] | t/1000
 template <int NB>
-MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t) {
+MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchCoreT<NB>& s, int i, int t) {
   using D = AntDims<NB>;
   int nb3 = ant_obs_extra<NB>(K);
   if (i < 3) return s.qpos[i];
@@ -2077,8 +2062,8 @@ MZ_HD float ant_obs_elem(const AntDev& K, const AntScratchT<NB>& s, int i, int t
 }
 
 // constant tables of the scratch block, once per step (to be followed by a cx.sync() before the first forward evaluation)
-template <int NB, class C>
-MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
+template <int NB, class C, class S>
+MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, S& s) {
   MZ_FOR(i, AntDims<NB>::NLO) s.qlo[i] = 0.f;  // the state that enters a step is fp32: no low-order parts yet
   MZ_FOR(one, 1) s.bkey[4] = 0;                  // (LDS does not survive the launch: nothing is staged yet)
   constexpr bool quad = NB <= 1 && C::row_solver;  // the quad forward pass keeps M in registers — and its kernels do not even allocate part 2 of the scratch block
@@ -2105,8 +2090,8 @@ MZ_HD void ant_fill_tables(const C& cx, const AntDev& K, AntScratchT<NB>& s) {
 // ------------------------------------------------------------------ MazeEnv.step for the Ant (maze_env.py:448-481, ant.py:61-73)
 // in: s.qpos/qvel/warm loaded, action[8], *t_io = steps so far.  out: obs[obs_dim], reward, done, goal_idx, info[4], *t_io + 1
 // (t travels through memory so that it does not occupy a register across the whole step)
-template <int NB, class C>
-MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const float* action, float* obs, float* reward,
+template <int NB, class C, class S>
+MZ_HD void ant_env_step(const C& cx, const AntDev& K, S& s, const float* action, float* obs, float* reward,
                         uint8_t* done, int* goal_idx, float* info, int* t_io) {
   using D = AntDims<NB>;
   MZ_FOR(i, D::NV) s.fact[i] = 0.f;
@@ -2128,7 +2113,8 @@ MZ_HD void ant_env_step(const C& cx, const AntDev& K, AntScratchT<NB>& s, const 
     float o6[6];
     for (int k = 0; k < 6; k++) o6[k] = ant_obs_elem<NB>(K, s, k, t);
     float outer; int tm, gi;
-    task_eval_dev(K.task, o6, &outer, &tm, &gi);
+    // (per-env goals: the step kernel parks the env slot in *goal_idx — through LDS, so that it does not occupy a register across the step)
+    task_eval_dev(K.task, o6, &outer, &tm, &gi, (K.task.env_goals && goal_idx) ? *goal_idx : -1);
     *reward = (float)K.task.inner_scale * ((float)K.task.fwd_w * fwd - cc) + outer;
     *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
     if (goal_idx) *goal_idx = gi;

@@ -259,8 +259,9 @@ __device__ __forceinline__ void ant_lane_consts(const AntDev& K, DevCtx<G, PROF>
 // sub-enumerators of geom_contacts, staged as before — and take the first slots; their rows are built inside the solver by the
 // lanes that own them (block_rows_direct).  A robot geom touching the block is a record like any other, flagged so that the slide
 // lanes see its reaction.
-template <int NB, int G, bool PROF>
-__device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step, const AntDev& K, AntScratchT<NB>& s, bool first) {
+// SCR: AntScratchCoreT<NB> (product kernels: all they allocate) or AntScratchT<NB> (instrumented builds: the phase timers live there)
+template <int NB, int G, bool PROF, class SCR>
+__device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step, const AntDev& K, SCR& s, bool first) {
   static_assert(G >= 16, "one DPP row per env at least");
   static_assert(NB <= 1, "row layout: 14 robot dofs + one block's two slides");
   using namespace rows;
@@ -563,8 +564,8 @@ __device__ __forceinline__ float ant_forward_rows(const DevCtx<G, PROF>& cx_step
 // it — and writes only what the next evaluation reads (qpos, qvel, the solver's warm start) to LDS: one hand-off per stage instead
 // of three.  The free joint's quaternion is advanced redundantly by every lane (the three body-frame rates come by row
 // broadcast) and stored by one.
-template <int NB, bool XREG, int G, bool PROF>
-__device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool first_frame) {
+template <int NB, bool XREG, int G, bool PROF, class SCR>
+__device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, const AntDev& K, SCR& s, bool first_frame) {
   using namespace rows;
   using C = DevCtx<G, PROF>;  // (MZ_FOR)
   using D = AntDims<NB>;
@@ -617,7 +618,7 @@ __device__ __forceinline__ void ant_mj_step_rows(const DevCtx<G, PROF>& cx, cons
     }
   };
   for (int st = 0; st < 4; st++) {
-    const float qacc = ant_forward_rows(cx, K, s, first_frame && st == 0);
+    const float qacc = ant_forward_rows<NB>(cx, K, s, first_frame && st == 0);
     const float bw = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float aw = st == 2 ? 1.0f : 0.5f;  // Butcher A: diag(1/2, 1/2, 1)
     accv += bw * qvel;

@@ -14,6 +14,7 @@
 // physics is a 1e-5 tolerance quantity.  The task predicates inside (task_eval_dev) are written so that those flags
 // cannot change a flag: fp64, no contraction, squared thresholds instead of sqrt.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,7 +27,7 @@
 
 // ------------------------------------------------------------------ Ant kernels
 template <int NB, int G, bool P>
-__device__ __forceinline__ void ant_load(const DevCtx<G, P>& cx, AntScratchT<NB>& s, const float* rec) {
+__device__ __forceinline__ void ant_load(const DevCtx<G, P>& cx, AntScratchCoreT<NB>& s, const float* rec) {
   using D = AntDims<NB>;
   for (int i = cx.l; i < D::REC_T; i += G) {
     float v = rec[i];
@@ -36,7 +37,7 @@ __device__ __forceinline__ void ant_load(const DevCtx<G, P>& cx, AntScratchT<NB>
   }
 }
 template <int NB, int G, bool P>
-__device__ __forceinline__ void ant_store(const DevCtx<G, P>& cx, const AntScratchT<NB>& s, float* rec) {
+__device__ __forceinline__ void ant_store(const DevCtx<G, P>& cx, const AntScratchCoreT<NB>& s, float* rec) {
   using D = AntDims<NB>;
   for (int i = cx.l; i < D::REC_T; i += G) {
     float v = i < D::NQ ? s.qpos[i] : (i < D::NQ + D::NV ? s.qvel[i - D::NQ] : s.warm[i - D::NQ - D::NV]);
@@ -53,7 +54,12 @@ struct alignas(16) AntEnvLDS { AntScratchT<NB> s; AntIO io; };
 // LDS bytes of one env: scratch block + I/O staging.  The quad forward pass (plain ant / one two-slide block at >= 16 lanes per env, not
 // instrumented) touches only part 1 of the scratch block (AntScratchT::slim_bytes): 4.7 + 0.3 KB per plain-ant env, 32 envs per CU.
 template <int NB, int G, bool PROF>
-constexpr size_t ant_scratch_bytes() { return (NB <= 1 && G >= 16 && !PROF) ? (AntScratchT<NB>::slim_bytes() + 15) / 16 * 16 : sizeof(AntScratchT<NB>); }
+constexpr bool ant_core_only() { return NB <= 1 && G >= 16 && !PROF; }
+// the scratch type a step kernel instantiation allocates and hands down: the core where nothing beneath it may reach further
+template <int NB, int G, bool PROF>
+using AntScratchOf = std::conditional_t<ant_core_only<NB, G, PROF>(), AntScratchCoreT<NB>, AntScratchT<NB>>;
+template <int NB, int G, bool PROF>
+constexpr size_t ant_scratch_bytes() { return sizeof(AntScratchOf<NB, G, PROF>); }
 template <int NB, int G, bool PROF>
 constexpr size_t ant_env_lds_bytes() { return ant_scratch_bytes<NB, G, PROF>() + (sizeof(AntIO) + 15) / 16 * 16; }
 
@@ -99,7 +105,8 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
   int env = wg * EPB + slot;
   const bool live = env < n;
   if (!live) env = n - 1;  // surplus groups shadow the last env (no stores)
-  AntScratchT<NB>& s = *reinterpret_cast<AntScratchT<NB>*>(lds_raw + (size_t)slot * EB);
+  using S = AntScratchOf<NB, G, PROF>;
+  S& s = *reinterpret_cast<S*>(lds_raw + (size_t)slot * EB);
   AntIO& io = *reinterpret_cast<AntIO*>(lds_raw + (size_t)slot * EB + SB);
   float* act_s = io.act;
   float* obs_s = io.obs;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
   float* rec = state + (size_t)env * D::REC;
   ant_load<NB>(cx, s, rec);
   for (int i = cx.l; i < ANT_NU; i += G) act_s[i] = actions[(size_t)env * ANT_NU + i];
-  if (cx.l == 0) { iout_s[2] = ((const int*)rec)[D::REC_T]; iout_s[3] = ((const int*)rec)[D::REC_T + 1]; }  // t, episode: parked in LDS for the step
+  if (cx.l == 0) { iout_s[1] = env; iout_s[2] = ((const int*)rec)[D::REC_T]; iout_s[3] = ((const int*)rec)[D::REC_T + 1]; }  // env slot (per-env goals: ant_env_step), t, episode: parked in LDS for the step
   if constexpr (PROF) { if (cx.l == 0) { for (int k = 0; k < 16; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); } }
 #ifdef MZ_EXP_STAMPS
   if (cx.l == 0) { s.red[2] = 0.f; s.red[3] = 0.f; s.bkey[0] = 0; s.bkey[1] = 0; s.bkey[2] = 0; s.bkey[3] = 0; }
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
   int env2 = xcd_block(blockIdx.x, gridDim.x) * EPB + slot2;
   const bool live2 = env2 < n;
   if (!live2) env2 = n - 1;
-  AntScratchT<NB>& s2 = *reinterpret_cast<AntScratchT<NB>*>(lds_raw + (size_t)slot2 * EB);
+  S& s2 = *reinterpret_cast<S*>(lds_raw + (size_t)slot2 * EB);
   const AntIO& io2 = *reinterpret_cast<const AntIO*>(lds_raw + (size_t)slot2 * EB + SB);
   const float* obs2 = io2.obs;
   const float* out2 = io2.out;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256, (ant_occupancy<NB, G, WPS>())) void ant_step_k
       float mx = 0.f;
       int npass = 0, nover = 0, pmax = 0, ncyc = 0, nscan = 0;
       for (int q = 0; q < 64 / G; q++) {
-        const AntScratchT<NB>& sq = *reinterpret_cast<const AntScratchT<NB>*>(lds_raw + (size_t)q * EB);
+        const S& sq = *reinterpret_cast<const S*>(lds_raw + (size_t)q * EB);
         mx = fmaxf(mx, sq.red[3]);
         npass += sq.bkey[0]; nover += sq.bkey[1]; pmax = sq.bkey[0] > pmax ? sq.bkey[0] : pmax; ncyc += sq.bkey[2]; nscan += sq.bkey[3];
       }
@@ -448,14 +455,14 @@ static hipError_t dispatch_ant_forward(mz_handle* h, hipStream_t st, const float
 
 // MazeTask.reward / termination on rows of observations (parity tests: the instance of task_eval_dev that is inlined into
 // the Ant step kernel of THIS translation unit, i.e. compiled with its relaxed floating-point flags)
-__global__ void ant_task_eval_kernel(const AntDev* __restrict__ Kp, int n, int obs_dim, const float* __restrict__ obs,
+__global__ void ant_task_eval_kernel(const AntDev* __restrict__ Kp, int n, int nenv, int obs_dim, const float* __restrict__ obs,
                                      float* __restrict__ reward, uint8_t* __restrict__ done, int* __restrict__ goal_idx) {
   int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   float o6[6];
   for (int k = 0; k < 6; k++) o6[k] = obs[(size_t)row * obs_dim + k];
   float r; int tm, gi;
-  task_eval_dev(Kp->task, o6, &r, &tm, &gi);
+  task_eval_dev(Kp->task, o6, &r, &tm, &gi, row < nenv ? row : -1);  // per-env goals (mz_bind_env_goals): row r is env r
   reward[row] = r;
   done[row] = (uint8_t)(tm ? 1 : 0);
   if (goal_idx) goal_idx[row] = gi;
@@ -543,7 +550,7 @@ hipError_t mzk_ant_get_state(mz_handle* h, hipStream_t st, float* qpos, float* q
 hipError_t mzk_ant_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx) {
   hipError_t e = ant_sync_constants(h, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ant_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->ant_dev, n, h->lay.ostride, obs, reward, done, goal_idx);
+  hipLaunchKernelGGL(ant_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->ant_dev, n, h->n, h->lay.ostride, obs, reward, done, goal_idx);
   return hipGetLastError();
 }
 #endif  // MZ_ISA_ONLY

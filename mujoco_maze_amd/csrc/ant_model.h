@@ -50,6 +50,10 @@ struct TaskDev {
   int goal_dim[MZ_MAX_GOAL];
   double goal_pos[MZ_MAX_GOAL][3], thr[MZ_MAX_GOAL], thr_sq[MZ_MAX_GOAL], rscale[MZ_MAX_GOAL];
   double penalty, task_scale, inner_scale, fwd_w, ctrl_w;
+  // per-env goal POSITIONS (mz_bind_env_goals; device pointer, [N][MZ_MAX_GOAL][3] float64, or NULL: the batch shares goal_pos).  The
+  // reference resamples a task's goals at EVERY episode reset (maze_env.py:374-376: one task object per env); thresholds, reward
+  // scales and dims stay the task class's
+  const double* env_goals;
 };
 
 struct MazeDev {

@@ -456,7 +456,7 @@ __device__ __forceinline__ void ant_limit_consts(const AntDev& K, DevCtx<G, PROF
 // con_row_item in ant_dyn.h — the same arithmetic) straight from the contact's staged geometry into the owner lane's registers:
 // only the block's two columns of the Jacobian exist, so the generic 3 x (hub + 2) row builder and its LDS round trip are skipped.
 template <int NB>
-__device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScratchT<NB>& s, int c, float (&jb)[3][2], float (&ar)[3], float& Dout) {
+__device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScratchCoreT<NB>& s, int c, float (&jb)[3][2], float (&ar)[3], float& Dout) {
   using D = AntDims<NB>;
   const int src = s.csrc[c];
   const float* q = src >= 0 ? con_stage<NB>(s, src) : &s.cY[c][0][0];
@@ -539,8 +539,8 @@ __device__ __forceinline__ void block_rows_direct(const AntDev& K, const AntScra
 #else
 #define MZ_IF_OWNER(c) if (true)
 #endif
-template <int NB, int G, bool PROF, bool WR = false>
-__device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, const AntDev& K, AntScratchT<NB>& s, bool compare,
+template <int NB, int G, bool PROF, bool WR = false, class SCR>
+__device__ __forceinline__ float ant_solve_rows_core(const DevCtx<G, PROF>& cx, const AntDev& K, SCR& s, bool compare,
                                                     const float (&Mrow)[14 + 2 * NB], const float qfs, const float (&Sax)[6], const float hq, const float hv) {
   // (hq, hv: angle and velocity of this lane's own hinge, from the forward pass's registers — the limit row reads no LDS)
   static_assert(G >= 16, "one DPP row per env at least");

@@ -1292,7 +1292,7 @@ MZ_HD void gen_store_obs(const GenDev& K, const Q* qpos, const Q* qvel, int t, f
 // obs: a row of obs_dim floats (view entries left open, see gen_store_obs).
 template <class C>
 MZ_HD void gen_env_step(const C& cx, const GenDev& K, GenScratch& s, const float* action, float* obs, float* reward, uint8_t* done, int* goal_idx,
-                        float* info, int* t_io) {
+                        float* info, int* t_io, int env = -1) {
   const mz_model& m = K.m;
   MZ_FOR(i, m.nv) s.fact[i] = 0.0;
   MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
@@ -1342,7 +1342,7 @@ MZ_HD void gen_env_step(const C& cx, const GenDev& K, GenScratch& s, const float
     float o6[6];
     for (int k = 0; k < 6; k++) o6[k] = k < base - 1 ? obs[k] : 0.f;
     float outer; int tm, gi;
-    task_eval_dev(K.task, o6, &outer, &tm, &gi);
+    task_eval_dev(K.task, o6, &outer, &tm, &gi, env);
     *reward = (float)(K.task.inner_scale * inner + (double)outer);
     *done = (uint8_t)((tm ? 1 : 0) | (t >= K.task.max_steps ? 2 : 0));
     if (goal_idx) *goal_idx = gi;

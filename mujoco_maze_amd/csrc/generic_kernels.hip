@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void generic_step_kernel(const GenDev* __restri
   for (int i = cx.l; i < nu; i += 64) L.io.act[i] = actions[(size_t)env * nu + i];
   if (cx.l == 0) { L.io.iout[2] = ((const int*)rec)[rec_t]; L.io.iout[3] = ((const int*)rec)[rec_t + 1]; }
   cx.sync();
-  gen_env_step(cx, K, s, L.io.act, L.io.obs, &L.io.out[0], (uint8_t*)&L.io.iout[0], &L.io.iout[1], &L.io.out[1], &L.io.iout[2]);
+  gen_env_step(cx, K, s, L.io.act, L.io.obs, &L.io.out[0], (uint8_t*)&L.io.iout[0], &L.io.iout[1], &L.io.out[1], &L.io.iout[2], env);
   cx.sync();
   const uint8_t d = *(const uint8_t*)&L.io.iout[0];
   const int t_new = L.io.iout[2];
@@ -120,14 +120,14 @@ __global__ void generic_get_state_kernel(int nq, int nv, int n, const float* sta
   else if (i == nq + 2 * nv) { if (t) t[env] = ((const int*)rec)[i]; }
 }
 
-__global__ void generic_task_eval_kernel(const GenDev* __restrict__ Kp, int n, int obs_dim, const float* __restrict__ obs, float* __restrict__ reward,
+__global__ void generic_task_eval_kernel(const GenDev* __restrict__ Kp, int n, int nenv, int obs_dim, const float* __restrict__ obs, float* __restrict__ reward,
                                          uint8_t* __restrict__ done, int* __restrict__ goal_idx) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   float o6[6];
   for (int k = 0; k < 6; k++) o6[k] = k < obs_dim ? obs[(size_t)row * obs_dim + k] : 0.f;
   float r; int tm, gi;
-  task_eval_dev(Kp->task, o6, &r, &tm, &gi);
+  task_eval_dev(Kp->task, o6, &r, &tm, &gi, row < nenv ? row : -1);  // per-env goals (mz_bind_env_goals): row r is env r
   reward[row] = r; done[row] = (uint8_t)(tm ? 1 : 0);
   if (goal_idx) goal_idx[row] = gi;
 }
@@ -176,6 +176,6 @@ hipError_t mzk_generic_get_state(mz_handle* h, hipStream_t st, float* qpos, floa
   return hipGetLastError();
 }
 hipError_t mzk_generic_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx) {
-  hipLaunchKernelGGL(generic_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->gen_dev, n, h->model.obs_dim, obs, reward, done, goal_idx);
+  hipLaunchKernelGGL(generic_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->gen_dev, n, h->n, h->model.obs_dim, obs, reward, done, goal_idx);
   return hipGetLastError();
 }

@@ -269,6 +269,41 @@ int32_t mz_bind_record(mz_handle* h, float* record_dev) {
   return MZ_OK;
 }
 
+}  // extern "C"
+// (re)build the task block from h->model (+ the bound per-env goal table) and upload it to the handle's kernels
+static int upload_task(mz_handle* h) {
+  mz_model* m = &h->model;
+  if (h->robot == MZ_ROBOT_ANT) {
+    task_dev_from_model(&h->ant.task, m); h->ant.task.env_goals = h->env_goals;
+    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->ant_dev) + offsetof(AntDev, task), &h->ant.task, sizeof(TaskDev), hipMemcpyHostToDevice));
+  } else if (h->robot == MZ_ROBOT_POINT) {
+    task_dev_from_model(&h->point.task, m); h->point.task.env_goals = h->env_goals;
+    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->point_dev) + offsetof(PointDev, task), &h->point.task, sizeof(TaskDev), hipMemcpyHostToDevice));
+  } else if (h->robot == MZ_ROBOT_SWIMMER) {
+    task_dev_from_model(&h->swimmer.task, m); h->swimmer.task.env_goals = h->env_goals;
+    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->swimmer_dev) + offsetof(SwimmerDev, task), &h->swimmer.task, sizeof(TaskDev), hipMemcpyHostToDevice));
+  } else {
+    TaskDev t;
+    task_dev_from_model(&t, m); t.env_goals = h->env_goals;
+    HIPCHK(h, mzk_generic_set_task(h, &t));
+  }
+  return MZ_OK;
+}
+extern "C" {
+
+// Per-env goal positions.  The reference gives every env its own task object and resamples its goals at EVERY episode reset
+// (MazeEnv.reset -> MazeTask.sample_goals, maze_env.py:374-376); a batch that shares one goal table cannot.  goal_pos_dev: DEVICE
+// pointer, [num_envs][MZ_MAX_GOAL][3] float64, caller-owned and caller-updated (the host mirror rewrites the rows of the envs
+// whose episode ended, between two steps); NULL unbinds (back to the shared table of mz_set_goals / the model).  Thresholds, reward
+// scales, dims and the goal COUNT stay those of the shared table.  Synchronises on `stream` first.  Returns MZ_OK or an error code.
+int32_t mz_bind_env_goals(mz_handle* h, const double* goal_pos_dev, void* stream) {
+  if (!h) return MZ_ERR_ARG;
+  DeviceScope scope(h->device);
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  h->env_goals = goal_pos_dev;
+  return upload_task(h);
+}
+
 int32_t mz_set_goals(mz_handle* h, int32_t ngoal, const double* pos, const double* threshold, const double* reward_scale, const int32_t* dim,
                      void* stream) {
   if (!h) return MZ_ERR_ARG;
@@ -284,21 +319,7 @@ int32_t mz_set_goals(mz_handle* h, int32_t ngoal, const double* pos, const doubl
     m->goal_threshold[g] = threshold[g]; m->goal_reward_scale[g] = reward_scale[g]; m->goal_dim[g] = dim[g];
   }
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));  // steps already queued keep the goals they were launched with
-  if (h->robot == MZ_ROBOT_ANT) {
-    task_dev_from_model(&h->ant.task, m);
-    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->ant_dev) + offsetof(AntDev, task), &h->ant.task, sizeof(TaskDev), hipMemcpyHostToDevice));
-  } else if (h->robot == MZ_ROBOT_POINT) {
-    task_dev_from_model(&h->point.task, m);
-    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->point_dev) + offsetof(PointDev, task), &h->point.task, sizeof(TaskDev), hipMemcpyHostToDevice));
-  } else if (h->robot == MZ_ROBOT_SWIMMER) {
-    task_dev_from_model(&h->swimmer.task, m);
-    HIPCHK(h, hipMemcpy(reinterpret_cast<char*>(h->swimmer_dev) + offsetof(SwimmerDev, task), &h->swimmer.task, sizeof(TaskDev), hipMemcpyHostToDevice));
-  } else {
-    TaskDev t;
-    task_dev_from_model(&t, m);
-    HIPCHK(h, mzk_generic_set_task(h, &t));
-  }
-  return MZ_OK;
+  return upload_task(h);
 }
 
 int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* obs_dev, void* stream) {

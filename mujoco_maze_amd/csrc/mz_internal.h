@@ -45,6 +45,7 @@ struct mz_handle {
   uint64_t seed, env0;  // env0: global slot of local env 0 (sharded runs)
   char err[256];
   int lanes_set;  // lanes_per_env chosen by the caller (else the per-robot default)
+  const double* env_goals;  // caller's per-env goal positions (mz_bind_env_goals), or NULL: carried into every TaskDev copy
   int simds;      // 4 x the device's compute units, read once in mz_create: the batch-size rules of the launch shapes compare wave counts with it
   // kernel timing ring (option "time_kernels")
   int ntime, itime;

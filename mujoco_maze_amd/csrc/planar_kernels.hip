@@ -65,7 +65,7 @@ __device__ __forceinline__ void planar_step_body(const PointDev& P, PlanarScratc
   for (int i = cx.l; i < NOBS; i += G) o[i] = planar_obs_elem<NB, NS>(P, s, i, t_new);
   cx.sync();
   float outer; int tm, gi;
-  task_eval_dev(P.task, o, &outer, &tm, &gi);  // flags from the fp32 observation that is returned
+  task_eval_dev(P.task, o, &outer, &tm, &gi, env);  // flags from the fp32 observation that is returned
   const uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
   const bool rst = auto_reset && d;  // vector-env convention: obs <- first observation of the new episode, terminal one -> final_obs
   if (live) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void swimmer_step_kernel(const SwimmerDev* __r
 #endif
   if (!live) return;
   float outer; int tm, gi;
-  task_eval_dev(P.task, o, &outer, &tm, &gi);
+  task_eval_dev(P.task, o, &outer, &tm, &gi, env);
   uint8_t d = (uint8_t)((tm ? 1 : 0) | (t_new >= P.task.max_steps ? 2 : 0));
   const bool rst = auto_reset && d;
   if (!rst || final_obs) swimmer_store_row<NL, NB>(P, qf, o, NO, ostride, ((rst && final_obs) ? final_obs : obs) + (size_t)env * ostride);
@@ -340,14 +340,14 @@ hipError_t mzk_view_fill(mz_handle* h, hipStream_t st, float* obs, float* final_
 
 // ------------------------------------------------------------------ parity-test kernels
 // MazeTask.reward / termination on rows of observations: the task_eval_dev instance of this translation unit
-__global__ void planar_task_eval_kernel(const TaskDev* __restrict__ Tp, int n, int obs_dim, const float* __restrict__ obs,
+__global__ void planar_task_eval_kernel(const TaskDev* __restrict__ Tp, int n, int nenv, int obs_dim, const float* __restrict__ obs,
                                         float* __restrict__ reward, uint8_t* __restrict__ done, int* __restrict__ goal_idx) {
   int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   float o6[6];
   for (int k = 0; k < 6; k++) o6[k] = obs[(size_t)row * obs_dim + k];
   float r; int tm, gi;
-  task_eval_dev(*Tp, o6, &r, &tm, &gi);
+  task_eval_dev(*Tp, o6, &r, &tm, &gi, row < nenv ? row : -1);  // per-env goals (mz_bind_env_goals): row r is env r
   reward[row] = r;
   done[row] = (uint8_t)(tm ? 1 : 0);
   if (goal_idx) goal_idx[row] = gi;
@@ -492,7 +492,7 @@ hipError_t mzk_planar_get_state(mz_handle* h, hipStream_t st, float* qpos_dev, f
 
 hipError_t mzk_planar_task_eval(mz_handle* h, hipStream_t st, int n, const float* obs, float* reward, uint8_t* done, int* goal_idx) {
   const TaskDev* Tp = h->robot == MZ_ROBOT_SWIMMER ? &h->swimmer_dev->task : &h->point_dev->task;
-  hipLaunchKernelGGL(planar_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Tp, n, h->model.obs_dim, obs, reward, done, goal_idx);
+  hipLaunchKernelGGL(planar_task_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Tp, n, h->n, h->model.obs_dim, obs, reward, done, goal_idx);
   return hipGetLastError();
 }
 

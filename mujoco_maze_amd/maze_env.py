@@ -191,6 +191,9 @@ class VecMazeEnv:
         self._record = None
         self._resampled_goals = False
         self._warned_goal_resampling = False
+        self._env_goals = None   # float64 [N, MZ_MAX_GOAL, 3] once the task's sample_goals() said the goals move (per-env goal positions)
+        self._goal_pool = None
+        self._goal_gen = None
         self.set_auto_reset(auto_reset)
         lo = np.array([m.act_ctrlrange[a][0] for a in range(m.nu)], dtype=np.float32)
         hi = np.array([m.act_ctrlrange[a][1] for a in range(m.nu)], dtype=np.float32)
@@ -288,6 +291,46 @@ class VecMazeEnv:
                 m.goal_pos[i][k] = float(pos[i, k])
             m.goal_threshold[i], m.goal_reward_scale[i], m.goal_dim[i] = float(thr[i]), float(rs[i]), int(dim[i])
 
+    @property
+    def env_goals(self):
+        """float64 [N, MZ_MAX_GOAL, 3] device tensor of per-env goal positions (None while the batch shares one goal table): the
+        tensor the step kernel's goal predicate reads (mz_bind_env_goals).  Writing into it moves the goals of single envs."""
+        return self._env_goals
+
+    def _draw_goal_pool(self) -> None:
+        """Per-env goals (maze_env.py:374-376: the reference calls `sample_goals()` at every episode reset of every env, each env its own
+        task object).  Here one task object serves the batch, so a full reset() draws N goal tables from it — env i starts with draw i —
+        and keeps the N draws as the pool from which the episodes that end later (device auto-reset, masked reset) take their next
+        goals, picked by a device-side RNG: no host round trip in the step loop.  Positions only; number, thresholds, reward scales
+        and dimensions of the goals are those of the shared table."""
+        torch, n = self._torch, self.num_envs
+        first = [np.asarray(g.pos, np.float64).copy() for g in self._task.goals]
+        rows = np.zeros((n, 8, 3), np.float64)
+        for r in range(n):
+            if r and not self._task.sample_goals():
+                raise ValueError(f"{type(self._task).__name__}.sample_goals() returned True, then False: it must keep resampling")
+            if len(self._task.goals) != len(first) or len(first) > 8:
+                raise ValueError("sample_goals() must keep the number of goals (and at most MZ_MAX_GOAL = 8 of them)")
+            for i, g in enumerate(self._task.goals):
+                rows[r, i, : g.dim] = np.asarray(g.pos, np.float64)[: g.dim]
+        for g, p0 in zip(self._task.goals, first):  # the task object (and the uploaded shared table) keep the FIRST draw
+            g.pos = p0
+        self._goal_pool = torch.as_tensor(rows, device=self.device)
+        if self._env_goals is None:
+            self._env_goals = self._goal_pool.clone()
+            self._goal_gen = torch.Generator(device=self.device)
+            rc = self._lib.mz_bind_env_goals(self._h, _ptr(self._env_goals), self._stream())
+            _capi.check(self._lib, self._h, rc, "mz_bind_env_goals")
+        else:
+            self._env_goals.copy_(self._goal_pool)
+        self._goal_gen.manual_seed(self._seed)
+
+    def _resample_env_goals(self, which) -> None:
+        """Envs in `which` (bool [N], device) take a random member of the pool as their goals; the others keep theirs."""
+        torch = self._torch
+        idx = torch.randint(0, self.num_envs, (self.num_envs,), device=self.device, generator=self._goal_gen)
+        torch.where(which[:, None, None], self._goal_pool[idx], self._env_goals, out=self._env_goals)
+
     def _sync_goals_across_ranks(self) -> None:
         """Sharded runs (sharding.py): every rank called sample_goals() on its own unsynchronised RNG — rank 0's goals win, so that
         the batch really has ONE goal table (positions only: thresholds / reward scales are class constants of the task)."""
@@ -313,22 +356,28 @@ class VecMazeEnv:
     def reset(self, mask=None, seed: Optional[int] = None):
         """Reset all (or the masked) envs; returns the observation tensor [N, obs_dim] on the GPU.
 
-        A full reset (mask None) first asks the task for new goals — `MazeTask.sample_goals()`, maze_env.py:374-376 — and
-        re-uploads the goal table when it says they changed.  The batch shares ONE goal table (the reference has one task
-        object per env), so a masked reset of some envs leaves the goals of the others alone: it does not resample."""
+        A full reset (mask None) first asks the task for new goals — `MazeTask.sample_goals()`, maze_env.py:374-376 — and when it
+        says they changed the batch moves to PER-ENV goal positions (`env_goals`, _draw_goal_pool): every env its own draw, and
+        every later episode start (masked reset, device auto-reset) a new one for that env, as the reference's one-task-per-env
+        does.  Tasks whose goals never move keep the one shared table."""
         if seed is not None:
             self._seed = int(seed)
         if mask is None and self._task.sample_goals():
             self._resampled_goals = True
             self._sync_goals_across_ranks()
-            self.set_goals()
-            if self._auto_reset and not self._warned_goal_resampling:
+            self.set_goals()  # the shared table follows the draw (thresholds, reward scales, dims; the host copy of the model)
+            if not self._host_rewards:
+                self._draw_goal_pool()  # every env its own draw of sample_goals(); the step kernel reads the per-env table from here on
+            elif self._auto_reset and not self._warned_goal_resampling:
                 import warnings
 
                 self._warned_goal_resampling = True
-                warnings.warn(f"{type(self._task).__name__}.sample_goals() returned True and auto_reset is on: the reference resamples goals "
-                              "at EVERY episode reset (maze_env.py:374-376), the device auto-reset (and a masked reset) keeps the batch's "
-                              "one goal table — goals change at full reset() calls only")
+                warnings.warn(f"{type(self._task).__name__}.sample_goals() returned True, auto_reset is on and the task's reward()/termination() are "
+                              "Python overrides judged on the host from ONE task object: the reference resamples goals at EVERY episode reset "
+                              "(maze_env.py:374-376), here they change at full reset() calls only")
+        elif mask is not None and self._env_goals is not None:
+            mkb = self._torch.as_tensor(mask, device=self.device).to(self._torch.bool)
+            self._resample_env_goals(mkb)  # the masked envs start a new episode: new goals for them (maze_env.py:374-376), the others keep theirs
         mk = None
         if mask is not None:
             mk = self._torch.as_tensor(mask, device=self.device).to(self._torch.uint8).contiguous()
@@ -351,6 +400,8 @@ class VecMazeEnv:
         _capi.check(self._lib, self._h, rc, "mz_step")
         if self._host_rewards:
             self._apply_host_task()
+        elif self._env_goals is not None and self._auto_reset:
+            self._resample_env_goals(self._done != 0)  # the kernel judged this step with the old goals and restarted these envs
         info = {"position": self._info[:, :2], "reward_forward": self._info[:, 2], "reward_ctrl": self._info[:, 3],
                 "goal_index": self._goal}
         if self._auto_reset:

@@ -143,56 +143,142 @@ class MovingGoalCross(InheritedRewardCross):
 @pytest.mark.gpu
 @pytest.mark.parametrize("model_cls", [mm.PointEnv, mm.AntEnv, mm.SwimmerEnv])
 def test_resampled_goals_reach_the_device(model_cls):
-    """reset() asks the task for new goals and re-uploads the goal table (mz_set_goals): termination / reward of the kernel's
-    own predicate follow the NEW goal, threshold included."""
+    """reset() asks the task for new goals (maze_env.py:374-376).  The reference has one task object per env, so every env gets its
+    OWN draw: the batch moves to per-env goal positions (mz_bind_env_goals) and termination / reward of the kernel's predicate
+    follow each env's goal, threshold included; the shared table (mz_set_goals) keeps the first draw."""
     import torch
 
     from mujoco_maze_amd.maze_env import VecMazeEnv
 
     n, scale = 32, 4.0
     env = VecMazeEnv(model_cls, MovingGoalCross, maze_size_scaling=scale, num_envs=n, inner_reward_scaling=0.0)
-    assert not env._host_rewards  # the stock reward: judged inside the kernel
+    assert not env._host_rewards and env.env_goals is None  # the stock reward: judged inside the kernel; one table until goals move
     zero = torch.zeros((n, env.nu), device=env.device)
+    east, north = np.array([8.0, 0.0]), np.array([8.0, -4.0])
     for episode in range(3):
         env.reset(seed=episode)
+        eg = env.env_goals.cpu().numpy()
+        assert eg.shape == (n, 8, 3) and not eg[:, 1:].any() and not eg[:, 0, 2].any()
+        eg = eg[:, 0, :2]
+        is_east = np.all(eg == east, axis=1)
+        assert np.all(is_east | np.all(eg == north, axis=1)) and 0 < is_east.sum() < n  # every env one of the task's draws, both occur
         goal = env._task.goals[0]
-        assert np.allclose(goal.pos, [8.0, 0.0] if episode % 2 == 0 else [8.0, -4.0])
-        other = np.array([8.0, -4.0] if episode % 2 == 0 else [8.0, 0.0])
+        assert np.allclose(goal.pos, eg[0])  # the task object keeps the FIRST draw ...
+        other = np.where(is_east[:, None], north, east)
         qpos = env.get_state()[0]
-        qpos[: n // 4, 0], qpos[: n // 4, 1] = float(goal.pos[0]) - 0.7, float(goal.pos[1])   # inside 0.8, outside the default 0.6
-        qpos[n // 4: n // 2, 0], qpos[n // 4: n // 2, 1] = float(other[0]) - 0.1, float(other[1])  # at the goal of the OTHER episodes
-        env.set_state(qpos=qpos)
+        q = qpos.cpu().numpy()
+        q[: n // 4, 0], q[: n // 4, 1] = eg[: n // 4, 0] - 0.7, eg[: n // 4, 1]                # inside 0.8, outside the default 0.6
+        q[n // 4: n // 2, 0], q[n // 4: n // 2, 1] = other[n // 4: n // 2, 0] - 0.1, other[n // 4: n // 2, 1]  # at the goal of OTHER envs
+        env.set_state(qpos=torch.as_tensor(q, device=env.device))
         obs, rew, done, info = env.step(zero)
         o = obs.double().cpu().numpy()
-        want = np.array([env._task.termination(x) for x in o])
+        want = np.linalg.norm(o[:, :2] - eg, axis=1) <= goal.threshold
         got = (done.cpu().numpy() & 1).astype(bool)
         assert np.array_equal(got, want), episode
         assert want[: n // 4].all() and not want[n // 4:].any()
         assert np.allclose(rew.cpu().numpy(), np.where(want, 1.0, env._task.PENALTY), atol=1e-7)
         assert np.array_equal(info["goal_index"].cpu().numpy(), np.where(want, 0, -1))
-        # the parity-test entry evaluates the same table
+        # the parity-test entry judges row r with env r's goals
         r2, d2, g2 = env.debug_task_eval(obs)
         assert np.array_equal(d2.cpu().numpy().astype(bool), want)
-        # ... and so does the host copy of the model (what the oracle / parity tools judge with)
+        # ... and so do the shared table and the host copy of the model (what the oracle / parity tools judge env 0 with)
         assert env.model.c.ngoal == 1 and np.allclose([env.model.c.goal_pos[0][k] for k in range(2)], goal.pos)
         assert env.model.c.goal_threshold[0] == goal.threshold
+    # writing into the tensor moves the goal of a single env
+    env.reset(seed=9)
+    env.env_goals[5, 0, :2] = torch.as_tensor([0.3, 0.0], dtype=torch.float64)  # next to the start cell
+    obs, rew, done, info = env.step(zero)
+    d = done.cpu().numpy() & 1
+    assert d[5] == 1 and d.sum() == 1
     env.close()
 
 
+class RandomGoalCross(InheritedRewardCross):
+    """Goal drawn uniformly along the east arm at every episode start (a continuous distribution: no two draws coincide)."""
+
+    def __init__(self, scale: float) -> None:
+        super().__init__(scale)
+        self._rng = np.random.default_rng(5)
+
+    def sample_goals(self) -> bool:
+        self.goals = [MazeGoal(np.array([self._rng.uniform(1.0, 2.0) * self.scale, 0.0]), threshold=0.8)]
+        return True
+
+
 @pytest.mark.gpu
-def test_goal_resampling_under_auto_reset_warns_once():
-    """The reference resamples goals at every episode reset (maze_env.py:374-376); the device auto-reset keeps the batch's one goal
-    table.  A task whose sample_goals() returns True under auto_reset says so (once)."""
+@pytest.mark.parametrize("model_cls", [mm.PointEnv, mm.AntEnv])
+def test_goals_are_resampled_per_env_at_every_episode_start(model_cls):
+    """maze_env.py:374-376 under the device auto-reset and under a masked reset: exactly the envs whose episode ended get new goals
+    (members of the pool drawn at the last full reset), the others keep theirs; the terminal step itself was judged with the OLD goal.
+    No host round trip: the rows are rewritten by device-side ops after the step kernel."""
+    import warnings
+
+    import torch
+
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+
+    n = 64
+    env = VecMazeEnv(model_cls, RandomGoalCross, maze_size_scaling=4.0, num_envs=n, auto_reset=True, inner_reward_scaling=0.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # no "goals change at full reset() only" warning any more
+        env.reset(seed=1)
+    pool = env._goal_pool.cpu().numpy()
+    g0 = env.env_goals.cpu().numpy().copy()
+    assert np.array_equal(g0, pool) and len(np.unique(g0[:, 0, 0])) == n  # env i starts with draw i
+    q = env.get_state()[0].cpu().numpy()
+    at_goal = np.arange(n) % 4 == 0
+    q[at_goal, 0], q[at_goal, 1] = g0[at_goal, 0, 0] - 0.2, g0[at_goal, 0, 1]
+    env.set_state(qpos=torch.as_tensor(q, device=env.device))
+    zero = torch.zeros((n, env.nu), device=env.device)
+    obs, rew, done, info = env.step(zero)
+    d = (done.cpu().numpy() & 1).astype(bool)
+    assert np.array_equal(d, at_goal) and np.allclose(rew.cpu().numpy()[at_goal], 1.0)
+    g1 = env.env_goals.cpu().numpy()
+    assert np.array_equal(g1[~at_goal], g0[~at_goal])
+    changed = np.any(g1 != g0, axis=(1, 2))
+    assert not changed[~at_goal].any() and changed[at_goal].sum() >= at_goal.sum() - 2  # a pool member picked at random (may pick its own)
+    assert all(np.any(np.all(pool == row, axis=(1, 2))) for row in g1)
+    # the restarted envs are judged with their NEW goals from the next step on: put them at the old goal -> not done (unless the new one is near)
+    q = env.get_state()[0].cpu().numpy()
+    q[at_goal, 0], q[at_goal, 1] = g0[at_goal, 0, 0] - 0.2, g0[at_goal, 0, 1]
+    env.set_state(qpos=torch.as_tensor(q, device=env.device))
+    obs, rew, done, info = env.step(zero)
+    fin = np.where((done.cpu().numpy() != 0)[:, None], info["final_observation"].double().cpu().numpy(), obs.double().cpu().numpy())
+    want = np.linalg.norm(fin[:, :2] - g1[:, 0, :2], axis=1) <= 0.8
+    assert np.array_equal((done.cpu().numpy() & 1).astype(bool), want) and want.sum() < at_goal.sum()
+    # masked reset: the same rule
+    g2 = env.env_goals.cpu().numpy().copy()
+    mask = np.zeros(n, np.uint8)
+    mask[1::8] = 1
+    env.reset(mask=torch.as_tensor(mask, device=env.device))
+    g3 = env.env_goals.cpu().numpy()
+    assert np.array_equal(g3[mask == 0], g2[mask == 0]) and np.any(g3[mask == 1] != g2[mask == 1])
+    # a full reset draws a fresh pool
+    env.reset(seed=2)
+    assert not np.array_equal(env._goal_pool.cpu().numpy(), pool) and np.array_equal(env.env_goals.cpu().numpy(), env._goal_pool.cpu().numpy())
+    env.close()
+
+
+class MovingGoalPythonReward(MovingGoalCross):
+    def reward(self, obs):
+        return 1.0 if self.termination(obs) else -0.5
+
+
+@pytest.mark.gpu
+def test_goal_resampling_of_host_judged_tasks_under_auto_reset_warns_once():
+    """Python reward()/termination() overrides are judged on the host from the ONE task object: its goals can only change at a full
+    reset() (the reference resamples at every episode reset, maze_env.py:374-376).  Such a task under auto_reset says so (once)."""
     import warnings
 
     from mujoco_maze_amd.maze_env import VecMazeEnv
 
-    env = VecMazeEnv(mm.PointEnv, MovingGoalCross, maze_size_scaling=4.0, num_envs=4, auto_reset=True)
+    env = VecMazeEnv(mm.PointEnv, MovingGoalPythonReward, maze_size_scaling=4.0, num_envs=4, auto_reset=True)
+    assert env._host_rewards
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         env.reset(seed=0)
         env.reset(seed=1)
-    assert sum("sample_goals" in str(x.message) for x in w) == 1
+    assert sum("sample_goals" in str(x.message) for x in w) == 1 and env.env_goals is None
     env.close()
 
 
