@@ -12,7 +12,7 @@
 #pragma once
 // ------------------------------------------------------------------ experiment switches
 // The kernel sources carry compile-time switches of the form MZ_EXP_<NAME>: instrumentation (PROF, SWPROF, STAMPS, SUBTICK, SUBTICK2,
-// TRACE, RK4TICK) and TIMING EXPERIMENTS that switch parts of the physics off or reroute them (NOSECOND, NOSEARCH, NODETECT, NOFACEPATH,
+// TRACE, RK4TICK, GENPROF) and TIMING EXPERIMENTS that switch parts of the physics off or reroute them (NOSECOND, NOSEARCH, NODETECT, NOFACEPATH,
 // SPHEREONLY, NOCOLLISION, NOARROW, NONEWTON, NOWALL, ONECAND, NOREFINE, NOLAUNDER, BRANCHY, NOBLOCKCACHE, LCRELOAD, NOXCD — several of
 // them WRONG PHYSICS by design; tools/README.md).  None of them may reach the product library by accident: a translation unit
 // that sees any MZ_EXP_* macro without -DMZ_EXPERIMENTS does not compile, csrc/Makefile's default target refuses flags that carry
@@ -22,7 +22,7 @@
     defined(MZ_EXP_SPHEREONLY) || defined(MZ_EXP_NOCOLLISION) || defined(MZ_EXP_NOARROW) || defined(MZ_EXP_NONEWTON) || defined(MZ_EXP_NOWALL) || \
     defined(MZ_EXP_ONECAND) || defined(MZ_EXP_NOREFINE) || defined(MZ_EXP_NOLAUNDER) || defined(MZ_EXP_BRANCHY) || defined(MZ_EXP_NOBLOCKCACHE) || \
     defined(MZ_EXP_LCRELOAD) || defined(MZ_EXP_NOXCD) || defined(MZ_EXP_PROF) || defined(MZ_EXP_SWPROF) || defined(MZ_EXP_STAMPS) || \
-    defined(MZ_EXP_SUBTICK) || defined(MZ_EXP_SUBTICK2) || defined(MZ_EXP_TRACE) || defined(MZ_EXP_RK4TICK))
+    defined(MZ_EXP_SUBTICK) || defined(MZ_EXP_SUBTICK2) || defined(MZ_EXP_TRACE) || defined(MZ_EXP_RK4TICK) || defined(MZ_EXP_GENPROF))
 #error "MZ_EXP_* switches build instrumented / timing-experiment kernels (several with wrong physics): pass -DMZ_EXPERIMENTS with them, and never into libmazestep.so"
 #endif
 #include <math.h>

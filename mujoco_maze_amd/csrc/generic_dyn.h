@@ -24,6 +24,7 @@
 // One env per lane group; its working set (GenScratch) lives in LDS for the whole step.  Serial tree walks run on the group's
 // first lane, everything indexed by body / dof / geom / collision item / constraint row is an MZ_FOR over the lanes.
 #pragma once
+#include <stddef.h>
 #include "ant_dyn.h"    // MZ_FOR, MZ_HD, HostCtx, TaskDev / MazeDev, task_eval_dev
 #include "point_dyn.h"  // point_bounce: CollisionDetector.detect + the bounce rule, operation by operation (Point step shape)
 
@@ -59,6 +60,8 @@ struct GenDev {
   int max_iter, ls_iter;
   double tol, inv_scale;
   int dof_parent[GN_NV];
+  int limj[GN_NJ], nlimj;            // the limited hinge / slide joints (candidates of the limit rows)
+  int body_depth[GN_NB], max_depth;  // tree level of every body (world 0): the kinematic / RNE passes walk level by level, the bodies of a level side by side
   // the Point's manual wall bounce (maze_env.py:451-464): point_bounce reads these three names
   int nseg, obs_extra;
   double seg[MZ_MAX_SEG][4], restitution;
@@ -169,6 +172,16 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
         if (m->body_dofnum[a] > 0) { p = m->body_dofadr[a] + m->body_dofnum[a] - 1; break; }
     g->dof_parent[i] = p;
   }
+  g->nlimj = 0;
+  for (int j = 0; j < m->njnt; j++)
+    if (m->jnt_limited[j] && (m->jnt_type[j] == MZ_JNT_HINGE || m->jnt_type[j] == MZ_JNT_SLIDE)) g->limj[g->nlimj++] = j;
+  g->max_depth = 0;
+  g->body_depth[0] = 0;
+  for (int b = 1; b < m->nbody; b++) {  // (a parent's index is below its children's: mjcf.py / MuJoCo body order)
+    if (m->body_parent[b] >= b) return gen_fail(err, errlen, "general engine: bodies must be ordered parents first");
+    g->body_depth[b] = g->body_depth[m->body_parent[b]] + 1;
+    if (g->body_depth[b] > g->max_depth) g->max_depth = g->body_depth[b];
+  }
   g->max_iter = 100; g->ls_iter = 50; g->tol = 1e-10;
   g->inv_scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
   g->nseg = m->manual_collision ? m->nseg : 0;
@@ -181,7 +194,17 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
   return MZ_OK;
 }
 
+// The model's tree topology as the kernel walks it, staged in LDS once per step (gen_load_topology): every one of these small integers is
+// the head of a dependent chain (body -> parent -> joint -> dof ...), and from the constant block in global memory each link cost a
+// full L2 round trip on a lone wavefront.  int8: all counts are <= MZ_MAX_* = 24 (28 for qpos addresses); -1 = none.
+struct GenTopo {
+  int8_t body_parent[GN_NB], body_jntadr[GN_NB], body_jntnum[GN_NB], body_dofadr[GN_NB], body_dofnum[GN_NB], body_depth[GN_NB];
+  int8_t jnt_type[GN_NJ], jnt_dofadr[GN_NJ], jnt_qposadr[GN_NJ], jnt_bodyid[GN_NJ];
+  int8_t dof_bodyid[GN_NV], dof_parent[GN_NV];
+  int8_t geom_bodyid[GN_NG];
+};
 struct alignas(16) GenScratch {
+  GenTopo tp;
   double qpos[GN_NQ], qvel[GN_NV], warm[GN_NV], fact[GN_NV], x0q[GN_NQ], x0v[GN_NV], accv[GN_NV], accf[GN_NV], dxv[GN_NV];
   double qacc[GN_NV], qas[GN_NV], qfs[GN_NV], bias[GN_NV], passive[GN_NV];
   double xpos[GN_NB][3], xquat[GN_NB][4], xmat[GN_NB][9], xipos[GN_NB][3];
@@ -190,17 +213,56 @@ struct alignas(16) GenScratch {
   double gpos[GN_NG][3], gmat[GN_NG][9];
   double S[GN_NV][6], refpoint[3];
   double M[GN_NV][GN_NV], H[GN_NV][GN_NV];
-  // contacts: found by the items into a pool (arrival order), then the active ones compacted in the oracle's order
+  // contacts: found by the items into a pool (arrival order), then the active ones compacted in the oracle's order.  The pool is dead
+  // once compacted: the solver's per-contact iterates share its bytes
   int npool, ncon, nlim, status, iters, pad;
-  int pkey[GN_POOL];
-  double pdist[GN_POOL], ppos[GN_POOL][3], pnrm[GN_POOL][3], phint[GN_POOL][3];
+  union {
+    struct { int pkey[GN_POOL]; double pdist[GN_POOL], ppos[GN_POOL][3], pnrm[GN_POOL][3], phint[GN_POOL][3]; };
+    struct {
+      double cu[GN_NC][3], cjv[GN_NC][3];  // J qacc - aref and J search of the Newton iterate
+      double cg[GN_NC][3], cW[GN_NC][5];   // gradient and Hessian weights of the contact's pyramid there (gen_contact_eval)
+    };
+  };
   int citem[GN_NC];
   double cdist[GN_NC], cpos[GN_NC][3], cnrm[GN_NC][3], chint[GN_NC][3];
-  double cJ[GN_NC][3][GN_NV], caref[GN_NC][3], cD[GN_NC], cu[GN_NC][3], cjv[GN_NC][3];
-  int ldof[GN_NL];
+  double caref[GN_NC][3], cD[GN_NC];
+  int ldof[GN_NL], lflag[2 * GN_NJ];
   double lsign[GN_NL], lD[GN_NL], laref[GN_NL], ljar[GN_NL], ljv[GN_NL];
   double grad[GN_NV], search[GN_NV], Mx[GN_NV], Ms[GN_NV], red[8];
+  double ctmp[GN_NV], cdinv[GN_NV];  // gen_chol_solve: the column in flight, reciprocals of the factor's diagonal
+#ifdef MZ_EXP_GENPROF
+  unsigned long long prof[20], prof_t0;  // phase timers of the instrumented build (tools/exp_general_prof.sh)
+#endif
+  // LAST: the contacts' Jacobian rows [contact][normal, mu t1, mu t2] at a row stride of the MODEL's nv (gen_cj).  The step kernel
+  // allocates the block only as far as 3 nv GN_NC doubles of it (gen_scratch_bytes): 30 KB for a 20-dof model instead of 37 — what
+  // keeps two envs per CU up to 22 dofs (generic_kernels.hip)
+  double cJf[GN_NC * 3 * GN_NV];
 };
+MZ_HD size_t gen_scratch_bytes(int nv) { return (offsetof(GenScratch, cJf) + sizeof(double) * 3 * (size_t)nv * GN_NC + 15) / 16 * 16; }
+#if defined(MZ_EXP_GENPROF) && defined(__HIP_DEVICE_COMPILE__)
+#define GEN_TICK(id) do { if (cx.lane0() == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); s.prof[id] += now_ - s.prof_t0; s.prof_t0 = now_; } } while (0)
+#else
+#define GEN_TICK(id) do {} while (0)
+#endif
+
+MZ_HD double* gen_cj(GenScratch& s, int nv, int k, int a) { return s.cJf + (size_t)(3 * k + a) * nv; }
+MZ_HD const double* gen_cj(const GenScratch& s, int nv, int k, int a) { return s.cJf + (size_t)(3 * k + a) * nv; }
+
+template <class C>
+MZ_HD void gen_load_topology(const C& cx, const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  MZ_FOR(b, m.nbody) {
+    s.tp.body_parent[b] = (int8_t)m.body_parent[b]; s.tp.body_jntadr[b] = (int8_t)m.body_jntadr[b]; s.tp.body_jntnum[b] = (int8_t)m.body_jntnum[b];
+    s.tp.body_dofadr[b] = (int8_t)m.body_dofadr[b]; s.tp.body_dofnum[b] = (int8_t)m.body_dofnum[b]; s.tp.body_depth[b] = (int8_t)K.body_depth[b];
+  }
+  MZ_FOR(j, m.njnt) {
+    s.tp.jnt_type[j] = (int8_t)m.jnt_type[j]; s.tp.jnt_dofadr[j] = (int8_t)m.jnt_dofadr[j]; s.tp.jnt_qposadr[j] = (int8_t)m.jnt_qposadr[j];
+    s.tp.jnt_bodyid[j] = (int8_t)m.jnt_bodyid[j];
+  }
+  MZ_FOR(i, m.nv) { s.tp.dof_bodyid[i] = (int8_t)m.dof_bodyid[i]; s.tp.dof_parent[i] = (int8_t)K.dof_parent[i]; }
+  MZ_FOR(g, m.ngeom) s.tp.geom_bodyid[g] = (int8_t)m.geom_bodyid[g];
+  cx.sync();
+}
 
 // slot of the contact pool (LDS counter; a wavefront's arrival order is whatever it is — the compaction sorts by key)
 MZ_HD int gen_take(int* counter) {
@@ -277,68 +339,80 @@ MZ_HD double gd_impedance(const double* si, double x) {
   return d0 + y * (dmax - d0);
 }
 
-// ------------------------------------------------------------------ kinematics (serial: parents before children)
-MZ_HD void gen_kinematics(const GenDev& K, GenScratch& s) {
+// ------------------------------------------------------------------ kinematics (parents before children, level by level)
+// pose of body b from its parent's (mj_kinematics); the bodies of one tree level are independent of each other
+MZ_HD void gen_kin_body(const GenDev& K, GenScratch& s, int b) {
   const mz_model& m = K.m;
-  for (int k = 0; k < 3; k++) s.xpos[0][k] = 0.0;
-  s.xquat[0][0] = 1.0; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.0;
-  gd_quat2mat(s.xmat[0], s.xquat[0]);
-  for (int b = 1; b < m.nbody; b++) {
-    const int p = m.body_parent[b], j0 = m.body_jntadr[b], jn = m.body_jntnum[b];
-    double pos[3], quat[4];
-    if (jn == 1 && m.jnt_type[j0] == MZ_JNT_FREE) {
-      const int qa = m.jnt_qposadr[j0];
-      for (int k = 0; k < 3; k++) pos[k] = s.qpos[qa + k];
-      for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
-      gd_quat_norm(quat);
-      for (int k = 0; k < 3; k++) { s.xanchor[j0][k] = pos[k]; s.xaxis[j0][k] = m.jnt_axis[j0][k]; }
-    } else {
-      double t[3];
-      gd_mulmat(t, s.xmat[p], m.body_pos[b]);
-      for (int k = 0; k < 3; k++) pos[k] = s.xpos[p][k] + t[k];
-      gd_quat_mul(quat, s.xquat[p], m.body_quat[b]);
-      for (int j = j0; j < j0 + jn; j++) {
-        double mat[9], axis[3], anchor[3];
-        gd_quat2mat(mat, quat);
-        gd_mulmat(axis, mat, m.jnt_axis[j]);
-        gd_mulmat(anchor, mat, m.jnt_pos[j]);
-        for (int k = 0; k < 3; k++) anchor[k] += pos[k];
-        if (m.jnt_type[j] == MZ_JNT_SLIDE) {
-          const double q = s.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]];
-          for (int k = 0; k < 3; k++) pos[k] += axis[k] * q;
-        } else {  // hinge: rotate about the joint axis through the anchor; ball: the coordinates ARE the relative quaternion
-          double ql[4], qn[4], v[3];
-          if (m.jnt_type[j] == MZ_JNT_BALL) {
-            for (int k = 0; k < 4; k++) ql[k] = s.qpos[m.jnt_qposadr[j] + k];
-            gd_quat_norm(ql);
-          } else {
-            const double q = s.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]], sh = sin(0.5 * q);
-            ql[0] = cos(0.5 * q); ql[1] = m.jnt_axis[j][0] * sh; ql[2] = m.jnt_axis[j][1] * sh; ql[3] = m.jnt_axis[j][2] * sh;
-          }
-          gd_quat_mul(qn, quat, ql);
-          for (int k = 0; k < 4; k++) quat[k] = qn[k];
-          gd_quat2mat(mat, quat);
-          gd_mulmat(v, mat, m.jnt_pos[j]);
-          for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
-        }
-        for (int k = 0; k < 3; k++) { s.xaxis[j][k] = axis[k]; s.xanchor[j][k] = anchor[k]; }
-      }
-    }
+  const int p = s.tp.body_parent[b], j0 = s.tp.body_jntadr[b], jn = s.tp.body_jntnum[b];
+  double pos[3], quat[4];
+  if (jn == 1 && s.tp.jnt_type[j0] == MZ_JNT_FREE) {
+    const int qa = s.tp.jnt_qposadr[j0];
+    for (int k = 0; k < 3; k++) pos[k] = s.qpos[qa + k];
+    for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
     gd_quat_norm(quat);
-    for (int k = 0; k < 3; k++) s.xpos[b][k] = pos[k];
-    for (int k = 0; k < 4; k++) s.xquat[b][k] = quat[k];
-    gd_quat2mat(s.xmat[b], quat);
+    for (int k = 0; k < 3; k++) { s.xanchor[j0][k] = pos[k]; s.xaxis[j0][k] = m.jnt_axis[j0][k]; }
+  } else {
     double t[3];
-    gd_mulmat(t, s.xmat[b], m.body_ipos[b]);
-    for (int k = 0; k < 3; k++) s.xipos[b][k] = s.xpos[b][k] + t[k];
+    gd_mulmat(t, s.xmat[p], m.body_pos[b]);
+    for (int k = 0; k < 3; k++) pos[k] = s.xpos[p][k] + t[k];
+    gd_quat_mul(quat, s.xquat[p], m.body_quat[b]);
+    for (int j = j0; j < j0 + jn; j++) {
+      double mat[9], axis[3], anchor[3];
+      gd_quat2mat(mat, quat);
+      gd_mulmat(axis, mat, m.jnt_axis[j]);
+      gd_mulmat(anchor, mat, m.jnt_pos[j]);
+      for (int k = 0; k < 3; k++) anchor[k] += pos[k];
+      if (s.tp.jnt_type[j] == MZ_JNT_SLIDE) {
+        const double q = s.qpos[s.tp.jnt_qposadr[j]] - m.qpos0[s.tp.jnt_qposadr[j]];
+        for (int k = 0; k < 3; k++) pos[k] += axis[k] * q;
+      } else {  // hinge: rotate about the joint axis through the anchor; ball: the coordinates ARE the relative quaternion
+        double ql[4], qn[4], v[3];
+        if (s.tp.jnt_type[j] == MZ_JNT_BALL) {
+          for (int k = 0; k < 4; k++) ql[k] = s.qpos[s.tp.jnt_qposadr[j] + k];
+          gd_quat_norm(ql);
+        } else {
+          const double q = s.qpos[s.tp.jnt_qposadr[j]] - m.qpos0[s.tp.jnt_qposadr[j]], sh = sin(0.5 * q);
+          ql[0] = cos(0.5 * q); ql[1] = m.jnt_axis[j][0] * sh; ql[2] = m.jnt_axis[j][1] * sh; ql[3] = m.jnt_axis[j][2] * sh;
+        }
+        gd_quat_mul(qn, quat, ql);
+        for (int k = 0; k < 4; k++) quat[k] = qn[k];
+        gd_quat2mat(mat, quat);
+        gd_mulmat(v, mat, m.jnt_pos[j]);
+        for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
+      }
+      for (int k = 0; k < 3; k++) { s.xaxis[j][k] = axis[k]; s.xanchor[j][k] = anchor[k]; }
+    }
   }
-  for (int k = 0; k < 3; k++) s.refpoint[k] = s.xpos[1][k];
+  gd_quat_norm(quat);
+  for (int k = 0; k < 3; k++) s.xpos[b][k] = pos[k];
+  for (int k = 0; k < 4; k++) s.xquat[b][k] = quat[k];
+  gd_quat2mat(s.xmat[b], quat);
+  double t[3];
+  gd_mulmat(t, s.xmat[b], m.body_ipos[b]);
+  for (int k = 0; k < 3; k++) s.xipos[b][k] = s.xpos[b][k] + t[k];
+}
+// kinematics of the whole tree, level by level (GenDev::body_depth): ends behind a fence
+template <class C>
+MZ_HD void gen_kinematics(const C& cx, const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  MZ_FOR(one, 1) {
+    for (int k = 0; k < 3; k++) s.xpos[0][k] = 0.0;
+    s.xquat[0][0] = 1.0; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.0;
+    gd_quat2mat(s.xmat[0], s.xquat[0]);
+  }
+  for (int d = 1; d <= K.max_depth; d++) {
+    cx.sync();
+    MZ_FOR(b, m.nbody) if (s.tp.body_depth[b] == d) gen_kin_body(K, s, b);
+  }
+  cx.sync();
+  MZ_FOR(k, 3) s.refpoint[k] = s.xpos[1][k];
+  cx.sync();
 }
 
 // geom poses, motion axes, body spatial inertias about the reference point (one item per geom / joint / body)
 MZ_HD void gen_geom_item(const GenDev& K, GenScratch& s, int g) {
   const mz_model& m = K.m;
-  const int b = m.geom_bodyid[g];
+  const int b = s.tp.geom_bodyid[g];
   double t[3], q[4];
   gd_mulmat(t, s.xmat[b], m.geom_pos[g]);
   for (int k = 0; k < 3; k++) s.gpos[g][k] = s.xpos[b][k] + t[k];
@@ -347,15 +421,15 @@ MZ_HD void gen_geom_item(const GenDev& K, GenScratch& s, int g) {
 }
 MZ_HD void gen_axis_item(const GenDev& K, GenScratch& s, int j) {
   const mz_model& m = K.m;
-  const int b = m.jnt_bodyid[j], d0 = m.jnt_dofadr[j];
+  const int b = s.tp.jnt_bodyid[j], d0 = s.tp.jnt_dofadr[j];
   const double* c = s.refpoint;
   double off[3];
-  if (m.jnt_type[j] == MZ_JNT_FREE || m.jnt_type[j] == MZ_JNT_BALL) {
+  if (s.tp.jnt_type[j] == MZ_JNT_FREE || s.tp.jnt_type[j] == MZ_JNT_BALL) {
     // the rotational dofs are the angular velocity in the child frame: rotations about the body's own axes through the anchor
-    const int r0 = m.jnt_type[j] == MZ_JNT_FREE ? d0 + 3 : d0;
-    const double* anchor = m.jnt_type[j] == MZ_JNT_FREE ? s.xpos[b] : s.xanchor[j];
+    const int r0 = s.tp.jnt_type[j] == MZ_JNT_FREE ? d0 + 3 : d0;
+    const double* anchor = s.tp.jnt_type[j] == MZ_JNT_FREE ? s.xpos[b] : s.xanchor[j];
     for (int k = 0; k < 3; k++) {
-      if (m.jnt_type[j] == MZ_JNT_FREE) {
+      if (s.tp.jnt_type[j] == MZ_JNT_FREE) {
         for (int e = 0; e < 6; e++) s.S[d0 + k][e] = 0.0;
         s.S[d0 + k][3 + k] = 1.0;
       }
@@ -363,7 +437,7 @@ MZ_HD void gen_axis_item(const GenDev& K, GenScratch& s, int j) {
       for (int e = 0; e < 3; e++) { off[e] = c[e] - anchor[e]; s.S[r0 + k][e] = ax[e]; }
       gd_cross(s.S[r0 + k] + 3, ax, off);
     }
-  } else if (m.jnt_type[j] == MZ_JNT_SLIDE) {
+  } else if (s.tp.jnt_type[j] == MZ_JNT_SLIDE) {
     for (int e = 0; e < 3; e++) { s.S[d0][e] = 0.0; s.S[d0][3 + e] = s.xaxis[j][e]; }
   } else {
     for (int e = 0; e < 3; e++) { off[e] = c[e] - s.xanchor[j][e]; s.S[d0][e] = s.xaxis[j][e]; }
@@ -393,9 +467,9 @@ MZ_HD void gen_mass_item(const GenDev& K, GenScratch& s, int i) {
   const mz_model& m = K.m;
   double F[6];
   for (int j = 0; j < m.nv; j++) s.M[i][j] = 0.0;
-  gd_inertia_mul(F, s.crb[m.dof_bodyid[i]], s.S[i]);
+  gd_inertia_mul(F, s.crb[s.tp.dof_bodyid[i]], s.S[i]);
   s.M[i][i] = gd_dot6(s.S[i], F) + m.dof_armature[i];
-  for (int j = K.dof_parent[i]; j >= 0; j = K.dof_parent[j]) s.M[i][j] = gd_dot6(s.S[j], F);
+  for (int j = s.tp.dof_parent[i]; j >= 0; j = s.tp.dof_parent[j]) s.M[i][j] = gd_dot6(s.S[j], F);
 }
 
 // ------------------------------------------------------------------ narrow phase
@@ -818,36 +892,31 @@ MZ_HD void gen_compact_item(const GenDev& K, GenScratch& s, int e, int np) {
     const GenPair& Q = K.item[s.pkey[o] / GN_KEY].P;
     if (s.pdist[o] < Q.margin - Q.gap && (s.pkey[o] < s.pkey[e] || (s.pkey[o] == s.pkey[e] && o < e))) rank++;
   }
-  if (rank >= GN_NC) return;  // (counted by gen_limits_serial)
+  if (rank >= GN_NC) return;  // (counted by gen_forward)
   s.citem[rank] = s.pkey[e] / GN_KEY; s.cdist[rank] = s.pdist[e];
   for (int k = 0; k < 3; k++) { s.cpos[rank][k] = s.ppos[e][k]; s.cnrm[rank][k] = s.pnrm[e][k]; s.chint[rank][k] = s.phint[e][k]; }
 }
 
-// contact count and the joint-limit rows (hinge / slide), serial
-MZ_HD void gen_limits_serial(const GenDev& K, GenScratch& s) {
+// joint-limit rows (hinge / slide): candidate e = (limited joint e / 2, lower | upper side).  gen_limit_flag marks the active ones; after a
+// fence gen_limit_row fills the row at its rank among them — the serial loop's order (joint by joint, lower side first)
+MZ_HD void gen_limit_flag(const GenDev& K, GenScratch& s, int e) {
   const mz_model& m = K.m;
-  int np = s.npool, c = 0;
-  if (np > GN_POOL) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; np = GN_POOL; }
-  for (int e = 0; e < np; e++) { const GenPair& P = K.item[s.pkey[e] / GN_KEY].P; if (s.pdist[e] < P.margin - P.gap) c++; }
-  if (c > GN_NC) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; c = GN_NC; }
-  s.ncon = c;
+  const int j = K.limj[e >> 1];
+  const double q = s.qpos[s.tp.jnt_qposadr[j]], dist = (e & 1) ? m.jnt_range[j][1] - q : q - m.jnt_range[j][0];
+  s.lflag[e] = dist < m.jnt_margin[j] ? 1 : 0;
+}
+MZ_HD void gen_limit_row(const GenDev& K, GenScratch& s, int e) {
+  const mz_model& m = K.m;
+  if (!s.lflag[e]) return;
   int nl = 0;
-  for (int j = 0; j < m.njnt; j++) {
-    if (!m.jnt_limited[j] || (m.jnt_type[j] != MZ_JNT_HINGE && m.jnt_type[j] != MZ_JNT_SLIDE)) continue;
-    const double q = s.qpos[m.jnt_qposadr[j]];
-    for (int side = -1; side <= 1; side += 2) {
-      const double dist = side < 0 ? q - m.jnt_range[j][0] : m.jnt_range[j][1] - q;
-      if (!(dist < m.jnt_margin[j])) continue;
-      if (nl >= GN_NL) { s.status |= MZ_STATUS_CONTACT_OVERFLOW; continue; }  // a dropped constraint row is never silent
-      const int dof = m.jnt_dofadr[j];
-      const double imp = gd_impedance(m.jnt_solimp[j], fabs(dist - m.jnt_margin[j]));
-      const double R = fmax(1e-15, (1.0 - imp) * m.dof_invweight0[dof] / imp), sg = -(double)side;
-      s.ldof[nl] = dof; s.lsign[nl] = sg; s.lD[nl] = 1.0 / R;
-      s.laref[nl] = -K.lim_B[j] * (sg * s.qvel[dof]) - K.lim_K[j] * imp * (dist - m.jnt_margin[j]);
-      nl++;
-    }
-  }
-  s.nlim = nl;
+  for (int o = 0; o < e; o++) nl += s.lflag[o];
+  if (nl >= GN_NL) return;  // (counted by gen_forward: a dropped constraint row is never silent)
+  const int j = K.limj[e >> 1], dof = s.tp.jnt_dofadr[j];
+  const double q = s.qpos[s.tp.jnt_qposadr[j]], dist = (e & 1) ? m.jnt_range[j][1] - q : q - m.jnt_range[j][0];
+  const double imp = gd_impedance(m.jnt_solimp[j], fabs(dist - m.jnt_margin[j]));
+  const double R = fmax(1e-15, (1.0 - imp) * m.dof_invweight0[dof] / imp), sg = (e & 1) ? -1.0 : 1.0;
+  s.ldof[nl] = dof; s.lsign[nl] = sg; s.lD[nl] = 1.0 / R;
+  s.laref[nl] = -K.lim_B[j] * (sg * s.qvel[dof]) - K.lim_K[j] * imp * (dist - m.jnt_margin[j]);
 }
 
 // one item per (contact, frame axis): the contact frame, the Jacobian row J(body2) - J(body1), the reference acceleration
@@ -876,20 +945,21 @@ MZ_HD void gen_contact_row_item(const GenDev& K, GenScratch& s, int item) {
   }
   const double* dir = a == 0 ? n : (a == 1 ? t1 : t2);
   const double sc = a == 0 ? 1.0 : P.mu;
-  double off[3], J[GN_NV];
+  double off[3];
+  double* J = gen_cj(s, m.nv, c, a);  // (built in place: a local array indexed by a run-time dof would live in scratch memory)
   for (int k = 0; k < 3; k++) off[k] = s.cpos[c][k] - s.refpoint[k];
   for (int i = 0; i < m.nv; i++) J[i] = 0.0;
   for (int side = 0; side < 2; side++) {  // the contact force acts on geom2's body (+) and reacts on geom1's (-)
     const double sgn = side ? 1.0 : -1.0;
-    for (int b = side ? I.b2 : I.b1; b > 0; b = m.body_parent[b])
-      for (int i = m.body_dofadr[b]; i >= 0 && i < m.body_dofadr[b] + m.body_dofnum[b]; i++) {
+    for (int b = side ? I.b2 : I.b1; b > 0; b = s.tp.body_parent[b])
+      for (int i = s.tp.body_dofadr[b]; i >= 0 && i < s.tp.body_dofadr[b] + s.tp.body_dofnum[b]; i++) {
         double wx[3];
         gd_cross(wx, s.S[i], off);
         J[i] += sgn * sc * ((s.S[i][3] + wx[0]) * dir[0] + (s.S[i][4] + wx[1]) * dir[1] + (s.S[i][5] + wx[2]) * dir[2]);
       }
   }
   double vel = 0.0;
-  for (int i = 0; i < m.nv; i++) { s.cJ[c][a][i] = J[i]; vel += J[i] * s.qvel[i]; }
+  for (int i = 0; i < m.nv; i++) vel += J[i] * s.qvel[i];
   double aref = -P.B * vel;
   if (a == 0) {
     const double imp = gd_impedance(P.solimp, fabs(s.cdist[c] - (P.margin - P.gap)));
@@ -935,45 +1005,60 @@ MZ_HD void gen_rows_slope(double D, const double* u, const double* v, double alp
 }
 
 // ------------------------------------------------------------------ velocities, bias (RNE), passive (damping + fluid), actuation
-MZ_HD void gen_rne_serial(const GenDev& K, GenScratch& s) {
+// velocity, acceleration and inertial + velocity-product force of body b from its parent's (mj_comVel / mj_rne forward pass)
+MZ_HD void gen_rne_body(const GenDev& K, GenScratch& s, int b) {
   const mz_model& m = K.m;
-  for (int e = 0; e < 6; e++) { s.cvel[0][e] = 0.0; s.cacc[0][e] = 0.0; }
-  s.cacc[0][3] = -m.gravity[0]; s.cacc[0][4] = -m.gravity[1]; s.cacc[0][5] = -m.gravity[2];
-  for (int b = 1; b < m.nbody; b++) {
-    const int p = m.body_parent[b], j0 = m.body_jntadr[b];
-    double v[6], a[6];
-    for (int e = 0; e < 6; e++) { v[e] = s.cvel[p][e]; a[e] = s.cacc[p][e]; }
-    for (int j = j0; j < j0 + m.body_jntnum[b]; j++) {
-      const int d0 = m.jnt_dofadr[j];
-      if (m.jnt_type[j] == MZ_JNT_FREE || m.jnt_type[j] == MZ_JNT_BALL) {
-        // mj_comVel: the free joint's translations first (world-fixed axes: no derivative); then all three rotation-axis
-        // derivatives from the velocity in front of them, then the rotations' own velocity
-        int r0 = d0;
-        if (m.jnt_type[j] == MZ_JNT_FREE) {
-          for (int k = 0; k < 3; k++)
-            for (int e = 0; e < 6; e++) v[e] += s.S[d0 + k][e] * s.qvel[d0 + k];
-          r0 = d0 + 3;
-        }
-        double sd[3][6];
-        for (int k = 0; k < 3; k++) gd_motion_cross(sd[k], v, s.S[r0 + k]);
+  const int p = s.tp.body_parent[b], j0 = s.tp.body_jntadr[b];
+  double v[6], a[6];
+  for (int e = 0; e < 6; e++) { v[e] = s.cvel[p][e]; a[e] = s.cacc[p][e]; }
+  for (int j = j0; j < j0 + s.tp.body_jntnum[b]; j++) {
+    const int d0 = s.tp.jnt_dofadr[j];
+    if (s.tp.jnt_type[j] == MZ_JNT_FREE || s.tp.jnt_type[j] == MZ_JNT_BALL) {
+      // mj_comVel: the free joint's translations first (world-fixed axes: no derivative); then all three rotation-axis
+      // derivatives from the velocity in front of them, then the rotations' own velocity
+      int r0 = d0;
+      if (s.tp.jnt_type[j] == MZ_JNT_FREE) {
         for (int k = 0; k < 3; k++)
-          for (int e = 0; e < 6; e++) { a[e] += sd[k][e] * s.qvel[r0 + k]; v[e] += s.S[r0 + k][e] * s.qvel[r0 + k]; }
-      } else {
-        double sd[6];
-        gd_motion_cross(sd, v, s.S[d0]);
-        for (int e = 0; e < 6; e++) { a[e] += sd[e] * s.qvel[d0]; v[e] += s.S[d0][e] * s.qvel[d0]; }
+          for (int e = 0; e < 6; e++) v[e] += s.S[d0 + k][e] * s.qvel[d0 + k];
+        r0 = d0 + 3;
       }
+      double sd[3][6];
+      for (int k = 0; k < 3; k++) gd_motion_cross(sd[k], v, s.S[r0 + k]);
+      for (int k = 0; k < 3; k++)
+        for (int e = 0; e < 6; e++) { a[e] += sd[k][e] * s.qvel[r0 + k]; v[e] += s.S[r0 + k][e] * s.qvel[r0 + k]; }
+    } else {
+      double sd[6];
+      gd_motion_cross(sd, v, s.S[d0]);
+      for (int e = 0; e < 6; e++) { a[e] += sd[e] * s.qvel[d0]; v[e] += s.S[d0][e] * s.qvel[d0]; }
     }
-    double Ia[6], Iv[6], vf[6];
-    gd_inertia_mul(Ia, s.cinert[b], a);
-    gd_inertia_mul(Iv, s.cinert[b], v);
-    gd_force_cross(vf, v, Iv);
-    for (int e = 0; e < 6; e++) { s.cvel[b][e] = v[e]; s.cacc[b][e] = a[e]; s.cfrc[b][e] = Ia[e] + vf[e]; }
   }
-  for (int b = m.nbody - 1; b >= 1; b--) {
-    const int p = m.body_parent[b];
-    if (p > 0) for (int e = 0; e < 6; e++) s.cfrc[p][e] += s.cfrc[b][e];
+  double Ia[6], Iv[6], vf[6];
+  gd_inertia_mul(Ia, s.cinert[b], a);
+  gd_inertia_mul(Iv, s.cinert[b], v);
+  gd_force_cross(vf, v, Iv);
+  for (int e = 0; e < 6; e++) { s.cvel[b][e] = v[e]; s.cacc[b][e] = a[e]; s.cfrc[b][e] = Ia[e] + vf[e]; }
+}
+// The two tree passes of an evaluation, level by level (the bodies of a level side by side; round 6 — on one lane they were 15 % of an
+// Ant env-step): down — velocities / accelerations / body forces (RNE forward); up — composite inertias (CRB) and subtree forces (RNE
+// backward), parent by parent over its children in the serial loop's order (highest index first), so the sums are the same numbers.
+template <class C>
+MZ_HD void gen_tree_passes(const C& cx, const GenDev& K, GenScratch& s) {
+  const mz_model& m = K.m;
+  MZ_FOR(e, 6) { s.cvel[0][e] = 0.0; s.cacc[0][e] = e >= 3 ? -m.gravity[e - 3] : 0.0; }
+  for (int d = 1; d <= K.max_depth; d++) {
+    cx.sync();
+    MZ_FOR(b, m.nbody) if (s.tp.body_depth[b] == d) gen_rne_body(K, s, b);
   }
+  for (int d = K.max_depth - 1; d >= 1; d--) {
+    cx.sync();
+    MZ_FOR(p, m.nbody) if (s.tp.body_depth[p] == d)
+      for (int c = m.nbody - 1; c > p; c--)
+        if (s.tp.body_parent[c] == p) {
+          for (int k = 0; k < 10; k++) s.crb[p][k] += s.crb[c][k];
+          for (int e = 0; e < 6; e++) s.cfrc[p][e] += s.cfrc[c][e];
+        }
+  }
+  cx.sync();
 }
 // MuJoCo's inertia-box fluid model (option density / viscosity; swimmer.xml:3): wrench of body b about the reference point
 MZ_HD void gen_fluid_item(const GenDev& K, GenScratch& s, int b) {
@@ -1020,12 +1105,12 @@ MZ_HD void gen_fluid_item(const GenDev& K, GenScratch& s, int b) {
 }
 MZ_HD void gen_force_item(const GenDev& K, GenScratch& s, int i) {
   const mz_model& m = K.m;
-  const double bias = gd_dot6(s.S[i], s.cfrc[m.dof_bodyid[i]]);
+  const double bias = gd_dot6(s.S[i], s.cfrc[s.tp.dof_bodyid[i]]);
   double pas = -m.dof_damping[i] * s.qvel[i];
   if (m.density > 0.0 || m.viscosity > 0.0)
     for (int b = 1; b < m.nbody; b++) {  // dof i moves body b iff body(i) is b or an ancestor of b
       bool hit = false;
-      for (int a = b; a > 0; a = m.body_parent[a]) if (a == m.dof_bodyid[i]) { hit = true; break; }
+      for (int a = b; a > 0; a = s.tp.body_parent[a]) if (a == s.tp.dof_bodyid[i]) { hit = true; break; }
       if (hit) pas += gd_dot6(s.S[i], s.ffl[b]);
     }
   s.bias[i] = bias; s.passive[i] = pas;
@@ -1033,20 +1118,94 @@ MZ_HD void gen_force_item(const GenDev& K, GenScratch& s, int i) {
 }
 
 // dense Cholesky + solve on one lane (A = L L^T in the lower triangle of H)
-MZ_HD bool gen_chol_solve(double (*A)[GN_NV], int n, double* x) {
-  for (int j = 0; j < n; j++) {
-    double d = A[j][j];
-    for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
-    if (d < 1e-15) return false;
-    A[j][j] = sqrt(d);
-    for (int i = j + 1; i < n; i++) {
-      double t = A[i][j];
-      for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
-      A[i][j] = t / A[j][j];
+// Cholesky factorisation and solve of the n x n system A x = b (A: M for qacc_smooth, M + J^T W J for the Newton direction), spread
+// over the wavefront: lane i owns row i, and the right-hand side rides along as row n of the augmented matrix [A; b^T] — its "factor
+// row" IS the forward substitution L y = b, at no extra step.  Column j needs only the finished columns k < j: every lane forms its own
+// t_i = A[i][j] - sum_k L[i][k] L[j][k] at once (left-looking), the pivot goes round through LDS, one reciprocal square root per
+// column and no division; the back substitution L^T x = y runs column by column the same way.  (Round 6: on ONE lane — n^3 / 6
+// dependent LDS round trips — this was 63-71 % of an Ant env-step on the general engine: profiles/r06/general_engine_phases.txt.)
+// In: Asrc (lower triangle; may be A itself), x = b.  Out: x = Asrc^-1 b; A holds the factor, s.cdinv the reciprocals of its diagonal.
+// False: not positive definite (A and x are garbage then).  Called by every lane of the group; ends behind a fence.
+template <class C>
+MZ_HD bool gen_chol_solve(const C& cx, GenScratch& s, const double (*Asrc)[GN_NV], double (*A)[GN_NV], int n, double* x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (C::nlanes == 64) {
+    // On the device the rows live in REGISTERS (lane l: row l; lane n: the right-hand side), the loops over columns are unrolled to
+    // GN_NV with uniform guards, and a pivot row's entries come by v_readlane — no LDS round trip inside the factorisation (each one
+    // is ~150 cycles for a lone wavefront; the LDS form below, kept for the one-lane host build, measured 28 k cycles per solve of
+    // a 14 x 14 system).  L^T x = y needs COLUMN l of the factor in lane l: the rows cross LDS once, y with them.
+    const int l = cx.l;
+    const bool isrow = l < n;
+    double r[GN_NV];
+#pragma unroll
+    for (int k = 0; k < GN_NV; k++) r[k] = (k < n && (isrow ? k <= l : l == n)) ? (isrow ? Asrc[l][k] : x[k]) : 0.0;
+    bool ok = true;
+    double dinv = 0.0;
+#pragma unroll
+    for (int j = 0; j < GN_NV; j++) {
+      if (j < n) {
+        double t = r[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) t -= r[k] * C::readlaned(r[k], j);
+        const double d = C::readlaned(t, j);
+        ok = ok && d >= 1e-15;
+        const double inv = rsqrt(d);
+        r[j] = l == j ? d * inv : (l > j ? t * inv : 0.0);
+        if (l == j) dinv = inv;
+      }
     }
+    if (!ok) return false;  // (uniform: every lane saw the same pivots)
+    cx.sync();              // (every lane has read its row of Asrc)
+#pragma unroll
+    for (int k = 0; k < GN_NV; k++) if (k < n) { if (isrow && k <= l) A[l][k] = r[k]; else if (l == n) x[k] = r[k]; }
+    cx.sync();
+    double y = isrow ? x[l] : 0.0;
+#pragma unroll
+    for (int k = 0; k < GN_NV; k++) r[k] = (isrow && k < n && k > l) ? A[k][l] : 0.0;  // column l of the factor below the diagonal
+#pragma unroll
+    for (int j = GN_NV - 1; j >= 0; j--) {
+      if (j < n) {
+        const double xj = C::readlaned(y * dinv, j);
+        y = l == j ? xj : y - r[j] * xj;
+      }
+    }
+    cx.sync();  // (every lane has read y)
+    if (isrow) { x[l] = y; s.cdinv[l] = dinv; }
+    cx.sync();
+    return true;
   }
-  for (int i = 0; i < n; i++) { double t = x[i]; for (int k = 0; k < i; k++) t -= A[i][k] * x[k]; x[i] = t / A[i][i]; }
-  for (int i = n - 1; i >= 0; i--) { double t = x[i]; for (int k = i + 1; k < n; k++) t -= A[k][i] * x[k]; x[i] = t / A[i][i]; }
+#endif
+  if (Asrc != A) { MZ_FOR(e, n * n) { const int i = e / n, j = e - n * i; if (j <= i) A[i][j] = Asrc[i][j]; } cx.sync(); }
+  for (int j = 0; j < n; j++) {
+    MZ_FOR(i, n + 1) if (i >= j) {
+      const double* Ai = i < n ? A[i] : x;  // (row n: the right-hand side)
+      const double* Aj = A[j];
+      double t0 = Ai[j], t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four partial sums: the loads of a group of four are in flight together
+      int k = 0;
+      for (; k + 4 <= j; k += 4) { t0 -= Ai[k] * Aj[k]; t1 -= Ai[k + 1] * Aj[k + 1]; t2 -= Ai[k + 2] * Aj[k + 2]; t3 -= Ai[k + 3] * Aj[k + 3]; }
+      for (; k < j; k++) t0 -= Ai[k] * Aj[k];
+      s.ctmp[i] = (t0 + t1) + (t2 + t3);
+    }
+    cx.sync();
+    const double d = s.ctmp[j];
+    if (!(d >= 1e-15)) return false;  // (every lane reads the same pivot: a uniform exit)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double inv = rsqrt(d);
+#else
+    const double inv = 1.0 / sqrt(d);
+#endif
+    MZ_FOR(i, n + 1) if (i >= j) {
+      if (i < n) A[i][j] = i == j ? d * inv : s.ctmp[i] * inv; else x[j] = s.ctmp[i] * inv;  // (x[j] <- y_j: entries k > j of b are still to come)
+      if (i == j) s.cdinv[j] = inv;
+    }
+    cx.sync();
+  }
+  for (int j = n - 1; j >= 0; j--) {  // L^T x = y
+    const double xj = x[j] * s.cdinv[j];
+    cx.sync();  // (everybody has read x[j] before its owner overwrites it)
+    MZ_FOR(i, n) { if (i == j) x[i] = xj; else if (i < j) x[i] -= A[j][i] * xj; }
+    cx.sync();
+  }
   return true;
 }
 
@@ -1060,7 +1219,7 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
     MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * (x[j] - s.qas[j]); c += 0.5 * t * (x[i] - s.qas[i]); }
     MZ_FOR(k, ncon) {
       double u[3];
-      for (int a = 0; a < 3; a++) { double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += s.cJ[k][a][i] * x[i]; u[a] = t; }
+      for (int a = 0; a < 3; a++) { const double* Jr = gen_cj(s, nv, k, a); double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += Jr[i] * x[i]; u[a] = t; }
       c += gen_contact_eval(s.cD[k], u, nullptr, nullptr);
     }
     MZ_FOR(l, nlim) { const double jar = s.lsign[l] * x[s.ldof[l]] - s.laref[l]; if (jar < 0.0) c += 0.5 * s.lD[l] * jar * jar; }
@@ -1074,42 +1233,52 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
   bool done = false;
   int it = 0;
   double prev_cost = cw < cs ? cw : cs;
+  GEN_TICK(7);
   while (!done && it < K.max_iter) {
     MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * (s.qacc[j] - s.qas[j]); s.Mx[i] = t; }
-    MZ_FOR(e, 3 * ncon) { const int k = e / 3, a = e - 3 * k; double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += s.cJ[k][a][i] * s.qacc[i]; s.cu[k][a] = t; }
+    MZ_FOR(k, ncon) {  // a contact's three residuals, and from them its gradient and Hessian weights — once, not once per entry that uses them
+      double u[3];
+      for (int a = 0; a < 3; a++) { const double* Jr = gen_cj(s, nv, k, a); double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += Jr[i] * s.qacc[i]; u[a] = t; s.cu[k][a] = t; }
+      gen_contact_eval(s.cD[k], u, s.cg[k], s.cW[k]);
+    }
     MZ_FOR(l, nlim) s.ljar[l] = s.lsign[l] * s.qacc[s.ldof[l]] - s.laref[l];
     cx.sync();
+    GEN_TICK(8);
     double gpart = 0.0;
     MZ_FOR(i, nv) {
       double g = s.Mx[i];
-      for (int k = 0; k < ncon; k++) { double g3[3]; gen_contact_eval(s.cD[k], s.cu[k], g3, nullptr); g += s.cJ[k][0][i] * g3[0] + s.cJ[k][1][i] * g3[1] + s.cJ[k][2][i] * g3[2]; }
+      for (int k = 0; k < ncon; k++) { const double* Jk = gen_cj(s, nv, k, 0); g += Jk[i] * s.cg[k][0] + Jk[nv + i] * s.cg[k][1] + Jk[2 * nv + i] * s.cg[k][2]; }
       for (int l = 0; l < nlim; l++) if (s.ldof[l] == i && s.ljar[l] < 0.0) g += s.lsign[l] * s.lD[l] * s.ljar[l];
       s.grad[i] = g; gpart += g * g;
     }
     const double gn = sqrt(cx.gsum(gpart));
+    GEN_TICK(9);
     if (K.inv_scale * gn < K.tol) break;
-    MZ_FOR(e, nv * nv) {
-      const int i = e / nv, j = e - nv * i;
+    // H = M + J^T W J: the lower triangle only (all the factorisation reads).  Rows r and nv - 1 - r together hold nv + 1 entries:
+    // (nv + 1) * ceil(nv / 2) items cover the triangle (nv odd: the middle row twice, same values)
+    MZ_FOR(e, (nv + 1) * ((nv + 1) / 2)) {
+      const int r = e / (nv + 1), c = e - (nv + 1) * r;
+      const int i = c <= r ? r : nv - 1 - r, j = c <= r ? c : c - r - 1;
       double acc = s.M[i][j];
       for (int k = 0; k < ncon; k++) {
-        double W[5];
-        gen_contact_eval(s.cD[k], s.cu[k], nullptr, W);
-        const double ni = s.cJ[k][0][i], pi = s.cJ[k][1][i], qi = s.cJ[k][2][i], nj = s.cJ[k][0][j], pj = s.cJ[k][1][j], qj = s.cJ[k][2][j];
+        const double* W = s.cW[k];
+        const double* Jk = gen_cj(s, nv, k, 0);
+        const double ni = Jk[i], pi = Jk[nv + i], qi = Jk[2 * nv + i], nj = Jk[j], pj = Jk[nv + j], qj = Jk[2 * nv + j];
         acc += W[0] * ni * nj + W[1] * (ni * pj + pi * nj) + W[2] * (ni * qj + qi * nj) + W[3] * pi * pj + W[4] * qi * qj;
       }
       if (i == j) for (int l = 0; l < nlim; l++) if (s.ldof[l] == i && s.ljar[l] < 0.0) acc += s.lD[l];
       s.H[i][j] = acc;
     }
     cx.sync();
-    MZ_FOR(one, 1) {
-      for (int i = 0; i < nv; i++) s.search[i] = -s.grad[i];
-      if (!gen_chol_solve(s.H, nv, s.search)) { s.status |= MZ_STATUS_BAD_STATE; s.red[0] = 1.0; } else s.red[0] = 0.0;
-    }
+    GEN_TICK(10);
+    MZ_FOR(i, nv) s.search[i] = -s.grad[i];
     cx.sync();
-    if (s.red[0] != 0.0) break;
+    const bool posdef = gen_chol_solve(cx, s, s.H, s.H, nv, s.search);
+    GEN_TICK(11);
+    if (!posdef) { MZ_FOR(one, 1) s.status |= MZ_STATUS_BAD_STATE; break; }
     // line search on phi(alpha) = cost(qacc + alpha search): unit step when no row changes state, else safeguarded Newton on phi'
     MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * s.search[j]; s.Ms[i] = t; }
-    MZ_FOR(e, 3 * ncon) { const int k = e / 3, a = e - 3 * k; double t = 0.0; for (int i = 0; i < nv; i++) t += s.cJ[k][a][i] * s.search[i]; s.cjv[k][a] = t; }
+    MZ_FOR(e, 3 * ncon) { const double* Jr = s.cJf + (size_t)e * nv; double t = 0.0; for (int i = 0; i < nv; i++) t += Jr[i] * s.search[i]; s.cjv[e / 3][e % 3] = t; }
     MZ_FOR(l, nlim) s.ljv[l] = s.lsign[l] * s.search[s.ldof[l]];
     cx.sync();
     bool changed = false;
@@ -1139,12 +1308,14 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
       }
     }
     cx.sync();
+    GEN_TICK(12);
     if (!(alpha > 0.0)) break;
     MZ_FOR(i, nv) s.qacc[i] += alpha * s.search[i];
     cx.sync();
     it++;
     if (!changed) break;  // the unit Newton step stayed inside one active set: exact minimiser
     const double cnow = cost_at(s.qacc);
+    GEN_TICK(13);
     if (!(K.inv_scale * (prev_cost - cnow) > 0.0)) break;  // round-off floor
     prev_cost = cnow;
     if (it >= K.max_iter) { MZ_FOR(one, 1) s.status |= MZ_STATUS_SOLVER_MAXITER; }
@@ -1157,42 +1328,60 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
 template <class C>
 MZ_HD void gen_forward(const C& cx, const GenDev& K, GenScratch& s) {
   const mz_model& m = K.m;
-  MZ_FOR(one, 1) { gen_kinematics(K, s); s.npool = 0; }
-  cx.sync();
+  GEN_TICK(15);
+  MZ_FOR(one, 1) s.npool = 0;
+  gen_kinematics(cx, K, s);
+  GEN_TICK(0);
   MZ_FOR(g, m.ngeom) gen_geom_item(K, s, g);
   MZ_FOR(j, m.njnt) gen_axis_item(K, s, j);
   MZ_FOR(b, m.nbody) if (b > 0) gen_inertia_item(K, s, b);
   cx.sync();
+  GEN_TICK(1);
   MZ_FOR(it, K.nitem) gen_collide_item(K, s, it);
-  MZ_FOR(one, 1) {
-    for (int b = m.nbody - 1; b >= 1; b--) { const int p = m.body_parent[b]; if (p > 0) for (int k = 0; k < 10; k++) s.crb[p][k] += s.crb[b][k]; }
-    gen_rne_serial(K, s);
-  }
-  cx.sync();
+  GEN_TICK(2);
+  gen_tree_passes(cx, K, s);
+  GEN_TICK(3);
   MZ_FOR(i, m.nv) gen_mass_item(K, s, i);
   MZ_FOR(b, m.nbody) gen_fluid_item(K, s, b);
-  { const int np = s.npool < GN_POOL ? s.npool : GN_POOL; MZ_FOR(e, np) gen_compact_item(K, s, e, np); }
-  MZ_FOR(one, 1) gen_limits_serial(K, s);
+  {
+    const int np = s.npool < GN_POOL ? s.npool : GN_POOL;
+    double cnt = 0.0, lcnt = 0.0;
+    MZ_FOR(e, np) { const GenPair& P = K.item[s.pkey[e] / GN_KEY].P; if (s.pdist[e] < P.margin - P.gap) cnt += 1.0; gen_compact_item(K, s, e, np); }
+    MZ_FOR(e, 2 * K.nlimj) { gen_limit_flag(K, s, e); lcnt += (double)s.lflag[e]; }
+    const int c = (int)cx.gsum(cnt), nl = (int)cx.gsum(lcnt);
+    cx.sync();  // (the flags are visible)
+    MZ_FOR(e, 2 * K.nlimj) gen_limit_row(K, s, e);
+    MZ_FOR(one, 1) {
+      if (s.npool > GN_POOL || c > GN_NC || nl > GN_NL) s.status |= MZ_STATUS_CONTACT_OVERFLOW;
+      s.ncon = c < GN_NC ? c : GN_NC;
+      s.nlim = nl < GN_NL ? nl : GN_NL;
+    }
+  }
   cx.sync();
+  GEN_TICK(4);
   MZ_FOR(i, m.nv) gen_force_item(K, s, i);
   MZ_FOR(e, m.nv * m.nv) { const int i = e / m.nv, j = e - m.nv * i; if (i < j) s.M[i][j] = s.M[j][i]; }  // gen_mass_item wrote the lower triangle
   MZ_FOR(item, 3 * s.ncon) gen_contact_row_item(K, s, item);
   cx.sync();
-  MZ_FOR(one, 1) {  // qacc_smooth = M^-1 qfrc_smooth (H is free until the solver assembles the Hessian)
-    for (int i = 0; i < m.nv; i++) { for (int j = 0; j <= i; j++) s.H[i][j] = s.M[i][j]; s.qas[i] = s.qfs[i]; }
-    if (!gen_chol_solve(s.H, m.nv, s.qas)) s.status |= MZ_STATUS_BAD_STATE;
-  }
+  GEN_TICK(5);
+  // qacc_smooth = M^-1 qfrc_smooth (H is free until the solver assembles the Hessian)
+  MZ_FOR(i, m.nv) s.qas[i] = s.qfs[i];
   cx.sync();
+  if (!gen_chol_solve(cx, s, s.M, s.H, m.nv, s.qas)) { MZ_FOR(one, 1) s.status |= MZ_STATUS_BAD_STATE; }
+  cx.sync();
+  GEN_TICK(6);
   gen_solve(cx, K, s);
+  GEN_TICK(14);
 }
 
-MZ_HD void gen_integrate_pos(const GenDev& K, GenScratch& s, const double* base, const double* vel, double h) {  // serial (one lane)
+// mj_integratePos of joint j (the joints are independent of each other: one lane each)
+MZ_HD void gen_integrate_joint(const GenDev& K, GenScratch& s, const double* base, const double* vel, double h, int j) {
   const mz_model& m = K.m;
-  for (int j = 0; j < m.njnt; j++) {
-    const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-    if (m.jnt_type[j] == MZ_JNT_FREE || m.jnt_type[j] == MZ_JNT_BALL) {  // mj_integratePos: q <- q * exp(h w / 2), w in the child frame
+  {
+    const int qa = s.tp.jnt_qposadr[j], da = s.tp.jnt_dofadr[j];
+    if (s.tp.jnt_type[j] == MZ_JNT_FREE || s.tp.jnt_type[j] == MZ_JNT_BALL) {  // mj_integratePos: q <- q * exp(h w / 2), w in the child frame
       int qq = qa, dw = da;
-      if (m.jnt_type[j] == MZ_JNT_FREE) {
+      if (s.tp.jnt_type[j] == MZ_JNT_FREE) {
         for (int k = 0; k < 3; k++) s.qpos[qa + k] = base[qa + k] + h * vel[da + k];
         qq = qa + 3; dw = da + 3;
       }
@@ -1230,12 +1419,12 @@ MZ_HD void gen_mj_step(const C& cx, const GenDev& K, GenScratch& s) {
     }
     cx.sync();
     if (st < 3) {
-      MZ_FOR(one, 1) gen_integrate_pos(K, s, s.x0q, s.dxv, h);
+      MZ_FOR(j, m.njnt) gen_integrate_joint(K, s, s.x0q, s.dxv, h, j);
       MZ_FOR(i, m.nv) s.qvel[i] = s.Mx[i];
       cx.sync();
     }
   }
-  MZ_FOR(one, 1) gen_integrate_pos(K, s, s.x0q, s.accv, h);
+  MZ_FOR(j, m.njnt) gen_integrate_joint(K, s, s.x0q, s.accv, h, j);
   MZ_FOR(i, m.nv) { s.qvel[i] = s.x0v[i] + h * s.accf[i]; s.warm[i] = s.qacc[i]; }  // qacc_warmstart: the last stage's qacc (mj_advance)
   cx.sync();
 }
@@ -1294,6 +1483,7 @@ template <class C>
 MZ_HD void gen_env_step(const C& cx, const GenDev& K, GenScratch& s, const float* action, float* obs, float* reward, uint8_t* done, int* goal_idx,
                         float* info, int* t_io, int env = -1) {
   const mz_model& m = K.m;
+  gen_load_topology(cx, K, s);
   MZ_FOR(i, m.nv) s.fact[i] = 0.0;
   MZ_FOR(one, 1) { s.status = 0; s.red[1] = s.qpos[0]; s.red[2] = s.qpos[1]; }
   cx.sync();

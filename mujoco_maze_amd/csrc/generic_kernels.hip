@@ -4,9 +4,9 @@
 // specialised kernels).
 //
 //   generic_step_kernel   one MazeEnv.step per env: ONE WAVEFRONT (64 lanes) per environment, the env's working set
-//                         (GenScratch, ~100 KB, float64) in LDS for the frame_skip x 4 forward evaluations of the step — a
-//                         gfx950 workgroup may hold up to 160 KB; the compiled mz_model itself is the constant block (global
-//                         memory, uniform loads).
+//                         (GenScratch, 77 KB, float64) in LDS for the frame_skip x 4 forward evaluations of the step — two
+//                         envs share a CU's 160 KB; the compiled mz_model itself is the constant block (global memory).
+//                         The tree passes run level by level, the factorisations row-parallel (generic_dyn.h).
 //   reset / state copy kernels.
 //
 // HBM layout: state[N][REC] fp32 record = qpos[nq] | qvel[nv] | qacc_warmstart[nv] | t | episode (REC = nq + 2 nv + 2).
@@ -22,17 +22,20 @@
 #include "mz_internal.h"
 
 struct GenIO { float act[MZ_MAX_ACT], obs[MZ_MAX_OBS + MZ_VIEW_DIM], out[8]; int iout[4]; };
-struct alignas(16) GenEnvLDS { GenScratch s; GenIO io; };
+// LDS of one env: I/O staging | scratch block, the latter cut behind the Jacobian rows its model needs (gen_scratch_bytes).  Two envs
+// (workgroups of one wavefront) share a CU while that stays within half of the 160 KB: models of up to 22 dofs.
+constexpr size_t GEN_IO_BYTES = (sizeof(GenIO) + 15) / 16 * 16;
+static size_t gen_env_lds_bytes(int nv) { return GEN_IO_BYTES + gen_scratch_bytes(nv); }
 
 __global__ __launch_bounds__(64) void generic_step_kernel(const GenDev* __restrict__ Kp, int n, float* __restrict__ state, const float* __restrict__ actions,
                                                            float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                                                            int* __restrict__ goal_idx, float* __restrict__ info, int* __restrict__ status, int auto_reset,
                                                            uint64_t seed, uint64_t env0, float* __restrict__ final_obs, float* __restrict__ record) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  GenEnvLDS& L = *reinterpret_cast<GenEnvLDS*>(lds_raw);
+  struct { GenIO& io; } L{*reinterpret_cast<GenIO*>(lds_raw)};
   const GenDev& K = *Kp;
   const mz_model& m = K.m;
-  GenScratch& s = L.s;
+  GenScratch& s = *reinterpret_cast<GenScratch*>(lds_raw + GEN_IO_BYTES);
   DevCtx<64> cx{(int)threadIdx.x};
   const int env = blockIdx.x, nq = m.nq, nv = m.nv, nu = m.nu, rec_t = nq + 2 * nv, REC = rec_t + 2, obs_dim = m.obs_dim;
   float* rec = state + (size_t)env * REC;
@@ -42,9 +45,21 @@ __global__ __launch_bounds__(64) void generic_step_kernel(const GenDev* __restri
   }
   for (int i = cx.l; i < nu; i += 64) L.io.act[i] = actions[(size_t)env * nu + i];
   if (cx.l == 0) { L.io.iout[2] = ((const int*)rec)[rec_t]; L.io.iout[3] = ((const int*)rec)[rec_t + 1]; }
+#ifdef MZ_EXP_GENPROF
+  if (cx.l == 0) { for (int k = 0; k < 20; k++) s.prof[k] = 0; s.prof_t0 = __builtin_amdgcn_s_memtime(); }
+#endif
   cx.sync();
   gen_env_step(cx, K, s, L.io.act, L.io.obs, &L.io.out[0], (uint8_t*)&L.io.iout[0], &L.io.iout[1], &L.io.out[1], &L.io.iout[2], env);
   cx.sync();
+#ifdef MZ_EXP_GENPROF
+  if (cx.l == 0 && blockIdx.x % 97 == 5) {
+    unsigned long long tot = 0;
+    for (int k = 0; k < 16; k++) tot += s.prof[k];
+    printf("GENPROF %d total %llu kin %llu items %llu collide %llu crb+rne %llu mass/compact/limits %llu force/rows %llu qas %llu | warmcost %llu Mx/cu %llu grad %llu H %llu chol %llu ls %llu cost %llu tail %llu | rk4/io %llu iters %d ncon %d\n",
+           (int)blockIdx.x, tot, s.prof[0], s.prof[1], s.prof[2], s.prof[3], s.prof[4], s.prof[5], s.prof[6], s.prof[7], s.prof[8], s.prof[9], s.prof[10], s.prof[11], s.prof[12],
+           s.prof[13], s.prof[14], s.prof[15], s.iters, s.ncon);
+  }
+#endif
   const uint8_t d = *(const uint8_t*)&L.io.iout[0];
   const int t_new = L.io.iout[2];
   uint32_t episode = (uint32_t)L.io.iout[3];
@@ -151,11 +166,11 @@ hipError_t mzk_generic_set_task(mz_handle* h, const TaskDev* task) {
 void mzk_generic_destroy(mz_handle* h) { if (h->gen_dev) { (void)hipFree(h->gen_dev); h->gen_dev = nullptr; } }
 hipError_t mzk_generic_step(mz_handle* h, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, int* gi, float* inf) {
   static int lds_set[32] = {};
-  const int lds = (int)sizeof(GenEnvLDS), dv = h->device & 31;
-  if (lds_set[dv] != lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int lds = (int)gen_env_lds_bytes(h->model.nv), lds_max = (int)gen_env_lds_bytes(GN_NV), dv = h->device & 31;
+  if (lds_set[dv] != lds_max) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e != hipSuccess) return e;
-    lds_set[dv] = lds;
+    lds_set[dv] = lds_max;
   }
   hipLaunchKernelGGL(generic_step_kernel, dim3(h->n), dim3(64), lds, st, h->gen_dev, h->n, h->state, a, o, r, d, gi, inf, h->status, h->auto_reset, h->seed,
                      h->env0, h->final_obs, h->record);

@@ -417,6 +417,7 @@ extern "C" int emu_generic_forward(const mz_model* m, const double* qpos, const 
     if (m->act_ctrllimited[u]) c = fmin(fmax(c, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
     s->fact[m->act_dofid[u]] += m->act_gear[u] * c;
   }
+  gen_load_topology(cx, *K, *s);
   gen_forward(cx, *K, *s);
   for (int i = 0; i < m->nv; i++) qacc[i] = s->qacc[i];
   counts[0] = s->ncon; counts[1] = s->nlim; counts[2] = s->iters; counts[3] = s->status;
@@ -444,6 +445,7 @@ extern "C" int emu_generic_raw_steps(const mz_model* m, double* qpos, double* qv
     if (m->act_ctrllimited[u]) c = fmin(fmax(c, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
     s->fact[m->act_dofid[u]] += m->act_gear[u] * c;
   }
+  gen_load_topology(cx, *K, *s);
   for (int k = 0; k < nsteps; k++) gen_mj_step(cx, *K, *s);
   for (int i = 0; i < m->nq; i++) qpos[i] = s->qpos[i];
   for (int i = 0; i < m->nv; i++) { qvel[i] = s->qvel[i]; if (warm) warm[i] = s->warm[i]; }
