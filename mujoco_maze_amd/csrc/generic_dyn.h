@@ -61,7 +61,7 @@ struct GenDev {
   double tol, inv_scale;
   int dof_parent[GN_NV];
   int limj[GN_NJ], nlimj;            // the limited hinge / slide joints (candidates of the limit rows)
-  int body_depth[GN_NB], max_depth;  // tree level of every body (world 0): the kinematic / RNE passes walk level by level, the bodies of a level side by side
+  int body_depth[GN_NB], max_depth, child_first[GN_NB], child_next[GN_NB];  // tree level of every body (world 0): the kinematic / RNE passes walk level by level, the bodies of a level side by side
   // the Point's manual wall bounce (maze_env.py:451-464): point_bounce reads these three names
   int nseg, obs_extra;
   double seg[MZ_MAX_SEG][4], restitution;
@@ -177,6 +177,8 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
     if (m->jnt_limited[j] && (m->jnt_type[j] == MZ_JNT_HINGE || m->jnt_type[j] == MZ_JNT_SLIDE)) g->limj[g->nlimj++] = j;
   g->max_depth = 0;
   g->body_depth[0] = 0;
+  for (int b = 0; b < GN_NB; b++) { g->child_first[b] = -1; g->child_next[b] = -1; }
+  for (int b = 1; b < m->nbody; b++) { const int p = m->body_parent[b]; g->child_next[b] = g->child_first[p]; g->child_first[p] = b; }  // (ascending b: the list ends up highest first)
   for (int b = 1; b < m->nbody; b++) {  // (a parent's index is below its children's: mjcf.py / MuJoCo body order)
     if (m->body_parent[b] >= b) return gen_fail(err, errlen, "general engine: bodies must be ordered parents first");
     g->body_depth[b] = g->body_depth[m->body_parent[b]] + 1;
@@ -199,6 +201,7 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
 // full L2 round trip on a lone wavefront.  int8: all counts are <= MZ_MAX_* = 24 (28 for qpos addresses); -1 = none.
 struct GenTopo {
   int8_t body_parent[GN_NB], body_jntadr[GN_NB], body_jntnum[GN_NB], body_dofadr[GN_NB], body_dofnum[GN_NB], body_depth[GN_NB];
+  int8_t child_first[GN_NB], child_next[GN_NB];  // a body's children, highest index first (the order the serial up-pass added them in)
   int8_t jnt_type[GN_NJ], jnt_dofadr[GN_NJ], jnt_qposadr[GN_NJ], jnt_bodyid[GN_NJ];
   int8_t dof_bodyid[GN_NV], dof_parent[GN_NV];
   int8_t geom_bodyid[GN_NG];
@@ -254,6 +257,7 @@ MZ_HD void gen_load_topology(const C& cx, const GenDev& K, GenScratch& s) {
   MZ_FOR(b, m.nbody) {
     s.tp.body_parent[b] = (int8_t)m.body_parent[b]; s.tp.body_jntadr[b] = (int8_t)m.body_jntadr[b]; s.tp.body_jntnum[b] = (int8_t)m.body_jntnum[b];
     s.tp.body_dofadr[b] = (int8_t)m.body_dofadr[b]; s.tp.body_dofnum[b] = (int8_t)m.body_dofnum[b]; s.tp.body_depth[b] = (int8_t)K.body_depth[b];
+    s.tp.child_first[b] = (int8_t)K.child_first[b]; s.tp.child_next[b] = (int8_t)K.child_next[b];
   }
   MZ_FOR(j, m.njnt) {
     s.tp.jnt_type[j] = (int8_t)m.jnt_type[j]; s.tp.jnt_dofadr[j] = (int8_t)m.jnt_dofadr[j]; s.tp.jnt_qposadr[j] = (int8_t)m.jnt_qposadr[j];
@@ -324,6 +328,22 @@ MZ_HD void gd_force_cross(double* r, const double* v, const double* f) {
   gd_cross(a, v, f); gd_cross(b, v + 3, f + 3); gd_cross(c, v, f + 3);
   r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
 }
+// dot products of run-time length over LDS operands: four partial sums, so that the loads of four terms are in flight together (a
+// rolled loop with one accumulator pays one LDS round trip per term on a lone wavefront)
+MZ_HD double gd_dotn(const double* a, const double* b, int n) {
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= n; k += 4) { t0 += a[k] * b[k]; t1 += a[k + 1] * b[k + 1]; t2 += a[k + 2] * b[k + 2]; t3 += a[k + 3] * b[k + 3]; }
+  for (; k < n; k++) t0 += a[k] * b[k];
+  return (t0 + t1) + (t2 + t3);
+}
+MZ_HD double gd_dotn_diff(const double* a, const double* x, const double* y, int n) {  // a . (x - y)
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= n; k += 4) { t0 += a[k] * (x[k] - y[k]); t1 += a[k + 1] * (x[k + 1] - y[k + 1]); t2 += a[k + 2] * (x[k + 2] - y[k + 2]); t3 += a[k + 3] * (x[k + 3] - y[k + 3]); }
+  for (; k < n; k++) t0 += a[k] * (x[k] - y[k]);
+  return (t0 + t1) + (t2 + t3);
+}
 MZ_HD double gd_dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
 MZ_HD double gd_impedance(const double* si, double x) {
   const double d0 = si[0], dmax = si[1], width = si[2], mid = si[3], power = si[4];
@@ -371,8 +391,10 @@ MZ_HD void gen_kin_body(const GenDev& K, GenScratch& s, int b) {
           for (int k = 0; k < 4; k++) ql[k] = s.qpos[s.tp.jnt_qposadr[j] + k];
           gd_quat_norm(ql);
         } else {
-          const double q = s.qpos[s.tp.jnt_qposadr[j]] - m.qpos0[s.tp.jnt_qposadr[j]], sh = sin(0.5 * q);
-          ql[0] = cos(0.5 * q); ql[1] = m.jnt_axis[j][0] * sh; ql[2] = m.jnt_axis[j][1] * sh; ql[3] = m.jnt_axis[j][2] * sh;
+          const double q = s.qpos[s.tp.jnt_qposadr[j]] - m.qpos0[s.tp.jnt_qposadr[j]];
+          double sh, ch;
+          sincos(0.5 * q, &sh, &ch);  // (one argument reduction for the two)
+          ql[0] = ch; ql[1] = m.jnt_axis[j][0] * sh; ql[2] = m.jnt_axis[j][1] * sh; ql[3] = m.jnt_axis[j][2] * sh;
         }
         gd_quat_mul(qn, quat, ql);
         for (int k = 0; k < 4; k++) quat[k] = qn[k];
@@ -1052,11 +1074,10 @@ MZ_HD void gen_tree_passes(const C& cx, const GenDev& K, GenScratch& s) {
   for (int d = K.max_depth - 1; d >= 1; d--) {
     cx.sync();
     MZ_FOR(p, m.nbody) if (s.tp.body_depth[p] == d)
-      for (int c = m.nbody - 1; c > p; c--)
-        if (s.tp.body_parent[c] == p) {
-          for (int k = 0; k < 10; k++) s.crb[p][k] += s.crb[c][k];
-          for (int e = 0; e < 6; e++) s.cfrc[p][e] += s.cfrc[c][e];
-        }
+      for (int c = s.tp.child_first[p]; c >= 0; c = s.tp.child_next[c]) {
+        for (int k = 0; k < 10; k++) s.crb[p][k] += s.crb[c][k];
+        for (int e = 0; e < 6; e++) s.cfrc[p][e] += s.cfrc[c][e];
+      }
   }
   cx.sync();
 }
@@ -1137,8 +1158,16 @@ MZ_HD bool gen_chol_solve(const C& cx, GenScratch& s, const double (*Asrc)[GN_NV
     const int l = cx.l;
     const bool isrow = l < n;
     double r[GN_NV];
+    {  // (all GN_NV loads of the lane's row unconditionally — they are in bounds whatever n is — and back to back: ONE LDS round trip;
+       //  what the lane must not see is masked afterwards)
+      const double* src = isrow ? Asrc[l] : x;
 #pragma unroll
-    for (int k = 0; k < GN_NV; k++) r[k] = (k < n && (isrow ? k <= l : l == n)) ? (isrow ? Asrc[l][k] : x[k]) : 0.0;
+      for (int k = 0; k < GN_NV; k++) r[k] = src[k];
+#pragma unroll
+      for (int k = 0; k < GN_NV; k++) asm volatile("" : "+v"(r[k]));  // (pins the loads where they are: the compiler otherwise sinks each one into a branch of its mask — 24 round trips)
+#pragma unroll
+      for (int k = 0; k < GN_NV; k++) r[k] = (k < n && (isrow ? k <= l : l == n)) ? r[k] : 0.0;
+    }
     bool ok = true;
     double dinv = 0.0;
 #pragma unroll
@@ -1156,12 +1185,21 @@ MZ_HD bool gen_chol_solve(const C& cx, GenScratch& s, const double (*Asrc)[GN_NV
     }
     if (!ok) return false;  // (uniform: every lane saw the same pivots)
     cx.sync();              // (every lane has read its row of Asrc)
+    if (l <= n) {  // (whole rows, zeros above the diagonal and behind column n included: nobody reads those, and the stores go out back to back)
+      double* dst = isrow ? A[l] : x;
 #pragma unroll
-    for (int k = 0; k < GN_NV; k++) if (k < n) { if (isrow && k <= l) A[l][k] = r[k]; else if (l == n) x[k] = r[k]; }
+      for (int k = 0; k < GN_NV; k++) dst[k] = r[k];
+    }
     cx.sync();
-    double y = isrow ? x[l] : 0.0;
+    const int lc = isrow ? l : 0;
+    double y = x[lc];
 #pragma unroll
-    for (int k = 0; k < GN_NV; k++) r[k] = (isrow && k < n && k > l) ? A[k][l] : 0.0;  // column l of the factor below the diagonal
+    for (int k = 0; k < GN_NV; k++) r[k] = A[k][lc];  // column l of the factor ...
+#pragma unroll
+    for (int k = 0; k < GN_NV; k++) asm volatile("" : "+v"(r[k]));
+    y = isrow ? y : 0.0;
+#pragma unroll
+    for (int k = 0; k < GN_NV; k++) r[k] = (isrow && k < n && k > l) ? r[k] : 0.0;  // ... below the diagonal (rows >= n hold whatever LDS held: selected away, never computed with)
 #pragma unroll
     for (int j = GN_NV - 1; j >= 0; j--) {
       if (j < n) {
@@ -1216,10 +1254,10 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
   if (ncon == 0 && nlim == 0) { MZ_FOR(i, nv) s.qacc[i] = s.qas[i]; MZ_FOR(one, 1) s.iters = 0; cx.sync(); return; }
   auto cost_at = [&](const double* x) {  // partial cost over this lane's rows (+ the smooth part on its dofs)
     double c = 0.0;
-    MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * (x[j] - s.qas[j]); c += 0.5 * t * (x[i] - s.qas[i]); }
+    MZ_FOR(i, nv) c += 0.5 * gd_dotn_diff(s.M[i], x, s.qas, nv) * (x[i] - s.qas[i]);
     MZ_FOR(k, ncon) {
       double u[3];
-      for (int a = 0; a < 3; a++) { const double* Jr = gen_cj(s, nv, k, a); double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += Jr[i] * x[i]; u[a] = t; }
+      for (int a = 0; a < 3; a++) u[a] = gd_dotn(gen_cj(s, nv, k, a), x, nv) - s.caref[k][a];
       c += gen_contact_eval(s.cD[k], u, nullptr, nullptr);
     }
     MZ_FOR(l, nlim) { const double jar = s.lsign[l] * x[s.ldof[l]] - s.laref[l]; if (jar < 0.0) c += 0.5 * s.lD[l] * jar * jar; }
@@ -1235,10 +1273,10 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
   double prev_cost = cw < cs ? cw : cs;
   GEN_TICK(7);
   while (!done && it < K.max_iter) {
-    MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * (s.qacc[j] - s.qas[j]); s.Mx[i] = t; }
+    MZ_FOR(i, nv) s.Mx[i] = gd_dotn_diff(s.M[i], s.qacc, s.qas, nv);
     MZ_FOR(k, ncon) {  // a contact's three residuals, and from them its gradient and Hessian weights — once, not once per entry that uses them
       double u[3];
-      for (int a = 0; a < 3; a++) { const double* Jr = gen_cj(s, nv, k, a); double t = -s.caref[k][a]; for (int i = 0; i < nv; i++) t += Jr[i] * s.qacc[i]; u[a] = t; s.cu[k][a] = t; }
+      for (int a = 0; a < 3; a++) { u[a] = gd_dotn(gen_cj(s, nv, k, a), s.qacc, nv) - s.caref[k][a]; s.cu[k][a] = u[a]; }
       gen_contact_eval(s.cD[k], u, s.cg[k], s.cW[k]);
     }
     MZ_FOR(l, nlim) s.ljar[l] = s.lsign[l] * s.qacc[s.ldof[l]] - s.laref[l];
@@ -1247,6 +1285,7 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
     double gpart = 0.0;
     MZ_FOR(i, nv) {
       double g = s.Mx[i];
+#pragma unroll 2
       for (int k = 0; k < ncon; k++) { const double* Jk = gen_cj(s, nv, k, 0); g += Jk[i] * s.cg[k][0] + Jk[nv + i] * s.cg[k][1] + Jk[2 * nv + i] * s.cg[k][2]; }
       for (int l = 0; l < nlim; l++) if (s.ldof[l] == i && s.ljar[l] < 0.0) g += s.lsign[l] * s.lD[l] * s.ljar[l];
       s.grad[i] = g; gpart += g * g;
@@ -1260,6 +1299,7 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
       const int r = e / (nv + 1), c = e - (nv + 1) * r;
       const int i = c <= r ? r : nv - 1 - r, j = c <= r ? c : c - r - 1;
       double acc = s.M[i][j];
+#pragma unroll 2
       for (int k = 0; k < ncon; k++) {
         const double* W = s.cW[k];
         const double* Jk = gen_cj(s, nv, k, 0);
@@ -1277,8 +1317,8 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
     GEN_TICK(11);
     if (!posdef) { MZ_FOR(one, 1) s.status |= MZ_STATUS_BAD_STATE; break; }
     // line search on phi(alpha) = cost(qacc + alpha search): unit step when no row changes state, else safeguarded Newton on phi'
-    MZ_FOR(i, nv) { double t = 0.0; for (int j = 0; j < nv; j++) t += s.M[i][j] * s.search[j]; s.Ms[i] = t; }
-    MZ_FOR(e, 3 * ncon) { const double* Jr = s.cJf + (size_t)e * nv; double t = 0.0; for (int i = 0; i < nv; i++) t += Jr[i] * s.search[i]; s.cjv[e / 3][e % 3] = t; }
+    MZ_FOR(i, nv) s.Ms[i] = gd_dotn(s.M[i], s.search, nv);
+    MZ_FOR(e, 3 * ncon) s.cjv[e / 3][e % 3] = gd_dotn(s.cJf + (size_t)e * nv, s.search, nv);
     MZ_FOR(l, nlim) s.ljv[l] = s.lsign[l] * s.search[s.ldof[l]];
     cx.sync();
     bool changed = false;
@@ -1388,7 +1428,10 @@ MZ_HD void gen_integrate_joint(const GenDev& K, GenScratch& s, const double* bas
       const double w[3] = {vel[dw], vel[dw + 1], vel[dw + 2]}, n = sqrt(gd_dot3(w, w));
       double q[4] = {base[qq], base[qq + 1], base[qq + 2], base[qq + 3]};
       if (n > 1e-15) {
-        const double sh = sin(0.5 * h * n) / n, qr[4] = {cos(0.5 * h * n), w[0] * sh, w[1] * sh, w[2] * sh};
+        double sh, ch;
+        sincos(0.5 * h * n, &sh, &ch);
+        sh /= n;
+        const double qr[4] = {ch, w[0] * sh, w[1] * sh, w[2] * sh};
         double qn[4];
         gd_quat_mul(qn, q, qr);
         for (int k = 0; k < 4; k++) q[k] = qn[k];
