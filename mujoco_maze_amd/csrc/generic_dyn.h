@@ -442,7 +442,6 @@ MZ_HD void gen_geom_item(const GenDev& K, GenScratch& s, int g) {
   gd_quat2mat(s.gmat[g], q);
 }
 MZ_HD void gen_axis_item(const GenDev& K, GenScratch& s, int j) {
-  const mz_model& m = K.m;
   const int b = s.tp.jnt_bodyid[j], d0 = s.tp.jnt_dofadr[j];
   const double* c = s.refpoint;
   double off[3];
@@ -1029,7 +1028,6 @@ MZ_HD void gen_rows_slope(double D, const double* u, const double* v, double alp
 // ------------------------------------------------------------------ velocities, bias (RNE), passive (damping + fluid), actuation
 // velocity, acceleration and inertial + velocity-product force of body b from its parent's (mj_comVel / mj_rne forward pass)
 MZ_HD void gen_rne_body(const GenDev& K, GenScratch& s, int b) {
-  const mz_model& m = K.m;
   const int p = s.tp.body_parent[b], j0 = s.tp.body_jntadr[b];
   double v[6], a[6];
   for (int e = 0; e < 6; e++) { v[e] = s.cvel[p][e]; a[e] = s.cacc[p][e]; }
@@ -1416,7 +1414,6 @@ MZ_HD void gen_forward(const C& cx, const GenDev& K, GenScratch& s) {
 
 // mj_integratePos of joint j (the joints are independent of each other: one lane each)
 MZ_HD void gen_integrate_joint(const GenDev& K, GenScratch& s, const double* base, const double* vel, double h, int j) {
-  const mz_model& m = K.m;
   {
     const int qa = s.tp.jnt_qposadr[j], da = s.tp.jnt_dofadr[j];
     if (s.tp.jnt_type[j] == MZ_JNT_FREE || s.tp.jnt_type[j] == MZ_JNT_BALL) {  // mj_integratePos: q <- q * exp(h w / 2), w in the child frame

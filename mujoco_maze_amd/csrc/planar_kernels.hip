@@ -30,6 +30,9 @@
 // every such partial store left the L2 as a transaction of its own (PMC, round 4: WRITE_SIZE 1.9 MB per launch against 0.3 MB of
 // algorithmic writes, FETCH_SIZE 1.1 MB against 0.2); its two records are 64 contiguous bytes.
 struct PointState { float* qv; int* t; uint32_t* ep; int rec; };
+// The bare Point's record (no movable bodies) carries the solver's warm start behind t | episode: qacc - qacc_smooth of the step's last
+// forward evaluation, the first guess of the next step's first solve (round 6; reset and set_state clear it)
+constexpr int PT_WARM_OFF = 8;
 __device__ __forceinline__ float& st_q(const PointState& S, int n, int nv, int k, int env) { return S.rec ? S.qv[(size_t)env * S.rec + k] : S.qv[(size_t)k * n + env]; }
 __device__ __forceinline__ float& st_v(const PointState& S, int n, int nv, int k, int env) { return S.rec ? S.qv[(size_t)env * S.rec + nv + k] : S.qv[(size_t)(nv + k) * n + env]; }
 __device__ __forceinline__ int& st_t(const PointState& S, int nv, int env) { return S.rec ? reinterpret_cast<int*>(S.qv)[(size_t)env * S.rec + 2 * nv] : S.t[env]; }
@@ -48,6 +51,7 @@ __device__ __forceinline__ void planar_step_body(const PointDev& P, PlanarScratc
   using D = PlanarDims<NB, NS>;
   constexpr int NV = D::NV, NOBS = D::NOBS;
   for (int k = cx.l; k < NV; k += G) { s.q[k] = (double)st_q(S, n, NV, k, env); s.v[k] = (double)st_v(S, n, NV, k, env); }
+  if constexpr (NB == 0 && NS == 0) { for (int k = cx.l; k < 3; k += G) s.wds[k] = (double)S.qv[(size_t)env * S.rec + PT_WARM_OFF + k]; }  // the bare Point's warm start
   double a[2] = {(double)actions[(size_t)env * 2], (double)actions[(size_t)env * 2 + 1]};
   cx.sync();
 #ifdef MZ_EXP_PROF
@@ -109,6 +113,7 @@ __device__ __forceinline__ void planar_step_body(const PointDev& P, PlanarScratc
       st_v(S, n, NV, k, env) = (float)s.v[k];
     }
     if (cx.l == 0) { st_t(S, NV, env) = rst ? 0 : t_new; st_ep(S, NV, env) = ep; }
+    if constexpr (NB == 0 && NS == 0) { for (int k = cx.l; k < 3; k += G) S.qv[(size_t)env * S.rec + PT_WARM_OFF + k] = rst ? 0.f : (float)s.wds[k]; }
   }
 }
 
@@ -147,6 +152,7 @@ __global__ void point_reset_kernel(const PointDev* Pp, int n, PointState S, cons
     }
     st_t(S, NV, env) = 0;
     st_ep(S, NV, env) = 0;
+    if (NB == 0 && NS == 0) for (int k = 0; k < 3; k++) S.qv[(size_t)env * S.rec + PT_WARM_OFF + k] = 0.f;
   }
   if (obs) {
     const int nb3 = (Pp->observe_blocks ? 3 * NB : 0) + (Pp->observe_balls ? 3 * NS : 0);
@@ -182,6 +188,7 @@ __global__ void point_set_state_kernel(int n, PointState S, const float* qpos, c
     if (qvel) st_v(S, n, KQ, k, env) = qvel[(size_t)env * KQ + k];
   }
   if (t) st_t(S, KQ, env) = t[env];
+  if (KQ == 3 && S.rec > PT_WARM_OFF && (qpos || qvel)) for (int k = 0; k < 3; k++) S.qv[(size_t)env * S.rec + PT_WARM_OFF + k] = 0.f;  // a new state: no guess
 }
 template <int KQ>
 __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* qvel, float* warm, int* t) {
@@ -190,7 +197,7 @@ __global__ void point_get_state_kernel(int n, PointState S, float* qpos, float* 
   for (int k = 0; k < KQ; k++) {
     if (qpos) qpos[(size_t)env * KQ + k] = st_q(S, n, KQ, k, env);
     if (qvel) qvel[(size_t)env * KQ + k] = st_v(S, n, KQ, k, env);
-    if (warm) warm[(size_t)env * KQ + k] = 0.f;
+    if (warm) warm[(size_t)env * KQ + k] = (KQ == 3 && S.rec > PT_WARM_OFF) ? S.qv[(size_t)env * S.rec + PT_WARM_OFF + k] : 0.f;
   }
   if (t) t[env] = st_t(S, KQ, env);
 }
@@ -373,6 +380,7 @@ __global__ void point_detect_kernel(const PointDev* __restrict__ Pp, int n, cons
 // ------------------------------------------------------------------ entry points of this translation unit (mz_internal.h)
 // floats per env of the Point's env-major state record (q | v | t | episode, padded to 16 bytes); 0 = SoA (the chains)
 int mzk_planar_record_width(const mz_handle* h) {
+  if (h->robot == MZ_ROBOT_POINT && h->point.nblock == 0 && h->point.nball == 0) return PT_WARM_OFF + 4;  // q[3] v[3] t episode | warm start[3] | pad: 48 B
   return h->robot == MZ_ROBOT_POINT ? (2 * mzk_planar_state_width(h) + 2 + 3) / 4 * 4 : 0;
 }
 int mzk_planar_state_width(const mz_handle* h) {

@@ -129,6 +129,7 @@ static int planar_env_step_t(const PointDev& P, int n, float* qpos, float* qvel,
   for (int e = 0; e < n; e++) {
     double a[2] = {(double)actions[2 * e], (double)actions[2 * e + 1]};
     for (int k = 0; k < NV; k++) { s->q[k] = (double)qpos[NV * e + k]; s->v[k] = (double)qvel[NV * e + k]; }
+    if constexpr (NB == 0 && NS == 0) { s->wds[0] = s->wds[1] = s->wds[2] = 0.0; }  // (a state handed in carries no warm start: as after mz_set_state)
     const int t_new = t[e] + 1;
     planar_env_step<NB, NS>(cx, P, *s, a);
     float o[NOBS];

@@ -4,7 +4,7 @@
 #           profiles/<tag>/{summary,kernel_stats,pmc}_<env>_<envs>.*), their bench lines, phase timers and tail phases
 #   part b: soak, parity quantiles, the configs next to the BASELINE ones, the batch-size sweep
 #   tools/evidence.sh <tag> [a|b|ab]
-tag=${1:-r05}; part=${2:-ab}
+tag=${1:-r06}; part=${2:-ab}
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/evidence_$tag
 mkdir -p $out
@@ -29,6 +29,7 @@ if [[ $part == *b* ]]; then
   timeout 1800 python tools/soak.py ${SOAK_STEPS:-8000} 2>/dev/null > $out/soak.txt
   timeout 1500 python tools/parity_stats.py ${PARITY_MODE:-} 2>/dev/null > $out/parity.md
   bash tools/gpu_other_configs.sh > /dev/null 2>&1; cp gpurun_out/other_configs.txt $out/
+  python tools/general_engine_bench.py 2048 100 2>/dev/null | grep -v Warning > $out/general_engine.txt
   for a in "--envs 8192" "--envs 16384" "--envs 32768" "--env PointUMaze-v0 --envs 8192" "--env PointUMaze-v0 --envs 16384" "--env AntPush-v0 --envs 4096" "--env AntPush-v0 --envs 8192"; do
     python bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-live-pmc --sustained 0 $a 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-62s %8.3f M env-steps/s   kernel %.4f ms   flagged envs %d' % (d['metric'][34:], d['value']/1e6, d['roofline']['kernel_ms'], d['config']['bad_envs']))"
   done > $out/batch_sweep.txt
