@@ -1163,8 +1163,10 @@ MZ_HD bool gen_chol_solve(const C& cx, GenScratch& s, const double (*Asrc)[GN_NV
       for (int k = 0; k < GN_NV; k++) r[k] = src[k];
 #pragma unroll
       for (int k = 0; k < GN_NV; k++) asm volatile("" : "+v"(r[k]));  // (pins the loads where they are: the compiler otherwise sinks each one into a branch of its mask — 24 round trips)
+      // (masked with integer ands on ONE per-lane bound: as a select over three conditions this loop became six branches per entry)
+      const int kmax = isrow ? (l < n - 1 ? l : n - 1) : (l == n ? n - 1 : -1);
 #pragma unroll
-      for (int k = 0; k < GN_NV; k++) r[k] = (k < n && (isrow ? k <= l : l == n)) ? r[k] : 0.0;
+      for (int k = 0; k < GN_NV; k++) r[k] = __longlong_as_double(__double_as_longlong(r[k]) & (k <= kmax ? ~0ll : 0ll));
     }
     bool ok = true;
     double dinv = 0.0;
@@ -1196,8 +1198,9 @@ MZ_HD bool gen_chol_solve(const C& cx, GenScratch& s, const double (*Asrc)[GN_NV
 #pragma unroll
     for (int k = 0; k < GN_NV; k++) asm volatile("" : "+v"(r[k]));
     y = isrow ? y : 0.0;
+    const int klo = isrow ? l : GN_NV;
 #pragma unroll
-    for (int k = 0; k < GN_NV; k++) r[k] = (isrow && k < n && k > l) ? r[k] : 0.0;  // ... below the diagonal (rows >= n hold whatever LDS held: selected away, never computed with)
+    for (int k = 0; k < GN_NV; k++) r[k] = __longlong_as_double(__double_as_longlong(r[k]) & ((k > klo && k < n) ? ~0ll : 0ll));  // ... below the diagonal (rows >= n hold whatever LDS held: masked away, never computed with)
 #pragma unroll
     for (int j = GN_NV - 1; j >= 0; j--) {
       if (j < n) {
