@@ -61,7 +61,8 @@ struct GenDev {
   double tol, inv_scale;
   int dof_parent[GN_NV];
   int limj[GN_NJ], nlimj;            // the limited hinge / slide joints (candidates of the limit rows)
-  int body_depth[GN_NB], max_depth, child_first[GN_NB], child_next[GN_NB];  // tree level of every body (world 0): the kinematic / RNE passes walk level by level, the bodies of a level side by side
+  int body_depth[GN_NB], max_depth;
+  unsigned subtree[GN_NB];  // bit b: body b is body p itself or one of its descendants  // tree level of every body (world 0): the kinematic / RNE passes walk level by level, the bodies of a level side by side
   // the Point's manual wall bounce (maze_env.py:451-464): point_bounce reads these three names
   int nseg, obs_extra;
   double seg[MZ_MAX_SEG][4], restitution;
@@ -177,8 +178,8 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
     if (m->jnt_limited[j] && (m->jnt_type[j] == MZ_JNT_HINGE || m->jnt_type[j] == MZ_JNT_SLIDE)) g->limj[g->nlimj++] = j;
   g->max_depth = 0;
   g->body_depth[0] = 0;
-  for (int b = 0; b < GN_NB; b++) { g->child_first[b] = -1; g->child_next[b] = -1; }
-  for (int b = 1; b < m->nbody; b++) { const int p = m->body_parent[b]; g->child_next[b] = g->child_first[p]; g->child_first[p] = b; }  // (ascending b: the list ends up highest first)
+  for (int b = 0; b < GN_NB; b++) g->subtree[b] = 0u;
+  for (int b = 1; b < m->nbody; b++) for (int a = b; a > 0; a = m->body_parent[a]) g->subtree[a] |= 1u << b;
   for (int b = 1; b < m->nbody; b++) {  // (a parent's index is below its children's: mjcf.py / MuJoCo body order)
     if (m->body_parent[b] >= b) return gen_fail(err, errlen, "general engine: bodies must be ordered parents first");
     g->body_depth[b] = g->body_depth[m->body_parent[b]] + 1;
@@ -201,17 +202,18 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
 // full L2 round trip on a lone wavefront.  int8: all counts are <= MZ_MAX_* = 24 (28 for qpos addresses); -1 = none.
 struct GenTopo {
   int8_t body_parent[GN_NB], body_jntadr[GN_NB], body_jntnum[GN_NB], body_dofadr[GN_NB], body_dofnum[GN_NB], body_depth[GN_NB];
-  int8_t child_first[GN_NB], child_next[GN_NB];  // a body's children, highest index first (the order the serial up-pass added them in)
   int8_t jnt_type[GN_NJ], jnt_dofadr[GN_NJ], jnt_qposadr[GN_NJ], jnt_bodyid[GN_NJ];
   int8_t dof_bodyid[GN_NV], dof_parent[GN_NV];
   int8_t geom_bodyid[GN_NG];
+  uint32_t subtree[GN_NB];  // bit b: body b belongs to the subtree of this body (itself included): composite inertias and subtree forces are
+                            // summed straight from the bodies' own values by whoever needs them — no up-pass over the tree
 };
 struct alignas(16) GenScratch {
   GenTopo tp;
   double qpos[GN_NQ], qvel[GN_NV], warm[GN_NV], fact[GN_NV], x0q[GN_NQ], x0v[GN_NV], accv[GN_NV], accf[GN_NV], dxv[GN_NV];
   double qacc[GN_NV], qas[GN_NV], qfs[GN_NV], bias[GN_NV], passive[GN_NV];
   double xpos[GN_NB][3], xquat[GN_NB][4], xmat[GN_NB][9], xipos[GN_NB][3];
-  double cinert[GN_NB][10], crb[GN_NB][10], cvel[GN_NB][6], cacc[GN_NB][6], cfrc[GN_NB][6], ffl[GN_NB][6];
+  double cinert[GN_NB][10], cvel[GN_NB][6], cacc[GN_NB][6], cfrc[GN_NB][6], ffl[GN_NB][6];  // (cfrc: each body's OWN inertial + velocity-product force)
   double xanchor[GN_NJ][3], xaxis[GN_NJ][3];
   double gpos[GN_NG][3], gmat[GN_NG][9];
   double S[GN_NV][6], refpoint[3];
@@ -257,7 +259,7 @@ MZ_HD void gen_load_topology(const C& cx, const GenDev& K, GenScratch& s) {
   MZ_FOR(b, m.nbody) {
     s.tp.body_parent[b] = (int8_t)m.body_parent[b]; s.tp.body_jntadr[b] = (int8_t)m.body_jntadr[b]; s.tp.body_jntnum[b] = (int8_t)m.body_jntnum[b];
     s.tp.body_dofadr[b] = (int8_t)m.body_dofadr[b]; s.tp.body_dofnum[b] = (int8_t)m.body_dofnum[b]; s.tp.body_depth[b] = (int8_t)K.body_depth[b];
-    s.tp.child_first[b] = (int8_t)K.child_first[b]; s.tp.child_next[b] = (int8_t)K.child_next[b];
+    s.tp.subtree[b] = K.subtree[b];
   }
   MZ_FOR(j, m.njnt) {
     s.tp.jnt_type[j] = (int8_t)m.jnt_type[j]; s.tp.jnt_dofadr[j] = (int8_t)m.jnt_dofadr[j]; s.tp.jnt_qposadr[j] = (int8_t)m.jnt_qposadr[j];
@@ -336,6 +338,19 @@ MZ_HD double gd_dotn(const double* a, const double* b, int n) {
   for (; k + 4 <= n; k += 4) { t0 += a[k] * b[k]; t1 += a[k + 1] * b[k + 1]; t2 += a[k + 2] * b[k + 2]; t3 += a[k + 3] * b[k + 3]; }
   for (; k < n; k++) t0 += a[k] * b[k];
   return (t0 + t1) + (t2 + t3);
+}
+// the three rows of a contact (normal, mu t1, mu t2: consecutive in the Jacobian store at a stride of n) against one vector — its loads shared
+MZ_HD void gd_dot3n(const double* J, const double* x, int n, double* out) {
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0;
+  const double* J1 = J + n;
+  const double* J2 = J + 2 * n;
+  int k = 0;
+  for (; k + 2 <= n; k += 2) {
+    const double x0 = x[k], x1 = x[k + 1];
+    a0 += J[k] * x0; a1 += J[k + 1] * x1; b0 += J1[k] * x0; b1 += J1[k + 1] * x1; c0 += J2[k] * x0; c1 += J2[k + 1] * x1;
+  }
+  if (k < n) { const double x0 = x[k]; a0 += J[k] * x0; b0 += J1[k] * x0; c0 += J2[k] * x0; }
+  out[0] = a0 + a1; out[1] = b0 + b1; out[2] = c0 + c1;
 }
 MZ_HD double gd_dotn_diff(const double* a, const double* x, const double* y, int n) {  // a . (x - y)
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
@@ -481,14 +496,18 @@ MZ_HD void gen_inertia_item(const GenDev& K, GenScratch& s, int b) {
   I[0] = ms; I[1] = ms * r[0]; I[2] = ms * r[1]; I[3] = ms * r[2];
   I[4] = Iw[0] + ms * (rr - r[0] * r[0]); I[5] = Iw[4] + ms * (rr - r[1] * r[1]); I[6] = Iw[8] + ms * (rr - r[2] * r[2]);
   I[7] = Iw[1] - ms * r[0] * r[1]; I[8] = Iw[2] - ms * r[0] * r[2]; I[9] = Iw[5] - ms * r[1] * r[2];
-  for (int k = 0; k < 10; k++) s.crb[b][k] = I[k];
 }
 // row i of the joint-space inertia: M[i][j] for the dofs j on the path from i to its root
 MZ_HD void gen_mass_item(const GenDev& K, GenScratch& s, int i) {
   const mz_model& m = K.m;
   double F[6];
   for (int j = 0; j < m.nv; j++) s.M[i][j] = 0.0;
-  gd_inertia_mul(F, s.crb[s.tp.dof_bodyid[i]], s.S[i]);
+  double crb[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // composite inertia of the dof's subtree (mj_crb), summed here from the bodies' own
+  for (uint32_t mk = s.tp.subtree[s.tp.dof_bodyid[i]]; mk; mk &= mk - 1) {
+    const double* I = s.cinert[__builtin_ctz(mk)];
+    for (int k = 0; k < 10; k++) crb[k] += I[k];
+  }
+  gd_inertia_mul(F, crb, s.S[i]);
   s.M[i][i] = gd_dot6(s.S[i], F) + m.dof_armature[i];
   for (int j = s.tp.dof_parent[i]; j >= 0; j = s.tp.dof_parent[j]) s.M[i][j] = gd_dot6(s.S[j], F);
 }
@@ -800,7 +819,11 @@ MZ_HD void gen_collide_item(const GenDev& K, GenScratch& s, int it) {
   const GenItem& I = K.item[it];
   const double margin = I.P.margin;
   int n = 0;
+  const double active_below = I.P.margin - I.P.gap;
   auto emit = [&](double dist, const double* pos, const double* nrm, const double* hint) {
+    // only ACTIVE contacts enter the pool (dist < margin - gap; the others make no constraint row) — their index n within the item still
+    // counts, so the keys order the survivors as the oracle orders them
+    if (!(dist < active_below)) { n++; return; }
     const int slot = gen_take(&s.npool);
     if (slot < GN_POOL) {
       s.pkey[slot] = it * GN_KEY + (n < GN_KEY ? n : GN_KEY - 1); s.pdist[slot] = dist;
@@ -906,15 +929,17 @@ MZ_HD void gen_collide_item(const GenDev& K, GenScratch& s, int it) {
 
 // pool -> the ACTIVE contacts (dist < margin - gap), in key order: entry e's slot = the number of active entries with a smaller key
 MZ_HD void gen_compact_item(const GenDev& K, GenScratch& s, int e, int np) {
-  const GenPair& P = K.item[s.pkey[e] / GN_KEY].P;
-  if (!(s.pdist[e] < P.margin - P.gap)) return;
-  int rank = 0;
-  for (int o = 0; o < np; o++) {
-    const GenPair& Q = K.item[s.pkey[o] / GN_KEY].P;
-    if (s.pdist[o] < Q.margin - Q.gap && (s.pkey[o] < s.pkey[e] || (s.pkey[o] == s.pkey[e] && o < e))) rank++;
+  const int key = s.pkey[e];
+  int r0 = 0, r1 = 0, r2 = 0, r3 = 0, o = 0;  // (four keys per round trip)
+  for (; o + 4 <= np; o += 4) {
+    const int k0 = s.pkey[o], k1 = s.pkey[o + 1], k2 = s.pkey[o + 2], k3 = s.pkey[o + 3];
+    r0 += (k0 < key || (k0 == key && o < e)) ? 1 : 0; r1 += (k1 < key || (k1 == key && o + 1 < e)) ? 1 : 0;
+    r2 += (k2 < key || (k2 == key && o + 2 < e)) ? 1 : 0; r3 += (k3 < key || (k3 == key && o + 3 < e)) ? 1 : 0;
   }
+  for (; o < np; o++) { const int k0 = s.pkey[o]; r0 += (k0 < key || (k0 == key && o < e)) ? 1 : 0; }
+  const int rank = (r0 + r1) + (r2 + r3);
   if (rank >= GN_NC) return;  // (counted by gen_forward)
-  s.citem[rank] = s.pkey[e] / GN_KEY; s.cdist[rank] = s.pdist[e];
+  s.citem[rank] = key / GN_KEY; s.cdist[rank] = s.pdist[e];
   for (int k = 0; k < 3; k++) { s.cpos[rank][k] = s.ppos[e][k]; s.cnrm[rank][k] = s.pnrm[e][k]; s.chint[rank][k] = s.phint[e][k]; }
 }
 
@@ -1058,9 +1083,10 @@ MZ_HD void gen_rne_body(const GenDev& K, GenScratch& s, int b) {
   gd_force_cross(vf, v, Iv);
   for (int e = 0; e < 6; e++) { s.cvel[b][e] = v[e]; s.cacc[b][e] = a[e]; s.cfrc[b][e] = Ia[e] + vf[e]; }
 }
-// The two tree passes of an evaluation, level by level (the bodies of a level side by side; round 6 — on one lane they were 15 % of an
-// Ant env-step): down — velocities / accelerations / body forces (RNE forward); up — composite inertias (CRB) and subtree forces (RNE
-// backward), parent by parent over its children in the serial loop's order (highest index first), so the sums are the same numbers.
+// The tree pass of an evaluation, level by level (the bodies of a level side by side; round 6 — on one lane the passes were 15 % of an
+// Ant env-step): down — velocities / accelerations / each body's own force (RNE forward).  There is no up-pass: composite inertias
+// (CRB) and subtree forces (RNE backward) are sums over a subtree, and the dof lanes that need them (gen_mass_item, gen_force_item) add
+// them up themselves from the bodies' own values by the subtree bit masks of GenTopo — independent loads instead of level fences.
 template <class C>
 MZ_HD void gen_tree_passes(const C& cx, const GenDev& K, GenScratch& s) {
   const mz_model& m = K.m;
@@ -1068,14 +1094,6 @@ MZ_HD void gen_tree_passes(const C& cx, const GenDev& K, GenScratch& s) {
   for (int d = 1; d <= K.max_depth; d++) {
     cx.sync();
     MZ_FOR(b, m.nbody) if (s.tp.body_depth[b] == d) gen_rne_body(K, s, b);
-  }
-  for (int d = K.max_depth - 1; d >= 1; d--) {
-    cx.sync();
-    MZ_FOR(p, m.nbody) if (s.tp.body_depth[p] == d)
-      for (int c = s.tp.child_first[p]; c >= 0; c = s.tp.child_next[c]) {
-        for (int k = 0; k < 10; k++) s.crb[p][k] += s.crb[c][k];
-        for (int e = 0; e < 6; e++) s.cfrc[p][e] += s.cfrc[c][e];
-      }
   }
   cx.sync();
 }
@@ -1124,14 +1142,13 @@ MZ_HD void gen_fluid_item(const GenDev& K, GenScratch& s, int b) {
 }
 MZ_HD void gen_force_item(const GenDev& K, GenScratch& s, int i) {
   const mz_model& m = K.m;
-  const double bias = gd_dot6(s.S[i], s.cfrc[s.tp.dof_bodyid[i]]);
+  const uint32_t sub = s.tp.subtree[s.tp.dof_bodyid[i]];
+  double f6[6] = {0, 0, 0, 0, 0, 0};  // force on the dof's subtree (mj_rne backward pass), summed here
+  for (uint32_t mk = sub; mk; mk &= mk - 1) { const double* f = s.cfrc[__builtin_ctz(mk)]; for (int e = 0; e < 6; e++) f6[e] += f[e]; }
+  const double bias = gd_dot6(s.S[i], f6);
   double pas = -m.dof_damping[i] * s.qvel[i];
   if (m.density > 0.0 || m.viscosity > 0.0)
-    for (int b = 1; b < m.nbody; b++) {  // dof i moves body b iff body(i) is b or an ancestor of b
-      bool hit = false;
-      for (int a = b; a > 0; a = s.tp.body_parent[a]) if (a == s.tp.dof_bodyid[i]) { hit = true; break; }
-      if (hit) pas += gd_dot6(s.S[i], s.ffl[b]);
-    }
+    for (uint32_t mk = sub; mk; mk &= mk - 1) pas += gd_dot6(s.S[i], s.ffl[__builtin_ctz(mk)]);  // dof i moves body b iff body(i) is b or an ancestor of b
   s.bias[i] = bias; s.passive[i] = pas;
   s.qfs[i] = pas - bias + s.fact[i];
 }
@@ -1258,7 +1275,8 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
     MZ_FOR(i, nv) c += 0.5 * gd_dotn_diff(s.M[i], x, s.qas, nv) * (x[i] - s.qas[i]);
     MZ_FOR(k, ncon) {
       double u[3];
-      for (int a = 0; a < 3; a++) u[a] = gd_dotn(gen_cj(s, nv, k, a), x, nv) - s.caref[k][a];
+      gd_dot3n(gen_cj(s, nv, k, 0), x, nv, u);
+      for (int a = 0; a < 3; a++) u[a] -= s.caref[k][a];
       c += gen_contact_eval(s.cD[k], u, nullptr, nullptr);
     }
     MZ_FOR(l, nlim) { const double jar = s.lsign[l] * x[s.ldof[l]] - s.laref[l]; if (jar < 0.0) c += 0.5 * s.lD[l] * jar * jar; }
@@ -1277,7 +1295,8 @@ MZ_HD void gen_solve(const C& cx, const GenDev& K, GenScratch& s) {
     MZ_FOR(i, nv) s.Mx[i] = gd_dotn_diff(s.M[i], s.qacc, s.qas, nv);
     MZ_FOR(k, ncon) {  // a contact's three residuals, and from them its gradient and Hessian weights — once, not once per entry that uses them
       double u[3];
-      for (int a = 0; a < 3; a++) { u[a] = gd_dotn(gen_cj(s, nv, k, a), s.qacc, nv) - s.caref[k][a]; s.cu[k][a] = u[a]; }
+      gd_dot3n(gen_cj(s, nv, k, 0), s.qacc, nv, u);
+      for (int a = 0; a < 3; a++) { u[a] -= s.caref[k][a]; s.cu[k][a] = u[a]; }
       gen_contact_eval(s.cD[k], u, s.cg[k], s.cW[k]);
     }
     MZ_FOR(l, nlim) s.ljar[l] = s.lsign[l] * s.qacc[s.ldof[l]] - s.laref[l];
@@ -1387,7 +1406,7 @@ MZ_HD void gen_forward(const C& cx, const GenDev& K, GenScratch& s) {
   {
     const int np = s.npool < GN_POOL ? s.npool : GN_POOL;
     double cnt = 0.0, lcnt = 0.0;
-    MZ_FOR(e, np) { const GenPair& P = K.item[s.pkey[e] / GN_KEY].P; if (s.pdist[e] < P.margin - P.gap) cnt += 1.0; gen_compact_item(K, s, e, np); }
+    MZ_FOR(e, np) { cnt += 1.0; gen_compact_item(K, s, e, np); }  // (every pool entry is an active contact: gen_collide_item's emit)
     MZ_FOR(e, 2 * K.nlimj) { gen_limit_flag(K, s, e); lcnt += (double)s.lflag[e]; }
     const int c = (int)cx.gsum(cnt), nl = (int)cx.gsum(lcnt);
     cx.sync();  // (the flags are visible)
