@@ -1656,7 +1656,8 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
       float g = s.Mx[i], ga = fabsf(g);
       int c0 = 0, c1 = s.ncon, col = i < 6 ? i : i - 8;
       if (i >= 6 && i < 14) { int l = (i - 6) >> 1; c0 = s.cbeg[l]; c1 = s.cbeg[l + 1]; col = NH + ((i - 6) & 1); }
-      for (int c = c0; c < c1; c++) {
+#pragma unroll 2
+      for (int c = c0; c < c1; c++) {  // (two contacts' loads in flight together)
         float g3[3];
         contact_eval(s.cD[c], s.cu[c], g3, nullptr);
         float t = s.cJ[c][0][col] * g3[0] + s.cJ[c][1][col] * g3[1] + s.cJ[c][2][col] * g3[2];
@@ -1698,8 +1699,19 @@ MZ_HD void ant_solve(const C& cx, const AntDev& K, AntScratchT<NB>& s, bool comp
         dst = &s.H.ll[l][t]; acc = s.M.ll[l][t];
         if (t != 1) acc += s.lact[2 * l + (t == 2 ? 1 : 0)];
       }
-      for (int c = c0; c < c1; c++)
-        acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
+      {  // (round 6) four contacts per round trip, into independent partial sums: rolled, with one accumulator, every contact of the
+         // range cost the lane a full LDS latency — and a three-block maze holds thirty of them per hub entry
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int c = c0;
+        for (; c + 4 <= c1; c += 4) {
+          acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
+          a1 += s.cJ[c + 1][0][ci] * s.cY[c + 1][0][cj] + s.cJ[c + 1][1][ci] * s.cY[c + 1][1][cj] + s.cJ[c + 1][2][ci] * s.cY[c + 1][2][cj];
+          a2 += s.cJ[c + 2][0][ci] * s.cY[c + 2][0][cj] + s.cJ[c + 2][1][ci] * s.cY[c + 2][1][cj] + s.cJ[c + 2][2][ci] * s.cY[c + 2][2][cj];
+          a3 += s.cJ[c + 3][0][ci] * s.cY[c + 3][0][cj] + s.cJ[c + 3][1][ci] * s.cY[c + 3][1][cj] + s.cJ[c + 3][2][ci] * s.cY[c + 3][2][cj];
+        }
+        for (; c < c1; c++) acc += s.cJ[c][0][ci] * s.cY[c][0][cj] + s.cJ[c][1][ci] * s.cY[c][1][cj] + s.cJ[c][2][ci] * s.cY[c][2][cj];
+        acc = (acc + a1) + (a2 + a3);
+      }
       *dst = acc;
     }
     cx.sync();

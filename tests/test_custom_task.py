@@ -193,6 +193,34 @@ def test_resampled_goals_reach_the_device(model_cls):
     env.close()
 
 
+@pytest.mark.gpu
+def test_per_env_goals_on_the_general_engine():
+    """The same per-env goal table through the general engine (a user robot: tests/user_robots.py): every env judged with its own goal."""
+    import torch
+
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+    from tests import user_robots
+
+    BipedAnt, _ = user_robots.robot_classes()
+    n = 16
+    env = VecMazeEnv(BipedAnt, MovingGoalCross, maze_size_scaling=4.0, num_envs=n, inner_reward_scaling=0.0)
+    assert env.launch_info()["engine"] == 1 and not env._host_rewards
+    env.reset(seed=0)
+    eg = env.env_goals.cpu().numpy()[:, 0, :2]
+    assert len({tuple(g) for g in eg}) == 2
+    q = env.get_state()[0].cpu().numpy()
+    near = np.arange(n) % 4 == 0
+    q[near, 0], q[near, 1] = eg[near, 0] - 0.5, eg[near, 1]
+    env.set_state(qpos=torch.as_tensor(q, device=env.device))
+    obs, rew, done, info = env.step(torch.zeros((n, env.nu), device=env.device))
+    o = obs.double().cpu().numpy()
+    want = np.linalg.norm(o[:, :2] - eg, axis=1) <= 0.8
+    assert want[near].all() and not want[~near].any()
+    assert np.array_equal((done.cpu().numpy() & 1).astype(bool), want)
+    assert np.array_equal(info["goal_index"].cpu().numpy(), np.where(want, 0, -1))
+    env.close()
+
+
 class RandomGoalCross(InheritedRewardCross):
     """Goal drawn uniformly along the east arm at every episode start (a continuous distribution: no two draws coincide)."""
 
