@@ -314,7 +314,10 @@ int32_t mz_bind_env_goals(mz_handle* h, const double* goal_pos_dev, void* stream
 int32_t mz_reset(mz_handle* h, const uint8_t* mask_dev, uint64_t seed, float* obs_dev, void* stream);
 
 /* State injection / read-back (row-major [N, nq], [N, nv], [N, nv], [N]).
- * Any pointer may be NULL to skip that field. */
+ * Any pointer may be NULL to skip that field.  warmstart = the constraint solver's starting guess carried between steps
+ * (MuJoCo's qacc_warmstart): the Ant and the general engine keep the last evaluation's qacc; the bare Point keeps its constraint part
+ * qacc - qacc_smooth (read back by mz_get_state; mz_set_state with a new qpos / qvel clears it — a guess only, results agree to the
+ * solver tolerance whatever it holds); the Swimmer / Reacher and the Point with movable bodies keep none (reads 0, writes ignored). */
 int32_t mz_set_state(mz_handle* h, const float* qpos_dev, const float* qvel_dev, const float* warmstart_dev,
                      const int32_t* t_dev, void* stream);
 int32_t mz_get_state(mz_handle* h, float* qpos_dev, float* qvel_dev, float* warmstart_dev, int32_t* t_dev,
