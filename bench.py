@@ -384,7 +384,16 @@ def main():
         one_step(i)
     for i in range(args.warmup):
         one_step(args.settle + i)
-    env.set_option("time_kernels", args.steps)
+    # HIP event pairs around the step kernel on its own stream, over the timed region — around every `stride`-th launch: a pair costs the
+    # queue 4.6 us per launch (7.6 with default event flags; profiles/r06/event_overhead.txt), 10 % of a Point or Swimmer step, and the
+    # instrument must not be what `value` measures.  kernel_ms = mean over the sampled launches (>= 5 of them even for --steps 20)
+    def time_every(k_steps):
+        stride = 8 if k_steps >= 64 else (4 if k_steps >= 20 else 1)
+        env.set_option("time_kernels", (k_steps + stride - 1) // stride)
+        env.set_option("time_kernels_stride", stride)
+        return stride
+
+    ev_stride = time_every(args.steps)
     dt = timed(args.steps)
     kernel_ms = env.kernel_ms()
     status = env.status()
@@ -394,7 +403,7 @@ def main():
     # loop once more over SUSTAINED_STEPS launches, NOT part of `value` / `ms_per_step`
     sustained = None
     if world == 1 and args.sustained > 0:
-        env.set_option("time_kernels", args.sustained)
+        time_every(args.sustained)
         dt_s = timed(args.sustained)
         sustained = {"value": n * args.sustained / dt_s, "kernel_ms": env.kernel_ms(), "ms_per_step": dt_s / args.sustained * 1e3, "steps": args.sustained,
                      "note": "same loop, run after the timed window; not part of value"}
@@ -436,7 +445,9 @@ def main():
                           if os.environ.get("MZ_BENCH_SINGLE_GPU") == "1" else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": kernel, "kernel_ms": kernel_ms, "kernel_ms_per_rank": kernel_ms_ranks, "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "kernel_ms_per_rank": kernel_ms_ranks,
+                         "kernel_ms_source": "HIP event pairs on the kernel's stream around every %d-th launch of the timed region (mz_last_kernel_ms)" % ev_stride,
+                         "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_per_env_step": per_env,
                          "traffic_source": traffic_source,
                          "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,

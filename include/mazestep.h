@@ -263,7 +263,8 @@ int32_t mz_nu(const mz_handle* h);
  * kernel, 2 = the kernel held to 256 registers so that two waves share a SIMD, 0 = default: by the wave count of the
  * launch — more waves than SIMDs takes the second), "profile_phases" (0/1: instrumented Ant kernel, see
  * mz_read_phase_cycles), "time_kernels" (n > 0: ring of n HIP event pairs around the step kernel, see
- * mz_last_kernel_ms). Returns MZ_OK, MZ_ERR_ARG, or MZ_ERR_UNSUPPORTED for an Ant-only key on another robot. */
+ * mz_last_kernel_ms), "time_kernels_stride" (k >= 1, default 1: only every k-th mz_step carries the pair — a pair costs the queue
+ * ~5 us per launch, a tenth of a Point or Swimmer step; bench.py samples every 8th). Returns MZ_OK, MZ_ERR_ARG, or MZ_ERR_UNSUPPORTED for an Ant-only key on another robot. */
 int32_t mz_set_option(mz_handle* h, const char* key, double value);
 
 /* What the next mz_step launches (ABI 8).  The kernel instantiation a handle steps with is chosen from the robot, its maze's

@@ -227,11 +227,18 @@ int32_t mz_set_option(mz_handle* h, const char* key, double value) {
   }
   if (!strcmp(key, "time_kernels")) {
     if (h->ev) { for (int i = 0; i < 2 * h->ntime; i++) (void)hipEventDestroy(h->ev[i]); free(h->ev); h->ev = nullptr; }
-    h->ntime = (int)value; h->itime = 0;
+    h->ntime = (int)value; h->itime = 0; h->time_phase = 0;
     if (h->ntime > 0) {
       h->ev = (hipEvent_t*)calloc((size_t)2 * h->ntime, sizeof(hipEvent_t));
-      for (int i = 0; i < 2 * h->ntime; i++) HIPCHK(h, hipEventCreate(&h->ev[i]));
+      // (no system-scope fence: the default event writes back and invalidates the caches at every record — the timestamps are read by this process
+      // after a synchronise, nothing on the host polls the memory the kernels write)
+      for (int i = 0; i < 2 * h->ntime; i++) HIPCHK(h, hipEventCreateWithFlags(&h->ev[i], hipEventDisableSystemFence));
     }
+    return MZ_OK;
+  }
+  if (!strcmp(key, "time_kernels_stride")) {  // time every k-th launch only: an event pair costs a small kernel 7.6 us of its 45 (profiles/r06/event_overhead.txt)
+    if (value < 1) return set_err(h, MZ_ERR_ARG, "time_kernels_stride must be >= 1", hipSuccess);
+    h->time_stride = (int)value; h->time_phase = 0;
     return MZ_OK;
   }
   return set_err(h, MZ_ERR_ARG, "unknown option", hipSuccess);
@@ -361,7 +368,7 @@ int32_t mz_step(mz_handle* h, const float* actions_dev, float* obs_dev, float* r
   DeviceScope scope(h->device);
   hipStream_t st = (hipStream_t)stream;
   int slot = -1;
-  if (h->ntime > 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
+  if (h->ntime > 0 && (h->time_phase++ % (h->time_stride > 0 ? h->time_stride : 1)) == 0) { slot = h->itime % h->ntime; HIPCHK(h, hipEventRecord(h->ev[2 * slot], st)); }
   if (h->robot == MZ_ROBOT_ANT) HIPCHK(h, mzk_ant_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
   else if (h->robot == MZ_ROBOT_GENERIC) HIPCHK(h, mzk_generic_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));
   else HIPCHK(h, mzk_planar_step(h, st, actions_dev, obs_dev, reward_dev, done_dev, goal_idx_dev, info_dev));

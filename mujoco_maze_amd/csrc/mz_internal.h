@@ -49,6 +49,7 @@ struct mz_handle {
   int simds;      // 4 x the device's compute units, read once in mz_create: the batch-size rules of the launch shapes compare wave counts with it
   // kernel timing ring (option "time_kernels")
   int ntime, itime;
+  int time_stride, time_phase;  // option "time_kernels_stride": every k-th launch carries the event pair
   hipEvent_t* ev;  // 2 * ntime
   long nsteps;
 };
