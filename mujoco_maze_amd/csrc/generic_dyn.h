@@ -42,7 +42,7 @@
 // collision item kinds (geom1 -> geom2 in MuJoCo's order: by type, then by id; the maze boxes are world geoms with ids below
 // every robot geom's)
 enum { GK_PLANE_SPHERE = 0, GK_PLANE_CAPSULE, GK_PLANE_BOX, GK_SPHERE_SPHERE, GK_SPHERE_CAPSULE, GK_SPHERE_BOX, GK_CAPSULE_BOX, GK_BOX_BOX,
-       GK_SPHERE_WALL, GK_CAPSULE_WALL, GK_WALL_BOX };
+       GK_SPHERE_WALL, GK_CAPSULE_WALL, GK_WALL_BOX, GK_CAPSULE_CAPSULE };
 // step shapes (mz_model.step_kind; 0 = the robot family's)
 #define GN_STEP_MOTORS 1  // ant.py:61-73 / swimmer.py:37-48: clamped motors, frame_skip x mj_step, forward reward, control cost
 #define GN_STEP_POINT 2   // point.py:44-61: heading += a[1] (wrapped), teleport a[0] along it, velocity clip, no control, no inner reward
@@ -131,10 +131,9 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
       int kind = -1;
       if (t1 == MZ_GEOM_PLANE) kind = t2 == MZ_GEOM_SPHERE ? GK_PLANE_SPHERE : t2 == MZ_GEOM_CAPSULE ? GK_PLANE_CAPSULE : t2 == MZ_GEOM_BOX ? GK_PLANE_BOX : -1;
       else if (t1 == MZ_GEOM_SPHERE) kind = t2 == MZ_GEOM_SPHERE ? GK_SPHERE_SPHERE : t2 == MZ_GEOM_CAPSULE ? GK_SPHERE_CAPSULE : t2 == MZ_GEOM_BOX ? GK_SPHERE_BOX : -1;
-      else if (t1 == MZ_GEOM_CAPSULE) kind = t2 == MZ_GEOM_BOX ? GK_CAPSULE_BOX : -1;
+      else if (t1 == MZ_GEOM_CAPSULE) kind = t2 == MZ_GEOM_BOX ? GK_CAPSULE_BOX : t2 == MZ_GEOM_CAPSULE ? GK_CAPSULE_CAPSULE : -1;
       else if (t1 == MZ_GEOM_BOX) kind = t2 == MZ_GEOM_BOX ? GK_BOX_BOX : -1;
-      if (kind < 0) return gen_fail(err, errlen, "general engine: a geom pair that can collide has no narrow phase here (capsule-capsule: give the robot's own "
-                                                 "geoms conaffinity 0, as the reference assets do; geom types: plane, sphere, capsule, box)");
+      if (kind < 0) return gen_fail(err, errlen, "general engine: a geom pair that can collide has no narrow phase here (geom types: plane, sphere, capsule, box)");
       if (n >= GN_NI) return gen_fail(err, errlen, "general engine: too many geom pairs");
       GenItem& it = g->item[n++];
       it.kind = kind; it.g1 = g1; it.g2 = g2; it.b1 = m->geom_bodyid[g1]; it.b2 = m->geom_bodyid[g2]; it.pad = 0;
@@ -513,6 +512,46 @@ MZ_HD void gen_mass_item(const GenDev& K, GenScratch& s, int i) {
 }
 
 // ------------------------------------------------------------------ narrow phase
+// two spheres (mjraw_SphereSphere): normal from the first to the second; returns the number of contacts emitted
+template <class E>
+MZ_HD int gen_sphere_pair(const double* c1, double r1, const double* c2, double r2, double margin, E& emit) {
+  const double dv[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]}, cd = sqrt(gd_dot3(dv, dv)), dist = cd - r1 - r2;
+  if (dist > margin) return 0;
+  double nrm[3] = {1.0, 0.0, 0.0}, pos[3];
+  if (!(cd < 1e-15)) for (int k = 0; k < 3; k++) nrm[k] = dv[k] / cd;
+  for (int k = 0; k < 3; k++) pos[k] = c1[k] + nrm[k] * (r1 + 0.5 * dist);
+  emit(dist, pos, nrm, nullptr);
+  return 1;
+}
+// capsule vs capsule (mjraw_CapsuleCapsule as restated in oracle/mzo_physics.c capsule_capsule): nearest points of the axis segments, clamped
+// one coordinate after the other, then sphere-sphere; parallel axes: the segment ends, up to two contacts
+template <class E>
+MZ_HD void gen_capsule_vs_capsule(const double* pos1, const double* mat1, double r1, double hl1, const double* pos2, const double* mat2, double r2,
+                                  double hl2, double margin, E& emit) {
+  const double a1[3] = {mat1[2] * hl1, mat1[5] * hl1, mat1[8] * hl1}, a2[3] = {mat2[2] * hl2, mat2[5] * hl2, mat2[8] * hl2};
+  const double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  const double ma = gd_dot3(a1, a1), mb = -gd_dot3(a1, a2), mc = gd_dot3(a2, a2), u = -gd_dot3(a1, dif), v = gd_dot3(a2, dif), det = ma * mc - mb * mb;
+  auto clamp1 = [](double x) { return x > 1.0 ? 1.0 : (x < -1.0 ? -1.0 : x); };
+  auto pair_at = [&](double x1, double x2) {
+    const double v1[3] = {pos1[0] + a1[0] * x1, pos1[1] + a1[1] * x1, pos1[2] + a1[2] * x1}, v2[3] = {pos2[0] + a2[0] * x2, pos2[1] + a2[1] * x2, pos2[2] + a2[2] * x2};
+    return gen_sphere_pair(v1, r1, v2, r2, margin, emit);
+  };
+  if (fabs(det) >= 1e-15) {
+    double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > 1.0) { x1 = 1.0; x2 = (v - mb) / mc; }
+    else if (x1 < -1.0) { x1 = -1.0; x2 = (v + mb) / mc; }
+    if (x2 > 1.0) { x2 = 1.0; x1 = clamp1((u - mb) / ma); }
+    else if (x2 < -1.0) { x2 = -1.0; x1 = clamp1((u + mb) / ma); }
+    pair_at(x1, x2);
+    return;
+  }
+  int n = pair_at(1.0, clamp1((v - mb) / mc));
+  n += pair_at(-1.0, clamp1((v + mb) / mc));
+  if (n >= 2) return;
+  n += pair_at(clamp1((u - mb) / ma), 1.0);
+  if (n >= 2) return;
+  pair_at(clamp1((u + mb) / ma), -1.0);
+}
 // sphere (centre c in box coordinates) vs axis-aligned box; normal from the sphere to the box (mjraw_SphereBox)
 MZ_HD bool gen_sphere_box(const double* c, double r, const double* bs, double margin, double* dist, double* pos, double* nrm) {
   double q[3], dd;
@@ -889,6 +928,11 @@ MZ_HD void gen_collide_item(const GenDev& K, GenScratch& s, int it) {
     if (!(cd < 1e-15)) for (int k = 0; k < 3; k++) nrm[k] = dv[k] / cd;
     for (int k = 0; k < 3; k++) pos[k] = c1[k] + nrm[k] * (r1 + 0.5 * dist);
     emit(dist, pos, nrm, nullptr);
+    return;
+  }
+  if (I.kind == GK_CAPSULE_CAPSULE) {
+    gen_capsule_vs_capsule(s.gpos[I.g1], s.gmat[I.g1], m.geom_size[I.g1][0], m.geom_size[I.g1][1], s.gpos[I.g2], s.gmat[I.g2], m.geom_size[I.g2][0],
+                           m.geom_size[I.g2][1], margin, emit);
     return;
   }
   if (I.kind == GK_SPHERE_BOX) { gen_sphere_vs_box(s.gpos[I.g1], m.geom_size[I.g1][0], s.gpos[I.g2], s.gmat[I.g2], m.geom_size[I.g2], margin, emit); return; }

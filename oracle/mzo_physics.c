@@ -5,7 +5,7 @@
  * gym's do_simulation, mujoco_maze/point.py:57-59, swimmer.py:39):
  * kinematics, joint-space inertia (composite rigid body), bias forces
  * (recursive Newton-Euler), passive damping, motor actuation with ctrl clamp,
- * collision (plane-sphere, plane-capsule, sphere-box, capsule-box), joint-limit
+ * collision (plane-sphere, plane-capsule, sphere-box, capsule-box, capsule-capsule), joint-limit
  * and pyramidal-cone contact constraints with MuJoCo's impedance / reference-
  * acceleration model, the primal Newton solver, and RK4 integration with
  * manifold quaternion update.
@@ -926,6 +926,52 @@ static void collide_walls(const mz_model* m, mzo_data* d, int g) {
     }
 }
 
+/* two spheres (mjraw_SphereSphere): normal from the first to the second; returns the number of contacts added */
+static int sphere_pair(mzo_data* d, const pairparam* pp, const double* c1, double r1, const double* c2, double r2) {
+  double dv[3], pos[3], nrm[3];
+  sub3(dv, c2, c1);
+  const double cd = norm3(dv), dist = cd - r1 - r2;
+  if (dist > pp->margin) return 0;
+  if (cd < MINVAL) { nrm[0] = 1.0; nrm[1] = 0.0; nrm[2] = 0.0; }
+  else { nrm[0] = dv[0] / cd; nrm[1] = dv[1] / cd; nrm[2] = dv[2] / cd; }
+  for (int k = 0; k < 3; k++) pos[k] = c1[k] + nrm[k] * (r1 + 0.5 * dist);
+  add_contact(d, pp, dist, pos, nrm, NULL);
+  return 1;
+}
+
+/* capsule vs capsule (MuJoCo engine_collision_primitive.c mjraw_CapsuleCapsule, restated): the nearest points of the two axis segments
+ * — the unconstrained minimiser of |p1 + x1 a1 - p2 - x2 a2|^2, clamped to [-1, 1] one coordinate after the other — then sphere-sphere
+ * between them; parallel axes (|det| < mjMINVAL): the segment ends, up to two contacts.  a1, a2: axes scaled by the half lengths. */
+static void capsule_capsule(mzo_data* d, const pairparam* pp, const double* pos1, const double* mat1, double r1, double hl1,
+                            const double* pos2, const double* mat2, double r2, double hl2) {
+  const double a1[3] = {mat1[2] * hl1, mat1[5] * hl1, mat1[8] * hl1}, a2[3] = {mat2[2] * hl2, mat2[5] * hl2, mat2[8] * hl2};
+  double dif[3], v1[3], v2[3];
+  sub3(dif, pos1, pos2);
+  const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = ma * mc - mb * mb;
+#define MZO_CLAMP1(x) ((x) > 1.0 ? 1.0 : ((x) < -1.0 ? -1.0 : (x)))
+#define MZO_PTS(x1, x2) do { for (int k = 0; k < 3; k++) { v1[k] = pos1[k] + a1[k] * (x1); v2[k] = pos2[k] + a2[k] * (x2); } } while (0)
+  if (fabs(det) >= MINVAL) {
+    double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > 1.0) { x1 = 1.0; x2 = (v - mb) / mc; }
+    else if (x1 < -1.0) { x1 = -1.0; x2 = (v + mb) / mc; }
+    if (x2 > 1.0) { x2 = 1.0; x1 = MZO_CLAMP1((u - mb) / ma); }
+    else if (x2 < -1.0) { x2 = -1.0; x1 = MZO_CLAMP1((u + mb) / ma); }
+    MZO_PTS(x1, x2);
+    sphere_pair(d, pp, v1, r1, v2, r2);
+    return;
+  }
+  int n = 0;
+  double x;
+  x = MZO_CLAMP1((v - mb) / mc); MZO_PTS(1.0, x); n += sphere_pair(d, pp, v1, r1, v2, r2);   /* x1 = 1 */
+  x = MZO_CLAMP1((v + mb) / mc); MZO_PTS(-1.0, x); n += sphere_pair(d, pp, v1, r1, v2, r2);  /* x1 = -1 */
+  if (n >= 2) return;
+  x = MZO_CLAMP1((u - mb) / ma); MZO_PTS(x, 1.0); n += sphere_pair(d, pp, v1, r1, v2, r2);   /* x2 = 1 */
+  if (n >= 2) return;
+  x = MZO_CLAMP1((u + mb) / ma); MZO_PTS(x, -1.0); sphere_pair(d, pp, v1, r1, v2, r2);       /* x2 = -1 */
+#undef MZO_PTS
+#undef MZO_CLAMP1
+}
+
 /* explicit non-plane pairs: robot sphere / capsule against a movable block's box, block against block */
 static void collide_pair(const mz_model* m, mzo_data* d, int ga, int gb) {
   int g1 = ga, g2 = gb;
@@ -961,6 +1007,9 @@ static void collide_pair(const mz_model* m, mzo_data* d, int ga, int gb) {
     else { nrm[0] = dv[0] / cd; nrm[1] = dv[1] / cd; nrm[2] = dv[2] / cd; }
     for (int k = 0; k < 3; k++) pos[k] = d->geom_xpos[g1][k] + nrm[k] * (r1 + 0.5 * dist);
     add_contact(d, &pp, dist, pos, nrm, NULL);
+  } else if (t1 == MZ_GEOM_CAPSULE && t2 == MZ_GEOM_CAPSULE) { /* a robot's own limbs against each other, same type: geom1 = the lower id */
+    capsule_capsule(d, &pp, d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1][0], m->geom_size[g1][1], d->geom_xpos[g2], d->geom_xmat[g2],
+                    m->geom_size[g2][0], m->geom_size[g2][1]);
   } else if (t2 == MZ_GEOM_BOX && t1 == MZ_GEOM_SPHERE) {
     double dist, pos[3], nrm[3];
     if (sphere_box(d->geom_xpos[g1], m->geom_size[g1][0], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], pp.margin, &dist, pos, nrm))
@@ -993,7 +1042,7 @@ static void collision(const mz_model* m, mzo_data* d) {
 }
 
 /* Narrow-phase probes (tests/test_narrowphase_probes.py, tests/test_mujoco_crosscheck.py): one routine on one hand-made pose.
- * kind 0 capsule (geom1: pos, mat, size = radius, half length) vs box (geom2); 1 box vs box; 2 sphere (size[0]) vs box.
+ * kind 0 capsule (geom1: pos, mat, size = radius, half length) vs box (geom2); 1 box vs box; 2 sphere (size[0]) vs box; 3 capsule vs capsule.
  * out: per contact 7 doubles dist | pos | normal (geom1 -> geom2); returns the contact count. */
 int mzo_probe_pair(int kind, const double* pos1, const double* mat1, const double* size1, const double* pos2, const double* mat2,
                    const double* size2, double margin, int max_con, double* out) {
@@ -1004,6 +1053,7 @@ int mzo_probe_pair(int kind, const double* pos1, const double* mat1, const doubl
   pp.margin = margin; pp.mu = 1.0; pp.condim = 3;
   memcpy(pp.solref, sr, sizeof(sr)); memcpy(pp.solimp, si, sizeof(si));
   if (kind == 0) capsule_box(d, &pp, pos1, mat1, size1[0], size1[1], pos2, mat2, size2);
+  else if (kind == 3) capsule_capsule(d, &pp, pos1, mat1, size1[0], size1[1], pos2, mat2, size2[0], size2[1]);
   else if (kind == 1) box_box(d, &pp, pos1, mat1, size1, pos2, mat2, size2);
   else {
     double dist, cp[3], nrm[3];

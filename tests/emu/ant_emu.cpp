@@ -397,7 +397,8 @@ extern "C" int emu_probe_pair(int kind, const double* pos1, const double* mat1, 
   if (kind == 0) {
     const double axis[3] = {mat1[2], mat1[5], mat1[8]};
     gen_capsule_vs_box(pos1, axis, size1[0], size1[1], pos2, mat2, size2, margin, emit);
-  } else if (kind == 1) gen_box_vs_box(pos1, mat1, size1, pos2, mat2, size2, margin, emit);
+  } else if (kind == 3) gen_capsule_vs_capsule(pos1, mat1, size1[0], size1[1], pos2, mat2, size2[0], size2[1], margin, emit);
+  else if (kind == 1) gen_box_vs_box(pos1, mat1, size1, pos2, mat2, size2, margin, emit);
   else gen_sphere_vs_box(pos1, size1[0], pos2, mat2, size2, margin, emit);
   return n;
 }

@@ -1,5 +1,5 @@
 """Fixed probe poses for the narrow-phase routines restated from MuJoCo (oracle/mzo_physics.c: capsule_box = mjc_CapsuleBox,
-box_box = mjc_BoxBox, plane-box inside collide_plane = mjc_PlaneBox) with the contact sets DERIVED BY HAND
+box_box = mjc_BoxBox, capsule_capsule = mjc_CapsuleCapsule, plane-box inside collide_plane = mjc_PlaneBox) with the contact sets DERIVED BY HAND
 from the routines' documented construction (closest feature, second support point, face clipping).  Shared by
 tests/test_narrowphase_probes.py (the oracle must produce exactly these) and tests/test_mujoco_crosscheck.py (real MuJoCo,
 where available, must produce them too — a per-routine verdict on the restatement).
@@ -88,6 +88,16 @@ def probes():
     out.append(("two cubes crossing edge on edge (mjc_BoxBox's edge-edge case): one contact midway, normal along edge x edge", "box_box",
                 ([0, 0, 0], roty(np.pi / 4), CUBE), ([0, 0, 2 * h - 0.01], rotx(np.pi / 4), CUBE), 0.0,
                 [[-0.01, 0, 0, h - 0.005, 0, 0, 1]]))
+    # ---- mjc_CapsuleCapsule: nearest points of the two axis segments, then sphere-sphere; parallel axes: the ends of the overlap
+    capy = np.array([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]])  # geom z axis -> +y
+    out.append(("capsules crossing at right angles, 0.25 apart: one contact between the axes", "capsule_capsule",
+                ([0, 0, 0], CAPX, CAP), ([0, 0, 0.25], capy, CAP), 0.1, [[0.05, 0, 0, 0.125, 0, 0, 1]]))
+    out.append(("parallel capsules, shifted by 0.2 along the axis: the two ends of the stretch they share", "capsule_capsule",
+                ([0, 0, 0], CAPX, CAP), ([0.2, 0, 0.25], CAPX, CAP), 0.1, [[0.05, 0.5, 0, 0.125, 0, 0, 1], [0.05, -0.3, 0, 0.125, 0, 0, 1]]))
+    nn = np.array([0.3, 0.0, 0.2]) / np.hypot(0.3, 0.2)
+    dd = np.hypot(0.3, 0.2) - 0.2
+    out.append(("skew capsules, both nearest points clamped to segment ends", "capsule_capsule",
+                ([0, 0, 0], CAPX, CAP), ([0.8, 0, 0.7], I3, CAP), 0.2, [[dd, *(np.array([0.5, 0, 0]) + nn * (0.1 + 0.5 * dd)), *nn]]))
     return out
 
 

@@ -53,7 +53,7 @@ class Oracle:
 
     def probe_pair(self, kind, pos1, mat1, size1, pos2, mat2, size2, margin):
         """One narrow-phase routine on one pose ('capsule_box' | 'box_box' | 'sphere_box'): array [ncon, 7] = dist | pos | normal."""
-        k = {"capsule_box": 0, "box_box": 1, "sphere_box": 2}[kind]
+        k = {"capsule_box": 0, "box_box": 1, "sphere_box": 2, "capsule_capsule": 3}[kind]
         a = [np.ascontiguousarray(x, np.float64).ravel() for x in (pos1, mat1, size1, pos2, mat2, size2)]
         a[2] = np.resize(a[2], 3) if a[2].size < 3 else a[2]
         out = np.zeros((16, 7))

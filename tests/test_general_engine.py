@@ -246,6 +246,25 @@ def test_user_robot_with_a_box_geom_in_a_block_maze(oracle):
     assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 3, 8)) > 20
 
 
+def test_user_robot_whose_limbs_collide_with_each_other(oracle):
+    """MuJoCo's default collision rule (every geom pair but parent-child) on a user robot: the arms of tests/user_robots.py PINCER close
+    onto each other and a third arm's ball comes down on them — capsule-capsule (mjc_CapsuleCapsule) and sphere-capsule contacts between
+    sibling bodies of ONE robot, two-body Jacobians; kernel code (host build) against the oracle."""
+    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.PINCER, frame_skip=2, reset_qvel="normal")
+    m = cm.c
+    assert m.nv == 9 and m.nu == 3
+    n = 12
+    st, _ = oracle.reset(cm, n, 4)
+    rng = np.random.default_rng(2)
+    st["qpos"][:, 7] = -rng.uniform(0.10, 0.22, n)   # left arm swung towards -y ...
+    st["qpos"][:, 8] = rng.uniform(0.10, 0.22, n)    # ... right arm towards +y: the arms cross / press near their tips
+    st["qpos"][:, 9] = rng.uniform(0.15, 0.30, n)    # the top arm lowered: its ball between / on the arms
+    pairs = oracle.forward(cm, st["qpos"], st["qvel"], np.zeros((n, 3)), st["warm"])["counts"][:, 0]
+    assert pairs.min() >= 1  # (every env has a limb-limb contact to begin with; the bar floats 0.2 above the floor)
+    acts = [np.column_stack([-rng.uniform(2, 10, n), rng.uniform(2, 10, n), rng.uniform(0, 10, n)]) for _ in range(8)]
+    assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 1, 3, 7)) > 30
+
+
 def test_plane_box_with_tilted_corners(oracle):
     """mjc_PlaneBox for a box of general orientation, through the model path: the SPIN plate of SpinUMaze/ant (half sizes 0.4, 0.4,
     0.2, centre 0.2 above the floor) tilted by 0.1 rad about y.  By hand: a corner (sx 0.4, sy 0.4, sz 0.2) sits at height
@@ -269,8 +288,8 @@ def test_plane_box_with_tilted_corners(oracle):
 
 
 def test_general_engine_narrow_phase_equals_the_oracles_on_random_poses(oracle):
-    """csrc/generic_dyn.h gen_sphere_vs_box / gen_capsule_vs_box / gen_box_vs_box (host build, tests/emu) against the oracle's
-    routines on 6000 random poses of boxes of general orientation — same contact count, same order, 1e-12."""
+    """csrc/generic_dyn.h gen_sphere_vs_box / gen_capsule_vs_box / gen_box_vs_box / gen_capsule_vs_capsule (host build, tests/emu) against the
+    oracle's routines on 8000 random poses of boxes of general orientation — same contact count, same order, 1e-12."""
     import ctypes as C
     from tests import emu_lib
 
@@ -279,10 +298,10 @@ def test_general_engine_narrow_phase_equals_the_oracles_on_random_poses(oracle):
     lib.emu_probe_pair.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_double, C.c_int, C.c_void_p]
     vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     rng = np.random.default_rng(0)
-    kinds = ["capsule_box", "box_box", "sphere_box"]
-    seen = [0, 0, 0]
-    for it in range(6000):
-        kind = it % 3
+    kinds = ["capsule_box", "box_box", "sphere_box", "capsule_capsule"]
+    seen = [0, 0, 0, 0]
+    for it in range(8000):
+        kind = it % 4
         q1, q2 = rng.normal(size=4), rng.normal(size=4)
         m1 = np.ascontiguousarray(model.quat_to_mat(q1 / np.linalg.norm(q1)))
         m2 = np.eye(3) if it % 5 == 0 else np.ascontiguousarray(model.quat_to_mat(q2 / np.linalg.norm(q2)))

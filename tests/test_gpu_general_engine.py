@@ -192,6 +192,27 @@ def test_user_robot_with_boxes_in_a_block_maze_on_the_device(torch, oracle):
     env.close()
 
 
+def test_user_robot_whose_limbs_collide_on_the_device(torch, oracle):
+    """MuJoCo's default collision rule on a user robot (tests/user_robots.py PINCER: every geom pair but parent-child): capsule-capsule
+    (mjc_CapsuleCapsule) and sphere-capsule contacts between sibling bodies of one robot, on the device, equal to the oracle at 1e-6."""
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+    from tests import user_robots
+
+    n = 256
+    env = VecMazeEnv(user_robots.pincer_class(), T.DistRewardUMaze, num_envs=n, maze_size_scaling=4.0)
+    cm, m = env.model, env.model.c
+    assert env.launch_info()["engine"] == 1 and m.nv == 9
+    st, _ = oracle.reset(cm, n, 4)
+    rng = np.random.default_rng(2)
+    st["qpos"][:, 7] = -rng.uniform(0.10, 0.22, n)
+    st["qpos"][:, 8] = rng.uniform(0.10, 0.22, n)
+    st["qpos"][:, 9] = rng.uniform(0.15, 0.30, n)
+    acts = [np.column_stack([-rng.uniform(2, 10, n), rng.uniform(2, 10, n), rng.uniform(0, 10, n)]) for _ in range(12)]
+    contacts = _step_against_oracle(torch, oracle, env, st, acts, checks=(0, 2, 11), max_outlier_frac=0.02)
+    assert contacts > 600
+    env.close()
+
+
 def test_general_engine_top_down_view_and_record(torch, oracle):
     """TOP_DOWN_VIEW tasks and the sharded run's packed record on the general engine: view entries filled from the row's own robot /
     block positions, time entry behind the view, record = obs | reward | done."""

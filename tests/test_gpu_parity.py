@@ -1447,3 +1447,27 @@ def test_instrumented_kernel_steps_like_the_product_kernel(torch, env_id, n, lan
         env.close()
     for a, b in zip(*outs):  # (two instantiations: the compiler contracts their arithmetic differently — the same step to round-off, not to the bit)
         assert np.allclose(a[:, :-1], b[:, :-1], atol=1e-4, rtol=1e-5) and np.array_equal(a[:, -1], b[:, -1])
+
+def test_kernel_timing_ring_and_its_stride(torch):
+    """Options "time_kernels" / "time_kernels_stride" (bench.py's roofline.kernel_ms): HIP event pairs around the step kernel on its own
+    stream, around every k-th launch only when asked — a pair around EVERY launch costs the queue ~5 us, a tenth of a Point step
+    (profiles/r06/event_overhead.txt).  The sampled mean agrees with the all-launches mean; no ring -> -1."""
+    env = mm.make("PointUMaze-v0", num_envs=2048, auto_reset=True)
+    env.reset(seed=1)
+    a = torch.zeros((2048, 2), device=env.device)
+    assert env.kernel_ms() == -1.0
+    for _ in range(50):
+        env.step(a)
+    env.set_option("time_kernels", 64)
+    for _ in range(64):
+        env.step(a)
+    every = env.kernel_ms()
+    env.set_option("time_kernels", 16)
+    env.set_option("time_kernels_stride", 4)
+    for _ in range(64):
+        env.step(a)
+    sampled = env.kernel_ms()
+    assert 0.005 < every < 1.0 and 0.005 < sampled < 1.0 and abs(sampled - every) < 0.25 * every, (every, sampled)
+    with pytest.raises(Exception):
+        env.set_option("time_kernels_stride", 0)
+    env.close()

@@ -88,6 +88,59 @@ BRANCHING_SWIMMER = """
 """
 
 
+# a robot whose own limbs collide (MuJoCo's default: every geom pair but parent-child, contype = conaffinity = 1): two arms hinged side by side
+# on a free-floating bar close onto each other — capsule-capsule contacts between sibling bodies, and a ball on a third arm for sphere-capsule
+PINCER = """
+<mujoco model="pincer">
+  <compiler angle="degree" coordinate="local" inertiafromgeom="true"/>
+  <option integrator="RK4" timestep="0.01"/>
+  <default>
+    <joint armature="0.5" damping="0.5" limited="true"/>
+    <geom contype="1" conaffinity="1" condim="3" density="20.0" friction="1 0.5 0.5" margin="0.01" solimp="0.9 0.95 0.001" solref="0.02 1"/>
+    <motor ctrllimited="true" ctrlrange="-10 10"/>
+  </default>
+  <worldbody>
+    <geom name="floor" type="plane" size="40 40 40"/>
+    <body name="bar" pos="0 0 0.3">
+      <geom name="bar_geom" type="capsule" size="0.1" fromto="-0.3 0 0 0.3 0 0"/>
+      <freejoint name="root"/>
+      <body name="left_arm" pos="0.3 0.15 0">
+        <joint name="left_hinge" type="hinge" axis="0 0 1" pos="0 0 0" range="-60 30"/>
+        <geom name="left_arm_geom" type="capsule" size="0.06" fromto="0.12 0 0 0.6 0 0"/>
+      </body>
+      <body name="right_arm" pos="0.3 -0.15 0">
+        <joint name="right_hinge" type="hinge" axis="0 0 1" pos="0 0 0" range="-30 60"/>
+        <geom name="right_arm_geom" type="capsule" size="0.06" fromto="0.12 0 0 0.6 0 0"/>
+      </body>
+      <body name="top_arm" pos="0.3 0 0.12">
+        <joint name="top_hinge" type="hinge" axis="0 1 0" pos="0 0 0" range="-20 60"/>
+        <geom name="top_arm_geom" type="capsule" size="0.04" fromto="0.12 0 0 0.4 0 0"/>
+        <geom name="top_ball" type="sphere" size="0.07" pos="0.5 0 0"/>
+      </body>
+    </body>
+  </worldbody>
+  <actuator>
+    <motor joint="left_hinge" gear="1"/>
+    <motor joint="right_hinge" gear="1"/>
+    <motor joint="top_hinge" gear="1"/>
+  </actuator>
+</mujoco>
+"""
+
+
+def pincer_class():
+    from mujoco_maze_amd.agent_model import AgentModel
+
+    class Pincer(AgentModel):
+        ROBOT = "generic"
+        FILE = PINCER
+        MANUAL_COLLISION = False
+        FRAME_SKIP = 2
+        RESET_QVEL = "normal"
+
+    return Pincer
+
+
 def robot_classes():
     from mujoco_maze_amd.agent_model import AgentModel
 
