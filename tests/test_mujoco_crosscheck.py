@@ -110,15 +110,15 @@ def _probe_geom_xml(name, kind_is_capsule, g, sphere=False):
 
 def test_narrowphase_probes_against_mujoco():
     """Per-routine verdict on the restated narrow phase: the hand-derived contact sets of tests/narrowphase_probes.py (which the
-    oracle reproduces exactly, tests/test_narrowphase_probes.py) against mjc_CapsuleBox / mjc_BoxBox themselves.  Each probe is
+    oracle reproduces exactly, tests/test_narrowphase_probes.py) against mjc_CapsuleBox / mjc_BoxBox / mjc_CapsuleCapsule themselves.  Each probe is
     a two-geom model: geom1 on a free body, geom2 in the world (both static for mj_forward's collision stage)."""
     from tests import narrowphase_probes as NP
 
     verdict = {}
     for name, kind, g1, g2, margin, want in NP.probes():
         xml = f"""<mujoco><option gravity="0 0 0"/><default><geom margin="{margin}" contype="1" conaffinity="1"/></default><worldbody>
-          <body name="a">{_probe_geom_xml("g1", kind == "capsule_box", g1, sphere=kind == "sphere_box")}<freejoint/></body>
-          {_probe_geom_xml("g2", False, g2)}</worldbody></mujoco>"""
+          <body name="a">{_probe_geom_xml("g1", kind in ("capsule_box", "capsule_capsule"), g1, sphere=kind == "sphere_box")}<freejoint/></body>
+          {_probe_geom_xml("g2", kind == "capsule_capsule", g2)}</worldbody></mujoco>"""
         model = mujoco.MjModel.from_xml_string(xml)
         data = mujoco.MjData(model)
         mujoco.mj_forward(model, data)
