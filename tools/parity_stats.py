@@ -41,6 +41,31 @@ def oracle_sensitive(cm, start, act, ref_qvel, e, rng, atol=1e-5):
 # `parity_stats.py long`: the large-sample version (4 x the envs, a checkpoint every 10 steps of a 300-step rollout; the Push / Fall
 # mazes every 10 steps of 100) — minutes of oracle time on the GPU box's host cores, written to profiles/<round>/parity_long.md
 LONG = len(sys.argv) > 1 and sys.argv[1] == "long"
+# `parity_stats.py general`: the general engine (csrc/generic_dyn.h) — registered ids forced onto it ("!general"), the SPIN-plate mazes of
+# tests/test_general_engine.py ("spin:<task>/<robot>") and the user robots of tests/user_robots.py ("user:<robot>/<task class>")
+if len(sys.argv) > 1 and sys.argv[1] == "general":
+    CONFIGS = [("AntUMaze-v0!general", 512, (0, 1, 10, 50, 100)), ("AntPush-v0!general", 256, (0, 10, 50)), ("AntFall-v0!general", 256, (5, 20, 60)),
+               ("PointUMaze-v0!general", 1024, (0, 1, 10, 50, 100)), ("PointPush-v0!general", 512, (0, 10, 50, 100)), ("SwimmerUMaze-v0!general", 1024, (0, 10, 100)),
+               ("spin:SpinUMaze/ant", 256, (0, 1, 10, 30)), ("spin:SpinCellMaze/ant", 256, (0, 1, 10, 30)), ("spin:SpinUMaze/point", 512, (0, 1, 10, 30)),
+               ("user:BipedAnt/DistRewardPush", 256, (0, 10, 50)), ("user:BipedAnt/GoalRewardUMaze", 512, (0, 10, 50, 100)), ("user:Pincer/DistRewardUMaze", 512, (0, 10, 50))]
+
+
+def make_env(env_id, n):
+    if env_id.startswith("spin:") or env_id.startswith("user:"):
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from mujoco_maze_amd import maze_task as T
+        from mujoco_maze_amd.maze_env import VecMazeEnv
+        from tests import user_robots
+        what, task = env_id[5:].split("/")
+        if env_id.startswith("spin:"):
+            from tests.test_general_engine import SPIN_TASKS
+            return VecMazeEnv(mm.AntEnv if task == "ant" else mm.PointEnv, SPIN_TASKS[what], num_envs=n, maze_size_scaling=4.0)
+        cls = user_robots.pincer_class() if what == "Pincer" else user_robots.robot_classes()[0]
+        return VecMazeEnv(cls, getattr(T, task), num_envs=n, maze_size_scaling=4.0)
+    kw = {"maze_size_scaling": float(env_id.split("@")[1].split("!")[0])} if "@" in env_id else {}
+    if env_id.endswith("!general"):
+        kw["engine"] = "general"
+    return mm.make(env_id.split("@")[0].split("+")[0].split("!")[0], num_envs=n, force_vec=True, **kw)
 if LONG:
     CONFIGS = [(e, 4 * n, tuple(range(0, (301 if max(c) >= 100 else 101), 10))) for e, n, c in CONFIGS]
 # experiments: MZ_PS_CONFIGS="AntUMaze-v0,AntPush-v0" keeps those configs, MZ_PS_OPTS="ls_iterations=0,max_iterations=60" sets handle options
@@ -49,7 +74,8 @@ if os.environ.get("MZ_PS_CONFIGS"):
 OPTS = [kv.split("=") for kv in os.environ.get("MZ_PS_OPTS", "").split(",") if kv]
 for env_id, n, checks in CONFIGS:
     far = env_id.endswith("+far")
-    env = mm.make(env_id.split("@")[0].split("+")[0], num_envs=n, force_vec=True, **({"maze_size_scaling": float(env_id.split("@")[1])} if "@" in env_id else {}))
+    env = make_env(env_id, n)
+    carries_warm = env_id.startswith("Ant") or env.launch_info()["engine"] == 1
     for k_, v_ in OPTS: env.set_option(k_, float(v_))
     cm = env.model
     prng = np.random.default_rng(5)
@@ -65,7 +91,7 @@ for env_id, n, checks in CONFIGS:
         act = rng.uniform(lo, hi, (n, env.nu)).astype(np.float32)
         if k in checks:
             s = {kk: (v.astype(np.float32).astype(np.float64) if v.dtype != np.int32 else v.copy()) for kk, v in st.items()}
-            env.set_state(s["qpos"], s["qvel"], s["warm"] if env_id.startswith("Ant") else None, s["t"])
+            env.set_state(s["qpos"], s["qvel"], s["warm"] if carries_warm else None, s["t"])
             obs, rew, done, info = env.step(torch.as_tensor(act, device=env.device))
             qpos, qvel, _, _ = [x.cpu().numpy() for x in env.get_state()]
             start = {kk: v.copy() for kk, v in s.items()}
