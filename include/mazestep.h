@@ -149,6 +149,8 @@ typedef struct mz_model {
   double jnt_margin[MZ_MAX_JNT];
   double jnt_solref[MZ_MAX_JNT][2];
   double jnt_solimp[MZ_MAX_JNT][5];
+  double jnt_stiffness[MZ_MAX_JNT]; /* hinge / slide spring (MJCF joint stiffness): passive force -k (q - springref); a model with any goes to the general engine */
+  double jnt_springref[MZ_MAX_JNT]; /* rest position of that spring in joint coordinates (radians / metres; MJCF springref) */
 
   /* dofs */
   int32_t dof_bodyid[MZ_MAX_DOF];

@@ -89,7 +89,7 @@ static inline void gen_pair(GenPair* p, const mz_model* m, const double* f1, con
 // does the model need this engine (no specialised kernel steps it)?  mazestep.hip asks before it dispatches.
 static inline int gen_model_needs_general_engine(const mz_model* m) {
   if (m->robot == MZ_ROBOT_GENERIC || m->engine == 1) return 1;
-  for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MZ_JNT_BALL) return 1;  // SPIN plates
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MZ_JNT_BALL || m->jnt_stiffness[j] != 0.0) return 1;  // SPIN plates; joint springs
   if (m->nblock > 3) return 1;
   for (int k = 0; k < m->nblock; k++)  // a three-slide block (MultiFall's XYZ block) has a specialised kernel for the one-block ant only
     if (m->body_jntnum[m->block_bodyid[k]] != 2 && !(m->robot == MZ_ROBOT_ANT && m->nblock == 1)) return 1;
@@ -1191,6 +1191,12 @@ MZ_HD void gen_force_item(const GenDev& K, GenScratch& s, int i) {
   for (uint32_t mk = sub; mk; mk &= mk - 1) { const double* f = s.cfrc[__builtin_ctz(mk)]; for (int e = 0; e < 6; e++) f6[e] += f[e]; }
   const double bias = gd_dot6(s.S[i], f6);
   double pas = -m.dof_damping[i] * s.qvel[i];
+  {  // joint spring (mj_passive), hinge / slide
+    const int j = m.dof_jntid[i];
+    const double k = m.jnt_stiffness[j];
+    if (k != 0.0 && (s.tp.jnt_type[j] == MZ_JNT_HINGE || s.tp.jnt_type[j] == MZ_JNT_SLIDE))
+      pas -= k * (s.qpos[s.tp.jnt_qposadr[j]] - m.qpos0[s.tp.jnt_qposadr[j]] - m.jnt_springref[j]);
+  }
   if (m.density > 0.0 || m.viscosity > 0.0)
     for (uint32_t mk = sub; mk; mk &= mk - 1) pas += gd_dot6(s.S[i], s.ffl[__builtin_ctz(mk)]);  // dof i moves body b iff body(i) is b or an ancestor of b
   s.bias[i] = bias; s.passive[i] = pas;

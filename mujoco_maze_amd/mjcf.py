@@ -10,7 +10,9 @@ built-in robot — other masses, sizes, gears, limits, contact parameters — lo
 Supported elements: `<compiler angle coordinate inertiafromgeom>`, `<option timestep integrator density viscosity
 collision>`, one top-level `<default>` with `<geom>`, `<joint>`, `<motor>`; `<worldbody>` with one plane geom (the
 floor) and one robot body tree of `<body>`, `<joint type=free|ball|slide|hinge>`, `<freejoint>`,
-`<geom type=sphere|capsule|box>`; `<actuator><motor>`.  Lights, cameras, sites, assets and materials are skipped.
+`<geom type=sphere|capsule|box>` (orientation by fromto, quat, axisangle, euler, zaxis or xyaxes — bodies too); `<actuator><motor>`.
+Lights, cameras, sites, assets and materials are skipped; **anything else that would change the physics is an error, not a skip**
+(joint springs, dry friction, tendons, equality constraints, contact pairs, gear vectors ...).
 The device kernels are written for the topologies of the four built-in robots (`csrc/*_dyn.h` check it when the
 model is created), so an XML may change parameters, not structure.
 """
@@ -30,6 +32,69 @@ def _floats(text: str) -> tuple:
     return tuple(float(t) for t in text.split())
 
 
+# Attributes that do not change the physics: skipped.  Every OTHER attribute an element carries must be one the reader implements —
+# an MJCF that says `stiffness="8"` or `euler="0 90 0"` and is stepped without it would be a different robot, silently (round 6).
+_COSMETIC = {"name", "rgba", "material", "group", "user", "priority"}
+
+
+def _check_attrs(e: ET.Element, known: set, what: str) -> None:
+    extra = sorted(set(e.attrib) - known - _COSMETIC)
+    if extra:
+        raise ValueError(f"{what}: attribute(s) {', '.join(extra)} are not implemented by this MJCF subset (known: {', '.join(sorted(known))})")
+
+
+def _orientation(a, radians: bool, eulerseq: str, what: str):
+    """quat | axisangle | euler | zaxis | xyaxes of an MJCF body / geom -> unit quaternion (w, x, y, z), or None when the element has none."""
+    import math
+
+    import numpy as np
+
+    from mujoco_maze_amd.model import axis_angle_quat, quat_mul, quat_z_to_vec
+
+    given = [k for k in ("quat", "axisangle", "euler", "zaxis", "xyaxes") if k in a]
+    if not given:
+        return None
+    if len(given) > 1:
+        raise ValueError(f"{what}: more than one orientation attribute ({', '.join(given)})")
+    k, v = given[0], _floats(a[given[0]])
+    ang = (lambda x: x) if radians else math.radians
+    if k == "quat":
+        if len(v) != 4:
+            raise ValueError(f"{what}: quat needs four numbers")
+        q = np.array(v, dtype=np.float64)
+    elif k == "axisangle":
+        if len(v) != 4:
+            raise ValueError(f"{what}: axisangle needs four numbers")
+        ax = np.array(v[:3], dtype=np.float64)
+        q = axis_angle_quat(ax / np.linalg.norm(ax), ang(v[3]))
+    elif k == "euler":
+        if len(v) != 3 or len(eulerseq) != 3 or any(c not in "xyzXYZ" for c in eulerseq):
+            raise ValueError(f"{what}: euler needs three numbers and a three-letter eulerseq")
+        q = np.array([1.0, 0.0, 0.0, 0.0])
+        for c, x in zip(eulerseq, v):  # lower case: rotations about the MOVING axes (post-multiply); upper case: about the fixed ones
+            r = axis_angle_quat(np.eye(3)["xyz".index(c.lower())], ang(x))
+            q = quat_mul(q, r) if c.islower() else quat_mul(r, q)
+    elif k == "zaxis":
+        if len(v) != 3:
+            raise ValueError(f"{what}: zaxis needs three numbers")
+        q = quat_z_to_vec(v)
+    else:
+        if len(v) != 6:
+            raise ValueError(f"{what}: xyaxes needs six numbers")
+        x = np.array(v[:3], dtype=np.float64); x /= np.linalg.norm(x)
+        y = np.array(v[3:], dtype=np.float64); y -= x * (x @ y); y /= np.linalg.norm(y)
+        R3 = np.column_stack([x, y, np.cross(x, y)])
+        w = math.sqrt(max(0.0, 1.0 + R3[0, 0] + R3[1, 1] + R3[2, 2])) / 2.0
+        if w > 1e-6:
+            q = np.array([w, (R3[2, 1] - R3[1, 2]) / (4 * w), (R3[0, 2] - R3[2, 0]) / (4 * w), (R3[1, 0] - R3[0, 1]) / (4 * w)])
+        else:  # a half turn: the axis is the eigenvector of R3 for +1
+            vals, vecs = np.linalg.eigh((R3 + R3.T) / 2.0)
+            ax = vecs[:, int(np.argmax(vals))]
+            q = np.array([0.0, *ax])
+    q = np.asarray(q, dtype=np.float64)
+    return tuple(q / np.linalg.norm(q))
+
+
 def _fmt(values: Sequence[float]) -> str:
     return " ".join(repr(float(v)) for v in values)
 
@@ -46,6 +111,8 @@ def _geom_attrs(g: R.GeomSpec, default: Optional[R.GeomSpec]) -> dict:
         a["size"] = _fmt(g.size[:1])
     else:
         a["size"] = _fmt(g.size)
+        if g.quat is not None:
+            a["quat"] = _fmt(g.quat)
         a["pos"] = _fmt(g.pos)
     if g.mass is not None:
         a["mass"] = repr(float(g.mass))
@@ -76,7 +143,7 @@ def spec_to_mjcf(spec: R.RobotSpec) -> str:
     elems = []
     for b in spec.bodies:
         parent = world if b.parent < 0 else elems[b.parent]
-        e = ET.SubElement(parent, "body", name=b.name, pos=_fmt(b.pos))
+        e = ET.SubElement(parent, "body", name=b.name, pos=_fmt(b.pos), **({"quat": _fmt(b.quat)} if tuple(b.quat) != (1.0, 0.0, 0.0, 0.0) else {}))
         elems.append(e)
         for g in b.geoms:
             ET.SubElement(e, "geom", **_geom_attrs(g, dg))
@@ -88,7 +155,10 @@ def spec_to_mjcf(spec: R.RobotSpec) -> str:
                 a.update(axis=_fmt(j.axis), pos=_fmt(j.pos), limited="true" if j.limited else "false", range=_fmt(j.range))
             for f in _JOINT_FIELDS:
                 v = getattr(j, f)
-                a[f] = _fmt(v) if isinstance(v, tuple) else repr(v)
+                # (MJCF's names for a joint's LIMIT parameters are solreflimit / solimplimit: real MuJoCo refuses `solref` on a joint)
+                a[{"solref": "solreflimit", "solimp": "solimplimit"}.get(f, f)] = _fmt(v) if isinstance(v, tuple) else repr(v)
+            if j.stiffness != 0.0:
+                a.update(stiffness=repr(j.stiffness), springref=repr(j.springref))
             ET.SubElement(e, "joint", **a)
     act = ET.SubElement(root, "actuator")
     for m in spec.actuators:
@@ -99,11 +169,16 @@ def spec_to_mjcf(spec: R.RobotSpec) -> str:
 
 
 # ---------------------------------------------------------------- reader
-def _apply_geom(base: R.GeomSpec, e: ET.Element, name: str) -> R.GeomSpec:
+def _apply_geom(base: R.GeomSpec, e: ET.Element, name: str, radians: bool = False, eulerseq: str = "xyz") -> R.GeomSpec:
     import dataclasses
 
     kw = {}
     a = e.attrib
+    _check_attrs(e, {"type", "size", "pos", "fromto", "mass", "density", "margin", "gap", "contype", "conaffinity", "condim", "friction", "solref",
+                     "solimp", "quat", "axisangle", "euler", "zaxis", "xyaxes"}, f"geom {name!r}")
+    q = _orientation(a, radians, eulerseq, f"geom {name!r}")
+    if q is not None:
+        kw["quat"] = q
     if "type" in a:
         if a["type"] not in _GEOM_TYPE:
             raise ValueError(f"geom {name!r}: type {a['type']!r} is not supported (plane, sphere, capsule, box)")
@@ -142,6 +217,15 @@ def _apply_joint(base: R.JointSpec, e: ET.Element, name: str, radians: bool) -> 
 
     a = e.attrib
     kw = {}
+    _check_attrs(e, {"type", "axis", "pos", "limited", "range", "armature", "damping", "margin", "solref", "solimp", "solreflimit", "solimplimit",
+                     "ref", "frictionloss", "stiffness", "springref"}, f"joint {name!r}")
+    for f in ("ref", "frictionloss"):  # parsed so that a ZERO passes; anything else is physics this subset lacks
+        if f in a and float(a[f]) != 0.0:
+            raise ValueError(f"joint {name!r}: {f}={a[f]!r} is not implemented (reference offsets and dry friction)")
+    if "stiffness" in a:
+        kw["stiffness"] = float(a["stiffness"])
+    if "springref" in a:
+        kw["springref"] = float(a["springref"])
     jt = "free" if e.tag == "freejoint" else a.get("type", "hinge")  # MuJoCo's default joint type is hinge
     if jt not in _JOINT_TYPE:
         raise ValueError(f"joint {name!r}: type {jt!r} is not supported (free, ball, slide, hinge)")
@@ -157,14 +241,18 @@ def _apply_joint(base: R.JointSpec, e: ET.Element, name: str, radians: bool) -> 
         if radians and kw["type"] == R.HINGE:
             rng = tuple(math.degrees(v) for v in rng)
         kw["range"] = rng
+    if "springref" in kw and radians and kw["type"] == R.HINGE:
+        kw["springref"] = math.degrees(kw["springref"])
     for f in ("armature", "damping", "margin"):
         if f in a:
             kw[f] = float(a[f])
-    if "solref" in a:
-        kw["solref"] = _floats(a["solref"])
-    if "solimp" in a:
-        si = _floats(a["solimp"])
-        kw["solimp"] = tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
+    for key in ("solref", "solreflimit"):  # (MJCF's name for a joint's limit parameters is solreflimit / solimplimit; the short forms are this repo's own writer's)
+        if key in a:
+            kw["solref"] = _floats(a[key])
+    for key in ("solimp", "solimplimit"):
+        if key in a:
+            si = _floats(a[key])
+            kw["solimp"] = tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
     return dataclasses.replace(base, name=name, **kw)
 
 
@@ -177,14 +265,30 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
     root = ET.fromstring(text)
     if root.tag != "mujoco":
         raise ValueError("not an MJCF document (root element must be <mujoco>)")
+    for ch in root:  # sections that change the physics and are not implemented must not be skipped silently
+        if ch.tag in ("tendon", "equality", "contact", "extension", "deformable"):
+            raise ValueError(f"<{ch.tag}> is not implemented by this MJCF subset")
+        if ch.tag not in ("compiler", "option", "default", "worldbody", "actuator", "asset", "visual", "size", "statistic", "custom", "sensor", "keyframe"):
+            raise ValueError(f"unknown top-level element <{ch.tag}>")
     comp = root.find("compiler")
     radians = comp is not None and comp.get("angle", "degree") == "radian"
+    eulerseq = comp.get("eulerseq", "xyz") if comp is not None else "xyz"
+    if comp is not None:
+        _check_attrs(comp, {"angle", "coordinate", "inertiafromgeom", "eulerseq", "meshdir", "texturedir", "autolimits", "balanceinertia", "boundmass", "boundinertia"}, "<compiler>")
+        if comp.get("autolimits", "false") == "true":
+            raise ValueError("<compiler autolimits> is not implemented: say limited=\"true\" where a range applies")
     if comp is not None and comp.get("coordinate", "local") != "local":
         raise ValueError("only coordinate=\"local\" is supported")
     if comp is None or comp.get("inertiafromgeom", "auto") not in ("true", "auto"):
         raise ValueError("inertiafromgeom must be true (bodies get their inertia from their geoms)")
     opt = root.find("option")
     oa = opt.attrib if opt is not None else {}
+    if opt is not None:
+        _check_attrs(opt, {"timestep", "integrator", "density", "viscosity", "collision", "gravity", "iterations", "tolerance", "solver", "cone", "jacobian"}, "<option>")
+        if "gravity" in oa and tuple(_floats(oa["gravity"])) != (0.0, 0.0, -9.81):
+            raise ValueError("<option gravity>: only MuJoCo's default (0 0 -9.81) is implemented")
+        if oa.get("cone", "pyramidal") != "pyramidal" or oa.get("solver", "Newton") != "Newton":
+            raise ValueError("<option>: the pyramidal cone and the Newton solver are what is implemented")
     if oa.get("integrator", "Euler") != "RK4":
         raise ValueError("only integrator=\"RK4\" is implemented on the device (all reference assets use it)")
     dflt = root.find("default")
@@ -195,7 +299,7 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
         if dflt.find("default") is not None:
             raise ValueError("nested <default> classes are not supported")
         if dflt.find("geom") is not None:
-            geom0 = _apply_geom(geom0, dflt.find("geom"), "")
+            geom0 = _apply_geom(geom0, dflt.find("geom"), "", radians, eulerseq)
             geom0.explicit_solimp = False
         if dflt.find("joint") is not None:
             joint0 = _apply_joint(joint0, dflt.find("joint"), "", radians)
@@ -207,17 +311,25 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
     floors = [g for g in world.findall("geom") if g.get("type") == "plane"]
     if len(floors) != 1:
         raise ValueError("expected exactly one plane geom (the floor) in <worldbody>")
-    floor = _apply_geom(geom0, floors[0], floors[0].get("name", "floor"))
+    floor = _apply_geom(geom0, floors[0], floors[0].get("name", "floor"), radians, eulerseq)
     bodies: List[R.BodySpec] = []
 
     def walk(e: ET.Element, parent: int):
         name = e.get("name", f"body{len(bodies)}")
+        _check_attrs(e, {"pos", "quat", "axisangle", "euler", "zaxis", "xyaxes"}, f"body {name!r}")
         b = R.BodySpec(name, parent, _floats(e.get("pos", "0 0 0")))
+        bq = _orientation(e.attrib, radians, eulerseq, f"body {name!r}")
+        if bq is not None:
+            b.quat = bq
         idx = len(bodies)
         bodies.append(b)
         for k, ch in enumerate(e):
+            if ch.tag == "inertial" and (comp is None or comp.get("inertiafromgeom", "auto") != "true"):
+                raise ValueError(f"body {name!r}: <inertial> under inertiafromgeom=\"auto\" would override the geoms' inertia; not implemented")
+            if ch.tag not in ("geom", "joint", "freejoint", "body", "inertial", "site", "camera", "light"):
+                raise ValueError(f"body {name!r}: child element <{ch.tag}> is not implemented")
             if ch.tag == "geom":
-                b.geoms.append(_apply_geom(geom0, ch, ch.get("name", f"{name}_geom{k}")))
+                b.geoms.append(_apply_geom(geom0, ch, ch.get("name", f"{name}_geom{k}"), radians, eulerseq))
             elif ch.tag == "joint":
                 b.joints.append(_apply_joint(joint0, ch, ch.get("name", f"{name}_joint{k}"), radians))
             elif ch.tag == "freejoint":  # takes no defaults (MuJoCo: armature = damping = 0, never limited)
@@ -235,6 +347,9 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
             raise ValueError(f"actuator <{mtr.tag}> is not supported (motor only)")
         a = dict(motor_attrs)
         a.update(mtr.attrib)
+        extra = sorted(set(a) - {"joint", "gear", "ctrlrange", "ctrllimited", "forcelimited", "forcerange"} - _COSMETIC)
+        if extra or a.get("forcelimited", "false") == "true" or any(x != 0.0 for x in _floats(a.get("gear", "1"))[1:]):
+            raise ValueError(f"motor on {a.get('joint')!r}: only joint, a scalar gear, ctrlrange and ctrllimited are implemented ({', '.join(extra) or 'force limits / gear vector'})")
         gear = _floats(a.get("gear", "1"))[0]
         acts.append(R.ActuatorSpec(a["joint"], gear, _floats(a.get("ctrlrange", "0 0")), a.get("ctrllimited", "false") == "true"))
     nq = sum({R.FREE: 7, R.BALL: 4}.get(j.type, 1) for b in bodies for j in b.joints)
@@ -249,6 +364,9 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
         return R.RobotSpec("generic", bodies, acts, floor, wall_defaults, timestep=float(oa.get("timestep", 0.002)), frame_skip=int(frame_skip),
                            nq_robot=nq, nv_robot=nv, density=float(oa.get("density", 0.0)), viscosity=float(oa.get("viscosity", 0.0)),
                            collision_predefined=oa.get("collision", "all") == "predefined", reset_qvel=reset_qvel, torso_z=bodies[0].pos[2])
+    if any(tuple(b.quat) != (1.0, 0.0, 0.0, 0.0) or any(g.quat is not None for g in b.geoms) or any(j.stiffness != 0.0 for j in b.joints) for b in bodies):
+        raise ValueError(f"{like.name}: a variant of a built-in robot may change parameters, not structure — turned bodies / geoms and joint springs "
+                         "need an AgentModel with ROBOT = \"generic\" (the general engine)")
     chain = (like.name in ("swimmer", "reacher") and nq == nv == len(bodies) + 2 and 2 <= len(bodies) <= 6 and len(acts) == len(bodies) - 1
              and all(b.parent == i - 1 for i, b in enumerate(bodies)))
     if not chain and ((nq, nv) != (like.nq_robot, like.nv_robot) or len(acts) != len(like.actuators)):

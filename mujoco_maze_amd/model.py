@@ -52,6 +52,7 @@ class MzModel(C.Structure):
         ("jnt_bodyid", i32 * MAX_JNT), ("jnt_limited", i32 * MAX_JNT),
         ("jnt_pos", (f64 * 3) * MAX_JNT), ("jnt_axis", (f64 * 3) * MAX_JNT), ("jnt_range", (f64 * 2) * MAX_JNT),
         ("jnt_margin", f64 * MAX_JNT), ("jnt_solref", (f64 * 2) * MAX_JNT), ("jnt_solimp", (f64 * 5) * MAX_JNT),
+        ("jnt_stiffness", f64 * MAX_JNT), ("jnt_springref", f64 * MAX_JNT),
         ("dof_bodyid", i32 * MAX_DOF), ("dof_jntid", i32 * MAX_DOF),
         ("dof_armature", f64 * MAX_DOF), ("dof_damping", f64 * MAX_DOF), ("dof_invweight0", f64 * MAX_DOF),
         ("qpos0", f64 * MAX_Q),
@@ -139,7 +140,8 @@ def resolve_geom(g: R.GeomSpec):
         quat = quat_z_to_vec(a - b)
         size[1] = 0.5 * np.linalg.norm(a - b)
     else:
-        pos, quat = np.array(g.pos, dtype=np.float64), np.array([1.0, 0.0, 0.0, 0.0])
+        pos = np.array(g.pos, dtype=np.float64)
+        quat = np.array(g.quat if getattr(g, "quat", None) is not None else [1.0, 0.0, 0.0, 0.0], dtype=np.float64)
     return pos, quat, size
 
 
@@ -280,7 +282,7 @@ def needs_general_engine(cm) -> bool:
     m = cm.c
     if m.robot == ROBOT_ID["generic"] or m.engine == 1 or m.nblock > 3:
         return True
-    if any(m.jnt_type[j] == R.BALL for j in range(m.njnt)):
+    if any(m.jnt_type[j] == R.BALL or m.jnt_stiffness[j] != 0.0 for j in range(m.njnt)):
         return True
     if any(m.body_jntnum[m.block_bodyid[k]] != 2 for k in range(m.nblock)) and not (m.robot == ROBOT_ID["ant"] and m.nblock == 1):
         return True
@@ -474,6 +476,7 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     for bi, b in enumerate(spec.bodies, start=1):
         parent[bi] = b.parent + 1
         bpos[bi] = b.pos
+        bquat[bi] = getattr(b, "quat", (1.0, 0.0, 0.0, 0.0))
         m.body_jntadr[bi] = len(jrows) if b.joints else -1
         m.body_jntnum[bi] = len(b.joints)
         m.body_dofadr[bi] = nv if b.joints else -1
@@ -496,8 +499,13 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
             m.jnt_margin[jid] = j.margin
             m.jnt_solref[jid][:] = j.solref
             m.jnt_solimp[jid][:] = j.solimp
+            if getattr(j, "stiffness", 0.0) != 0.0:
+                if j.type not in (R.HINGE, R.SLIDE):
+                    raise NotImplementedError(f"joint {j.name!r}: springs are implemented on hinge and slide joints")
+                m.jnt_stiffness[jid] = j.stiffness
+                m.jnt_springref[jid] = math.radians(j.springref) if j.type == R.HINGE else j.springref
             if j.type == R.FREE:
-                qpos0 += [b.pos[0], b.pos[1], b.pos[2], 1.0, 0.0, 0.0, 0.0]
+                qpos0 += [b.pos[0], b.pos[1], b.pos[2], *getattr(b, "quat", (1.0, 0.0, 0.0, 0.0))]
                 dq, dv = 7, 6
             elif j.type == R.BALL:
                 if j.limited:

@@ -34,6 +34,7 @@ class GeomSpec:
     margin: float = 0.0
     gap: float = 0.0
     explicit_solimp: bool = False  # set on the geom itself (not inherited from <default>)
+    quat: Optional[Tuple[float, float, float, float]] = None  # orientation in the body frame (quat / euler / axisangle / zaxis / xyaxes of the MJCF); fromto wins
 
 
 @dataclass
@@ -49,6 +50,8 @@ class JointSpec:
     margin: float = 0.0
     solref: Tuple[float, float] = (0.02, 1.0)
     solimp: Tuple[float, float, float, float, float] = (0.9, 0.95, 0.001, 0.5, 2.0)
+    stiffness: float = 0.0   # hinge / slide spring: passive force -stiffness * (q - springref)
+    springref: float = 0.0   # its rest position (degrees for hinges, like `range`)
 
 
 @dataclass
@@ -58,6 +61,7 @@ class BodySpec:
     pos: Tuple[float, float, float]
     joints: List[JointSpec] = field(default_factory=list)
     geoms: List[GeomSpec] = field(default_factory=list)
+    quat: Tuple[float, float, float, float] = (1.0, 0.0, 0.0, 0.0)  # orientation in the parent's frame
 
 
 @dataclass

@@ -365,6 +365,10 @@ static void velocity_and_forces(const mz_model* m, mzo_data* d, const double* ct
     d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
     d->qfrc_actuator[i] = 0.0;
   }
+  /* joint springs (mj_passive: -stiffness * (qpos - qpos_spring)), hinge and slide joints */
+  for (int j = 0; j < m->njnt; j++)
+    if (m->jnt_stiffness[j] != 0.0 && (m->jnt_type[j] == MZ_JNT_HINGE || m->jnt_type[j] == MZ_JNT_SLIDE))
+      d->qfrc_passive[m->jnt_dofadr[j]] -= m->jnt_stiffness[j] * (d->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]] - m->jnt_springref[j]);
   /* inertia-box fluid model (swimmer): [ASSUME-9] only when density/viscosity > 0 */
   if (m->density > 0.0 || m->viscosity > 0.0) mzo_fluid_passive(m, d);
   for (int a = 0; a < m->nu; a++) {

@@ -265,6 +265,41 @@ def test_user_robot_whose_limbs_collide_with_each_other(oracle):
     assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 1, 3, 7)) > 30
 
 
+def test_joint_spring_is_a_harmonic_oscillator(oracle):
+    """MJCF joint stiffness / springref (mj_passive: -k (q - springref)) in the oracle: an arm on a vertical hinge with a torsion spring and
+    no damping swings about the spring's rest angle with omega = sqrt(k / I) — I the pivot's entry of the mass matrix (inertia + armature).
+    Half a period from rest at 0 it stands at twice the rest angle, a full period later it is back; energy is not the test (the spring's
+    potential is not in the oracle's energy sum), the closed form is."""
+    k, ref = 1.5, 20.0
+    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref), frame_skip=1, reset_qvel="normal")
+    m = cm.c
+    assert m.nv == 1 and m.jnt_stiffness[0] == k and np.isclose(m.jnt_springref[0], np.radians(ref)) and model.needs_general_engine(cm)
+    inertia = oracle.forward(cm, np.zeros((1, 1)), np.zeros((1, 1)))["M"][0][0, 0]
+    period = 2.0 * np.pi / np.sqrt(k / inertia)
+    h = m.timestep
+    half = int(round(0.5 * period / h))
+    q, v, _ = oracle.raw_steps(cm, np.zeros(1), np.zeros(1), None, half)
+    # (the step count rounds the half period to h: |q - 2 ref| <= amplitude * (omega h / 2)^2 / 2 + RK4's h^4 error)
+    assert abs(q[0] - 2.0 * np.radians(ref)) < 2e-5 and abs(v[0]) < np.radians(ref) * np.sqrt(k / inertia) * (np.sqrt(k / inertia) * h), (q, v)
+    q, v, _ = oracle.raw_steps(cm, q, v, None, half)
+    assert abs(q[0]) < 1e-4
+
+
+def test_user_robot_with_joint_springs(oracle):
+    """The springy biped (tests/user_robots.py: stiffness / springref on knees and tail) through the kernel code (host build) against the
+    oracle: the passive spring forces reach qfrc_smooth on both sides."""
+    cm = model.compile_model("generic", T.GoalRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRINGY_BIPED, frame_skip=5, reset_qvel="normal")
+    plain = model.compile_model("generic", T.GoalRewardUMaze(4.0), 4.0, robot_xml=user_robots.BIPED_ANT, frame_skip=5, reset_qvel="normal")
+    n = 12
+    st, _ = oracle.reset(cm, n, 3)
+    a0 = oracle.forward(cm, st["qpos"], st["qvel"], np.zeros((n, cm.c.nu)), st["warm"])["qacc"]
+    a1 = oracle.forward(plain, st["qpos"], st["qvel"], np.zeros((n, cm.c.nu)), st["warm"])["qacc"]
+    assert np.abs(a0 - a1).max() > 0.1  # the springs matter: knees at 30..70 degrees pulled towards 50, the tail towards -10
+    rng = np.random.default_rng(1)
+    acts = [rng.uniform(-20, 20, (n, cm.c.nu)) for _ in range(9)]
+    assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 3, 8)) > 20
+
+
 def test_plane_box_with_tilted_corners(oracle):
     """mjc_PlaneBox for a box of general orientation, through the model path: the SPIN plate of SpinUMaze/ant (half sizes 0.4, 0.4,
     0.2, centre 0.2 above the floor) tilted by 0.1 rad about y.  By hand: a corner (sx 0.4, sy 0.4, sz 0.2) sits at height

@@ -213,6 +213,24 @@ def test_user_robot_whose_limbs_collide_on_the_device(torch, oracle):
     env.close()
 
 
+def test_user_robot_with_joint_springs_on_the_device(torch, oracle):
+    """MJCF joint stiffness / springref on a user robot (tests/user_robots.py SPRINGY_BIPED): the passive spring forces on the device, equal to
+    the oracle at 1e-6 over a rollout with floor contacts."""
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+    from tests import user_robots
+
+    n = 256
+    env = VecMazeEnv(user_robots.springy_class(), T.GoalRewardUMaze, num_envs=n, maze_size_scaling=4.0)
+    cm = env.model
+    assert env.launch_info()["engine"] == 1 and any(cm.c.jnt_stiffness[j] != 0.0 for j in range(cm.c.njnt))
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(1)
+    acts = [rng.uniform(-20, 20, (n, cm.c.nu)) for _ in range(16)]
+    contacts = _step_against_oracle(torch, oracle, env, st, acts, checks=(0, 3, 15), max_outlier_frac=0.02)
+    assert contacts > 300
+    env.close()
+
+
 def test_general_engine_top_down_view_and_record(torch, oracle):
     """TOP_DOWN_VIEW tasks and the sharded run's packed record on the general engine: view entries filled from the row's own robot /
     block positions, time entry behind the view, record = obs | reward | done."""

@@ -244,3 +244,93 @@ def test_chain_lane_group_form_matches_one_lane_and_oracle(oracle, robot, nlink)
         oracle.step(cm, st, act.astype(np.float64))
         if k % 15 == 14: hold = np.sign(rng.uniform(-1, 1, (n, m.nu)))
     assert at_limit > 0  # limit rows were active at a checkpoint
+
+_ORIENT = """
+<mujoco model="orient">
+  <compiler angle="degree" coordinate="local" inertiafromgeom="true"{seq}/>
+  <option integrator="RK4" timestep="0.01"/>
+  <default><geom conaffinity="0" condim="3" density="100"/></default>
+  <worldbody>
+    <geom name="floor" type="plane" size="40 40 40" conaffinity="1"/>
+    <body name="torso" pos="0 0 0.5">
+      <freejoint name="root"/>
+      <geom name="g" type="capsule" {geom}/>
+      <body name="arm" pos="0.3 0 0" {body}>
+        <joint name="j" type="hinge" axis="0 0 1" limited="true" range="-30 30"/>
+        <geom name="a" type="box" size="0.2 0.05 0.02" pos="0.2 0 0"/>
+      </body>
+    </body>
+  </worldbody>
+  <actuator><motor joint="j" gear="1" ctrllimited="true" ctrlrange="-1 1"/></actuator>
+</mujoco>
+"""
+
+
+def _compiled(geom, body="", seq=""):
+    from mujoco_maze_amd import maze_task as T
+    from mujoco_maze_amd import model
+
+    return model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=_ORIENT.format(geom=geom, body=body, seq=seq), frame_skip=1, reset_qvel="normal").c
+
+
+def test_orientation_attributes_of_geoms_and_bodies():
+    """quat / axisangle / euler / zaxis / xyaxes (MJCF's alternatives to fromto) on geoms and bodies: a capsule along (1, 1, 0) said five
+    ways compiles to the same geom frame, inertia and mass as its fromto form; a body turned by 90 degrees about z carries its child
+    geoms and joint axes with it.  Angles follow <compiler angle>, euler its eulerseq (lower case: moving axes)."""
+    import numpy as np
+
+    from mujoco_maze_amd import model
+
+    ref = _compiled('size="0.05" fromto="-0.2 -0.2 0 0.2 0.2 0"')
+    hl = 0.2 * np.sqrt(2.0)
+    forms = [f'size="0.05 {hl}" pos="0 0 0" zaxis="1 1 0"',
+             f'size="0.05 {hl}" axisangle="-1 1 0 90"',                       # z -> (1, 1, 0) / sqrt 2: a quarter turn about (-1, 1, 0)
+             f'size="0.05 {hl}" euler="0 90 45" ',                           # with eulerseq="XYZ" (fixed axes), see below
+             f'size="0.05 {hl}" xyaxes="0 0 -1 -1 1 0"',                     # x = -z, y = (-1, 1, 0): z = x x y = (1, 1, 0)
+             'size="0.05 %.17g" quat="%.17g %.17g %.17g 0"' % (hl, np.cos(np.pi / 4), -np.sin(np.pi / 4) / np.sqrt(2), np.sin(np.pi / 4) / np.sqrt(2))]
+    for k, form in enumerate(forms):
+        seq = ' eulerseq="XYZ"' if "euler" in form else ""                     # fixed axes: about X by 0, then Y by 90 (z -> x), then Z by 45 (x -> (1, 1, 0))
+        m = _compiled(form, seq=seq)
+        zax = model.quat_to_mat(np.array(m.geom_quat[1]))[:, 2]
+        assert np.allclose(np.abs(zax @ np.array([1, 1, 0]) / np.sqrt(2)), 1.0, atol=1e-12), (k, form, zax)
+        assert np.allclose(m.geom_size[1][:2], ref.geom_size[1][:2]) and np.allclose(m.geom_pos[1], ref.geom_pos[1])
+        assert np.isclose(m.body_mass[1], ref.body_mass[1], rtol=1e-12) and np.allclose(m.body_inertia[1], ref.body_inertia[1], atol=1e-12), (k, form)
+    # a body turned by a quarter about z: its box geom's long axis and its hinge axis in the parent frame
+    m = _compiled('size="0.05" fromto="-0.2 0 0 0.2 0 0"', body='euler="0 0 90"')
+    R = model.quat_to_mat(np.array(m.body_quat[2]))
+    assert np.allclose(R @ [1, 0, 0], [0, 1, 0], atol=1e-12) and np.allclose(R @ [0, 0, 1], [0, 0, 1], atol=1e-12)
+    m2 = _compiled('size="0.05" fromto="-0.2 0 0 0.2 0 0"', body='quat="%.17g 0 0 %.17g"' % (np.cos(np.pi / 4), np.sin(np.pi / 4)))
+    assert np.allclose(m.body_quat[2], m2.body_quat[2], atol=1e-12)
+    # the turned arm's centre of mass sits at +y of the torso now: the composite inertia of the tree knows it
+    # and the moving-axes default: xyz with (0, 90, 45) turns about y first, then about the NEW z — the geom z axis ends on +x
+    m3 = _compiled('size="0.05 0.2" euler="0 90 45"')
+    assert np.allclose(model.quat_to_mat(np.array(m3.geom_quat[1]))[:, 2], [1, 0, 0], atol=1e-12)
+
+
+def test_physics_this_subset_lacks_is_an_error_not_a_skip():
+    """An MJCF attribute or section that changes the physics and is not implemented stops the load (round 6: it was skipped — a robot with
+    `frictionloss="0.1"` stepped without its dry friction; joint springs, first on that list, are implemented now).  Cosmetic attributes (rgba, material, group) and sections (asset, visual) pass."""
+    ok = 'size="0.05" fromto="-0.2 0 0 0.2 0 0" rgba="1 0 0 1" material="m" group="1"'
+    _compiled(ok)
+    base = _ORIENT.format(geom=ok, body="", seq="")
+    from mujoco_maze_amd import maze_task as T
+    from mujoco_maze_amd import model
+
+    def load(xml):
+        return model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=xml, frame_skip=1, reset_qvel="normal")
+
+    load(base.replace("</mujoco>", "<asset><texture name=\"t\" type=\"2d\" builtin=\"flat\" width=\"8\" height=\"8\"/></asset></mujoco>"))
+    for bad, word in ((base.replace('range="-30 30"', 'range="-30 30" ref="10"'), "ref"),
+                      (base.replace('range="-30 30"', 'range="-30 30" frictionloss="0.1"'), "frictionloss"),
+                      (base.replace('range="-30 30"', 'range="-30 30" springdamper="1 1"'), "springdamper"),
+                      (base.replace('gear="1"', 'gear="1 0 0 0 0 1"'), "gear"),
+                      (base.replace('gear="1"', 'gear="1" forcelimited="true" forcerange="-1 1"'), "force"),
+                      (base.replace("</mujoco>", "<tendon><fixed name=\"t\"><joint joint=\"j\" coef=\"1\"/></fixed></tendon></mujoco>"), "tendon"),
+                      (base.replace("</mujoco>", "<equality><weld body1=\"torso\" body2=\"arm\"/></equality></mujoco>"), "equality"),
+                      (base.replace('<option integrator="RK4"', '<option gravity="0 0 -1.6" integrator="RK4"'), "gravity"),
+                      (base.replace('<option integrator="RK4"', '<option cone="elliptic" integrator="RK4"'), "cone"),
+                      (base.replace('pos="0.2 0 0"/>', 'pos="0.2 0 0" fluidshape="ellipsoid"/>'), "fluidshape"),
+                      (base.replace('<body name="arm" pos="0.3 0 0" >', '<body name="arm" pos="0.3 0 0" gravcomp="1">'), "gravcomp")):
+        with pytest.raises(ValueError) as ei:
+            load(bad)
+        assert word in str(ei.value), (word, str(ei.value))

@@ -128,6 +128,43 @@ PINCER = """
 """
 
 
+# the biped with springs in its knees and tail (MJCF joint stiffness / springref): passive forces -k (q - springref)
+SPRINGY_BIPED = BIPED_ANT.replace('name="left_knee" type="hinge"', 'name="left_knee" type="hinge" stiffness="6" springref="50"') \
+                         .replace('name="right_knee" type="hinge"', 'name="right_knee" type="hinge" stiffness="6" springref="50"') \
+                         .replace('name="tail_joint" type="hinge"', 'name="tail_joint" type="hinge" stiffness="3" springref="-10"') \
+                         .replace('model="biped_ant"', 'model="springy_biped"')
+
+# one arm on a vertical hinge fixed to the world, a torsion spring and no damping: a harmonic oscillator the oracle can be checked on
+SPRING_ARM = """
+<mujoco model="spring_arm">
+  <compiler angle="degree" coordinate="local" inertiafromgeom="true"/>
+  <option integrator="RK4" timestep="0.002"/>
+  <default><geom conaffinity="0" contype="0" condim="3" density="500"/></default>
+  <worldbody>
+    <geom name="floor" type="plane" size="40 40 40" conaffinity="1"/>
+    <body name="arm" pos="0 0 0.3">
+      <joint name="pivot" type="hinge" axis="0 0 1" pos="0 0 0" armature="0.02" damping="0" stiffness="{k}" springref="{ref}"/>
+      <geom name="arm_geom" type="capsule" size="0.03" fromto="0 0 0 0.4 0 0"/>
+    </body>
+  </worldbody>
+  <actuator><motor joint="pivot" gear="1" ctrllimited="true" ctrlrange="-1 1"/></actuator>
+</mujoco>
+"""
+
+
+def springy_class():
+    from mujoco_maze_amd.agent_model import AgentModel
+
+    class SpringyBiped(AgentModel):
+        ROBOT = "generic"
+        FILE = SPRINGY_BIPED
+        MANUAL_COLLISION = False
+        FRAME_SKIP = 5
+        RESET_QVEL = "normal"
+
+    return SpringyBiped
+
+
 def pincer_class():
     from mujoco_maze_amd.agent_model import AgentModel
 
