@@ -8,7 +8,7 @@ built-in robot — other masses, sizes, gears, limits, contact parameters — lo
     env = mm.make("AntUMaze-v0", num_envs=4096, robot_xml="my_ant.xml")
 
 Supported elements: `<compiler angle coordinate inertiafromgeom>`, `<option timestep integrator density viscosity
-collision>`, one top-level `<default>` with `<geom>`, `<joint>`, `<motor>`; `<worldbody>` with one plane geom (the
+collision>`, `<default>` with `<geom>`, `<joint>`, `<motor>` and nested classes (`class=`, `childclass=`); `<worldbody>` with one plane geom (the
 floor) and one robot body tree of `<body>`, `<joint type=free|ball|slide|hinge>`, `<freejoint>`,
 `<geom type=sphere|capsule|box>` (orientation by fromto, quat, axisangle, euler, zaxis or xyaxes — bodies too); `<actuator><motor>`.
 Lights, cameras, sites, assets and materials are skipped; **anything else that would change the physics is an error, not a skip**
@@ -175,7 +175,7 @@ def _apply_geom(base: R.GeomSpec, e: ET.Element, name: str, radians: bool = Fals
     kw = {}
     a = e.attrib
     _check_attrs(e, {"type", "size", "pos", "fromto", "mass", "density", "margin", "gap", "contype", "conaffinity", "condim", "friction", "solref",
-                     "solimp", "quat", "axisangle", "euler", "zaxis", "xyaxes"}, f"geom {name!r}")
+                     "solimp", "quat", "axisangle", "euler", "zaxis", "xyaxes", "class"}, f"geom {name!r}")
     q = _orientation(a, radians, eulerseq, f"geom {name!r}")
     if q is not None:
         kw["quat"] = q
@@ -218,7 +218,7 @@ def _apply_joint(base: R.JointSpec, e: ET.Element, name: str, radians: bool) -> 
     a = e.attrib
     kw = {}
     _check_attrs(e, {"type", "axis", "pos", "limited", "range", "armature", "damping", "margin", "solref", "solimp", "solreflimit", "solimplimit",
-                     "ref", "frictionloss", "stiffness", "springref"}, f"joint {name!r}")
+                     "ref", "frictionloss", "stiffness", "springref", "class"}, f"joint {name!r}")
     for f in ("ref", "frictionloss"):  # parsed so that a ZERO passes; anything else is physics this subset lacks
         if f in a and float(a[f]) != 0.0:
             raise ValueError(f"joint {name!r}: {f}={a[f]!r} is not implemented (reference offsets and dry friction)")
@@ -295,16 +295,38 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
     geom0 = R.GeomSpec(name="", type=R.SPHERE, size=(0.0,))  # MuJoCo's built-in defaults
     joint0 = R.JointSpec(name="", type=R.HINGE)
     motor_attrs = {}
+    # default classes (MJCF: the top-level <default> is class "main"; a nested <default class="x"> inherits everything of the class
+    # around it; an element names its class with class="x", a body hands one down to its whole subtree with childclass="x")
+    classes = {"main": (geom0, joint0, motor_attrs)}
+
+    def read_defaults(d: ET.Element, cname: str, parent: str):
+        g, j, mo = classes[parent]
+        for ch in d:
+            if ch.tag not in ("default", "geom", "joint", "motor", "site", "camera", "light", "material", "mesh"):
+                raise ValueError(f"<default class={cname!r}>: settings for <{ch.tag}> are not implemented")
+        if d.find("geom") is not None:
+            g = _apply_geom(g, d.find("geom"), "", radians, eulerseq)
+            g.explicit_solimp = False
+        if d.find("joint") is not None:
+            j = _apply_joint(j, d.find("joint"), "", radians)
+        if d.find("motor") is not None:
+            mo = dict(mo)
+            mo.update(d.find("motor").attrib)
+        classes[cname] = (g, j, mo)
+        for sub in d.findall("default"):
+            if not sub.get("class"):
+                raise ValueError("a nested <default> needs a class name")
+            read_defaults(sub, sub.get("class"), cname)
+
     if dflt is not None:
-        if dflt.find("default") is not None:
-            raise ValueError("nested <default> classes are not supported")
-        if dflt.find("geom") is not None:
-            geom0 = _apply_geom(geom0, dflt.find("geom"), "", radians, eulerseq)
-            geom0.explicit_solimp = False
-        if dflt.find("joint") is not None:
-            joint0 = _apply_joint(joint0, dflt.find("joint"), "", radians)
-        if dflt.find("motor") is not None:
-            motor_attrs = dict(dflt.find("motor").attrib)
+        read_defaults(dflt, "main", "main")
+    geom0, joint0, motor_attrs = classes["main"]
+
+    def cls_of(e: ET.Element, inherited: str) -> str:
+        c = e.get("class", inherited)
+        if c not in classes:
+            raise ValueError(f"{e.tag} {e.get('name', '')!r}: unknown default class {c!r}")
+        return c
     world = root.find("worldbody")
     if world is None:
         raise ValueError("<worldbody> missing")
@@ -314,9 +336,11 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
     floor = _apply_geom(geom0, floors[0], floors[0].get("name", "floor"), radians, eulerseq)
     bodies: List[R.BodySpec] = []
 
-    def walk(e: ET.Element, parent: int):
+    def walk(e: ET.Element, parent: int, inherited: str = "main"):
         name = e.get("name", f"body{len(bodies)}")
-        _check_attrs(e, {"pos", "quat", "axisangle", "euler", "zaxis", "xyaxes"}, f"body {name!r}")
+        _check_attrs(e, {"pos", "quat", "axisangle", "euler", "zaxis", "xyaxes", "childclass"}, f"body {name!r}")
+        if "childclass" in e.attrib:
+            inherited = cls_of(ET.Element("body", {"class": e.get("childclass"), "name": name}), inherited)
         b = R.BodySpec(name, parent, _floats(e.get("pos", "0 0 0")))
         bq = _orientation(e.attrib, radians, eulerseq, f"body {name!r}")
         if bq is not None:
@@ -329,13 +353,13 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
             if ch.tag not in ("geom", "joint", "freejoint", "body", "inertial", "site", "camera", "light"):
                 raise ValueError(f"body {name!r}: child element <{ch.tag}> is not implemented")
             if ch.tag == "geom":
-                b.geoms.append(_apply_geom(geom0, ch, ch.get("name", f"{name}_geom{k}"), radians, eulerseq))
+                b.geoms.append(_apply_geom(classes[cls_of(ch, inherited)][0], ch, ch.get("name", f"{name}_geom{k}"), radians, eulerseq))
             elif ch.tag == "joint":
-                b.joints.append(_apply_joint(joint0, ch, ch.get("name", f"{name}_joint{k}"), radians))
+                b.joints.append(_apply_joint(classes[cls_of(ch, inherited)][1], ch, ch.get("name", f"{name}_joint{k}"), radians))
             elif ch.tag == "freejoint":  # takes no defaults (MuJoCo: armature = damping = 0, never limited)
                 b.joints.append(_apply_joint(R.JointSpec(name="", type=R.FREE), ch, ch.get("name", f"{name}_joint{k}"), radians))
         for ch in e.findall("body"):
-            walk(ch, idx)
+            walk(ch, idx, inherited)
 
     roots = world.findall("body")
     if len(roots) != 1:
@@ -345,8 +369,9 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
     for mtr in (root.find("actuator") if root.find("actuator") is not None else []):
         if mtr.tag != "motor":
             raise ValueError(f"actuator <{mtr.tag}> is not supported (motor only)")
-        a = dict(motor_attrs)
+        a = dict(classes[cls_of(mtr, "main")][2])
         a.update(mtr.attrib)
+        a.pop("class", None)
         extra = sorted(set(a) - {"joint", "gear", "ctrlrange", "ctrllimited", "forcelimited", "forcerange"} - _COSMETIC)
         if extra or a.get("forcelimited", "false") == "true" or any(x != 0.0 for x in _floats(a.get("gear", "1"))[1:]):
             raise ValueError(f"motor on {a.get('joint')!r}: only joint, a scalar gear, ctrlrange and ctrllimited are implemented ({', '.join(extra) or 'force limits / gear vector'})")

@@ -334,3 +334,59 @@ def test_physics_this_subset_lacks_is_an_error_not_a_skip():
         with pytest.raises(ValueError) as ei:
             load(bad)
         assert word in str(ei.value), (word, str(ei.value))
+
+def test_default_classes_and_childclass():
+    """MJCF default classes: a nested <default class=...> inherits the class around it; `class=` on an element picks one, `childclass=` on a
+    body hands one down its subtree.  The same robot written flat (every attribute on the element) compiles to the same model."""
+    import numpy as np
+
+    from mujoco_maze_amd import maze_task as T
+    from mujoco_maze_amd import model
+
+    head = '<mujoco model="cls"><compiler angle="degree" coordinate="local" inertiafromgeom="true"/><option integrator="RK4" timestep="0.01"/>'
+    nested = head + """
+      <default>
+        <geom conaffinity="0" condim="3" density="100" friction="1 0.5 0.5"/>
+        <joint armature="0.1" damping="0.2" limited="true"/>
+        <motor ctrllimited="true" ctrlrange="-1 1"/>
+        <default class="heavy"><geom density="400"/>
+          <default class="stiff"><joint damping="2" stiffness="3"/></default>
+        </default>
+      </default>
+      <worldbody><geom name="floor" type="plane" size="40 40 40" conaffinity="1"/>
+        <body name="torso" pos="0 0 0.5"><freejoint name="root"/>
+          <geom name="g" type="capsule" size="0.05" fromto="-0.2 0 0 0.2 0 0"/>
+          <body name="arm" pos="0.2 0 0" childclass="stiff">
+            <joint name="j1" type="hinge" axis="0 0 1" range="-30 30"/>
+            <geom name="a" type="capsule" size="0.04" fromto="0 0 0 0.3 0 0"/>
+            <body name="hand" pos="0.3 0 0">
+              <joint name="j2" type="hinge" axis="0 1 0" range="-20 20" class="main"/>
+              <geom name="h" type="sphere" size="0.06" class="heavy"/>
+            </body>
+          </body>
+        </body>
+      </worldbody>
+      <actuator><motor joint="j1" gear="2"/><motor joint="j2" gear="1"/></actuator></mujoco>"""
+    flat = head + """
+      <default><geom conaffinity="0" condim="3" friction="1 0.5 0.5"/><motor ctrllimited="true" ctrlrange="-1 1"/></default>
+      <worldbody><geom name="floor" type="plane" size="40 40 40" conaffinity="1"/>
+        <body name="torso" pos="0 0 0.5"><freejoint name="root"/>
+          <geom name="g" type="capsule" size="0.05" fromto="-0.2 0 0 0.2 0 0" density="100"/>
+          <body name="arm" pos="0.2 0 0">
+            <joint name="j1" type="hinge" axis="0 0 1" range="-30 30" limited="true" armature="0.1" damping="2" stiffness="3"/>
+            <geom name="a" type="capsule" size="0.04" fromto="0 0 0 0.3 0 0" density="400"/>
+            <body name="hand" pos="0.3 0 0">
+              <joint name="j2" type="hinge" axis="0 1 0" range="-20 20" limited="true" armature="0.1" damping="0.2"/>
+              <geom name="h" type="sphere" size="0.06" density="400"/>
+            </body>
+          </body>
+        </body>
+      </worldbody>
+      <actuator><motor joint="j1" gear="2"/><motor joint="j2" gear="1"/></actuator></mujoco>"""
+    a = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=nested, frame_skip=1, reset_qvel="normal").c
+    b = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=flat, frame_skip=1, reset_qvel="normal").c
+    for f in ("body_mass", "body_inertia", "dof_damping", "dof_armature", "jnt_stiffness", "jnt_range", "jnt_limited", "geom_friction", "act_gear", "act_ctrlrange"):
+        assert np.allclose(np.array(getattr(a, f)), np.array(getattr(b, f))), f
+    assert a.jnt_stiffness[1] == 3.0 and a.jnt_stiffness[2] == 0.0 and a.dof_damping[6] == 2.0 and a.dof_damping[7] == 0.2
+    with pytest.raises(ValueError):
+        model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=nested.replace('class="heavy"/>', 'class="nope"/>'), frame_skip=1, reset_qvel="normal")
