@@ -88,7 +88,7 @@ static inline void gen_pair(GenPair* p, const mz_model* m, const double* f1, con
 
 // does the model need this engine (no specialised kernel steps it)?  mazestep.hip asks before it dispatches.
 static inline int gen_model_needs_general_engine(const mz_model* m) {
-  if (m->robot == MZ_ROBOT_GENERIC || m->engine == 1) return 1;
+  if (m->robot == MZ_ROBOT_GENERIC || m->engine == 1 || !m->integrator_rk4) return 1;
   for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MZ_JNT_BALL || m->jnt_stiffness[j] != 0.0) return 1;  // SPIN plates; joint springs
   if (m->nblock > 3) return 1;
   for (int k = 0; k < m->nblock; k++)  // a three-slide block (MultiFall's XYZ block) has a specialised kernel for the one-block ant only
@@ -1518,6 +1518,26 @@ template <class C>
 MZ_HD void gen_mj_step(const C& cx, const GenDev& K, GenScratch& s) {
   const mz_model& m = K.m;
   const double h = m.timestep;
+  if (!m.integrator_rk4) {
+    // MuJoCo's default integrator (mj_EulerSkip as restated in oracle/mzo_physics.c mzo_mj_step): one evaluation per step, semi-implicit,
+    // implicit in the joint damping: (M + h diag(damping)) qacc' = M qacc; qvel += h qacc'; qpos integrates the new velocity
+    gen_forward(cx, K, s);
+    bool damped = false;
+    for (int i = 0; i < m.nv; i++) damped = damped || m.dof_damping[i] > 0.0;  // (uniform)
+    MZ_FOR(i, m.nv) { s.Mx[i] = damped ? gd_dotn(s.M[i], s.qacc, m.nv) : s.qacc[i]; s.warm[i] = s.qacc[i]; }
+    if (damped) {
+      MZ_FOR(e, m.nv * m.nv) { const int i = e / m.nv, j = e - m.nv * i; if (j <= i) s.H[i][j] = s.M[i][j] + (i == j ? h * m.dof_damping[i] : 0.0); }
+      cx.sync();
+      if (!gen_chol_solve(cx, s, s.H, s.H, m.nv, s.Mx)) { MZ_FOR(one, 1) s.status |= MZ_STATUS_BAD_STATE; }
+    }
+    cx.sync();
+    MZ_FOR(i, m.nq) s.x0q[i] = s.qpos[i];
+    MZ_FOR(i, m.nv) s.qvel[i] += h * s.Mx[i];
+    cx.sync();
+    MZ_FOR(j, m.njnt) gen_integrate_joint(K, s, s.x0q, s.qvel, h, j);
+    cx.sync();
+    return;
+  }
   MZ_FOR(i, m.nq) s.x0q[i] = s.qpos[i];
   MZ_FOR(i, m.nv) { s.x0v[i] = s.qvel[i]; s.accv[i] = 0.0; s.accf[i] = 0.0; }
   cx.sync();

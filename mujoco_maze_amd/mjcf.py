@@ -7,7 +7,7 @@ built-in robot — other masses, sizes, gears, limits, contact parameters — lo
 
     env = mm.make("AntUMaze-v0", num_envs=4096, robot_xml="my_ant.xml")
 
-Supported elements: `<compiler angle coordinate inertiafromgeom>`, `<option timestep integrator density viscosity
+Supported elements: `<compiler angle coordinate inertiafromgeom>`, `<option timestep integrator (RK4; Euler for user robots) density viscosity
 collision>`, `<default>` with `<geom>`, `<joint>`, `<motor>` and nested classes (`class=`, `childclass=`); `<worldbody>` with one plane geom (the
 floor) and one robot body tree of `<body>`, `<joint type=free|ball|slide|hinge>`, `<freejoint>`,
 `<geom type=sphere|capsule|box>` (orientation by fromto, quat, axisangle, euler, zaxis or xyaxes — bodies too); `<actuator><motor>`.
@@ -128,7 +128,7 @@ def spec_to_mjcf(spec: R.RobotSpec) -> str:
     """MJCF text of a RobotSpec (lossless for `spec_from_mjcf`)."""
     root = ET.Element("mujoco", model=spec.name)
     ET.SubElement(root, "compiler", angle="degree", coordinate="local", inertiafromgeom="true")
-    opt = {"integrator": "RK4", "timestep": repr(spec.timestep)}
+    opt = {"integrator": getattr(spec, "integrator", "RK4"), "timestep": repr(spec.timestep)}
     if spec.density or spec.viscosity:
         opt["density"], opt["viscosity"] = repr(spec.density), repr(spec.viscosity)
     if spec.collision_predefined:
@@ -289,8 +289,10 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
             raise ValueError("<option gravity>: only MuJoCo's default (0 0 -9.81) is implemented")
         if oa.get("cone", "pyramidal") != "pyramidal" or oa.get("solver", "Newton") != "Newton":
             raise ValueError("<option>: the pyramidal cone and the Newton solver are what is implemented")
-    if oa.get("integrator", "Euler") != "RK4":
-        raise ValueError("only integrator=\"RK4\" is implemented on the device (all reference assets use it)")
+    integrator = oa.get("integrator", "Euler")  # (MuJoCo's default)
+    if integrator not in ("RK4", "Euler") or (integrator == "Euler" and like is not None):
+        raise ValueError("integrator: RK4 (all reference assets) or, for an AgentModel with ROBOT = \"generic\", MuJoCo's default Euler; "
+                         "implicit / implicitfast are not implemented")
     dflt = root.find("default")
     geom0 = R.GeomSpec(name="", type=R.SPHERE, size=(0.0,))  # MuJoCo's built-in defaults
     joint0 = R.JointSpec(name="", type=R.HINGE)
@@ -388,7 +390,8 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
         wall_defaults = dataclasses.replace(geom0, name="wall", type=R.BOX, size=(1.0, 1.0, 1.0), contype=1, conaffinity=1)
         return R.RobotSpec("generic", bodies, acts, floor, wall_defaults, timestep=float(oa.get("timestep", 0.002)), frame_skip=int(frame_skip),
                            nq_robot=nq, nv_robot=nv, density=float(oa.get("density", 0.0)), viscosity=float(oa.get("viscosity", 0.0)),
-                           collision_predefined=oa.get("collision", "all") == "predefined", reset_qvel=reset_qvel, torso_z=bodies[0].pos[2])
+                           collision_predefined=oa.get("collision", "all") == "predefined", reset_qvel=reset_qvel, torso_z=bodies[0].pos[2],
+                           integrator=integrator)
     if any(tuple(b.quat) != (1.0, 0.0, 0.0, 0.0) or any(g.quat is not None for g in b.geoms) or any(j.stiffness != 0.0 for j in b.joints) for b in bodies):
         raise ValueError(f"{like.name}: a variant of a built-in robot may change parameters, not structure — turned bodies / geoms and joint springs "
                          "need an AgentModel with ROBOT = \"generic\" (the general engine)")

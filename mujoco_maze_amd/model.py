@@ -280,7 +280,7 @@ def needs_general_engine(cm) -> bool:
     a SPIN plate's ball joint, more than three movable blocks, blocks of several sizes, a three-slide block anywhere but the
     one-block ant) or the caller asked for the general engine."""
     m = cm.c
-    if m.robot == ROBOT_ID["generic"] or m.engine == 1 or m.nblock > 3:
+    if m.robot == ROBOT_ID["generic"] or m.engine == 1 or m.nblock > 3 or m.integrator_rk4 == 0:
         return True
     if any(m.jnt_type[j] == R.BALL or m.jnt_stiffness[j] != 0.0 for j in range(m.njnt)):
         return True
@@ -371,7 +371,7 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
     m.robot = ROBOT_ID[robot]
     m.timestep = spec.timestep
     m.frame_skip = spec.frame_skip
-    m.integrator_rk4 = 1
+    m.integrator_rk4 = 0 if getattr(spec, "integrator", "RK4") == "Euler" else 1
     m.collision_predefined = int(spec.collision_predefined)
     m.gravity[:] = (0.0, 0.0, -9.81)
     m.density, m.viscosity = spec.density, spec.viscosity

@@ -88,6 +88,7 @@ class RobotSpec:
     collision_predefined: bool = False  # swimmer.xml:3 collision="predefined": no dynamic pairs
     reset_qvel: str = "normal"  # "normal" | "uniform01" | "uniform_sym"
     torso_z: float = 0.0
+    integrator: str = "RK4"  # "RK4" (every reference asset) | "Euler" (MuJoCo's default: semi-implicit, implicit in joint damping; general engine)
 
 
 def _ant() -> RobotSpec:

@@ -1331,7 +1331,7 @@ static int bad(const double* x, int n) {
   return 0;
 }
 
-/* one mj_step with RK4 */
+/* one mj_step: RK4 (every reference asset) or MuJoCo's default Euler (user robots) */
 void mzo_mj_step(const mz_model* m, mzo_data* d, const double* ctrl) {
   int nq = m->nq, nv = m->nv;
   double h = m->timestep;
@@ -1340,6 +1340,30 @@ void mzo_mj_step(const mz_model* m, mzo_data* d, const double* ctrl) {
   if (bad(d->qpos, nq) || bad(d->qvel, nv)) d->status |= MZ_STATUS_BAD_STATE;
   mzo_forward(m, d, ctrl);
   if (bad(d->qacc, nv)) d->status |= MZ_STATUS_BAD_STATE;
+  if (!m->integrator_rk4) {
+    /* MuJoCo's default integrator (engine_forward.c mj_EulerSkip; >= 2.1.2 semantics [ASSUME-1]): semi-implicit Euler, implicit in
+     * the joint damping — (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint = M qacc, then qvel += h qacc', qpos integrates
+     * the NEW velocity; without damping qacc' = qacc.  qacc_warmstart keeps the solver's qacc (mj_advance). */
+    double qa[ND], L[ND][ND];
+    int damped = 0;
+    for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0.0) damped = 1;
+    for (int i = 0; i < nv; i++) qa[i] = d->qacc[i];
+    if (damped) {
+      for (int i = 0; i < nv; i++) {
+        double t = 0.0;
+        for (int j = 0; j < nv; j++) { t += d->M[i][j] * d->qacc[j]; L[i][j] = d->M[i][j]; }
+        qa[i] = t;
+        L[i][i] += h * m->dof_damping[i];
+      }
+      if (chol_factor(L, nv)) d->status |= MZ_STATUS_BAD_STATE;
+      chol_solve(L, nv, qa);
+    }
+    for (int k = 0; k < nv; k++) d->qvel[k] += h * qa[k];
+    integrate_pos(m, d->qpos, d->qvel, h);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+    d->time += h;
+    return;
+  }
   memcpy(X0q, d->qpos, sizeof(double) * nq);
   memcpy(Xv[0], d->qvel, sizeof(double) * nv);
   memcpy(F[0], d->qacc, sizeof(double) * nv);

@@ -165,3 +165,15 @@ def generic_env_step(cm, st, actions):
                                   _vp(out["reward"]), _vp(out["done"]), _vp(out["goal_idx"]), _vp(out["info"]), _vp(out["status"]), err, 256)
     assert rc == 0, (rc, err.value.decode())
     return out
+
+
+def generic_raw_steps(cm, qpos, qvel, nsteps, ctrl=None):
+    """`nsteps` mj_step of the general engine's kernel code (one lane, float64 state in and out): (qpos, qvel) after them."""
+    lib = load()
+    qp, qv = np.array(qpos, np.float64), np.array(qvel, np.float64)
+    c = None if ctrl is None else np.ascontiguousarray(ctrl, np.float64)
+    status = C.c_int32(0)
+    err = C.create_string_buffer(256)
+    rc = lib.emu_generic_raw_steps(C.byref(cm.c), _vp(qp), _vp(qv), None, None if c is None else _vp(c), int(nsteps), C.byref(status), err, 256)
+    assert rc == 0 and (status.value & 7) == 0, (rc, status.value, err.value.decode())
+    return qp, qv

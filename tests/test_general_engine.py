@@ -271,7 +271,7 @@ def test_joint_spring_is_a_harmonic_oscillator(oracle):
     Half a period from rest at 0 it stands at twice the rest angle, a full period later it is back; energy is not the test (the spring's
     potential is not in the oracle's energy sum), the closed form is."""
     k, ref = 1.5, 20.0
-    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref), frame_skip=1, reset_qvel="normal")
+    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref, b=0, integ='integrator="RK4"'), frame_skip=1, reset_qvel="normal")
     m = cm.c
     assert m.nv == 1 and m.jnt_stiffness[0] == k and np.isclose(m.jnt_springref[0], np.radians(ref)) and model.needs_general_engine(cm)
     inertia = oracle.forward(cm, np.zeros((1, 1)), np.zeros((1, 1)))["M"][0][0, 0]
@@ -283,6 +283,38 @@ def test_joint_spring_is_a_harmonic_oscillator(oracle):
     assert abs(q[0] - 2.0 * np.radians(ref)) < 2e-5 and abs(v[0]) < np.radians(ref) * np.sqrt(k / inertia) * (np.sqrt(k / inertia) * h), (q, v)
     q, v, _ = oracle.raw_steps(cm, q, v, None, half)
     assert abs(q[0]) < 1e-4
+
+
+def test_euler_integrator_is_mujocos_semi_implicit_rule(oracle):
+    """MuJoCo's default integrator for user robots (mj_EulerSkip, >= 2.1.2: implicit in the joint damping): on the damped spring arm — one dof,
+    no constraint — a step is  a = (-k (q - r) - b v) / I;  a' = I a / (I + h b);  v += h a';  q += h v.  The oracle follows that recurrence
+    to round-off (the kernel code follows the oracle: the next test — a one-dof arm is no maze robot for the device)."""
+    k, ref, b = 1.5, 20.0, 0.3
+    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref, b=b, integ=""), frame_skip=1,
+                             reset_qvel="normal")
+    m = cm.c
+    assert m.integrator_rk4 == 0 and model.needs_general_engine(cm)
+    inertia = oracle.forward(cm, np.zeros((1, 1)), np.zeros((1, 1)))["M"][0][0, 0]
+    h, r = m.timestep, np.radians(ref)
+    q, v = 0.1, -0.4
+    for _ in range(400):
+        a = (-k * (q - r) - b * v) / inertia
+        v += h * (inertia * a / (inertia + h * b))
+        q += h * v
+    qo, vo, _ = oracle.raw_steps(cm, np.array([0.1]), np.array([-0.4]), None, 400)
+    assert abs(qo[0] - q) < 1e-12 and abs(vo[0] - v) < 1e-12
+
+
+def test_user_robot_under_the_euler_integrator(oracle):
+    """The biped with no integrator attribute (MuJoCo's default: Euler) at a 5 ms step: floor contacts, limits, motors — kernel code (host
+    build) against the oracle over a rollout."""
+    cm = model.compile_model("generic", T.GoalRewardUMaze(4.0), 4.0, robot_xml=user_robots.EULER_BIPED, frame_skip=8, reset_qvel="normal")
+    assert cm.c.integrator_rk4 == 0
+    n = 12
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(1)
+    acts = [rng.uniform(-20, 20, (n, cm.c.nu)) for _ in range(9)]
+    assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 3, 8)) > 20
 
 
 def test_user_robot_with_joint_springs(oracle):

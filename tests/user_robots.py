@@ -138,18 +138,35 @@ SPRINGY_BIPED = BIPED_ANT.replace('name="left_knee" type="hinge"', 'name="left_k
 SPRING_ARM = """
 <mujoco model="spring_arm">
   <compiler angle="degree" coordinate="local" inertiafromgeom="true"/>
-  <option integrator="RK4" timestep="0.002"/>
+  <option {integ} timestep="0.002"/>
   <default><geom conaffinity="0" contype="0" condim="3" density="500"/></default>
   <worldbody>
     <geom name="floor" type="plane" size="40 40 40" conaffinity="1"/>
     <body name="arm" pos="0 0 0.3">
-      <joint name="pivot" type="hinge" axis="0 0 1" pos="0 0 0" armature="0.02" damping="0" stiffness="{k}" springref="{ref}"/>
+      <joint name="pivot" type="hinge" axis="0 0 1" pos="0 0 0" armature="0.02" damping="{b}" stiffness="{k}" springref="{ref}"/>
       <geom name="arm_geom" type="capsule" size="0.03" fromto="0 0 0 0.4 0 0"/>
     </body>
   </worldbody>
   <actuator><motor joint="pivot" gear="1" ctrllimited="true" ctrlrange="-1 1"/></actuator>
 </mujoco>
 """
+
+
+# the biped under MuJoCo's DEFAULT integrator (no integrator attribute = Euler: semi-implicit, implicit in the joint damping), a smaller step
+EULER_BIPED = BIPED_ANT.replace('<option integrator="RK4" timestep="0.02"/>', '<option timestep="0.005"/>').replace('model="biped_ant"', 'model="euler_biped"')
+
+
+def euler_class():
+    from mujoco_maze_amd.agent_model import AgentModel
+
+    class EulerBiped(AgentModel):
+        ROBOT = "generic"
+        FILE = EULER_BIPED
+        MANUAL_COLLISION = False
+        FRAME_SKIP = 8
+        RESET_QVEL = "normal"
+
+    return EulerBiped
 
 
 def springy_class():
