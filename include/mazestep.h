@@ -104,7 +104,8 @@ typedef struct mz_model {
                                * (ant.py:75-96), point 3/3 (point.py:63-81), swimmer / reacher ALL nq / nv, movable blocks
                                * included (swimmer.py:50-69) */
   int32_t frame_skip;
-  int32_t integrator_rk4;
+  int32_t integrator_rk4; /* 1: RK4 (every reference asset); 0: MuJoCo's default Euler — semi-implicit, implicit in the joint damping
+                           * (mj_EulerSkip) — for user robots, stepped by the general engine */
   int32_t collision_predefined; /* swimmer: no dynamic contact pairs */
   int32_t manual_collision;     /* Point: CollisionDetector bounce */
   int32_t max_episode_steps;    /* gym TimeLimit (mujoco_maze/__init__.py:31) */
