@@ -182,6 +182,9 @@ typedef struct mz_model {
   int32_t act_ctrllimited[MZ_MAX_ACT];
   double act_gear[MZ_MAX_ACT];
   double act_ctrlrange[MZ_MAX_ACT][2];
+  double act_gainprm[MZ_MAX_ACT];    /* actuator force = gainprm * ctrl + biasprm[0] + biasprm[1] * length + biasprm[2] * velocity, with length =  */
+  double act_biasprm[MZ_MAX_ACT][3]; /* gear * q, velocity = gear * qvel of its joint; on the dof: gear * force.  motor: 1 | 0 0 0; <position kp>:
+                                      * kp | 0 -kp 0; <velocity kv>: kv | 0 0 -kv.  Anything but a motor is stepped by the general engine */
 
   /* maze world (maze_env.py:116-152): cell (i,j) centre = (j*s - torso_x, i*s - torso_y) */
   int32_t grid_rows, grid_cols;

@@ -14,7 +14,7 @@ from typing import Optional
 class AgentModel:
     """Subclass it for a robot of your own (reference README.md:127): `ROBOT = "generic"`, `FILE` = path (or text) of its MJCF —
     free / ball / slide / hinge joints (with springs: stiffness / springref), sphere / capsule / box geoms in any orientation (the
-    robot's own limbs may collide with each other: MuJoCo's contype / conaffinity and parent-child rules), motors; what the reader does
+    robot's own limbs may collide with each other: MuJoCo's contype / conaffinity and parent-child rules), motors and position / velocity servos, RK4 or MuJoCo's default Euler; what the reader does
     not implement it refuses by name — plus `FRAME_SKIP` and, optionally, `RESET_QVEL` ("normal" | "uniform01" |
     "uniform_sym": the reset noise of ant.py / point.py / swimmer.py) and `STEP`: "motors" (default; the ant's step shape,
     ant.py:61-73: clamped motors, forward reward |dxy| / dt, control cost) or "point" (point.py:44-61: the action turns and moves

@@ -55,6 +55,7 @@ struct GenDev {
   TaskDev task;
   MazeDev maze;
   int nitem, step_kind;
+  int servos, pad_servos;  // some actuator has a position / velocity term (mz_model.act_biasprm)
   GenItem item[GN_NI];
   double lim_K[GN_NJ], lim_B[GN_NJ];
   int max_iter, ls_iter;
@@ -90,6 +91,7 @@ static inline void gen_pair(GenPair* p, const mz_model* m, const double* f1, con
 static inline int gen_model_needs_general_engine(const mz_model* m) {
   if (m->robot == MZ_ROBOT_GENERIC || m->engine == 1 || !m->integrator_rk4) return 1;
   for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MZ_JNT_BALL || m->jnt_stiffness[j] != 0.0) return 1;  // SPIN plates; joint springs
+  for (int a = 0; a < m->nu; a++) if (m->act_gainprm[a] != 1.0 || m->act_biasprm[a][0] != 0.0 || m->act_biasprm[a][1] != 0.0 || m->act_biasprm[a][2] != 0.0) return 1;  // servos
   if (m->nblock > 3) return 1;
   for (int k = 0; k < m->nblock; k++)  // a three-slide block (MultiFall's XYZ block) has a specialised kernel for the one-block ant only
     if (m->body_jntnum[m->block_bodyid[k]] != 2 && !(m->robot == MZ_ROBOT_ANT && m->nblock == 1)) return 1;
@@ -175,6 +177,8 @@ static inline int gen_dev_from_model(GenDev* g, const mz_model* m, char* err, in
   g->nlimj = 0;
   for (int j = 0; j < m->njnt; j++)
     if (m->jnt_limited[j] && (m->jnt_type[j] == MZ_JNT_HINGE || m->jnt_type[j] == MZ_JNT_SLIDE)) g->limj[g->nlimj++] = j;
+  g->servos = 0;
+  for (int a = 0; a < m->nu; a++) if (m->act_biasprm[a][1] != 0.0 || m->act_biasprm[a][2] != 0.0) g->servos = 1;
   g->max_depth = 0;
   g->body_depth[0] = 0;
   for (int b = 0; b < GN_NB; b++) g->subtree[b] = 0u;
@@ -1199,8 +1203,16 @@ MZ_HD void gen_force_item(const GenDev& K, GenScratch& s, int i) {
   }
   if (m.density > 0.0 || m.viscosity > 0.0)
     for (uint32_t mk = sub; mk; mk &= mk - 1) pas += gd_dot6(s.S[i], s.ffl[__builtin_ctz(mk)]);  // dof i moves body b iff body(i) is b or an ancestor of b
+  double act = s.fact[i];
+  if (K.servos)  // <position> / <velocity> actuators: bias1 * length + bias2 * velocity of the joint, at every evaluation
+    for (int u = 0; u < m.nu; u++)
+      if (m.act_dofid[u] == i) {
+        const int jq = s.tp.jnt_qposadr[m.dof_jntid[i]];
+        const double g = m.act_gear[u];
+        act += g * (m.act_biasprm[u][1] * g * (s.qpos[jq] - m.qpos0[jq]) + m.act_biasprm[u][2] * g * s.qvel[i]);
+      }
   s.bias[i] = bias; s.passive[i] = pas;
-  s.qfs[i] = pas - bias + s.fact[i];
+  s.qfs[i] = pas - bias + act;
 }
 
 // dense Cholesky + solve on one lane (A = L L^T in the lower triangle of H)
@@ -1634,7 +1646,7 @@ MZ_HD void gen_env_step(const C& cx, const GenDev& K, GenScratch& s, const float
       for (int u = 0; u < m.nu; u++) {
         double c = (double)action[u];
         if (m.act_ctrllimited[u]) c = fmin(fmax(c, m.act_ctrlrange[u][0]), m.act_ctrlrange[u][1]);
-        s.fact[m.act_dofid[u]] += m.act_gear[u] * c;
+        s.fact[m.act_dofid[u]] += m.act_gear[u] * (m.act_gainprm[u] * c + m.act_biasprm[u][0]);  // (a servo's state-dependent part: gen_force_item)
       }
   }
   cx.sync();

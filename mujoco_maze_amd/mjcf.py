@@ -10,7 +10,8 @@ built-in robot — other masses, sizes, gears, limits, contact parameters — lo
 Supported elements: `<compiler angle coordinate inertiafromgeom>`, `<option timestep integrator (RK4; Euler for user robots) density viscosity
 collision>`, `<default>` with `<geom>`, `<joint>`, `<motor>` and nested classes (`class=`, `childclass=`); `<worldbody>` with one plane geom (the
 floor) and one robot body tree of `<body>`, `<joint type=free|ball|slide|hinge>`, `<freejoint>`,
-`<geom type=sphere|capsule|box>` (orientation by fromto, quat, axisangle, euler, zaxis or xyaxes — bodies too); `<actuator><motor>`.
+`<geom type=sphere|capsule|box>` (orientation by fromto, quat, axisangle, euler, zaxis or xyaxes — bodies too);
+`<actuator>` with `<motor>`, `<position kp>`, `<velocity kv>`.
 Lights, cameras, sites, assets and materials are skipped; **anything else that would change the physics is an error, not a skip**
 (joint springs, dry friction, tendons, equality constraints, contact pairs, gear vectors ...).
 The device kernels are written for the topologies of the four built-in robots (`csrc/*_dyn.h` check it when the
@@ -162,8 +163,9 @@ def spec_to_mjcf(spec: R.RobotSpec) -> str:
             ET.SubElement(e, "joint", **a)
     act = ET.SubElement(root, "actuator")
     for m in spec.actuators:
-        ET.SubElement(act, "motor", joint=m.joint, gear=repr(m.gear), ctrlrange=_fmt(m.ctrlrange),
-                      ctrllimited="true" if m.ctrllimited else "false")
+        kind = getattr(m, "kind", "motor")
+        ET.SubElement(act, kind, joint=m.joint, gear=repr(m.gear), ctrlrange=_fmt(m.ctrlrange), ctrllimited="true" if m.ctrllimited else "false",
+                      **({} if kind == "motor" else {"kp" if kind == "position" else "kv": repr(m.gain)}))
     ET.indent(root)
     return ET.tostring(root, encoding="unicode")
 
@@ -369,16 +371,20 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
     walk(roots[0], -1)
     acts = []
     for mtr in (root.find("actuator") if root.find("actuator") is not None else []):
-        if mtr.tag != "motor":
-            raise ValueError(f"actuator <{mtr.tag}> is not supported (motor only)")
-        a = dict(classes[cls_of(mtr, "main")][2])
+        if mtr.tag not in ("motor", "position", "velocity"):
+            raise ValueError(f"actuator <{mtr.tag}> is not implemented (motor, position, velocity)")
+        # (class defaults are read for motors; a servo carries its settings itself)
+        a = dict(classes[cls_of(mtr, "main")][2]) if mtr.tag == "motor" else {}
         a.update(mtr.attrib)
         a.pop("class", None)
-        extra = sorted(set(a) - {"joint", "gear", "ctrlrange", "ctrllimited", "forcelimited", "forcerange"} - _COSMETIC)
+        gain_key = {"motor": None, "position": "kp", "velocity": "kv"}[mtr.tag]
+        extra = sorted(set(a) - {"joint", "gear", "ctrlrange", "ctrllimited", "forcelimited", "forcerange", gain_key} - _COSMETIC)
         if extra or a.get("forcelimited", "false") == "true" or any(x != 0.0 for x in _floats(a.get("gear", "1"))[1:]):
-            raise ValueError(f"motor on {a.get('joint')!r}: only joint, a scalar gear, ctrlrange and ctrllimited are implemented ({', '.join(extra) or 'force limits / gear vector'})")
+            raise ValueError(f"{mtr.tag} on {a.get('joint')!r}: only joint, a scalar gear, ctrlrange, ctrllimited{' and ' + gain_key if gain_key else ''} are implemented "
+                             f"({', '.join(extra) or 'force limits / gear vector'})")
         gear = _floats(a.get("gear", "1"))[0]
-        acts.append(R.ActuatorSpec(a["joint"], gear, _floats(a.get("ctrlrange", "0 0")), a.get("ctrllimited", "false") == "true"))
+        acts.append(R.ActuatorSpec(a["joint"], gear, _floats(a.get("ctrlrange", "0 0")), a.get("ctrllimited", "false") == "true",
+                                   kind=mtr.tag, gain=float(a.get(gain_key, "1")) if gain_key else 1.0))
     nq = sum({R.FREE: 7, R.BALL: 4}.get(j.type, 1) for b in bodies for j in b.joints)
     nv = sum({R.FREE: 6, R.BALL: 3}.get(j.type, 1) for b in bodies for j in b.joints)
     # The swimmer family's kernels are written for planar chains of 2..6 links (csrc/swimmer_dyn.h is generic in the link count;
@@ -392,9 +398,9 @@ def spec_from_mjcf(source: str, like: Optional[R.RobotSpec], frame_skip: int = 1
                            nq_robot=nq, nv_robot=nv, density=float(oa.get("density", 0.0)), viscosity=float(oa.get("viscosity", 0.0)),
                            collision_predefined=oa.get("collision", "all") == "predefined", reset_qvel=reset_qvel, torso_z=bodies[0].pos[2],
                            integrator=integrator)
-    if any(tuple(b.quat) != (1.0, 0.0, 0.0, 0.0) or any(g.quat is not None for g in b.geoms) or any(j.stiffness != 0.0 for j in b.joints) for b in bodies):
+    if any(a.kind != "motor" for a in acts) or any(tuple(b.quat) != (1.0, 0.0, 0.0, 0.0) or any(g.quat is not None for g in b.geoms) or any(j.stiffness != 0.0 for j in b.joints) for b in bodies):
         raise ValueError(f"{like.name}: a variant of a built-in robot may change parameters, not structure — turned bodies / geoms and joint springs "
-                         "need an AgentModel with ROBOT = \"generic\" (the general engine)")
+                         "and servo actuators need an AgentModel with ROBOT = \"generic\" (the general engine)")
     chain = (like.name in ("swimmer", "reacher") and nq == nv == len(bodies) + 2 and 2 <= len(bodies) <= 6 and len(acts) == len(bodies) - 1
              and all(b.parent == i - 1 for i, b in enumerate(bodies)))
     if not chain and ((nq, nv) != (like.nq_robot, like.nv_robot) or len(acts) != len(like.actuators)):

@@ -62,7 +62,7 @@ class MzModel(C.Structure):
         ("geom_friction", (f64 * 3) * MAX_GEOM), ("geom_solref", (f64 * 2) * MAX_GEOM), ("geom_solimp", (f64 * 5) * MAX_GEOM),
         ("geom_margin", f64 * MAX_GEOM), ("geom_gap", f64 * MAX_GEOM), ("geom_rbound", f64 * MAX_GEOM),
         ("act_dofid", i32 * MAX_ACT), ("act_ctrllimited", i32 * MAX_ACT), ("act_gear", f64 * MAX_ACT),
-        ("act_ctrlrange", (f64 * 2) * MAX_ACT),
+        ("act_ctrlrange", (f64 * 2) * MAX_ACT), ("act_gainprm", f64 * MAX_ACT), ("act_biasprm", (f64 * 3) * MAX_ACT),
         ("grid_rows", i32), ("grid_cols", i32), ("grid", (u8 * MAX_GRID) * MAX_GRID),
         ("maze_scale", f64), ("torso_x", f64), ("torso_y", f64),
         ("wall_half_xy", f64), ("wall_half_z", f64), ("wall_center_z", f64),
@@ -283,6 +283,8 @@ def needs_general_engine(cm) -> bool:
     if m.robot == ROBOT_ID["generic"] or m.engine == 1 or m.nblock > 3 or m.integrator_rk4 == 0:
         return True
     if any(m.jnt_type[j] == R.BALL or m.jnt_stiffness[j] != 0.0 for j in range(m.njnt)):
+        return True
+    if any(m.act_gainprm[a] != 1.0 or any(m.act_biasprm[a][k] != 0.0 for k in range(3)) for a in range(m.nu)):
         return True
     if any(m.body_jntnum[m.block_bodyid[k]] != 2 for k in range(m.nblock)) and not (m.robot == ROBOT_ID["ant"] and m.nblock == 1):
         return True
@@ -579,6 +581,11 @@ def compile_model(robot: str, task: MazeTask, scale: float, *, inner_reward_scal
         m.act_gear[a] = act.gear
         m.act_ctrlrange[a][:] = act.ctrlrange
         m.act_ctrllimited[a] = int(act.ctrllimited)
+        kind, k = getattr(act, "kind", "motor"), getattr(act, "gain", 1.0)
+        m.act_gainprm[a] = 1.0 if kind == "motor" else k
+        m.act_biasprm[a][:] = {"motor": (0.0, 0.0, 0.0), "position": (0.0, -k, 0.0), "velocity": (0.0, 0.0, -k)}[kind]
+        if kind != "motor" and spec.bodies and m.jnt_type[names.index(act.joint)] not in (R.HINGE, R.SLIDE):
+            raise NotImplementedError(f"actuator on {act.joint!r}: servos act on hinge and slide joints")
 
     # ---- constants at qpos0: M, invweights
     xpos, xquat = _kinematics_qpos0(nbody, parent, bpos, bquat)

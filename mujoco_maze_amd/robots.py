@@ -70,6 +70,8 @@ class ActuatorSpec:
     gear: float
     ctrlrange: Tuple[float, float]
     ctrllimited: bool = True
+    kind: str = "motor"  # "motor" (force = gear * ctrl) | "position" (gain kp: kp (ctrl - gear q)) | "velocity" (gain kv: kv (ctrl - gear qvel))
+    gain: float = 1.0     # kp / kv of a servo
 
 
 @dataclass

@@ -377,7 +377,11 @@ static void velocity_and_forces(const mz_model* m, mzo_data* d, const double* ct
       if (u < m->act_ctrlrange[a][0]) u = m->act_ctrlrange[a][0];
       if (u > m->act_ctrlrange[a][1]) u = m->act_ctrlrange[a][1];
     }
-    d->qfrc_actuator[m->act_dofid[a]] += m->act_gear[a] * u;
+    /* mj_fwdActuation: force = gain * ctrl + bias0 + bias1 * length + bias2 * velocity (length = gear * q of the joint); motors: gain 1, bias 0 */
+    const int dof = m->act_dofid[a], jq = m->jnt_qposadr[m->dof_jntid[dof]];
+    const double len = m->act_gear[a] * (d->qpos[jq] - m->qpos0[jq]), vel = m->act_gear[a] * d->qvel[dof];
+    const double force = m->act_gainprm[a] * u + m->act_biasprm[a][0] + m->act_biasprm[a][1] * len + m->act_biasprm[a][2] * vel;
+    d->qfrc_actuator[dof] += m->act_gear[a] * force;
   }
   for (int i = 0; i < m->nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
 }

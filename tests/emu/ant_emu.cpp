@@ -417,7 +417,7 @@ extern "C" int emu_generic_forward(const mz_model* m, const double* qpos, const 
   for (int u = 0; u < m->nu && ctrl; u++) {
     double c = ctrl[u];
     if (m->act_ctrllimited[u]) c = fmin(fmax(c, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
-    s->fact[m->act_dofid[u]] += m->act_gear[u] * c;
+    s->fact[m->act_dofid[u]] += m->act_gear[u] * (m->act_gainprm[u] * c + m->act_biasprm[u][0]);
   }
   gen_load_topology(cx, *K, *s);
   gen_forward(cx, *K, *s);
@@ -445,7 +445,7 @@ extern "C" int emu_generic_raw_steps(const mz_model* m, double* qpos, double* qv
   for (int u = 0; u < m->nu && ctrl; u++) {
     double c = ctrl[u];
     if (m->act_ctrllimited[u]) c = fmin(fmax(c, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
-    s->fact[m->act_dofid[u]] += m->act_gear[u] * c;
+    s->fact[m->act_dofid[u]] += m->act_gear[u] * (m->act_gainprm[u] * c + m->act_biasprm[u][0]);
   }
   gen_load_topology(cx, *K, *s);
   for (int k = 0; k < nsteps; k++) gen_mj_step(cx, *K, *s);

@@ -271,7 +271,7 @@ def test_joint_spring_is_a_harmonic_oscillator(oracle):
     Half a period from rest at 0 it stands at twice the rest angle, a full period later it is back; energy is not the test (the spring's
     potential is not in the oracle's energy sum), the closed form is."""
     k, ref = 1.5, 20.0
-    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref, b=0, integ='integrator="RK4"'), frame_skip=1, reset_qvel="normal")
+    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref, b=0, integ='integrator="RK4"', act=user_robots.SPRING_ARM_MOTOR), frame_skip=1, reset_qvel="normal")
     m = cm.c
     assert m.nv == 1 and m.jnt_stiffness[0] == k and np.isclose(m.jnt_springref[0], np.radians(ref)) and model.needs_general_engine(cm)
     inertia = oracle.forward(cm, np.zeros((1, 1)), np.zeros((1, 1)))["M"][0][0, 0]
@@ -290,7 +290,7 @@ def test_euler_integrator_is_mujocos_semi_implicit_rule(oracle):
     no constraint — a step is  a = (-k (q - r) - b v) / I;  a' = I a / (I + h b);  v += h a';  q += h v.  The oracle follows that recurrence
     to round-off (the kernel code follows the oracle: the next test — a one-dof arm is no maze robot for the device)."""
     k, ref, b = 1.5, 20.0, 0.3
-    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref, b=b, integ=""), frame_skip=1,
+    cm = model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, robot_xml=user_robots.SPRING_ARM.format(k=k, ref=ref, b=b, integ="", act=user_robots.SPRING_ARM_MOTOR), frame_skip=1,
                              reset_qvel="normal")
     m = cm.c
     assert m.integrator_rk4 == 0 and model.needs_general_engine(cm)
@@ -314,6 +314,42 @@ def test_user_robot_under_the_euler_integrator(oracle):
     st, _ = oracle.reset(cm, n, 3)
     rng = np.random.default_rng(1)
     acts = [rng.uniform(-20, 20, (n, cm.c.nu)) for _ in range(9)]
+    assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 3, 8)) > 20
+
+
+def test_servo_actuators_closed_forms(oracle):
+    """MJCF <position kp> and <velocity kv> (mj_fwdActuation: force = gain ctrl + bias1 length + bias2 velocity, length = gear q) on the
+    one-dof arm.  Position servo, no spring, no damping: kp (ctrl - q) is a spring towards the target — from rest at 0 the arm stands at
+    2 ctrl after half a period 2 pi / sqrt(kp / I).  Velocity servo: I v' = kv (ctrl - v), so v(t) = ctrl (1 - exp(-kv t / I))."""
+    kp, target = 2.0, 0.3
+    arm = lambda act: model.compile_model("generic", T.DistRewardUMaze(4.0), 4.0, frame_skip=1, reset_qvel="normal",  # noqa: E731
+                                          robot_xml=user_robots.SPRING_ARM.format(k=0, ref=0, b=0, integ='integrator="RK4"', act=act))
+    cm = arm(f'<position joint="pivot" kp="{kp}" ctrllimited="true" ctrlrange="-1 1"/>')
+    m = cm.c
+    assert m.act_gainprm[0] == kp and tuple(m.act_biasprm[0]) == (0.0, -kp, 0.0) and model.needs_general_engine(cm)
+    inertia = oracle.forward(cm, np.zeros((1, 1)), np.zeros((1, 1)))["M"][0][0, 0]
+    half = int(round(np.pi / np.sqrt(kp / inertia) / m.timestep))
+    q, v, _ = oracle.raw_steps(cm, np.zeros(1), np.zeros(1), np.array([target]), half)
+    assert abs(q[0] - 2.0 * target) < 2e-5, q
+    q, v, _ = oracle.raw_steps(cm, np.zeros(1), np.zeros(1), np.array([5.0]), half)  # the control is clamped to its range first
+    assert abs(q[0] - 2.0) < 2e-4, q
+    kv, vt = 0.5, 0.8
+    cm = arm(f'<velocity joint="pivot" kv="{kv}" ctrllimited="true" ctrlrange="-1 1"/>')
+    assert tuple(cm.c.act_biasprm[0]) == (0.0, 0.0, -kv)
+    n = 500
+    q, v, _ = oracle.raw_steps(cm, np.zeros(1), np.zeros(1), np.array([vt]), n)
+    assert abs(v[0] - vt * (1.0 - np.exp(-kv * n * cm.c.timestep / inertia))) < 1e-9, v
+
+
+def test_user_robot_with_servo_actuators(oracle):
+    """The biped with position servos on its knees and a velocity servo on its tail (tests/user_robots.py SERVO_BIPED) through the kernel
+    code (host build) against the oracle: the state-dependent actuator forces are re-evaluated at every RK4 stage on both sides."""
+    cm = model.compile_model("generic", T.GoalRewardUMaze(4.0), 4.0, robot_xml=user_robots.SERVO_BIPED, frame_skip=5, reset_qvel="normal")
+    assert model.needs_general_engine(cm) and [cm.c.act_gainprm[a] for a in range(cm.c.nu)] == [1.0, 15.0, 1.0, 15.0, 2.0]
+    n = 12
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(1)
+    acts = [rng.uniform(-3, 3, (n, cm.c.nu)) * np.array([6.0, 1.0, 6.0, 1.0, 1.0]) for _ in range(9)]
     assert _emu_vs_oracle(oracle, cm, st, acts, checks=(0, 3, 8)) > 20
 
 

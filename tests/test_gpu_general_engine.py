@@ -249,6 +249,24 @@ def test_user_robot_under_the_euler_integrator_on_the_device(torch, oracle):
     env.close()
 
 
+def test_user_robot_with_servo_actuators_on_the_device(torch, oracle):
+    """MJCF <position kp> / <velocity kv> actuators on a user robot (tests/user_robots.py SERVO_BIPED): state-dependent actuator forces on the
+    device, equal to the oracle at 1e-6 over a rollout with floor contacts."""
+    from mujoco_maze_amd.maze_env import VecMazeEnv
+    from tests import user_robots
+
+    n = 256
+    env = VecMazeEnv(user_robots.servo_class(), T.GoalRewardUMaze, num_envs=n, maze_size_scaling=4.0)
+    cm = env.model
+    assert env.launch_info()["engine"] == 1 and cm.c.act_biasprm[1][1] == -15.0
+    st, _ = oracle.reset(cm, n, 3)
+    rng = np.random.default_rng(1)
+    acts = [rng.uniform(-3, 3, (n, cm.c.nu)) * np.array([6.0, 1.0, 6.0, 1.0, 1.0]) for _ in range(16)]
+    contacts = _step_against_oracle(torch, oracle, env, st, acts, checks=(0, 3, 15), max_outlier_frac=0.02)
+    assert contacts > 300
+    env.close()
+
+
 def test_general_engine_top_down_view_and_record(torch, oracle):
     """TOP_DOWN_VIEW tasks and the sharded run's packed record on the general engine: view entries filled from the row's own robot /
     block positions, time entry behind the view, record = obs | reward | done."""

@@ -147,9 +147,10 @@ SPRING_ARM = """
       <geom name="arm_geom" type="capsule" size="0.03" fromto="0 0 0 0.4 0 0"/>
     </body>
   </worldbody>
-  <actuator><motor joint="pivot" gear="1" ctrllimited="true" ctrlrange="-1 1"/></actuator>
+  <actuator>{act}</actuator>
 </mujoco>
 """
+SPRING_ARM_MOTOR = '<motor joint="pivot" gear="1" ctrllimited="true" ctrlrange="-1 1"/>'
 
 
 # the biped under MuJoCo's DEFAULT integrator (no integrator attribute = Euler: semi-implicit, implicit in the joint damping), a smaller step
@@ -167,6 +168,26 @@ def euler_class():
         RESET_QVEL = "normal"
 
     return EulerBiped
+
+
+# the biped with position servos on its knees and a velocity servo on the tail (MJCF <position kp>, <velocity kv>): PD-style control
+SERVO_BIPED = BIPED_ANT.replace('<motor joint="left_knee" gear="1"/>', '<position joint="left_knee" kp="15" ctrllimited="true" ctrlrange="0.5 1.2"/>') \
+                       .replace('<motor joint="right_knee" gear="1"/>', '<position joint="right_knee" kp="15" gear="1" ctrllimited="true" ctrlrange="0.5 1.2"/>') \
+                       .replace('<motor joint="tail_joint" gear="0.5"/>', '<velocity joint="tail_joint" kv="2" gear="0.5" ctrllimited="true" ctrlrange="-3 3"/>') \
+                       .replace('model="biped_ant"', 'model="servo_biped"')
+
+
+def servo_class():
+    from mujoco_maze_amd.agent_model import AgentModel
+
+    class ServoBiped(AgentModel):
+        ROBOT = "generic"
+        FILE = SERVO_BIPED
+        MANUAL_COLLISION = False
+        FRAME_SKIP = 5
+        RESET_QVEL = "normal"
+
+    return ServoBiped
 
 
 def springy_class():
